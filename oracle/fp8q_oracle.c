@@ -1,0 +1,229 @@
+/*
+ * fp8q_oracle.c -- CPU restatement of the reference's FP8 fake-quantization hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path (fp8-quantization_amd/) may call,
+ * link or import this file; it is the checker that tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py compare the HIP kernels against.
+ *
+ * Parity pin: every function here is checked against golden vectors produced by importing
+ * the reference itself (tests/golden/make_golden.py -> the .npz fixtures in tests/golden, tests/test_oracle_golden.py).
+ *
+ * Arithmetic contract.  The reference evaluates the chain below with fp32 ATen CPU ops.
+ * Two of those ops (log2, pow) are 1-ULP vector routines whose last bit depends on the
+ * library build (measured: torch 2.10 CPU pow(2,e) differs from the correctly rounded
+ * result on 1.8 % of inputs, numpy's differs from torch's on 20 %).  This restatement -- and
+ * the HIP kernels, bit for bit -- define them as CORRECTLY ROUNDED fp32 functions
+ * (computed through double precision), and keep every other step (the order of the fp32
+ * additions that form `bias`, floor, clamp, the fp32 subtraction that forms the scale
+ * exponent, IEEE division, round-half-even, the final multiply) exactly as the reference
+ * orders them.  Against the reference's own output this is identical on ~98 % of elements,
+ * within 2 fp32 ULP on the rest except at exact rounding ties (<= 1 step of the FP8 grid,
+ * a few per million elements).
+ *
+ * Reference (paths relative to /root/reference):
+ *   quantization/quantizers/fp8_quantizer.py:91-133   quantize_to_fp8_ste_MM
+ *   quantization/quantizers/fp8_quantizer.py:13-50    generate_all_values_fp(_scaled)
+ *   quantization/range_estimators.py:56-125           current/all/running min-max
+ *   quantization/range_estimators.py:285-369          FP_MSE_Estimator
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* correctly rounded fp32 log2 / 2^e (double libm is < 1 ulp(double); the second rounding
+ * to fp32 is wrong only if the double result sits within ~1e-16 relative of an fp32
+ * rounding boundary) */
+static inline float cr_log2f(float a) { return (float)log2((double)a); }
+static inline float cr_exp2f(float e) { return (float)exp2((double)e); }
+
+/* torch.max / torch.min propagate NaN from either operand */
+static inline float t_max(float a, float b) { return (a != a) ? a : ((b != b) ? b : (a > b ? a : b)); }
+static inline float t_min(float a, float b) { return (a != a) ? a : ((b != b) ? b : (a < b ? a : b)); }
+
+typedef struct {
+    float maxval, minval, bias, M;
+} orc_chan_t;
+
+/* fp8_quantizer.py:105-113: M, E, bias, minval for one channel */
+static orc_chan_t orc_chan(float maxval, float mbits, int n_bits, int sign_bits)
+{
+    orc_chan_t p;
+    float M = rintf(mbits); /* round_ste_func == torch.round: half to even */
+    float hi = (float)(n_bits - sign_bits);
+    if (M < 1.0f) M = 1.0f;
+    if (M > hi) M = hi;
+    float E = (float)(n_bits - sign_bits) - M;
+    float two_E = cr_exp2f(E);                      /* 2**E, exact */
+    float c = 2.0f - cr_exp2f(-M);                  /* 2 - 2**(-M), exact */
+    /* ((2**E - log2(maxval)) + log2(2 - 2**-M)) - 1, each step rounded to fp32 */
+    float b = two_E - cr_log2f(maxval);
+    b = b + cr_log2f(c);
+    b = b - 1.0f;
+    p.maxval = maxval;
+    p.minval = sign_bits == 1 ? -maxval : 0.0f;     /* -maxval, or zeros_like(maxval) */
+    p.bias = b;
+    p.M = M;
+    return p;
+}
+
+/* fp8_quantizer.py:112-133 for one element */
+static inline float orc_quant1(float x, const orc_chan_t *p)
+{
+    float xc = t_min(t_max(x, p->minval), p->maxval);
+    float v = cr_log2f(fabsf(xc)) + p->bias;
+    float ls = floorf(v);
+    if (ls < 1.0f) ls = 1.0f;                       /* torch.clamp(min=1.0); NaN stays NaN */
+    float e = (ls - p->M) - p->bias;
+    float s = cr_exp2f(e);
+    return rintf(xc / s) * s;                       /* torch.round = half to even */
+}
+
+/* K1.  x,y: [C, inner] contiguous fp32.  maxval: n_maxval == 1 (per tensor) or == C. */
+int orc_quantize_f32(const float *x, float *y, int64_t C, int64_t inner, const float *maxval,
+                     int64_t n_maxval, float mbits, int n_bits, int sign_bits)
+{
+    if (n_maxval != 1 && n_maxval != C) return -1;
+#pragma omp parallel for schedule(static)
+    for (int64_t c = 0; c < C; ++c) {
+        orc_chan_t p = orc_chan(maxval[n_maxval == 1 ? 0 : c], mbits, n_bits, sign_bits);
+        const float *xr = x + c * inner;
+        float *yr = y + c * inner;
+        for (int64_t i = 0; i < inner; ++i) yr[i] = orc_quant1(xr[i], &p);
+    }
+    return 0;
+}
+
+/* flat per-tensor variant that parallelises over elements (cpu_baseline on big tensors) */
+int orc_quantize_flat_f32(const float *x, float *y, int64_t n, float maxval, float mbits,
+                          int n_bits, int sign_bits)
+{
+    orc_chan_t p = orc_chan(maxval, mbits, n_bits, sign_bits);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) y[i] = orc_quant1(x[i], &p);
+    return 0;
+}
+
+/* K2/K3: min and max over the last dim of [C, inner]; NaN anywhere in a row -> NaN (torch.min/max).
+ * range_estimators.py:62-74, 84-98 */
+int orc_minmax_f32(const float *x, int64_t C, int64_t inner, float *mn, float *mx)
+{
+#pragma omp parallel for schedule(static)
+    for (int64_t c = 0; c < C; ++c) {
+        const float *xr = x + c * inner;
+        float lo = INFINITY, hi = -INFINITY;
+        int nan = 0;
+        for (int64_t i = 0; i < inner; ++i) {
+            float v = xr[i];
+            nan |= (v != v);
+            lo = v < lo ? v : lo;
+            hi = v > hi ? v : hi;
+        }
+        mn[c] = nan ? NAN : lo;
+        mx[c] = nan ? NAN : hi;
+    }
+    return 0;
+}
+
+/* fold a new batch estimate into the running one.
+ * mode 0: overwrite (current_minmax :72-73); 1: min/max (allminmax :97-98);
+ * 2: EMA (running_minmax :122-123: (1-m)*new + m*cur).  `first` = no previous estimate. */
+int orc_fold_f32(float *cur_mn, float *cur_mx, const float *mn, const float *mx, int64_t C,
+                 int mode, double momentum, int first)
+{
+    for (int64_t c = 0; c < C; ++c) {
+        if (first || mode == 0) {
+            cur_mn[c] = mn[c];
+            cur_mx[c] = mx[c];
+        } else if (mode == 1) {
+            cur_mn[c] = t_min(cur_mn[c], mn[c]);
+            cur_mx[c] = t_max(cur_mx[c], mx[c]);
+        } else {
+            /* python: (1 - momentum) in double, then each scalar is cast to fp32 by ATen */
+            float om = (float)(1.0 - momentum), mo = (float)momentum;
+            cur_mn[c] = om * mn[c] + mo * cur_mn[c];
+            cur_mx[c] = om * mx[c] + mo * cur_mx[c];
+        }
+    }
+    return 0;
+}
+
+/* K5: fp8_quantizer.py:236  maxval = |max(|x_min|, x_max)| */
+int orc_absmax_f32(const float *mn, const float *mx, int64_t C, float *maxval)
+{
+    for (int64_t c = 0; c < C; ++c) maxval[c] = fabsf(t_max(fabsf(mn[c]), mx[c]));
+    return 0;
+}
+
+/* K4: FP_MSE_Estimator inner loops (range_estimators.py:337-347).
+ * x: [C, inner] (C == 1 for per-tensor); grid: [n_cand, C]; mbits: [n_m];
+ * mses: [n_m, n_cand, C], accumulated (+=) with the per-channel mean of (x - xq)^2.
+ * The mean itself is accumulated in double (the reference sums fp32 with ATen's
+ * vectorised cascade; both are within ~1e-6 relative of the exact value). */
+int orc_mse_grid_f32(const float *x, int64_t C, int64_t inner, const float *grid, int64_t n_cand,
+                     const float *mbits, int n_m, int n_bits, int sign_bits, float *mses)
+{
+    int64_t jobs = (int64_t)n_m * n_cand * C;
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int64_t j = 0; j < jobs; ++j) {
+        int64_t c = j % C;
+        int64_t i = (j / C) % n_cand;
+        int m = (int)(j / (C * n_cand));
+        orc_chan_t p = orc_chan(grid[i * C + c], mbits[m], n_bits, sign_bits);
+        const float *xr = x + c * inner;
+        double acc = 0.0;
+        for (int64_t k = 0; k < inner; ++k) {
+            float d = xr[k] - orc_quant1(xr[k], &p);
+            acc += (double)(d * d);
+        }
+        mses[j] += (float)(acc / (double)inner);
+    }
+    return 0;
+}
+
+/* a9: every value of an (n_bits, ebits, bias) format, ascending (fp8_quantizer.py:13-41).
+ * out must hold 2^n_bits doubles.  Codes: sign | exponent | fraction; exponent code 0 is
+ * subnormal; the all-ones exponent is an ordinary binade (no inf/NaN). */
+static int cmp_double(const void *a, const void *b)
+{
+    double x = *(const double *)a, y = *(const double *)b;
+    return (x > y) - (x < y);
+}
+
+int orc_fp_grid(int n_bits, int ebits, int bias, double *out)
+{
+    int fbits = n_bits - 1 - ebits;
+    if (fbits < 0 || ebits < 0) return -1;
+    int64_t n = 0;
+    for (int s = 0; s < 2; ++s)
+        for (int e = 0; e < (1 << ebits); ++e)
+            for (int f = 0; f < (1 << fbits); ++f) {
+                int sub = (e == 0);
+                double frac = (double)f / (double)(1 << fbits) + 1.0 - sub;
+                out[n++] = (s ? 1.0 : -1.0) * ldexp(frac, e - bias + sub);
+            }
+    qsort(out, (size_t)n, sizeof(double), cmp_double);
+    return 0;
+}
+
+int orc_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+void orc_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}

@@ -1,0 +1,276 @@
+#!/usr/bin/env python
+"""Generate the golden fixtures under tests/golden/ by IMPORTING the reference.
+
+Run once, in the development container only (the reference lives at
+/root/reference and never travels to the GPU box):
+
+    cd /tmp && python -B /root/repo/tests/golden/make_golden.py
+
+The fixtures are data only: seeded inputs, and the outputs the reference's own
+functions produced for them (torch CPU, fp32).  Nothing of the reference's
+source is stored.  The reference needs `timm` (absent here) only for six
+activation class names (quantization/hijacker.py:7-8) -> stub modules.
+
+Fixture files:
+  g1_quantize.npz    quantize_to_fp8_ste_MM   (fp8_quantizer.py:91-133)
+  g2_grids.npz       generate_all_values_fp   (fp8_quantizer.py:13-41)
+  g3_estimators.npz  Current/All/RunningMinMax (range_estimators.py:56-125) + set_quant_range
+  g4_mse.npz         FP_MSE_Estimator         (range_estimators.py:285-369)
+  g6_manager.npz     QuantizationManager.forward state machine (quantization_manager.py:114-122)
+"""
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+import numpy as np
+import torch
+import torch.nn as nn
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def _install_stubs():
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+
+    mk = lambda n: type(n, (nn.Module,), {})
+    stub("timm")
+    stub("timm.models")
+    stub("timm.models.layers")
+    stub("timm.models.layers.activations", Swish=mk("Swish"), HardSwish=mk("HardSwish"),
+         HardSigmoid=mk("HardSigmoid"))
+    stub("timm.models.layers.activations_me", SwishMe=mk("SwishMe"), HardSwishMe=mk("HardSwishMe"),
+         HardSigmoidMe=mk("HardSigmoidMe"))
+
+
+_install_stubs()
+sys.path.insert(0, REF)
+from quantization.quantizers.fp8_quantizer import (  # noqa: E402
+    quantize_to_fp8_ste_MM, FPQuantizer, generate_all_values_fp, generate_all_float_values_scaled)
+from quantization.range_estimators import RangeEstimators  # noqa: E402
+from quantization.quantization_manager import QuantizationManager, QMethods  # noqa: E402
+
+torch.set_num_threads(1)
+
+
+def default_maxval(M, n_bits=8):
+    E = n_bits - 1 - M
+    return float((2 - 2.0 ** (-M)) * 2.0 ** (2 ** E - 1 - 2 ** (E - 1)))
+
+
+def edge_inputs(M, maxval, sign_bits, n_bits=8):
+    """Hand-picked hard inputs for one (M, maxval): ties, binade edges, clamps, specials."""
+    E = n_bits - sign_bits - M
+    bias = 2.0 ** E - np.log2(maxval) + np.log2(2 - 2.0 ** (-M)) - 1
+    vals = [0.0, -0.0, 1e-30, -1e-30, 1e-42, float(maxval), -float(maxval),
+            float(maxval) * 1.5, -float(maxval) * 1.5, float("inf"), float("-inf"), float("nan"),
+            float(np.nextafter(np.float32(maxval), np.float32(0))),
+            float(np.nextafter(np.float32(maxval), np.float32(np.inf)))]
+    pmax = int(2 ** E)
+    ps = sorted(set([1, 2, 3, pmax // 2, pmax - 2, pmax - 1, pmax]))
+    for p in ps:
+        if p < 1:
+            continue
+        s = 2.0 ** (p - M - bias)
+        lo = 2.0 ** (p - bias)  # lower edge of binade p
+        for k in (0, 1, 2, 2 ** M - 1, 2 ** M, 2 ** M + 1, 2 ** (M + 1) - 2, 2 ** (M + 1) - 1):
+            t = np.float32((k + 0.5) * s)  # rounding tie (exact when bias is an integer)
+            vals += [float(t), float(np.nextafter(t, np.float32(0))),
+                     float(np.nextafter(t, np.float32(np.inf))), -float(t)]
+        b = np.float32(lo)
+        vals += [float(b), float(np.nextafter(b, np.float32(0))),
+                 float(np.nextafter(b, np.float32(np.inf))), -float(b)]
+    return np.array(vals, dtype=np.float32)
+
+
+def make_g1():
+    out = {}
+    rng = np.random.RandomState(1234)
+    base = rng.randn(2048).astype(np.float32)
+    out["base"] = base
+    cases = []
+    cid = 0
+    for M in (1, 2, 3, 4, 5, 6):
+        mv_list = [default_maxval(M), 3.0, 1.0, 0.7361, 0.0123]
+        for mv in mv_list:
+            for sb in (1, 0):
+                if sb == 0 and mv not in (default_maxval(M), 0.7361):
+                    continue
+                # scale the normals so that ~2% of them clip
+                x = np.concatenate([base * np.float32(mv / 2.3), edge_inputs(M, mv, sb)])
+                xt = torch.from_numpy(x.copy())
+                y = quantize_to_fp8_ste_MM(xt, 8, torch.Tensor([mv]), torch.Tensor([float(M)]), sb)
+                out[f"c{cid}_x"] = x
+                out[f"c{cid}_y"] = y.numpy()
+                cases.append((cid, M, mv, sb, 1))
+                cid += 1
+    # per-channel maxval [8], x [8, 300]
+    for M in (2, 3, 5):
+        mvs = (np.abs(rng.randn(8)) * 2 + 0.05).astype(np.float32)
+        x = (rng.randn(8, 300) * (mvs[:, None] / 2.0)).astype(np.float32)
+        y = quantize_to_fp8_ste_MM(torch.from_numpy(x.copy()), 8, torch.from_numpy(mvs.copy()),
+                                   torch.Tensor([float(M)]), 1)
+        out[f"c{cid}_x"] = x
+        out[f"c{cid}_y"] = y.numpy()
+        out[f"c{cid}_maxval"] = mvs
+        cases.append((cid, M, -1.0, 1, 8))
+        cid += 1
+    # all-zero channel -> maxval 0 -> NaN channel (fp8_quantizer.py:110,128)
+    mvs = np.array([1.0, 0.0, 2.5], dtype=np.float32)
+    x = (rng.randn(3, 64)).astype(np.float32)
+    x[1] = 0
+    y = quantize_to_fp8_ste_MM(torch.from_numpy(x.copy()), 8, torch.from_numpy(mvs.copy()),
+                               torch.Tensor([3.0]), 1)
+    out[f"c{cid}_x"] = x
+    out[f"c{cid}_y"] = y.numpy()
+    out[f"c{cid}_maxval"] = mvs
+    cases.append((cid, 3, -1.0, 1, 3))
+    cid += 1
+    # non-integer mantissa bits are rounded half-to-even then clamped (fp8_quantizer.py:105)
+    for mb in (2.5, 3.5, 0.2, 9.0):
+        x = base[:512] * np.float32(0.5)
+        y = quantize_to_fp8_ste_MM(torch.from_numpy(x.copy()), 8, torch.Tensor([1.7]),
+                                   torch.Tensor([mb]), 1)
+        out[f"c{cid}_x"] = x
+        out[f"c{cid}_y"] = y.numpy()
+        cases.append((cid, mb, 1.7, 1, 1))
+        cid += 1
+    out["cases"] = np.array(cases, dtype=np.float64)  # id, mbits, maxval(-1: per-channel), sign, n_maxval
+    np.savez_compressed(os.path.join(OUT, "g1_quantize.npz"), **out)
+    print("g1:", cid, "cases")
+
+
+def make_g2():
+    out = {}
+    for e in (2, 3, 4, 5):
+        for b in (2 ** (e - 1), 2 ** (e - 1) + 1, 1):
+            out[f"e{e}_b{b}"] = generate_all_values_fp(8, e, b)
+        out[f"scaled_e{e}"] = generate_all_float_values_scaled(8, e, 2 ** (e - 1), 3.0)
+    np.savez_compressed(os.path.join(OUT, "g2_grids.npz"), **out)
+    print("g2 ok")
+
+
+def make_g3():
+    out = {}
+    torch.manual_seed(0)
+    w = torch.randn(64, 3, 7, 7) * 0.1  # BASELINE config 2 tensor
+    out["w"] = w.numpy()
+    est = RangeEstimators.current_minmax.cls(per_channel=True)
+    mn, mx = est(w)
+    out["w_cur_pc_min"], out["w_cur_pc_max"] = mn.numpy(), mx.numpy()
+    est = RangeEstimators.current_minmax.cls(per_channel=False)
+    mn, mx = est(w)
+    out["w_cur_pt_min"], out["w_cur_pt_max"] = mn.numpy(), mx.numpy()
+    # quantizer range set from per-channel min/max (fp8_quantizer.py:222-240), then quantize
+    q = FPQuantizer(n_bits=8, per_channel=True, mantissa_bits=2, maxval=None, set_maxval=True)
+    q.set_quant_range(out_t(out["w_cur_pc_min"]), out_t(out["w_cur_pc_max"]))
+    out["w_maxval"] = q.maxval.numpy()
+    out["w_q_e5m2"] = q(w).numpy()
+    # three sequential activation batches
+    acts = [torch.randn(4, 8, 6, 6) * (1 + i) + 0.3 * i for i in range(3)]
+    out["acts"] = np.stack([a.numpy() for a in acts])
+    for name in ("allminmax", "running_minmax"):
+        for pc in (False, True):
+            est = RangeEstimators[name].cls(per_channel=pc)
+            mins, maxs = [], []
+            for a in acts:
+                mn, mx = est(a)
+                mins.append(mn.numpy().copy().reshape(-1))
+                maxs.append(mx.numpy().copy().reshape(-1))
+            out[f"{name}_pc{int(pc)}_min"] = np.stack(mins)
+            out[f"{name}_pc{int(pc)}_max"] = np.stack(maxs)
+    # NaN handling of min/max
+    an = acts[0].clone()
+    an[1, 2, 3, 4] = float("nan")
+    est = RangeEstimators.allminmax.cls(per_channel=False)
+    mn, mx = est(an)
+    out["nan_min"], out["nan_max"] = mn.numpy(), mx.numpy()
+    # allow_unsigned: ReLU output -> sign_bits 0 (fp8_quantizer.py:216-225)
+    q = FPQuantizer(n_bits=8, per_channel=False, mantissa_bits=3, maxval=None, set_maxval=True,
+                    allow_unsigned=True)
+    r = torch.relu(acts[1])
+    q.set_quant_range(r.min(), r.max())
+    out["relu_x"] = r.numpy()
+    out["relu_sign_bits"] = np.array(q.sign_bits)
+    out["relu_maxval"] = q.maxval.numpy()
+    out["relu_q"] = q(r).numpy()
+    np.savez_compressed(os.path.join(OUT, "g3_estimators.npz"), **out)
+    print("g3 ok")
+
+
+def out_t(a):
+    return torch.from_numpy(np.array(a))
+
+
+def make_g4():
+    out = {}
+    torch.manual_seed(1)
+    cfgs = [
+        ("w_pc_fixm", (32, 3, 3, 3), True, False, 3),
+        ("w_pc_srchm", (32, 3, 3, 3), True, True, 3),
+        ("a_pt_fixm", (2, 8, 14, 14), False, False, 3),
+        ("a_pt_srchm", (2, 8, 14, 14), False, True, 2),
+    ]
+    for name, shape, pc, incl, M in cfgs:
+        q = FPQuantizer(n_bits=8, per_channel=pc, mantissa_bits=M, maxval=None, set_maxval=True,
+                        mse_include_mantissa_bits=incl)
+        est = RangeEstimators.MSE.cls(per_channel=pc, quantizer=q)
+        xs = [torch.randn(*shape) * 0.2, torch.randn(*shape) * 0.3]
+        for b, x in enumerate(xs):
+            mn, mx = est(x)
+            out[f"{name}_x{b}"] = x.numpy()
+            out[f"{name}_mses{b}"] = est.mses.numpy().copy()
+            out[f"{name}_min{b}"] = mn.numpy().copy()
+            out[f"{name}_max{b}"] = mx.numpy().copy()
+            out[f"{name}_mbits{b}"] = np.array(float(q.mantissa_bits))
+        out[f"{name}_grid"] = est.search_grid.numpy().copy()
+    # allow_unsigned + one-sided data: sign_bits stays 1 inside the search grid sign, range min = 0
+    q = FPQuantizer(n_bits=8, per_channel=False, mantissa_bits=3, maxval=None, set_maxval=True,
+                    mse_include_mantissa_bits=False, allow_unsigned=True)
+    est = RangeEstimators.MSE.cls(per_channel=False, quantizer=q)
+    x = torch.relu(torch.randn(2, 8, 14, 14))
+    mn, mx = est(x)
+    out["relu_x"] = x.numpy()
+    out["relu_mses"] = est.mses.numpy().copy()
+    out["relu_min"], out["relu_max"] = mn.numpy().copy(), mx.numpy().copy()
+    out["relu_sign_bits"] = np.array(q.sign_bits)
+    np.savez_compressed(os.path.join(OUT, "g4_mse.npz"), **out)
+    print("g4 ok")
+
+
+def make_g6():
+    """QuantizationManager state machine: estimate -> fix, ranges frozen afterwards."""
+    out = {}
+    torch.manual_seed(2)
+    xs = [torch.randn(4, 16, 5, 5) * (0.5 + i) for i in range(3)]
+    out["xs"] = np.stack([x.numpy() for x in xs])
+    qm = QuantizationManager(qmethod=QMethods.fp_quantizer.cls,
+                             init=RangeEstimators.allminmax.cls, per_channel=False,
+                             qparams=dict(n_bits=8, mantissa_bits=3, maxval=None, set_maxval=True))
+    ys = [qm(xs[0]).numpy().copy(), qm(xs[1]).numpy().copy()]
+    out["maxval_after2"] = qm.quantizer.maxval.numpy().copy()
+    qm.fix_ranges()
+    ys.append(qm(xs[2]).numpy().copy())
+    out["maxval_after_fix"] = qm.quantizer.maxval.numpy().copy()
+    out["ys"] = np.stack(ys)
+    # set_maxval=False (CLI default): estimation is a no-op, default maxval is used
+    qm = QuantizationManager(qmethod=QMethods.fp_quantizer.cls,
+                             init=RangeEstimators.allminmax.cls, per_channel=False,
+                             qparams=dict(n_bits=8, mantissa_bits=2, maxval=None, set_maxval=False))
+    out["nomaxval_y"] = qm(xs[0] * 1e4).numpy().copy()
+    out["nomaxval_maxval"] = qm.quantizer.maxval.numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "g6_manager.npz"), **out)
+    print("g6 ok")
+
+
+if __name__ == "__main__":
+    make_g1()
+    make_g2()
+    make_g3()
+    make_g4()
+    make_g6()
+    assert not os.path.exists(os.path.join(REF, "quantization", "__pycache__")), "pycache leaked"
