@@ -1,0 +1,862 @@
+// fp8q_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels + the C ABI of include/fp8q.h.
+//
+// Every kernel here is elementwise or a reduction: the roofline is HBM bandwidth, not MFMA.
+// Common shape: 256-thread blocks (4 waves, one per SIMD), 16 B per lane per memory
+// instruction (1 KiB per wave-instruction), several independent loads in flight per lane,
+// persistent grids of ~8 blocks per CU that stride over the tensor.
+//
+// Kernel inventory:
+//   k_quant_rows     K1, one channel per blockIdx.y (per-tensor: one row).  Scale LUT in LDS.
+//   k_quant_multi    K1, per-channel with short rows: flat tiles that span many channels,
+//                    per-channel constants (and LUTs when rows are long enough) staged in LDS.
+//   k_quant_scalar   K1 fallback for x / y that are not 16-byte co-aligned.
+//   k_minmax_partial K2/K3 stage 1: per-(row, split) min / max / NaN flag.
+//   k_minmax_final   K2/K3 stage 2 + K5: reduce the splits, fold into the running estimate
+//                    (current / all / EMA), write |max(|min|, max)|.
+//   k_minmax_quant   K2+K5+K1 fused for weight tensors: whole rows staged in LDS, row min/max,
+//                    maxval, LUT, quantize, one read + one write of HBM per element.
+//   k_mse_grid       K4: all candidate maxvals x mantissa widths in one pass over x.
+//   k_copy           float4 copy with K1's launch shape (measured HBM ceiling).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/fp8q.h"
+#include "fp8q_device.h"
+
+using namespace fp8q;
+
+namespace {
+
+constexpr int kUnroll = 4;           // float4 loads in flight per lane
+constexpr int kTargetBlocks = 2048;  // 256 CUs x 8 blocks
+constexpr int kMultiTile = 4096;     // elements per k_quant_multi tile (16 KiB in, 16 KiB out)
+constexpr int kMultiMaxCh = 512;     // channels per tile whose constants fit the LDS budget
+constexpr int kFusedMaxElems = 16384;  // LDS tile of k_minmax_quant: 64 KiB of x
+
+__device__ __forceinline__ float4 ldg4(const float4 *p) { return *p; }
+__device__ __forceinline__ void stg4(float4 *p, const float4 &v) { *p = v; }
+
+// ---------------------------------------------------------------------------------------------
+// K1 rows: blockIdx.y = row (channel), blockIdx.x strides over the row.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+k_quant_rows(const float *__restrict__ x, float *__restrict__ y, int64_t inner,
+             const float *__restrict__ maxval, int per_channel, QFmt f)
+{
+    __shared__ float lut[kLutMax];
+    const int row = blockIdx.y;
+    const int tid = threadIdx.x;
+    const Chan c = make_chan(maxval[per_channel ? row : 0], f);
+    for (int i = tid; i <= f.pmax; i += kBlock)
+        lut[i] = i == 0 ? __builtin_nanf("") : scale_exact(c, (float)i, f.M);
+    __syncthreads();
+    const float pmaxf = (float)f.pmax;
+
+    const float *xr = x + (int64_t)row * inner;
+    float *yr = y + (int64_t)row * inner;
+    // peel to 16-byte alignment (x and y are co-aligned: checked on the host)
+    int64_t head = ((16 - ((uintptr_t)xr & 15)) & 15) >> 2;
+    if (head > inner) head = inner;
+    const int64_t nvec = (inner - head) >> 2;
+    const int64_t tail0 = head + (nvec << 2);
+    if (blockIdx.x == 0) {
+        if (tid < head) yr[tid] = quant_lut(xr[tid], c, lut, pmaxf);
+        const int64_t t = tail0 + tid;
+        if (t < inner) yr[t] = quant_lut(xr[t], c, lut, pmaxf);
+    }
+    const float4 *xv = reinterpret_cast<const float4 *>(xr + head);
+    float4 *yv = reinterpret_cast<float4 *>(yr + head);
+
+    const int64_t step = (int64_t)gridDim.x * (kBlock * kUnroll);
+    for (int64_t base = (int64_t)blockIdx.x * (kBlock * kUnroll); base < nvec; base += step) {
+        float4 v[kUnroll];
+        if (base + kBlock * kUnroll <= nvec) {
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) v[u] = ldg4(xv + base + u * kBlock + tid);
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                v[u].x = quant_lut(v[u].x, c, lut, pmaxf);
+                v[u].y = quant_lut(v[u].y, c, lut, pmaxf);
+                v[u].z = quant_lut(v[u].z, c, lut, pmaxf);
+                v[u].w = quant_lut(v[u].w, c, lut, pmaxf);
+            }
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) stg4(yv + base + u * kBlock + tid, v[u]);
+        } else {
+            for (int u = 0; u < kUnroll; ++u) {
+                const int64_t i = base + u * kBlock + tid;
+                if (i < nvec) {
+                    float4 w = ldg4(xv + i);
+                    w.x = quant_lut(w.x, c, lut, pmaxf);
+                    w.y = quant_lut(w.y, c, lut, pmaxf);
+                    w.z = quant_lut(w.z, c, lut, pmaxf);
+                    w.w = quant_lut(w.w, c, lut, pmaxf);
+                    stg4(yv + i, w);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1 multi: flat tiles over [C, inner] with short rows.  Dynamic LDS:
+//   Chan chans[max_ch]; float lut[max_ch * lut_stride] (LUT variant only)
+// ---------------------------------------------------------------------------------------------
+struct MultiArgs {
+    int inner;          // row length (< 2^20)
+    int tile;           // elements per tile, multiple of 4
+    int max_ch;         // channels a tile can span
+    int lut_stride;     // pmax + 1
+    uint32_t magic;     // floor(2^32 / inner) + 1: n / inner == umulhi(n, magic) for n*inner < 2^32
+};
+
+template <bool LUT>
+__device__ __forceinline__ float quant_multi_elem(float x, const Chan *chans, const float *lut,
+                                                  int ch, const QFmt &f, int lut_stride)
+{
+    if (LUT) {
+        // only the clamp bounds and bias are needed: 16-byte LDS read
+        const float4 h = *reinterpret_cast<const float4 *>(&chans[ch]);
+        Chan c;
+        c.maxv = h.x;
+        c.minv = h.y;
+        c.bias = h.z;
+        return quant_lut(x, c, lut + ch * lut_stride, (float)f.pmax);
+    } else {
+        const Chan c = chans[ch];
+        return quant_direct(x, c, f.M);
+    }
+}
+
+template <bool LUT>
+__global__ void __launch_bounds__(kBlock)
+k_quant_multi(const float *__restrict__ x, float *__restrict__ y, int64_t total,
+              const float *__restrict__ maxval, QFmt f, MultiArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    Chan *chans = reinterpret_cast<Chan *>(smem);
+    float *lut = reinterpret_cast<float *>(smem + (size_t)a.max_ch * sizeof(Chan));
+    const int tid = threadIdx.x;
+
+    for (int64_t t0 = (int64_t)blockIdx.x * a.tile; t0 < total; t0 += (int64_t)gridDim.x * a.tile) {
+        const int n = (int)((total - t0) < a.tile ? (total - t0) : a.tile);
+        const int64_t ch0 = t0 / a.inner;
+        const int rem0 = (int)(t0 - ch0 * a.inner);
+        const int nch = (rem0 + n - 1) / a.inner + 1;
+        __syncthreads();  // previous tile finished with the LDS
+        for (int j = tid; j < nch; j += kBlock) chans[j] = make_chan(maxval[ch0 + j], f);
+        if (LUT) {
+            __syncthreads();
+            for (int j = tid; j < nch * a.lut_stride; j += kBlock) {
+                const int cj = j / a.lut_stride, pj = j - cj * a.lut_stride;
+                lut[j] = pj == 0 ? __builtin_nanf("") : scale_exact(chans[cj], (float)pj, f.M);
+            }
+        }
+        __syncthreads();
+
+        const float *xt = x + t0;
+        float *yt = y + t0;
+        for (int o = tid * 4; o < n; o += kBlock * 4) {
+            const uint32_t n0 = (uint32_t)(o + rem0);
+            int ch = (int)__umulhi(n0, a.magic);
+            int r = (int)n0 - ch * a.inner;
+            if (o + 4 <= n) {
+                float4 v = ldg4(reinterpret_cast<const float4 *>(xt + o));
+                float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    e[j] = quant_multi_elem<LUT>(e[j], chans, lut, ch, f, a.lut_stride);
+                    if (++r == a.inner) {
+                        r = 0;
+                        ++ch;
+                    }
+                }
+                stg4(reinterpret_cast<float4 *>(yt + o), make_float4(e[0], e[1], e[2], e[3]));
+            } else {
+                for (int j = 0; o + j < n; ++j) {
+                    yt[o + j] = quant_multi_elem<LUT>(xt[o + j], chans, lut, ch, f, a.lut_stride);
+                    if (++r == a.inner) {
+                        r = 0;
+                        ++ch;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// K1 scalar fallback (x / y not 16-byte co-aligned): one row per blockIdx.y, dword accesses
+__global__ void __launch_bounds__(kBlock)
+k_quant_scalar(const float *__restrict__ x, float *__restrict__ y, int64_t inner,
+               const float *__restrict__ maxval, int per_channel, QFmt f)
+{
+    const int row = blockIdx.y;
+    const Chan c = make_chan(maxval[per_channel ? row : 0], f);
+    const float *xr = x + (int64_t)row * inner;
+    float *yr = y + (int64_t)row * inner;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < inner;
+         i += (int64_t)gridDim.x * kBlock)
+        yr[i] = quant_direct(xr[i], c, f.M);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2/K3 stage 1: min / max / NaN of x[row, split range] -> ws[(row * nsplit + split) * 4 ..]
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void block_reduce_store(MinMax m, float *out)
+{
+    __shared__ float s_mn[4], s_mx[4];
+    __shared__ int s_nan[4];
+    mm_wave_reduce(m);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) {
+        s_mn[wave] = m.mn;
+        s_mx[wave] = m.mx;
+        s_nan[wave] = m.nan;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float mn = fminf(fminf(s_mn[0], s_mn[1]), fminf(s_mn[2], s_mn[3]));
+        float mx = fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3]));
+        const int nan = s_nan[0] | s_nan[1] | s_nan[2] | s_nan[3];
+        if (nan) mn = mx = __builtin_nanf("");
+        out[0] = mn;
+        out[1] = mx;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_minmax_partial(const float *__restrict__ x, int64_t inner, int nsplit, float *__restrict__ ws)
+{
+    const int row = blockIdx.y, split = blockIdx.x, tid = threadIdx.x;
+    const float *xr = x + (int64_t)row * inner;
+    MinMax m;
+    mm_init(m);
+    int64_t head = ((16 - ((uintptr_t)xr & 15)) & 15) >> 2;
+    if (head > inner) head = inner;
+    const int64_t nvec = (inner - head) >> 2;
+    const int64_t tail0 = head + (nvec << 2);
+    if (split == 0) {
+        if (tid < head) mm_acc(m, xr[tid]);
+        if (tail0 + tid < inner) mm_acc(m, xr[tail0 + tid]);
+    }
+    const float4 *xv = reinterpret_cast<const float4 *>(xr + head);
+    constexpr int U = 8;
+    const int64_t step = (int64_t)nsplit * (kBlock * U);
+    for (int64_t base = (int64_t)split * (kBlock * U); base < nvec; base += step) {
+        if (base + kBlock * U <= nvec) {
+            float4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = ldg4(xv + base + u * kBlock + tid);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                mm_acc(m, v[u].x);
+                mm_acc(m, v[u].y);
+                mm_acc(m, v[u].z);
+                mm_acc(m, v[u].w);
+            }
+        } else {
+            for (int u = 0; u < U; ++u) {
+                const int64_t i = base + u * kBlock + tid;
+                if (i < nvec) {
+                    const float4 w = ldg4(xv + i);
+                    mm_acc(m, w.x);
+                    mm_acc(m, w.y);
+                    mm_acc(m, w.z);
+                    mm_acc(m, w.w);
+                }
+            }
+        }
+    }
+    block_reduce_store(m, ws + ((int64_t)row * nsplit + split) * 2);
+}
+
+// torch.min / torch.max of two values (NaN from either side wins)
+__device__ __forceinline__ float tmin(float a, float b) { return (a != a) ? a : ((b != b) ? b : fminf(a, b)); }
+__device__ __forceinline__ float tmax(float a, float b) { return (a != a) ? a : ((b != b) ? b : fmaxf(a, b)); }
+
+struct FoldArgs {
+    int mode;     // FP8Q_FOLD_*
+    int first;    // no previous estimate
+    float om;     // fl32(1 - momentum)   (python double arithmetic, then cast: range_estimators.py:122)
+    float mo;     // fl32(momentum)
+};
+
+__device__ __forceinline__ void fold_store(float mn, float mx, int64_t row, float *cur_min,
+                                           float *cur_max, float *maxval_out, const FoldArgs &fa)
+{
+    if (!fa.first && fa.mode == FP8Q_FOLD_ALL) {
+        mn = tmin(cur_min[row], mn);
+        mx = tmax(cur_max[row], mx);
+    } else if (!fa.first && fa.mode == FP8Q_FOLD_RUNNING) {
+        // (1-m)*new + m*cur as three separately rounded fp32 ops (no FMA: -ffp-contract=off)
+        mn = fa.om * mn + fa.mo * cur_min[row];
+        mx = fa.om * mx + fa.mo * cur_max[row];
+    }
+    if (cur_min) cur_min[row] = mn;
+    if (cur_max) cur_max[row] = mx;
+    if (maxval_out) maxval_out[row] = fabsf(tmax(fabsf(mn), mx));  // fp8_quantizer.py:236
+}
+
+// K2/K3 stage 2: one wave per row reduces the row's splits
+__global__ void __launch_bounds__(kBlock)
+k_minmax_final(const float *__restrict__ ws, int64_t C, int nsplit, float *cur_min, float *cur_max,
+               float *maxval_out, FoldArgs fa)
+{
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= C) return;
+    MinMax m;
+    mm_init(m);
+    for (int s = lane; s < nsplit; s += 64) {
+        const float a = ws[(row * nsplit + s) * 2], b = ws[(row * nsplit + s) * 2 + 1];
+        mm_acc(m, a);
+        mm_acc(m, b);
+    }
+    mm_wave_reduce(m);
+    if (lane == 0) {
+        if (m.nan) m.mn = m.mx = __builtin_nanf("");
+        fold_store(m.mn, m.mx, row, cur_min, cur_max, maxval_out, fa);
+    }
+}
+
+// K2 for short rows: one wave per row, no workspace, fold fused
+__global__ void __launch_bounds__(kBlock)
+k_minmax_waverow(const float *__restrict__ x, int64_t C, int inner, float *cur_min, float *cur_max,
+                 float *maxval_out, FoldArgs fa)
+{
+    const int lane = threadIdx.x & 63;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < C;
+         row += (int64_t)gridDim.x * 4) {
+        const float *xr = x + row * inner;
+        MinMax m;
+        mm_init(m);
+        for (int i = lane; i < inner; i += 64) mm_acc(m, xr[i]);
+        mm_wave_reduce(m);
+        if (lane == 0) {
+            if (m.nan) m.mn = m.mx = __builtin_nanf("");
+            fold_store(m.mn, m.mx, row, cur_min, cur_max, maxval_out, fa);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2+K5+K1 fused (weights, estimate_ranges state): R whole rows per block staged in LDS.
+// Dynamic LDS: float xs[pad + R*inner (+3)] | Chan chans[R] | float lut[R * lut_stride] (LUT only)
+// ---------------------------------------------------------------------------------------------
+struct FusedArgs {
+    int inner;
+    int rows_per_block;
+    int lut_stride;   // pmax + 1
+    int xs_floats;    // LDS floats reserved for the x tile (multiple of 4)
+    uint32_t magic;
+};
+
+template <bool LUT>
+__global__ void __launch_bounds__(kBlock)
+k_minmax_quant(const float *__restrict__ x, float *__restrict__ y, int64_t C, float *row_min,
+               float *row_max, float *maxval_out, QFmt f, FusedArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *xs = reinterpret_cast<float *>(smem);
+    Chan *chans = reinterpret_cast<Chan *>(smem + (size_t)a.xs_floats * 4);
+    float *lut = reinterpret_cast<float *>(smem + (size_t)a.xs_floats * 4 +
+                                           (size_t)a.rows_per_block * sizeof(Chan));
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+
+    for (int64_t r0 = (int64_t)blockIdx.x * a.rows_per_block; r0 < C;
+         r0 += (int64_t)gridDim.x * a.rows_per_block) {
+        const int R = (int)((C - r0) < a.rows_per_block ? (C - r0) : a.rows_per_block);
+        const int n = R * a.inner;
+        const float *xt = x + r0 * a.inner;
+        float *yt = y + r0 * a.inner;
+        // LDS index = pad + i so that LDS and global addresses share their 16-byte phase
+        const int pad = (int)(((uintptr_t)xt & 15) >> 2);
+        int head = (4 - pad) & 3;
+        if (head > n) head = n;
+        const int nvec = (n - head) >> 2;
+        const int tail0 = head + (nvec << 2);
+        __syncthreads();
+        // ---- stage the tile: global -> LDS
+        if (tid < head) xs[pad + tid] = xt[tid];
+        if (tail0 + tid < n) xs[pad + tail0 + tid] = xt[tail0 + tid];
+        {
+            const float4 *xv = reinterpret_cast<const float4 *>(xt + head);
+            float4 *sv = reinterpret_cast<float4 *>(xs + pad + head);
+            for (int i = tid; i < nvec; i += kBlock) sv[i] = ldg4(xv + i);
+        }
+        __syncthreads();
+        // ---- row min / max: one wave per row
+        for (int r = wave; r < R; r += 4) {
+            const float *xr = xs + pad + r * a.inner;
+            MinMax m;
+            mm_init(m);
+            for (int i = lane; i < a.inner; i += 64) mm_acc(m, xr[i]);
+            mm_wave_reduce(m);
+            if (m.nan) m.mn = m.mx = __builtin_nanf("");
+            const float mv = fabsf(tmax(fabsf(m.mn), m.mx));   // fp8_quantizer.py:236
+            // the xor-shuffle reduction leaves min/max in every lane: all lanes derive the
+            // channel constants (same cost as one lane doing it), lane 0 publishes them
+            const Chan c = make_chan(mv, f);
+            if (lane == 0) {
+                if (row_min) row_min[r0 + r] = m.mn;
+                if (row_max) row_max[r0 + r] = m.mx;
+                if (maxval_out) maxval_out[r0 + r] = mv;
+                chans[r] = c;
+            }
+            if (LUT) {
+                for (int p = lane; p < a.lut_stride; p += 64)
+                    lut[r * a.lut_stride + p] =
+                        p == 0 ? __builtin_nanf("") : scale_exact(c, (float)p, f.M);
+            }
+        }
+        __syncthreads();
+        // ---- quantize out of LDS, write coalesced
+        if (tid < head) {
+            yt[tid] = quant_multi_elem<LUT>(xs[pad + tid], chans, lut, 0, f, a.lut_stride);
+        }
+        if (tail0 + tid < n) {
+            const int i = tail0 + tid;
+            const int ch = (int)__umulhi((uint32_t)i, a.magic);
+            yt[i] = quant_multi_elem<LUT>(xs[pad + i], chans, lut, ch, f, a.lut_stride);
+        }
+        {
+            const float4 *sv = reinterpret_cast<const float4 *>(xs + pad + head);
+            float4 *yv = reinterpret_cast<float4 *>(yt + head);
+            for (int i = tid; i < nvec; i += kBlock) {
+                const uint32_t n0 = (uint32_t)(head + i * 4);
+                int ch = (int)__umulhi(n0, a.magic);
+                int r = (int)n0 - ch * a.inner;
+                const float4 v = sv[i];
+                float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    e[j] = quant_multi_elem<LUT>(e[j], chans, lut, ch, f, a.lut_stride);
+                    if (++r == a.inner) {
+                        r = 0;
+                        ++ch;
+                    }
+                }
+                stg4(yv + i, make_float4(e[0], e[1], e[2], e[3]));
+            }
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// K4: FP-MSE grid search (range_estimators.py:337-347), ALU-bound.
+// One lane = one candidate maxval; every lane walks the SAME x tile, broadcast out of LDS, so a
+// candidate's squared error accumulates in one register and no cross-lane reduction exists.
+// Block = 128 lanes (candidates i0..i0+127 of one mantissa width m, one row c, one split of the
+// row).  Per-candidate scale LUT (and its reciprocal) in LDS, built with scale_exact(): the
+// scales are the same numbers K1 uses; rint(xc * (1/s)) differs from rint(xc / s) only at exact
+// ties, where |x - q| is the same either way.
+// Dynamic LDS: float xs[kMseTile] | float lut[128 * stride] | float ilut[128 * stride]
+// ---------------------------------------------------------------------------------------------
+constexpr int kMseBlock = 128;
+constexpr int kMseTile = 2048;
+constexpr int kMseMaxM = 8;
+
+struct MseArgs {
+    QFmt fmt[kMseMaxM];
+    int n_m;
+    int n_cand;
+    int cgroups;   // ceil(n_cand / 128)
+    int nsplit;
+    int64_t inner;
+    int64_t C;
+};
+
+__global__ void __launch_bounds__(kMseBlock)
+k_mse_grid(const float *__restrict__ x, const float *__restrict__ grid, double *__restrict__ ws,
+           MseArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *xs = reinterpret_cast<float *>(smem);
+    const int tid = threadIdx.x;
+    const int split = blockIdx.x;
+    const int m = blockIdx.y / a.cgroups;
+    const int cand = (blockIdx.y - m * a.cgroups) * kMseBlock + tid;
+    const int64_t c = blockIdx.z;
+    const QFmt f = a.fmt[m];
+    const int stride = f.pmax + 2;             // odd or even, rows are read at lane-varying p
+    float *lut = xs + kMseTile + tid * stride;
+    float *ilut = lut + kMseBlock * stride;
+    const bool active = cand < a.n_cand;
+
+    // set_quant_range(-g, g): maxval = |max(|-g|, g)|  (fp8_quantizer.py:236)
+    const float gv = active ? grid[(int64_t)cand * a.C + c] : 1.0f;
+    const Chan ch = make_chan(fabsf(fmaxf(fabsf(-gv), gv)), f);
+    for (int p = 0; p <= f.pmax; ++p) {
+        const float sc = p == 0 ? __builtin_nanf("") : scale_exact(ch, (float)p, f.M);
+        lut[p] = sc;
+        ilut[p] = 1.0f / sc;
+    }
+    const float pmaxf = (float)f.pmax;
+    const float *xr = x + c * a.inner;
+    double acc = 0.0;
+
+    for (int64_t t0 = (int64_t)split * kMseTile; t0 < a.inner; t0 += (int64_t)a.nsplit * kMseTile) {
+        const int n = (int)((a.inner - t0) < kMseTile ? (a.inner - t0) : kMseTile);
+        __syncthreads();
+        for (int i = tid; i < kMseTile; i += kMseBlock) xs[i] = i < n ? xr[t0 + i] : 0.0f;
+        __syncthreads();
+        // zero padding: q(0) = 0 exactly, contributes nothing (degenerate maxval -> NaN anyway)
+        const int n32 = (n + 31) & ~31;
+        for (int j = 0; j < n32; j += 32) {
+            float pa = 0.0f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float4 v = *reinterpret_cast<const float4 *>(xs + j + u * 4);
+                const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float xv = e[q];
+                    const float xc = fminf(fmaxf(xv, ch.minv), ch.maxv);
+                    const float vv = __builtin_amdgcn_logf(fabsf(xc)) + ch.bias;
+                    const float ls = fminf(fmaxf(floorf(vv), 1.0f), pmaxf);
+                    const int idx = (int)ls;
+                    const float r = rintf(xc * ilut[idx]);
+                    const float qv = r * lut[idx];
+                    const float d = xv - qv;
+                    pa = fmaf(d, d, pa);
+                }
+            }
+            acc += (double)pa;
+        }
+    }
+    if (active) ws[((c * a.n_m + m) * a.n_cand + cand) * a.nsplit + split] = acc;
+}
+
+// mses[m, i, c] += sum_over_splits / inner
+__global__ void __launch_bounds__(kBlock)
+k_mse_final(const double *__restrict__ ws, float *__restrict__ mses, int64_t C, int n_m, int n_cand,
+            int nsplit, double inv_inner)
+{
+    const int64_t total = C * n_m * n_cand;
+    for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < total;
+         j += (int64_t)gridDim.x * kBlock) {
+        // j indexes ws rows: ((c * n_m + m) * n_cand + i)
+        const int64_t c = j / ((int64_t)n_m * n_cand);
+        const int64_t mi = j - c * n_m * n_cand;   // m * n_cand + i
+        double sum = 0.0;
+        for (int s2 = 0; s2 < nsplit; ++s2) sum += ws[j * nsplit + s2];
+        mses[mi * C + c] += (float)(sum * inv_inner);
+    }
+}
+
+// float4 copy with K1's launch shape: the achievable-HBM yardstick
+__global__ void __launch_bounds__(kBlock)
+k_copy(const float4 *__restrict__ x, float4 *__restrict__ y, int64_t nvec)
+{
+    const int tid = threadIdx.x;
+    const int64_t step = (int64_t)gridDim.x * (kBlock * kUnroll);
+    for (int64_t base = (int64_t)blockIdx.x * (kBlock * kUnroll); base < nvec; base += step) {
+        float4 v[kUnroll];
+        if (base + kBlock * kUnroll <= nvec) {
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) v[u] = ldg4(x + base + u * kBlock + tid);
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) stg4(y + base + u * kBlock + tid, v[u]);
+        } else {
+            for (int u = 0; u < kUnroll; ++u) {
+                const int64_t i = base + u * kBlock + tid;
+                if (i < nvec) stg4(y + i, ldg4(x + i));
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+int make_fmt(float mbits, int n_bits, int sign_bits, QFmt *f)
+{
+    if (!(mbits == mbits) || n_bits < 2 || n_bits > 16 || (sign_bits != 0 && sign_bits != 1))
+        return FP8Q_EINVAL;
+    float M = nearbyintf(mbits);  // round half to even (default rounding mode) = torch.round
+    const float hi = (float)(n_bits - sign_bits);
+    if (M < 1.0f) M = 1.0f;
+    if (M > hi) M = hi;
+    const int E = n_bits - sign_bits - (int)M;
+    if (E < 0) return FP8Q_EINVAL;
+    if (E > 7) return FP8Q_EUNSUPPORTED;
+    f->M = M;
+    f->two_E = (float)(1 << E);
+    f->l_c = (float)log2((double)(2.0f - exp2f(-M)));
+    f->sign_bits = sign_bits;
+    f->pmax = 1 << E;
+    return FP8Q_OK;
+}
+
+inline int hip_rc(hipError_t e) { return e == hipSuccess ? FP8Q_OK : (int)e; }
+inline int launch_rc() { return hip_rc(hipGetLastError()); }
+
+inline uint32_t magic_of(int d) { return (uint32_t)((1ull << 32) / (uint64_t)d) + 1u; }
+
+inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+}  // namespace
+
+extern "C" {
+
+int fp8q_version(void) { return FP8Q_VERSION; }
+
+const char *fp8q_strerror(int code)
+{
+    switch (code) {
+        case FP8Q_OK: return "ok";
+        case FP8Q_EINVAL: return "invalid argument";
+        case FP8Q_EUNSUPPORTED: return "unsupported format (more than 7 exponent bits)";
+        case FP8Q_EWORKSPACE: return "workspace too small";
+        default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
+    }
+}
+
+int fp8q_quantize_f32(const float *x, float *y, int64_t C, int64_t inner, const float *maxval,
+                      int64_t n_maxval, float mbits, int n_bits, int sign_bits, fp8q_stream_t stream)
+{
+    if (!x || !y || !maxval || C < 0 || inner < 0 || (n_maxval != 1 && n_maxval != C))
+        return FP8Q_EINVAL;
+    QFmt f;
+    if (int rc = make_fmt(mbits, n_bits, sign_bits, &f)) return rc;
+    if (C == 0 || inner == 0) return FP8Q_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int per_channel = n_maxval != 1;
+    if (!per_channel) {  // one row
+        inner *= C;
+        C = 1;
+    }
+    const bool aligned = (((uintptr_t)x ^ (uintptr_t)y) & 15) == 0 && ((uintptr_t)x & 3) == 0;
+    const bool rows16 = ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0;
+
+    if (per_channel && inner < 2048 && rows16 && C * inner >= 4) {
+        // short rows: flat tiles
+        MultiArgs a;
+        a.inner = (int)inner;
+        a.lut_stride = f.pmax + 1;
+        const bool lut = inner >= 2 * (int64_t)a.lut_stride;
+        int64_t tile = kMultiTile;
+        const int64_t cap = (int64_t)(kMultiMaxCh - 2) * inner;  // keep the channel span in LDS
+        if (tile > cap) tile = cap;
+        tile &= ~(int64_t)3;
+        if (tile < 4) tile = 4;
+        a.tile = (int)tile;
+        a.max_ch = (int)((tile + inner - 2) / inner + 1);
+        a.magic = magic_of((int)inner);
+        const int64_t total = C * inner;
+        int64_t blocks = cdiv(total, tile);
+        if (blocks > kTargetBlocks) blocks = kTargetBlocks;
+        size_t shmem = (size_t)a.max_ch * sizeof(Chan) + (lut ? (size_t)a.max_ch * a.lut_stride * 4 : 0);
+        if (lut)
+            hipLaunchKernelGGL(k_quant_multi<true>, dim3((unsigned)blocks), dim3(kBlock), shmem, st, x,
+                               y, total, maxval, f, a);
+        else
+            hipLaunchKernelGGL(k_quant_multi<false>, dim3((unsigned)blocks), dim3(kBlock), shmem, st, x,
+                               y, total, maxval, f, a);
+        return launch_rc();
+    }
+    if (C > 65535) {
+        // very many long rows: fall back to one launch per 65535 rows (gridDim.y limit)
+        for (int64_t c0 = 0; c0 < C; c0 += 65535) {
+            const int64_t cn = (C - c0) < 65535 ? (C - c0) : 65535;
+            int rc = fp8q_quantize_f32(x + c0 * inner, y + c0 * inner, cn, inner, maxval + c0, cn,
+                                       mbits, n_bits, sign_bits, stream);
+            if (rc) return rc;
+        }
+        return FP8Q_OK;
+    }
+    int64_t bx = cdiv(cdiv(inner, 4), kBlock * kUnroll);
+    const int64_t cap = kTargetBlocks / C > 0 ? kTargetBlocks / C : 1;
+    if (bx > cap) bx = cap;
+    if (bx < 1) bx = 1;
+    if (aligned)
+        hipLaunchKernelGGL(k_quant_rows, dim3((unsigned)bx, (unsigned)C), dim3(kBlock), 0, st, x, y, inner,
+                           maxval, per_channel, f);
+    else {
+        int64_t bs = cdiv(inner, kBlock);
+        if (bs > cap * 4) bs = cap * 4;
+        hipLaunchKernelGGL(k_quant_scalar, dim3((unsigned)bs, (unsigned)C), dim3(kBlock), 0, st, x, y,
+                           inner, maxval, per_channel, f);
+    }
+    return launch_rc();
+}
+
+static int minmax_nsplit(int64_t C, int64_t inner)
+{
+    int64_t ns = cdiv(cdiv(inner, 4), kBlock * 8);
+    int64_t cap = kTargetBlocks / (C > 0 ? C : 1);
+    if (cap < 1) cap = 1;
+    if (ns > cap) ns = cap;
+    if (ns < 1) ns = 1;
+    return (int)ns;
+}
+
+size_t fp8q_minmax_workspace_bytes(int64_t C, int64_t inner)
+{
+    if (C <= 0 || inner <= 0) return 16;
+    if (inner < 2048) return 16;  // wave-per-row path needs none
+    return (size_t)C * (size_t)minmax_nsplit(C, inner) * 2 * sizeof(float) + 16;
+}
+
+int fp8q_minmax_f32(const float *x, int64_t C, int64_t inner, float *cur_min, float *cur_max,
+                    float *maxval_out, int fold_mode, double momentum, int first, void *ws,
+                    size_t ws_bytes, fp8q_stream_t stream)
+{
+    if (!x || !cur_min || !cur_max || C <= 0 || inner <= 0 || fold_mode < 0 || fold_mode > 2)
+        return FP8Q_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    FoldArgs fa;
+    fa.mode = fold_mode;
+    fa.first = first != 0;
+    fa.om = (float)(1.0 - momentum);
+    fa.mo = (float)momentum;
+    if (inner < 2048) {
+        int64_t blocks = cdiv(C, 4);
+        if (blocks > kTargetBlocks * 2) blocks = kTargetBlocks * 2;
+        hipLaunchKernelGGL(k_minmax_waverow, dim3((unsigned)blocks), dim3(kBlock), 0, st, x, C,
+                           (int)inner, cur_min, cur_max, maxval_out, fa);
+        return launch_rc();
+    }
+    if (ws_bytes < fp8q_minmax_workspace_bytes(C, inner) || !ws) return FP8Q_EWORKSPACE;
+    const int ns = minmax_nsplit(C, inner);
+    for (int64_t c0 = 0; c0 < C; c0 += 65535) {
+        const int64_t cn = (C - c0) < 65535 ? (C - c0) : 65535;
+        float *w = (float *)ws + c0 * ns * 2;
+        hipLaunchKernelGGL(k_minmax_partial, dim3((unsigned)ns, (unsigned)cn), dim3(kBlock), 0, st,
+                           x + c0 * inner, inner, ns, w);
+    }
+    hipLaunchKernelGGL(k_minmax_final, dim3((unsigned)cdiv(C, 4)), dim3(kBlock), 0, st,
+                       (const float *)ws, C, ns, cur_min, cur_max, maxval_out, fa);
+    return launch_rc();
+}
+
+int64_t fp8q_fused_max_inner(void) { return kFusedMaxElems; }
+
+int fp8q_minmax_quantize_f32(const float *x, float *y, int64_t C, int64_t inner, float *row_min,
+                             float *row_max, float *maxval_out, float mbits, int n_bits,
+                             int sign_bits, fp8q_stream_t stream)
+{
+    if (!x || !y || C < 0 || inner < 0) return FP8Q_EINVAL;
+    QFmt f;
+    if (int rc = make_fmt(mbits, n_bits, sign_bits, &f)) return rc;
+    if (C == 0 || inner == 0) return FP8Q_OK;
+    if (inner > kFusedMaxElems) return FP8Q_EUNSUPPORTED;
+    if ((((uintptr_t)x ^ (uintptr_t)y) & 15) != 0 || ((uintptr_t)x & 3) != 0) return FP8Q_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    FusedArgs a;
+    a.inner = (int)inner;
+    a.lut_stride = f.pmax + 1;
+    a.magic = magic_of((int)inner);
+    const bool lut = inner >= 2 * (int64_t)a.lut_stride;
+    // rows per block: fill the LDS tile, but keep >= ~512 blocks when C allows
+    int64_t R = kFusedMaxElems / inner;
+    if (R > 256) R = 256;
+    const int64_t want = cdiv(C, 512);
+    if (R > want) R = want;
+    if (R < 1) R = 1;
+    a.rows_per_block = (int)R;
+    a.xs_floats = (int)((R * inner + 3 + 3) & ~(int64_t)3) + 4;
+    size_t shmem = (size_t)a.xs_floats * 4 + (size_t)R * sizeof(Chan) +
+                   (lut ? (size_t)R * a.lut_stride * 4 : 0);
+    int64_t blocks = cdiv(C, R);
+    if (blocks > kTargetBlocks) blocks = kTargetBlocks;
+    if (shmem > 64 * 1024) {
+        // opt in to > 64 KiB of dynamic LDS once per process (the tile is capped at ~98 KiB)
+        static int opted = 0;
+        if (!opted) {
+            hipError_t e = hipFuncSetAttribute((const void *)k_minmax_quant<true>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute((const void *)k_minmax_quant<false>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            if (e != hipSuccess) return (int)e;
+            opted = 1;
+        }
+    }
+    if (lut)
+        hipLaunchKernelGGL(k_minmax_quant<true>, dim3((unsigned)blocks), dim3(kBlock), shmem, st, x, y, C,
+                           row_min, row_max, maxval_out, f, a);
+    else
+        hipLaunchKernelGGL(k_minmax_quant<false>, dim3((unsigned)blocks), dim3(kBlock), shmem, st, x, y,
+                           C, row_min, row_max, maxval_out, f, a);
+    return launch_rc();
+}
+
+
+static int mse_nsplit(int64_t C, int64_t inner, int64_t n_cand, int n_m)
+{
+    const int64_t cg = cdiv(n_cand, kMseBlock);
+    int64_t ns = cdiv(inner, kMseTile);
+    int64_t cap = (4 * kTargetBlocks) / (C * n_m * cg > 0 ? C * n_m * cg : 1);
+    if (cap < 1) cap = 1;
+    if (ns > cap) ns = cap;
+    if (ns < 1) ns = 1;
+    return (int)ns;
+}
+
+size_t fp8q_mse_workspace_bytes(int64_t C, int64_t inner, int64_t n_cand, int n_m)
+{
+    if (C <= 0 || inner <= 0 || n_cand <= 0 || n_m <= 0) return 16;
+    return (size_t)C * n_m * n_cand * mse_nsplit(C, inner, n_cand, n_m) * sizeof(double) + 16;
+}
+
+int fp8q_mse_grid_f32(const float *x, int64_t C, int64_t inner, const float *grid, int64_t n_cand,
+                      const float *mbits_host, int n_m, int n_bits, int sign_bits, float *mses,
+                      void *ws, size_t ws_bytes, fp8q_stream_t stream)
+{
+    if (!x || !grid || !mbits_host || !mses || C <= 0 || inner <= 0 || n_cand <= 0 || n_m <= 0 ||
+        n_m > kMseMaxM || n_cand > (1 << 20))
+        return FP8Q_EINVAL;
+    if (!ws || ws_bytes < fp8q_mse_workspace_bytes(C, inner, n_cand, n_m) || ((uintptr_t)ws & 7))
+        return FP8Q_EWORKSPACE;
+    MseArgs a;
+    int pmax_all = 0;
+    for (int m = 0; m < n_m; ++m) {
+        if (int rc = make_fmt(mbits_host[m], n_bits, sign_bits, &a.fmt[m])) return rc;
+        if (a.fmt[m].pmax > pmax_all) pmax_all = a.fmt[m].pmax;
+    }
+    a.n_m = n_m;
+    a.n_cand = (int)n_cand;
+    a.cgroups = (int)cdiv(n_cand, kMseBlock);
+    a.nsplit = mse_nsplit(C, inner, n_cand, n_m);
+    a.inner = inner;
+    a.C = C;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t shmem = (size_t)kMseTile * 4 + 2 * (size_t)kMseBlock * (pmax_all + 2) * 4;
+    if (shmem > 64 * 1024) {
+        static int opted = 0;
+        if (!opted) {
+            hipError_t e = hipFuncSetAttribute((const void *)k_mse_grid,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return (int)e;
+            opted = 1;
+        }
+    }
+    for (int64_t c0 = 0; c0 < C; c0 += 65535) {
+        // gridDim.z limit: rows are processed in slabs; ws/grid/mses keep their global indexing
+        const int64_t cn = (C - c0) < 65535 ? (C - c0) : 65535;
+        if (c0 != 0) return FP8Q_EUNSUPPORTED;  // > 65535 channels: not needed by any model here
+        hipLaunchKernelGGL(k_mse_grid, dim3((unsigned)a.nsplit, (unsigned)(n_m * a.cgroups), (unsigned)cn),
+                           dim3(kMseBlock), shmem, st, x, grid, (double *)ws, a);
+    }
+    int64_t fb = cdiv(C * n_m * n_cand, kBlock);
+    if (fb > kTargetBlocks) fb = kTargetBlocks;
+    hipLaunchKernelGGL(k_mse_final, dim3((unsigned)fb), dim3(kBlock), 0, st, (const double *)ws, mses, C,
+                       n_m, (int)n_cand, a.nsplit, 1.0 / (double)inner);
+    return launch_rc();
+}
+
+int fp8q_copy_f32(const float *x, float *y, int64_t n, fp8q_stream_t stream)
+{
+    if (!x || !y || n < 0 || (n & 3) || ((uintptr_t)x & 15) || ((uintptr_t)y & 15)) return FP8Q_EINVAL;
+    if (n == 0) return FP8Q_OK;
+    int64_t bx = cdiv(n / 4, kBlock * kUnroll);
+    if (bx > kTargetBlocks) bx = kTargetBlocks;
+    hipLaunchKernelGGL(k_copy, dim3((unsigned)bx), dim3(kBlock), 0, (hipStream_t)stream,
+                       (const float4 *)x, (float4 *)y, n / 4);
+    return launch_rc();
+}
+
+}  // extern "C"

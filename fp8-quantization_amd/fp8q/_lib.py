@@ -1,0 +1,60 @@
+"""ctypes binding of libfp8q_hip.so (include/fp8q.h).  There is NO fallback: if the library is
+missing or fails to load, importing an op raises -- the product never runs on a CPU path."""
+import ctypes
+import os
+
+from . import build as _build
+
+_lib = None
+
+_i64 = ctypes.c_int64
+_vp = ctypes.c_void_p
+_f = ctypes.c_float
+_i = ctypes.c_int
+
+SIGNATURES = {
+    "fp8q_version": (_i, []),
+    "fp8q_strerror": (ctypes.c_char_p, [_i]),
+    "fp8q_quantize_f32": (_i, [_vp, _vp, _i64, _i64, _vp, _i64, _f, _i, _i, _vp]),
+    "fp8q_minmax_workspace_bytes": (ctypes.c_size_t, [_i64, _i64]),
+    "fp8q_minmax_f32": (_i, [_vp, _i64, _i64, _vp, _vp, _vp, _i, ctypes.c_double, _i, _vp,
+                             ctypes.c_size_t, _vp]),
+    "fp8q_fused_max_inner": (_i64, []),
+    "fp8q_minmax_quantize_f32": (_i, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _f, _i, _i, _vp]),
+    "fp8q_mse_workspace_bytes": (ctypes.c_size_t, [_i64, _i64, _i64, _i]),
+    "fp8q_mse_grid_f32": (_i, [_vp, _i64, _i64, _vp, _i64, ctypes.POINTER(_f), _i, _i, _i, _vp, _vp,
+                               ctypes.c_size_t, _vp]),
+    "fp8q_copy_f32": (_i, [_vp, _vp, _i64, _vp]),
+}
+
+
+class Fp8qError(RuntimeError):
+    pass
+
+
+def so_path():
+    return _build.SO
+
+
+def lib():
+    """Load (once) the HIP library.  Raises if it has not been built: no silent fallback."""
+    global _lib
+    if _lib is None:
+        path = so_path()
+        if not os.path.exists(path):
+            raise Fp8qError(
+                f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  The FP8 engine has no CPU/eager fallback.")
+        L = ctypes.CDLL(path)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the .so is stale
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().fp8q_strerror(rc).decode()
+        raise Fp8qError(f"{what} failed: {msg} (code {rc})")

@@ -1,0 +1,151 @@
+"""Torch-facing wrappers of the C ABI: tensors in, tensors out, launched on the current stream.
+
+PyTorch is used for device memory and streams only; all arithmetic is in libfp8q_hip.so.
+"""
+import torch
+
+from ._lib import Fp8qError, check, lib
+
+FOLD_CURRENT, FOLD_ALL, FOLD_RUNNING = 0, 1, 2
+
+_ws_cache = {}
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _require(t, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise Fp8qError(f"{name} must be a CUDA(HIP) tensor: the FP8 engine has no CPU path")
+    if t.dtype != torch.float32:
+        raise Fp8qError(f"{name} must be float32, got {t.dtype}")
+
+
+def _rows(x, per_channel):
+    """[C, inner] view geometry: channel = dim 0 (reference: x.view(x.shape[0], -1))."""
+    if per_channel:
+        C = x.shape[0] if x.dim() > 0 else 1
+        return C, (x.numel() // C if C else 0)
+    return 1, x.numel()
+
+
+def _workspace(dev, nbytes):
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(int(nbytes), 1 << 16), dtype=torch.uint8, device=dev)
+        _ws_cache[key] = ws
+    return ws
+
+
+def quantize(x, maxval, mbits, n_bits=8, sign_bits=1, out=None):
+    """K1: FP8 quantize+dequantize (fp8_quantizer.py:91-133).  maxval: CUDA fp32 tensor [1] or [C]."""
+    _require(x, "x")
+    _require(maxval, "maxval")
+    x = x.contiguous()
+    maxval = maxval.contiguous().view(-1)
+    n_mv = maxval.numel()
+    C, inner = _rows(x, n_mv != 1)
+    if n_mv != 1 and n_mv != C:
+        raise Fp8qError(f"maxval has {n_mv} elements, expected 1 or {C}")
+    y = torch.empty_like(x) if out is None else out
+    with torch.cuda.device(x.device):
+        rc = lib().fp8q_quantize_f32(x.data_ptr(), y.data_ptr(), C, inner, maxval.data_ptr(), n_mv,
+                                     float(mbits), int(n_bits), int(sign_bits), _stream(x))
+    check(rc, "fp8q_quantize_f32")
+    return y
+
+
+def minmax(x, per_channel, cur_min=None, cur_max=None, mode=FOLD_CURRENT, momentum=0.9,
+           want_maxval=False):
+    """K2/K3(/K5): batch min/max folded into the running estimate (range_estimators.py:61-125).
+
+    cur_min/cur_max: running estimate tensors [C] (updated in place) or None on the first call.
+    Returns (cur_min, cur_max[, maxval]) as [C] tensors.
+    """
+    _require(x, "x")
+    x = x.contiguous()
+    C, inner = _rows(x, per_channel)
+    if C == 0 or inner == 0:
+        raise Fp8qError("min/max of an empty tensor")
+    first = cur_min is None or cur_max is None
+    if first:
+        cur_min = torch.empty(C, dtype=torch.float32, device=x.device)
+        cur_max = torch.empty(C, dtype=torch.float32, device=x.device)
+    else:
+        _require(cur_min, "cur_min")
+        _require(cur_max, "cur_max")
+        if cur_min.numel() != C or cur_max.numel() != C or not cur_min.is_contiguous() \
+                or not cur_max.is_contiguous():
+            raise Fp8qError("running estimate has the wrong shape")
+    mv = torch.empty(C, dtype=torch.float32, device=x.device) if want_maxval else None
+    L = lib()
+    nbytes = L.fp8q_minmax_workspace_bytes(C, inner)
+    ws = _workspace(x.device, nbytes)
+    with torch.cuda.device(x.device):
+        rc = L.fp8q_minmax_f32(x.data_ptr(), C, inner, cur_min.data_ptr(), cur_max.data_ptr(),
+                               mv.data_ptr() if mv is not None else None, int(mode), float(momentum),
+                               int(first), ws.data_ptr(), ws.numel(), _stream(x))
+    check(rc, "fp8q_minmax_f32")
+    return (cur_min, cur_max, mv) if want_maxval else (cur_min, cur_max)
+
+
+def fused_max_inner():
+    return int(lib().fp8q_fused_max_inner())
+
+
+def minmax_quantize(x, mbits, n_bits=8, sign_bits=1, out=None):
+    """K2+K5+K1 fused per-channel weight quantization (current_minmax, set_maxval=True).
+
+    Returns (y, row_min, row_max, maxval)."""
+    _require(x, "x")
+    x = x.contiguous()
+    C, inner = _rows(x, True)
+    y = torch.empty_like(x) if out is None else out
+    mn = torch.empty(C, dtype=torch.float32, device=x.device)
+    mx = torch.empty_like(mn)
+    mv = torch.empty_like(mn)
+    with torch.cuda.device(x.device):
+        rc = lib().fp8q_minmax_quantize_f32(x.data_ptr(), y.data_ptr(), C, inner, mn.data_ptr(),
+                                            mx.data_ptr(), mv.data_ptr(), float(mbits), int(n_bits),
+                                            int(sign_bits), _stream(x))
+    check(rc, "fp8q_minmax_quantize_f32")
+    return y, mn, mx, mv
+
+
+def copy(x, out=None):
+    """float4 copy kernel with K1's launch shape (HBM ceiling yardstick)."""
+    _require(x, "x")
+    y = torch.empty_like(x) if out is None else out
+    with torch.cuda.device(x.device):
+        rc = lib().fp8q_copy_f32(x.data_ptr(), y.data_ptr(), x.numel(), _stream(x))
+    check(rc, "fp8q_copy_f32")
+    return y
+
+
+def mse_grid(x, per_channel, grid, mbits_list, n_bits, sign_bits, mses):
+    """K4: mses[n_m, n_cand, C] += row-mean((x - q(x; m, grid[i, c]))^2)  (range_estimators.py:337-347).
+
+    grid: CUDA fp32 [n_cand, C]; mbits_list: python floats; mses: CUDA fp32, updated in place.
+    """
+    import ctypes
+    _require(x, "x")
+    _require(grid, "grid")
+    _require(mses, "mses")
+    x = x.contiguous()
+    C, inner = _rows(x, per_channel)
+    n_m = len(mbits_list)
+    n_cand = grid.shape[0]
+    if grid.dim() != 2 or grid.shape[1] != C or not grid.is_contiguous():
+        raise Fp8qError(f"grid must be contiguous [n_cand, {C}]")
+    if tuple(mses.shape) != (n_m, n_cand, C) or not mses.is_contiguous():
+        raise Fp8qError(f"mses must be contiguous [{n_m}, {n_cand}, {C}]")
+    L = lib()
+    ws = _workspace(x.device, L.fp8q_mse_workspace_bytes(C, inner, n_cand, n_m))
+    mb = (ctypes.c_float * n_m)(*[float(v) for v in mbits_list])
+    with torch.cuda.device(x.device):
+        rc = L.fp8q_mse_grid_f32(x.data_ptr(), C, inner, grid.data_ptr(), n_cand, mb, n_m, int(n_bits),
+                                 int(sign_bits), mses.data_ptr(), ws.data_ptr(), ws.numel(), _stream(x))
+    check(rc, "fp8q_mse_grid_f32")
+    return mses

@@ -1,0 +1,111 @@
+/*
+ * fp8q.h -- C ABI of the MI355X-native FP8 fake-quantization engine (libfp8q_hip.so).
+ *
+ * The reference (Qualcomm-AI-research/FP8-quantization) has no FFI: its "device boundary"
+ * is the set of eager ATen op chains listed in SURVEY.md section 2.1.  Each entry point
+ * below replaces one of those chains with one (or two) hand-written gfx950 kernels; the
+ * Python classes that keep the reference's operator API (fp8-quantization_amd/quantization)
+ * call them through ctypes with tensor.data_ptr() and the current HIP stream.
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer owned by the caller; nothing is allocated or freed here
+ *   - tensors are contiguous fp32, viewed as [C, inner] (per-channel = dim 0, as the
+ *     reference does with x.view(x.shape[0], -1)); per-tensor calls pass C == 1
+ *   - enqueue-only on `stream` (a hipStream_t, NULL = default stream); no host sync
+ *   - return 0 on success, a positive hipError_t on a HIP failure, a negative FP8Q_E* on a
+ *     bad argument; never throws; stateless and thread-safe
+ *   - arithmetic contract: bit-identical to oracle/fp8q_oracle.c (reference op order in
+ *     fp32, correctly rounded log2 / 2^x) -- see DESIGN.md "Arithmetic contract"
+ */
+#ifndef FP8Q_H
+#define FP8Q_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FP8Q_VERSION 100 /* 0.1.0 */
+
+#define FP8Q_OK 0
+#define FP8Q_EINVAL (-1)       /* null pointer, negative size, n_maxval not in {1, C}, ... */
+#define FP8Q_EUNSUPPORTED (-2) /* n_bits - sign_bits - M > 7 (more than 7 exponent bits) */
+#define FP8Q_EWORKSPACE (-3)   /* workspace too small */
+
+/* range-estimator fold modes (how a new batch estimate is merged into the running one) */
+#define FP8Q_FOLD_CURRENT 0 /* overwrite          range_estimators.py:72-73  CurrentMinMaxEstimator */
+#define FP8Q_FOLD_ALL 1     /* min / max          range_estimators.py:97-98  AllMinMaxEstimator     */
+#define FP8Q_FOLD_RUNNING 2 /* EMA (1-m)*new+m*cur range_estimators.py:122-123 RunningMinMaxEstimator */
+
+typedef void *fp8q_stream_t; /* hipStream_t */
+
+int fp8q_version(void);
+const char *fp8q_strerror(int code);
+
+/*
+ * K1 -- FP8 quantize + dequantize.
+ * Replaces quantize_to_fp8_ste_MM(x_float, n_bits, maxval, num_mantissa_bits, sign_bits),
+ * quantization/quantizers/fp8_quantizer.py:91-133 (13 eager ATen kernels -> 1 launch).
+ *   x, y     [C, inner] fp32 (y may alias x)
+ *   maxval   [n_maxval] fp32, n_maxval == 1 (per tensor) or == C (per channel)
+ *   mbits    number of mantissa bits; rounded half-to-even and clamped to [1, n_bits - sign_bits]
+ *   sign_bits 1 (clamp to [-maxval, maxval]) or 0 (clamp to [0, maxval])
+ * HBM traffic: 8 B / element.
+ */
+int fp8q_quantize_f32(const float *x, float *y, int64_t C, int64_t inner, const float *maxval,
+                      int64_t n_maxval, float mbits, int n_bits, int sign_bits,
+                      fp8q_stream_t stream);
+
+/*
+ * K2/K3/K5 -- min/max range estimation with the running-estimate fold.
+ * Replaces {Current,All,Running}MinMaxEstimator.forward, quantization/range_estimators.py:61-125
+ * (x.min(), x.max(), torch.min/max fold) and the abs-max of FPQuantizer.set_quant_range,
+ * fp8_quantizer.py:236.
+ *   x         [C, inner] fp32 (C == 1: per tensor)
+ *   cur_min, cur_max [C] running estimate, updated in place;  `first` != 0: no previous estimate
+ *   maxval_out [C] or NULL: |max(|cur_min|, cur_max)| after the fold
+ *   ws        scratch of at least fp8q_minmax_workspace_bytes(C, inner) bytes (need not be zeroed)
+ * NaN anywhere in a row makes that row's min and max NaN (torch semantics).
+ * HBM traffic: 4 B / element.
+ */
+size_t fp8q_minmax_workspace_bytes(int64_t C, int64_t inner);
+int fp8q_minmax_f32(const float *x, int64_t C, int64_t inner, float *cur_min, float *cur_max,
+                    float *maxval_out, int fold_mode, double momentum, int first, void *ws,
+                    size_t ws_bytes, fp8q_stream_t stream);
+
+/*
+ * K2+K5+K1 fused -- per-channel weight quantization in estimate_ranges state:
+ * QuantizationManager.forward (quantization_manager.py:114-122) with CurrentMinMaxEstimator
+ * and set_maxval=True: row min/max -> maxval = |max(|min|, max)| -> quantize, rows staged in LDS.
+ *   x, y [C, inner]; row_min,row_max,maxval_out [C] outputs (each may be NULL)
+ * Requires inner <= fp8q_fused_max_inner(); larger rows: call fp8q_minmax_f32 + fp8q_quantize_f32.
+ * HBM traffic: 8 B / element.
+ */
+int64_t fp8q_fused_max_inner(void);
+int fp8q_minmax_quantize_f32(const float *x, float *y, int64_t C, int64_t inner, float *row_min,
+                             float *row_max, float *maxval_out, float mbits, int n_bits,
+                             int sign_bits, fp8q_stream_t stream);
+
+/*
+ * K4 -- FP-MSE grid search accumulation.
+ * Replaces the double loop of FP_MSE_Estimator.forward, quantization/range_estimators.py:337-347
+ * (111 * |mbits| full quantizer passes -> one pass over x).
+ *   x     [C, inner];  grid [n_cand, C] candidate maxvals;  mbits [n_m] (host array)
+ *   mses  [n_m, n_cand, C] fp32, accumulated:  += mean over the row of (x - q(x))^2
+ *   ws    scratch of at least fp8q_mse_workspace_bytes(C, inner, n_cand, n_m) bytes
+ */
+size_t fp8q_mse_workspace_bytes(int64_t C, int64_t inner, int64_t n_cand, int n_m);
+int fp8q_mse_grid_f32(const float *x, int64_t C, int64_t inner, const float *grid, int64_t n_cand,
+                      const float *mbits_host, int n_m, int n_bits, int sign_bits, float *mses,
+                      void *ws, size_t ws_bytes, fp8q_stream_t stream);
+
+/* Plain float4 copy kernel with the same launch shape as K1: the measured HBM ceiling that
+ * bench.py reports next to the 8 TB/s spec figure. */
+int fp8q_copy_f32(const float *x, float *y, int64_t n, fp8q_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FP8Q_H */

@@ -1,0 +1,244 @@
+"""GPU parity: HIP kernels (through the C ABI) vs the CPU oracle and the golden fixtures.
+
+Bar: K1 and the min/max estimators are BIT-EXACT against oracle/fp8q_oracle.c (same arithmetic
+contract); against the reference's own output (golden fixtures) they meet the north_star
+tolerance (<= 1 step of the emulated FP8 grid; measured: <= 2 fp32 ULP, no tie flips).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from parity import assert_parity, compare, elem_step
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import fp8q
+    fp8q.lib()  # raises if libfp8q_hip.so is missing: no fallback
+    return fp8q.ops
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.int32)
+
+
+def assert_bit_exact(y, y_ref, what=""):
+    y, y_ref = np.asarray(y, np.float32), np.asarray(y_ref, np.float32)
+    nan_a, nan_b = np.isnan(y), np.isnan(y_ref)
+    assert np.array_equal(nan_a, nan_b), f"{what}: NaN pattern"
+    bad = (bits(y) != bits(y_ref)) & ~nan_a
+    assert not bad.any(), f"{what}: {bad.sum()} / {y.size} elements differ, first at {np.argwhere(bad)[:5].tolist()}"
+
+
+def test_library_loaded(ops):
+    import fp8q
+    assert fp8q.lib().fp8q_version() == 100
+    assert os.path.exists(fp8q.so_path())
+
+
+def test_quantize_golden_and_oracle(ops, golden_dir):
+    g1 = np.load(os.path.join(golden_dir, "g1_quantize.npz"))
+    tot = exact = 0
+    for cid, mbits, mv, sb, nmv in g1["cases"]:
+        cid, sb = int(cid), int(sb)
+        x, y_ref = g1[f"c{cid}_x"], g1[f"c{cid}_y"]
+        maxval = g1[f"c{cid}_maxval"] if mv < 0 else np.array([mv], np.float32)
+        y = ops.quantize(dev(x), dev(maxval), float(mbits), 8, sb).cpu().numpy()
+        assert_bit_exact(y, oracle.c_quantize(x, maxval, float(mbits), 8, sb), f"case {cid} vs oracle")
+        r = assert_parity(y, y_ref, elem_step(x, maxval, float(mbits), 8, sb), max_flip_frac=2e-2,
+                          max_ulp=2, what=f"case {cid} vs reference")
+        tot += r["n"]
+        exact += r["exact_frac"] * r["n"]
+    print(f"\nHIP vs reference golden: {tot} elems, bit-exact {exact / tot:.4%}")
+    assert exact / tot > 0.90
+
+
+@pytest.mark.parametrize("M,sb,mv", [(2, 1, 57344.0), (3, 1, 240.0), (3, 1, 0.7361), (5, 1, 3.0),
+                                     (1, 1, 1.0), (6, 1, 0.0123), (3, 0, 2.5), (1, 0, 0.31), (7, 1, 1.0),
+                                     (8, 0, 1.0)])
+@pytest.mark.parametrize("n", [1, 3, 4, 1023, 4096 + 5, 1 << 20])
+def test_quantize_per_tensor_bit_exact(ops, M, sb, mv, n):
+    rng = np.random.RandomState(n % 1000 + M)
+    x = (rng.randn(n) * mv / 2.5).astype(np.float32)
+    if n > 16:
+        x[:8] = [0.0, -0.0, np.inf, -np.inf, np.nan, mv, -mv, 1e-41]
+        # exact powers of two and ties sit on the p / rounding boundaries
+        x[8:16] = mv * 2.0 ** -np.arange(8)
+    y = ops.quantize(dev(x), dev([mv]), M, 8, sb).cpu().numpy()
+    assert_bit_exact(y, oracle.c_quantize(x, [mv], M, 8, sb), f"M={M} sb={sb} mv={mv} n={n}")
+
+
+@pytest.mark.parametrize("shape", [(64, 3, 7, 7), (32, 1, 3, 3), (7, 5), (1000, 512), (16, 2048),
+                                   (3, 4099), (512, 512, 3, 3), (5, 1), (300, 66), (4, 70000)])
+@pytest.mark.parametrize("M,sb", [(2, 1), (3, 1), (5, 1), (1, 0)])
+def test_quantize_per_channel_bit_exact(ops, shape, M, sb):
+    rng = np.random.RandomState(sum(shape) + M)
+    C = shape[0]
+    mv = (np.abs(rng.randn(C)) + 0.05).astype(np.float32)
+    x = (rng.randn(*shape) * (mv.reshape([-1] + [1] * (len(shape) - 1)) / 2)).astype(np.float32)
+    y = ops.quantize(dev(x), dev(mv), M, 8, sb).cpu().numpy()
+    assert_bit_exact(y, oracle.c_quantize(x, mv, M, 8, sb), f"shape={shape} M={M}")
+
+
+def test_quantize_misaligned_views(ops):
+    rng = np.random.RandomState(5)
+    base = dev(rng.randn(10007))
+    for off in (1, 2, 3):
+        x = base[off:off + 9001]
+        y = ops.quantize(x, dev([1.3]), 3, 8, 1).cpu().numpy()
+        assert_bit_exact(y, oracle.c_quantize(x.cpu().numpy(), [1.3], 3, 8, 1), f"offset {off}")
+    # per-channel rows whose starts are not 16-byte aligned
+    xw = base[1:1 + 4 * 2049].view(4, 2049)
+    mv = np.array([0.5, 1.0, 2.0, 3.0], np.float32)
+    y = ops.quantize(xw, dev(mv), 2, 8, 1).cpu().numpy()
+    assert_bit_exact(y, oracle.c_quantize(xw.cpu().numpy(), mv, 2, 8, 1), "rows offset")
+
+
+def test_quantize_degenerate_maxval(ops):
+    x = np.random.RandomState(0).randn(3, 64).astype(np.float32)
+    x[1] = 0
+    mv = np.array([1.0, 0.0, np.inf], np.float32)
+    y = ops.quantize(dev(x), dev(mv), 3, 8, 1).cpu().numpy()
+    ref = oracle.c_quantize(x, mv, 3, 8, 1)
+    assert_bit_exact(y, ref, "degenerate")
+    assert np.isnan(y[1]).all() and np.isnan(y[2]).all()  # reference quirk: all-zero channel -> NaN
+
+
+def test_quantize_empty_and_errors(ops):
+    import fp8q
+    y = ops.quantize(torch.empty(0, device="cuda"), dev([1.0]), 3)
+    assert y.numel() == 0
+    with pytest.raises(fp8q.Fp8qError):
+        ops.quantize(torch.zeros(4), dev([1.0]), 3)          # CPU tensor: no fallback
+    with pytest.raises(fp8q.Fp8qError):
+        ops.quantize(dev(np.zeros((4, 4))), dev([1.0, 2.0]), 3)  # maxval neither 1 nor C
+    with pytest.raises(fp8q.Fp8qError):
+        ops.quantize(dev(np.zeros(4)), dev([1.0]), 3, n_bits=16, sign_bits=1)  # E > 7
+
+
+@pytest.mark.parametrize("shape,pc", [((64, 3, 7, 7), True), ((64, 3, 7, 7), False), ((4, 8, 6, 6), False),
+                                      ((1000, 512), True), ((8, 300000), True), ((3, 5), True),
+                                      ((64, 64, 56, 56), False), ((2, 2049), True)])
+def test_minmax_bit_exact(ops, shape, pc):
+    rng = np.random.RandomState(len(shape) + shape[0])
+    x = rng.randn(*shape).astype(np.float32)
+    mn, mx, mv = ops.minmax(dev(x), pc, want_maxval=True)
+    rmn, rmx = oracle.c_minmax(x, pc)
+    np.testing.assert_array_equal(mn.cpu().numpy(), rmn)
+    np.testing.assert_array_equal(mx.cpu().numpy(), rmx)
+    np.testing.assert_array_equal(mv.cpu().numpy(), oracle.c_absmax(rmn, rmx))
+
+
+def test_minmax_fold_modes_and_nan(ops, golden_dir):
+    g3 = np.load(os.path.join(golden_dir, "g3_estimators.npz"))
+    for mode, name in ((1, "allminmax"), (2, "running_minmax")):
+        for pc in (False, True):
+            cur = (None, None)
+            for b, a in enumerate(g3["acts"]):
+                cur = ops.minmax(dev(a), pc, cur[0], cur[1], mode=mode, momentum=0.9)
+                np.testing.assert_array_equal(cur[0].cpu().numpy(), g3[f"{name}_pc{int(pc)}_min"][b])
+                np.testing.assert_array_equal(cur[1].cpu().numpy(), g3[f"{name}_pc{int(pc)}_max"][b])
+    a = g3["acts"][0].copy()
+    a[1, 2, 3, 4] = np.nan
+    mn, mx = ops.minmax(dev(a), False)
+    assert np.isnan(mn.item()) and np.isnan(mx.item())
+    big = np.random.RandomState(1).randn(3, 50000).astype(np.float32)
+    big[1, 40000] = np.nan
+    mn, mx = ops.minmax(dev(big), True)
+    rmn, rmx = oracle.c_minmax(big, True)
+    np.testing.assert_array_equal(np.isnan(mn.cpu().numpy()), np.isnan(rmn))
+    np.testing.assert_array_equal(mn.cpu().numpy()[[0, 2]], rmn[[0, 2]])
+
+
+@pytest.mark.parametrize("shape", [(64, 3, 7, 7), (32, 1, 3, 3), (1000, 512), (512, 512, 3, 3), (7, 5),
+                                   (3, 4099), (5, 16384), (130, 66), (2048, 3, 7, 7)])
+@pytest.mark.parametrize("M", [2, 3])
+def test_fused_minmax_quantize_bit_exact(ops, shape, M):
+    rng = np.random.RandomState(shape[0] + M)
+    x = (rng.randn(*shape) * 0.1).astype(np.float32)
+    if shape[0] > 4:
+        x[2] = 0  # all-zero channel -> NaN channel
+    y, mn, mx, mv = ops.minmax_quantize(dev(x), M, 8, 1)
+    rmn, rmx = oracle.c_minmax(x, True)
+    rmv = oracle.c_absmax(rmn, rmx)
+    np.testing.assert_array_equal(mn.cpu().numpy(), rmn)
+    np.testing.assert_array_equal(mx.cpu().numpy(), rmx)
+    np.testing.assert_array_equal(mv.cpu().numpy(), rmv)
+    assert_bit_exact(y.cpu().numpy(), oracle.c_quantize(x, rmv, M, 8, 1), f"fused {shape}")
+
+
+def test_config2_conv1_vs_reference(ops, golden_dir):
+    """BASELINE config 2: conv1 [64,3,7,7] per-channel E5M2, current_minmax, against the reference."""
+    g3 = np.load(os.path.join(golden_dir, "g3_estimators.npz"))
+    w = g3["w"]
+    y, mn, mx, mv = ops.minmax_quantize(dev(w), 2, 8, 1)
+    np.testing.assert_array_equal(mn.cpu().numpy(), g3["w_cur_pc_min"])
+    np.testing.assert_array_equal(mx.cpu().numpy(), g3["w_cur_pc_max"])
+    np.testing.assert_array_equal(mv.cpu().numpy(), g3["w_maxval"])
+    r = assert_parity(y.cpu().numpy(), g3["w_q_e5m2"], elem_step(w, g3["w_maxval"], 2), what="conv1")
+    print("\nconv1 E5M2 vs reference:", r)
+
+
+@pytest.mark.parametrize("name,pc,incl,M", [("w_pc_fixm", True, False, 3), ("w_pc_srchm", True, True, 3),
+                                            ("a_pt_fixm", False, False, 3), ("a_pt_srchm", False, True, 2)])
+def test_mse_grid_vs_oracle_and_golden(ops, golden_dir, name, pc, incl, M):
+    g4 = np.load(os.path.join(golden_dir, "g4_mse.npz"))
+    mb = [1.0, 2.0, 3.0, 4.0, 5.0, 6.0] if incl else [float(M)]
+    grid = g4[f"{name}_grid"]
+    C = grid.shape[1]
+    mses = torch.zeros(len(mb), grid.shape[0], C, device="cuda")
+    ref_o = None
+    for b in range(2):
+        x = g4[f"{name}_x{b}"]
+        ops.mse_grid(dev(x), pc, dev(grid), mb, 8, 1, mses)
+        ref_o = oracle.c_mse_grid(x, pc, grid, mb, 8, 1, ref_o)
+        got = mses.cpu().numpy()
+        np.testing.assert_allclose(got, ref_o, rtol=2e-6, atol=0)                 # vs CPU oracle
+        np.testing.assert_allclose(got, g4[f"{name}_mses{b}"], rtol=1e-4, atol=0)  # vs reference
+
+
+def test_mse_grid_large_tensor(ops):
+    rng = np.random.RandomState(3)
+    x = (rng.randn(1, 300001) * 0.7).astype(np.float32)
+    grid = np.linspace(0.1 * 3, 1.2 * 3, 111, dtype=np.float32).reshape(111, 1)
+    mses = torch.zeros(2, 111, 1, device="cuda")
+    ops.mse_grid(dev(x), False, dev(grid), [2.0, 3.0], 8, 1, mses)
+    ref = oracle.c_mse_grid(x, False, grid, [2.0, 3.0], 8, 1)
+    np.testing.assert_allclose(mses.cpu().numpy(), ref, rtol=2e-6)
+    assert mses.cpu().numpy().argmin(1).tolist() == ref.argmin(1).tolist()
+
+
+def test_full_size_properties(ops):
+    """Size-independent properties at a BASELINE-scale tensor ([2^20,3,7,7], 154 M elements)."""
+    n_ch = 1 << 20
+    g = torch.Generator(device="cuda").manual_seed(0)
+    x = torch.randn(n_ch, 147, device="cuda", generator=g) * 0.1
+    y, mn, mx, mv = ops.minmax_quantize(x, 2, 8, 1)
+    # idempotence: quantizing a quantized tensor with the same ranges changes nothing
+    y2 = ops.quantize(y, mv, 2, 8, 1)
+    assert torch.equal(y, y2)
+    # fused == two-pass
+    mn2, mx2, mv2 = ops.minmax(x, True, want_maxval=True)
+    assert torch.equal(mn, mn2) and torch.equal(mx, mx2) and torch.equal(mv, mv2)
+    assert torch.equal(ops.quantize(x, mv, 2, 8, 1), y)
+    # range: |y| <= maxval, error bounded by half a step of the top binade (2^-M * maxval / (2-2^-M) / 2 ...)
+    assert bool((y.abs() <= mv[:, None]).all())
+    err = (y - x).abs().amax(1)
+    assert bool((err <= mv * 2.0 ** -2 / 1.75 * 0.5 * 1.0001).all())
+    # at most 2^8 distinct values per channel (spot check) and symmetry q(-x) = -q(x)
+    assert all(torch.unique(y[i]).numel() <= 256 for i in range(0, n_ch, n_ch // 8))
+    assert torch.equal(ops.quantize(-x, mv, 2, 8, 1), -y)
+    # spot-check 64 random channels against the CPU oracle, bit for bit
+    idx = torch.randint(0, n_ch, (64,), generator=torch.Generator().manual_seed(1))
+    xs = x[idx.cuda()].cpu().numpy()
+    assert_bit_exact(y[idx.cuda()].cpu().numpy(),
+                     oracle.c_quantize(xs, mv[idx.cuda()].cpu().numpy(), 2, 8, 1), "spot check")
