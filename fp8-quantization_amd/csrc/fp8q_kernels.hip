@@ -111,6 +111,11 @@ struct MultiArgs {
     uint32_t magic;     // floor(2^32 / inner) + 1: n / inner == umulhi(n, magic) for n*inner < 2^32
 };
 
+__device__ __forceinline__ int div_small(uint32_t n, uint32_t magic)
+{
+    return magic == 0u ? (int)n : (int)__umulhi(n, magic);   // magic == 0 encodes inner == 1
+}
+
 template <bool LUT>
 __device__ __forceinline__ float quant_multi_elem(float x, const Chan *chans, const float *lut,
                                                   int ch, const QFmt &f, int lut_stride)
@@ -159,7 +164,7 @@ k_quant_multi(const float *__restrict__ x, float *__restrict__ y, int64_t total,
         float *yt = y + t0;
         for (int o = tid * 4; o < n; o += kBlock * 4) {
             const uint32_t n0 = (uint32_t)(o + rem0);
-            int ch = (int)__umulhi(n0, a.magic);
+            int ch = div_small(n0, a.magic);
             int r = (int)n0 - ch * a.inner;
             if (o + 4 <= n) {
                 float4 v = ldg4(reinterpret_cast<const float4 *>(xt + o));
@@ -413,11 +418,12 @@ k_minmax_quant(const float *__restrict__ x, float *__restrict__ y, int64_t C, fl
         __syncthreads();
         // ---- quantize out of LDS, write coalesced
         if (tid < head) {
-            yt[tid] = quant_multi_elem<LUT>(xs[pad + tid], chans, lut, 0, f, a.lut_stride);
+            const int ch = div_small((uint32_t)tid, a.magic);   // short rows: the head can span rows
+            yt[tid] = quant_multi_elem<LUT>(xs[pad + tid], chans, lut, ch, f, a.lut_stride);
         }
         if (tail0 + tid < n) {
             const int i = tail0 + tid;
-            const int ch = (int)__umulhi((uint32_t)i, a.magic);
+            const int ch = div_small((uint32_t)i, a.magic);
             yt[i] = quant_multi_elem<LUT>(xs[pad + i], chans, lut, ch, f, a.lut_stride);
         }
         {
@@ -425,7 +431,7 @@ k_minmax_quant(const float *__restrict__ x, float *__restrict__ y, int64_t C, fl
             float4 *yv = reinterpret_cast<float4 *>(yt + head);
             for (int i = tid; i < nvec; i += kBlock) {
                 const uint32_t n0 = (uint32_t)(head + i * 4);
-                int ch = (int)__umulhi(n0, a.magic);
+                int ch = div_small(n0, a.magic);
                 int r = (int)n0 - ch * a.inner;
                 const float4 v = sv[i];
                 float e[4] = {v.x, v.y, v.z, v.w};
@@ -593,7 +599,8 @@ int make_fmt(float mbits, int n_bits, int sign_bits, QFmt *f)
 inline int hip_rc(hipError_t e) { return e == hipSuccess ? FP8Q_OK : (int)e; }
 inline int launch_rc() { return hip_rc(hipGetLastError()); }
 
-inline uint32_t magic_of(int d) { return (uint32_t)((1ull << 32) / (uint64_t)d) + 1u; }
+// n / d == umulhi(n, magic) for n * d < 2^32; d == 1 is handled by div_small()
+inline uint32_t magic_of(int d) { return d <= 1 ? 0u : (uint32_t)((1ull << 32) / (uint64_t)d) + 1u; }
 
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

@@ -46,8 +46,8 @@ def main():
     report("K3 minmax per-tensor 1GiB", n, 4, timeit(lambda: ops.minmax(x, False)))
     # conv1-shaped synthetic [N,3,7,7]
     N = 1 << 21
-    xw = x[: N * 147].view(N, 3, 7, 7)
-    yw = y[: N * 147].view(N, 3, 7, 7)
+    xw = (torch.randn(N * 147, device=dev) * 0.1).view(N, 3, 7, 7)
+    yw = torch.empty_like(xw)
     mn, mx, mvw = ops.minmax(xw, True, want_maxval=True)
     report("K1 per-channel [2^21,3,7,7] E5M2 (multi, LUT)", N * 147, 8,
            timeit(lambda: ops.quantize(xw, mvw, 2, 8, 1, out=yw)))
