@@ -3,43 +3,49 @@
 // Arithmetic contract (identical, bit for bit, to oracle/fp8q_oracle.c):
 //   the reference's fp32 op chain quantize_to_fp8_ste_MM
 //   (/root/reference/quantization/quantizers/fp8_quantizer.py:105-133) with log2 and 2^x
-//   defined as correctly rounded fp32 functions.
+//   defined as correctly rounded fp32 functions:
+//       xc = min(max(x, lo), maxval)
+//       p  = max(floor(fl32(log2(|xc|) + bias)), 1)
+//       s  = 2^fl32((p - M) - bias)
+//       y  = rint(xc / s) * s            (IEEE division, round half to even)
 //
-// How each step is made exact AND cheap on CDNA4:
-//   p = floor(log2|xc| + bias)   v_log_f32 (1 ulp) decides p unless the sum lands within
-//                                2^-13 of an integer (or |xc| is denormal): those rare lanes
-//                                (~2.4e-4) re-evaluate with a double-precision log2.
-//   s = 2^fl32((p - M) - bias)   only (channel, p) matter, p <= 2^E <= 128:
-//                                  * LUT kernels: one table per channel in LDS, built once per
-//                                    block with scale_exact(); 1 ds_read per element.
-//                                  * direct kernels: scale_exact() per element.
-//                                scale_exact() never calls exp2 per element: with bias = bi + bf,
-//                                2^e = 2^(k-bi) * g * 2^delta, g = 2^-bf (per channel, double),
-//                                delta = fl32(k - bias) - (k - bias) (exact in double, |delta| <=
-//                                2^-17) and 2^delta = 1 + u + u^2/2, u = delta*ln2 (error < 3e-17).
-//   y = rint(xc / s) * s         IEEE fp32 division (hipcc default: correctly rounded), v_rndne.
+// How each step is exact AND cheap on CDNA4 (~17 VALU ops per element on the fast path):
+//   p  v_log_f32 (1 ulp) decides p unless the fp32 sum lands within 2^-15 of an integer; only
+//      those lanes (~6e-5 of elements) re-evaluate with a double-precision log2.
+//   s  depends on (channel, p) only and p <= 2^E <= 128: a per-channel table {s, 1/s} in LDS,
+//      built once per block by scale_exact(); one ds_read_b64 per element.  scale_exact() needs
+//      no exp2 per entry: with bias = bi + bf, 2^e = 2^(k-bi) * g * 2^delta, g = 2^-bf (one
+//      double exp2 per channel), delta = fl32(k - bias) - (k - bias) (exact in double,
+//      |delta| <= 2^-17) and 2^delta = 1 + u + u^2/2, u = delta ln 2 (error < 3e-17).
+//   y  q0 = xc * (1/s) differs from fl32(xc / s) by < 3 * 2^-24 * q <= 2^(M-22); rint(q0) is
+//      therefore rint(xc / s) unless q0 is within 2^(M-21) of a rounding tie; only those lanes
+//      (~1e-5) redo the IEEE division.
+//   Channels whose bias is outside (-100, 100) (maxval below 1e-28 or non-finite, ...) take the
+//   exact path for every element (Chan::pthr = -1), so no range assumption leaks into results.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace fp8q {
 
+typedef float vf4 __attribute__((ext_vector_type(4)));
+
 constexpr int kBlock = 256;
-constexpr int kLutMax = 132;                  // 2^7 + 1 entries, padded
-constexpr float kNearEps = 1.220703125e-4f;   // 2^-13, see p_of()
+constexpr int kLutMax = 130;   // 2^7 + 1 entries (+1 pad)
 
 // host-computed format constants (kernel argument, by value)
 struct QFmt {
     float M;        // clamp(rint(mbits), 1, n_bits - sign_bits)      fp8_quantizer.py:105
     float two_E;    // 2^E, E = n_bits - sign_bits - M                 :106
     float l_c;      // fl32(log2(2 - 2^-M))                            :110
+    float qthr;     // 0.5 - 2^(M-21): |q0 - rint(q0)| above this -> redo the division exactly
     int sign_bits;  // 1: clamp lo = -maxval, 0: clamp lo = 0          :112
-    int pmax;       // 2^E: largest value p can take (LUT has pmax+1 entries)
+    int pmax;       // 2^E: largest value p can take (tables have pmax+1 entries)
 };
 
 struct __attribute__((aligned(16))) Chan {
     float maxv, minv, bias;
-    int bi;          // floor(bias)
+    float pthr;      // 0.5 - 2^-15, or -1: every element takes the exact path
     double g;        // 2^-(bias - floor(bias))  in (0.5, 1]
     double bias_d;   // (double)bias
 };
@@ -55,9 +61,9 @@ __device__ __forceinline__ Chan make_chan(float maxv, const QFmt &f)
     b = b + f.l_c;                                  // every step rounded to fp32
     b = b - 1.0f;
     c.bias = b;
-    const float fb = floorf(b);
-    c.bi = (int)fminf(fmaxf(fb, -16384.0f), 16384.0f);  // non-finite bias: g is NaN anyway
-    c.g = exp2(-(double)(b - fb));                  // b - fb is exact in fp32
+    // fast-path preconditions: every scale and its reciprocal are normal fp32 numbers
+    c.pthr = (b > -100.0f && b < 100.0f && maxv < 0x1p120f) ? (0.5f - 0x1p-15f) : -1.0f;
+    c.g = exp2(-(double)(b - floorf(b)));           // b - floor(b) is exact in fp32
     c.bias_d = (double)b;
     return c;
 }
@@ -72,56 +78,128 @@ __device__ __forceinline__ float scale_exact(const Chan &c, float ls, float M)
     const double u = delta * 0.69314718055994530942;
     const double t = fma(u, 0.5 * u, u);            // 2^delta - 1
     const double s = fma(c.g, t, c.g);              // g * 2^delta
-    const int n = (int)k - c.bi;
+    const float fb = floorf(c.bias);
+    const int n = (int)k - (int)fminf(fmaxf(fb, -16384.0f), 16384.0f);  // non-finite bias: s is NaN
     return (float)ldexp(s, n);                      // one rounding to fp32 (denormals included)
 }
 
-__device__ __forceinline__ float p_exact(float a, float bias)
+// {s, 1/s} table entry for p (entry 0 is never selected by a finite p; it holds NaN)
+__device__ __forceinline__ float2 lut_entry(const Chan &c, int p, float M)
 {
-    return floorf((float)log2((double)a) + bias);
+    if (p == 0) return make_float2(__builtin_nanf(""), __builtin_nanf(""));
+    const float s = scale_exact(c, (float)p, M);
+    return make_float2(s, 1.0f / s);
 }
 
-// floor(fl32(log2_cr(a) + bias)) for a = |xc| >= 0.
-// v_log_f32 is accurate to 1 ulp and |log2 a|, |bias| < 512, so the fast sum differs from the
-// exact one by < 6e-5: the floors can only disagree if the fast sum is within 2^-13 of an integer.
-__device__ __forceinline__ float p_of(float a, float bias)
+// the three per-element channel constants the table kernels need
+struct ChanLite {
+    float maxv, minv, bias, pthr;
+};
+
+__device__ __forceinline__ ChanLite lite(const Chan &c)
 {
-    const float v = __builtin_amdgcn_logf(a) + bias;
-    float fl = floorf(v);
+    ChanLite l;
+    l.maxv = c.maxv;
+    l.minv = c.minv;
+    l.bias = c.bias;
+    l.pthr = c.pthr;
+    return l;
+}
+
+// exact path of one element (rare lanes only)
+__device__ __noinline__ float quant_exact(float x, float maxv, float minv, float bias,
+                                          const float2 *lut, float pmaxf)
+{
+    if (x != x) return x;
+    const float xc = __builtin_amdgcn_fmed3f(x, minv, maxv);
+    float ls = floorf((float)log2((double)fabsf(xc)) + bias);
+    ls = __builtin_amdgcn_fmed3f(ls, 1.0f, pmaxf);   // NaN -> 1 (then every table entry is NaN)
+    const float s = lut[(int)ls].x;
+    return rintf(xc / s) * s;
+}
+
+// Fast path of one element; sets `risky` when the exact path must redo it.
+// class mask 0x93: sNaN | qNaN | -denormal | +denormal (v_log_f32 flushes denormals; a denormal
+// xc can only come from a denormal x unless maxval itself is denormal, and then pthr == -1).
+__device__ __forceinline__ float quant_fast(float x, const ChanLite &c, const float2 *lut, float pmaxf,
+                                            float qthr, bool &risky)
+{
+    const float xc = __builtin_amdgcn_fmed3f(x, c.minv, c.maxv);
+    const float v = __builtin_amdgcn_logf(fabsf(xc)) + c.bias;
+    const float fl = floorf(v);
     const float fr = v - fl;
-    // class mask 0x90 = +/- denormal (v_log_f32 flushes denormal inputs)
-    const bool risky = (fabsf(fr - 0.5f) > (0.5f - kNearEps)) | __builtin_amdgcn_classf(a, 0x90);
-    if (__builtin_expect(risky, 0)) fl = p_exact(a, bias);
-    return fl;   // NaN if a is NaN or (-inf + inf); -inf for a == 0
+    const float ls = __builtin_amdgcn_fmed3f(fl, 1.0f, pmaxf);
+    const float2 t = lut[(int)ls];
+    const float q0 = xc * t.y;
+    const float r = rintf(q0);
+    // (x == 0: v = -inf, fr = NaN, the comparison is false and p = 1 is already exact)
+    risky = __builtin_amdgcn_classf(x, 0x93) | (fabsf(fr - 0.5f) > c.pthr) | (fabsf(q0 - r) > qthr) |
+            (c.pthr < 0.0f);
+    return r * t.x;
 }
 
-// NaN-propagating clamp: torch.min(torch.max(x, lo), hi).  x == NaN is patched by the caller's
-// final select; v_max_f32(-0, +0) = +0 and v_min_f32(-0, +0) = -0 match ATen's CPU kernels.
-__device__ __forceinline__ float clamp_ref(float x, const Chan &c)
+// N elements of one channel, in place: one branch for the whole group
+template <int N>
+__device__ __forceinline__ void quant_group(float (&v)[N], const ChanLite &c, const float2 *lut,
+                                            float pmaxf, float qthr)
 {
-    return fminf(fmaxf(x, c.minv), c.maxv);
+    float y[N];
+    bool rk[N];
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        y[j] = quant_fast(v[j], c, lut, pmaxf, qthr, rk[j]);
+        any |= rk[j];
+    }
+    if (__builtin_expect(any, 0)) {
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+            if (rk[j]) y[j] = quant_exact(v[j], c.maxv, c.minv, c.bias, lut, pmaxf);
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j) v[j] = y[j];
 }
 
-// one element, scale from a per-channel LUT in LDS (lut[0] unused, lut[1..pmax])
-__device__ __forceinline__ float quant_lut(float x, const Chan &c, const float *lut, float pmaxf)
+// one element whose channel varies per element (short-row kernels)
+__device__ __forceinline__ float quant_one(float x, const ChanLite &c, const float2 *lut, float pmaxf,
+                                           float qthr)
 {
-    const float xc = clamp_ref(x, c);
-    float ls = p_of(fabsf(xc), c.bias);
-    ls = fminf(fmaxf(ls, 1.0f), pmaxf);             // clamp(min=1); NaN -> 1 (x NaN patched below,
-    const float s = lut[(int)ls];                   // degenerate maxval makes every LUT entry NaN)
-    const float y = rintf(xc / s) * s;
-    return (x != x) ? x : y;
+    bool risky;
+    float y = quant_fast(x, c, lut, pmaxf, qthr, risky);
+    if (__builtin_expect(risky, 0)) y = quant_exact(x, c.maxv, c.minv, c.bias, lut, pmaxf);
+    return y;
 }
 
-// one element, scale computed directly
+// one element, no table (rows too short to amortise one): exact scale computed directly
 __device__ __forceinline__ float quant_direct(float x, const Chan &c, float M)
 {
-    const float xc = clamp_ref(x, c);
-    float ls = p_of(fabsf(xc), c.bias);
-    ls = fmaxf(ls, 1.0f);
+    const float xc = __builtin_amdgcn_fmed3f(x, c.minv, c.maxv);
+    const float a = fabsf(xc);
+    const float v = __builtin_amdgcn_logf(a) + c.bias;
+    float fl = floorf(v);
+    const float fr = v - fl;
+    const bool risky = __builtin_amdgcn_classf(x, 0x90) | (fabsf(fr - 0.5f) > c.pthr) | (c.pthr < 0.0f);
+    if (__builtin_expect(risky, 0)) fl = floorf((float)log2((double)a) + c.bias);
+    const float ls = fmaxf(fl, 1.0f);
     const float s = scale_exact(c, ls, M);
     const float y = rintf(xc / s) * s;
     return (x != x) ? x : y;
+}
+
+// ---- streaming memory access: 16 B per lane, optionally nontemporal -------------------------
+template <bool NT>
+__device__ __forceinline__ vf4 ld16(const vf4 *p)
+{
+    return NT ? __builtin_nontemporal_load(p) : *p;
+}
+
+template <bool NT>
+__device__ __forceinline__ void st16(vf4 *p, vf4 v)
+{
+    if (NT)
+        __builtin_nontemporal_store(v, p);
+    else
+        *p = v;
 }
 
 // ---- wave / block reductions (wave = 64 lanes) ---------------------------------------------

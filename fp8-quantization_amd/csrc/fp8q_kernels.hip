@@ -28,30 +28,39 @@ using namespace fp8q;
 
 namespace {
 
-constexpr int kUnroll = 4;           // float4 loads in flight per lane
+constexpr int kUnroll = 4;           // 16-byte loads in flight per lane
 constexpr int kTargetBlocks = 2048;  // 256 CUs x 8 blocks
-constexpr int kMultiTile = 4096;     // elements per k_quant_multi tile (16 KiB in, 16 KiB out)
+constexpr int kMultiTile = 8192;     // elements per k_quant_multi tile (32 KiB in, 32 KiB out)
 constexpr int kMultiMaxCh = 512;     // channels per tile whose constants fit the LDS budget
-constexpr int kFusedMaxElems = 16384;  // LDS tile of k_minmax_quant: 64 KiB of x
+constexpr int kFusedTile = 4096;     // k_minmax_quant: elements staged per block when rows are short
+constexpr int kFusedMaxElems = 16384;  // longest row k_minmax_quant accepts (64 KiB of LDS)
+constexpr int64_t kNtBytes = 64ll << 20;  // tensors at least this big stream with nontemporal hints
 
-__device__ __forceinline__ float4 ldg4(const float4 *p) { return *p; }
-__device__ __forceinline__ void stg4(float4 *p, const float4 &v) { *p = v; }
+// n / d == umulhi(n, magic) for n * d < 2^32; magic == 0 encodes d == 1
+inline uint32_t magic_of(int d) { return d <= 1 ? 0u : (uint32_t)((1ull << 32) / (uint64_t)d) + 1u; }
+
+__device__ __forceinline__ int div_small(uint32_t n, uint32_t magic)
+{
+    return magic == 0u ? (int)n : (int)__umulhi(n, magic);
+}
 
 // ---------------------------------------------------------------------------------------------
-// K1 rows: blockIdx.y = row (channel), blockIdx.x strides over the row.
+// K1 rows: blockIdx.y = row (channel), blockIdx.x strides over the row.  {s, 1/s} table in LDS.
 // ---------------------------------------------------------------------------------------------
+template <bool NT>
 __global__ void __launch_bounds__(kBlock)
 k_quant_rows(const float *__restrict__ x, float *__restrict__ y, int64_t inner,
              const float *__restrict__ maxval, int per_channel, QFmt f)
 {
-    __shared__ float lut[kLutMax];
+    __shared__ float2 lut[kLutMax];
     const int row = blockIdx.y;
     const int tid = threadIdx.x;
-    const Chan c = make_chan(maxval[per_channel ? row : 0], f);
-    for (int i = tid; i <= f.pmax; i += kBlock)
-        lut[i] = i == 0 ? __builtin_nanf("") : scale_exact(c, (float)i, f.M);
+    const Chan cfull = make_chan(maxval[per_channel ? row : 0], f);
+    for (int i = tid; i <= f.pmax; i += kBlock) lut[i] = lut_entry(cfull, i, f.M);
     __syncthreads();
+    const ChanLite c = lite(cfull);
     const float pmaxf = (float)f.pmax;
+    const float qthr = f.qthr;
 
     const float *xr = x + (int64_t)row * inner;
     float *yr = y + (int64_t)row * inner;
@@ -61,38 +70,42 @@ k_quant_rows(const float *__restrict__ x, float *__restrict__ y, int64_t inner,
     const int64_t nvec = (inner - head) >> 2;
     const int64_t tail0 = head + (nvec << 2);
     if (blockIdx.x == 0) {
-        if (tid < head) yr[tid] = quant_lut(xr[tid], c, lut, pmaxf);
+        if (tid < head) yr[tid] = quant_one(xr[tid], c, lut, pmaxf, qthr);
         const int64_t t = tail0 + tid;
-        if (t < inner) yr[t] = quant_lut(xr[t], c, lut, pmaxf);
+        if (t < inner) yr[t] = quant_one(xr[t], c, lut, pmaxf, qthr);
     }
-    const float4 *xv = reinterpret_cast<const float4 *>(xr + head);
-    float4 *yv = reinterpret_cast<float4 *>(yr + head);
+    const vf4 *xv = reinterpret_cast<const vf4 *>(xr + head);
+    vf4 *yv = reinterpret_cast<vf4 *>(yr + head);
 
     const int64_t step = (int64_t)gridDim.x * (kBlock * kUnroll);
     for (int64_t base = (int64_t)blockIdx.x * (kBlock * kUnroll); base < nvec; base += step) {
-        float4 v[kUnroll];
         if (base + kBlock * kUnroll <= nvec) {
+            vf4 v[kUnroll];
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u) v[u] = ldg4(xv + base + u * kBlock + tid);
+            for (int u = 0; u < kUnroll; ++u) v[u] = ld16<NT>(xv + base + u * kBlock + tid);
+            float e[kUnroll * 4];
 #pragma unroll
             for (int u = 0; u < kUnroll; ++u) {
-                v[u].x = quant_lut(v[u].x, c, lut, pmaxf);
-                v[u].y = quant_lut(v[u].y, c, lut, pmaxf);
-                v[u].z = quant_lut(v[u].z, c, lut, pmaxf);
-                v[u].w = quant_lut(v[u].w, c, lut, pmaxf);
+                e[4 * u + 0] = v[u].x;
+                e[4 * u + 1] = v[u].y;
+                e[4 * u + 2] = v[u].z;
+                e[4 * u + 3] = v[u].w;
             }
+            quant_group<kUnroll * 4>(e, c, lut, pmaxf, qthr);
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u) stg4(yv + base + u * kBlock + tid, v[u]);
+            for (int u = 0; u < kUnroll; ++u) {
+                vf4 w = {e[4 * u + 0], e[4 * u + 1], e[4 * u + 2], e[4 * u + 3]};
+                st16<NT>(yv + base + u * kBlock + tid, w);
+            }
         } else {
             for (int u = 0; u < kUnroll; ++u) {
                 const int64_t i = base + u * kBlock + tid;
                 if (i < nvec) {
-                    float4 w = ldg4(xv + i);
-                    w.x = quant_lut(w.x, c, lut, pmaxf);
-                    w.y = quant_lut(w.y, c, lut, pmaxf);
-                    w.z = quant_lut(w.z, c, lut, pmaxf);
-                    w.w = quant_lut(w.w, c, lut, pmaxf);
-                    stg4(yv + i, w);
+                    const vf4 w = ld16<NT>(xv + i);
+                    float e[4] = {w.x, w.y, w.z, w.w};
+                    quant_group<4>(e, c, lut, pmaxf, qthr);
+                    vf4 o = {e[0], e[1], e[2], e[3]};
+                    st16<NT>(yv + i, o);
                 }
             }
         }
@@ -101,53 +114,93 @@ k_quant_rows(const float *__restrict__ x, float *__restrict__ y, int64_t inner,
 
 // ---------------------------------------------------------------------------------------------
 // K1 multi: flat tiles over [C, inner] with short rows.  Dynamic LDS:
-//   Chan chans[max_ch]; float lut[max_ch * lut_stride] (LUT variant only)
+//   Chan chans[max_ch]; float2 lut[max_ch * lut_stride] (LUT variant only)
 // ---------------------------------------------------------------------------------------------
 struct MultiArgs {
     int inner;          // row length (< 2^20)
     int tile;           // elements per tile, multiple of 4
     int max_ch;         // channels a tile can span
     int lut_stride;     // pmax + 1
-    uint32_t magic;     // floor(2^32 / inner) + 1: n / inner == umulhi(n, magic) for n*inner < 2^32
+    uint32_t magic;     // see magic_of()
 };
 
-__device__ __forceinline__ int div_small(uint32_t n, uint32_t magic)
-{
-    return magic == 0u ? (int)n : (int)__umulhi(n, magic);   // magic == 0 encodes inner == 1
-}
-
+// four consecutive elements starting in channel `ch` at offset `r` inside its row
 template <bool LUT>
-__device__ __forceinline__ float quant_multi_elem(float x, const Chan *chans, const float *lut,
-                                                  int ch, const QFmt &f, int lut_stride)
+__device__ __forceinline__ void quant4_multi(float (&e)[4], const Chan *chans, const float2 *lut, int ch,
+                                             int r, int inner, const QFmt &f, int lut_stride)
 {
     if (LUT) {
-        // only the clamp bounds and bias are needed: 16-byte LDS read
-        const float4 h = *reinterpret_cast<const float4 *>(&chans[ch]);
-        Chan c;
-        c.maxv = h.x;
-        c.minv = h.y;
-        c.bias = h.z;
-        return quant_lut(x, c, lut + ch * lut_stride, (float)f.pmax);
+        ChanLite c[4];
+        const float2 *l[4];
+        float yv[4];
+        bool rk[4];
+        bool any = false;
+        const float pmaxf = (float)f.pmax;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float4 h = *reinterpret_cast<const float4 *>(&chans[ch]);   // 16-byte LDS read
+            c[j].maxv = h.x;
+            c[j].minv = h.y;
+            c[j].bias = h.z;
+            c[j].pthr = h.w;
+            l[j] = lut + ch * lut_stride;
+            yv[j] = quant_fast(e[j], c[j], l[j], pmaxf, f.qthr, rk[j]);
+            any |= rk[j];
+            if (++r == inner) {
+                r = 0;
+                ++ch;
+            }
+        }
+        if (__builtin_expect(any, 0)) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (rk[j]) yv[j] = quant_exact(e[j], c[j].maxv, c[j].minv, c[j].bias, l[j], pmaxf);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) e[j] = yv[j];
     } else {
-        const Chan c = chans[ch];
-        return quant_direct(x, c, f.M);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            e[j] = quant_direct(e[j], chans[ch], f.M);
+            if (++r == inner) {
+                r = 0;
+                ++ch;
+            }
+        }
     }
 }
 
 template <bool LUT>
+__device__ __forceinline__ float quant1_multi(float x, const Chan *chans, const float2 *lut, int ch,
+                                              const QFmt &f, int lut_stride)
+{
+    if (LUT) return quant_one(x, lite(chans[ch]), lut + ch * lut_stride, (float)f.pmax, f.qthr);
+    return quant_direct(x, chans[ch], f.M);
+}
+
+template <bool LUT, bool NT>
 __global__ void __launch_bounds__(kBlock)
 k_quant_multi(const float *__restrict__ x, float *__restrict__ y, int64_t total,
               const float *__restrict__ maxval, QFmt f, MultiArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     Chan *chans = reinterpret_cast<Chan *>(smem);
-    float *lut = reinterpret_cast<float *>(smem + (size_t)a.max_ch * sizeof(Chan));
+    float2 *lut = reinterpret_cast<float2 *>(smem + (size_t)a.max_ch * sizeof(Chan));
     const int tid = threadIdx.x;
 
     for (int64_t t0 = (int64_t)blockIdx.x * a.tile; t0 < total; t0 += (int64_t)gridDim.x * a.tile) {
         const int n = (int)((total - t0) < a.tile ? (total - t0) : a.tile);
-        const int64_t ch0 = t0 / a.inner;
-        const int rem0 = (int)(t0 - ch0 * a.inner);
+        // first channel of the tile: double division + one-step correction (t0 < 2^53)
+        int64_t ch0 = (int64_t)((double)t0 / (double)a.inner);
+        int64_t rem = t0 - ch0 * a.inner;
+        if (rem < 0) {
+            --ch0;
+            rem += a.inner;
+        } else if (rem >= a.inner) {
+            ++ch0;
+            rem -= a.inner;
+        }
+        const int rem0 = (int)rem;
         const int nch = (rem0 + n - 1) / a.inner + 1;
         __syncthreads();  // previous tile finished with the LDS
         for (int j = tid; j < nch; j += kBlock) chans[j] = make_chan(maxval[ch0 + j], f);
@@ -155,7 +208,7 @@ k_quant_multi(const float *__restrict__ x, float *__restrict__ y, int64_t total,
             __syncthreads();
             for (int j = tid; j < nch * a.lut_stride; j += kBlock) {
                 const int cj = j / a.lut_stride, pj = j - cj * a.lut_stride;
-                lut[j] = pj == 0 ? __builtin_nanf("") : scale_exact(chans[cj], (float)pj, f.M);
+                lut[j] = lut_entry(chans[cj], pj, f.M);
             }
         }
         __syncthreads();
@@ -167,20 +220,14 @@ k_quant_multi(const float *__restrict__ x, float *__restrict__ y, int64_t total,
             int ch = div_small(n0, a.magic);
             int r = (int)n0 - ch * a.inner;
             if (o + 4 <= n) {
-                float4 v = ldg4(reinterpret_cast<const float4 *>(xt + o));
+                const vf4 v = ld16<NT>(reinterpret_cast<const vf4 *>(xt + o));
                 float e[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    e[j] = quant_multi_elem<LUT>(e[j], chans, lut, ch, f, a.lut_stride);
-                    if (++r == a.inner) {
-                        r = 0;
-                        ++ch;
-                    }
-                }
-                stg4(reinterpret_cast<float4 *>(yt + o), make_float4(e[0], e[1], e[2], e[3]));
+                quant4_multi<LUT>(e, chans, lut, ch, r, a.inner, f, a.lut_stride);
+                vf4 w = {e[0], e[1], e[2], e[3]};
+                st16<NT>(reinterpret_cast<vf4 *>(yt + o), w);
             } else {
                 for (int j = 0; o + j < n; ++j) {
-                    yt[o + j] = quant_multi_elem<LUT>(xt[o + j], chans, lut, ch, f, a.lut_stride);
+                    yt[o + j] = quant1_multi<LUT>(xt[o + j], chans, lut, ch, f, a.lut_stride);
                     if (++r == a.inner) {
                         r = 0;
                         ++ch;
@@ -196,13 +243,17 @@ __global__ void __launch_bounds__(kBlock)
 k_quant_scalar(const float *__restrict__ x, float *__restrict__ y, int64_t inner,
                const float *__restrict__ maxval, int per_channel, QFmt f)
 {
+    __shared__ float2 lut[kLutMax];
     const int row = blockIdx.y;
-    const Chan c = make_chan(maxval[per_channel ? row : 0], f);
+    const Chan cfull = make_chan(maxval[per_channel ? row : 0], f);
+    for (int i = threadIdx.x; i <= f.pmax; i += kBlock) lut[i] = lut_entry(cfull, i, f.M);
+    __syncthreads();
+    const ChanLite c = lite(cfull);
     const float *xr = x + (int64_t)row * inner;
     float *yr = y + (int64_t)row * inner;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < inner;
          i += (int64_t)gridDim.x * kBlock)
-        yr[i] = quant_direct(xr[i], c, f.M);
+        yr[i] = quant_one(xr[i], c, lut, (float)f.pmax, f.qthr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -230,6 +281,7 @@ __device__ __forceinline__ void block_reduce_store(MinMax m, float *out)
     }
 }
 
+template <bool NT>
 __global__ void __launch_bounds__(kBlock)
 k_minmax_partial(const float *__restrict__ x, int64_t inner, int nsplit, float *__restrict__ ws)
 {
@@ -245,14 +297,14 @@ k_minmax_partial(const float *__restrict__ x, int64_t inner, int nsplit, float *
         if (tid < head) mm_acc(m, xr[tid]);
         if (tail0 + tid < inner) mm_acc(m, xr[tail0 + tid]);
     }
-    const float4 *xv = reinterpret_cast<const float4 *>(xr + head);
+    const vf4 *xv = reinterpret_cast<const vf4 *>(xr + head);
     constexpr int U = 8;
     const int64_t step = (int64_t)nsplit * (kBlock * U);
     for (int64_t base = (int64_t)split * (kBlock * U); base < nvec; base += step) {
         if (base + kBlock * U <= nvec) {
-            float4 v[U];
+            vf4 v[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) v[u] = ldg4(xv + base + u * kBlock + tid);
+            for (int u = 0; u < U; ++u) v[u] = ld16<NT>(xv + base + u * kBlock + tid);
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 mm_acc(m, v[u].x);
@@ -264,7 +316,7 @@ k_minmax_partial(const float *__restrict__ x, int64_t inner, int nsplit, float *
             for (int u = 0; u < U; ++u) {
                 const int64_t i = base + u * kBlock + tid;
                 if (i < nvec) {
-                    const float4 w = ldg4(xv + i);
+                    const vf4 w = ld16<NT>(xv + i);
                     mm_acc(m, w.x);
                     mm_acc(m, w.y);
                     mm_acc(m, w.z);
@@ -347,7 +399,7 @@ k_minmax_waverow(const float *__restrict__ x, int64_t C, int inner, float *cur_m
 
 // ---------------------------------------------------------------------------------------------
 // K2+K5+K1 fused (weights, estimate_ranges state): R whole rows per block staged in LDS.
-// Dynamic LDS: float xs[pad + R*inner (+3)] | Chan chans[R] | float lut[R * lut_stride] (LUT only)
+// Dynamic LDS: float xs[xs_floats] | Chan chans[R] | float2 lut[R * lut_stride] (LUT only)
 // ---------------------------------------------------------------------------------------------
 struct FusedArgs {
     int inner;
@@ -365,8 +417,8 @@ k_minmax_quant(const float *__restrict__ x, float *__restrict__ y, int64_t C, fl
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *xs = reinterpret_cast<float *>(smem);
     Chan *chans = reinterpret_cast<Chan *>(smem + (size_t)a.xs_floats * 4);
-    float *lut = reinterpret_cast<float *>(smem + (size_t)a.xs_floats * 4 +
-                                           (size_t)a.rows_per_block * sizeof(Chan));
+    float2 *lut = reinterpret_cast<float2 *>(smem + (size_t)a.xs_floats * 4 +
+                                             (size_t)a.rows_per_block * sizeof(Chan));
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
 
     for (int64_t r0 = (int64_t)blockIdx.x * a.rows_per_block; r0 < C;
@@ -382,73 +434,92 @@ k_minmax_quant(const float *__restrict__ x, float *__restrict__ y, int64_t C, fl
         const int nvec = (n - head) >> 2;
         const int tail0 = head + (nvec << 2);
         __syncthreads();
-        // ---- stage the tile: global -> LDS
+        // ---- stage the tile: global -> LDS (read once; weights are re-read by nobody)
         if (tid < head) xs[pad + tid] = xt[tid];
         if (tail0 + tid < n) xs[pad + tail0 + tid] = xt[tail0 + tid];
         {
-            const float4 *xv = reinterpret_cast<const float4 *>(xt + head);
-            float4 *sv = reinterpret_cast<float4 *>(xs + pad + head);
-            for (int i = tid; i < nvec; i += kBlock) sv[i] = ldg4(xv + i);
+            const vf4 *xv = reinterpret_cast<const vf4 *>(xt + head);
+            vf4 *sv = reinterpret_cast<vf4 *>(xs + pad + head);
+            for (int i = tid; i < nvec; i += kBlock) sv[i] = xv[i];
         }
         __syncthreads();
-        // ---- row min / max: one wave per row
-        for (int r = wave; r < R; r += 4) {
-            const float *xr = xs + pad + r * a.inner;
+        // ---- row min / max: one wave per row (R >= 4) or the whole block on one row (R == 1)
+        if (R == 1) {
+            __shared__ float s_mn[4], s_mx[4];
+            __shared__ int s_nan[4];
             MinMax m;
             mm_init(m);
-            for (int i = lane; i < a.inner; i += 64) mm_acc(m, xr[i]);
+            for (int i = tid; i < a.inner; i += kBlock) mm_acc(m, xs[pad + i]);
             mm_wave_reduce(m);
-            if (m.nan) m.mn = m.mx = __builtin_nanf("");
-            const float mv = fabsf(tmax(fabsf(m.mn), m.mx));   // fp8_quantizer.py:236
-            // the xor-shuffle reduction leaves min/max in every lane: all lanes derive the
-            // channel constants (same cost as one lane doing it), lane 0 publishes them
-            const Chan c = make_chan(mv, f);
             if (lane == 0) {
-                if (row_min) row_min[r0 + r] = m.mn;
-                if (row_max) row_max[r0 + r] = m.mx;
-                if (maxval_out) maxval_out[r0 + r] = mv;
-                chans[r] = c;
+                s_mn[wave] = m.mn;
+                s_mx[wave] = m.mx;
+                s_nan[wave] = m.nan;
             }
-            if (LUT) {
-                for (int p = lane; p < a.lut_stride; p += 64)
-                    lut[r * a.lut_stride + p] =
-                        p == 0 ? __builtin_nanf("") : scale_exact(c, (float)p, f.M);
+            __syncthreads();
+            float mn = fminf(fminf(s_mn[0], s_mn[1]), fminf(s_mn[2], s_mn[3]));
+            float mx = fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3]));
+            if (s_nan[0] | s_nan[1] | s_nan[2] | s_nan[3]) mn = mx = __builtin_nanf("");
+            const float mv = fabsf(tmax(fabsf(mn), mx));       // fp8_quantizer.py:236
+            const Chan c = make_chan(mv, f);
+            if (tid == 0) {
+                if (row_min) row_min[r0] = mn;
+                if (row_max) row_max[r0] = mx;
+                if (maxval_out) maxval_out[r0] = mv;
+                chans[0] = c;
+            }
+            if (LUT)
+                for (int p = tid; p < a.lut_stride; p += kBlock) lut[p] = lut_entry(c, p, f.M);
+        } else {
+            for (int r = wave; r < R; r += 4) {
+                const float *xr = xs + pad + r * a.inner;
+                MinMax m;
+                mm_init(m);
+                for (int i = lane; i < a.inner; i += 64) mm_acc(m, xr[i]);
+                mm_wave_reduce(m);
+                if (m.nan) m.mn = m.mx = __builtin_nanf("");
+                const float mv = fabsf(tmax(fabsf(m.mn), m.mx));   // fp8_quantizer.py:236
+                // the xor-shuffle reduction leaves min/max in every lane: all lanes derive the
+                // channel constants (same cost as one lane doing it), lane 0 publishes them
+                const Chan c = make_chan(mv, f);
+                if (lane == 0) {
+                    if (row_min) row_min[r0 + r] = m.mn;
+                    if (row_max) row_max[r0 + r] = m.mx;
+                    if (maxval_out) maxval_out[r0 + r] = mv;
+                    chans[r] = c;
+                }
+                if (LUT)
+                    for (int p = lane; p < a.lut_stride; p += 64)
+                        lut[r * a.lut_stride + p] = lut_entry(c, p, f.M);
             }
         }
         __syncthreads();
         // ---- quantize out of LDS, write coalesced
         if (tid < head) {
             const int ch = div_small((uint32_t)tid, a.magic);   // short rows: the head can span rows
-            yt[tid] = quant_multi_elem<LUT>(xs[pad + tid], chans, lut, ch, f, a.lut_stride);
+            yt[tid] = quant1_multi<LUT>(xs[pad + tid], chans, lut, ch, f, a.lut_stride);
         }
         if (tail0 + tid < n) {
             const int i = tail0 + tid;
             const int ch = div_small((uint32_t)i, a.magic);
-            yt[i] = quant_multi_elem<LUT>(xs[pad + i], chans, lut, ch, f, a.lut_stride);
+            yt[i] = quant1_multi<LUT>(xs[pad + i], chans, lut, ch, f, a.lut_stride);
         }
         {
-            const float4 *sv = reinterpret_cast<const float4 *>(xs + pad + head);
-            float4 *yv = reinterpret_cast<float4 *>(yt + head);
+            const vf4 *sv = reinterpret_cast<const vf4 *>(xs + pad + head);
+            vf4 *yv = reinterpret_cast<vf4 *>(yt + head);
             for (int i = tid; i < nvec; i += kBlock) {
                 const uint32_t n0 = (uint32_t)(head + i * 4);
-                int ch = div_small(n0, a.magic);
-                int r = (int)n0 - ch * a.inner;
-                const float4 v = sv[i];
+                const int ch = div_small(n0, a.magic);
+                const int r = (int)n0 - ch * a.inner;
+                const vf4 v = sv[i];
                 float e[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    e[j] = quant_multi_elem<LUT>(e[j], chans, lut, ch, f, a.lut_stride);
-                    if (++r == a.inner) {
-                        r = 0;
-                        ++ch;
-                    }
-                }
-                stg4(yv + i, make_float4(e[0], e[1], e[2], e[3]));
+                quant4_multi<LUT>(e, chans, lut, ch, r, a.inner, f, a.lut_stride);
+                vf4 w = {e[0], e[1], e[2], e[3]};
+                yv[i] = w;
             }
         }
     }
 }
-
 
 // ---------------------------------------------------------------------------------------------
 // K4: FP-MSE grid search (range_estimators.py:337-347), ALU-bound.
@@ -552,23 +623,24 @@ k_mse_final(const double *__restrict__ ws, float *__restrict__ mses, int64_t C, 
     }
 }
 
-// float4 copy with K1's launch shape: the achievable-HBM yardstick
+// 16-byte-per-lane copy with K1's launch shape: the achievable-HBM yardstick
+template <bool NT>
 __global__ void __launch_bounds__(kBlock)
-k_copy(const float4 *__restrict__ x, float4 *__restrict__ y, int64_t nvec)
+k_copy(const vf4 *__restrict__ x, vf4 *__restrict__ y, int64_t nvec)
 {
     const int tid = threadIdx.x;
     const int64_t step = (int64_t)gridDim.x * (kBlock * kUnroll);
     for (int64_t base = (int64_t)blockIdx.x * (kBlock * kUnroll); base < nvec; base += step) {
-        float4 v[kUnroll];
         if (base + kBlock * kUnroll <= nvec) {
+            vf4 v[kUnroll];
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u) v[u] = ldg4(x + base + u * kBlock + tid);
+            for (int u = 0; u < kUnroll; ++u) v[u] = ld16<NT>(x + base + u * kBlock + tid);
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u) stg4(y + base + u * kBlock + tid, v[u]);
+            for (int u = 0; u < kUnroll; ++u) st16<NT>(y + base + u * kBlock + tid, v[u]);
         } else {
             for (int u = 0; u < kUnroll; ++u) {
                 const int64_t i = base + u * kBlock + tid;
-                if (i < nvec) stg4(y + i, ldg4(x + i));
+                if (i < nvec) st16<NT>(y + i, ld16<NT>(x + i));
             }
         }
     }
@@ -591,6 +663,7 @@ int make_fmt(float mbits, int n_bits, int sign_bits, QFmt *f)
     f->M = M;
     f->two_E = (float)(1 << E);
     f->l_c = (float)log2((double)(2.0f - exp2f(-M)));
+    f->qthr = 0.5f - ldexpf(1.0f, (int)M - 21);
     f->sign_bits = sign_bits;
     f->pmax = 1 << E;
     return FP8Q_OK;
@@ -599,8 +672,6 @@ int make_fmt(float mbits, int n_bits, int sign_bits, QFmt *f)
 inline int hip_rc(hipError_t e) { return e == hipSuccess ? FP8Q_OK : (int)e; }
 inline int launch_rc() { return hip_rc(hipGetLastError()); }
 
-// n / d == umulhi(n, magic) for n * d < 2^32; d == 1 is handled by div_small()
-inline uint32_t magic_of(int d) { return d <= 1 ? 0u : (uint32_t)((1ull << 32) / (uint64_t)d) + 1u; }
 
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
@@ -637,6 +708,7 @@ int fp8q_quantize_f32(const float *x, float *y, int64_t C, int64_t inner, const 
     }
     const bool aligned = (((uintptr_t)x ^ (uintptr_t)y) & 15) == 0 && ((uintptr_t)x & 3) == 0;
     const bool rows16 = ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0;
+    const bool nt = C * inner * 4 >= kNtBytes;
 
     if (per_channel && inner < 2048 && rows16 && C * inner >= 4) {
         // short rows: flat tiles
@@ -647,25 +719,31 @@ int fp8q_quantize_f32(const float *x, float *y, int64_t C, int64_t inner, const 
         int64_t tile = kMultiTile;
         const int64_t cap = (int64_t)(kMultiMaxCh - 2) * inner;  // keep the channel span in LDS
         if (tile > cap) tile = cap;
+        const int64_t total = C * inner;
+        // small tensors: shrink the tile so that every CU gets work
+        while (tile > 1024 && cdiv(total, tile) < 512) tile >>= 1;
         tile &= ~(int64_t)3;
         if (tile < 4) tile = 4;
         a.tile = (int)tile;
         a.max_ch = (int)((tile + inner - 2) / inner + 1);
         a.magic = magic_of((int)inner);
-        const int64_t total = C * inner;
         int64_t blocks = cdiv(total, tile);
         if (blocks > kTargetBlocks) blocks = kTargetBlocks;
-        size_t shmem = (size_t)a.max_ch * sizeof(Chan) + (lut ? (size_t)a.max_ch * a.lut_stride * 4 : 0);
-        if (lut)
-            hipLaunchKernelGGL(k_quant_multi<true>, dim3((unsigned)blocks), dim3(kBlock), shmem, st, x,
-                               y, total, maxval, f, a);
+        const size_t shmem =
+            (size_t)a.max_ch * sizeof(Chan) + (lut ? (size_t)a.max_ch * a.lut_stride * sizeof(float2) : 0);
+        const dim3 g((unsigned)blocks), b(kBlock);
+        if (lut && nt)
+            hipLaunchKernelGGL((k_quant_multi<true, true>), g, b, shmem, st, x, y, total, maxval, f, a);
+        else if (lut)
+            hipLaunchKernelGGL((k_quant_multi<true, false>), g, b, shmem, st, x, y, total, maxval, f, a);
+        else if (nt)
+            hipLaunchKernelGGL((k_quant_multi<false, true>), g, b, shmem, st, x, y, total, maxval, f, a);
         else
-            hipLaunchKernelGGL(k_quant_multi<false>, dim3((unsigned)blocks), dim3(kBlock), shmem, st, x,
-                               y, total, maxval, f, a);
+            hipLaunchKernelGGL((k_quant_multi<false, false>), g, b, shmem, st, x, y, total, maxval, f, a);
         return launch_rc();
     }
     if (C > 65535) {
-        // very many long rows: fall back to one launch per 65535 rows (gridDim.y limit)
+        // very many long rows: one launch per 65535 rows (gridDim.y limit)
         for (int64_t c0 = 0; c0 < C; c0 += 65535) {
             const int64_t cn = (C - c0) < 65535 ? (C - c0) : 65535;
             int rc = fp8q_quantize_f32(x + c0 * inner, y + c0 * inner, cn, inner, maxval + c0, cn,
@@ -678,10 +756,13 @@ int fp8q_quantize_f32(const float *x, float *y, int64_t C, int64_t inner, const 
     const int64_t cap = kTargetBlocks / C > 0 ? kTargetBlocks / C : 1;
     if (bx > cap) bx = cap;
     if (bx < 1) bx = 1;
-    if (aligned)
-        hipLaunchKernelGGL(k_quant_rows, dim3((unsigned)bx, (unsigned)C), dim3(kBlock), 0, st, x, y, inner,
-                           maxval, per_channel, f);
-    else {
+    if (aligned) {
+        const dim3 g((unsigned)bx, (unsigned)C), b(kBlock);
+        if (nt)
+            hipLaunchKernelGGL(k_quant_rows<true>, g, b, 0, st, x, y, inner, maxval, per_channel, f);
+        else
+            hipLaunchKernelGGL(k_quant_rows<false>, g, b, 0, st, x, y, inner, maxval, per_channel, f);
+    } else {
         int64_t bs = cdiv(inner, kBlock);
         if (bs > cap * 4) bs = cap * 4;
         hipLaunchKernelGGL(k_quant_scalar, dim3((unsigned)bs, (unsigned)C), dim3(kBlock), 0, st, x, y,
@@ -731,8 +812,12 @@ int fp8q_minmax_f32(const float *x, int64_t C, int64_t inner, float *cur_min, fl
     for (int64_t c0 = 0; c0 < C; c0 += 65535) {
         const int64_t cn = (C - c0) < 65535 ? (C - c0) : 65535;
         float *w = (float *)ws + c0 * ns * 2;
-        hipLaunchKernelGGL(k_minmax_partial, dim3((unsigned)ns, (unsigned)cn), dim3(kBlock), 0, st,
-                           x + c0 * inner, inner, ns, w);
+        if (C * inner * 4 >= kNtBytes)
+            hipLaunchKernelGGL(k_minmax_partial<true>, dim3((unsigned)ns, (unsigned)cn), dim3(kBlock), 0,
+                               st, x + c0 * inner, inner, ns, w);
+        else
+            hipLaunchKernelGGL(k_minmax_partial<false>, dim3((unsigned)ns, (unsigned)cn), dim3(kBlock), 0,
+                               st, x + c0 * inner, inner, ns, w);
     }
     hipLaunchKernelGGL(k_minmax_final, dim3((unsigned)cdiv(C, 4)), dim3(kBlock), 0, st,
                        (const float *)ws, C, ns, cur_min, cur_max, maxval_out, fa);
@@ -757,8 +842,9 @@ int fp8q_minmax_quantize_f32(const float *x, float *y, int64_t C, int64_t inner,
     a.lut_stride = f.pmax + 1;
     a.magic = magic_of((int)inner);
     const bool lut = inner >= 2 * (int64_t)a.lut_stride;
-    // rows per block: fill the LDS tile, but keep >= ~512 blocks when C allows
-    int64_t R = kFusedMaxElems / inner;
+    // rows per block: ~kFusedTile elements (16 KiB of LDS -> 8 blocks per CU), at least one row,
+    // and few enough that a small tensor still spreads over >= 512 blocks
+    int64_t R = kFusedTile / inner;
     if (R > 256) R = 256;
     const int64_t want = cdiv(C, 512);
     if (R > want) R = want;
@@ -766,7 +852,7 @@ int fp8q_minmax_quantize_f32(const float *x, float *y, int64_t C, int64_t inner,
     a.rows_per_block = (int)R;
     a.xs_floats = (int)((R * inner + 3 + 3) & ~(int64_t)3) + 4;
     size_t shmem = (size_t)a.xs_floats * 4 + (size_t)R * sizeof(Chan) +
-                   (lut ? (size_t)R * a.lut_stride * 4 : 0);
+                   (lut ? (size_t)R * a.lut_stride * sizeof(float2) : 0);
     int64_t blocks = cdiv(C, R);
     if (blocks > kTargetBlocks) blocks = kTargetBlocks;
     if (shmem > 64 * 1024) {
@@ -861,8 +947,12 @@ int fp8q_copy_f32(const float *x, float *y, int64_t n, fp8q_stream_t stream)
     if (n == 0) return FP8Q_OK;
     int64_t bx = cdiv(n / 4, kBlock * kUnroll);
     if (bx > kTargetBlocks) bx = kTargetBlocks;
-    hipLaunchKernelGGL(k_copy, dim3((unsigned)bx), dim3(kBlock), 0, (hipStream_t)stream,
-                       (const float4 *)x, (float4 *)y, n / 4);
+    if (n * 4 >= kNtBytes)
+        hipLaunchKernelGGL(k_copy<true>, dim3((unsigned)bx), dim3(kBlock), 0, (hipStream_t)stream,
+                           (const vf4 *)x, (vf4 *)y, n / 4);
+    else
+        hipLaunchKernelGGL(k_copy<false>, dim3((unsigned)bx), dim3(kBlock), 0, (hipStream_t)stream,
+                           (const vf4 *)x, (vf4 *)y, n / 4);
     return launch_rc();
 }
 

@@ -59,8 +59,9 @@ def main():
     yr = y.view(4096, -1)
     mvr = torch.rand(4096, device=dev) + 0.5
     report("K1 per-channel [4096,65536] E4M3 (rows)", n, 8, timeit(lambda: ops.quantize(xr, mvr, 3, 8, 1, out=yr)))
-    xk = x[: 1 << 27].view(-1, 4608)
-    yk = y[: 1 << 27].view(-1, 4608)
+    nk = (1 << 27) // 4608
+    xk = x[: nk * 4608].view(nk, 4608)
+    yk = y[: nk * 4608].view(nk, 4608)
     report("fused minmax+quant [29127,4608] E5M2", xk.numel(), 8, timeit(lambda: ops.minmax_quantize(xk, 2, 8, 1, out=yk)))
     xd = x[: 9 << 22].view(-1, 1, 3, 3)
     yd = y[: 9 << 22].view(-1, 1, 3, 3)
