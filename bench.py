@@ -1,0 +1,241 @@
+#!/usr/bin/env python
+"""bench.py -- FP8 quantize+dequantize throughput on MI355X (driver contract).
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json config 2, scaled as north_star allows: "synthetic NxCxKxK tensors"):
+    a conv1-shaped weight tensor [2^21, 3, 7, 7] fp32 per GPU (308 M elements, 1.23 GB in +
+    1.23 GB out -- far beyond the 256 MB Infinity Cache), per-output-channel E5M2
+    (n_bits 8, 2 mantissa bits), ranges from current_minmax (computed once, outside the timed
+    region: validation runs with fixed ranges, quantization_manager.py:93-98).
+One step = one pass of the hot path quantize_to_fp8_ste_MM (fp8_quantizer.py:91-133) over
+the tensor = one launch of the HIP kernel k_quant_multi through the C ABI (fp8q_quantize_f32).
+Inputs are resident in HBM before the timed region.
+
+N > 1 (one process per GPU, torch.distributed/RCCL): output channels are sharded across
+ranks -- channels are independent, so the data path has no collective (weak scaling: every
+rank owns 2^21 channels).  `value` = channels*147 of ALL ranks / max-over-ranks time.
+
+The JSON line also carries:
+  roofline      the dominant kernel's algorithmic bytes (8 B/element) / its HIP-event launch time
+  cpu_baseline  the CPU oracle (oracle/fp8q_oracle.c, OpenMP) on a bounded sample, rank 0, N=1
+  extras        other kernels of the path on their own shapes (not part of `value`)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "fp8-quantization_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0       # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+BYTES_PER_ELEM = 8          # K1: 4 B read + 4 B written
+N_CH = 1 << 21              # channels per GPU
+ROW = 3 * 7 * 7             # conv1 filter
+MBITS, NBITS, SIGN = 2, 8, 1  # E5M2
+
+
+def ev_time(fn, iters, warm=2):
+    """median / mean seconds per call, HIP events on the current stream."""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+           for _ in range(iters)]
+    for a, b in evs:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) * 1e-3 for a, b in evs)
+    return ts[len(ts) // 2], sum(ts) / len(ts)
+
+
+def cpu_baseline(x_cpu, maxval_cpu):
+    """CPU oracle on a bounded sample of the same workload (whole channels), all host cores."""
+    import numpy as np
+    import oracle
+    threads = oracle.num_threads()
+    n_ch = 1 << 14
+    xs = np.ascontiguousarray(x_cpu[:n_ch])
+    mv = np.ascontiguousarray(maxval_cpu[:n_ch])
+    t0 = time.perf_counter()
+    oracle.c_quantize(xs, mv, MBITS, NBITS, SIGN)
+    dt = time.perf_counter() - t0
+    # scale the sample to ~10 s of CPU work, capped by what was generated
+    scale = max(1, min(int(10.0 / max(dt, 1e-3)), x_cpu.shape[0] // n_ch))
+    n_ch *= scale
+    xs = np.ascontiguousarray(x_cpu[:n_ch])
+    mv = np.ascontiguousarray(maxval_cpu[:n_ch])
+    t0 = time.perf_counter()
+    ref = oracle.c_quantize(xs, mv, MBITS, NBITS, SIGN)
+    dt = time.perf_counter() - t0
+    return dict(value=round(xs.size / dt / 1e9, 4), unit="Gelem/s", cores=threads, kind="port",
+                sample=f"first {n_ch} channels ({xs.size} elements) of the bench tensor, "
+                       f"oracle/fp8q_oracle.c with OpenMP, {dt:.2f} s"), ref, n_ch
+
+
+def torch_eager_cpu(x_cpu, maxval_cpu, n_ch):
+    """The reference-equivalent eager ATen path on the host cores (informational)."""
+    from oracle import torch_eager as te
+    torch.set_num_threads(os.cpu_count() or 1)
+    xs = x_cpu[:n_ch]
+    mv = maxval_cpu[:n_ch]
+    mb = torch.tensor([float(MBITS)])
+    te.fake_quant(xs[:1024], NBITS, mv[:1024], mb, SIGN)
+    t0 = time.perf_counter()
+    te.fake_quant(xs, NBITS, mv, mb, SIGN)
+    dt = time.perf_counter() - t0
+    return dict(value=round(xs.numel() / dt / 1e9, 4), unit="Gelem/s", cores=torch.get_num_threads(),
+                sample=f"{n_ch} channels, torch {torch.__version__} CPU eager op chain")
+
+
+def extras(ops, dev):
+    """Other kernels of the path, each on the shape that exercises it (rank 0, N=1 only)."""
+    out = {}
+    n = 1 << 28
+    x = torch.randn(n, device=dev)
+    y = torch.empty_like(x)
+    mv1 = torch.tensor([3.0], device=dev)
+
+    def rec(name, nelem, bpe, fn, iters=10):
+        med, _ = ev_time(fn, iters)
+        out[name] = dict(us=round(med * 1e6, 1), gelem_s=round(nelem / med / 1e9, 1),
+                         gb_s=round(nelem * bpe / med / 1e9, 1), frac_of_8tbs=round(nelem * bpe / med / 8e12, 3))
+
+    rec("copy_ceiling_1GiB", n, 8, lambda: ops.copy(x, out=y))
+    rec("k1_per_tensor_e4m3_1GiB", n, 8, lambda: ops.quantize(x, mv1, 3, 8, 1, out=y))
+    rec("k3_minmax_per_tensor_1GiB", n, 4, lambda: ops.minmax(x, False))
+    a = x[: 64 * 64 * 112 * 112].view(64, 64, 112, 112)
+    ya = y[: a.numel()].view_as(a)
+    rec("k1_act_64x64x112x112_e5m2", a.numel(), 8, lambda: ops.quantize(a, mv1, 2, 8, 1, out=ya))
+    rec("k3_act_64x64x112x112_allminmax", a.numel(), 4, lambda: ops.minmax(a, False))
+    w = torch.randn(64, 3, 7, 7, device=dev) * 0.1
+    yw = torch.empty_like(w)
+    rec("conv1_64x3x7x7_fused_minmax_quant_e5m2", w.numel(), 8,
+        lambda: ops.minmax_quantize(w, 2, 8, 1, out=yw), iters=200)
+    del x, y
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        sys.exit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 "
+                 "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (the FP8 engine has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import fp8q
+    ops = fp8q.ops
+    fp8q.lib()  # fail loudly if the HIP library is missing
+
+    # synthetic weights: this rank's shard of output channels (seed differs per rank)
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    x = torch.randn(N_CH, 3, 7, 7, device=dev, generator=g) * 0.1
+    y = torch.empty_like(x)
+    _, _, maxval = ops.minmax(x, True, want_maxval=True)   # current_minmax + set_quant_range, once
+    torch.cuda.synchronize()
+
+    def step():
+        ops.quantize(x, maxval, MBITS, NBITS, SIGN, out=y)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    evs = []
+    for _ in range(args.steps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        step()
+        b.record()
+        evs.append((a, b))
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kern_s = sum(a.elapsed_time(b) for a, b in evs) * 1e-3 / max(len(evs), 1)
+
+    n_elem = x.numel()
+    total_elem = n_elem * world
+    value = total_elem * args.steps / elapsed / 1e9
+    achieved = n_elem * BYTES_PER_ELEM / kern_s / 1e9
+
+    if rank == 0:
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("k_quant_multi_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "FP8 quant+dequant Gelems/sec", "value": round(value, 2), "unit": "Gelem/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"conv1-shaped weights [{N_CH},3,7,7] fp32 per GPU, per-channel E5M2 "
+                                   "quantize+dequantize, fixed ranges from current_minmax (BASELINE config 2, "
+                                   "synthetic NxCxKxK scale-up)",
+                       "elements_per_gpu": n_elem, "parallelism": f"channel-sharded x{world}, no data-path collective"},
+            "roofline": {"bound": "hbm", "kernel": "k_quant_multi<LUT,NT>", "achieved": round(achieved, 1),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": traffic, "algorithmic_bytes_per_launch": n_elem * BYTES_PER_ELEM,
+                         "avg_launch_us": round(kern_s * 1e6, 1)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            # bounded sample: generate only what the CPU leg needs
+            sample_ch = 1 << 18
+            xc = x[:sample_ch].cpu()
+            mvc = maxval[:sample_ch].cpu()
+            cb, ref, n_ch = cpu_baseline(xc.numpy(), mvc.numpy())
+            line["cpu_baseline"] = cb
+            # the sample doubles as a parity check of the timed kernel's output
+            import numpy as np
+            got = y[:n_ch].cpu().numpy()
+            line["cpu_baseline"]["gpu_output_bit_exact_on_sample"] = bool(
+                np.array_equal(got.view(np.int32), ref.view(np.int32)))
+            line["cpu_eager_torch"] = torch_eager_cpu(xc, mvc, min(n_ch, 1 << 16))
+        if world == 1 and not args.no_extras:
+            del x, y
+            torch.cuda.empty_cache()
+            line["extras"] = extras(ops, dev)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -695,11 +695,11 @@ const char *fp8q_strerror(int code)
 int fp8q_quantize_f32(const float *x, float *y, int64_t C, int64_t inner, const float *maxval,
                       int64_t n_maxval, float mbits, int n_bits, int sign_bits, fp8q_stream_t stream)
 {
-    if (!x || !y || !maxval || C < 0 || inner < 0 || (n_maxval != 1 && n_maxval != C))
-        return FP8Q_EINVAL;
+    if (C < 0 || inner < 0 || (n_maxval != 1 && n_maxval != C)) return FP8Q_EINVAL;
     QFmt f;
     if (int rc = make_fmt(mbits, n_bits, sign_bits, &f)) return rc;
-    if (C == 0 || inner == 0) return FP8Q_OK;
+    if (C == 0 || inner == 0) return FP8Q_OK;   // empty tensor: nothing to do (pointers may be null)
+    if (!x || !y || !maxval) return FP8Q_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const int per_channel = n_maxval != 1;
     if (!per_channel) {  // one row
@@ -830,10 +830,11 @@ int fp8q_minmax_quantize_f32(const float *x, float *y, int64_t C, int64_t inner,
                              float *row_max, float *maxval_out, float mbits, int n_bits,
                              int sign_bits, fp8q_stream_t stream)
 {
-    if (!x || !y || C < 0 || inner < 0) return FP8Q_EINVAL;
+    if (C < 0 || inner < 0) return FP8Q_EINVAL;
     QFmt f;
     if (int rc = make_fmt(mbits, n_bits, sign_bits, &f)) return rc;
     if (C == 0 || inner == 0) return FP8Q_OK;
+    if (!x || !y) return FP8Q_EINVAL;
     if (inner > kFusedMaxElems) return FP8Q_EUNSUPPORTED;
     if ((((uintptr_t)x ^ (uintptr_t)y) & 15) != 0 || ((uintptr_t)x & 3) != 0) return FP8Q_EINVAL;
     hipStream_t st = (hipStream_t)stream;
