@@ -1,0 +1,220 @@
+"""FP8 quantizer on the MI355X engine.
+
+`quantize_to_fp8_ste_MM` and `FPQuantizer` keep the names, arguments and observable state of
+/root/reference/quantization/quantizers/fp8_quantizer.py:91-133 and :151-272; the arithmetic is
+one HIP kernel launch (fp8q.ops.quantize -> fp8q_quantize_f32) instead of 13 eager ATen ops.
+There is no CPU path: tensors must live on the GPU (fp8q raises otherwise).
+"""
+import numpy as np
+import torch
+from torch import nn
+
+from fp8q import ops as _ops
+
+
+class QuantizerNotInitializedError(Exception):
+    """Raised when fix_ranges() is requested for a quantizer that has no range yet
+    (reference: quantization/quantizers/utils.py:6-12)."""
+
+    def __init__(self):
+        super().__init__("Quantizer has  not been initialized yet")
+
+
+class _RoundSTE(torch.autograd.Function):
+    """round-half-even forward, identity backward (reference rounding_utils.py:12-19)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return torch.round(x)
+
+    @staticmethod
+    def backward(ctx, grad):
+        return grad
+
+
+round_ste_func = _RoundSTE.apply
+
+
+class _FakeQuantSTE(torch.autograd.Function):
+    """HIP forward; straight-through gradient w.r.t. x inside the clamp range is what the
+    reference's STE chain yields for the PTQ path (backward is unused under no_grad)."""
+
+    @staticmethod
+    def forward(ctx, x, maxval, mbits, n_bits, sign_bits):
+        return _ops.quantize(x, maxval, mbits, n_bits, sign_bits)
+
+    @staticmethod
+    def backward(ctx, grad):
+        return grad, None, None, None, None
+
+
+def _host_float(t):
+    """python float of a 1-element tensor / number (mantissa bits are host-side scalars)."""
+    if isinstance(t, torch.Tensor):
+        return float(t.detach().reshape(-1)[0].item()) if t.numel() == 1 else float(t)
+    return float(t)
+
+
+def quantize_to_fp8_ste_MM(x_float, n_bits, maxval, num_mantissa_bits, sign_bits):
+    """Same call signature as fp8_quantizer.py:91-97.  maxval: tensor [1] or [C] on x's device."""
+    mbits = _host_float(num_mantissa_bits)
+    if not isinstance(maxval, torch.Tensor):
+        maxval = torch.tensor([float(maxval)], dtype=torch.float32)
+    maxval = maxval.detach().to(device=x_float.device, dtype=torch.float32).reshape(-1)
+    if x_float.requires_grad and torch.is_grad_enabled():
+        return _FakeQuantSTE.apply(x_float, maxval, mbits, int(n_bits), int(sign_bits))
+    return _ops.quantize(x_float, maxval, mbits, int(n_bits), int(sign_bits))
+
+
+# ---- format enumeration (independent definition of the grid, fp8_quantizer.py:13-50) ------------
+def generate_all_values_fp(num_total_bits=8, num_exponent_bits=4, bias=8):
+    """Every value representable with 1 sign bit, `num_exponent_bits` exponent bits and the rest
+    fraction bits; exponent code 0 is subnormal, the top exponent code is an ordinary binade."""
+    fbits = num_total_bits - 1 - num_exponent_bits
+    e = np.arange(2 ** num_exponent_bits, dtype=np.float64)[:, None]
+    f = np.arange(2 ** fbits, dtype=np.float64)[None, :] / 2.0 ** fbits
+    sub = (e == 0).astype(np.float64)
+    mag = 2.0 ** (e - bias + sub) * (f + 1.0 - sub)
+    return np.sort(np.concatenate([-mag.ravel(), mag.ravel()]))
+
+
+def generate_all_float_values_scaled(num_total_bits, num_exp_bits, exp_bias, range_limit_fp):
+    grid = generate_all_values_fp(num_total_bits, num_exp_bits, exp_bias)
+    return grid / (np.max(np.abs(grid)) / range_limit_fp)
+
+
+def get_max_value(num_exponent_bits=4, bias=8):
+    fbits = 7 - num_exponent_bits
+    return 2.0 ** (2 ** num_exponent_bits - 1 - bias) * (2.0 - 2.0 ** -fbits)
+
+
+class QuantizerBase(nn.Module):
+    """Protocol of every quantizer (reference base_quantizers.py:8-47)."""
+
+    def __init__(self, n_bits, per_channel=False, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.n_bits = n_bits
+        self.per_channel = per_channel
+        self.state = None
+        self.x_min_fp32 = self.x_max_fp32 = None
+
+    @property
+    def is_initialized(self):
+        raise NotImplementedError()
+
+    @property
+    def symmetric(self):
+        raise NotImplementedError()
+
+    def forward(self, x_float):
+        raise NotImplementedError()
+
+    def set_quant_range(self, x_min, x_max):
+        raise NotImplementedError()
+
+    def extra_repr(self):
+        return f"n_bits={self.n_bits}, per_channel={self.per_channel}, is_initalized={self.is_initialized}"
+
+    def reset(self):
+        self._delta = None
+
+
+class FPQuantizer(QuantizerBase):
+    """8-bit floating point fake-quantizer with an ExMy split and a real-valued exponent bias.
+
+    Constructor kwargs, attributes (`maxval`, `mantissa_bits`, `sign_bits`, `set_maxval`,
+    `allow_unsigned`, `mse_include_mantissa_bits`) and methods follow the reference class
+    (fp8_quantizer.py:151-272).  `maxval` lives on the GPU ([1] or [C]); `mantissa_bits` stays a
+    host tensor because the kernel takes it by value.
+    """
+
+    def __init__(self, *args, scale_domain=None, mantissa_bits=4, maxval=3, set_maxval=False,
+                 learn_maxval=False, learn_mantissa_bits=False, mse_include_mantissa_bits=True,
+                 allow_unsigned=False, **kwargs):
+        super().__init__(*args, **kwargs)
+        m = mantissa_bits
+        self.ebits = self.n_bits - m - 1
+        self.default_bias = 2 ** (self.ebits - 1)
+        # largest value of the format with the IEEE-like default bias (:177-179)
+        default_maxval = (2 - 2 ** (-m)) * 2 ** (2 ** self.ebits - 1 - self.default_bias)
+        self.maxval = torch.Tensor([maxval if maxval is not None else default_maxval])
+        self.mantissa_bits = torch.Tensor([float(m)])
+        self.set_maxval = set_maxval
+        self.learning_maxval = learn_maxval
+        self.learning_mantissa_bits = learn_mantissa_bits
+        self.mse_include_mantissa_bits = mse_include_mantissa_bits
+        self.allow_unsigned = allow_unsigned
+        self.sign_bits = 1
+
+    # -- hot path ---------------------------------------------------------------------------
+    def forward(self, x_float):
+        if self.maxval.device != x_float.device:
+            self.maxval = self.maxval.to(x_float.device)
+        return quantize_to_fp8_ste_MM(x_float, self.n_bits, self.maxval, self.mantissa_bits,
+                                      self.sign_bits)
+
+    # NB: plain methods, as in the reference (:207-211): truthy when used without a call
+    def is_initialized(self):
+        return True
+
+    def symmetric(self):
+        return False
+
+    def effective_bit_width(self):
+        return None
+
+    def _make_unsigned(self, x_min):
+        if not self.allow_unsigned:
+            return False
+        if isinstance(x_min, torch.Tensor):
+            return bool(torch.all(x_min >= 0))
+        return x_min >= 0
+
+    def set_quant_range(self, x_min, x_max):
+        """:222-240.  Only acts when set_maxval=True: maxval = |max(|x_min|, x_max)|."""
+        if self._make_unsigned(x_min):
+            self.sign_bits = 0
+        if not self.set_maxval:
+            return
+        dev = self.maxval.device
+        if not isinstance(x_max, torch.Tensor):
+            x_max = torch.tensor([float(x_max)], dtype=torch.float32, device=dev)
+            x_min = torch.tensor([float(x_min)], dtype=torch.float32, device=dev)
+        mv = torch.abs(torch.max(torch.abs(x_min), x_max)).detach().to(torch.float32)
+        self.maxval = mv.reshape(1) if mv.dim() == 0 else mv
+
+    def _set_maxval_tensor(self, mv):
+        """engine fast path: maxval already computed on the device by the range kernel."""
+        self.maxval = mv
+
+    def make_range_trainable(self):
+        if self.learning_maxval:
+            self.learn_maxval()
+        if self.learning_mantissa_bits:
+            self.learn_mantissa_bits()
+
+    def learn_maxval(self):
+        self.learning_maxval = True
+        self.maxval = nn.Parameter(self.maxval)
+
+    def learn_mantissa_bits(self):
+        self.learning_mantissa_bits = True
+        self.mantissa_bits = nn.Parameter(self.mantissa_bits)
+
+    def fix_ranges(self):
+        for name in ("maxval", "mantissa_bits"):
+            p = getattr(self, name)
+            if isinstance(p, nn.Parameter):
+                delattr(self, name)
+                setattr(self, name, p.data.clone())
+
+    def exponent_bias(self):
+        """the real-valued bias implied by maxval (what the reference prints in extra_repr)."""
+        m = float(np.clip(np.round(_host_float(self.mantissa_bits)), 1, 7))
+        e = 7 - m
+        return 2 ** e - torch.log2(self.maxval.float().cpu()) + float(np.log2(2 - 2 ** (-m))) - 1, e
+
+    def extra_repr(self):
+        bias, e = self.exponent_bias()
+        b = "[per_channel]" if bias.numel() > 1 else f"{bias.item()}"
+        return f"Exponent: {e} bits; mode: ; bias: {b}"

@@ -1,0 +1,466 @@
+"""Operator-wrapping layer: quantized drop-ins for Conv/Linear/LayerNorm (+BN, +activation).
+
+Keeps the reference's operator API so that model code written against it runs unchanged:
+  QuantizedModule / QuantizedActivation / FP32Acts   base_quantized_classes.py:40-181
+  QuantizationHijacker                               hijacker.py:32-112
+  BNFusedHijacker                                    quantized_folded_bn.py:12-68
+  QuantConv*, QuantLinear, BNQConv*, ..., quantize_model, quantize_sequential, fold_bn,
+  QuantizedActivationWrapper, Flattener              autoquant_utils.py:20-381
+Every weight / activation quantization goes through QuantizationManager -> HIP kernels.
+"""
+import copy
+import warnings
+
+import torch
+from torch import nn
+from torch.nn import functional as F
+from torch.nn.modules.conv import _ConvNd
+from torch.nn.modules.pooling import _AdaptiveAvgPoolNd, _AvgPoolNd
+
+from .manager import QuantizationManager, AsymmetricUniformQuantizer
+from .estimators import RangeEstimators, CurrentMinMaxEstimator, RunningMinMaxEstimator
+
+# activation modules that may be fused behind a weight layer (hijacker.py:15-29); the timm
+# variants are optional -- only their class names matter
+activations_set = [nn.ReLU, nn.ReLU6, nn.Hardtanh, nn.Sigmoid, nn.Tanh, nn.GELU, nn.PReLU]
+try:  # pragma: no cover - timm is not installed in the build image
+    from timm.models.layers.activations import Swish, HardSwish, HardSigmoid
+    from timm.models.layers.activations_me import SwishMe, HardSwishMe, HardSigmoidMe
+    activations_set += [Swish, SwishMe, HardSwish, HardSwishMe, HardSigmoid, HardSigmoidMe]
+except Exception:
+    pass
+
+
+def _for_managers(module, fn, need_init):
+    def visit(layer):
+        if isinstance(layer, QuantizationManager) and (not need_init or layer.quantizer.is_initialized):
+            fn(layer)
+    module.apply(visit)
+
+
+class QuantizedModule(nn.Module):
+    """Switches a module between quantized and full-precision behaviour and carries the
+    quantization settings every wrapped layer receives (base_quantized_classes.py:47-100)."""
+
+    def __init__(self, *args, method=AsymmetricUniformQuantizer, act_method=None,
+                 weight_range_method=CurrentMinMaxEstimator, act_range_method=RunningMinMaxEstimator,
+                 n_bits=8, n_bits_act=None, per_channel_weights=False, percentile=None,
+                 weight_range_options=None, act_range_options=None, scale_domain="linear",
+                 act_quant_kwargs={}, weight_quant_kwargs={}, quantize_input=False, fp8_kwargs=None,
+                 **kwargs):
+        kwargs.pop("act_quant_dict", None)
+        super().__init__(*args, **kwargs)
+        self.method = method
+        self.act_method = act_method or method
+        self.n_bits = n_bits
+        self.n_bits_act = n_bits_act or n_bits
+        self.per_channel_weights = per_channel_weights
+        self.percentile = percentile
+        self.weight_range_method = weight_range_method
+        self.weight_range_options = weight_range_options or {}
+        self.act_range_method = act_range_method
+        self.act_range_options = act_range_options or {}
+        self.scale_domain = scale_domain
+        self.quantize_input = quantize_input
+        self.fp8_kwargs = fp8_kwargs or {}
+        self.quant_params = None
+        self.register_buffer("_quant_w", torch.BoolTensor([False]))
+        self.register_buffer("_quant_a", torch.BoolTensor([False]))
+        # host mirrors of the two flags: the forward pass never reads a device tensor to branch
+        self._qw = self._qa = False
+        self.act_qparams = dict(n_bits=self.n_bits_act, scale_domain=scale_domain,
+                                **act_quant_kwargs, **self.fp8_kwargs)
+        self.weight_qparams = dict(n_bits=self.n_bits, scale_domain=scale_domain,
+                                   **weight_quant_kwargs, **self.fp8_kwargs)
+
+    def _flag(self, name, value):
+        old = getattr(self, name)
+        setattr(self, name, torch.BoolTensor([value]).to(old.device))
+        if name == "_quant_w":
+            self._qw = value
+        else:
+            self._qa = value
+
+    def _load_from_state_dict(self, state_dict, prefix, *a, **k):
+        super()._load_from_state_dict(state_dict, prefix, *a, **k)
+        self._qw, self._qa = bool(self._quant_w.item()), bool(self._quant_a.item())
+
+    def quantized_weights(self):
+        self._flag("_quant_w", True)
+
+    def full_precision_weights(self):
+        self._flag("_quant_w", False)
+
+    def quantized_acts(self):
+        self._flag("_quant_a", True)
+
+    def full_precision_acts(self):
+        self._flag("_quant_a", False)
+
+    def quantized(self):
+        self.quantized_weights()
+        self.quantized_acts()
+
+    def full_precision(self):
+        self.full_precision_weights()
+        self.full_precision_acts()
+
+    def get_quantizer_status(self):
+        return dict(quant_a=self._qa, quant_w=self._qw)
+
+    def set_quantizer_status(self, status):
+        (self.quantized_acts if status["quant_a"] else self.full_precision_acts)()
+        (self.quantized_weights if status["quant_w"] else self.full_precision_weights)()
+
+    def learn_ranges(self):
+        _for_managers(self, lambda m: m.learn_ranges(), need_init=True)
+
+    def fix_ranges(self):
+        _for_managers(self, lambda m: m.fix_ranges(), need_init=True)
+
+    def estimate_ranges(self):
+        _for_managers(self, lambda m: m.estimate_ranges(), need_init=False)
+
+    def estimate_ranges_train(self):
+        _for_managers(self, lambda m: m.estimate_ranges_train(), need_init=True)
+
+    def extra_repr(self):
+        state = f"weight_quant={self._qw}, act_quant={self._qa}"
+        parent = super().extra_repr()
+        return f"{parent},\n{state}" if parent else state
+
+
+class QuantizedActivation(QuantizedModule):
+    """A standalone activation quantizer (residual sums, pooled outputs, ...)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.activation_quantizer = QuantizationManager(
+            qmethod=self.act_method, init=self.act_range_method, qparams=self.act_qparams,
+            range_estim_params=self.act_range_options)
+
+    def quantize_activations(self, x):
+        return self.activation_quantizer(x) if self._qa else x
+
+    def forward(self, x):
+        return self.quantize_activations(x)
+
+
+class FP32Acts(nn.Module):
+    def forward(self, x):
+        return x
+
+    def reset_ranges(self):
+        pass
+
+
+class QuantizationHijacker(QuantizedModule):
+    """Mixin placed in front of nn.Conv*/nn.Linear/nn.LayerNorm in the MRO: intercepts forward,
+    quantizes the weight on every call (the reference does not cache, hijacker.py:88-98) and the
+    layer output (or input when quantize_input=True)."""
+
+    def __init__(self, *args, activation=None, **kwargs):
+        super().__init__(*args, **kwargs)
+        if activation is not None:
+            assert isinstance(activation, tuple(activations_set)), str(activation)
+        self.activation_function = copy.deepcopy(activation) if activation else None
+        self.activation_quantizer = QuantizationManager(
+            qmethod=self.act_method, init=self.act_range_method, qparams=self.act_qparams,
+            range_estim_params=self.act_range_options)
+        # reference quirk (hijacker.py:57): a CLASS is compared with an enum MEMBER, so the test is
+        # always False and weight estimators get `weight_range_options`, never `percentile`
+        if self.weight_range_method == RangeEstimators.current_minmax:
+            w_opts = dict(percentile=self.percentile)
+        else:
+            w_opts = self.weight_range_options
+        self.weight_quantizer = QuantizationManager(
+            qmethod=self.method, init=self.weight_range_method, per_channel=self.per_channel_weights,
+            qparams=self.weight_qparams, range_estim_params=w_opts)
+
+    def forward(self, x, offsets=None):
+        if self.quantize_input and self._qa:
+            x = self.activation_quantizer(x)
+        weight, bias = self.get_params()
+        out = self.run_forward(x, weight, bias, offsets=offsets)
+        return self._finish(out)
+
+    def _finish(self, out):
+        if self.activation_function is not None:
+            out = self.activation_function(out)
+        if not self.quantize_input and self._qa:
+            out = self.activation_quantizer(out)
+        return out
+
+    def get_params(self):
+        weight, bias = self.get_weight_bias()
+        if self._qw:
+            weight = self.quantize_weights(weight)
+        return weight, bias
+
+    def quantize_weights(self, weights):
+        return self.weight_quantizer(weights)
+
+    def get_weight_bias(self):
+        return self.weight, getattr(self, "bias", None)
+
+    def run_forward(self, x, weight, bias, offsets=None):
+        raise NotImplementedError()
+
+    def extra_repr(self):
+        where = "input" if self.quantize_input else "output"
+        return f"{super().extra_repr()}-{where}"
+
+
+class BNFusedHijacker(QuantizationHijacker):
+    """Weight layer followed by a batch norm kept in full precision (quantized_folded_bn.py):
+    the BN is NOT folded into the weights, it is applied to the layer output as F.batch_norm."""
+
+    def __init__(self, *args, **kwargs):
+        kwargs.pop("bias", None)                       # BN supplies the shift
+        super().__init__(*args, **kwargs, bias=False)
+        dim = self.get_bn_dim()
+        self.register_buffer("running_mean", torch.zeros(dim))
+        self.register_buffer("running_var", torch.ones(dim))
+        self.momentum = kwargs.pop("momentum", 0.1)
+        self.gamma = nn.Parameter(torch.ones(dim))
+        self.beta = nn.Parameter(torch.zeros(dim))
+        self.epsilon = kwargs.get("eps", 1e-5)
+        self.bias = None
+
+    def forward(self, x):
+        if self.quantize_input and self._qa:
+            x = self.activation_quantizer(x)
+        weight, bias = self.get_params()
+        out = self.run_forward(x, weight, bias)
+        out = F.batch_norm(out, self.running_mean, self.running_var, self.gamma, self.beta,
+                           self.training, self.momentum, self.epsilon)
+        return self._finish(out)
+
+    def get_bn_dim(self):
+        if isinstance(self, nn.Linear):
+            return self.out_features
+        if isinstance(self, _ConvNd):
+            return self.out_channels
+        raise NotImplementedError(f"Unsupported type used: {self}. Must be a linear or "
+                                  "(transpose)-convolutional nn.Module")
+
+
+# ---- concrete layers: the functional op each one runs on the (fake-quantized) weight ------------
+def _conv_forward(fn, transposed=False):
+    def run_forward(self, x, weight, bias, offsets=None):
+        extra = dict(output_padding=self.output_padding) if transposed else {}
+        return fn(x.contiguous(), weight.contiguous(), bias=bias, stride=self.stride,
+                  padding=self.padding, dilation=self.dilation, groups=self.groups, **extra)
+    return run_forward
+
+
+def _linear_forward(self, x, weight, bias, offsets=None):
+    return F.linear(x.contiguous(), weight.contiguous(), bias=bias)
+
+
+class QuantConv1d(QuantizationHijacker, nn.Conv1d):
+    run_forward = _conv_forward(F.conv1d)
+
+
+class QuantConv(QuantizationHijacker, nn.Conv2d):
+    run_forward = _conv_forward(F.conv2d)
+
+
+class QuantConvTransposeBase(QuantizationHijacker):
+    def quantize_weights(self, weights):
+        # transposed-conv weights are (in, out, *k): per-channel means per OUTPUT channel, so
+        # swap dims 0/1 around the quantizer call (autoquant_utils.py:46-58)
+        if self.per_channel_weights:
+            weights = weights.transpose(1, 0).contiguous()
+        weights = self.weight_quantizer(weights)
+        if self.per_channel_weights:
+            weights = weights.transpose(1, 0).contiguous()
+        return weights
+
+
+class QuantConvTranspose1d(QuantConvTransposeBase, nn.ConvTranspose1d):
+    run_forward = _conv_forward(F.conv_transpose1d, transposed=True)
+
+
+class QuantConvTranspose(QuantConvTransposeBase, nn.ConvTranspose2d):
+    run_forward = _conv_forward(F.conv_transpose2d, transposed=True)
+
+
+class QuantLinear(QuantizationHijacker, nn.Linear):
+    run_forward = _linear_forward
+
+
+class BNQConv1d(BNFusedHijacker, nn.Conv1d):
+    run_forward = _conv_forward(F.conv1d)
+
+
+class BNQConv(BNFusedHijacker, nn.Conv2d):
+    run_forward = _conv_forward(F.conv2d)
+
+
+class BNQLinear(BNFusedHijacker, nn.Linear):
+    run_forward = _linear_forward
+
+
+class QuantLayerNorm(QuantizationHijacker, nn.LayerNorm):
+    def run_forward(self, x, weight, bias, offsets=None):
+        return F.layer_norm(input=x.contiguous(), normalized_shape=self.normalized_shape,
+                            weight=weight.contiguous(), bias=bias.contiguous(), eps=self.eps)
+
+
+class QuantizedActivationWrapper(QuantizedActivation):
+    """Runs a parameter-free layer (pooling) and quantizes its output; with tied quantizers the
+    output reuses the producer's activation quantizer WITHOUT updating its range
+    (autoquant_utils.py:125-163)."""
+
+    def __init__(self, layer, tie_activation_quantizers=False, input_quantizer=None, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.tie_activation_quantizers = tie_activation_quantizers
+        if input_quantizer:
+            assert isinstance(input_quantizer, QuantizationManager)
+            self.activation_quantizer = input_quantizer
+        self.layer = layer
+
+    def quantize_activations_no_range_update(self, x):
+        return self.activation_quantizer.quantizer(x) if self._qa else x
+
+    def forward(self, x):
+        x = self.layer(x)
+        if self.tie_activation_quantizers:
+            return self.quantize_activations_no_range_update(x)
+        return self.quantize_activations(x)
+
+    def extra_repr(self):
+        return f"tie_activation_quantizers={self.tie_activation_quantizers}"
+
+
+class Flattener(nn.Module):
+    def forward(self, x):
+        return x.view(x.shape[0], -1)
+
+
+non_bn_module_map = {nn.Conv1d: QuantConv1d, nn.Conv2d: QuantConv, nn.ConvTranspose1d: QuantConvTranspose1d,
+                     nn.ConvTranspose2d: QuantConvTranspose, nn.Linear: QuantLinear,
+                     nn.LayerNorm: QuantLayerNorm}
+bn_module_map = {nn.Conv1d: BNQConv1d, nn.Conv2d: BNQConv, nn.Linear: BNQLinear}
+non_param_modules = (_AdaptiveAvgPoolNd, _AvgPoolNd)
+quant_conv_modules = (QuantConv1d, QuantConv, BNQConv1d, BNQConv)
+
+
+# ---- model rewriting -----------------------------------------------------------------------------
+def next_bn(seq, i):
+    return i + 1 < len(seq) and isinstance(seq[i + 1], (nn.BatchNorm2d, nn.BatchNorm1d))
+
+
+def get_act(seq, i):
+    """(activation module, its index) if seq[i] is followed by [bn,] act; else (None, None)."""
+    acts = tuple(activations_set)
+    if i + 1 < len(seq) and isinstance(seq[i + 1], acts):
+        return seq[i + 1], i + 1
+    if i + 2 < len(seq) and next_bn(seq, i) and isinstance(seq[i + 2], acts):
+        return seq[i + 2], i + 2
+    return None, None
+
+
+def get_module_args(mod, act):
+    if isinstance(mod, _ConvNd):
+        kw = dict(in_channels=mod.in_channels, out_channels=mod.out_channels,
+                  kernel_size=mod.kernel_size, stride=mod.stride, padding=mod.padding,
+                  dilation=mod.dilation, groups=mod.groups, bias=mod.bias is not None)
+        if isinstance(mod, (nn.ConvTranspose1d, nn.ConvTranspose2d)):
+            kw["output_padding"] = mod.output_padding
+    elif isinstance(mod, nn.Linear):
+        kw = dict(in_features=mod.in_features, out_features=mod.out_features, bias=mod.bias is not None)
+    elif isinstance(mod, nn.LayerNorm):
+        kw = dict(normalized_shape=mod.normalized_shape, eps=mod.eps)
+    else:
+        raise ValueError
+    kw["activation"] = act
+    return kw
+
+
+def fold_bn(seq, i, **quant_params):
+    """Build the quantized replacement of seq[i] (+ following BN, + following activation).
+    Returns (module, index of the next unconsumed entry).  'fold' is historical: the BN stays
+    a separate fp32 op inside the fused module (autoquant_utils.py:266-289)."""
+    has_bn = next_bn(seq, i)
+    act, _ = get_act(seq, i)
+    src = seq[i]
+    cls = (bn_module_map if has_bn else non_bn_module_map)[type(src)]
+    new = cls(**get_module_args(src, act), **quant_params)
+    new.weight.data = src.weight.data.clone()
+    if has_bn:
+        bn = seq[i + 1]
+        new.gamma.data = bn.weight.data.clone()
+        new.beta.data = bn.bias.data.clone()
+        new.running_mean.data = bn.running_mean.data.clone()
+        new.running_var.data = bn.running_var.data.clone()
+        if src.bias is not None:
+            new.running_mean.data -= src.bias.data
+            print("Warning: bias in conv/linear before batch normalization.")
+        new.epsilon = bn.eps
+    elif src.bias is not None:
+        new.bias.data = src.bias.data.clone()
+    return new, i + 1 + int(has_bn) + int(bool(act))
+
+
+def _last_quantized(mods):
+    if mods and isinstance(mods[-1], QuantizedModule):
+        return mods[-1]
+    if mods and isinstance(mods[-1], nn.Sequential) and isinstance(mods[-1][-1], QuantizedModule):
+        return mods[-1][-1]
+    return None
+
+
+def quantize_sequential(model, specials=None, tie_activation_quantizers=False, **quant_params):
+    specials = specials or {}
+    out, i = [], 0
+    while i < len(model):
+        m = model[i]
+        if isinstance(m, QuantizedModule):
+            out.append(m)
+        elif type(m) in non_bn_module_map:
+            new, i = fold_bn(model, i, **quant_params)
+            out.append(new)
+            continue
+        elif type(m) in specials:
+            out.append(specials[type(m)](m, **quant_params))
+        elif isinstance(m, non_param_modules):
+            prev = _last_quantized(out)
+            if prev is not None and tie_activation_quantizers:
+                print(f"Tying input quantizer {i-1}^th layer of type {type(prev)} to the "
+                      f"quantized {type(m)} following it")
+                out.append(QuantizedActivationWrapper(m, tie_activation_quantizers=True,
+                                                      input_quantizer=prev.activation_quantizer,
+                                                      **quant_params))
+            else:
+                out.append(QuantizedActivationWrapper(m, **quant_params))
+                if tie_activation_quantizers:
+                    warnings.warn("Input quantizer not found, so we do not tie quantizers")
+        else:
+            out.append(quantize_model(m, specials=specials, **quant_params))
+        i += 1
+    return nn.Sequential(*out)
+
+
+def quantize_model(model, specials=None, tie_activation_quantizers=False, **quant_params):
+    specials = specials or {}
+    if isinstance(model, nn.Sequential):
+        return quantize_sequential(model, specials, tie_activation_quantizers, **quant_params)
+    if type(model) in specials:
+        return specials[type(model)](model, **quant_params)
+    if isinstance(model, non_param_modules):
+        return QuantizedActivationWrapper(model, **quant_params)
+    if type(model) in non_bn_module_map:      # exact type: subclasses are treated as containers
+        new = non_bn_module_map[type(model)](**get_module_args(model, None), **quant_params)
+        new.weight.data = model.weight.data
+        if getattr(model, "bias", None) is not None:
+            new.bias.data = model.bias.data
+        return new
+    # unknown container: quantize its children in place on a copy
+    clone = copy.deepcopy(model)
+    for name, child in clone._modules.items():
+        q = quantize_model(child, specials=specials, **quant_params)
+        if q is not None:
+            setattr(clone, name, q)
+    return clone

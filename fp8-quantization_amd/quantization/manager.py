@@ -1,0 +1,139 @@
+"""QuantizationManager: range-estimation state machine in front of a quantizer.
+
+API of /root/reference/quantization/quantization_manager.py:28-135 (constructor arguments,
+`state`, `estimate_ranges/fix_ranges/learn_ranges/reset_ranges`, `forward`).  `forward` keeps
+the reference order -- update the range from the CURRENT batch, then quantize that batch with
+it (:114-122) -- but picks the cheapest kernel sequence for it:
+
+  estimate, per-channel current_minmax, set_maxval  -> 1 launch  (fp8q_minmax_quantize_f32)
+  estimate, any min/max estimator                    -> 2-3 launches (minmax [+final], quantize)
+  fixed ranges                                       -> 1 launch  (fp8q_quantize_f32)
+  anything else (custom estimator / quantizer)       -> the generic protocol calls
+"""
+from enum import auto
+
+from torch import nn
+
+from fp8q import ops as _ops
+from .registry import BaseEnumOptions, ClassEnumOptions, MethodMap
+from .fp8 import FPQuantizer, QuantizerBase, QuantizerNotInitializedError
+from .estimators import (RangeEstimators, RangeEstimatorBase, CurrentMinMaxEstimator,
+                         AllMinMaxEstimator, RunningMinMaxEstimator)
+
+
+class _UniformQuantizerOutOfScope(QuantizerBase):
+    """INT quantizers are the CPU comparison baseline of compute_quant_error.py only
+    (out of scope for the GPU hot path)."""
+
+    def __init__(self, *args, **kwargs):
+        raise NotImplementedError(
+            f"{type(self).__name__}: uniform (INT) quantizers are outside the FP8 hot-path scope of "
+            "this build; use --qmethod fp_quantizer")
+
+
+class SymmetricUniformQuantizer(_UniformQuantizerOutOfScope):
+    pass
+
+
+class AsymmetricUniformQuantizer(_UniformQuantizerOutOfScope):
+    pass
+
+
+class QMethods(ClassEnumOptions):
+    symmetric_uniform = MethodMap(SymmetricUniformQuantizer)
+    asymmetric_uniform = MethodMap(AsymmetricUniformQuantizer)
+    fp_quantizer = MethodMap(FPQuantizer)
+
+
+class Qstates(BaseEnumOptions):
+    estimate_ranges = auto()         # ranges follow the data in train and eval mode
+    fix_ranges = auto()              # ranges frozen
+    learn_ranges = auto()            # range parameters are nn.Parameters
+    estimate_ranges_train = auto()   # follow the data in train mode, frozen in eval mode
+
+
+_MINMAX = (CurrentMinMaxEstimator, AllMinMaxEstimator, RunningMinMaxEstimator)
+
+
+class QuantizationManager(nn.Module):
+    def __init__(self, qmethod=QMethods.fp_quantizer.cls, init=RangeEstimators.current_minmax.cls,
+                 per_channel=False, x_min=None, x_max=None, qparams=None, range_estim_params=None):
+        super().__init__()
+        self.state = Qstates.estimate_ranges
+        self.qmethod = qmethod
+        self.init = init
+        self.per_channel = per_channel
+        self.qparams = qparams if qparams else {}
+        self.range_estim_params = range_estim_params if range_estim_params else {}
+        self.range_estimator = None
+
+        self.quantizer = self.qmethod(per_channel=self.per_channel, **self.qparams)
+        self.quantizer.state = self.state
+        if x_min is not None and x_max is not None:
+            self.set_quant_range(x_min, x_max)
+            self.fix_ranges()
+        else:
+            self.range_estimator = self.init(per_channel=self.per_channel, quantizer=self.quantizer,
+                                             **self.range_estim_params)
+
+    @property
+    def n_bits(self):
+        return self.quantizer.n_bits
+
+    def _set_state(self, state):
+        self.state = state
+        self.quantizer.state = state
+
+    def estimate_ranges(self):
+        self._set_state(Qstates.estimate_ranges)
+
+    def fix_ranges(self):
+        if not self.quantizer.is_initialized:
+            raise QuantizerNotInitializedError()
+        self._set_state(Qstates.fix_ranges)
+
+    def learn_ranges(self):
+        self.quantizer.make_range_trainable()
+        self._set_state(Qstates.learn_ranges)
+
+    def estimate_ranges_train(self):
+        self._set_state(Qstates.estimate_ranges_train)
+
+    def reset_ranges(self):
+        self.range_estimator.reset()
+        self.quantizer.reset()
+        self.estimate_ranges()
+
+    def set_quant_range(self, x_min, x_max):
+        self.quantizer.set_quant_range(x_min, x_max)
+
+    def _estimating(self):
+        return self.state == Qstates.estimate_ranges or (
+            self.state == Qstates.estimate_ranges_train and self.training)
+
+    def forward(self, x):
+        q, est = self.quantizer, self.range_estimator
+        if not self._estimating():
+            return q(x)
+        fast = (type(q) is FPQuantizer and type(est) in _MINMAX and not q.allow_unsigned
+                and not getattr(est, "percentile", None) and x.is_cuda and not x.requires_grad)
+        if not fast:
+            xmin, xmax = est(x)                      # generic protocol, reference order
+            self.set_quant_range(xmin, xmax)
+            return q(x)
+        if not q.set_maxval:
+            est(x)                                   # estimate is tracked, the format's maxval stays
+            return q(x)
+        inner = x.numel() // max(x.shape[0], 1) if x.dim() > 0 else 1
+        if (type(est) is CurrentMinMaxEstimator and self.per_channel and x.dim() > 0
+                and 0 < inner <= _ops.fused_max_inner()):
+            y, mn, mx, mv = _ops.minmax_quantize(x, float(q.mantissa_bits), q.n_bits, q.sign_bits)
+            est.current_xmin, est.current_xmax, est.last_maxval = mn, mx, mv
+            q._set_maxval_tensor(mv)
+            return y
+        est(x)
+        q._set_maxval_tensor(est.last_maxval)        # == |max(|xmin|, xmax)| (fp8_quantizer.py:236)
+        return q(x)
+
+    def extra_repr(self):
+        return f"state={self.state.name}"

@@ -17,6 +17,7 @@ Fixture files:
   g3_estimators.npz  Current/All/RunningMinMax (range_estimators.py:56-125) + set_quant_range
   g4_mse.npz         FP_MSE_Estimator         (range_estimators.py:285-369)
   g6_manager.npz     QuantizationManager.forward state machine (quantization_manager.py:114-122)
+  g7_tinycnn.npz     quantize_model on a tiny CNN (autoquant_utils.py:292-381), config-3 settings
 """
 import os
 import sys
@@ -267,10 +268,75 @@ def make_g6():
     print("g6 ok")
 
 
+def tiny_cnn():
+    """conv-bn-relu, conv(+bias)-relu6, residual-free tail: avgpool, flatten, fc  (<100 KB)."""
+    torch.manual_seed(7)
+    net = nn.Sequential(nn.Conv2d(3, 16, 3, padding=1, bias=False), nn.BatchNorm2d(16), nn.ReLU(),
+                        nn.Conv2d(16, 24, 3, stride=2, padding=1, bias=True), nn.ReLU6(),
+                        nn.Conv2d(24, 24, 3, padding=1, groups=24, bias=False), nn.BatchNorm2d(24), nn.ReLU(),
+                        nn.AdaptiveAvgPool2d(1), nn.Flatten(), nn.Linear(24, 10))
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.2)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.1)
+    return net.eval()
+
+
+def make_g7():
+    """Wrapper level: reference quantize_model on a tiny CNN with BASELINE config-3 settings
+    (fp_quantizer E5M2, per-channel current_minmax weights, per-tensor allminmax activations,
+    1 calibration batch, fix_ranges, then a validation batch)."""
+    from quantization.autoquant_utils import quantize_model
+    from quantization.base_quantized_classes import QuantizedModule
+    out = {}
+    net = tiny_cnn()
+    for k, v in net.state_dict().items():
+        out["sd_" + k] = v.numpy().copy()
+    torch.manual_seed(8)
+    calib = torch.randn(8, 3, 16, 16)
+    val = torch.randn(8, 3, 16, 16) * 1.3
+    out["calib"], out["val"] = calib.numpy(), val.numpy()
+    for tag, M, act_est in (("e5m2", 2, "allminmax"), ("e4m3", 3, "allminmax"), ("e4m3_run", 3, "running_minmax")):
+        qparams = dict(method=QMethods.fp_quantizer.cls, act_method=None,
+                       weight_range_method=RangeEstimators.current_minmax.cls,
+                       act_range_method=RangeEstimators[act_est].cls, n_bits=8, n_bits_act=8,
+                       per_channel_weights=True, percentile=None, quantize_input=False,
+                       fp8_kwargs=dict(maxval=None, mantissa_bits=M, set_maxval=True, learn_maxval=False,
+                                       learn_mantissa_bits=False, mse_include_mantissa_bits=False,
+                                       allow_unsigned=False))
+        q = quantize_model(copy_net(net), tie_activation_quantizers=True, **qparams).eval()
+
+        def each(fn):
+            for m in q.modules():
+                if isinstance(m, QuantizedModule):
+                    fn(m)
+        with torch.no_grad():
+            out[f"{tag}_fp_logits"] = q(val).numpy().copy()          # quantizers off
+            each(lambda m: m.quantized())
+            out[f"{tag}_calib_logits"] = q(calib).numpy().copy()     # estimate_ranges state
+            each(lambda m: m.fix_ranges())
+            out[f"{tag}_val_logits"] = q(val).numpy().copy()
+        mgrs = [(n, m) for n, m in q.named_modules() if isinstance(m, QuantizationManager)]
+        out[f"{tag}_mgr_names"] = np.array([n for n, _ in mgrs])
+        for n, m in mgrs:
+            out[f"{tag}_maxval_{n}"] = m.quantizer.maxval.numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "g7_tinycnn.npz"), **out)
+    print("g7 ok")
+
+
+def copy_net(net):
+    import copy
+    return copy.deepcopy(net)
+
+
 if __name__ == "__main__":
     make_g1()
     make_g2()
     make_g3()
     make_g4()
     make_g6()
+    make_g7()
     assert not os.path.exists(os.path.join(REF, "quantization", "__pycache__")), "pycache leaked"

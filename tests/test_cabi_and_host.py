@@ -1,0 +1,182 @@
+"""CPU-only checks: the C-ABI library loads and exports every symbol include/fp8q.h declares,
+the host-side mirror of the reference API builds models and enforces its contracts, and the
+product path fails loudly (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_symbols_exported():
+    import fp8q
+    hdr = open(os.path.join(ROOT, "include", "fp8q.h")).read()
+    names = set(re.findall(r"\b(fp8q_[a-z0-9_]+)\s*\(", hdr))
+    assert {"fp8q_quantize_f32", "fp8q_minmax_f32", "fp8q_minmax_quantize_f32", "fp8q_mse_grid_f32",
+            "fp8q_version", "fp8q_strerror", "fp8q_copy_f32"} <= names
+    lib = ctypes.CDLL(fp8q.so_path())
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/fp8q.h but not exported"
+    assert set(fp8q._lib.SIGNATURES) == names, "ctypes signature table out of sync with the header"
+    assert fp8q.lib().fp8q_version() == 100
+    assert fp8q.lib().fp8q_strerror(-2).decode().startswith("unsupported")
+
+
+def test_argument_validation_without_gpu():
+    """Argument errors are detected before any launch, so they can be exercised on a CPU box."""
+    import fp8q
+    L = fp8q.lib()
+    assert L.fp8q_quantize_f32(None, None, 4, 4, None, 3, 3.0, 8, 1, None) == -1      # n_maxval not in {1, C}
+    assert L.fp8q_quantize_f32(None, None, 0, 0, None, 1, 3.0, 8, 1, None) == 0       # empty tensor is a no-op
+    assert L.fp8q_quantize_f32(None, None, 4, 4, None, 1, float("nan"), 8, 1, None) == -1
+    assert L.fp8q_quantize_f32(None, None, 4, 4, None, 1, 1.0, 16, 1, None) == -2     # 14 exponent bits
+    assert L.fp8q_minmax_f32(None, 1, 8, None, None, None, 0, 0.9, 1, None, 0, None) == -1
+    assert L.fp8q_fused_max_inner() >= 4608                                           # largest ResNet-18 filter
+
+
+def test_no_cpu_fallback():
+    import fp8q
+    from quantization.quantizers.fp8_quantizer import FPQuantizer
+    q = FPQuantizer(n_bits=8, mantissa_bits=3, maxval=1.0)
+    with pytest.raises(fp8q.Fp8qError, match="no CPU path"):
+        q(torch.randn(16))
+    with pytest.raises(fp8q.Fp8qError):
+        fp8q.ops.minmax(torch.randn(16), False)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "fp8-quantization_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(import|from)\s+oracle\b", src, re.M), f"{f} imports the oracle"
+                assert "fp8q_oracle" not in src.replace("oracle/fp8q_oracle.c", ""), f
+
+
+def test_registries_and_defaults():
+    from quantization.quantization_manager import QMethods, Qstates, QuantizationManager
+    from quantization.range_estimators import RangeEstimators
+    from quantization.quantizers.fp8_quantizer import FPQuantizer
+    assert QMethods.list_names() == ["symmetric_uniform", "asymmetric_uniform", "fp_quantizer"]
+    assert RangeEstimators.list_names() == ["current_minmax", "allminmax", "running_minmax", "MSE"]
+    assert Qstates.list_names() == ["estimate_ranges", "fix_ranges", "learn_ranges", "estimate_ranges_train"]
+    assert QMethods.fp_quantizer.cls is FPQuantizer
+    assert isinstance(RangeEstimators.allminmax(per_channel=False), RangeEstimators.allminmax.cls)
+    # default maxval of the formats when maxval=None (reference probe: E5M2 57344, E4M3 240)
+    assert FPQuantizer(n_bits=8, mantissa_bits=2, maxval=None).maxval.item() == 57344.0
+    assert FPQuantizer(n_bits=8, mantissa_bits=3, maxval=None).maxval.item() == 240.0
+    q = FPQuantizer(n_bits=8, mantissa_bits=3)
+    assert q.maxval.item() == 3.0 and q.sign_bits == 1 and q.is_initialized() and q.symmetric() is False
+    qm = QuantizationManager(qmethod=QMethods.fp_quantizer.cls, init=RangeEstimators.allminmax.cls,
+                             qparams=dict(n_bits=8, mantissa_bits=3))
+    assert qm.state == Qstates.estimate_ranges and qm.n_bits == 8
+    qm.fix_ranges()
+    assert qm.state == Qstates.fix_ranges and qm.quantizer.state == Qstates.fix_ranges
+    with pytest.raises(NotImplementedError):
+        QMethods.symmetric_uniform(n_bits=8)
+
+
+def test_set_quant_range_host_semantics():
+    from quantization.quantizers.fp8_quantizer import FPQuantizer
+    q = FPQuantizer(n_bits=8, mantissa_bits=3, set_maxval=False)
+    q.set_quant_range(-5.0, 2.0)
+    assert q.maxval.item() == 3.0                     # set_maxval=False: estimation is a no-op
+    q = FPQuantizer(n_bits=8, mantissa_bits=3, set_maxval=True)
+    q.set_quant_range(-5.0, 2.0)
+    assert q.maxval.tolist() == [5.0]
+    q.set_quant_range(torch.tensor([-1.0, -0.5]), torch.tensor([0.25, 2.0]))
+    assert q.maxval.tolist() == [1.0, 2.0]
+    q.set_quant_range(torch.tensor(-1.5), torch.tensor(0.5))          # 0-dim -> [1]
+    assert q.maxval.shape == (1,) and q.maxval.item() == 1.5
+    qu = FPQuantizer(n_bits=8, mantissa_bits=3, set_maxval=True, allow_unsigned=True)
+    qu.set_quant_range(torch.tensor(0.0), torch.tensor(4.0))
+    assert qu.sign_bits == 0
+    qs = FPQuantizer(n_bits=8, mantissa_bits=3, set_maxval=True, allow_unsigned=False)
+    qs.set_quant_range(torch.tensor(0.0), torch.tensor(4.0))
+    assert qs.sign_bits == 1
+
+
+def _tiny():
+    return nn.Sequential(nn.Conv2d(3, 8, 3, bias=False), nn.BatchNorm2d(8), nn.ReLU(),
+                         nn.Conv2d(8, 8, 1, bias=True), nn.ReLU6(),
+                         nn.AdaptiveAvgPool2d(1), nn.Flatten(), nn.Linear(8, 4))
+
+
+def _qparams():
+    from quantization.quantization_manager import QMethods
+    from quantization.range_estimators import RangeEstimators
+    return dict(method=QMethods.fp_quantizer.cls, weight_range_method=RangeEstimators.current_minmax.cls,
+                act_range_method=RangeEstimators.allminmax.cls, per_channel_weights=True, n_bits=8,
+                fp8_kwargs=dict(mantissa_bits=2, set_maxval=True, maxval=None))
+
+
+def test_quantize_model_structure():
+    from quantization.autoquant_utils import (quantize_model, BNQConv, QuantConv, QuantLinear,
+                                              QuantizedActivationWrapper)
+    from quantization.quantization_manager import QuantizationManager
+    from quantization.range_estimators import CurrentMinMaxEstimator, AllMinMaxEstimator
+    fp = _tiny()
+    qm = quantize_model(fp, tie_activation_quantizers=True, **_qparams())
+    kinds = [type(m) for m in qm]
+    assert kinds == [BNQConv, QuantConv, QuantizedActivationWrapper, nn.Flatten, QuantLinear]
+    assert isinstance(qm[0].activation_function, nn.ReLU) and isinstance(qm[1].activation_function, nn.ReLU6)
+    assert qm[0].bias is None and torch.equal(qm[0].gamma, fp[1].weight) and qm[0].epsilon == fp[1].eps
+    assert torch.equal(qm[1].bias, fp[3].bias) and torch.equal(qm[4].weight, fp[7].weight)
+    assert qm[2].activation_quantizer is qm[1].activation_quantizer          # tied to the producer
+    assert qm[0].weight_quantizer.per_channel and not qm[0].activation_quantizer.per_channel
+    assert isinstance(qm[0].weight_quantizer.range_estimator, CurrentMinMaxEstimator)
+    assert isinstance(qm[0].activation_quantizer.range_estimator, AllMinMaxEstimator)
+    assert qm[0].weight_quantizer.quantizer.set_maxval and qm[0].weight_quantizer.quantizer.maxval.item() == 57344.0
+    n_mgr = sum(isinstance(m, QuantizationManager) for m in qm.modules())
+    assert n_mgr == 6   # 3 weight + 3 activation managers (the pooled output shares one)
+    keys = list(qm.state_dict().keys())
+    assert "0._quant_w" in keys and "0.gamma" in keys and "0.running_mean" in keys
+    assert not any("maxval" in k for k in keys)       # reference: maxval is not a buffer
+
+
+def test_full_precision_forward_equals_fp_model_on_cpu():
+    """With quantization switched off the wrapped model is the fp32 model (runs on CPU)."""
+    from quantization.autoquant_utils import quantize_model
+    fp = _tiny().eval()
+    qm = quantize_model(fp, **_qparams()).eval()
+    x = torch.randn(2, 3, 9, 9)
+    with torch.no_grad():
+        torch.testing.assert_close(qm(x), fp(x), rtol=1e-5, atol=1e-6)
+    for m in qm.modules():
+        if hasattr(m, "quantized"):
+            m.quantized()
+    import fp8q
+    with pytest.raises(fp8q.Fp8qError):      # quantized + CPU tensors: loud failure, no fallback
+        with torch.no_grad():
+            qm(x)
+
+
+def test_quantized_model_switches():
+    from quantization.base_quantized_model import QuantizedModel
+    from quantization.autoquant_utils import quantize_model
+    from quantization.quantization_manager import Qstates, QuantizationManager
+
+    class Net(QuantizedModel):
+        def __init__(self):
+            super().__init__(input_size=(1, 3, 9, 9))
+            self.body = quantize_model(_tiny(), **_qparams())
+
+        def forward(self, x):
+            return self.body(x)
+
+    net = Net()
+    net.set_quant_state(weight_quant=True, act_quant=False)
+    assert net.body[0]._quant_w.item() and not net.body[0]._quant_a.item()
+    assert net.body[0].get_quantizer_status() == dict(quant_a=False, quant_w=True)
+    net.fix_ranges()
+    assert all(m.state == Qstates.fix_ranges for m in net.modules() if isinstance(m, QuantizationManager))
+    net.estimate_ranges()
+    assert all(m.state == Qstates.estimate_ranges for m in net.modules() if isinstance(m, QuantizationManager))
+    with pytest.raises(ValueError):
+        net.load_state_dict({"body.0.weight": torch.zeros(1)})

@@ -1,0 +1,188 @@
+"""GPU tests of the host-side mirror of the reference API against golden fixtures produced by the
+reference's own classes (QuantizationManager, estimators, FP_MSE_Estimator, quantize_model)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+from parity import assert_parity, elem_step
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def _mgr(init, per_channel=False, **fp8):
+    from quantization.quantization_manager import QuantizationManager, QMethods
+    from quantization.range_estimators import RangeEstimators
+    qp = dict(n_bits=8, mantissa_bits=3, maxval=None, set_maxval=True)
+    qp.update(fp8)
+    return QuantizationManager(qmethod=QMethods.fp_quantizer.cls, init=RangeEstimators[init].cls,
+                               per_channel=per_channel, qparams=qp)
+
+
+def test_manager_state_machine_vs_reference(golden_dir):
+    from quantization.quantization_manager import Qstates
+    g6 = np.load(os.path.join(golden_dir, "g6_manager.npz"))
+    xs = g6["xs"]
+    qm = _mgr("allminmax")
+    y0 = qm(dev(xs[0])).cpu().numpy()
+    mv0 = qm.quantizer.maxval.cpu().numpy().copy()
+    y1 = qm(dev(xs[1])).cpu().numpy()
+    np.testing.assert_array_equal(qm.quantizer.maxval.cpu().numpy(), g6["maxval_after2"])
+    qm.fix_ranges()
+    assert qm.state == Qstates.fix_ranges
+    y2 = qm(dev(xs[2])).cpu().numpy()     # larger data, frozen (smaller) range -> clipping
+    np.testing.assert_array_equal(qm.quantizer.maxval.cpu().numpy(), g6["maxval_after_fix"])
+    for i, (y, mv) in enumerate(((y0, mv0), (y1, g6["maxval_after2"]), (y2, g6["maxval_after_fix"]))):
+        assert_parity(y, g6["ys"][i], elem_step(xs[i], mv, 3), what=f"batch {i}")
+    # set_maxval=False (CLI default): estimation is a no-op, the format's default range is used
+    qm = _mgr("allminmax", mantissa_bits=2, set_maxval=False)
+    y = qm(dev(xs[0] * 1e4)).cpu().numpy()
+    np.testing.assert_array_equal(qm.quantizer.maxval.cpu().numpy(), g6["nomaxval_maxval"])
+    assert_parity(y, g6["nomaxval_y"], elem_step(xs[0] * 1e4, g6["nomaxval_maxval"], 2), what="default maxval")
+    assert qm.range_estimator.current_xmax is not None      # the estimate itself is still tracked
+
+
+def test_estimator_classes_vs_reference(golden_dir):
+    from quantization.range_estimators import RangeEstimators
+    g3 = np.load(os.path.join(golden_dir, "g3_estimators.npz"))
+    for name in ("allminmax", "running_minmax"):
+        for pc in (False, True):
+            est = RangeEstimators[name].cls(per_channel=pc)
+            for b, a in enumerate(g3["acts"]):
+                mn, mx = est(dev(a))
+                assert mn.dim() == (1 if pc else 0)
+                np.testing.assert_array_equal(mn.cpu().numpy().reshape(-1), g3[f"{name}_pc{int(pc)}_min"][b])
+                np.testing.assert_array_equal(mx.cpu().numpy().reshape(-1), g3[f"{name}_pc{int(pc)}_max"][b])
+            est.reset()
+            assert est.current_xmin is None
+    est = RangeEstimators.current_minmax.cls(per_channel=True)
+    mn, mx = est(dev(g3["w"]))
+    np.testing.assert_array_equal(mn.cpu().numpy(), g3["w_cur_pc_min"])
+    np.testing.assert_array_equal(est.current_xmax.cpu().numpy(), g3["w_cur_pc_max"])
+
+
+def test_weight_manager_conv1_config2(golden_dir):
+    """BASELINE config 2 through the operator API: per-channel current_minmax + E5M2."""
+    g3 = np.load(os.path.join(golden_dir, "g3_estimators.npz"))
+    qm = _mgr("current_minmax", per_channel=True, mantissa_bits=2)
+    y = qm(dev(g3["w"])).cpu().numpy()
+    np.testing.assert_array_equal(qm.quantizer.maxval.cpu().numpy(), g3["w_maxval"])
+    np.testing.assert_array_equal(qm.range_estimator.current_xmin.cpu().numpy(), g3["w_cur_pc_min"])
+    assert_parity(y, g3["w_q_e5m2"], elem_step(g3["w"], g3["w_maxval"], 2), what="conv1")
+    qm.fix_ranges()
+    y2 = qm(dev(g3["w"])).cpu().numpy()                     # fixed-range kernel gives the same bits
+    assert np.array_equal(y.view(np.int32), y2.view(np.int32))
+
+
+def test_allow_unsigned_path(golden_dir):
+    g3 = np.load(os.path.join(golden_dir, "g3_estimators.npz"))
+    qm = _mgr("current_minmax", allow_unsigned=True)
+    y = qm(dev(g3["relu_x"])).cpu().numpy()
+    assert qm.quantizer.sign_bits == int(g3["relu_sign_bits"]) == 0
+    np.testing.assert_array_equal(qm.quantizer.maxval.cpu().numpy(), g3["relu_maxval"])
+    assert_parity(y, g3["relu_q"], elem_step(g3["relu_x"], g3["relu_maxval"], 3, 8, 0), what="relu")
+
+
+@pytest.mark.parametrize("name,pc,incl,M", [("w_pc_fixm", True, False, 3), ("w_pc_srchm", True, True, 3),
+                                            ("a_pt_fixm", False, False, 3), ("a_pt_srchm", False, True, 2)])
+def test_mse_estimator_vs_reference(golden_dir, name, pc, incl, M):
+    from quantization.quantizers.fp8_quantizer import FPQuantizer
+    from quantization.range_estimators import RangeEstimators
+    g4 = np.load(os.path.join(golden_dir, "g4_mse.npz"))
+    q = FPQuantizer(n_bits=8, per_channel=pc, mantissa_bits=M, maxval=None, set_maxval=True,
+                    mse_include_mantissa_bits=incl)
+    est = RangeEstimators.MSE.cls(per_channel=pc, quantizer=q)
+    for b in range(2):
+        mn, mx = est(dev(g4[f"{name}_x{b}"]))
+        if b == 0:
+            np.testing.assert_array_equal(est.search_grid.cpu().numpy(), g4[f"{name}_grid"])
+        ref_mses = g4[f"{name}_mses{b}"]
+        np.testing.assert_allclose(est.mses.cpu().numpy(), ref_mses, rtol=1e-4)
+        assert float(q.mantissa_bits) == float(g4[f"{name}_mbits{b}"])
+        got, ref = mx.cpu().numpy().reshape(-1), g4[f"{name}_max{b}"].reshape(-1)
+        np.testing.assert_array_equal(mn.cpu().numpy().reshape(-1), -got)
+        mb = [1, 2, 3, 4, 5, 6] if incl else [M]
+        mi = mb.index(int(float(q.mantissa_bits)))
+        grid = g4[f"{name}_grid"]
+        for c in range(grid.shape[1]):     # same candidate, or an equally good one (<= 1e-5 rel)
+            if got[c] != ref[c]:
+                j_got = int(np.argmin(np.abs(grid[:, c] - got[c])))
+                j_ref = int(np.argmin(np.abs(grid[:, c] - ref[c])))
+                assert abs(ref_mses[mi, j_got, c] - ref_mses[mi, j_ref, c]) <= 1e-5 * ref_mses[mi, j_ref, c]
+
+
+def test_mse_estimator_unsigned(golden_dir):
+    from quantization.quantizers.fp8_quantizer import FPQuantizer
+    from quantization.range_estimators import RangeEstimators
+    g4 = np.load(os.path.join(golden_dir, "g4_mse.npz"))
+    q = FPQuantizer(n_bits=8, per_channel=False, mantissa_bits=3, maxval=None, set_maxval=True,
+                    mse_include_mantissa_bits=False, allow_unsigned=True)
+    est = RangeEstimators.MSE.cls(per_channel=False, quantizer=q)
+    mn, mx = est(dev(g4["relu_x"]))
+    assert q.sign_bits == int(g4["relu_sign_bits"])
+    np.testing.assert_allclose(est.mses.cpu().numpy(), g4["relu_mses"], rtol=1e-4)
+    np.testing.assert_array_equal(mx.cpu().numpy().reshape(-1), g4["relu_max"].reshape(-1))
+    np.testing.assert_array_equal(mn.cpu().numpy().reshape(-1), g4["relu_min"].reshape(-1))
+
+
+def _tiny_cnn(g7):
+    net = nn.Sequential(nn.Conv2d(3, 16, 3, padding=1, bias=False), nn.BatchNorm2d(16), nn.ReLU(),
+                        nn.Conv2d(16, 24, 3, stride=2, padding=1, bias=True), nn.ReLU6(),
+                        nn.Conv2d(24, 24, 3, padding=1, groups=24, bias=False), nn.BatchNorm2d(24), nn.ReLU(),
+                        nn.AdaptiveAvgPool2d(1), nn.Flatten(), nn.Linear(24, 10))
+    net.load_state_dict({k[3:]: torch.from_numpy(g7[k]) for k in g7.files if k.startswith("sd_")})
+    return net.eval()
+
+
+@pytest.mark.parametrize("tag,M,act_est", [("e5m2", 2, "allminmax"), ("e4m3", 3, "allminmax"),
+                                           ("e4m3_run", 3, "running_minmax")])
+def test_quantize_model_tiny_cnn_vs_reference(golden_dir, tag, M, act_est):
+    """Wrapper level (BASELINE config 3 procedure): calibrate on one batch, fix ranges, validate.
+    The conv/BN themselves run in MIOpen/rocBLAS (fp32): last-ulp differences before a quantizer
+    can move an activation by one grid step, hence the logits tolerance."""
+    from quantization.autoquant_utils import quantize_model
+    from quantization.base_quantized_classes import QuantizedModule
+    from quantization.quantization_manager import QuantizationManager, QMethods
+    from quantization.range_estimators import RangeEstimators
+    g7 = np.load(os.path.join(golden_dir, "g7_tinycnn.npz"))
+    qparams = dict(method=QMethods.fp_quantizer.cls, weight_range_method=RangeEstimators.current_minmax.cls,
+                   act_range_method=RangeEstimators[act_est].cls, n_bits=8, n_bits_act=8,
+                   per_channel_weights=True,
+                   fp8_kwargs=dict(maxval=None, mantissa_bits=M, set_maxval=True, learn_maxval=False,
+                                   learn_mantissa_bits=False, mse_include_mantissa_bits=False,
+                                   allow_unsigned=False))
+    q = quantize_model(_tiny_cnn(g7), tie_activation_quantizers=True, **qparams).eval().cuda()
+
+    def each(fn):
+        for m in q.modules():
+            if isinstance(m, QuantizedModule):
+                fn(m)
+    calib, val = dev(g7["calib"]), dev(g7["val"])
+    with torch.no_grad():
+        fp_logits = q(val).cpu().numpy()
+        each(lambda m: m.quantized())
+        calib_logits = q(calib).cpu().numpy()
+        each(lambda m: m.fix_ranges())
+        val_logits = q(val).cpu().numpy()
+    np.testing.assert_allclose(fp_logits, g7[f"{tag}_fp_logits"], rtol=1e-4, atol=1e-5)
+    names = [n for n, m in q.named_modules() if isinstance(m, QuantizationManager)]
+    assert names == list(g7[f"{tag}_mgr_names"])
+    for n, m in q.named_modules():
+        if isinstance(m, QuantizationManager):
+            ref = g7[f"{tag}_maxval_{n}"]
+            got = m.quantizer.maxval.cpu().numpy()
+            if n.endswith("weight_quantizer"):
+                np.testing.assert_array_equal(got, ref)            # weights: bit-equal ranges
+            else:
+                np.testing.assert_allclose(got, ref, rtol=1e-5)    # activations: conv rounding
+    for got, ref in ((calib_logits, g7[f"{tag}_calib_logits"]), (val_logits, g7[f"{tag}_val_logits"])):
+        assert np.array_equal(got.argmax(1), ref.argmax(1))
+        scale = np.abs(ref).max()
+        np.testing.assert_allclose(got, ref, rtol=0, atol=0.05 * scale)
+        assert np.mean(np.abs(got - ref)) < 0.01 * scale
