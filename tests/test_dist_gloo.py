@@ -1,0 +1,131 @@
+"""World-size-2 tests of the sharding / collective logic on CPU (gloo).  The local compute is an
+oracle-backed stand-in for fp8q.ops (same call signatures): tests may use the oracle, the product
+default (HIP) is exercised by the -m gpu tests."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle
+
+
+class OracleOps:
+    """fp8q.ops look-alike on CPU tensors, for the gloo tests only."""
+
+    @staticmethod
+    def minmax(x, per_channel, cur_min=None, cur_max=None, mode=0, momentum=0.9, want_maxval=False):
+        mn, mx = oracle.c_minmax(x.numpy(), per_channel)
+        if cur_min is not None:
+            mn, mx = oracle.c_fold(cur_min.numpy(), cur_max.numpy(), mn, mx, mode, momentum)
+        out = (torch.from_numpy(mn), torch.from_numpy(mx))
+        return out + (torch.from_numpy(oracle.c_absmax(mn, mx)),) if want_maxval else out
+
+    @staticmethod
+    def quantize(x, maxval, mbits, n_bits=8, sign_bits=1, out=None):
+        return torch.from_numpy(oracle.c_quantize(x.numpy(), maxval.numpy(), mbits, n_bits, sign_bits))
+
+    @staticmethod
+    def minmax_quantize(x, mbits, n_bits=8, sign_bits=1, out=None):
+        mn, mx = oracle.c_minmax(x.numpy(), True)
+        mv = oracle.c_absmax(mn, mx)
+        y = oracle.c_quantize(x.numpy(), mv, mbits, n_bits, sign_bits)
+        return torch.from_numpy(y), torch.from_numpy(mn), torch.from_numpy(mx), torch.from_numpy(mv)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, fn, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ret[rank] = fn(rank, world)
+    finally:
+        dist.destroy_process_group()
+
+
+def run(fn, world=2):
+    ret = mp.get_context("spawn").Manager().dict()
+    mp.spawn(_worker, args=(world, _free_port(), fn, ret), nprocs=world, join=True)
+    return [ret[r] for r in range(world)]
+
+
+def _weights():
+    rng = np.random.RandomState(0)
+    w = (rng.randn(13, 3, 3, 3) * 0.1).astype(np.float32)   # 13 channels: uneven split 7 + 6
+    w[4] = 0                                                # NaN channel quirk survives the gather
+    return w
+
+
+def _w_job(rank, world):
+    from fp8q import dist as fd
+    w = torch.from_numpy(_weights())
+    q, mv = fd.quantize_weight_sharded(w, 2, 8, 1, ops=OracleOps)
+    return q.numpy(), mv.numpy()
+
+
+def test_weight_channel_shard_allgather_bit_equal():
+    from fp8q.dist import channel_partition
+    assert channel_partition(13, 2) == [(0, 7), (7, 13)]
+    assert channel_partition(1000, 8)[0] == (0, 125) and channel_partition(3, 8)[5] == (3, 3)
+    w = _weights()
+    mn, mx = oracle.c_minmax(w, True)
+    mv = oracle.c_absmax(mn, mx)
+    ref = oracle.c_quantize(w, mv, 2, 8, 1)
+    for q, m in run(_w_job):
+        assert np.array_equal(np.isnan(q), np.isnan(ref))
+        assert np.array_equal(np.nan_to_num(q).view(np.int32), np.nan_to_num(ref).view(np.int32))
+        np.testing.assert_array_equal(m, mv)
+
+
+def _batches():
+    rng = np.random.RandomState(1)
+    return [(rng.randn(4, 8, 5, 5) * (1 + i)).astype(np.float32) for i in range(4)]
+
+
+def _c5_job(rank, world):
+    from fp8q import dist as fd
+    state, outs = None, []
+    for b in _batches():
+        x = torch.from_numpy(b[rank * 2:(rank + 1) * 2].copy())      # batch-sharded: 2 of 4 images
+        y, state = fd.calibrate_quantize_sharded(x, 3, 8, 1, state=state, ops=OracleOps)
+        outs.append(y.numpy())
+    return outs, state[0].numpy(), state[1].numpy()
+
+
+def test_batch_sharded_calibration_equals_single_process():
+    """allminmax is associative/commutative: the sharded run equals the 1-process run bit for bit."""
+    res = run(_c5_job)
+    cur = None
+    for i, b in enumerate(_batches()):
+        mn, mx = oracle.c_minmax(b, False)
+        cur = (mn, mx) if cur is None else oracle.c_fold(cur[0], cur[1], mn, mx, 1)
+        mv = oracle.c_absmax(*cur)
+        ref = oracle.c_quantize(b, mv, 3, 8, 1)
+        got = np.concatenate([res[0][0][i], res[1][0][i]])
+        assert np.array_equal(got.view(np.int32), ref.view(np.int32)), f"batch {i}"
+    for r in range(2):
+        np.testing.assert_array_equal(res[r][1], cur[0])
+        np.testing.assert_array_equal(res[r][2], cur[1])
+
+
+def _nan_job(rank, world):
+    from fp8q import dist as fd
+    mins = torch.tensor([-1.0 - rank, float("nan") if rank == 1 else -3.0, 0.5])
+    maxs = torch.tensor([2.0 + rank, 4.0, float("nan") if rank == 0 else 1.0])
+    fd.allreduce_ranges(mins, maxs)
+    return mins.numpy(), maxs.numpy()
+
+
+def test_allreduce_ranges_nan_propagates():
+    for mins, maxs in run(_nan_job):
+        assert mins[0] == -2.0 and maxs[0] == 3.0
+        assert np.isnan(mins[1]) and maxs[1] == 4.0
+        assert mins[2] == 0.5 and np.isnan(maxs[2])
