@@ -17,9 +17,9 @@
 //      no exp2 per entry: with bias = bi + bf, 2^e = 2^(k-bi) * g * 2^delta, g = 2^-bf (one
 //      double exp2 per channel), delta = fl32(k - bias) - (k - bias) (exact in double,
 //      |delta| <= 2^-17) and 2^delta = 1 + u + u^2/2, u = delta ln 2 (error < 3e-17).
-//   y  q0 = xc * (1/s) differs from fl32(xc / s) by < 3 * 2^-24 * q <= 2^(M-22); rint(q0) is
-//      therefore rint(xc / s) unless q0 is within 2^(M-21) of a rounding tie; only those lanes
-//      (~1e-5) redo the IEEE division.
+//   y  q0 = xc * rcp(s) (v_rcp_f32, 1 ulp) differs from fl32(xc / s) by < 2^-22 * q <= 2^(M-21);
+//      rint(q0) is therefore rint(xc / s) unless q0 is within 2^(M-20) of a rounding tie; only
+//      those lanes (~2e-5) redo the IEEE division.
 //   Channels whose bias is outside (-100, 100) (maxval below 1e-28 or non-finite, ...) take the
 //   exact path for every element (Chan::pthr = -1), so no range assumption leaks into results.
 #pragma once
@@ -38,7 +38,7 @@ struct QFmt {
     float M;        // clamp(rint(mbits), 1, n_bits - sign_bits)      fp8_quantizer.py:105
     float two_E;    // 2^E, E = n_bits - sign_bits - M                 :106
     float l_c;      // fl32(log2(2 - 2^-M))                            :110
-    float qthr;     // 0.5 - 2^(M-21): |q0 - rint(q0)| above this -> redo the division exactly
+    float qthr;     // 0.5 - 2^(M-20): |q0 - rint(q0)| above this -> redo the division exactly
     int sign_bits;  // 1: clamp lo = -maxval, 0: clamp lo = 0          :112
     int pmax;       // 2^E: largest value p can take (tables have pmax+1 entries)
 };
@@ -88,7 +88,7 @@ __device__ __forceinline__ float2 lut_entry(const Chan &c, int p, float M)
 {
     if (p == 0) return make_float2(__builtin_nanf(""), __builtin_nanf(""));
     const float s = scale_exact(c, (float)p, M);
-    return make_float2(s, 1.0f / s);
+    return make_float2(s, __builtin_amdgcn_rcpf(s));   // 1-ulp reciprocal: see QFmt::qthr
 }
 
 // the three per-element channel constants the table kernels need

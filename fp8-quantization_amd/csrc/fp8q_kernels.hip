@@ -30,9 +30,9 @@ namespace {
 
 constexpr int kUnroll = 4;           // 16-byte loads in flight per lane
 constexpr int kTargetBlocks = 2048;  // 256 CUs x 8 blocks
-constexpr int kMultiTile = 8192;     // elements per k_quant_multi tile (32 KiB in, 32 KiB out)
+constexpr int kMultiTile = 16384;    // elements per k_quant_multi tile (64 KiB in, 64 KiB out)
 constexpr int kMultiMaxCh = 512;     // channels per tile whose constants fit the LDS budget
-constexpr int kFusedTile = 4096;     // k_minmax_quant: elements staged per block when rows are short
+constexpr int kFusedTile = 8192;     // k_minmax_quant: elements staged per block when rows are short
 constexpr int kFusedMaxElems = 16384;  // longest row k_minmax_quant accepts (64 KiB of LDS)
 constexpr int64_t kNtBytes = 64ll << 20;  // tensors at least this big stream with nontemporal hints
 
@@ -113,40 +113,72 @@ k_quant_rows(const float *__restrict__ x, float *__restrict__ y, int64_t inner,
 }
 
 // ---------------------------------------------------------------------------------------------
-// K1 multi: flat tiles over [C, inner] with short rows.  Dynamic LDS:
-//   Chan chans[max_ch]; float2 lut[max_ch * lut_stride] (LUT variant only)
+// Short rows (inner < 2048): tiles of whole-or-partial rows with per-channel tables in LDS.
+// Shared by k_quant_multi (K1) and k_minmax_quant (K2+K5+K1).  Phases of one tile:
+//   B  make_chan for every channel the tile touches   (one pass: thread j <-> channel j)
+//   C  {s, 1/s} tables, entries spread over all threads (LUT variant)
+//   D  quantize; a 16-byte group that stays inside one row takes the single-channel fast path
 // ---------------------------------------------------------------------------------------------
-struct MultiArgs {
-    int inner;          // row length (< 2^20)
-    int tile;           // elements per tile, multiple of 4
+struct TileArgs {
+    int inner;          // row length
+    int tile;           // elements per tile (multiple of 4) / rows per tile for the fused kernel
     int max_ch;         // channels a tile can span
     int lut_stride;     // pmax + 1
-    uint32_t magic;     // see magic_of()
+    int group;          // lanes per row in the fused row reduction (power of two <= 64)
+    int xs_floats;      // fused kernel: LDS floats reserved for the staged x tile
+    uint32_t magic;     // n / inner      (see magic_of)
+    uint32_t lmagic;    // n / lut_stride
 };
+
+__device__ __forceinline__ void build_tables(const float *mv, int nch, Chan *chans, float2 *lut,
+                                             const QFmt &f, const TileArgs &a, bool with_lut)
+{
+    const int tid = threadIdx.x;
+    for (int j = tid; j < nch; j += kBlock) chans[j] = make_chan(mv[j], f);
+    __syncthreads();
+    if (with_lut) {
+        for (int j = tid; j < nch * a.lut_stride; j += kBlock) {
+            const int cj = div_small((uint32_t)j, a.lmagic), pj = j - cj * a.lut_stride;
+            lut[j] = lut_entry(chans[cj], pj, f.M);
+        }
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ ChanLite lite_lds(const Chan *c)
+{
+    const float4 h = *reinterpret_cast<const float4 *>(c);   // one ds_read_b128
+    ChanLite l;
+    l.maxv = h.x;
+    l.minv = h.y;
+    l.bias = h.z;
+    l.pthr = h.w;
+    return l;
+}
 
 // four consecutive elements starting in channel `ch` at offset `r` inside its row
 template <bool LUT>
-__device__ __forceinline__ void quant4_multi(float (&e)[4], const Chan *chans, const float2 *lut, int ch,
-                                             int r, int inner, const QFmt &f, int lut_stride)
+__device__ __forceinline__ void quant4_tile(float (&e)[4], const Chan *chans, const float2 *lut, int ch,
+                                            int r, const QFmt &f, const TileArgs &a)
 {
+    const float pmaxf = (float)f.pmax;
     if (LUT) {
+        if (r + 3 < a.inner) {     // common case: the group lies inside one row
+            quant_group<4>(e, lite_lds(chans + ch), lut + ch * a.lut_stride, pmaxf, f.qthr);
+            return;
+        }
         ChanLite c[4];
         const float2 *l[4];
         float yv[4];
         bool rk[4];
         bool any = false;
-        const float pmaxf = (float)f.pmax;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float4 h = *reinterpret_cast<const float4 *>(&chans[ch]);   // 16-byte LDS read
-            c[j].maxv = h.x;
-            c[j].minv = h.y;
-            c[j].bias = h.z;
-            c[j].pthr = h.w;
-            l[j] = lut + ch * lut_stride;
+            c[j] = lite_lds(chans + ch);
+            l[j] = lut + ch * a.lut_stride;
             yv[j] = quant_fast(e[j], c[j], l[j], pmaxf, f.qthr, rk[j]);
             any |= rk[j];
-            if (++r == inner) {
+            if (++r == a.inner) {
                 r = 0;
                 ++ch;
             }
@@ -162,7 +194,7 @@ __device__ __forceinline__ void quant4_multi(float (&e)[4], const Chan *chans, c
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             e[j] = quant_direct(e[j], chans[ch], f.M);
-            if (++r == inner) {
+            if (++r == a.inner) {
                 r = 0;
                 ++ch;
             }
@@ -171,17 +203,18 @@ __device__ __forceinline__ void quant4_multi(float (&e)[4], const Chan *chans, c
 }
 
 template <bool LUT>
-__device__ __forceinline__ float quant1_multi(float x, const Chan *chans, const float2 *lut, int ch,
-                                              const QFmt &f, int lut_stride)
+__device__ __forceinline__ float quant1_tile(float x, const Chan *chans, const float2 *lut, int ch,
+                                             const QFmt &f, const TileArgs &a)
 {
-    if (LUT) return quant_one(x, lite(chans[ch]), lut + ch * lut_stride, (float)f.pmax, f.qthr);
+    if (LUT) return quant_one(x, lite_lds(chans + ch), lut + ch * a.lut_stride, (float)f.pmax, f.qthr);
     return quant_direct(x, chans[ch], f.M);
 }
 
+// K1 multi.  Dynamic LDS: Chan chans[max_ch] | float2 lut[max_ch * lut_stride] (LUT variant)
 template <bool LUT, bool NT>
 __global__ void __launch_bounds__(kBlock)
 k_quant_multi(const float *__restrict__ x, float *__restrict__ y, int64_t total,
-              const float *__restrict__ maxval, QFmt f, MultiArgs a)
+              const float *__restrict__ maxval, QFmt f, TileArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     Chan *chans = reinterpret_cast<Chan *>(smem);
@@ -203,34 +236,39 @@ k_quant_multi(const float *__restrict__ x, float *__restrict__ y, int64_t total,
         const int rem0 = (int)rem;
         const int nch = (rem0 + n - 1) / a.inner + 1;
         __syncthreads();  // previous tile finished with the LDS
-        for (int j = tid; j < nch; j += kBlock) chans[j] = make_chan(maxval[ch0 + j], f);
-        if (LUT) {
-            __syncthreads();
-            for (int j = tid; j < nch * a.lut_stride; j += kBlock) {
-                const int cj = j / a.lut_stride, pj = j - cj * a.lut_stride;
-                lut[j] = lut_entry(chans[cj], pj, f.M);
-            }
-        }
-        __syncthreads();
+        build_tables(maxval + ch0, nch, chans, lut, f, a, LUT);
 
         const float *xt = x + t0;
         float *yt = y + t0;
-        for (int o = tid * 4; o < n; o += kBlock * 4) {
-            const uint32_t n0 = (uint32_t)(o + rem0);
-            int ch = div_small(n0, a.magic);
-            int r = (int)n0 - ch * a.inner;
-            if (o + 4 <= n) {
-                const vf4 v = ld16<NT>(reinterpret_cast<const vf4 *>(xt + o));
-                float e[4] = {v.x, v.y, v.z, v.w};
-                quant4_multi<LUT>(e, chans, lut, ch, r, a.inner, f, a.lut_stride);
-                vf4 w = {e[0], e[1], e[2], e[3]};
-                st16<NT>(reinterpret_cast<vf4 *>(yt + o), w);
-            } else {
-                for (int j = 0; o + j < n; ++j) {
-                    yt[o + j] = quant1_multi<LUT>(xt[o + j], chans, lut, ch, f, a.lut_stride);
-                    if (++r == a.inner) {
-                        r = 0;
-                        ++ch;
+        constexpr int U = 2;   // two 16-byte loads in flight per lane
+        for (int o0 = tid * 4; o0 < n; o0 += kBlock * 4 * U) {
+            vf4 v[U];
+            bool full[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int o = o0 + u * kBlock * 4;
+                full[u] = o + 4 <= n;
+                if (full[u]) v[u] = ld16<NT>(reinterpret_cast<const vf4 *>(xt + o));
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int o = o0 + u * kBlock * 4;
+                if (o >= n) break;
+                const uint32_t n0 = (uint32_t)(o + rem0);
+                int ch = div_small(n0, a.magic);
+                int r = (int)n0 - ch * a.inner;
+                if (full[u]) {
+                    float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+                    quant4_tile<LUT>(e, chans, lut, ch, r, f, a);
+                    vf4 w = {e[0], e[1], e[2], e[3]};
+                    st16<NT>(reinterpret_cast<vf4 *>(yt + o), w);
+                } else {
+                    for (int j = 0; o + j < n; ++j) {
+                        yt[o + j] = quant1_tile<LUT>(xt[o + j], chans, lut, ch, f, a);
+                        if (++r == a.inner) {
+                            r = 0;
+                            ++ch;
+                        }
                     }
                 }
             }
@@ -399,31 +437,27 @@ k_minmax_waverow(const float *__restrict__ x, int64_t C, int inner, float *cur_m
 
 // ---------------------------------------------------------------------------------------------
 // K2+K5+K1 fused (weights, estimate_ranges state): R whole rows per block staged in LDS.
-// Dynamic LDS: float xs[xs_floats] | Chan chans[R] | float2 lut[R * lut_stride] (LUT only)
+// Dynamic LDS: float xs[xs_floats] | float rowmv[R] | Chan chans[R] | float2 lut[R * lut_stride]
+//   A  stage the rows (coalesced 16-byte loads), row min/max with `group` lanes per row
+//   B-D as above, reading x from LDS
 // ---------------------------------------------------------------------------------------------
-struct FusedArgs {
-    int inner;
-    int rows_per_block;
-    int lut_stride;   // pmax + 1
-    int xs_floats;    // LDS floats reserved for the x tile (multiple of 4)
-    uint32_t magic;
-};
-
 template <bool LUT>
 __global__ void __launch_bounds__(kBlock)
 k_minmax_quant(const float *__restrict__ x, float *__restrict__ y, int64_t C, float *row_min,
-               float *row_max, float *maxval_out, QFmt f, FusedArgs a)
+               float *row_max, float *maxval_out, QFmt f, TileArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int Rmax = a.tile;
     float *xs = reinterpret_cast<float *>(smem);
-    Chan *chans = reinterpret_cast<Chan *>(smem + (size_t)a.xs_floats * 4);
-    float2 *lut = reinterpret_cast<float2 *>(smem + (size_t)a.xs_floats * 4 +
-                                             (size_t)a.rows_per_block * sizeof(Chan));
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    float *rowmv = xs + a.xs_floats;
+    Chan *chans = reinterpret_cast<Chan *>(rowmv + ((Rmax + 3) & ~3));
+    float2 *lut = reinterpret_cast<float2 *>(chans + Rmax);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int G = a.group, rows_per_pass = kBlock / G;
+    const int sub = tid & (G - 1), slot = tid / G;
 
-    for (int64_t r0 = (int64_t)blockIdx.x * a.rows_per_block; r0 < C;
-         r0 += (int64_t)gridDim.x * a.rows_per_block) {
-        const int R = (int)((C - r0) < a.rows_per_block ? (C - r0) : a.rows_per_block);
+    for (int64_t r0 = (int64_t)blockIdx.x * Rmax; r0 < C; r0 += (int64_t)gridDim.x * Rmax) {
+        const int R = (int)((C - r0) < Rmax ? (C - r0) : Rmax);
         const int n = R * a.inner;
         const float *xt = x + r0 * a.inner;
         float *yt = y + r0 * a.inner;
@@ -434,7 +468,7 @@ k_minmax_quant(const float *__restrict__ x, float *__restrict__ y, int64_t C, fl
         const int nvec = (n - head) >> 2;
         const int tail0 = head + (nvec << 2);
         __syncthreads();
-        // ---- stage the tile: global -> LDS (read once; weights are re-read by nobody)
+        // ---- A1: stage the tile
         if (tid < head) xs[pad + tid] = xt[tid];
         if (tail0 + tid < n) xs[pad + tail0 + tid] = xt[tail0 + tid];
         {
@@ -443,66 +477,42 @@ k_minmax_quant(const float *__restrict__ x, float *__restrict__ y, int64_t C, fl
             for (int i = tid; i < nvec; i += kBlock) sv[i] = xv[i];
         }
         __syncthreads();
-        // ---- row min / max: one wave per row (R >= 4) or the whole block on one row (R == 1)
-        if (R == 1) {
-            __shared__ float s_mn[4], s_mx[4];
-            __shared__ int s_nan[4];
+        // ---- A2: row min / max, G lanes per row (G <= 64 divides the wave)
+        for (int rb = 0; rb < R; rb += rows_per_pass) {
+            const int r = rb + slot;
             MinMax m;
             mm_init(m);
-            for (int i = tid; i < a.inner; i += kBlock) mm_acc(m, xs[pad + i]);
-            mm_wave_reduce(m);
-            if (lane == 0) {
-                s_mn[wave] = m.mn;
-                s_mx[wave] = m.mx;
-                s_nan[wave] = m.nan;
-            }
-            __syncthreads();
-            float mn = fminf(fminf(s_mn[0], s_mn[1]), fminf(s_mn[2], s_mn[3]));
-            float mx = fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3]));
-            if (s_nan[0] | s_nan[1] | s_nan[2] | s_nan[3]) mn = mx = __builtin_nanf("");
-            const float mv = fabsf(tmax(fabsf(mn), mx));       // fp8_quantizer.py:236
-            const Chan c = make_chan(mv, f);
-            if (tid == 0) {
-                if (row_min) row_min[r0] = mn;
-                if (row_max) row_max[r0] = mx;
-                if (maxval_out) maxval_out[r0] = mv;
-                chans[0] = c;
-            }
-            if (LUT)
-                for (int p = tid; p < a.lut_stride; p += kBlock) lut[p] = lut_entry(c, p, f.M);
-        } else {
-            for (int r = wave; r < R; r += 4) {
+            if (r < R) {
                 const float *xr = xs + pad + r * a.inner;
-                MinMax m;
-                mm_init(m);
-                for (int i = lane; i < a.inner; i += 64) mm_acc(m, xr[i]);
-                mm_wave_reduce(m);
+                for (int i = sub; i < a.inner; i += G) mm_acc(m, xr[i]);
+            }
+            for (int off = G >> 1; off >= 1; off >>= 1) {
+                m.mn = fminf(m.mn, __shfl_xor(m.mn, off, 64));
+                m.mx = fmaxf(m.mx, __shfl_xor(m.mx, off, 64));
+                m.nan |= __shfl_xor(m.nan, off, 64);
+            }
+            if (r < R && sub == 0) {
                 if (m.nan) m.mn = m.mx = __builtin_nanf("");
                 const float mv = fabsf(tmax(fabsf(m.mn), m.mx));   // fp8_quantizer.py:236
-                // the xor-shuffle reduction leaves min/max in every lane: all lanes derive the
-                // channel constants (same cost as one lane doing it), lane 0 publishes them
-                const Chan c = make_chan(mv, f);
-                if (lane == 0) {
-                    if (row_min) row_min[r0 + r] = m.mn;
-                    if (row_max) row_max[r0 + r] = m.mx;
-                    if (maxval_out) maxval_out[r0 + r] = mv;
-                    chans[r] = c;
-                }
-                if (LUT)
-                    for (int p = lane; p < a.lut_stride; p += 64)
-                        lut[r * a.lut_stride + p] = lut_entry(c, p, f.M);
+                if (row_min) row_min[r0 + r] = m.mn;
+                if (row_max) row_max[r0 + r] = m.mx;
+                if (maxval_out) maxval_out[r0 + r] = mv;
+                rowmv[r] = mv;
             }
         }
+        (void)lane;
         __syncthreads();
-        // ---- quantize out of LDS, write coalesced
+        // ---- B, C
+        build_tables(rowmv, R, chans, lut, f, a, LUT);
+        // ---- D: quantize out of LDS, write coalesced
         if (tid < head) {
             const int ch = div_small((uint32_t)tid, a.magic);   // short rows: the head can span rows
-            yt[tid] = quant1_multi<LUT>(xs[pad + tid], chans, lut, ch, f, a.lut_stride);
+            yt[tid] = quant1_tile<LUT>(xs[pad + tid], chans, lut, ch, f, a);
         }
         if (tail0 + tid < n) {
             const int i = tail0 + tid;
             const int ch = div_small((uint32_t)i, a.magic);
-            yt[i] = quant1_multi<LUT>(xs[pad + i], chans, lut, ch, f, a.lut_stride);
+            yt[i] = quant1_tile<LUT>(xs[pad + i], chans, lut, ch, f, a);
         }
         {
             const vf4 *sv = reinterpret_cast<const vf4 *>(xs + pad + head);
@@ -513,7 +523,7 @@ k_minmax_quant(const float *__restrict__ x, float *__restrict__ y, int64_t C, fl
                 const int r = (int)n0 - ch * a.inner;
                 const vf4 v = sv[i];
                 float e[4] = {v.x, v.y, v.z, v.w};
-                quant4_multi<LUT>(e, chans, lut, ch, r, a.inner, f, a.lut_stride);
+                quant4_tile<LUT>(e, chans, lut, ch, r, f, a);
                 vf4 w = {e[0], e[1], e[2], e[3]};
                 yv[i] = w;
             }
@@ -663,7 +673,7 @@ int make_fmt(float mbits, int n_bits, int sign_bits, QFmt *f)
     f->M = M;
     f->two_E = (float)(1 << E);
     f->l_c = (float)log2((double)(2.0f - exp2f(-M)));
-    f->qthr = 0.5f - ldexpf(1.0f, (int)M - 21);
+    f->qthr = 0.5f - ldexpf(1.0f, (int)M - 20);
     f->sign_bits = sign_bits;
     f->pmax = 1 << E;
     return FP8Q_OK;
@@ -712,9 +722,10 @@ int fp8q_quantize_f32(const float *x, float *y, int64_t C, int64_t inner, const 
 
     if (per_channel && inner < 2048 && rows16 && C * inner >= 4) {
         // short rows: flat tiles
-        MultiArgs a;
+        TileArgs a = {};
         a.inner = (int)inner;
         a.lut_stride = f.pmax + 1;
+        a.lmagic = magic_of(a.lut_stride);
         const bool lut = inner >= 2 * (int64_t)a.lut_stride;
         int64_t tile = kMultiTile;
         const int64_t cap = (int64_t)(kMultiMaxCh - 2) * inner;  // keep the channel span in LDS
@@ -838,26 +849,34 @@ int fp8q_minmax_quantize_f32(const float *x, float *y, int64_t C, int64_t inner,
     if (inner > kFusedMaxElems) return FP8Q_EUNSUPPORTED;
     if ((((uintptr_t)x ^ (uintptr_t)y) & 15) != 0 || ((uintptr_t)x & 3) != 0) return FP8Q_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    FusedArgs a;
+    TileArgs a = {};
     a.inner = (int)inner;
     a.lut_stride = f.pmax + 1;
+    a.lmagic = magic_of(a.lut_stride);
     a.magic = magic_of((int)inner);
     const bool lut = inner >= 2 * (int64_t)a.lut_stride;
-    // rows per block: ~kFusedTile elements (16 KiB of LDS -> 8 blocks per CU), at least one row,
-    // and few enough that a small tensor still spreads over >= 512 blocks
+    // rows per block: ~kFusedTile elements (LDS for 4+ blocks per CU), at least one row, at most
+    // 256 (one make_chan pass), and few enough that a small tensor still spreads over >= 512 blocks
     int64_t R = kFusedTile / inner;
     if (R > 256) R = 256;
     const int64_t want = cdiv(C, 512);
     if (R > want) R = want;
     if (R < 1) R = 1;
-    a.rows_per_block = (int)R;
+    a.tile = (int)R;
+    a.max_ch = (int)R;
+    // lanes per row in the reduction: ~8 elements per lane, power of two, <= 64... or the whole
+    // block for a single long row
+    int G = 1;
+    while (G < 64 && (int64_t)G * 8 < inner) G <<= 1;
+    if (R == 1) G = 64;
+    a.group = G;
     a.xs_floats = (int)((R * inner + 3 + 3) & ~(int64_t)3) + 4;
-    size_t shmem = (size_t)a.xs_floats * 4 + (size_t)R * sizeof(Chan) +
+    size_t shmem = (size_t)a.xs_floats * 4 + (size_t)((R + 3) & ~(int64_t)3) * 4 + (size_t)R * sizeof(Chan) +
                    (lut ? (size_t)R * a.lut_stride * sizeof(float2) : 0);
     int64_t blocks = cdiv(C, R);
     if (blocks > kTargetBlocks) blocks = kTargetBlocks;
     if (shmem > 64 * 1024) {
-        // opt in to > 64 KiB of dynamic LDS once per process (the tile is capped at ~98 KiB)
+        // opt in to > 64 KiB of dynamic LDS once per process
         static int opted = 0;
         if (!opted) {
             hipError_t e = hipFuncSetAttribute((const void *)k_minmax_quant<true>,
@@ -877,7 +896,6 @@ int fp8q_minmax_quantize_f32(const float *x, float *y, int64_t C, int64_t inner,
                            C, row_min, row_max, maxval_out, f, a);
     return launch_rc();
 }
-
 
 static int mse_nsplit(int64_t C, int64_t inner, int64_t n_cand, int n_m)
 {
