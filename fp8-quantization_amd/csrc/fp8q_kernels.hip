@@ -7,14 +7,13 @@
 //
 // Kernel inventory:
 //   k_quant_rows     K1, one channel per blockIdx.y (per-tensor: one row).  Scale LUT in LDS.
-//   k_quant_multi    K1, per-channel with short rows: flat tiles that span many channels,
-//                    per-channel constants (and LUTs when rows are long enough) staged in LDS.
+//   k_rows_tile      per-channel tensors with short rows, whole rows staged in LDS, row-aligned
+//                    compute: MODE 0 = K1, MODE 1 = K2+K5+K1 fused (weights in estimate_ranges
+//                    state: one read + one write of HBM per element), MODE 2 = K2 (+fold).
 //   k_quant_scalar   K1 fallback for x / y that are not 16-byte co-aligned.
 //   k_minmax_partial K2/K3 stage 1: per-(row, split) min / max / NaN flag.
 //   k_minmax_final   K2/K3 stage 2 + K5: reduce the splits, fold into the running estimate
 //                    (current / all / EMA), write |max(|min|, max)|.
-//   k_minmax_quant   K2+K5+K1 fused for weight tensors: whole rows staged in LDS, row min/max,
-//                    maxval, LUT, quantize, one read + one write of HBM per element.
 //   k_mse_grid       K4: all candidate maxvals x mantissa widths in one pass over x.
 //   k_copy           float4 copy with K1's launch shape (measured HBM ceiling).
 #include <hip/hip_runtime.h>
@@ -30,10 +29,8 @@ namespace {
 
 constexpr int kUnroll = 4;           // 16-byte loads in flight per lane
 constexpr int kTargetBlocks = 2048;  // 256 CUs x 8 blocks
-constexpr int kMultiTile = 16384;    // elements per k_quant_multi tile (64 KiB in, 64 KiB out)
-constexpr int kMultiMaxCh = 512;     // channels per tile whose constants fit the LDS budget
-constexpr int kFusedTile = 8192;     // k_minmax_quant: elements staged per block when rows are short
-constexpr int kFusedMaxElems = 16384;  // longest row k_minmax_quant accepts (64 KiB of LDS)
+constexpr int kTileElems = 5120;     // k_rows_tile: elements staged per block (20 KiB -> ~5 blocks/CU)
+constexpr int kTileMaxInner = 16384; // longest row k_rows_tile accepts (64 KiB of LDS)
 constexpr int64_t kNtBytes = 64ll << 20;  // tensors at least this big stream with nontemporal hints
 
 // n / d == umulhi(n, magic) for n * d < 2^32; magic == 0 encodes d == 1
@@ -113,36 +110,53 @@ k_quant_rows(const float *__restrict__ x, float *__restrict__ y, int64_t inner,
 }
 
 // ---------------------------------------------------------------------------------------------
-// Short rows (inner < 2048): tiles of whole-or-partial rows with per-channel tables in LDS.
-// Shared by k_quant_multi (K1) and k_minmax_quant (K2+K5+K1).  Phases of one tile:
-//   B  make_chan for every channel the tile touches   (one pass: thread j <-> channel j)
+// Short rows (per-channel tensors whose rows fit in LDS): k_rows_tile.
+// A block owns R WHOLE rows at a time, staged in LDS with coalesced 16-byte loads; all per-row
+// work is then row-aligned (G lanes walk one row), so channel constants are loaded once per row
+// and the inner loop is the same lean quant_group as the per-tensor kernel.  Phases of a tile:
+//   A1 stage rows global -> LDS                    A2 row min/max, G lanes per row   (MODE 1, 2)
+//   B  make_chan for the R rows (thread j <-> row j)
 //   C  {s, 1/s} tables, entries spread over all threads (LUT variant)
-//   D  quantize; a 16-byte group that stays inside one row takes the single-channel fast path
+//   D  quantize in place in LDS, row-aligned       E  LDS -> global, coalesced 16-byte stores
+// MODE 0: K1 with given per-channel maxval;  1: fused K2+K5+K1 (current_minmax, weights in
+// estimate_ranges state);  2: K2 only (row min/max + fold into the running estimate).
+// Dynamic LDS: float xs[xs_floats] | float rowmv[R4] | Chan chans[R] | float2 lut[R*lut_stride]
 // ---------------------------------------------------------------------------------------------
 struct TileArgs {
     int inner;          // row length
-    int tile;           // elements per tile (multiple of 4) / rows per tile for the fused kernel
-    int max_ch;         // channels a tile can span
+    int rows;           // R: rows per tile
     int lut_stride;     // pmax + 1
-    int group;          // lanes per row in the fused row reduction (power of two <= 64)
-    int xs_floats;      // fused kernel: LDS floats reserved for the staged x tile
+    int group;          // G: lanes per row (power of two <= 64, or 256 = whole block)
+    int xs_floats;      // LDS floats reserved for the staged rows (multiple of 4)
     uint32_t magic;     // n / inner      (see magic_of)
     uint32_t lmagic;    // n / lut_stride
 };
 
-__device__ __forceinline__ void build_tables(const float *mv, int nch, Chan *chans, float2 *lut,
-                                             const QFmt &f, const TileArgs &a, bool with_lut)
+// torch.min / torch.max of two values (NaN from either side wins)
+__device__ __forceinline__ float tmin(float a, float b) { return (a != a) ? a : ((b != b) ? b : fminf(a, b)); }
+__device__ __forceinline__ float tmax(float a, float b) { return (a != a) ? a : ((b != b) ? b : fmaxf(a, b)); }
+
+struct FoldArgs {
+    int mode;     // FP8Q_FOLD_*
+    int first;    // no previous estimate
+    float om;     // fl32(1 - momentum)   (python double arithmetic, then cast: range_estimators.py:122)
+    float mo;     // fl32(momentum)
+};
+
+__device__ __forceinline__ void fold_store(float mn, float mx, int64_t row, float *cur_min,
+                                           float *cur_max, float *maxval_out, const FoldArgs &fa)
 {
-    const int tid = threadIdx.x;
-    for (int j = tid; j < nch; j += kBlock) chans[j] = make_chan(mv[j], f);
-    __syncthreads();
-    if (with_lut) {
-        for (int j = tid; j < nch * a.lut_stride; j += kBlock) {
-            const int cj = div_small((uint32_t)j, a.lmagic), pj = j - cj * a.lut_stride;
-            lut[j] = lut_entry(chans[cj], pj, f.M);
-        }
-        __syncthreads();
+    if (!fa.first && fa.mode == FP8Q_FOLD_ALL) {
+        mn = tmin(cur_min[row], mn);
+        mx = tmax(cur_max[row], mx);
+    } else if (!fa.first && fa.mode == FP8Q_FOLD_RUNNING) {
+        // (1-m)*new + m*cur as three separately rounded fp32 ops (no FMA: -ffp-contract=off)
+        mn = fa.om * mn + fa.mo * cur_min[row];
+        mx = fa.om * mx + fa.mo * cur_max[row];
     }
+    if (cur_min) cur_min[row] = mn;
+    if (cur_max) cur_max[row] = mx;
+    if (maxval_out) maxval_out[row] = fabsf(tmax(fabsf(mn), mx));  // fp8_quantizer.py:236
 }
 
 __device__ __forceinline__ ChanLite lite_lds(const Chan *c)
@@ -156,122 +170,138 @@ __device__ __forceinline__ ChanLite lite_lds(const Chan *c)
     return l;
 }
 
-// four consecutive elements starting in channel `ch` at offset `r` inside its row
-template <bool LUT>
-__device__ __forceinline__ void quant4_tile(float (&e)[4], const Chan *chans, const float2 *lut, int ch,
-                                            int r, const QFmt &f, const TileArgs &a)
-{
-    const float pmaxf = (float)f.pmax;
-    if (LUT) {
-        if (r + 3 < a.inner) {     // common case: the group lies inside one row
-            quant_group<4>(e, lite_lds(chans + ch), lut + ch * a.lut_stride, pmaxf, f.qthr);
-            return;
-        }
-        ChanLite c[4];
-        const float2 *l[4];
-        float yv[4];
-        bool rk[4];
-        bool any = false;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            c[j] = lite_lds(chans + ch);
-            l[j] = lut + ch * a.lut_stride;
-            yv[j] = quant_fast(e[j], c[j], l[j], pmaxf, f.qthr, rk[j]);
-            any |= rk[j];
-            if (++r == a.inner) {
-                r = 0;
-                ++ch;
-            }
-        }
-        if (__builtin_expect(any, 0)) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (rk[j]) yv[j] = quant_exact(e[j], c[j].maxv, c[j].minv, c[j].bias, l[j], pmaxf);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) e[j] = yv[j];
-    } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            e[j] = quant_direct(e[j], chans[ch], f.M);
-            if (++r == a.inner) {
-                r = 0;
-                ++ch;
-            }
-        }
-    }
-}
+constexpr int kModeQuant = 0, kModeFused = 1, kModeMinMax = 2;
 
-template <bool LUT>
-__device__ __forceinline__ float quant1_tile(float x, const Chan *chans, const float2 *lut, int ch,
-                                             const QFmt &f, const TileArgs &a)
-{
-    if (LUT) return quant_one(x, lite_lds(chans + ch), lut + ch * a.lut_stride, (float)f.pmax, f.qthr);
-    return quant_direct(x, chans[ch], f.M);
-}
-
-// K1 multi.  Dynamic LDS: Chan chans[max_ch] | float2 lut[max_ch * lut_stride] (LUT variant)
-template <bool LUT, bool NT>
+template <int MODE, bool LUT, bool NT>
 __global__ void __launch_bounds__(kBlock)
-k_quant_multi(const float *__restrict__ x, float *__restrict__ y, int64_t total,
-              const float *__restrict__ maxval, QFmt f, TileArgs a)
+k_rows_tile(const float *__restrict__ x, float *__restrict__ y, int64_t C,
+            const float *__restrict__ maxval, float *row_min, float *row_max, float *maxval_out,
+            QFmt f, TileArgs a, FoldArgs fa)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    Chan *chans = reinterpret_cast<Chan *>(smem);
-    float2 *lut = reinterpret_cast<float2 *>(smem + (size_t)a.max_ch * sizeof(Chan));
+    const int Rmax = a.rows;
+    float *xs = reinterpret_cast<float *>(smem);
+    float *rowmv = xs + a.xs_floats;
+    Chan *chans = reinterpret_cast<Chan *>(rowmv + ((Rmax + 3) & ~3));
+    float2 *lut = reinterpret_cast<float2 *>(chans + Rmax);
+    __shared__ float s_mn[4], s_mx[4];
+    __shared__ int s_nan[4];
     const int tid = threadIdx.x;
+    const int G = a.group;
+    const int rows_per_pass = G >= kBlock ? 1 : kBlock / G;
+    const int sub = tid & (G - 1), slot = G >= kBlock ? 0 : tid / G;
+    const float pmaxf = (float)f.pmax;
 
-    for (int64_t t0 = (int64_t)blockIdx.x * a.tile; t0 < total; t0 += (int64_t)gridDim.x * a.tile) {
-        const int n = (int)((total - t0) < a.tile ? (total - t0) : a.tile);
-        // first channel of the tile: double division + one-step correction (t0 < 2^53)
-        int64_t ch0 = (int64_t)((double)t0 / (double)a.inner);
-        int64_t rem = t0 - ch0 * a.inner;
-        if (rem < 0) {
-            --ch0;
-            rem += a.inner;
-        } else if (rem >= a.inner) {
-            ++ch0;
-            rem -= a.inner;
+    for (int64_t r0 = (int64_t)blockIdx.x * Rmax; r0 < C; r0 += (int64_t)gridDim.x * Rmax) {
+        const int R = (int)((C - r0) < Rmax ? (C - r0) : Rmax);
+        const int n = R * a.inner;
+        const float *xt = x + r0 * a.inner;
+        // LDS index = pad + i so that LDS and global addresses share their 16-byte phase
+        const int pad = (int)(((uintptr_t)xt & 15) >> 2);
+        int head = (4 - pad) & 3;
+        if (head > n) head = n;
+        const int nvec = (n - head) >> 2;
+        const int tail0 = head + (nvec << 2);
+        __syncthreads();   // previous tile finished with the LDS
+        // ---- A1: stage the rows
+        if (tid < head) xs[pad + tid] = xt[tid];
+        if (tail0 + tid < n) xs[pad + tail0 + tid] = xt[tail0 + tid];
+        {
+            const vf4 *xv = reinterpret_cast<const vf4 *>(xt + head);
+            vf4 *sv = reinterpret_cast<vf4 *>(xs + pad + head);
+            for (int i = tid; i < nvec; i += kBlock) sv[i] = ld16<NT>(xv + i);
         }
-        const int rem0 = (int)rem;
-        const int nch = (rem0 + n - 1) / a.inner + 1;
-        __syncthreads();  // previous tile finished with the LDS
-        build_tables(maxval + ch0, nch, chans, lut, f, a, LUT);
-
-        const float *xt = x + t0;
-        float *yt = y + t0;
-        constexpr int U = 2;   // two 16-byte loads in flight per lane
-        for (int o0 = tid * 4; o0 < n; o0 += kBlock * 4 * U) {
-            vf4 v[U];
-            bool full[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int o = o0 + u * kBlock * 4;
-                full[u] = o + 4 <= n;
-                if (full[u]) v[u] = ld16<NT>(reinterpret_cast<const vf4 *>(xt + o));
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int o = o0 + u * kBlock * 4;
-                if (o >= n) break;
-                const uint32_t n0 = (uint32_t)(o + rem0);
-                int ch = div_small(n0, a.magic);
-                int r = (int)n0 - ch * a.inner;
-                if (full[u]) {
-                    float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
-                    quant4_tile<LUT>(e, chans, lut, ch, r, f, a);
-                    vf4 w = {e[0], e[1], e[2], e[3]};
-                    st16<NT>(reinterpret_cast<vf4 *>(yt + o), w);
-                } else {
-                    for (int j = 0; o + j < n; ++j) {
-                        yt[o + j] = quant1_tile<LUT>(xt[o + j], chans, lut, ch, f, a);
-                        if (++r == a.inner) {
-                            r = 0;
-                            ++ch;
-                        }
+        __syncthreads();
+        // ---- A2: row min / max
+        if (MODE != kModeQuant) {
+            for (int rb = 0; rb < R; rb += rows_per_pass) {
+                const int r = rb + slot;
+                MinMax m;
+                mm_init(m);
+                if (r < R) {
+                    const float *xr = xs + pad + r * a.inner;
+                    for (int i = sub; i < a.inner; i += G) mm_acc(m, xr[i]);
+                }
+                const int gw = G < 64 ? G : 64;
+                for (int off = gw >> 1; off >= 1; off >>= 1) {
+                    m.mn = fminf(m.mn, __shfl_xor(m.mn, off, 64));
+                    m.mx = fmaxf(m.mx, __shfl_xor(m.mx, off, 64));
+                    m.nan |= __shfl_xor(m.nan, off, 64);
+                }
+                if (G >= kBlock) {   // one row over the whole block: combine the four waves
+                    if ((tid & 63) == 0) {
+                        s_mn[tid >> 6] = m.mn;
+                        s_mx[tid >> 6] = m.mx;
+                        s_nan[tid >> 6] = m.nan;
+                    }
+                    __syncthreads();
+                    m.mn = fminf(fminf(s_mn[0], s_mn[1]), fminf(s_mn[2], s_mn[3]));
+                    m.mx = fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3]));
+                    m.nan = s_nan[0] | s_nan[1] | s_nan[2] | s_nan[3];
+                    __syncthreads();
+                }
+                if (r < R && sub == 0) {
+                    if (m.nan) m.mn = m.mx = __builtin_nanf("");
+                    if (MODE == kModeMinMax) {
+                        fold_store(m.mn, m.mx, r0 + r, row_min, row_max, maxval_out, fa);
+                    } else {
+                        const float mv = fabsf(tmax(fabsf(m.mn), m.mx));   // fp8_quantizer.py:236
+                        if (row_min) row_min[r0 + r] = m.mn;
+                        if (row_max) row_max[r0 + r] = m.mx;
+                        if (maxval_out) maxval_out[r0 + r] = mv;
+                        rowmv[r] = mv;
                     }
                 }
             }
+            if (MODE == kModeMinMax) continue;
+            __syncthreads();
+        }
+        // ---- B: channel constants (one pass), C: tables
+        {
+            const float *mvsrc = MODE == kModeQuant ? maxval + r0 : rowmv;
+            for (int j = tid; j < R; j += kBlock) chans[j] = make_chan(mvsrc[j], f);
+            __syncthreads();
+            if (LUT) {
+                for (int j = tid; j < R * a.lut_stride; j += kBlock) {
+                    const int cj = div_small((uint32_t)j, a.lmagic), pj = j - cj * a.lut_stride;
+                    lut[j] = lut_entry(chans[cj], pj, f.M);
+                }
+                __syncthreads();
+            }
+        }
+        // ---- D: quantize in place, G lanes per row
+        for (int rb = 0; rb < R; rb += rows_per_pass) {
+            const int r = rb + slot;
+            if (r < R) {
+                float *xr = xs + pad + r * a.inner;
+                if (LUT) {
+                    const ChanLite c = lite_lds(chans + r);
+                    const float2 *lrow = lut + r * a.lut_stride;
+                    int i = sub;
+                    for (; i + 3 * G < a.inner; i += 4 * G) {
+                        float e[4] = {xr[i], xr[i + G], xr[i + 2 * G], xr[i + 3 * G]};
+                        quant_group<4>(e, c, lrow, pmaxf, f.qthr);
+                        xr[i] = e[0];
+                        xr[i + G] = e[1];
+                        xr[i + 2 * G] = e[2];
+                        xr[i + 3 * G] = e[3];
+                    }
+                    for (; i < a.inner; i += G) xr[i] = quant_one(xr[i], c, lrow, pmaxf, f.qthr);
+                } else {
+                    const Chan c = chans[r];
+                    for (int i = sub; i < a.inner; i += G) xr[i] = quant_direct(xr[i], c, f.M);
+                }
+            }
+        }
+        __syncthreads();
+        // ---- E: LDS -> global
+        float *yt = y + r0 * a.inner;
+        if (tid < head) yt[tid] = xs[pad + tid];
+        if (tail0 + tid < n) yt[tail0 + tid] = xs[pad + tail0 + tid];
+        {
+            const vf4 *sv = reinterpret_cast<const vf4 *>(xs + pad + head);
+            vf4 *yv = reinterpret_cast<vf4 *>(yt + head);
+            for (int i = tid; i < nvec; i += kBlock) st16<NT>(yv + i, sv[i]);
         }
     }
 }
@@ -366,33 +396,6 @@ k_minmax_partial(const float *__restrict__ x, int64_t inner, int nsplit, float *
     block_reduce_store(m, ws + ((int64_t)row * nsplit + split) * 2);
 }
 
-// torch.min / torch.max of two values (NaN from either side wins)
-__device__ __forceinline__ float tmin(float a, float b) { return (a != a) ? a : ((b != b) ? b : fminf(a, b)); }
-__device__ __forceinline__ float tmax(float a, float b) { return (a != a) ? a : ((b != b) ? b : fmaxf(a, b)); }
-
-struct FoldArgs {
-    int mode;     // FP8Q_FOLD_*
-    int first;    // no previous estimate
-    float om;     // fl32(1 - momentum)   (python double arithmetic, then cast: range_estimators.py:122)
-    float mo;     // fl32(momentum)
-};
-
-__device__ __forceinline__ void fold_store(float mn, float mx, int64_t row, float *cur_min,
-                                           float *cur_max, float *maxval_out, const FoldArgs &fa)
-{
-    if (!fa.first && fa.mode == FP8Q_FOLD_ALL) {
-        mn = tmin(cur_min[row], mn);
-        mx = tmax(cur_max[row], mx);
-    } else if (!fa.first && fa.mode == FP8Q_FOLD_RUNNING) {
-        // (1-m)*new + m*cur as three separately rounded fp32 ops (no FMA: -ffp-contract=off)
-        mn = fa.om * mn + fa.mo * cur_min[row];
-        mx = fa.om * mx + fa.mo * cur_max[row];
-    }
-    if (cur_min) cur_min[row] = mn;
-    if (cur_max) cur_max[row] = mx;
-    if (maxval_out) maxval_out[row] = fabsf(tmax(fabsf(mn), mx));  // fp8_quantizer.py:236
-}
-
 // K2/K3 stage 2: one wave per row reduces the row's splits
 __global__ void __launch_bounds__(kBlock)
 k_minmax_final(const float *__restrict__ ws, int64_t C, int nsplit, float *cur_min, float *cur_max,
@@ -412,122 +415,6 @@ k_minmax_final(const float *__restrict__ ws, int64_t C, int nsplit, float *cur_m
     if (lane == 0) {
         if (m.nan) m.mn = m.mx = __builtin_nanf("");
         fold_store(m.mn, m.mx, row, cur_min, cur_max, maxval_out, fa);
-    }
-}
-
-// K2 for short rows: one wave per row, no workspace, fold fused
-__global__ void __launch_bounds__(kBlock)
-k_minmax_waverow(const float *__restrict__ x, int64_t C, int inner, float *cur_min, float *cur_max,
-                 float *maxval_out, FoldArgs fa)
-{
-    const int lane = threadIdx.x & 63;
-    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < C;
-         row += (int64_t)gridDim.x * 4) {
-        const float *xr = x + row * inner;
-        MinMax m;
-        mm_init(m);
-        for (int i = lane; i < inner; i += 64) mm_acc(m, xr[i]);
-        mm_wave_reduce(m);
-        if (lane == 0) {
-            if (m.nan) m.mn = m.mx = __builtin_nanf("");
-            fold_store(m.mn, m.mx, row, cur_min, cur_max, maxval_out, fa);
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// K2+K5+K1 fused (weights, estimate_ranges state): R whole rows per block staged in LDS.
-// Dynamic LDS: float xs[xs_floats] | float rowmv[R] | Chan chans[R] | float2 lut[R * lut_stride]
-//   A  stage the rows (coalesced 16-byte loads), row min/max with `group` lanes per row
-//   B-D as above, reading x from LDS
-// ---------------------------------------------------------------------------------------------
-template <bool LUT>
-__global__ void __launch_bounds__(kBlock)
-k_minmax_quant(const float *__restrict__ x, float *__restrict__ y, int64_t C, float *row_min,
-               float *row_max, float *maxval_out, QFmt f, TileArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int Rmax = a.tile;
-    float *xs = reinterpret_cast<float *>(smem);
-    float *rowmv = xs + a.xs_floats;
-    Chan *chans = reinterpret_cast<Chan *>(rowmv + ((Rmax + 3) & ~3));
-    float2 *lut = reinterpret_cast<float2 *>(chans + Rmax);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int G = a.group, rows_per_pass = kBlock / G;
-    const int sub = tid & (G - 1), slot = tid / G;
-
-    for (int64_t r0 = (int64_t)blockIdx.x * Rmax; r0 < C; r0 += (int64_t)gridDim.x * Rmax) {
-        const int R = (int)((C - r0) < Rmax ? (C - r0) : Rmax);
-        const int n = R * a.inner;
-        const float *xt = x + r0 * a.inner;
-        float *yt = y + r0 * a.inner;
-        // LDS index = pad + i so that LDS and global addresses share their 16-byte phase
-        const int pad = (int)(((uintptr_t)xt & 15) >> 2);
-        int head = (4 - pad) & 3;
-        if (head > n) head = n;
-        const int nvec = (n - head) >> 2;
-        const int tail0 = head + (nvec << 2);
-        __syncthreads();
-        // ---- A1: stage the tile
-        if (tid < head) xs[pad + tid] = xt[tid];
-        if (tail0 + tid < n) xs[pad + tail0 + tid] = xt[tail0 + tid];
-        {
-            const vf4 *xv = reinterpret_cast<const vf4 *>(xt + head);
-            vf4 *sv = reinterpret_cast<vf4 *>(xs + pad + head);
-            for (int i = tid; i < nvec; i += kBlock) sv[i] = xv[i];
-        }
-        __syncthreads();
-        // ---- A2: row min / max, G lanes per row (G <= 64 divides the wave)
-        for (int rb = 0; rb < R; rb += rows_per_pass) {
-            const int r = rb + slot;
-            MinMax m;
-            mm_init(m);
-            if (r < R) {
-                const float *xr = xs + pad + r * a.inner;
-                for (int i = sub; i < a.inner; i += G) mm_acc(m, xr[i]);
-            }
-            for (int off = G >> 1; off >= 1; off >>= 1) {
-                m.mn = fminf(m.mn, __shfl_xor(m.mn, off, 64));
-                m.mx = fmaxf(m.mx, __shfl_xor(m.mx, off, 64));
-                m.nan |= __shfl_xor(m.nan, off, 64);
-            }
-            if (r < R && sub == 0) {
-                if (m.nan) m.mn = m.mx = __builtin_nanf("");
-                const float mv = fabsf(tmax(fabsf(m.mn), m.mx));   // fp8_quantizer.py:236
-                if (row_min) row_min[r0 + r] = m.mn;
-                if (row_max) row_max[r0 + r] = m.mx;
-                if (maxval_out) maxval_out[r0 + r] = mv;
-                rowmv[r] = mv;
-            }
-        }
-        (void)lane;
-        __syncthreads();
-        // ---- B, C
-        build_tables(rowmv, R, chans, lut, f, a, LUT);
-        // ---- D: quantize out of LDS, write coalesced
-        if (tid < head) {
-            const int ch = div_small((uint32_t)tid, a.magic);   // short rows: the head can span rows
-            yt[tid] = quant1_tile<LUT>(xs[pad + tid], chans, lut, ch, f, a);
-        }
-        if (tail0 + tid < n) {
-            const int i = tail0 + tid;
-            const int ch = div_small((uint32_t)i, a.magic);
-            yt[i] = quant1_tile<LUT>(xs[pad + i], chans, lut, ch, f, a);
-        }
-        {
-            const vf4 *sv = reinterpret_cast<const vf4 *>(xs + pad + head);
-            vf4 *yv = reinterpret_cast<vf4 *>(yt + head);
-            for (int i = tid; i < nvec; i += kBlock) {
-                const uint32_t n0 = (uint32_t)(head + i * 4);
-                const int ch = div_small(n0, a.magic);
-                const int r = (int)n0 - ch * a.inner;
-                const vf4 v = sv[i];
-                float e[4] = {v.x, v.y, v.z, v.w};
-                quant4_tile<LUT>(e, chans, lut, ch, r, f, a);
-                vf4 w = {e[0], e[1], e[2], e[3]};
-                yv[i] = w;
-            }
-        }
     }
 }
 
@@ -685,6 +572,73 @@ inline int launch_rc() { return hip_rc(hipGetLastError()); }
 
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Launch k_rows_tile for [C, inner] (inner <= kTileMaxInner).  MODE 0: y, maxval;  1: y, outputs;
+// 2: outputs = running estimate (row_min/row_max) + maxval_out, folded with `fa`.
+int launch_rows_tile(int mode, const float *x, float *y, int64_t C, int64_t inner, const float *maxval,
+                     float *row_min, float *row_max, float *maxval_out, const QFmt &f, const FoldArgs &fa,
+                     hipStream_t st)
+{
+    TileArgs a = {};
+    a.inner = (int)inner;
+    a.lut_stride = f.pmax + 1;
+    a.lmagic = magic_of(a.lut_stride);
+    a.magic = magic_of((int)inner);
+    const bool lut = mode != kModeMinMax && inner >= 2 * (int64_t)a.lut_stride;
+    // lanes per row: ~8 elements per lane, power of two <= 64; a long row takes the whole block
+    int G = 1;
+    while (G < 64 && (int64_t)G * 8 < inner) G <<= 1;
+    int64_t R = kTileElems / inner;
+    if (inner * 4 > kTileElems) {   // long rows: one row per tile, all 256 threads on it
+        R = 1;
+        G = kBlock;
+    } else {
+        const int rpp = kBlock / G;                // rows per pass: keep R a multiple of it
+        if (R > 256) R = 256;                      // one make_chan pass
+        const int64_t want = cdiv(C, 1024);        // small tensors: spread over >= ~1024 blocks
+        if (R > want) R = want;
+        if (R >= rpp) R -= R % rpp;
+        if (R < 1) R = 1;
+    }
+    a.rows = (int)R;
+    a.group = G;
+    a.xs_floats = (int)((R * inner + 3 + 3) & ~(int64_t)3) + 4;
+    const size_t shmem = (size_t)a.xs_floats * 4 + (size_t)((R + 3) & ~(int64_t)3) * 4 +
+                         (size_t)R * sizeof(Chan) + (lut ? (size_t)R * a.lut_stride * sizeof(float2) : 0);
+    int64_t blocks = cdiv(C, R);
+    if (blocks > 2 * kTargetBlocks) blocks = 2 * kTargetBlocks;
+    const bool nt = C * inner * 4 >= kNtBytes;
+    const dim3 g((unsigned)blocks), b(kBlock);
+#define FP8Q_LAUNCH_TILE(M, L, N)                                                                       \
+    do {                                                                                                \
+        if (shmem > 64 * 1024) {                                                                        \
+            static int opted = 0;                                                                       \
+            if (!opted) {                                                                               \
+                hipError_t e = hipFuncSetAttribute((const void *)k_rows_tile<M, L, N>,                  \
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
+                if (e != hipSuccess) return (int)e;                                                     \
+                opted = 1;                                                                              \
+            }                                                                                           \
+        }                                                                                               \
+        hipLaunchKernelGGL((k_rows_tile<M, L, N>), g, b, shmem, st, x, y, C, maxval, row_min, row_max,  \
+                           maxval_out, f, a, fa);                                                       \
+    } while (0)
+    if (mode == kModeMinMax) {
+        if (nt) FP8Q_LAUNCH_TILE(kModeMinMax, false, true); else FP8Q_LAUNCH_TILE(kModeMinMax, false, false);
+    } else if (mode == kModeQuant) {
+        if (lut && nt) FP8Q_LAUNCH_TILE(kModeQuant, true, true);
+        else if (lut) FP8Q_LAUNCH_TILE(kModeQuant, true, false);
+        else if (nt) FP8Q_LAUNCH_TILE(kModeQuant, false, true);
+        else FP8Q_LAUNCH_TILE(kModeQuant, false, false);
+    } else {
+        if (lut && nt) FP8Q_LAUNCH_TILE(kModeFused, true, true);
+        else if (lut) FP8Q_LAUNCH_TILE(kModeFused, true, false);
+        else if (nt) FP8Q_LAUNCH_TILE(kModeFused, false, true);
+        else FP8Q_LAUNCH_TILE(kModeFused, false, false);
+    }
+#undef FP8Q_LAUNCH_TILE
+    return launch_rc();
+}
+
 }  // namespace
 
 extern "C" {
@@ -717,41 +671,12 @@ int fp8q_quantize_f32(const float *x, float *y, int64_t C, int64_t inner, const 
         C = 1;
     }
     const bool aligned = (((uintptr_t)x ^ (uintptr_t)y) & 15) == 0 && ((uintptr_t)x & 3) == 0;
-    const bool rows16 = ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0;
     const bool nt = C * inner * 4 >= kNtBytes;
 
-    if (per_channel && inner < 2048 && rows16 && C * inner >= 4) {
-        // short rows: flat tiles
-        TileArgs a = {};
-        a.inner = (int)inner;
-        a.lut_stride = f.pmax + 1;
-        a.lmagic = magic_of(a.lut_stride);
-        const bool lut = inner >= 2 * (int64_t)a.lut_stride;
-        int64_t tile = kMultiTile;
-        const int64_t cap = (int64_t)(kMultiMaxCh - 2) * inner;  // keep the channel span in LDS
-        if (tile > cap) tile = cap;
-        const int64_t total = C * inner;
-        // small tensors: shrink the tile so that every CU gets work
-        while (tile > 1024 && cdiv(total, tile) < 512) tile >>= 1;
-        tile &= ~(int64_t)3;
-        if (tile < 4) tile = 4;
-        a.tile = (int)tile;
-        a.max_ch = (int)((tile + inner - 2) / inner + 1);
-        a.magic = magic_of((int)inner);
-        int64_t blocks = cdiv(total, tile);
-        if (blocks > kTargetBlocks) blocks = kTargetBlocks;
-        const size_t shmem =
-            (size_t)a.max_ch * sizeof(Chan) + (lut ? (size_t)a.max_ch * a.lut_stride * sizeof(float2) : 0);
-        const dim3 g((unsigned)blocks), b(kBlock);
-        if (lut && nt)
-            hipLaunchKernelGGL((k_quant_multi<true, true>), g, b, shmem, st, x, y, total, maxval, f, a);
-        else if (lut)
-            hipLaunchKernelGGL((k_quant_multi<true, false>), g, b, shmem, st, x, y, total, maxval, f, a);
-        else if (nt)
-            hipLaunchKernelGGL((k_quant_multi<false, true>), g, b, shmem, st, x, y, total, maxval, f, a);
-        else
-            hipLaunchKernelGGL((k_quant_multi<false, false>), g, b, shmem, st, x, y, total, maxval, f, a);
-        return launch_rc();
+    if (per_channel && inner < 2048 && aligned) {
+        // short rows: whole rows staged in LDS
+        const FoldArgs nofold = {0, 1, 0.0f, 0.0f};
+        return launch_rows_tile(kModeQuant, x, y, C, inner, maxval, nullptr, nullptr, nullptr, f, nofold, st);
     }
     if (C > 65535) {
         // very many long rows: one launch per 65535 rows (gridDim.y limit)
@@ -795,7 +720,7 @@ static int minmax_nsplit(int64_t C, int64_t inner)
 size_t fp8q_minmax_workspace_bytes(int64_t C, int64_t inner)
 {
     if (C <= 0 || inner <= 0) return 16;
-    if (inner < 2048) return 16;  // wave-per-row path needs none
+    if (inner < 2048 && C > 1) return 16;  // row-tile path needs none
     return (size_t)C * (size_t)minmax_nsplit(C, inner) * 2 * sizeof(float) + 16;
 }
 
@@ -811,12 +736,10 @@ int fp8q_minmax_f32(const float *x, int64_t C, int64_t inner, float *cur_min, fl
     fa.first = first != 0;
     fa.om = (float)(1.0 - momentum);
     fa.mo = (float)momentum;
-    if (inner < 2048) {
-        int64_t blocks = cdiv(C, 4);
-        if (blocks > kTargetBlocks * 2) blocks = kTargetBlocks * 2;
-        hipLaunchKernelGGL(k_minmax_waverow, dim3((unsigned)blocks), dim3(kBlock), 0, st, x, C,
-                           (int)inner, cur_min, cur_max, maxval_out, fa);
-        return launch_rc();
+    if (inner < 2048 && C > 1 && ((uintptr_t)x & 3) == 0) {
+        QFmt f = {};
+        return launch_rows_tile(kModeMinMax, x, nullptr, C, inner, nullptr, cur_min, cur_max, maxval_out, f,
+                                fa, st);
     }
     if (ws_bytes < fp8q_minmax_workspace_bytes(C, inner) || !ws) return FP8Q_EWORKSPACE;
     const int ns = minmax_nsplit(C, inner);
@@ -835,7 +758,7 @@ int fp8q_minmax_f32(const float *x, int64_t C, int64_t inner, float *cur_min, fl
     return launch_rc();
 }
 
-int64_t fp8q_fused_max_inner(void) { return kFusedMaxElems; }
+int64_t fp8q_fused_max_inner(void) { return kTileMaxInner; }
 
 int fp8q_minmax_quantize_f32(const float *x, float *y, int64_t C, int64_t inner, float *row_min,
                              float *row_max, float *maxval_out, float mbits, int n_bits,
@@ -846,55 +769,11 @@ int fp8q_minmax_quantize_f32(const float *x, float *y, int64_t C, int64_t inner,
     if (int rc = make_fmt(mbits, n_bits, sign_bits, &f)) return rc;
     if (C == 0 || inner == 0) return FP8Q_OK;
     if (!x || !y) return FP8Q_EINVAL;
-    if (inner > kFusedMaxElems) return FP8Q_EUNSUPPORTED;
+    if (inner > kTileMaxInner) return FP8Q_EUNSUPPORTED;
     if ((((uintptr_t)x ^ (uintptr_t)y) & 15) != 0 || ((uintptr_t)x & 3) != 0) return FP8Q_EINVAL;
-    hipStream_t st = (hipStream_t)stream;
-    TileArgs a = {};
-    a.inner = (int)inner;
-    a.lut_stride = f.pmax + 1;
-    a.lmagic = magic_of(a.lut_stride);
-    a.magic = magic_of((int)inner);
-    const bool lut = inner >= 2 * (int64_t)a.lut_stride;
-    // rows per block: ~kFusedTile elements (LDS for 4+ blocks per CU), at least one row, at most
-    // 256 (one make_chan pass), and few enough that a small tensor still spreads over >= 512 blocks
-    int64_t R = kFusedTile / inner;
-    if (R > 256) R = 256;
-    const int64_t want = cdiv(C, 512);
-    if (R > want) R = want;
-    if (R < 1) R = 1;
-    a.tile = (int)R;
-    a.max_ch = (int)R;
-    // lanes per row in the reduction: ~8 elements per lane, power of two, <= 64... or the whole
-    // block for a single long row
-    int G = 1;
-    while (G < 64 && (int64_t)G * 8 < inner) G <<= 1;
-    if (R == 1) G = 64;
-    a.group = G;
-    a.xs_floats = (int)((R * inner + 3 + 3) & ~(int64_t)3) + 4;
-    size_t shmem = (size_t)a.xs_floats * 4 + (size_t)((R + 3) & ~(int64_t)3) * 4 + (size_t)R * sizeof(Chan) +
-                   (lut ? (size_t)R * a.lut_stride * sizeof(float2) : 0);
-    int64_t blocks = cdiv(C, R);
-    if (blocks > kTargetBlocks) blocks = kTargetBlocks;
-    if (shmem > 64 * 1024) {
-        // opt in to > 64 KiB of dynamic LDS once per process
-        static int opted = 0;
-        if (!opted) {
-            hipError_t e = hipFuncSetAttribute((const void *)k_minmax_quant<true>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-            if (e == hipSuccess)
-                e = hipFuncSetAttribute((const void *)k_minmax_quant<false>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-            if (e != hipSuccess) return (int)e;
-            opted = 1;
-        }
-    }
-    if (lut)
-        hipLaunchKernelGGL(k_minmax_quant<true>, dim3((unsigned)blocks), dim3(kBlock), shmem, st, x, y, C,
-                           row_min, row_max, maxval_out, f, a);
-    else
-        hipLaunchKernelGGL(k_minmax_quant<false>, dim3((unsigned)blocks), dim3(kBlock), shmem, st, x, y,
-                           C, row_min, row_max, maxval_out, f, a);
-    return launch_rc();
+    const FoldArgs nofold = {0, 1, 0.0f, 0.0f};
+    return launch_rows_tile(kModeFused, x, y, C, inner, nullptr, row_min, row_max, maxval_out, f, nofold,
+                            (hipStream_t)stream);
 }
 
 static int mse_nsplit(int64_t C, int64_t inner, int64_t n_cand, int n_m)
