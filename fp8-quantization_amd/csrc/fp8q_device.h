@@ -48,6 +48,9 @@ struct __attribute__((aligned(16))) Chan {
     float pthr;      // 0.5 - 2^-15, or -1: every element takes the exact path
     double g;        // 2^-(bias - floor(bias))  in (0.5, 1]
     double bias_d;   // (double)bias
+    float m0;        // fl32(g)
+    int bi;          // floor(bias), clamped (non-finite bias: g is NaN anyway)
+    float pad0, pad1;
 };
 
 // bias, clamp bounds and scale constants of one channel (fp8_quantizer.py:108-113)
@@ -63,8 +66,12 @@ __device__ __forceinline__ Chan make_chan(float maxv, const QFmt &f)
     c.bias = b;
     // fast-path preconditions: every scale and its reciprocal are normal fp32 numbers
     c.pthr = (b > -100.0f && b < 100.0f && maxv < 0x1p120f) ? (0.5f - 0x1p-15f) : -1.0f;
-    c.g = exp2(-(double)(b - floorf(b)));           // b - floor(b) is exact in fp32
+    const float fb = floorf(b);
+    c.g = exp2(-(double)(b - fb));                  // b - floor(b) is exact in fp32
     c.bias_d = (double)b;
+    c.m0 = (float)c.g;
+    c.bi = (int)fminf(fmaxf(fb, -16384.0f), 16384.0f);
+    c.pad0 = c.pad1 = 0.0f;
     return c;
 }
 
@@ -78,16 +85,23 @@ __device__ __forceinline__ float scale_exact(const Chan &c, float ls, float M)
     const double u = delta * 0.69314718055994530942;
     const double t = fma(u, 0.5 * u, u);            // 2^delta - 1
     const double s = fma(c.g, t, c.g);              // g * 2^delta
-    const float fb = floorf(c.bias);
-    const int n = (int)k - (int)fminf(fmaxf(fb, -16384.0f), 16384.0f);  // non-finite bias: s is NaN
-    return (float)ldexp(s, n);                      // one rounding to fp32 (denormals included)
+    return (float)ldexp(s, (int)k - c.bi);          // one rounding to fp32 (denormals included)
 }
 
 // {s, 1/s} table entry for p (entry 0 is never selected by a finite p; it holds NaN)
 __device__ __forceinline__ float2 lut_entry(const Chan &c, int p, float M)
 {
     if (p == 0) return make_float2(__builtin_nanf(""), __builtin_nanf(""));
-    const float s = scale_exact(c, (float)p, M);
+    // Shortcut: fl32(k - bias) is EXACT unless |k - bias| falls in a higher binade than bias
+    // (k - e == bias  <=>  no rounding happened).  Then 2^e = 2^(k - bi) * g exactly and, in the
+    // normal range (pthr >= 0 guarantees it), its fp32 rounding is ldexp(fl32(g), k - bi).
+    const float k = (float)p - M;
+    const float e = k - c.bias;
+    float s;
+    if ((k - e) == c.bias && c.pthr >= 0.0f)
+        s = ldexpf(c.m0, (int)k - c.bi);
+    else
+        s = scale_exact(c, (float)p, M);
     return make_float2(s, __builtin_amdgcn_rcpf(s));   // 1-ulp reciprocal: see QFmt::qthr
 }
 

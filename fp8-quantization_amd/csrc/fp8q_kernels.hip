@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/fp8q.h"
 #include "fp8q_device.h"
@@ -587,8 +588,13 @@ int launch_rows_tile(int mode, const float *x, float *y, int64_t C, int64_t inne
     // lanes per row: ~8 elements per lane, power of two <= 64; a long row takes the whole block
     int G = 1;
     while (G < 64 && (int64_t)G * 8 < inner) G <<= 1;
-    int64_t R = kTileElems / inner;
-    if (inner * 4 > kTileElems) {   // long rows: one row per tile, all 256 threads on it
+    static const int tile_elems = [] {   // tuning knob for experiments (default kTileElems)
+        const char *e = getenv("FP8Q_TILE_ELEMS");
+        const int v = e ? atoi(e) : 0;
+        return v >= 256 && v <= kTileMaxInner ? v : kTileElems;
+    }();
+    int64_t R = tile_elems / inner;
+    if (inner * 4 > tile_elems) {   // long rows: one row per tile, all 256 threads on it
         R = 1;
         G = kBlock;
     } else {

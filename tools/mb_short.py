@@ -1,0 +1,22 @@
+"""short-row kernels only (quick A/B)"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "fp8-quantization_amd")]
+import torch, fp8q
+from microbench import timeit, report
+ops = fp8q.ops
+dev = "cuda"
+N = 1 << 21
+xw = (torch.randn(N * 147, device=dev) * 0.1).view(N, 3, 7, 7)
+yw = torch.empty_like(xw)
+mn, mx, mvw = ops.minmax(xw, True, want_maxval=True)
+tag = os.environ.get("FP8Q_TILE_ELEMS", "default")
+report(f"[{tag}] K1 [2^21,3,7,7] E5M2", N * 147, 8, timeit(lambda: ops.quantize(xw, mvw, 2, 8, 1, out=yw)))
+report(f"[{tag}] K1 [2^21,3,7,7] E4M3", N * 147, 8, timeit(lambda: ops.quantize(xw, mvw, 3, 8, 1, out=yw)))
+report(f"[{tag}] K2 [2^21,3,7,7]", N * 147, 4, timeit(lambda: ops.minmax(xw, True)))
+report(f"[{tag}] fused [2^21,3,7,7] E5M2", N * 147, 8, timeit(lambda: ops.minmax_quantize(xw, 2, 8, 1, out=yw)))
+x6 = xw.view(-1)[: (1 << 19) * 576].view(1 << 19, 64, 3, 3)
+y6 = yw.view(-1)[: x6.numel()].view_as(x6)
+mv6 = torch.rand(x6.shape[0], device=dev) + 0.5
+report(f"[{tag}] K1 [2^19,64,3,3] E5M2", x6.numel(), 8, timeit(lambda: ops.quantize(x6, mv6, 2, 8, 1, out=y6)))
+report(f"[{tag}] fused [2^19,64,3,3] E5M2", x6.numel(), 8, timeit(lambda: ops.minmax_quantize(x6, 2, 8, 1, out=y6)))
