@@ -29,6 +29,8 @@
 namespace fp8q {
 
 typedef float vf4 __attribute__((ext_vector_type(4)));
+// 16 bytes at 4-byte alignment: still one global_load/store_dwordx4 on gfx950
+typedef float vf4u __attribute__((ext_vector_type(4), aligned(4)));
 
 constexpr int kBlock = 256;
 constexpr int kLutMax = 130;   // 2^7 + 1 entries (+1 pad)
@@ -214,6 +216,25 @@ __device__ __forceinline__ void st16(vf4 *p, vf4 v)
         __builtin_nontemporal_store(v, p);
     else
         *p = v;
+}
+
+template <bool NT>
+__device__ __forceinline__ vf4 ld16u(const float *p)
+{
+    const vf4u *q = reinterpret_cast<const vf4u *>(p);
+    vf4u v = NT ? __builtin_nontemporal_load(q) : *q;
+    return vf4{v.x, v.y, v.z, v.w};
+}
+
+template <bool NT>
+__device__ __forceinline__ void st16u(float *p, vf4 v)
+{
+    vf4u *q = reinterpret_cast<vf4u *>(p);
+    vf4u w = {v.x, v.y, v.z, v.w};
+    if (NT)
+        __builtin_nontemporal_store(w, q);
+    else
+        *q = w;
 }
 
 // ---- wave / block reductions (wave = 64 lanes) ---------------------------------------------

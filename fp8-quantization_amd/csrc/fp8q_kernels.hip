@@ -32,6 +32,8 @@ constexpr int kUnroll = 4;           // 16-byte loads in flight per lane
 constexpr int kTargetBlocks = 2048;  // 256 CUs x 8 blocks
 constexpr int kTileElems = 5120;     // k_rows_tile: elements staged per block (20 KiB -> ~5 blocks/CU)
 constexpr int kTileMaxInner = 16384; // longest row k_rows_tile accepts (64 KiB of LDS)
+constexpr int kDirectMaxInner = 2047; // k_rows_direct handles rows up to here
+constexpr int kDirectRows = 64;       // rows per k_rows_direct iteration (tables: ~20 KiB for E5M2)
 constexpr int64_t kNtBytes = 64ll << 20;  // tensors at least this big stream with nontemporal hints
 
 // n / d == umulhi(n, magic) for n * d < 2^32; magic == 0 encodes d == 1
@@ -303,6 +305,123 @@ k_rows_tile(const float *__restrict__ x, float *__restrict__ y, int64_t C,
             const vf4 *sv = reinterpret_cast<const vf4 *>(xs + pad + head);
             vf4 *yv = reinterpret_cast<vf4 *>(yt + head);
             for (int i = tid; i < nvec; i += kBlock) st16<NT>(yv + i, sv[i]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Short rows, register-streamed: k_rows_direct (inner <= kDirectMaxInner).
+// G lanes own one row: every element a lane touches belongs to ONE channel, so the channel
+// constants / table pointer are loaded once per row and the inner loop is the per-tensor one.
+// Rows start at arbitrary 4-byte offsets: lanes use 16-byte accesses at 4-byte alignment (one
+// dwordx4 each); the G lanes of a row cover G*16 contiguous bytes per instruction.
+// A block takes R rows per iteration; LDS holds only the tables of those rows:
+//   pass A (MODE 1, 2) row min/max straight from global, G-lane shuffle reduction
+//   tables            make_chan (thread j <-> row j), then {s, 1/s} entries over all threads
+//   pass B            quantize; in MODE 1 this re-reads the rows, which are L2-resident
+// Dynamic LDS: float rowmv[R4] | Chan chans[R] | float2 lut[R * lut_stride]
+// ---------------------------------------------------------------------------------------------
+template <int MODE, bool LUT, bool NT>
+__global__ void __launch_bounds__(kBlock)
+k_rows_direct(const float *__restrict__ x, float *__restrict__ y, int64_t C,
+              const float *__restrict__ maxval, float *row_min, float *row_max, float *maxval_out,
+              QFmt f, TileArgs a, FoldArgs fa)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int Rmax = a.rows;
+    float *rowmv = reinterpret_cast<float *>(smem);
+    Chan *chans = reinterpret_cast<Chan *>(rowmv + ((Rmax + 3) & ~3));
+    float2 *lut = reinterpret_cast<float2 *>(chans + Rmax);
+    const int tid = threadIdx.x;
+    const int G = a.group, rpp = kBlock / G;
+    const int sub = tid & (G - 1), slot = tid / G;
+    const int inner = a.inner, inner4 = inner & ~3;
+    const float pmaxf = (float)f.pmax;
+
+    for (int64_t r0 = (int64_t)blockIdx.x * Rmax; r0 < C; r0 += (int64_t)gridDim.x * Rmax) {
+        const int R = (int)((C - r0) < Rmax ? (C - r0) : Rmax);
+        __syncthreads();   // tables of the previous iteration are no longer read
+        if (MODE != kModeQuant) {
+            for (int rb = 0; rb < R; rb += rpp) {
+                const int r = rb + slot;
+                MinMax m;
+                mm_init(m);
+                if (r < R) {
+                    const float *xr = x + (r0 + r) * inner;
+                    for (int i = sub * 4; i < inner4; i += G * 4) {
+                        const vf4 v = ld16u<false>(xr + i);   // keep the rows in L2 for pass B
+                        mm_acc(m, v.x);
+                        mm_acc(m, v.y);
+                        mm_acc(m, v.z);
+                        mm_acc(m, v.w);
+                    }
+                    for (int i = inner4 + sub; i < inner; i += G) mm_acc(m, xr[i]);
+                }
+                for (int off = G >> 1; off >= 1; off >>= 1) {
+                    m.mn = fminf(m.mn, __shfl_xor(m.mn, off, 64));
+                    m.mx = fmaxf(m.mx, __shfl_xor(m.mx, off, 64));
+                    m.nan |= __shfl_xor(m.nan, off, 64);
+                }
+                if (r < R && sub == 0) {
+                    if (m.nan) m.mn = m.mx = __builtin_nanf("");
+                    if (MODE == kModeMinMax) {
+                        fold_store(m.mn, m.mx, r0 + r, row_min, row_max, maxval_out, fa);
+                    } else {
+                        const float mv = fabsf(tmax(fabsf(m.mn), m.mx));   // fp8_quantizer.py:236
+                        if (row_min) row_min[r0 + r] = m.mn;
+                        if (row_max) row_max[r0 + r] = m.mx;
+                        if (maxval_out) maxval_out[r0 + r] = mv;
+                        rowmv[r] = mv;
+                    }
+                }
+            }
+            if (MODE == kModeMinMax) continue;
+            __syncthreads();
+        }
+        {
+            const float *mvsrc = MODE == kModeQuant ? maxval + r0 : rowmv;
+            for (int j = tid; j < R; j += kBlock) chans[j] = make_chan(mvsrc[j], f);
+            __syncthreads();
+            if (LUT) {
+                for (int j = tid; j < R * a.lut_stride; j += kBlock) {
+                    const int cj = div_small((uint32_t)j, a.lmagic), pj = j - cj * a.lut_stride;
+                    lut[j] = lut_entry(chans[cj], pj, f.M);
+                }
+                __syncthreads();
+            }
+        }
+        for (int rb = 0; rb < R; rb += rpp) {
+            const int r = rb + slot;
+            if (r >= R) continue;
+            const float *xr = x + (r0 + r) * inner;
+            float *yr = y + (r0 + r) * inner;
+            if (LUT) {
+                const ChanLite c = lite_lds(chans + r);
+                const float2 *lrow = lut + r * a.lut_stride;
+                int i = sub * 4;
+                for (; i + G * 4 < inner4; i += G * 8) {      // two 16-byte groups in flight
+                    const vf4 v0 = ld16u<NT>(xr + i), v1 = ld16u<NT>(xr + i + G * 4);
+                    float e[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                    quant_group<8>(e, c, lrow, pmaxf, f.qthr);
+                    st16u<NT>(yr + i, vf4{e[0], e[1], e[2], e[3]});
+                    st16u<NT>(yr + i + G * 4, vf4{e[4], e[5], e[6], e[7]});
+                }
+                for (; i < inner4; i += G * 4) {
+                    const vf4 v = ld16u<NT>(xr + i);
+                    float e[4] = {v.x, v.y, v.z, v.w};
+                    quant_group<4>(e, c, lrow, pmaxf, f.qthr);
+                    st16u<NT>(yr + i, vf4{e[0], e[1], e[2], e[3]});
+                }
+                for (int j = inner4 + sub; j < inner; j += G) yr[j] = quant_one(xr[j], c, lrow, pmaxf, f.qthr);
+            } else {
+                const Chan c = chans[r];
+                for (int i = sub * 4; i < inner4; i += G * 4) {
+                    const vf4 v = ld16u<NT>(xr + i);
+                    st16u<NT>(yr + i, vf4{quant_direct(v.x, c, f.M), quant_direct(v.y, c, f.M),
+                                          quant_direct(v.z, c, f.M), quant_direct(v.w, c, f.M)});
+                }
+                for (int j = inner4 + sub; j < inner; j += G) yr[j] = quant_direct(xr[j], c, f.M);
+            }
         }
     }
 }
@@ -645,6 +764,61 @@ int launch_rows_tile(int mode, const float *x, float *y, int64_t C, int64_t inne
     return launch_rc();
 }
 
+// Launch k_rows_direct for [C, inner], inner <= kDirectMaxInner (any 4-byte aligned pointers).
+int launch_rows_direct(int mode, const float *x, float *y, int64_t C, int64_t inner, const float *maxval,
+                       float *row_min, float *row_max, float *maxval_out, const QFmt &f,
+                       const FoldArgs &fa, hipStream_t st)
+{
+    TileArgs a = {};
+    a.inner = (int)inner;
+    a.lut_stride = f.pmax + 1;
+    a.lmagic = magic_of(a.lut_stride);
+    a.magic = magic_of((int)inner);
+    const bool lut = mode != kModeMinMax && inner >= 2 * (int64_t)a.lut_stride;
+    // lanes per row: ~16-32 elements (4-8 dwordx4) per lane, power of two <= 64
+    int G = 1;
+    while (G < 64 && (int64_t)G * 24 < inner) G <<= 1;
+    static const int rows_env = [] {
+        const char *e = getenv("FP8Q_DIRECT_ROWS");
+        const int v = e ? atoi(e) : 0;
+        return v >= 1 && v <= 256 ? v : kDirectRows;
+    }();
+    const int rpp = kBlock / G;
+    int64_t R = rows_env;
+    if (R < rpp) R = rpp;                         // at least one full pass
+    const int64_t want = cdiv(C, 1024);           // small tensors: spread over >= ~1024 blocks
+    if (R > want) R = want;
+    if (R >= rpp) R -= R % rpp;
+    if (R < 1) R = 1;
+    if (R > 256) R = 256;
+    a.rows = (int)R;
+    a.group = G;
+    const size_t shmem = (size_t)((R + 3) & ~(int64_t)3) * 4 + (size_t)R * sizeof(Chan) +
+                         (lut ? (size_t)R * a.lut_stride * sizeof(float2) : 0);
+    int64_t blocks = cdiv(C, R);
+    if (blocks > 2 * kTargetBlocks) blocks = 2 * kTargetBlocks;
+    const bool nt = C * inner * 4 >= kNtBytes;
+    const dim3 g((unsigned)blocks), b(kBlock);
+#define FP8Q_LAUNCH_DIRECT(M, L, N)                                                                      \
+    hipLaunchKernelGGL((k_rows_direct<M, L, N>), g, b, shmem, st, x, y, C, maxval, row_min, row_max,    \
+                       maxval_out, f, a, fa)
+    if (mode == kModeMinMax) {
+        FP8Q_LAUNCH_DIRECT(kModeMinMax, false, false);
+    } else if (mode == kModeQuant) {
+        if (lut && nt) FP8Q_LAUNCH_DIRECT(kModeQuant, true, true);
+        else if (lut) FP8Q_LAUNCH_DIRECT(kModeQuant, true, false);
+        else if (nt) FP8Q_LAUNCH_DIRECT(kModeQuant, false, true);
+        else FP8Q_LAUNCH_DIRECT(kModeQuant, false, false);
+    } else {
+        if (lut && nt) FP8Q_LAUNCH_DIRECT(kModeFused, true, true);
+        else if (lut) FP8Q_LAUNCH_DIRECT(kModeFused, true, false);
+        else if (nt) FP8Q_LAUNCH_DIRECT(kModeFused, false, true);
+        else FP8Q_LAUNCH_DIRECT(kModeFused, false, false);
+    }
+#undef FP8Q_LAUNCH_DIRECT
+    return launch_rc();
+}
+
 }  // namespace
 
 extern "C" {
@@ -679,10 +853,11 @@ int fp8q_quantize_f32(const float *x, float *y, int64_t C, int64_t inner, const 
     const bool aligned = (((uintptr_t)x ^ (uintptr_t)y) & 15) == 0 && ((uintptr_t)x & 3) == 0;
     const bool nt = C * inner * 4 >= kNtBytes;
 
-    if (per_channel && inner < 2048 && aligned) {
-        // short rows: whole rows staged in LDS
+    if (per_channel && inner <= kDirectMaxInner && ((uintptr_t)x & 3) == 0 && ((uintptr_t)y & 3) == 0) {
+        // short rows: G lanes per row, tables in LDS
         const FoldArgs nofold = {0, 1, 0.0f, 0.0f};
-        return launch_rows_tile(kModeQuant, x, y, C, inner, maxval, nullptr, nullptr, nullptr, f, nofold, st);
+        return launch_rows_direct(kModeQuant, x, y, C, inner, maxval, nullptr, nullptr, nullptr, f, nofold,
+                                  st);
     }
     if (C > 65535) {
         // very many long rows: one launch per 65535 rows (gridDim.y limit)
@@ -726,7 +901,7 @@ static int minmax_nsplit(int64_t C, int64_t inner)
 size_t fp8q_minmax_workspace_bytes(int64_t C, int64_t inner)
 {
     if (C <= 0 || inner <= 0) return 16;
-    if (inner < 2048 && C > 1) return 16;  // row-tile path needs none
+    if (inner <= kDirectMaxInner && C > 1) return 16;  // short-row path needs none
     return (size_t)C * (size_t)minmax_nsplit(C, inner) * 2 * sizeof(float) + 16;
 }
 
@@ -742,10 +917,10 @@ int fp8q_minmax_f32(const float *x, int64_t C, int64_t inner, float *cur_min, fl
     fa.first = first != 0;
     fa.om = (float)(1.0 - momentum);
     fa.mo = (float)momentum;
-    if (inner < 2048 && C > 1 && ((uintptr_t)x & 3) == 0) {
+    if (inner <= kDirectMaxInner && C > 1 && ((uintptr_t)x & 3) == 0) {
         QFmt f = {};
-        return launch_rows_tile(kModeMinMax, x, nullptr, C, inner, nullptr, cur_min, cur_max, maxval_out, f,
-                                fa, st);
+        return launch_rows_direct(kModeMinMax, x, nullptr, C, inner, nullptr, cur_min, cur_max, maxval_out,
+                                  f, fa, st);
     }
     if (ws_bytes < fp8q_minmax_workspace_bytes(C, inner) || !ws) return FP8Q_EWORKSPACE;
     const int ns = minmax_nsplit(C, inner);
@@ -776,8 +951,12 @@ int fp8q_minmax_quantize_f32(const float *x, float *y, int64_t C, int64_t inner,
     if (C == 0 || inner == 0) return FP8Q_OK;
     if (!x || !y) return FP8Q_EINVAL;
     if (inner > kTileMaxInner) return FP8Q_EUNSUPPORTED;
-    if ((((uintptr_t)x ^ (uintptr_t)y) & 15) != 0 || ((uintptr_t)x & 3) != 0) return FP8Q_EINVAL;
+    if (((uintptr_t)x & 3) != 0 || ((uintptr_t)y & 3) != 0) return FP8Q_EINVAL;
     const FoldArgs nofold = {0, 1, 0.0f, 0.0f};
+    if (inner <= kDirectMaxInner)
+        return launch_rows_direct(kModeFused, x, y, C, inner, nullptr, row_min, row_max, maxval_out, f,
+                                  nofold, (hipStream_t)stream);
+    if ((((uintptr_t)x ^ (uintptr_t)y) & 15) != 0) return FP8Q_EINVAL;   // long rows: co-aligned only
     return launch_rows_tile(kModeFused, x, y, C, inner, nullptr, row_min, row_max, maxval_out, f, nofold,
                             (hipStream_t)stream);
 }
