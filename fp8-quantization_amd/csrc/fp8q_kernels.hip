@@ -131,6 +131,7 @@ struct TileArgs {
     int lut_stride;     // pmax + 1
     int group;          // G: lanes per row (power of two <= 64, or 256 = whole block)
     int xs_floats;      // LDS floats reserved for the staged rows (multiple of 4)
+    int coaligned;      // k_rows_direct: x and y share their 16-byte phase -> aligned vector body
     uint32_t magic;     // n / inner      (see magic_of)
     uint32_t lmagic;    // n / lut_stride
 };
@@ -395,32 +396,39 @@ k_rows_direct(const float *__restrict__ x, float *__restrict__ y, int64_t C,
             if (r >= R) continue;
             const float *xr = x + (r0 + r) * inner;
             float *yr = y + (r0 + r) * inner;
+            // 16-byte aligned body inside the row (x and y are co-aligned: host-checked, else the
+            // "body" starts at 0 and uses 4-byte-aligned vector accesses); <= 3 scalars either side
+            int head = a.coaligned ? (int)((4 - (((uintptr_t)xr >> 2) & 3)) & 3) : 0;
+            if (head > inner) head = inner;
+            const int bend = head + ((inner - head) & ~3);
             if (LUT) {
                 const ChanLite c = lite_lds(chans + r);
                 const float2 *lrow = lut + r * a.lut_stride;
-                int i = sub * 4;
-                for (; i + G * 4 < inner4; i += G * 8) {      // two 16-byte groups in flight
+                int i = head + sub * 4;
+                for (; i + G * 4 < bend; i += G * 8) {      // two 16-byte groups in flight
                     const vf4 v0 = ld16u<NT>(xr + i), v1 = ld16u<NT>(xr + i + G * 4);
                     float e[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
                     quant_group<8>(e, c, lrow, pmaxf, f.qthr);
                     st16u<NT>(yr + i, vf4{e[0], e[1], e[2], e[3]});
                     st16u<NT>(yr + i + G * 4, vf4{e[4], e[5], e[6], e[7]});
                 }
-                for (; i < inner4; i += G * 4) {
+                for (; i < bend; i += G * 4) {
                     const vf4 v = ld16u<NT>(xr + i);
                     float e[4] = {v.x, v.y, v.z, v.w};
                     quant_group<4>(e, c, lrow, pmaxf, f.qthr);
                     st16u<NT>(yr + i, vf4{e[0], e[1], e[2], e[3]});
                 }
-                for (int j = inner4 + sub; j < inner; j += G) yr[j] = quant_one(xr[j], c, lrow, pmaxf, f.qthr);
+                for (int j = sub; j < head; j += G) yr[j] = quant_one(xr[j], c, lrow, pmaxf, f.qthr);
+                for (int j = bend + sub; j < inner; j += G) yr[j] = quant_one(xr[j], c, lrow, pmaxf, f.qthr);
             } else {
                 const Chan c = chans[r];
-                for (int i = sub * 4; i < inner4; i += G * 4) {
+                for (int i = head + sub * 4; i < bend; i += G * 4) {
                     const vf4 v = ld16u<NT>(xr + i);
                     st16u<NT>(yr + i, vf4{quant_direct(v.x, c, f.M), quant_direct(v.y, c, f.M),
                                           quant_direct(v.z, c, f.M), quant_direct(v.w, c, f.M)});
                 }
-                for (int j = inner4 + sub; j < inner; j += G) yr[j] = quant_direct(xr[j], c, f.M);
+                for (int j = sub; j < head; j += G) yr[j] = quant_direct(xr[j], c, f.M);
+                for (int j = bend + sub; j < inner; j += G) yr[j] = quant_direct(xr[j], c, f.M);
             }
         }
     }
@@ -793,6 +801,7 @@ int launch_rows_direct(int mode, const float *x, float *y, int64_t C, int64_t in
     if (R > 256) R = 256;
     a.rows = (int)R;
     a.group = G;
+    a.coaligned = (y == nullptr) || ((((uintptr_t)x ^ (uintptr_t)y) & 15) == 0);
     const size_t shmem = (size_t)((R + 3) & ~(int64_t)3) * 4 + (size_t)R * sizeof(Chan) +
                          (lut ? (size_t)R * a.lut_stride * sizeof(float2) : 0);
     int64_t blocks = cdiv(C, R);
