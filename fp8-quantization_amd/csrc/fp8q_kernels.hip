@@ -33,7 +33,7 @@ constexpr int kTargetBlocks = 2048;  // 256 CUs x 8 blocks
 constexpr int kTileElems = 5120;     // k_rows_tile: elements staged per block (20 KiB -> ~5 blocks/CU)
 constexpr int kTileMaxInner = 16384; // longest row k_rows_tile accepts (64 KiB of LDS)
 constexpr int kDirectMaxInner = 2047; // k_rows_direct handles rows up to here
-constexpr int kDirectRows = 64;       // rows per k_rows_direct iteration (tables: ~20 KiB for E5M2)
+constexpr int kDirectElems = 16384;    // elements per k_rows_direct iteration
 constexpr int64_t kNtBytes = 64ll << 20;  // tensors at least this big stream with nontemporal hints
 
 // n / d == umulhi(n, magic) for n * d < 2^32; magic == 0 encodes d == 1
@@ -319,7 +319,8 @@ k_rows_tile(const float *__restrict__ x, float *__restrict__ y, int64_t C,
 // A block takes R rows per iteration; LDS holds only the tables of those rows:
 //   pass A (MODE 1, 2) row min/max straight from global, G-lane shuffle reduction
 //   tables            make_chan (thread j <-> row j), then {s, 1/s} entries over all threads
-//   pass B            quantize; in MODE 1 this re-reads the rows, which are L2-resident
+//   pass B            quantize the R rows as one flat contiguous range (coalesced 16-byte I/O);
+//                     in MODE 1 this re-reads the rows, which are L2-resident
 // Dynamic LDS: float rowmv[R4] | Chan chans[R] | float2 lut[R * lut_stride]
 // ---------------------------------------------------------------------------------------------
 template <int MODE, bool LUT, bool NT>
@@ -391,44 +392,63 @@ k_rows_direct(const float *__restrict__ x, float *__restrict__ y, int64_t C,
                 __syncthreads();
             }
         }
-        for (int rb = 0; rb < R; rb += rpp) {
-            const int r = rb + slot;
-            if (r >= R) continue;
-            const float *xr = x + (r0 + r) * inner;
-            float *yr = y + (r0 + r) * inner;
-            // 16-byte aligned body inside the row (x and y are co-aligned: host-checked, else the
-            // "body" starts at 0 and uses 4-byte-aligned vector accesses); <= 3 scalars either side
-            int head = a.coaligned ? (int)((4 - (((uintptr_t)xr >> 2) & 3)) & 3) : 0;
-            if (head > inner) head = inner;
-            const int bend = head + ((inner - head) & ~3);
-            if (LUT) {
-                const ChanLite c = lite_lds(chans + r);
-                const float2 *lrow = lut + r * a.lut_stride;
-                int i = head + sub * 4;
-                for (; i + G * 4 < bend; i += G * 8) {      // two 16-byte groups in flight
-                    const vf4 v0 = ld16u<NT>(xr + i), v1 = ld16u<NT>(xr + i + G * 4);
-                    float e[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-                    quant_group<8>(e, c, lrow, pmaxf, f.qthr);
-                    st16u<NT>(yr + i, vf4{e[0], e[1], e[2], e[3]});
-                    st16u<NT>(yr + i + G * 4, vf4{e[4], e[5], e[6], e[7]});
+        // ---- pass B: the R rows are one contiguous range -> flat, fully coalesced 16-byte I/O.
+        // The channel of a 16-byte group comes from one magic division; a group that straddles a
+        // row boundary stores only its first-row part (scalars); the <= 3 elements after each
+        // boundary are redone by one thread per boundary (disjoint addresses, no ordering needed).
+        {
+            const int n = R * inner;
+            const float *xt = x + r0 * inner;
+            float *yt = y + r0 * inner;
+            int head = a.coaligned ? (int)((4 - (((uintptr_t)xt >> 2) & 3)) & 3) : 0;
+            if (head > n || inner < 4) head = n;          // rows shorter than a group: all scalar
+            const int nvec = (n - head) >> 2;
+            const int bend = head + (nvec << 2);
+            auto quant_scalar = [&](int i) {
+                const int ch = div_small((uint32_t)i, a.magic);
+                if (LUT)
+                    yt[i] = quant_one(xt[i], lite_lds(chans + ch), lut + ch * a.lut_stride, pmaxf, f.qthr);
+                else
+                    yt[i] = quant_direct(xt[i], chans[ch], f.M);
+            };
+            for (int i = tid; i < head; i += kBlock) quant_scalar(i);
+            for (int i = bend + tid; i < n; i += kBlock) quant_scalar(i);
+            constexpr int U = 2;
+            for (int j0 = tid; j0 < nvec; j0 += kBlock * U) {
+                vf4 v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (j0 + u * kBlock < nvec) v[u] = ld16u<NT>(xt + head + (j0 + u * kBlock) * 4);
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int j = j0 + u * kBlock;
+                    if (j >= nvec) break;
+                    const int o = head + j * 4;
+                    const int ch = div_small((uint32_t)o, a.magic);
+                    const int b = inner - (o - ch * inner);        // elements left in this row (>= 1)
+                    float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+                    if (LUT) {
+                        quant_group<4>(e, lite_lds(chans + ch), lut + ch * a.lut_stride, pmaxf, f.qthr);
+                    } else {
+                        const Chan c = chans[ch];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) e[q] = quant_direct(e[q], c, f.M);
+                    }
+                    if (b >= 4) {
+                        st16u<NT>(yt + o, vf4{e[0], e[1], e[2], e[3]});
+                    } else {
+                        yt[o] = e[0];
+                        if (b > 1) yt[o + 1] = e[1];
+                        if (b > 2) yt[o + 2] = e[2];
+                    }
                 }
-                for (; i < bend; i += G * 4) {
-                    const vf4 v = ld16u<NT>(xr + i);
-                    float e[4] = {v.x, v.y, v.z, v.w};
-                    quant_group<4>(e, c, lrow, pmaxf, f.qthr);
-                    st16u<NT>(yr + i, vf4{e[0], e[1], e[2], e[3]});
-                }
-                for (int j = sub; j < head; j += G) yr[j] = quant_one(xr[j], c, lrow, pmaxf, f.qthr);
-                for (int j = bend + sub; j < inner; j += G) yr[j] = quant_one(xr[j], c, lrow, pmaxf, f.qthr);
-            } else {
-                const Chan c = chans[r];
-                for (int i = head + sub * 4; i < bend; i += G * 4) {
-                    const vf4 v = ld16u<NT>(xr + i);
-                    st16u<NT>(yr + i, vf4{quant_direct(v.x, c, f.M), quant_direct(v.y, c, f.M),
-                                          quant_direct(v.z, c, f.M), quant_direct(v.w, c, f.M)});
-                }
-                for (int j = sub; j < head; j += G) yr[j] = quant_direct(xr[j], c, f.M);
-                for (int j = bend + sub; j < inner; j += G) yr[j] = quant_direct(xr[j], c, f.M);
+            }
+            // boundary clean-up: row c+1 starts at local index (c+1)*inner
+            for (int c = tid; c < R - 1; c += kBlock) {
+                const int idx = (c + 1) * inner;
+                if (idx <= head || idx >= bend) continue;              // scalar regions: already right
+                const int end = head + (((idx - head) + 3) & ~3);      // end of the straddling group
+                for (int i = idx; i < end; ++i) quant_scalar(i);       // 0..3 elements
             }
         }
     }
@@ -786,19 +806,23 @@ int launch_rows_direct(int mode, const float *x, float *y, int64_t C, int64_t in
     // lanes per row: ~16-32 elements (4-8 dwordx4) per lane, power of two <= 64
     int G = 1;
     while (G < 64 && (int64_t)G * 24 < inner) G <<= 1;
-    static const int rows_env = [] {
-        const char *e = getenv("FP8Q_DIRECT_ROWS");
+    static const int elems_env = [] {   // tuning knob for experiments
+        const char *e = getenv("FP8Q_DIRECT_ELEMS");
         const int v = e ? atoi(e) : 0;
-        return v >= 1 && v <= 256 ? v : kDirectRows;
+        return v >= 256 && v <= (1 << 20) ? v : kDirectElems;
     }();
     const int rpp = kBlock / G;
-    int64_t R = rows_env;
+    int64_t R = elems_env / inner;
+    if (mode == kModeMinMax) R = 4 * rpp;         // no tables: a few passes per iteration
     if (R < rpp) R = rpp;                         // at least one full pass
+    if (R > 256) R = 256;                         // one make_chan pass
+    // tables must fit in ~40 KiB of LDS
+    const int64_t per_row = (int64_t)sizeof(Chan) + 4 + (lut ? (int64_t)a.lut_stride * 8 : 0);
+    if (R * per_row > 40 * 1024) R = (40 * 1024) / per_row;
     const int64_t want = cdiv(C, 1024);           // small tensors: spread over >= ~1024 blocks
     if (R > want) R = want;
-    if (R >= rpp) R -= R % rpp;
+    if (R >= 4) R &= ~(int64_t)3;                 // keeps tile starts 16-byte aligned for any inner
     if (R < 1) R = 1;
-    if (R > 256) R = 256;
     a.rows = (int)R;
     a.group = G;
     a.coaligned = (y == nullptr) || ((((uintptr_t)x ^ (uintptr_t)y) & 15) == 0);
