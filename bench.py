@@ -9,7 +9,7 @@ Workload (BASELINE.json config 2, scaled as north_star allows: "synthetic NxCxKx
     (n_bits 8, 2 mantissa bits), ranges from current_minmax (computed once, outside the timed
     region: validation runs with fixed ranges, quantization_manager.py:93-98).
 One step = one pass of the hot path quantize_to_fp8_ste_MM (fp8_quantizer.py:91-133) over
-the tensor = one launch of the HIP kernel k_quant_multi through the C ABI (fp8q_quantize_f32).
+the tensor = one launch of the HIP kernel k_rows_direct (MODE 0) through the C ABI (fp8q_quantize_f32).
 Inputs are resident in HBM before the timed region.
 
 N > 1 (one process per GPU, torch.distributed/RCCL): output channels are sharded across
@@ -197,7 +197,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("k_quant_multi_bytes_per_launch")
+                traffic = json.load(open(tpath)).get("k_rows_direct_bytes_per_launch")
             except Exception:
                 traffic = None
         line = {
@@ -209,7 +209,7 @@ def main():
                                    "quantize+dequantize, fixed ranges from current_minmax (BASELINE config 2, "
                                    "synthetic NxCxKxK scale-up)",
                        "elements_per_gpu": n_elem, "parallelism": f"channel-sharded x{world}, no data-path collective"},
-            "roofline": {"bound": "hbm", "kernel": "k_quant_multi<LUT,NT>", "achieved": round(achieved, 1),
+            "roofline": {"bound": "hbm", "kernel": "k_rows_direct<0,LUT,NT>", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "algorithmic_bytes_per_launch": n_elem * BYTES_PER_ELEM,
                          "avg_launch_us": round(kern_s * 1e6, 1)},

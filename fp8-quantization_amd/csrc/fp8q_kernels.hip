@@ -33,7 +33,7 @@ constexpr int kTargetBlocks = 2048;  // 256 CUs x 8 blocks
 constexpr int kTileElems = 5120;     // k_rows_tile: elements staged per block (20 KiB -> ~5 blocks/CU)
 constexpr int kTileMaxInner = 16384; // longest row k_rows_tile accepts (64 KiB of LDS)
 constexpr int kDirectMaxInner = 2047; // k_rows_direct handles rows up to here
-constexpr int kDirectElems = 16384;    // elements per k_rows_direct iteration
+constexpr int kDirectElems = 32768;    // elements per k_rows_direct iteration (tables capped at 40 KiB)
 constexpr int64_t kNtBytes = 64ll << 20;  // tensors at least this big stream with nontemporal hints
 
 // n / d == umulhi(n, magic) for n * d < 2^32; magic == 0 encodes d == 1
@@ -544,7 +544,7 @@ k_minmax_partial(const float *__restrict__ x, int64_t inner, int nsplit, float *
     block_reduce_store(m, ws + ((int64_t)row * nsplit + split) * 2);
 }
 
-// K2/K3 stage 2: one wave per row reduces the row's splits
+// K2/K3 stage 2: one wave per row reduces the row's splits (many rows, few splits)
 __global__ void __launch_bounds__(kBlock)
 k_minmax_final(const float *__restrict__ ws, int64_t C, int nsplit, float *cur_min, float *cur_max,
                float *maxval_out, FoldArgs fa)
@@ -555,14 +555,59 @@ k_minmax_final(const float *__restrict__ ws, int64_t C, int nsplit, float *cur_m
     MinMax m;
     mm_init(m);
     for (int s = lane; s < nsplit; s += 64) {
-        const float a = ws[(row * nsplit + s) * 2], b = ws[(row * nsplit + s) * 2 + 1];
-        mm_acc(m, a);
-        mm_acc(m, b);
+        const float2 ab = *reinterpret_cast<const float2 *>(ws + (row * nsplit + s) * 2);
+        mm_acc(m, ab.x);
+        mm_acc(m, ab.y);
     }
     mm_wave_reduce(m);
     if (lane == 0) {
         if (m.nan) m.mn = m.mx = __builtin_nanf("");
         fold_store(m.mn, m.mx, row, cur_min, cur_max, maxval_out, fa);
+    }
+}
+
+// K2/K3 stage 2 for few rows with many splits (per-tensor): one block per row, all partial loads
+// independent (the per-tensor activation path is latency-bound here: 2048 partials, one row)
+__global__ void __launch_bounds__(kBlock)
+k_minmax_final_block(const float *__restrict__ ws, int nsplit, float *cur_min, float *cur_max,
+                     float *maxval_out, FoldArgs fa)
+{
+    __shared__ float s_mn[4], s_mx[4];
+    __shared__ int s_nan[4];
+    const int64_t row = blockIdx.x;
+    const int tid = threadIdx.x;
+    MinMax m;
+    mm_init(m);
+    const float2 *w = reinterpret_cast<const float2 *>(ws) + row * nsplit;
+    float2 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int s2 = tid + u * kBlock;
+        v[u] = s2 < nsplit ? w[s2] : make_float2(__builtin_inff(), -__builtin_inff());
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        m.nan |= (v[u].x != v[u].x);
+        m.mn = fminf(m.mn, v[u].x);
+        m.mx = fmaxf(m.mx, v[u].y);
+    }
+    for (int s2 = tid + 8 * kBlock; s2 < nsplit; s2 += kBlock) {
+        const float2 ab = w[s2];
+        mm_acc(m, ab.x);
+        mm_acc(m, ab.y);
+    }
+    mm_wave_reduce(m);
+    if ((tid & 63) == 0) {
+        s_mn[tid >> 6] = m.mn;
+        s_mx[tid >> 6] = m.mx;
+        s_nan[tid >> 6] = m.nan;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float mn = fminf(fminf(s_mn[0], s_mn[1]), fminf(s_mn[2], s_mn[3]));
+        float mx = fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3]));
+        if (s_nan[0] | s_nan[1] | s_nan[2] | s_nan[3]) mn = mx = __builtin_nanf("");
+        fold_store(mn, mx, row, cur_min, cur_max, maxval_out, fa);
     }
 }
 
@@ -967,8 +1012,12 @@ int fp8q_minmax_f32(const float *x, int64_t C, int64_t inner, float *cur_min, fl
             hipLaunchKernelGGL(k_minmax_partial<false>, dim3((unsigned)ns, (unsigned)cn), dim3(kBlock), 0,
                                st, x + c0 * inner, inner, ns, w);
     }
-    hipLaunchKernelGGL(k_minmax_final, dim3((unsigned)cdiv(C, 4)), dim3(kBlock), 0, st,
-                       (const float *)ws, C, ns, cur_min, cur_max, maxval_out, fa);
+    if (ns > 64 && C <= 65535)
+        hipLaunchKernelGGL(k_minmax_final_block, dim3((unsigned)C), dim3(kBlock), 0, st, (const float *)ws,
+                           ns, cur_min, cur_max, maxval_out, fa);
+    else
+        hipLaunchKernelGGL(k_minmax_final, dim3((unsigned)cdiv(C, 4)), dim3(kBlock), 0, st,
+                           (const float *)ws, C, ns, cur_min, cur_max, maxval_out, fa);
     return launch_rc();
 }
 
