@@ -321,7 +321,7 @@ k_rows_tile(const float *__restrict__ x, float *__restrict__ y, int64_t C,
 //   tables            make_chan (thread j <-> row j), then {s, 1/s} entries over all threads
 //   pass B            quantize the R rows as one flat contiguous range (coalesced 16-byte I/O);
 //                     in MODE 1 this re-reads the rows, which are L2-resident
-// Dynamic LDS: float rowmv[R4] | Chan chans[R] | float2 lut[R * lut_stride]
+// Dynamic LDS: float rowmv[R4] | float4 patch[R] | Chan chans[R] | float2 lut[R * lut_stride]
 // ---------------------------------------------------------------------------------------------
 template <int MODE, bool LUT, bool NT>
 __global__ void __launch_bounds__(kBlock)
@@ -332,7 +332,8 @@ k_rows_direct(const float *__restrict__ x, float *__restrict__ y, int64_t C,
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int Rmax = a.rows;
     float *rowmv = reinterpret_cast<float *>(smem);
-    Chan *chans = reinterpret_cast<Chan *>(rowmv + ((Rmax + 3) & ~3));
+    float4 *patch = reinterpret_cast<float4 *>(rowmv + ((Rmax + 3) & ~3));
+    Chan *chans = reinterpret_cast<Chan *>(patch + Rmax);
     float2 *lut = reinterpret_cast<float2 *>(chans + Rmax);
     const int tid = threadIdx.x;
     const int G = a.group, rpp = kBlock / G;
@@ -393,9 +394,10 @@ k_rows_direct(const float *__restrict__ x, float *__restrict__ y, int64_t C,
             }
         }
         // ---- pass B: the R rows are one contiguous range -> flat, fully coalesced 16-byte I/O.
-        // The channel of a 16-byte group comes from one magic division; a group that straddles a
-        // row boundary stores only its first-row part (scalars); the <= 3 elements after each
-        // boundary are redone by one thread per boundary (disjoint addresses, no ordering needed).
+        // The channel of a 16-byte group comes from one magic division.  A group that straddles
+        // a row boundary is completed from an LDS patch: one thread per boundary first quantizes
+        // the <= 3 elements that follow it (with the next row's constants), so every store of the
+        // body is a full aligned 16 bytes (no partial-line read-modify-write in HBM).
         {
             const int n = R * inner;
             const float *xt = x + r0 * inner;
@@ -404,15 +406,24 @@ k_rows_direct(const float *__restrict__ x, float *__restrict__ y, int64_t C,
             if (head > n || inner < 4) head = n;          // rows shorter than a group: all scalar
             const int nvec = (n - head) >> 2;
             const int bend = head + (nvec << 2);
-            auto quant_scalar = [&](int i) {
+            auto quant_at = [&](int i) -> float {
                 const int ch = div_small((uint32_t)i, a.magic);
-                if (LUT)
-                    yt[i] = quant_one(xt[i], lite_lds(chans + ch), lut + ch * a.lut_stride, pmaxf, f.qthr);
-                else
-                    yt[i] = quant_direct(xt[i], chans[ch], f.M);
+                if (LUT) return quant_one(xt[i], lite_lds(chans + ch), lut + ch * a.lut_stride, pmaxf, f.qthr);
+                return quant_direct(xt[i], chans[ch], f.M);
             };
-            for (int i = tid; i < head; i += kBlock) quant_scalar(i);
-            for (int i = bend + tid; i < n; i += kBlock) quant_scalar(i);
+            for (int i = tid; i < head; i += kBlock) yt[i] = quant_at(i);
+            for (int i = bend + tid; i < n; i += kBlock) yt[i] = quant_at(i);
+            // patches: row c+1 starts at local index (c+1)*inner
+            for (int c = tid; c < R - 1; c += kBlock) {
+                const int idx = (c + 1) * inner;
+                float pv[3] = {0.0f, 0.0f, 0.0f};
+                if (idx > head && idx < bend) {
+                    const int end = head + (((idx - head) + 3) & ~3);   // end of the straddling group
+                    for (int i = idx, k = 0; i < end; ++i, ++k) pv[k] = quant_at(i);   // 0..3 elements
+                }
+                patch[c] = make_float4(pv[0], pv[1], pv[2], 0.0f);
+            }
+            __syncthreads();
             constexpr int U = 2;
             for (int j0 = tid; j0 < nvec; j0 += kBlock * U) {
                 vf4 v[U];
@@ -434,21 +445,14 @@ k_rows_direct(const float *__restrict__ x, float *__restrict__ y, int64_t C,
 #pragma unroll
                         for (int q = 0; q < 4; ++q) e[q] = quant_direct(e[q], c, f.M);
                     }
-                    if (b >= 4) {
-                        st16u<NT>(yt + o, vf4{e[0], e[1], e[2], e[3]});
-                    } else {
-                        yt[o] = e[0];
-                        if (b > 1) yt[o + 1] = e[1];
-                        if (b > 2) yt[o + 2] = e[2];
+                    if (b < 4) {   // e[b..3] belong to the next row: take them from its patch
+                        const float4 pt = patch[ch];
+                        e[3] = b == 3 ? pt.x : (b == 2 ? pt.y : pt.z);
+                        if (b < 3) e[2] = b == 2 ? pt.x : pt.y;
+                        if (b < 2) e[1] = pt.x;
                     }
+                    st16u<NT>(yt + o, vf4{e[0], e[1], e[2], e[3]});
                 }
-            }
-            // boundary clean-up: row c+1 starts at local index (c+1)*inner
-            for (int c = tid; c < R - 1; c += kBlock) {
-                const int idx = (c + 1) * inner;
-                if (idx <= head || idx >= bend) continue;              // scalar regions: already right
-                const int end = head + (((idx - head) + 3) & ~3);      // end of the straddling group
-                for (int i = idx; i < end; ++i) quant_scalar(i);       // 0..3 elements
             }
         }
     }
@@ -862,7 +866,7 @@ int launch_rows_direct(int mode, const float *x, float *y, int64_t C, int64_t in
     if (R < rpp) R = rpp;                         // at least one full pass
     if (R > 256) R = 256;                         // one make_chan pass
     // tables must fit in ~40 KiB of LDS
-    const int64_t per_row = (int64_t)sizeof(Chan) + 4 + (lut ? (int64_t)a.lut_stride * 8 : 0);
+    const int64_t per_row = (int64_t)sizeof(Chan) + 4 + 16 + (lut ? (int64_t)a.lut_stride * 8 : 0);
     if (R * per_row > 40 * 1024) R = (40 * 1024) / per_row;
     const int64_t want = cdiv(C, 1024);           // small tensors: spread over >= ~1024 blocks
     if (R > want) R = want;
@@ -871,7 +875,7 @@ int launch_rows_direct(int mode, const float *x, float *y, int64_t C, int64_t in
     a.rows = (int)R;
     a.group = G;
     a.coaligned = (y == nullptr) || ((((uintptr_t)x ^ (uintptr_t)y) & 15) == 0);
-    const size_t shmem = (size_t)((R + 3) & ~(int64_t)3) * 4 + (size_t)R * sizeof(Chan) +
+    const size_t shmem = (size_t)((R + 3) & ~(int64_t)3) * 4 + (size_t)R * 16 + (size_t)R * sizeof(Chan) +
                          (lut ? (size_t)R * a.lut_stride * sizeof(float2) : 0);
     int64_t blocks = cdiv(C, R);
     if (blocks > 2 * kTargetBlocks) blocks = 2 * kTargetBlocks;
