@@ -1,0 +1,102 @@
+"""Quantized ResNet (reference models/resnet_quantized.py:14-150) on the MI355X FP8 engine."""
+import torch
+from torch import nn
+
+from quantization.autoquant_utils import quantize_model, Flattener, QuantizedActivationWrapper
+from quantization.base_quantized_classes import QuantizedActivation, FP32Acts
+from quantization.base_quantized_model import QuantizedModel
+from .resnet import BasicBlock, Bottleneck, resnet18
+
+
+class QuantizedBlock(QuantizedActivation):
+    """Residual block: conv-bn-relu-conv-bn as fused quantized layers, plus one more activation
+    quantizer on relu(out + residual) (reference :39-46)."""
+
+    def __init__(self, block, **quant_params):
+        super().__init__(**quant_params)
+        if not isinstance(block, BasicBlock):
+            raise NotImplementedError("only BasicBlock (ResNet-18/34) is in scope")
+        body = nn.Sequential(block.conv1, block.bn1, block.relu, block.conv2, block.bn2)
+        self.features = quantize_model(body, **quant_params)
+        self.downsample = quantize_model(block.downsample, **quant_params) if block.downsample else None
+        self.relu = block.relu
+
+    def forward(self, x):
+        residual = x if self.downsample is None else self.downsample(x)
+        out = self.features(x)
+        out += residual
+        return self.quantize_activations(self.relu(out))
+
+
+class QuantizedResNet(QuantizedModel):
+    def __init__(self, resnet, input_size=(1, 3, 224, 224), quant_setup=None, **quant_params):
+        super().__init__(input_size)
+        specials = {BasicBlock: QuantizedBlock, Bottleneck: QuantizedBlock}
+        stem = [resnet.conv1, resnet.bn1, resnet.relu]
+        if hasattr(resnet, "maxpool"):          # ImageNet variant; Tiny-ImageNet nets have no maxpool
+            stem.append(resnet.maxpool)
+        body = nn.Sequential(*stem, resnet.layer1, resnet.layer2, resnet.layer3, resnet.layer4)
+        self.features = quantize_model(body, specials=specials, **quant_params)
+        if quant_setup == "LSQ_paper":
+            self.avgpool = resnet.avgpool       # the input of the last layer is quantized instead
+        else:
+            # pooled output reuses the last block's quantizer, without a range update
+            self.avgpool = QuantizedActivationWrapper(
+                resnet.avgpool, tie_activation_quantizers=True,
+                input_quantizer=self.features[-1][-1].activation_quantizer, **quant_params)
+        self.flattener = Flattener()
+        self.fc = quantize_model(resnet.fc, **quant_params)
+        self._apply_setup(quant_setup)
+
+    def _apply_setup(self, setup):
+        first, last_block = self.features[0], self.features[-1][-1]
+        if setup in (None, "all"):
+            return
+        if setup == "LSQ":
+            print("Set quantization to LSQ (first+last layer in 8 bits)")
+            first.weight_quantizer.quantizer.n_bits = 8
+            last_block.activation_quantizer.quantizer.n_bits = 8
+            last_block.features[-1].activation_quantizer.quantizer.n_bits = 8
+            self.fc.weight_quantizer.quantizer.n_bits = 8
+            self.fc.activation_quantizer = FP32Acts()
+        elif setup == "LSQ_paper":
+            first.activation_quantizer = FP32Acts()
+            first.weight_quantizer.quantizer.n_bits = 8
+            self.fc.activation_quantizer.quantizer.n_bits = 8
+            self.fc.weight_quantizer.quantizer.n_bits = 8
+            for layer in self.features.modules():
+                if isinstance(layer, QuantizedActivation):
+                    layer.activation_quantizer = FP32Acts()
+        elif setup == "FP_logits":
+            print("Do not quantize output of FC layer")
+            self.fc.activation_quantizer = FP32Acts()
+        elif setup == "fc4":
+            first.weight_quantizer.quantizer.n_bits = 8
+            self.fc.weight_quantizer.quantizer.n_bits = 4
+        else:
+            raise ValueError(f"Quantization setup '{setup}' not supported for Resnet")
+
+    def forward(self, x):
+        x = self.avgpool(self.features(x))
+        return self.fc(self.flattener(x))
+
+
+def resnet18_quantized(pretrained=True, model_dir=None, load_type="fp32", **qparams):
+    fp_model = resnet18()
+    if load_type == "fp32":
+        if pretrained:
+            if not model_dir:
+                raise RuntimeError("pretrained=True needs --model-dir <torchvision resnet18 state dict>: "
+                                   "there is no network access to download weights")
+            fp_model.load_state_dict(torch.load(model_dir, map_location="cpu"))
+        return QuantizedResNet(fp_model, **qparams)
+    if load_type == "quantized":
+        print(f"Loading pretrained quantized model from {model_dir}")
+        model = QuantizedResNet(fp_model, **qparams)
+        model.load_state_dict(torch.load(model_dir, map_location="cpu"))
+        return model
+    raise ValueError("wrong load_type specified")
+
+
+def resnet50_quantized(*args, **kwargs):
+    raise NotImplementedError("ResNet-50 is outside the scope of this build (SURVEY.md section 2)")

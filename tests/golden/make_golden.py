@@ -18,6 +18,8 @@ Fixture files:
   g4_mse.npz         FP_MSE_Estimator         (range_estimators.py:285-369)
   g6_manager.npz     QuantizationManager.forward state machine (quantization_manager.py:114-122)
   g7_tinycnn.npz     quantize_model on a tiny CNN (autoquant_utils.py:292-381), config-3 settings
+  g8_resnet18.npz    QuantizedResNet (models/resnet_quantized.py:49-133), BASELINE config 3 at 64x64
+  g9_mobilenetv2.npz QuantizedMobileNetV2 (models/mobilenet_v2_quantized.py:29-92) + MSE, config 4 at 64x64
 """
 import os
 import sys
@@ -332,6 +334,90 @@ def copy_net(net):
     return copy.deepcopy(net)
 
 
+def _load_own(name, relpath):
+    """import one of THIS repo's fp32 model definitions by path (the reference's `models` package
+    owns the name `models` in this process)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(name, os.path.join(os.path.dirname(OUT), "..",
+                                                                     "fp8-quantization_amd", relpath))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _model_golden(tag, qmodel, calib, val, out):
+    from quantization.base_quantized_classes import QuantizedModule
+    qmodel.eval()
+    with torch.no_grad():
+        out[f"{tag}_fp_logits"] = qmodel(val).numpy().copy()
+        qmodel.set_quant_state(True, True)
+        out[f"{tag}_calib_logits"] = qmodel(calib).numpy().copy()
+        qmodel.fix_ranges()
+        out[f"{tag}_val_logits"] = qmodel(val).numpy().copy()
+    seen, names = set(), []
+    for n, m in qmodel.named_modules():
+        if isinstance(m, QuantizationManager) and id(m) not in seen:
+            seen.add(id(m))
+            names.append(n)
+            out[f"{tag}_maxval_{n}"] = m.quantizer.maxval.numpy().copy()
+            out[f"{tag}_mbits_{n}"] = np.array(float(m.quantizer.mantissa_bits))
+    out[f"{tag}_mgr_names"] = np.array(names)
+    out[f"{tag}_state_keys"] = np.array(list(qmodel.state_dict().keys()))
+
+
+def _qparams(M, w_est, a_est, incl=False):
+    return dict(method=QMethods.fp_quantizer.cls, act_method=None,
+                weight_range_method=RangeEstimators[w_est].cls, act_range_method=RangeEstimators[a_est].cls,
+                n_bits=8, n_bits_act=8, per_channel_weights=True, percentile=None, quantize_input=False,
+                weight_range_options={}, act_range_options={},
+                fp8_kwargs=dict(maxval=None, mantissa_bits=M, set_maxval=True, learn_maxval=False,
+                                learn_mantissa_bits=False, mse_include_mantissa_bits=incl, allow_unsigned=False))
+
+
+def make_g8():
+    """BASELINE config 3 (reduced): reference QuantizedResNet on a seeded ResNet-18, 64x64 inputs,
+    E5M2, per-channel current_minmax weights, per-tensor allminmax activations."""
+    own = _load_own("amd_resnet", "models/resnet.py")
+    tv = types.ModuleType("torchvision")
+    tvm = types.ModuleType("torchvision.models")
+    tvr = types.ModuleType("torchvision.models.resnet")
+    tvr.BasicBlock, tvr.Bottleneck = own.BasicBlock, own.Bottleneck
+    tvm.resnet18 = own.resnet18
+    tvm.resnet50 = lambda *a, **k: (_ for _ in ()).throw(NotImplementedError())
+    tvm.resnet = tvr
+    tv.models = tvm
+    sys.modules.update({"torchvision": tv, "torchvision.models": tvm, "torchvision.models.resnet": tvr})
+    from models.resnet_quantized import QuantizedResNet      # the REFERENCE's class
+    torch.manual_seed(0)
+    fp = own.resnet18()
+    torch.manual_seed(1)
+    calib, val = torch.randn(4, 3, 64, 64), torch.randn(4, 3, 64, 64)
+    out = {}
+    q = QuantizedResNet(fp, input_size=(1, 3, 64, 64), **_qparams(2, "current_minmax", "allminmax"))
+    _model_golden("r18", q, calib, val, out)
+    np.savez_compressed(os.path.join(OUT, "g8_resnet18.npz"), **out)
+    print("g8 ok", len(out["r18_mgr_names"]), "managers")
+
+
+def make_g9():
+    """BASELINE config 4 (reduced): reference QuantizedMobileNetV2, E4M3, MSE range estimator for
+    weights and activations (--no-fp8-mse-include-mantissa-bits), 64x64 inputs."""
+    own = _load_own("amd_mbv2", "models/mobilenet_v2.py")
+    from models.mobilenet_v2 import MobileNetV2 as RefMobileNetV2   # reference fp32 definition
+    from models.mobilenet_v2_quantized import QuantizedMobileNetV2
+    torch.manual_seed(0)
+    mine = own.MobileNetV2(input_size=64)
+    ref_fp = RefMobileNetV2(input_size=64)
+    ref_fp.load_state_dict(mine.state_dict())     # also proves checkpoint-key compatibility
+    torch.manual_seed(1)
+    calib, val = torch.randn(4, 3, 64, 64), torch.randn(4, 3, 64, 64)
+    out = {}
+    q = QuantizedMobileNetV2(ref_fp, input_size=(1, 3, 64, 64), **_qparams(3, "MSE", "MSE"))
+    _model_golden("mbv2", q, calib, val, out)
+    np.savez_compressed(os.path.join(OUT, "g9_mobilenetv2.npz"), **out)
+    print("g9 ok", len(out["mbv2_mgr_names"]), "managers")
+
+
 if __name__ == "__main__":
     make_g1()
     make_g2()
@@ -339,4 +425,6 @@ if __name__ == "__main__":
     make_g4()
     make_g6()
     make_g7()
+    make_g8()
+    make_g9()
     assert not os.path.exists(os.path.join(REF, "quantization", "__pycache__")), "pycache leaked"
