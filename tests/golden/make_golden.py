@@ -345,6 +345,24 @@ def _load_own(name, relpath):
     return mod
 
 
+def warm_bn(model, seed=2):
+    """Give the seeded random-init network sane BN statistics (one train-mode batch, momentum 1):
+    without it activations vanish by ~10x per block and deep-layer MSE searches are decided by fp32
+    noise.  tests/test_models.py applies the identical procedure."""
+    torch.manual_seed(seed)
+    x = torch.randn(8, 3, 64, 64)
+    bns = [m for m in model.modules() if isinstance(m, nn.BatchNorm2d)]
+    for m in bns:
+        m.momentum = 1.0
+    model.train()
+    with torch.no_grad():
+        model(x)
+    model.eval()
+    for m in bns:
+        m.momentum = 0.1
+    return model
+
+
 def _model_golden(tag, qmodel, calib, val, out):
     from quantization.base_quantized_classes import QuantizedModule
     qmodel.eval()
@@ -389,7 +407,7 @@ def make_g8():
     sys.modules.update({"torchvision": tv, "torchvision.models": tvm, "torchvision.models.resnet": tvr})
     from models.resnet_quantized import QuantizedResNet      # the REFERENCE's class
     torch.manual_seed(0)
-    fp = own.resnet18()
+    fp = warm_bn(own.resnet18())
     torch.manual_seed(1)
     calib, val = torch.randn(4, 3, 64, 64), torch.randn(4, 3, 64, 64)
     out = {}
@@ -406,8 +424,8 @@ def make_g9():
     from models.mobilenet_v2 import MobileNetV2 as RefMobileNetV2   # reference fp32 definition
     from models.mobilenet_v2_quantized import QuantizedMobileNetV2
     torch.manual_seed(0)
-    mine = own.MobileNetV2(input_size=64)
-    ref_fp = RefMobileNetV2(input_size=64)
+    mine = warm_bn(own.MobileNetV2(input_size=64))
+    ref_fp = RefMobileNetV2(input_size=64).eval()
     ref_fp.load_state_dict(mine.state_dict())     # also proves checkpoint-key compatibility
     torch.manual_seed(1)
     calib, val = torch.randn(4, 3, 64, 64), torch.randn(4, 3, 64, 64)

@@ -1,0 +1,63 @@
+"""Oracle-backed stand-in for fp8q.ops on CPU tensors -- TEST USE ONLY.
+
+Lets the host-side mirror of the reference API (quantization/, models/) run end to end on a box
+without a GPU, with the CPU oracle doing the arithmetic, so that host logic can be checked against
+the reference's goldens independently of MIOpen/rocBLAS rounding.  The product never imports this."""
+import contextlib
+
+import numpy as np
+import torch
+
+import oracle
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def quantize(x, maxval, mbits, n_bits=8, sign_bits=1, out=None):
+    y = _t(oracle.c_quantize(x.detach().numpy(), maxval.detach().numpy(), mbits, n_bits, sign_bits))
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+def minmax(x, per_channel, cur_min=None, cur_max=None, mode=0, momentum=0.9, want_maxval=False):
+    mn, mx = oracle.c_minmax(x.detach().numpy(), per_channel)
+    if cur_min is not None and cur_max is not None:
+        mn, mx = oracle.c_fold(cur_min.numpy(), cur_max.numpy(), mn, mx, mode, momentum)
+    out = (_t(mn), _t(mx))
+    return out + (_t(oracle.c_absmax(mn, mx)),) if want_maxval else out
+
+
+def minmax_quantize(x, mbits, n_bits=8, sign_bits=1, out=None):
+    mn, mx = oracle.c_minmax(x.detach().numpy(), True)
+    mv = oracle.c_absmax(mn, mx)
+    return _t(oracle.c_quantize(x.detach().numpy(), mv, mbits, n_bits, sign_bits)), _t(mn), _t(mx), _t(mv)
+
+
+def mse_grid(x, per_channel, grid, mbits_list, n_bits, sign_bits, mses):
+    res = oracle.c_mse_grid(x.detach().numpy(), per_channel, grid.numpy(), list(mbits_list), n_bits, sign_bits,
+                            mses.numpy().copy())
+    mses.copy_(_t(res))
+    return mses
+
+
+def fused_max_inner():
+    return 16384
+
+
+@contextlib.contextmanager
+def patched():
+    """with oracle_ops.patched(): ... -> fp8q.ops.* run on the CPU oracle inside the block."""
+    import fp8q
+    names = ("quantize", "minmax", "minmax_quantize", "mse_grid", "fused_max_inner")
+    saved = {n: getattr(fp8q.ops, n) for n in names}
+    try:
+        for n in names:
+            setattr(fp8q.ops, n, globals()[n])
+        yield
+    finally:
+        for n, f in saved.items():
+            setattr(fp8q.ops, n, f)
