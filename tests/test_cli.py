@@ -1,0 +1,43 @@
+"""validate-quantized command: flag names of the reference's README repro line parse, map to the same
+quantization kwargs, and (GPU) the procedure runs end to end on synthetic batches."""
+import pytest
+import torch
+
+README_FLAGS = ("validate-quantized --architecture resnet18_quantized --batch-size 64 --seed 10 --n-bits 8 --cuda "
+                "--load-type fp32 --quant-setup all --qmethod fp_quantizer --per-channel --fp8-mantissa-bits=5 "
+                "--fp8-set-maxval --no-fp8-mse-include-mantissa-bits --weight-quant-method=current_minmax "
+                "--act-quant-method=allminmax --num-est-batches=1").split()
+
+
+def test_readme_command_parses_to_reference_kwargs():
+    import image_net
+    from quantization.quantizers.fp8_quantizer import FPQuantizer
+    from quantization.range_estimators import CurrentMinMaxEstimator, AllMinMaxEstimator
+    a = image_net.build_parser().parse_args(README_FLAGS)
+    assert a.command == "validate-quantized" and a.batch_size == 64 and a.seed == 10 and a.cuda
+    qp = image_net.quant_params_dict(a)
+    assert qp["method"] is FPQuantizer and qp["act_method"] is FPQuantizer
+    assert qp["weight_range_method"] is CurrentMinMaxEstimator and qp["act_range_method"] is AllMinMaxEstimator
+    assert qp["per_channel_weights"] and qp["n_bits"] == 8 and qp["quant_setup"] == "all" and not qp["quantize_input"]
+    assert qp["fp8_kwargs"] == dict(maxval=None, mantissa_bits=5, set_maxval=True, learn_maxval=False,
+                                    learn_mantissa_bits=False, mse_include_mantissa_bits=False,
+                                    allow_unsigned=False)
+    # reference defaults: --load-type quantized, running_minmax activations, set_maxval off, M=4
+    d = image_net.build_parser().parse_args(["validate-quantized", "--architecture", "mobilenet_v2_quantized",
+                                             "--qmethod", "fp_quantizer"])
+    assert d.load_type == "quantized" and d.act_quant_method == "running_minmax" and d.batch_size == 128
+    assert d.fp8_mantissa_bits == 4 and not d.fp8_set_maxval and d.fp8_mse_include_mantissa_bits
+    assert d.reestimate_bn_stats and d.num_est_batches == 1
+    with pytest.raises(SystemExit):      # INT qmethods: the reference crashes (UnboundLocalError) here
+        image_net.quant_params_dict(image_net.build_parser().parse_args(
+            ["validate-quantized", "--architecture", "resnet18_quantized"]))
+
+
+@pytest.mark.gpu
+def test_validate_quantized_synthetic_resnet18():
+    import image_net
+    argv = [f for f in README_FLAGS if not f.startswith("--batch-size") and f != "64"]
+    argv += ["--batch-size", "8", "--synthetic-batches", "2", "--image-size", "64", "--fp8-mantissa-bits=3"]
+    m = image_net.main(argv)
+    assert m["images"] == 16 and 0.0 <= m["top_1_accuracy"] <= 1.0 and m["loss"] == m["loss"]
+    assert 0.0 <= m["argmax_agreement_with_fp32"] <= 1.0
