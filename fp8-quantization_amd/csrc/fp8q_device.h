@@ -26,6 +26,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "fp8q_tables.h"
+
 namespace fp8q {
 
 typedef float vf4 __attribute__((ext_vector_type(4)));
@@ -52,29 +54,86 @@ struct __attribute__((aligned(16))) Chan {
     double bias_d;   // (double)bias
     float m0;        // fl32(g)
     int bi;          // floor(bias), clamped (non-finite bias: g is NaN anyway)
-    float pad0, pad1;
+    float bf;        // bias - floor(bias), exact
+    float pad1;
 };
 
-// bias, clamp bounds and scale constants of one channel (fp8_quantizer.py:108-113)
-__device__ __forceinline__ Chan make_chan(float maxv, const QFmt &f)
+// bias, clamp bounds and scale constants of one channel (fp8_quantizer.py:108-113), given the
+// correctly rounded fp32 log2(maxval) and a function for g = 2^-frac(bias) in double
+__device__ __forceinline__ Chan finish_chan(float maxv, float l_mv, const QFmt &f)
 {
     Chan c;
     c.maxv = maxv;
     c.minv = f.sign_bits == 1 ? -maxv : 0.0f;
-    const float l_mv = (float)log2((double)maxv);  // correctly rounded fp32 log2
     float b = f.two_E - l_mv;                       // ((2^E - log2 maxval) + log2(2-2^-M)) - 1,
     b = b + f.l_c;                                  // every step rounded to fp32
     b = b - 1.0f;
     c.bias = b;
     // fast-path preconditions: every scale and its reciprocal are normal fp32 numbers
     c.pthr = (b > -100.0f && b < 100.0f && maxv < 0x1p120f) ? (0.5f - 0x1p-15f) : -1.0f;
-    const float fb = floorf(b);
-    c.g = exp2(-(double)(b - fb));                  // b - floor(b) is exact in fp32
     c.bias_d = (double)b;
-    c.m0 = (float)c.g;
+    const float fb = floorf(b);
     c.bi = (int)fminf(fmaxf(fb, -16384.0f), 16384.0f);
-    c.pad0 = c.pad1 = 0.0f;
+    c.bf = b - fb;                                // frac(bias), exact in fp32
+    c.pad1 = 0.0f;
     return c;
+}
+
+// reference implementation: device libm in double (used where it runs once per block)
+__device__ __forceinline__ Chan make_chan(float maxv, const QFmt &f)
+{
+    Chan c = finish_chan(maxv, (float)log2((double)maxv), f);   // correctly rounded fp32 log2
+    c.g = exp2(-(double)c.bf);
+    c.m0 = (float)c.g;
+    return c;
+}
+
+// Table-driven variant for the kernels that need one per row: the same two double-precision
+// functions at < 2^-50 absolute error (so the fp32 roundings are the same as with libm), in ~60
+// instead of ~300 instructions.  `tab` = kFastTab staged in LDS.
+//   log2(m * 2^k), m in [1,2): i = top 7 mantissa bits, r = m * rc_i - 1 (|r| <= 2^-8),
+//                              log2 = k - log2(rc_i) + ln(1+r)/ln2, degree-7 series
+//   2^-bf, bf in [0,1):        j = floor(128 bf), 2^-bf = 2^(-j/128) * exp(-(bf - j/128) ln2), degree 6
+__device__ __forceinline__ Chan make_chan_fast(float maxv, const QFmt &f, const double *tab)
+{
+    const uint32_t bits = __float_as_uint(maxv);
+    const uint32_t e8 = (bits >> 23) & 0xffu;
+    if (__builtin_expect((bits >> 31) != 0u || e8 == 0u || e8 == 255u, 0))
+        return make_chan(maxv, f);                  // zero, denormal, negative, inf, NaN
+    const int i = (int)((bits >> 16) & 0x7fu);
+    const double m = (double)__uint_as_float((bits & 0x7fffffu) | 0x3f800000u);
+    const double r = fma(m, tab[i], -1.0);
+    double p = fma(r, 1.0 / 7.0, -1.0 / 6.0);
+    p = fma(r, p, 1.0 / 5.0);
+    p = fma(r, p, -1.0 / 4.0);
+    p = fma(r, p, 1.0 / 3.0);
+    p = fma(r, p, -1.0 / 2.0);
+    p = fma(r, p, 1.0);
+    p = p * r;                                      // ln(1 + r)
+    const double l2 = (double)((int)e8 - 127) + fma(p, 1.4426950408889634074, tab[128 + i]);
+    Chan c = finish_chan(maxv, (float)l2, f);
+    if (__builtin_expect(!(c.bf >= 0.0f && c.bf < 1.0f), 0)) {   // non-finite bias
+        c.g = exp2(-(double)c.bf);
+    } else {
+        const int j = (int)(c.bf * 128.0f);
+        const double t = -((double)c.bf - (double)j * (1.0 / 128.0)) * 0.69314718055994530942;
+        double q = fma(t, 1.0 / 720.0, 1.0 / 120.0);
+        q = fma(t, q, 1.0 / 24.0);
+        q = fma(t, q, 1.0 / 6.0);
+        q = fma(t, q, 0.5);
+        q = fma(t, q, 1.0);
+        q = q * t;                                  // exp(t) - 1
+        const double ej = tab[256 + j];
+        c.g = fma(ej, q, ej);
+    }
+    c.m0 = (float)c.g;
+    return c;
+}
+
+// cooperative copy of the tables into LDS (call once per block, then __syncthreads())
+__device__ __forceinline__ void stage_fast_tab(double *dst)
+{
+    for (int i = threadIdx.x; i < kFastTabSize; i += kBlock) dst[i] = kFastTab[i];
 }
 
 // correctly rounded fp32 value of 2^(fl32((ls - M) - bias)); ls is an integer-valued float

@@ -340,10 +340,12 @@ k_rows_direct(const float *__restrict__ x, float *__restrict__ y, int64_t C,
     const int sub = tid & (G - 1), slot = tid / G;
     const int inner = a.inner, inner4 = inner & ~3;
     const float pmaxf = (float)f.pmax;
+    __shared__ double ftab[kFastTabSize];
+    if (MODE != kModeMinMax) stage_fast_tab(ftab);
 
     for (int64_t r0 = (int64_t)blockIdx.x * Rmax; r0 < C; r0 += (int64_t)gridDim.x * Rmax) {
         const int R = (int)((C - r0) < Rmax ? (C - r0) : Rmax);
-        __syncthreads();   // tables of the previous iteration are no longer read
+        __syncthreads();   // tables of the previous iteration are no longer read (and ftab is staged)
         if (MODE != kModeQuant) {
             for (int rb = 0; rb < R; rb += rpp) {
                 const int r = rb + slot;
@@ -383,7 +385,7 @@ k_rows_direct(const float *__restrict__ x, float *__restrict__ y, int64_t C,
         }
         {
             const float *mvsrc = MODE == kModeQuant ? maxval + r0 : rowmv;
-            for (int j = tid; j < R; j += kBlock) chans[j] = make_chan(mvsrc[j], f);
+            for (int j = tid; j < R; j += kBlock) chans[j] = make_chan_fast(mvsrc[j], f, ftab);
             __syncthreads();
             if (LUT) {
                 for (int j = tid; j < R * a.lut_stride; j += kBlock) {

@@ -33,7 +33,8 @@ class Fp8qError(RuntimeError):
 
 
 def so_path():
-    return _build.SO
+    # FP8Q_SO: load an alternative build of the same library (kernel-tuning experiments only)
+    return os.environ.get("FP8Q_SO") or _build.SO
 
 
 def lib():

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(HERE), "csrc")
 SO = os.path.join(CSRC, "libfp8q_hip.so")
 SOURCES = ["fp8q_kernels.hip"]
-HEADERS = ["fp8q_device.h", os.path.join("..", "..", "include", "fp8q.h")]
+HEADERS = ["fp8q_device.h", "fp8q_tables.h", os.path.join("..", "..", "include", "fp8q.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 
 

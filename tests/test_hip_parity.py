@@ -239,8 +239,23 @@ def test_full_size_properties(ops):
     # at most 2^8 distinct values per channel (spot check) and symmetry q(-x) = -q(x)
     assert all(torch.unique(y[i]).numel() <= 256 for i in range(0, n_ch, n_ch // 8))
     assert torch.equal(ops.quantize(-x, mv, 2, 8, 1), -y)
-    # spot-check 64 random channels against the CPU oracle, bit for bit
-    idx = torch.randint(0, n_ch, (64,), generator=torch.Generator().manual_seed(1))
+    # spot-check 4096 random channels against the CPU oracle, bit for bit (also exercises the
+    # table-driven per-channel log2 / exp2 of the short-row kernels on many distinct maxvals)
+    idx = torch.randint(0, n_ch, (4096,), generator=torch.Generator().manual_seed(1))
     xs = x[idx.cuda()].cpu().numpy()
     assert_bit_exact(y[idx.cuda()].cpu().numpy(),
                      oracle.c_quantize(xs, mv[idx.cuda()].cpu().numpy(), 2, 8, 1), "spot check")
+
+
+def test_per_channel_constants_fast_vs_libm(ops):
+    """Short-row kernels derive bias / scale constants with table-driven double log2 / exp2; long-row
+    kernels use device libm.  Both must give the oracle's bits over a wide range of maxval."""
+    rng = np.random.RandomState(11)
+    C = 50000
+    mv = np.exp(rng.uniform(-40, 40, C)).astype(np.float32)
+    mv[:64] = np.float32(2.0) ** np.arange(-32, 32)           # exact powers of two
+    mv[64:72] = [0.0, np.inf, 1e-45, 1.17e-38, 3.4e38, 240.0, 57344.0, 1.0]
+    for M, inner in ((2, 72), (3, 40), (5, 8)):               # LUT and direct variants of k_rows_direct
+        x = (rng.randn(C, inner).astype(np.float32) * (np.where(np.isfinite(mv), mv, 1.0)[:, None] / 2))
+        y = ops.quantize(dev(x), dev(mv), M, 8, 1).cpu().numpy()
+        assert_bit_exact(y, oracle.c_quantize(x, mv, M, 8, 1), f"M={M} inner={inner}")
