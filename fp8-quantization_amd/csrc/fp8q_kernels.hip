@@ -32,7 +32,7 @@ constexpr int kUnroll = 4;           // 16-byte loads in flight per lane
 constexpr int kTargetBlocks = 2048;  // 256 CUs x 8 blocks
 constexpr int kTileElems = 5120;     // k_rows_tile: elements staged per block (20 KiB -> ~5 blocks/CU)
 constexpr int kTileMaxInner = 16384; // longest row k_rows_tile accepts (64 KiB of LDS)
-constexpr int kDirectMaxInner = 2047; // k_rows_direct handles rows up to here
+constexpr int kDirectMaxInner = 16384; // k_rows_direct handles rows up to here (magic division: n*inner < 2^32)
 constexpr int kDirectElems = 32768;    // elements per k_rows_direct iteration (tables capped at 40 KiB)
 constexpr int64_t kNtBytes = 64ll << 20;  // tensors at least this big stream with nontemporal hints
 
@@ -323,8 +323,8 @@ k_rows_tile(const float *__restrict__ x, float *__restrict__ y, int64_t C,
 //                     in MODE 1 this re-reads the rows, which are L2-resident
 // Dynamic LDS: float rowmv[R4] | float4 patch[R] | Chan chans[R] | float2 lut[R * lut_stride]
 // ---------------------------------------------------------------------------------------------
-template <int MODE, bool LUT, bool NT>
-__global__ void __launch_bounds__(kBlock)
+template <int MODE, bool LUT, bool NT, int BS>
+__global__ void __launch_bounds__(BS)
 k_rows_direct(const float *__restrict__ x, float *__restrict__ y, int64_t C,
               const float *__restrict__ maxval, float *row_min, float *row_max, float *maxval_out,
               QFmt f, TileArgs a, FoldArgs fa)
@@ -336,12 +336,15 @@ k_rows_direct(const float *__restrict__ x, float *__restrict__ y, int64_t C,
     Chan *chans = reinterpret_cast<Chan *>(patch + Rmax);
     float2 *lut = reinterpret_cast<float2 *>(chans + Rmax);
     const int tid = threadIdx.x;
-    const int G = a.group, rpp = kBlock / G;
+    const int G = a.group, rpp = BS / G;
     const int sub = tid & (G - 1), slot = tid / G;
     const int inner = a.inner, inner4 = inner & ~3;
     const float pmaxf = (float)f.pmax;
-    __shared__ double ftab[kFastTabSize];
-    if (MODE != kModeMinMax) stage_fast_tab(ftab);
+    // log2/exp2 tables: staged in LDS for 256-thread blocks; single-wave blocks read them through L1
+    __shared__ double ftab_lds[BS == 64 ? 1 : kFastTabSize];
+    const double *ftab = BS == 64 ? kFastTab : ftab_lds;
+    if (MODE != kModeMinMax && BS != 64)
+        for (int i = threadIdx.x; i < kFastTabSize; i += BS) ftab_lds[i] = kFastTab[i];
 
     for (int64_t r0 = (int64_t)blockIdx.x * Rmax; r0 < C; r0 += (int64_t)gridDim.x * Rmax) {
         const int R = (int)((C - r0) < Rmax ? (C - r0) : Rmax);
@@ -353,14 +356,27 @@ k_rows_direct(const float *__restrict__ x, float *__restrict__ y, int64_t C,
                 mm_init(m);
                 if (r < R) {
                     const float *xr = x + (r0 + r) * inner;
-                    for (int i = sub * 4; i < inner4; i += G * 4) {
-                        const vf4 v = ld16u<false>(xr + i);   // keep the rows in L2 for pass B
+                    int i = sub * 4;
+                    for (; i + 3 * G * 4 < inner4; i += G * 16) {   // four 16-byte loads in flight
+                        vf4 v[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) v[u] = ld16u<false>(xr + i + u * G * 4);   // stay in L2 for pass B
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            mm_acc(m, v[u].x);
+                            mm_acc(m, v[u].y);
+                            mm_acc(m, v[u].z);
+                            mm_acc(m, v[u].w);
+                        }
+                    }
+                    for (; i < inner4; i += G * 4) {
+                        const vf4 v = ld16u<false>(xr + i);
                         mm_acc(m, v.x);
                         mm_acc(m, v.y);
                         mm_acc(m, v.z);
                         mm_acc(m, v.w);
                     }
-                    for (int i = inner4 + sub; i < inner; i += G) mm_acc(m, xr[i]);
+                    for (int j = inner4 + sub; j < inner; j += G) mm_acc(m, xr[j]);
                 }
                 for (int off = G >> 1; off >= 1; off >>= 1) {
                     m.mn = fminf(m.mn, __shfl_xor(m.mn, off, 64));
@@ -385,10 +401,10 @@ k_rows_direct(const float *__restrict__ x, float *__restrict__ y, int64_t C,
         }
         {
             const float *mvsrc = MODE == kModeQuant ? maxval + r0 : rowmv;
-            for (int j = tid; j < R; j += kBlock) chans[j] = make_chan_fast(mvsrc[j], f, ftab);
+            for (int j = tid; j < R; j += BS) chans[j] = make_chan_fast(mvsrc[j], f, ftab);
             __syncthreads();
             if (LUT) {
-                for (int j = tid; j < R * a.lut_stride; j += kBlock) {
+                for (int j = tid; j < R * a.lut_stride; j += BS) {
                     const int cj = div_small((uint32_t)j, a.lmagic), pj = j - cj * a.lut_stride;
                     lut[j] = lut_entry(chans[cj], pj, f.M);
                 }
@@ -413,10 +429,10 @@ k_rows_direct(const float *__restrict__ x, float *__restrict__ y, int64_t C,
                 if (LUT) return quant_one(xt[i], lite_lds(chans + ch), lut + ch * a.lut_stride, pmaxf, f.qthr);
                 return quant_direct(xt[i], chans[ch], f.M);
             };
-            for (int i = tid; i < head; i += kBlock) yt[i] = quant_at(i);
-            for (int i = bend + tid; i < n; i += kBlock) yt[i] = quant_at(i);
+            for (int i = tid; i < head; i += BS) yt[i] = quant_at(i);
+            for (int i = bend + tid; i < n; i += BS) yt[i] = quant_at(i);
             // patches: row c+1 starts at local index (c+1)*inner
-            for (int c = tid; c < R - 1; c += kBlock) {
+            for (int c = tid; c < R - 1; c += BS) {
                 const int idx = (c + 1) * inner;
                 float pv[3] = {0.0f, 0.0f, 0.0f};
                 if (idx > head && idx < bend) {
@@ -426,15 +442,15 @@ k_rows_direct(const float *__restrict__ x, float *__restrict__ y, int64_t C,
                 patch[c] = make_float4(pv[0], pv[1], pv[2], 0.0f);
             }
             __syncthreads();
-            constexpr int U = 2;
-            for (int j0 = tid; j0 < nvec; j0 += kBlock * U) {
+            constexpr int U = 4;   // four 16-byte loads in flight per lane
+            for (int j0 = tid; j0 < nvec; j0 += BS * U) {
                 vf4 v[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u)
-                    if (j0 + u * kBlock < nvec) v[u] = ld16u<NT>(xt + head + (j0 + u * kBlock) * 4);
+                    if (j0 + u * BS < nvec) v[u] = ld16u<NT>(xt + head + (j0 + u * BS) * 4);
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    const int j = j0 + u * kBlock;
+                    const int j = j0 + u * BS;
                     if (j >= nvec) break;
                     const int o = head + j * 4;
                     const int ch = div_small((uint32_t)o, a.magic);
@@ -843,6 +859,17 @@ int launch_rows_tile(int mode, const float *x, float *y, int64_t C, int64_t inne
     return launch_rc();
 }
 
+// rows up to this length take k_rows_direct (tuning knob FP8Q_DIRECT_MAX_INNER for experiments)
+int64_t direct_max_inner()
+{
+    static const int v = [] {
+        const char *e = getenv("FP8Q_DIRECT_MAX_INNER");
+        const int n = e ? atoi(e) : 0;
+        return n >= 4 && n <= kDirectMaxInner ? n : kDirectMaxInner;
+    }();
+    return v;
+}
+
 // Launch k_rows_direct for [C, inner], inner <= kDirectMaxInner (any 4-byte aligned pointers).
 int launch_rows_direct(int mode, const float *x, float *y, int64_t C, int64_t inner, const float *maxval,
                        float *row_min, float *row_max, float *maxval_out, const QFmt &f,
@@ -862,14 +889,20 @@ int launch_rows_direct(int mode, const float *x, float *y, int64_t C, int64_t in
         const int v = e ? atoi(e) : 0;
         return v >= 256 && v <= (1 << 20) ? v : kDirectElems;
     }();
-    const int rpp = kBlock / G;
-    int64_t R = elems_env / inner;
+    static const int bs_env = [] {       // 64: one wave per block (no block-level barriers), 256: default
+        const char *e = getenv("FP8Q_DIRECT_BS");
+        return (e && atoi(e) == 64) ? 64 : 256;
+    }();
+    const int BSZ = (mode == kModeMinMax) ? 256 : bs_env;
+    const int rpp = BSZ / G;
+    int64_t R = (elems_env * BSZ / 256) / inner;
     if (mode == kModeMinMax) R = 4 * rpp;         // no tables: a few passes per iteration
     if (R < rpp) R = rpp;                         // at least one full pass
     if (R > 256) R = 256;                         // one make_chan pass
-    // tables must fit in ~40 KiB of LDS
+    // tables + the 3 KiB of staged log2/exp2 tables must fit in 40 KiB of LDS (4 blocks per CU)
     const int64_t per_row = (int64_t)sizeof(Chan) + 4 + 16 + (lut ? (int64_t)a.lut_stride * 8 : 0);
-    if (R * per_row > 40 * 1024) R = (40 * 1024) / per_row;
+    const int64_t lds_cap = BSZ == 64 ? 10 * 1024 - 64 : 36 * 1024;
+    if (R * per_row > lds_cap) R = lds_cap / per_row;
     const int64_t want = cdiv(C, 1024);           // small tensors: spread over >= ~1024 blocks
     if (R > want) R = want;
     if (R >= 4) R &= ~(int64_t)3;                 // keeps tile starts 16-byte aligned for any inner
@@ -880,12 +913,19 @@ int launch_rows_direct(int mode, const float *x, float *y, int64_t C, int64_t in
     const size_t shmem = (size_t)((R + 3) & ~(int64_t)3) * 4 + (size_t)R * 16 + (size_t)R * sizeof(Chan) +
                          (lut ? (size_t)R * a.lut_stride * sizeof(float2) : 0);
     int64_t blocks = cdiv(C, R);
-    if (blocks > 2 * kTargetBlocks) blocks = 2 * kTargetBlocks;
+    if (blocks > 2 * kTargetBlocks && BSZ != 64) blocks = 2 * kTargetBlocks;
     const bool nt = C * inner * 4 >= kNtBytes;
-    const dim3 g((unsigned)blocks), b(kBlock);
+    if (BSZ == 64 && blocks > 8 * kTargetBlocks) blocks = 8 * kTargetBlocks;
+    const dim3 g((unsigned)blocks), b(BSZ);
 #define FP8Q_LAUNCH_DIRECT(M, L, N)                                                                      \
-    hipLaunchKernelGGL((k_rows_direct<M, L, N>), g, b, shmem, st, x, y, C, maxval, row_min, row_max,    \
-                       maxval_out, f, a, fa)
+    do {                                                                                                 \
+        if (BSZ == 64)                                                                                   \
+            hipLaunchKernelGGL((k_rows_direct<M, L, N, 64>), g, b, shmem, st, x, y, C, maxval, row_min,  \
+                               row_max, maxval_out, f, a, fa);                                           \
+        else                                                                                             \
+            hipLaunchKernelGGL((k_rows_direct<M, L, N, 256>), g, b, shmem, st, x, y, C, maxval, row_min, \
+                               row_max, maxval_out, f, a, fa);                                           \
+    } while (0)
     if (mode == kModeMinMax) {
         FP8Q_LAUNCH_DIRECT(kModeMinMax, false, false);
     } else if (mode == kModeQuant) {
@@ -937,7 +977,7 @@ int fp8q_quantize_f32(const float *x, float *y, int64_t C, int64_t inner, const 
     const bool aligned = (((uintptr_t)x ^ (uintptr_t)y) & 15) == 0 && ((uintptr_t)x & 3) == 0;
     const bool nt = C * inner * 4 >= kNtBytes;
 
-    if (per_channel && inner <= kDirectMaxInner && ((uintptr_t)x & 3) == 0 && ((uintptr_t)y & 3) == 0) {
+    if (per_channel && inner <= direct_max_inner() && ((uintptr_t)x & 3) == 0 && ((uintptr_t)y & 3) == 0) {
         // short rows: G lanes per row, tables in LDS
         const FoldArgs nofold = {0, 1, 0.0f, 0.0f};
         return launch_rows_direct(kModeQuant, x, y, C, inner, maxval, nullptr, nullptr, nullptr, f, nofold,
@@ -985,7 +1025,7 @@ static int minmax_nsplit(int64_t C, int64_t inner)
 size_t fp8q_minmax_workspace_bytes(int64_t C, int64_t inner)
 {
     if (C <= 0 || inner <= 0) return 16;
-    if (inner <= kDirectMaxInner && C > 1) return 16;  // short-row path needs none
+    if (inner <= direct_max_inner() && C > 1) return 16;  // short-row path needs none
     return (size_t)C * (size_t)minmax_nsplit(C, inner) * 2 * sizeof(float) + 16;
 }
 
@@ -1001,7 +1041,7 @@ int fp8q_minmax_f32(const float *x, int64_t C, int64_t inner, float *cur_min, fl
     fa.first = first != 0;
     fa.om = (float)(1.0 - momentum);
     fa.mo = (float)momentum;
-    if (inner <= kDirectMaxInner && C > 1 && ((uintptr_t)x & 3) == 0) {
+    if (inner <= direct_max_inner() && C > 1 && ((uintptr_t)x & 3) == 0) {
         QFmt f = {};
         return launch_rows_direct(kModeMinMax, x, nullptr, C, inner, nullptr, cur_min, cur_max, maxval_out,
                                   f, fa, st);
@@ -1041,7 +1081,7 @@ int fp8q_minmax_quantize_f32(const float *x, float *y, int64_t C, int64_t inner,
     if (inner > kTileMaxInner) return FP8Q_EUNSUPPORTED;
     if (((uintptr_t)x & 3) != 0 || ((uintptr_t)y & 3) != 0) return FP8Q_EINVAL;
     const FoldArgs nofold = {0, 1, 0.0f, 0.0f};
-    if (inner <= kDirectMaxInner)
+    if (inner <= direct_max_inner())
         return launch_rows_direct(kModeFused, x, y, C, inner, nullptr, row_min, row_max, maxval_out, f,
                                   nofold, (hipStream_t)stream);
     if ((((uintptr_t)x ^ (uintptr_t)y) & 15) != 0) return FP8Q_EINVAL;   // long rows: co-aligned only
