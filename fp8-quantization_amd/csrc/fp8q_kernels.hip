@@ -7,9 +7,10 @@
 //
 // Kernel inventory:
 //   k_quant_rows     K1, one channel per blockIdx.y (per-tensor: one row).  Scale LUT in LDS.
-//   k_rows_tile      per-channel tensors with short rows, whole rows staged in LDS, row-aligned
-//                    compute: MODE 0 = K1, MODE 1 = K2+K5+K1 fused (weights in estimate_ranges
-//                    state: one read + one write of HBM per element), MODE 2 = K2 (+fold).
+//   k_rows_direct    per-channel tensors with short rows (R rows per block iteration, per-row
+//                    tables in LDS): MODE 0 = K1, MODE 1 = K2+K5+K1 fused (weights in
+//                    estimate_ranges state: one read + one write of HBM per element, the second
+//                    read of a tile hits L2), MODE 2 = K2 (+fold).
 //   k_quant_scalar   K1 fallback for x / y that are not 16-byte co-aligned.
 //   k_minmax_partial K2/K3 stage 1: per-(row, split) min / max / NaN flag.
 //   k_minmax_final   K2/K3 stage 2 + K5: reduce the splits, fold into the running estimate
@@ -30,8 +31,6 @@ namespace {
 
 constexpr int kUnroll = 4;           // 16-byte loads in flight per lane
 constexpr int kTargetBlocks = 2048;  // 256 CUs x 8 blocks
-constexpr int kTileElems = 5120;     // k_rows_tile: elements staged per block (20 KiB -> ~5 blocks/CU)
-constexpr int kTileMaxInner = 16384; // longest row k_rows_tile accepts (64 KiB of LDS)
 constexpr int kDirectMaxInner = 16384; // k_rows_direct handles rows up to here (magic division: n*inner < 2^32)
 constexpr int kDirectElems = 32768;    // elements per k_rows_direct iteration (tables capped at 40 KiB)
 constexpr int64_t kNtBytes = 64ll << 20;  // tensors at least this big stream with nontemporal hints
@@ -112,25 +111,12 @@ k_quant_rows(const float *__restrict__ x, float *__restrict__ y, int64_t inner,
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Short rows (per-channel tensors whose rows fit in LDS): k_rows_tile.
-// A block owns R WHOLE rows at a time, staged in LDS with coalesced 16-byte loads; all per-row
-// work is then row-aligned (G lanes walk one row), so channel constants are loaded once per row
-// and the inner loop is the same lean quant_group as the per-tensor kernel.  Phases of a tile:
-//   A1 stage rows global -> LDS                    A2 row min/max, G lanes per row   (MODE 1, 2)
-//   B  make_chan for the R rows (thread j <-> row j)
-//   C  {s, 1/s} tables, entries spread over all threads (LUT variant)
-//   D  quantize in place in LDS, row-aligned       E  LDS -> global, coalesced 16-byte stores
-// MODE 0: K1 with given per-channel maxval;  1: fused K2+K5+K1 (current_minmax, weights in
-// estimate_ranges state);  2: K2 only (row min/max + fold into the running estimate).
-// Dynamic LDS: float xs[xs_floats] | float rowmv[R4] | Chan chans[R] | float2 lut[R*lut_stride]
-// ---------------------------------------------------------------------------------------------
+// arguments of k_rows_direct
 struct TileArgs {
     int inner;          // row length
     int rows;           // R: rows per tile
     int lut_stride;     // pmax + 1
     int group;          // G: lanes per row (power of two <= 64, or 256 = whole block)
-    int xs_floats;      // LDS floats reserved for the staged rows (multiple of 4)
     int coaligned;      // k_rows_direct: x and y share their 16-byte phase -> aligned vector body
     uint32_t magic;     // n / inner      (see magic_of)
     uint32_t lmagic;    // n / lut_stride
@@ -175,140 +161,6 @@ __device__ __forceinline__ ChanLite lite_lds(const Chan *c)
 }
 
 constexpr int kModeQuant = 0, kModeFused = 1, kModeMinMax = 2;
-
-template <int MODE, bool LUT, bool NT>
-__global__ void __launch_bounds__(kBlock)
-k_rows_tile(const float *__restrict__ x, float *__restrict__ y, int64_t C,
-            const float *__restrict__ maxval, float *row_min, float *row_max, float *maxval_out,
-            QFmt f, TileArgs a, FoldArgs fa)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int Rmax = a.rows;
-    float *xs = reinterpret_cast<float *>(smem);
-    float *rowmv = xs + a.xs_floats;
-    Chan *chans = reinterpret_cast<Chan *>(rowmv + ((Rmax + 3) & ~3));
-    float2 *lut = reinterpret_cast<float2 *>(chans + Rmax);
-    __shared__ float s_mn[4], s_mx[4];
-    __shared__ int s_nan[4];
-    const int tid = threadIdx.x;
-    const int G = a.group;
-    const int rows_per_pass = G >= kBlock ? 1 : kBlock / G;
-    const int sub = tid & (G - 1), slot = G >= kBlock ? 0 : tid / G;
-    const float pmaxf = (float)f.pmax;
-
-    for (int64_t r0 = (int64_t)blockIdx.x * Rmax; r0 < C; r0 += (int64_t)gridDim.x * Rmax) {
-        const int R = (int)((C - r0) < Rmax ? (C - r0) : Rmax);
-        const int n = R * a.inner;
-        const float *xt = x + r0 * a.inner;
-        // LDS index = pad + i so that LDS and global addresses share their 16-byte phase
-        const int pad = (int)(((uintptr_t)xt & 15) >> 2);
-        int head = (4 - pad) & 3;
-        if (head > n) head = n;
-        const int nvec = (n - head) >> 2;
-        const int tail0 = head + (nvec << 2);
-        __syncthreads();   // previous tile finished with the LDS
-        // ---- A1: stage the rows
-        if (tid < head) xs[pad + tid] = xt[tid];
-        if (tail0 + tid < n) xs[pad + tail0 + tid] = xt[tail0 + tid];
-        {
-            const vf4 *xv = reinterpret_cast<const vf4 *>(xt + head);
-            vf4 *sv = reinterpret_cast<vf4 *>(xs + pad + head);
-            for (int i = tid; i < nvec; i += kBlock) sv[i] = ld16<NT>(xv + i);
-        }
-        __syncthreads();
-        // ---- A2: row min / max
-        if (MODE != kModeQuant) {
-            for (int rb = 0; rb < R; rb += rows_per_pass) {
-                const int r = rb + slot;
-                MinMax m;
-                mm_init(m);
-                if (r < R) {
-                    const float *xr = xs + pad + r * a.inner;
-                    for (int i = sub; i < a.inner; i += G) mm_acc(m, xr[i]);
-                }
-                const int gw = G < 64 ? G : 64;
-                for (int off = gw >> 1; off >= 1; off >>= 1) {
-                    m.mn = fminf(m.mn, __shfl_xor(m.mn, off, 64));
-                    m.mx = fmaxf(m.mx, __shfl_xor(m.mx, off, 64));
-                    m.nan |= __shfl_xor(m.nan, off, 64);
-                }
-                if (G >= kBlock) {   // one row over the whole block: combine the four waves
-                    if ((tid & 63) == 0) {
-                        s_mn[tid >> 6] = m.mn;
-                        s_mx[tid >> 6] = m.mx;
-                        s_nan[tid >> 6] = m.nan;
-                    }
-                    __syncthreads();
-                    m.mn = fminf(fminf(s_mn[0], s_mn[1]), fminf(s_mn[2], s_mn[3]));
-                    m.mx = fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3]));
-                    m.nan = s_nan[0] | s_nan[1] | s_nan[2] | s_nan[3];
-                    __syncthreads();
-                }
-                if (r < R && sub == 0) {
-                    if (m.nan) m.mn = m.mx = __builtin_nanf("");
-                    if (MODE == kModeMinMax) {
-                        fold_store(m.mn, m.mx, r0 + r, row_min, row_max, maxval_out, fa);
-                    } else {
-                        const float mv = fabsf(tmax(fabsf(m.mn), m.mx));   // fp8_quantizer.py:236
-                        if (row_min) row_min[r0 + r] = m.mn;
-                        if (row_max) row_max[r0 + r] = m.mx;
-                        if (maxval_out) maxval_out[r0 + r] = mv;
-                        rowmv[r] = mv;
-                    }
-                }
-            }
-            if (MODE == kModeMinMax) continue;
-            __syncthreads();
-        }
-        // ---- B: channel constants (one pass), C: tables
-        {
-            const float *mvsrc = MODE == kModeQuant ? maxval + r0 : rowmv;
-            for (int j = tid; j < R; j += kBlock) chans[j] = make_chan(mvsrc[j], f);
-            __syncthreads();
-            if (LUT) {
-                for (int j = tid; j < R * a.lut_stride; j += kBlock) {
-                    const int cj = div_small((uint32_t)j, a.lmagic), pj = j - cj * a.lut_stride;
-                    lut[j] = lut_entry(chans[cj], pj, f.M);
-                }
-                __syncthreads();
-            }
-        }
-        // ---- D: quantize in place, G lanes per row
-        for (int rb = 0; rb < R; rb += rows_per_pass) {
-            const int r = rb + slot;
-            if (r < R) {
-                float *xr = xs + pad + r * a.inner;
-                if (LUT) {
-                    const ChanLite c = lite_lds(chans + r);
-                    const float2 *lrow = lut + r * a.lut_stride;
-                    int i = sub;
-                    for (; i + 3 * G < a.inner; i += 4 * G) {
-                        float e[4] = {xr[i], xr[i + G], xr[i + 2 * G], xr[i + 3 * G]};
-                        quant_group<4>(e, c, lrow, pmaxf, f.qthr);
-                        xr[i] = e[0];
-                        xr[i + G] = e[1];
-                        xr[i + 2 * G] = e[2];
-                        xr[i + 3 * G] = e[3];
-                    }
-                    for (; i < a.inner; i += G) xr[i] = quant_one(xr[i], c, lrow, pmaxf, f.qthr);
-                } else {
-                    const Chan c = chans[r];
-                    for (int i = sub; i < a.inner; i += G) xr[i] = quant_direct(xr[i], c, f.M);
-                }
-            }
-        }
-        __syncthreads();
-        // ---- E: LDS -> global
-        float *yt = y + r0 * a.inner;
-        if (tid < head) yt[tid] = xs[pad + tid];
-        if (tail0 + tid < n) yt[tail0 + tid] = xs[pad + tail0 + tid];
-        {
-            const vf4 *sv = reinterpret_cast<const vf4 *>(xs + pad + head);
-            vf4 *yv = reinterpret_cast<vf4 *>(yt + head);
-            for (int i = tid; i < nvec; i += kBlock) st16<NT>(yv + i, sv[i]);
-        }
-    }
-}
 
 // ---------------------------------------------------------------------------------------------
 // Short rows, register-streamed: k_rows_direct (inner <= kDirectMaxInner).
@@ -787,85 +639,15 @@ inline int launch_rc() { return hip_rc(hipGetLastError()); }
 
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
-// Launch k_rows_tile for [C, inner] (inner <= kTileMaxInner).  MODE 0: y, maxval;  1: y, outputs;
-// 2: outputs = running estimate (row_min/row_max) + maxval_out, folded with `fa`.
-int launch_rows_tile(int mode, const float *x, float *y, int64_t C, int64_t inner, const float *maxval,
-                     float *row_min, float *row_max, float *maxval_out, const QFmt &f, const FoldArgs &fa,
-                     hipStream_t st)
-{
-    TileArgs a = {};
-    a.inner = (int)inner;
-    a.lut_stride = f.pmax + 1;
-    a.lmagic = magic_of(a.lut_stride);
-    a.magic = magic_of((int)inner);
-    const bool lut = mode != kModeMinMax && inner >= 2 * (int64_t)a.lut_stride;
-    // lanes per row: ~8 elements per lane, power of two <= 64; a long row takes the whole block
-    int G = 1;
-    while (G < 64 && (int64_t)G * 8 < inner) G <<= 1;
-    static const int tile_elems = [] {   // tuning knob for experiments (default kTileElems)
-        const char *e = getenv("FP8Q_TILE_ELEMS");
-        const int v = e ? atoi(e) : 0;
-        return v >= 256 && v <= kTileMaxInner ? v : kTileElems;
-    }();
-    int64_t R = tile_elems / inner;
-    if (inner * 4 > tile_elems) {   // long rows: one row per tile, all 256 threads on it
-        R = 1;
-        G = kBlock;
-    } else {
-        const int rpp = kBlock / G;                // rows per pass: keep R a multiple of it
-        if (R > 256) R = 256;                      // one make_chan pass
-        const int64_t want = cdiv(C, 1024);        // small tensors: spread over >= ~1024 blocks
-        if (R > want) R = want;
-        if (R >= rpp) R -= R % rpp;
-        if (R < 1) R = 1;
-    }
-    a.rows = (int)R;
-    a.group = G;
-    a.xs_floats = (int)((R * inner + 3 + 3) & ~(int64_t)3) + 4;
-    const size_t shmem = (size_t)a.xs_floats * 4 + (size_t)((R + 3) & ~(int64_t)3) * 4 +
-                         (size_t)R * sizeof(Chan) + (lut ? (size_t)R * a.lut_stride * sizeof(float2) : 0);
-    int64_t blocks = cdiv(C, R);
-    if (blocks > 2 * kTargetBlocks) blocks = 2 * kTargetBlocks;
-    const bool nt = C * inner * 4 >= kNtBytes;
-    const dim3 g((unsigned)blocks), b(kBlock);
-#define FP8Q_LAUNCH_TILE(M, L, N)                                                                       \
-    do {                                                                                                \
-        if (shmem > 64 * 1024) {                                                                        \
-            static int opted = 0;                                                                       \
-            if (!opted) {                                                                               \
-                hipError_t e = hipFuncSetAttribute((const void *)k_rows_tile<M, L, N>,                  \
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
-                if (e != hipSuccess) return (int)e;                                                     \
-                opted = 1;                                                                              \
-            }                                                                                           \
-        }                                                                                               \
-        hipLaunchKernelGGL((k_rows_tile<M, L, N>), g, b, shmem, st, x, y, C, maxval, row_min, row_max,  \
-                           maxval_out, f, a, fa);                                                       \
-    } while (0)
-    if (mode == kModeMinMax) {
-        if (nt) FP8Q_LAUNCH_TILE(kModeMinMax, false, true); else FP8Q_LAUNCH_TILE(kModeMinMax, false, false);
-    } else if (mode == kModeQuant) {
-        if (lut && nt) FP8Q_LAUNCH_TILE(kModeQuant, true, true);
-        else if (lut) FP8Q_LAUNCH_TILE(kModeQuant, true, false);
-        else if (nt) FP8Q_LAUNCH_TILE(kModeQuant, false, true);
-        else FP8Q_LAUNCH_TILE(kModeQuant, false, false);
-    } else {
-        if (lut && nt) FP8Q_LAUNCH_TILE(kModeFused, true, true);
-        else if (lut) FP8Q_LAUNCH_TILE(kModeFused, true, false);
-        else if (nt) FP8Q_LAUNCH_TILE(kModeFused, false, true);
-        else FP8Q_LAUNCH_TILE(kModeFused, false, false);
-    }
-#undef FP8Q_LAUNCH_TILE
-    return launch_rc();
-}
-
-// rows up to this length take k_rows_direct (tuning knob FP8Q_DIRECT_MAX_INNER for experiments)
+// K1 / K2: rows up to this length take k_rows_direct, longer ones the 2-D row kernels (measured
+// cross-over: [58254,4608] K1 6.3 TB/s with k_quant_rows vs 5.5 with k_rows_direct).  The fused
+// K2+K5+K1 path uses k_rows_direct up to kDirectMaxInner (5.1 TB/s at 4608 vs 3.9 two-pass).
 int64_t direct_max_inner()
 {
     static const int v = [] {
-        const char *e = getenv("FP8Q_DIRECT_MAX_INNER");
+        const char *e = getenv("FP8Q_DIRECT_MAX_INNER");   // tuning knob for experiments
         const int n = e ? atoi(e) : 0;
-        return n >= 4 && n <= kDirectMaxInner ? n : kDirectMaxInner;
+        return n >= 4 && n <= kDirectMaxInner ? n : 2047;
     }();
     return v;
 }
@@ -901,7 +683,12 @@ int launch_rows_direct(int mode, const float *x, float *y, int64_t C, int64_t in
     if (R > 256) R = 256;                         // one make_chan pass
     // tables + the 3 KiB of staged log2/exp2 tables must fit in 40 KiB of LDS (4 blocks per CU)
     const int64_t per_row = (int64_t)sizeof(Chan) + 4 + 16 + (lut ? (int64_t)a.lut_stride * 8 : 0);
-    const int64_t lds_cap = BSZ == 64 ? 10 * 1024 - 64 : 36 * 1024;
+    static const int lds_kb_env = [] {   // tuning knob: LDS budget of the per-row tables
+        const char *e = getenv("FP8Q_DIRECT_LDS_KB");
+        const int v = e ? atoi(e) : 0;
+        return v >= 4 && v <= 120 ? v : 36;
+    }();
+    const int64_t lds_cap = BSZ == 64 ? 10 * 1024 - 64 : (int64_t)lds_kb_env * 1024;
     if (R * per_row > lds_cap) R = lds_cap / per_row;
     const int64_t want = cdiv(C, 1024);           // small tensors: spread over >= ~1024 blocks
     if (R > want) R = want;
@@ -1067,7 +854,7 @@ int fp8q_minmax_f32(const float *x, int64_t C, int64_t inner, float *cur_min, fl
     return launch_rc();
 }
 
-int64_t fp8q_fused_max_inner(void) { return kTileMaxInner; }
+int64_t fp8q_fused_max_inner(void) { return kDirectMaxInner; }
 
 int fp8q_minmax_quantize_f32(const float *x, float *y, int64_t C, int64_t inner, float *row_min,
                              float *row_max, float *maxval_out, float mbits, int n_bits,
@@ -1078,15 +865,11 @@ int fp8q_minmax_quantize_f32(const float *x, float *y, int64_t C, int64_t inner,
     if (int rc = make_fmt(mbits, n_bits, sign_bits, &f)) return rc;
     if (C == 0 || inner == 0) return FP8Q_OK;
     if (!x || !y) return FP8Q_EINVAL;
-    if (inner > kTileMaxInner) return FP8Q_EUNSUPPORTED;
+    if (inner > kDirectMaxInner) return FP8Q_EUNSUPPORTED;
     if (((uintptr_t)x & 3) != 0 || ((uintptr_t)y & 3) != 0) return FP8Q_EINVAL;
     const FoldArgs nofold = {0, 1, 0.0f, 0.0f};
-    if (inner <= direct_max_inner())
-        return launch_rows_direct(kModeFused, x, y, C, inner, nullptr, row_min, row_max, maxval_out, f,
-                                  nofold, (hipStream_t)stream);
-    if ((((uintptr_t)x ^ (uintptr_t)y) & 15) != 0) return FP8Q_EINVAL;   // long rows: co-aligned only
-    return launch_rows_tile(kModeFused, x, y, C, inner, nullptr, row_min, row_max, maxval_out, f, nofold,
-                            (hipStream_t)stream);
+    return launch_rows_direct(kModeFused, x, y, C, inner, nullptr, row_min, row_max, maxval_out, f, nofold,
+                              (hipStream_t)stream);
 }
 
 static int mse_nsplit(int64_t C, int64_t inner, int64_t n_cand, int n_m)
