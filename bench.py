@@ -116,10 +116,31 @@ def extras(ops, dev):
     ya = y[: a.numel()].view_as(a)
     rec("k1_act_64x64x112x112_e5m2", a.numel(), 8, lambda: ops.quantize(a, mv1, 2, 8, 1, out=ya))
     rec("k3_act_64x64x112x112_allminmax", a.numel(), 4, lambda: ops.minmax(a, False))
+    # other ResNet-18 filter shapes, scaled up the same way (per-channel E5M2, fixed ranges / fused estimate)
+    for name, rows, shape in (("64x3x3", 1 << 18, (64, 3, 3)), ("512x3x3", 58254, (512, 3, 3))):
+        inner = shape[0] * shape[1] * shape[2]
+        xv = x[: rows * inner].view(rows, *shape)
+        yv = y[: rows * inner].view(rows, *shape)
+        _, _, mvv = ops.minmax(xv, True, want_maxval=True)
+        rec(f"k1_per_channel_Nx{name}_e5m2", xv.numel(), 8, lambda: ops.quantize(xv, mvv, 2, 8, 1, out=yv))
+        rec(f"fused_minmax_quant_Nx{name}_e5m2", xv.numel(), 8, lambda: ops.minmax_quantize(xv, 2, 8, 1, out=yv))
     w = torch.randn(64, 3, 7, 7, device=dev) * 0.1
     yw = torch.empty_like(w)
     rec("conv1_64x3x7x7_fused_minmax_quant_e5m2", w.numel(), 8,
         lambda: ops.minmax_quantize(w, 2, 8, 1, out=yw), iters=200)
+    # all 21 ResNet-18 weight tensors (11.68 M elements), re-quantized as on every forward
+    shapes = [(64, 3, 7, 7)] + [(64, 64, 3, 3)] * 4 + [(128, 64, 3, 3), (128, 128, 3, 3), (128, 64, 1, 1)] + \
+        [(128, 128, 3, 3)] * 2 + [(256, 128, 3, 3), (256, 256, 3, 3), (256, 128, 1, 1)] + [(256, 256, 3, 3)] * 2 + \
+        [(512, 256, 3, 3), (512, 512, 3, 3), (512, 256, 1, 1)] + [(512, 512, 3, 3)] * 2 + [(1000, 512)]
+    ws = [torch.randn(*sh, device=dev) * 0.05 for sh in shapes]
+    ys = [torch.empty_like(t) for t in ws]
+    mvs = [ops.minmax(t, True, want_maxval=True)[2] for t in ws]
+    n_w = sum(t.numel() for t in ws)
+
+    def all_weights():
+        for t, o, m in zip(ws, ys, mvs):
+            ops.quantize(t, m, 2, 8, 1, out=o)
+    rec("resnet18_all_21_weight_tensors_k1_e5m2", n_w, 8, all_weights, iters=50)
     del x, y
     return out
 
