@@ -20,7 +20,7 @@ def short(k):
 
 rows = list(csv.DictReader(open(os.path.join(kt, "bench_kernel_stats.csv"))))
 with open(f"profiles/{tag}_bench_kernel_stats.csv", "w") as f:
-    f.write(f"# rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline"
+    f.write(f"# rocprofv3 --kernel-trace --stats -- python bench.py --no-extras --no-cpu-baseline"
             f"   ({tag}, MI355X; kernel names shortened)\n")
     f.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs,StdDev\n")
     for r in rows:
