@@ -11,8 +11,35 @@ FOLD_CURRENT, FOLD_ALL, FOLD_RUNNING = 0, 1, 2
 _ws_cache = {}
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream(t):
+    """raw hipStream_t of torch's current stream on t's device (fast path avoids a Stream object)."""
+    if _raw_stream is not None:
+        return _raw_stream(t.device.index)
     return torch.cuda.current_stream(t.device).cuda_stream
+
+
+class _on_device:
+    """`with _on_device(t):` -- make t's device current for the launch; a no-op (and no torch call
+    beyond one integer query) when it already is, which is the single-GPU-per-process case."""
+    __slots__ = ("idx", "prev")
+
+    def __init__(self, t):
+        self.idx = t.device.index
+        self.prev = None
+
+    def __enter__(self):
+        cur = torch.cuda.current_device()
+        if cur != self.idx:
+            self.prev = cur
+            torch.cuda.set_device(self.idx)
+
+    def __exit__(self, *exc):
+        if self.prev is not None:
+            torch.cuda.set_device(self.prev)
+        return False
 
 
 def _require(t, name):
@@ -50,7 +77,7 @@ def quantize(x, maxval, mbits, n_bits=8, sign_bits=1, out=None):
     if n_mv != 1 and n_mv != C:
         raise Fp8qError(f"maxval has {n_mv} elements, expected 1 or {C}")
     y = torch.empty_like(x) if out is None else out
-    with torch.cuda.device(x.device):
+    with _on_device(x):
         rc = lib().fp8q_quantize_f32(x.data_ptr(), y.data_ptr(), C, inner, maxval.data_ptr(), n_mv,
                                      float(mbits), int(n_bits), int(sign_bits), _stream(x))
     check(rc, "fp8q_quantize_f32")
@@ -83,7 +110,7 @@ def minmax(x, per_channel, cur_min=None, cur_max=None, mode=FOLD_CURRENT, moment
     L = lib()
     nbytes = L.fp8q_minmax_workspace_bytes(C, inner)
     ws = _workspace(x.device, nbytes)
-    with torch.cuda.device(x.device):
+    with _on_device(x):
         rc = L.fp8q_minmax_f32(x.data_ptr(), C, inner, cur_min.data_ptr(), cur_max.data_ptr(),
                                mv.data_ptr() if mv is not None else None, int(mode), float(momentum),
                                int(first), ws.data_ptr(), ws.numel(), _stream(x))
@@ -106,7 +133,7 @@ def minmax_quantize(x, mbits, n_bits=8, sign_bits=1, out=None):
     mn = torch.empty(C, dtype=torch.float32, device=x.device)
     mx = torch.empty_like(mn)
     mv = torch.empty_like(mn)
-    with torch.cuda.device(x.device):
+    with _on_device(x):
         rc = lib().fp8q_minmax_quantize_f32(x.data_ptr(), y.data_ptr(), C, inner, mn.data_ptr(),
                                             mx.data_ptr(), mv.data_ptr(), float(mbits), int(n_bits),
                                             int(sign_bits), _stream(x))
@@ -118,7 +145,7 @@ def copy(x, out=None):
     """float4 copy kernel with K1's launch shape (HBM ceiling yardstick)."""
     _require(x, "x")
     y = torch.empty_like(x) if out is None else out
-    with torch.cuda.device(x.device):
+    with _on_device(x):
         rc = lib().fp8q_copy_f32(x.data_ptr(), y.data_ptr(), x.numel(), _stream(x))
     check(rc, "fp8q_copy_f32")
     return y
@@ -144,7 +171,7 @@ def mse_grid(x, per_channel, grid, mbits_list, n_bits, sign_bits, mses):
     L = lib()
     ws = _workspace(x.device, L.fp8q_mse_workspace_bytes(C, inner, n_cand, n_m))
     mb = (ctypes.c_float * n_m)(*[float(v) for v in mbits_list])
-    with torch.cuda.device(x.device):
+    with _on_device(x):
         rc = L.fp8q_mse_grid_f32(x.data_ptr(), C, inner, grid.data_ptr(), n_cand, mb, n_m, int(n_bits),
                                  int(sign_bits), mses.data_ptr(), ws.data_ptr(), ws.numel(), _stream(x))
     check(rc, "fp8q_mse_grid_f32")

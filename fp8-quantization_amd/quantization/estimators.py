@@ -12,7 +12,9 @@ import torch
 from torch import nn
 
 from fp8q import ops as _ops
-from .registry import ClassEnumOptions, MethodMap
+from enum import auto
+
+from .registry import BaseEnumOptions, ClassEnumOptions, MethodMap
 
 
 class NoDataPassedError(Exception):
@@ -165,10 +167,111 @@ class FP_MSE_Estimator(RangeEstimatorBase):
         return sign_bits * -1.0 * maxval, maxval
 
 
+class OptMethod(BaseEnumOptions):
+    grid = auto()
+    golden_section = auto()
+
+
+class LineSearchEstimator(RangeEstimatorBase):
+    """1-D grid search of the clipping threshold that minimises the squared quantization error
+    (reference range_estimators.py:133-282; used by compute_quant_error.py through
+    estimate_range_line_search).  Candidate k of `num_candidates` clips at
+    k * (max|x| + range_margin) * expand_range / num_candidates; losses accumulate over calls.
+
+    FP8 quantizers evaluate ALL candidates in one pass over x with the MSE-grid kernel
+    (fp8q_mse_grid_f32 with n_cand = num_candidates); INT quantizers, the comparison baseline,
+    loop over candidates with elementwise torch ops.  Only the symmetric 1-D search exists: the
+    reference takes it for every quantizer that can reach this estimator (`quantizer.symmetric`
+    is used without being called there, so it is truthy for FPQuantizer too -- SURVEY.md 3.4).
+    The reference evaluates in float64 on the CPU; here x is cast to fp32 on the device, and the
+    per-candidate sums are accumulated in double inside the kernel.
+    """
+
+    def __init__(self, num_candidates=1000, opt_method=OptMethod.grid, range_margin=0.5, expand_range=10.0,
+                 *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        assert opt_method in OptMethod
+        if opt_method != OptMethod.grid:
+            raise NotImplementedError("only the grid search is on the GPU path")
+        if self.quantizer is None:
+            raise NotImplementedError("A Quantizer must be given as an argument to the MSE RangeEstimator")
+        self.opt_method = opt_method
+        self.num_candidates = num_candidates
+        self.expand_range = expand_range
+        self.range_margin = range_margin
+        self.loss_array = None
+        self.max_pos_thr = self.max_neg_thr = self.max_search_range = None
+        self.one_sided_dist = None
+
+    @property
+    def step_size(self):
+        if self.one_sided_dist is None:
+            raise NoDataPassedError()
+        return self.max_search_range / self.num_candidates
+
+    def reset(self):
+        super().reset()
+        self.loss_array = None
+
+    def _define_search_range(self, data):
+        self.channel_groups = len(data) if self.per_channel else 1
+        self.loss_array = np.zeros((self.channel_groups, self.num_candidates + 1))
+        self.loss_array[:, 0] = np.inf            # candidate 0 would be an empty range
+        mn, mx = _ops.minmax(data, False)
+        lo, hi = float(mn), float(mx)
+        if self.one_sided_dist is None:
+            self.one_sided_dist = lo >= 0
+        self.max_pos_thr = max(abs(lo), hi) + self.range_margin
+        self.max_neg_thr = -self.max_pos_thr * self.expand_range
+        self.max_search_range = self.max_pos_thr * self.expand_range
+
+    def _candidate_losses(self, data):
+        """[channel_groups, num_candidates] sums of squared errors for candidates 1..N."""
+        from .fp8 import FPQuantizer
+        q = self.quantizer
+        n = self.num_candidates
+        thr = np.float32(self.step_size * np.arange(1, n + 1))            # what Tensor([x_max]) holds
+        C = self.channel_groups
+        inner = data.numel() // C
+        if isinstance(q, FPQuantizer):
+            if not q.set_maxval:
+                raise NotImplementedError("line search needs set_maxval=True to change the range")
+            grid = torch.from_numpy(thr).to(data.device).view(n, 1).expand(n, C).contiguous()
+            mses = torch.zeros(1, n, C, device=data.device)
+            sign_bits = 0 if (q.allow_unsigned and self.one_sided_dist) else q.sign_bits
+            _ops.mse_grid(data, self.per_channel, grid, [float(q.mantissa_bits)], q.n_bits, sign_bits, mses)
+            return (mses[0].double() * inner).transpose(0, 1).cpu().numpy()
+        import copy
+        out = np.zeros((C, n))
+        flat = data.view(C, -1)
+        for k in range(n):
+            tq = copy.deepcopy(q)
+            tq.per_channel = False
+            tq.set_quant_range(0.0 if self.one_sided_dist else -float(thr[k]), float(thr[k]))
+            out[:, k] = ((flat - tq(flat)) ** 2).sum(1).double().cpu().numpy()
+        return out
+
+    def forward(self, data):
+        data = data.detach()
+        if data.dtype != torch.float32:
+            data = data.float()
+        if self.loss_array is None:
+            self._define_search_range(data)
+        self.loss_array[:, 1:] += self._candidate_losses(data.contiguous())
+        best = self.loss_array.argmin(axis=1)
+        xmax = (self.step_size * best).astype(np.single)
+        xmin = np.zeros(self.channel_groups, np.single) if self.one_sided_dist else (-self.step_size * best).astype(np.single)
+        self.current_xmax = torch.tensor(xmax).to(device=data.device)
+        self.current_xmin = torch.tensor(xmin).to(device=data.device)
+        return self.current_xmin, self.current_xmax
+
+    def extra_repr(self):
+        return f"opt_method={self.opt_method.name} ,num_candidates={self.num_candidates}"
+
+
 def estimate_range_line_search(W, quant, num_candidates=None):
-    raise NotImplementedError(
-        "LineSearchEstimator (range_estimators.py:133-282, compute_quant_error.py only) is a "
-        "'next' row of SURVEY.md 8(f) and is not part of the GPU hot path yet")
+    kw = {} if num_candidates is None else dict(num_candidates=num_candidates)
+    return LineSearchEstimator(quantizer=quant, **kw).forward(W)
 
 
 class RangeEstimators(ClassEnumOptions):

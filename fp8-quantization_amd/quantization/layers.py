@@ -17,7 +17,8 @@ from torch.nn import functional as F
 from torch.nn.modules.conv import _ConvNd
 from torch.nn.modules.pooling import _AdaptiveAvgPoolNd, _AvgPoolNd
 
-from .manager import QuantizationManager, AsymmetricUniformQuantizer
+from .manager import QuantizationManager
+from .uniform import AsymmetricUniformQuantizer
 from .estimators import RangeEstimators, CurrentMinMaxEstimator, RunningMinMaxEstimator
 
 # activation modules that may be fused behind a weight layer (hijacker.py:15-29); the timm

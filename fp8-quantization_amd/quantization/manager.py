@@ -17,26 +17,9 @@ from torch import nn
 from fp8q import ops as _ops
 from .registry import BaseEnumOptions, ClassEnumOptions, MethodMap
 from .fp8 import FPQuantizer, QuantizerBase, QuantizerNotInitializedError
+from .uniform import SymmetricUniformQuantizer, AsymmetricUniformQuantizer
 from .estimators import (RangeEstimators, RangeEstimatorBase, CurrentMinMaxEstimator,
                          AllMinMaxEstimator, RunningMinMaxEstimator)
-
-
-class _UniformQuantizerOutOfScope(QuantizerBase):
-    """INT quantizers are the CPU comparison baseline of compute_quant_error.py only
-    (out of scope for the GPU hot path)."""
-
-    def __init__(self, *args, **kwargs):
-        raise NotImplementedError(
-            f"{type(self).__name__}: uniform (INT) quantizers are outside the FP8 hot-path scope of "
-            "this build; use --qmethod fp_quantizer")
-
-
-class SymmetricUniformQuantizer(_UniformQuantizerOutOfScope):
-    pass
-
-
-class AsymmetricUniformQuantizer(_UniformQuantizerOutOfScope):
-    pass
 
 
 class QMethods(ClassEnumOptions):

@@ -1,2 +1,2 @@
-from ..fp8 import QuantizerBase, FPQuantizer  # noqa: F401
+"""Alias of quantization.uniform under the reference's module name."""
 from ..uniform import AsymmetricUniformQuantizer, SymmetricUniformQuantizer  # noqa: F401

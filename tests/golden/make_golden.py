@@ -16,6 +16,7 @@ Fixture files:
   g2_grids.npz       generate_all_values_fp   (fp8_quantizer.py:13-41)
   g3_estimators.npz  Current/All/RunningMinMax (range_estimators.py:56-125) + set_quant_range
   g4_mse.npz         FP_MSE_Estimator         (range_estimators.py:285-369)
+  g5_quant_error.npz compute_quant_error.py (config 1) at 200 k samples + closed-form integrals
   g6_manager.npz     QuantizationManager.forward state machine (quantization_manager.py:114-122)
   g7_tinycnn.npz     quantize_model on a tiny CNN (autoquant_utils.py:292-381), config-3 settings
   g8_resnet18.npz    QuantizedResNet (models/resnet_quantized.py:49-133), BASELINE config 3 at 64x64
@@ -334,6 +335,48 @@ def copy_net(net):
     return copy.deepcopy(net)
 
 
+def make_g5():
+    """BASELINE config 1 (fast variant): compute_quant_error.py with 200 000 samples, seed 10.
+    Per distribution and format: line-search range, analytic quantization MSE, analytic dot-product
+    MSE -- plus a few raw values of the closed-form interval integrals (utils/distributions.py)."""
+    from utils.distributions import ClippedGaussDistr, UniformDistr, ClippedStudentTDistr
+    from quantization.quant_error_estimator import compute_expected_quant_mse, compute_expected_dot_prod_mse
+    from quantization.range_estimators import estimate_range_line_search
+    from quantization.quantizers.uniform_quantizers import SymmetricUniformQuantizer
+    from utils import seed_all
+    distrs = {"uniform": UniformDistr(range_min=-1.0, range_max=1.0, params_dict={}),
+              "gauss": ClippedGaussDistr(params_dict={"mu": 0.0, "sigma": 1.0}, range_min=-10.0, range_max=10.0),
+              "student": ClippedStudentTDistr(params_dict={"nu": 8.0}, range_min=-100.0, range_max=100.0)}
+    out = {}
+    n = 200000
+    for name, d in distrs.items():
+        seed_all(10)
+        sample = torch.tensor(d.sample((n,)))
+        out[f"{name}_sample_head"] = sample[:64].numpy().copy()
+        out[f"{name}_sample_sum"] = np.array(float(sample.sum()))
+        rows = []
+        for exp_bits in (5, 4, 3, 2, 0):
+            M = 7 - exp_bits
+            q = FPQuantizer(n_bits=8, mantissa_bits=M, set_maxval=True) if exp_bits > 0 \
+                else SymmetricUniformQuantizer(n_bits=8)
+            rmin, rmax = estimate_range_line_search(sample, q)
+            mse = compute_expected_quant_mse(d, q, rmin, rmax, n)
+            dp = compute_expected_dot_prod_mse(d, d, q, q, rmin, rmax, rmin, rmax)
+            rows.append((exp_bits, float(rmin), float(rmax), float(mse), float(dp)))
+            print(name, rows[-1])
+        out[f"{name}_rows"] = np.array(rows)
+        # raw integrals on a few intervals
+        ab = [(-0.7, -0.2, -0.5), (0.0, 0.3, 0.25), (0.1, 0.9, 1.0), (-1.0, 1.0, 0.0)]
+        if name != "uniform":
+            ab += [(2.0, 7.5, 3.0), (-9.0, -0.5, -4.0)]
+        out[f"{name}_ab"] = np.array(ab)
+        out[f"{name}_p_sqr_r"] = np.array([d.integr_interv_p_sqr_r(a, b, u) for a, b, u in ab])
+        out[f"{name}_x_p_signed_r"] = np.array([d.integr_interv_x_p_signed_r(a, b, u) for a, b, u in ab])
+        out[f"{name}_second_moment"] = np.array(d.eval_non_central_second_moment())
+    np.savez_compressed(os.path.join(OUT, "g5_quant_error.npz"), **out)
+    print("g5 ok")
+
+
 def _load_own(name, relpath):
     """import one of THIS repo's fp32 model definitions by path (the reference's `models` package
     owns the name `models` in this process)."""
@@ -441,6 +484,7 @@ if __name__ == "__main__":
     make_g2()
     make_g3()
     make_g4()
+    make_g5()
     make_g6()
     make_g7()
     make_g8()
