@@ -78,8 +78,8 @@ def test_registries_and_defaults():
     assert qm.state == Qstates.estimate_ranges and qm.n_bits == 8
     qm.fix_ranges()
     assert qm.state == Qstates.fix_ranges and qm.quantizer.state == Qstates.fix_ranges
-    with pytest.raises(NotImplementedError):
-        QMethods.symmetric_uniform(n_bits=8)
+    from quantization.quantizers.uniform_quantizers import SymmetricUniformQuantizer
+    assert isinstance(QMethods.symmetric_uniform(n_bits=8), SymmetricUniformQuantizer)
 
 
 def test_set_quant_range_host_semantics():
