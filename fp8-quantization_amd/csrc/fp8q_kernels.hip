@@ -176,7 +176,7 @@ constexpr int kModeQuant = 0, kModeFused = 1, kModeMinMax = 2;
 // Dynamic LDS: float rowmv[R4] | float4 patch[R] | Chan chans[R] | float2 lut[R * lut_stride]
 // ---------------------------------------------------------------------------------------------
 template <int MODE, bool LUT, bool NT, int BS>
-__global__ void __launch_bounds__(BS)
+__global__ void __launch_bounds__(BS, BS == 256 ? 4 : 1)   // <= 128 VGPRs: 4 blocks of 256 per CU
 k_rows_direct(const float *__restrict__ x, float *__restrict__ y, int64_t C,
               const float *__restrict__ maxval, float *row_min, float *row_max, float *maxval_out,
               QFmt f, TileArgs a, FoldArgs fa)
@@ -200,6 +200,17 @@ k_rows_direct(const float *__restrict__ x, float *__restrict__ y, int64_t C,
 
     for (int64_t r0 = (int64_t)blockIdx.x * Rmax; r0 < C; r0 += (int64_t)gridDim.x * Rmax) {
         const int R = (int)((C - r0) < Rmax ? (C - r0) : Rmax);
+        // geometry of pass B (the R rows as one flat range) -- needed early for the prefetch
+        const int n = R * inner;
+        const float *xt = x + r0 * inner;
+        float *yt = y + r0 * inner;
+        int head = a.coaligned ? (int)((4 - (((uintptr_t)xt >> 2) & 3)) & 3) : 0;
+        if (head > n || inner < 4) head = n;          // rows shorter than a group: all scalar
+        const int nvec = (n - head) >> 2;
+        const int bend = head + (nvec << 2);
+        constexpr int U = 4;   // four 16-byte loads in flight per lane
+        // (prefetching the first U loads before the table phase was measured: +25 VGPRs, one wave
+        // per SIMD less, -8 %: not done)
         __syncthreads();   // tables of the previous iteration are no longer read (and ftab is staged)
         if (MODE != kModeQuant) {
             for (int rb = 0; rb < R; rb += rpp) {
@@ -269,13 +280,6 @@ k_rows_direct(const float *__restrict__ x, float *__restrict__ y, int64_t C,
         // the <= 3 elements that follow it (with the next row's constants), so every store of the
         // body is a full aligned 16 bytes (no partial-line read-modify-write in HBM).
         {
-            const int n = R * inner;
-            const float *xt = x + r0 * inner;
-            float *yt = y + r0 * inner;
-            int head = a.coaligned ? (int)((4 - (((uintptr_t)xt >> 2) & 3)) & 3) : 0;
-            if (head > n || inner < 4) head = n;          // rows shorter than a group: all scalar
-            const int nvec = (n - head) >> 2;
-            const int bend = head + (nvec << 2);
             auto quant_at = [&](int i) -> float {
                 const int ch = div_small((uint32_t)i, a.magic);
                 if (LUT) return quant_one(xt[i], lite_lds(chans + ch), lut + ch * a.lut_stride, pmaxf, f.qthr);
@@ -294,7 +298,6 @@ k_rows_direct(const float *__restrict__ x, float *__restrict__ y, int64_t C,
                 patch[c] = make_float4(pv[0], pv[1], pv[2], 0.0f);
             }
             __syncthreads();
-            constexpr int U = 4;   // four 16-byte loads in flight per lane
             for (int j0 = tid; j0 < nvec; j0 += BS * U) {
                 vf4 v[U];
 #pragma unroll
