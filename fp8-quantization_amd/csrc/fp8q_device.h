@@ -261,6 +261,60 @@ __device__ __forceinline__ float quant_direct(float x, const Chan &c, float M)
     return (x != x) ? x : y;
 }
 
+// ---- storage codes --------------------------------------------------------
+// The byte layout is the one the reference's enumerator defines (fp8_quantizer.py:13-41):
+// [sign | E exponent bits | M fraction bits]; exponent code 0 is subnormal, the all-ones exponent
+// is an ordinary binade (no inf/NaN codes).  In terms of K1's integers (p = binade index >= 1,
+// r = rint(|xc| / s_p) <= 2^(M+1)):   r < 2^M (only when p == 1)  ->  exponent code 0, fraction r
+//                                     r == 2^(M+1) (rounded up)   ->  exponent code p+1, fraction 0
+//                                     otherwise                   ->  exponent code p, fraction r - 2^M
+// so decode(code) = +/- (fraction + [exp != 0] * 2^M) * s_max(exp,1), the very product K1 forms.
+__device__ __forceinline__ uint32_t encode_one(float x, const ChanLite &c, const float2 *lut, float pmaxf,
+                                               float qthr, int M, int sign_shift)
+{
+    // same decisions as quant_fast / quant_exact, keeping r and the table index
+    const float xc = __builtin_amdgcn_fmed3f(x, c.minv, c.maxv);
+    const float v = __builtin_amdgcn_logf(fabsf(xc)) + c.bias;
+    float fl = floorf(v);
+    const float fr = v - fl;
+    float ls = __builtin_amdgcn_fmed3f(fl, 1.0f, pmaxf);
+    float2 t = lut[(int)ls];
+    float q0 = xc * t.y;
+    float r = rintf(q0);
+    const bool risky = __builtin_amdgcn_classf(x, 0x93) | (fabsf(fr - 0.5f) > c.pthr) |
+                       (fabsf(q0 - r) > qthr) | (c.pthr < 0.0f);
+    if (__builtin_expect(risky, 0)) {
+        if (x != x) return 0u;                      // the format has no NaN code: documented as +0
+        fl = floorf((float)log2((double)fabsf(xc)) + c.bias);
+        ls = __builtin_amdgcn_fmed3f(fl, 1.0f, pmaxf);
+        t = lut[(int)ls];
+        r = rintf(xc / t.x);
+        if (r != r) return 0u;                      // degenerate channel (maxval 0 / inf / NaN)
+    }
+    const uint32_t ri = (uint32_t)fabsf(r);
+    const uint32_t m2 = 1u << M;
+    uint32_t e = (uint32_t)ls, f = ri - m2;
+    if (ri < m2) {
+        e = 0u;
+        f = ri;
+    } else if (ri == 2u * m2) {
+        e += 1u;
+        f = 0u;
+    }
+    const uint32_t sign = sign_shift >= 0 ? ((__float_as_uint(r) >> 31) << sign_shift) : 0u;
+    return sign | (e << M) | f;
+}
+
+__device__ __forceinline__ float decode_one(uint32_t code, const float2 *lut, int M, int sign_shift)
+{
+    const uint32_t m2 = 1u << M;
+    const uint32_t body = sign_shift >= 0 ? (code & ((1u << sign_shift) - 1u)) : code;
+    const uint32_t e = body >> M, f = body & (m2 - 1u);
+    const float r = (float)(f + (e ? m2 : 0u));
+    const float y = r * lut[e ? e : 1u].x;
+    return (sign_shift >= 0 && ((code >> sign_shift) & 1u)) ? -y : y;
+}
+
 // ---- streaming memory access: 16 B per lane, optionally nontemporal -------------------------
 template <bool NT>
 __device__ __forceinline__ vf4 ld16(const vf4 *p)

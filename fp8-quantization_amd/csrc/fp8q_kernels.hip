@@ -590,6 +590,62 @@ k_mse_final(const double *__restrict__ ws, float *__restrict__ mses, int64_t C, 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// N3: storage codes.  One row per blockIdx.y like k_quant_rows; a lane converts 16 consecutive
+// elements per step (4 x 16-byte fp32 accesses <-> one 16-byte access of codes).
+// encode: 4 B read + 1 B written per element; decode: 1 B read + 4 B written.
+// ---------------------------------------------------------------------------------------------
+template <bool ENCODE>
+__global__ void __launch_bounds__(kBlock)
+k_codec_rows(const float *__restrict__ x, uint8_t *__restrict__ codes, float *__restrict__ y, int64_t inner,
+             const float *__restrict__ maxval, int per_channel, QFmt f, int n_bits)
+{
+    __shared__ float2 lut[kLutMax];
+    const int row = blockIdx.y, tid = threadIdx.x;
+    const Chan cfull = make_chan(maxval[per_channel ? row : 0], f);
+    for (int i = tid; i <= f.pmax; i += kBlock) lut[i] = lut_entry(cfull, i, f.M);
+    __syncthreads();
+    const ChanLite c = lite(cfull);
+    const float pmaxf = (float)f.pmax;
+    const int M = (int)f.M, sign_shift = f.sign_bits == 1 ? n_bits - 1 : -1;
+    const float *xr = ENCODE ? x + (int64_t)row * inner : nullptr;
+    float *yr = ENCODE ? nullptr : y + (int64_t)row * inner;
+    uint8_t *cr = codes + (int64_t)row * inner;
+    // 16-element groups whose fp32 side is 16-byte aligned and whose code side is 16-byte aligned:
+    // that needs (row*inner) % 16 == 0; otherwise everything goes through the scalar loop
+    const uintptr_t fa = (uintptr_t)(ENCODE ? (const void *)xr : (const void *)yr);
+    const bool vec = (fa & 15) == 0 && ((uintptr_t)cr & 15) == 0;
+    const int64_t ngrp = vec ? inner >> 4 : 0;
+    for (int64_t g = (int64_t)blockIdx.x * kBlock + tid; g < ngrp; g += (int64_t)gridDim.x * kBlock) {
+        if (ENCODE) {
+            const vf4 *xv = reinterpret_cast<const vf4 *>(xr + g * 16);
+            vf4 v[4] = {xv[0], xv[1], xv[2], xv[3]};
+            uint32_t w[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                w[k] = encode_one(v[k].x, c, lut, pmaxf, f.qthr, M, sign_shift) |
+                       (encode_one(v[k].y, c, lut, pmaxf, f.qthr, M, sign_shift) << 8) |
+                       (encode_one(v[k].z, c, lut, pmaxf, f.qthr, M, sign_shift) << 16) |
+                       (encode_one(v[k].w, c, lut, pmaxf, f.qthr, M, sign_shift) << 24);
+            *reinterpret_cast<uint4 *>(cr + g * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+        } else {
+            const uint4 w4 = *reinterpret_cast<const uint4 *>(cr + g * 16);
+            const uint32_t w[4] = {w4.x, w4.y, w4.z, w4.w};
+            vf4 *yv = reinterpret_cast<vf4 *>(yr + g * 16);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                yv[k] = vf4{decode_one(w[k] & 255u, lut, M, sign_shift), decode_one((w[k] >> 8) & 255u, lut, M, sign_shift),
+                            decode_one((w[k] >> 16) & 255u, lut, M, sign_shift), decode_one(w[k] >> 24, lut, M, sign_shift)};
+        }
+    }
+    for (int64_t i = (ngrp << 4) + (int64_t)blockIdx.x * kBlock + tid; i < inner; i += (int64_t)gridDim.x * kBlock) {
+        if (ENCODE)
+            cr[i] = (uint8_t)encode_one(xr[i], c, lut, pmaxf, f.qthr, M, sign_shift);
+        else
+            yr[i] = decode_one(cr[i], lut, M, sign_shift);
+    }
+}
+
 // 16-byte-per-lane copy with K1's launch shape: the achievable-HBM yardstick
 template <bool NT>
 __global__ void __launch_bounds__(kBlock)
@@ -936,6 +992,52 @@ int fp8q_mse_grid_f32(const float *x, int64_t C, int64_t inner, const float *gri
     hipLaunchKernelGGL(k_mse_final, dim3((unsigned)fb), dim3(kBlock), 0, st, (const double *)ws, mses, C,
                        n_m, (int)n_cand, a.nsplit, 1.0 / (double)inner);
     return launch_rc();
+}
+
+static int codec_launch(bool encode, const float *x, uint8_t *codes, float *y, int64_t C, int64_t inner,
+                        const float *maxval, int64_t n_maxval, float mbits, int n_bits, int sign_bits,
+                        fp8q_stream_t stream)
+{
+    if (C < 0 || inner < 0 || (n_maxval != 1 && n_maxval != C) || n_bits > 8) return FP8Q_EINVAL;
+    QFmt f;
+    if (int rc = make_fmt(mbits, n_bits, sign_bits, &f)) return rc;
+    if ((int)f.M > 7 || (sign_bits == 1 && (int)f.M > n_bits - 1)) return FP8Q_EINVAL;
+    if (C == 0 || inner == 0) return FP8Q_OK;
+    if (!codes || !maxval || (encode ? !x : !y)) return FP8Q_EINVAL;
+    const int per_channel = n_maxval != 1;
+    if (!per_channel) {
+        inner *= C;
+        C = 1;
+    }
+    for (int64_t c0 = 0; c0 < C; c0 += 65535) {
+        const int64_t cn = (C - c0) < 65535 ? (C - c0) : 65535;
+        int64_t bx = cdiv(cdiv(inner, 16), kBlock);
+        const int64_t cap = kTargetBlocks / cn > 0 ? kTargetBlocks / cn : 1;
+        if (bx > cap) bx = cap;
+        if (bx < 1) bx = 1;
+        const dim3 g((unsigned)bx, (unsigned)cn), b(kBlock);
+        if (encode)
+            hipLaunchKernelGGL(k_codec_rows<true>, g, b, 0, (hipStream_t)stream, x + c0 * inner, codes + c0 * inner,
+                               (float *)nullptr, inner, maxval + (per_channel ? c0 : 0), per_channel, f, n_bits);
+        else
+            hipLaunchKernelGGL(k_codec_rows<false>, g, b, 0, (hipStream_t)stream, (const float *)nullptr,
+                               codes + c0 * inner, y + c0 * inner, inner, maxval + (per_channel ? c0 : 0),
+                               per_channel, f, n_bits);
+    }
+    return launch_rc();
+}
+
+int fp8q_encode_u8(const float *x, uint8_t *codes, int64_t C, int64_t inner, const float *maxval,
+                   int64_t n_maxval, float mbits, int n_bits, int sign_bits, fp8q_stream_t stream)
+{
+    return codec_launch(true, x, codes, nullptr, C, inner, maxval, n_maxval, mbits, n_bits, sign_bits, stream);
+}
+
+int fp8q_decode_u8(const uint8_t *codes, float *y, int64_t C, int64_t inner, const float *maxval,
+                   int64_t n_maxval, float mbits, int n_bits, int sign_bits, fp8q_stream_t stream)
+{
+    return codec_launch(false, nullptr, const_cast<uint8_t *>(codes), y, C, inner, maxval, n_maxval, mbits,
+                        n_bits, sign_bits, stream);
 }
 
 int fp8q_copy_f32(const float *x, float *y, int64_t n, fp8q_stream_t stream)

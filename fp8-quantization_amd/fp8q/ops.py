@@ -176,3 +176,40 @@ def mse_grid(x, per_channel, grid, mbits_list, n_bits, sign_bits, mses):
                                  int(sign_bits), mses.data_ptr(), ws.data_ptr(), ws.numel(), _stream(x))
     check(rc, "fp8q_mse_grid_f32")
     return mses
+
+
+def encode(x, maxval, mbits, n_bits=8, sign_bits=1, out=None):
+    """N3: uint8 storage codes of quantize(x) ([sign | exponent | fraction], fp8_quantizer.py:13-41)."""
+    _require(x, "x")
+    _require(maxval, "maxval")
+    x = x.contiguous()
+    maxval = maxval.contiguous().view(-1)
+    n_mv = maxval.numel()
+    C, inner = _rows(x, n_mv != 1)
+    if n_mv != 1 and n_mv != C:
+        raise Fp8qError(f"maxval has {n_mv} elements, expected 1 or {C}")
+    codes = torch.empty(x.shape, dtype=torch.uint8, device=x.device) if out is None else out
+    with _on_device(x):
+        rc = lib().fp8q_encode_u8(x.data_ptr(), codes.data_ptr(), C, inner, maxval.data_ptr(), n_mv, float(mbits),
+                                  int(n_bits), int(sign_bits), _stream(x))
+    check(rc, "fp8q_encode_u8")
+    return codes
+
+
+def decode(codes, maxval, mbits, n_bits=8, sign_bits=1, out=None):
+    """N3: fp32 values of uint8 storage codes; decode(encode(x)) == quantize(x) bit for bit."""
+    if not isinstance(codes, torch.Tensor) or not codes.is_cuda or codes.dtype != torch.uint8:
+        raise Fp8qError("codes must be a CUDA(HIP) uint8 tensor")
+    _require(maxval, "maxval")
+    codes = codes.contiguous()
+    maxval = maxval.contiguous().view(-1)
+    n_mv = maxval.numel()
+    C, inner = _rows(codes, n_mv != 1)
+    if n_mv != 1 and n_mv != C:
+        raise Fp8qError(f"maxval has {n_mv} elements, expected 1 or {C}")
+    y = torch.empty(codes.shape, dtype=torch.float32, device=codes.device) if out is None else out
+    with _on_device(codes):
+        rc = lib().fp8q_decode_u8(codes.data_ptr(), y.data_ptr(), C, inner, maxval.data_ptr(), n_mv, float(mbits),
+                                  int(n_bits), int(sign_bits), _stream(codes))
+    check(rc, "fp8q_decode_u8")
+    return y

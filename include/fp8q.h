@@ -101,6 +101,20 @@ int fp8q_mse_grid_f32(const float *x, int64_t C, int64_t inner, const float *gri
                       const float *mbits_host, int n_m, int n_bits, int sign_bits, float *mses,
                       void *ws, size_t ws_bytes, fp8q_stream_t stream);
 
+/*
+ * N3 -- real FP8 storage codes.  The reference only simulates the format; its
+ * enumerator generate_all_values_fp (fp8_quantizer.py:13-41) defines the byte layout
+ * [sign | E exponent bits | M fraction bits] (exponent code 0 subnormal, no inf/NaN codes).
+ *   fp8q_encode_u8: codes[i] = the byte whose value is quantize_to_fp8_ste_MM(x)[i]
+ *   fp8q_decode_u8: y[i] = value of codes[i]; decode(encode(x)) == fp8q_quantize_f32(x) bit for bit
+ * n_bits <= 8.  The format has no NaN: NaN inputs and degenerate channels (maxval 0/inf/NaN, whose
+ * K1 output is NaN) encode as 0.  HBM traffic: 5 B / element each.
+ */
+int fp8q_encode_u8(const float *x, uint8_t *codes, int64_t C, int64_t inner, const float *maxval,
+                   int64_t n_maxval, float mbits, int n_bits, int sign_bits, fp8q_stream_t stream);
+int fp8q_decode_u8(const uint8_t *codes, float *y, int64_t C, int64_t inner, const float *maxval,
+                   int64_t n_maxval, float mbits, int n_bits, int sign_bits, fp8q_stream_t stream);
+
 /* Plain float4 copy kernel with the same launch shape as K1: the measured HBM ceiling that
  * bench.py reports next to the 8 TB/s spec figure. */
 int fp8q_copy_f32(const float *x, float *y, int64_t n, fp8q_stream_t stream);

@@ -50,6 +50,9 @@ def lib():
         L.orc_absmax_f32.argtypes = [f32p, f32p, i64, f32p]
         L.orc_mse_grid_f32.argtypes = [f32p, i64, i64, f32p, i64, f32p, ctypes.c_int,
                                        ctypes.c_int, ctypes.c_int, f32p]
+        u8p = ctypes.POINTER(ctypes.c_uint8)
+        L.orc_encode_u8.argtypes = [f32p, u8p, i64, i64, f32p, i64, ctypes.c_float, ctypes.c_int, ctypes.c_int]
+        L.orc_decode_u8.argtypes = [u8p, f32p, i64, i64, f32p, i64, ctypes.c_float, ctypes.c_int, ctypes.c_int]
         L.orc_fp_grid.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                   ctypes.POINTER(ctypes.c_double)]
         L.orc_num_threads.restype = ctypes.c_int
@@ -131,6 +134,29 @@ def c_mse_grid(x, per_channel, grid, mbits_list, n_bits=8, sign_bits=1, mses=Non
     lib().orc_mse_grid_f32(_p(x2), C, x2.shape[1], _p(grid), grid.shape[0], _p(mb), mb.size,
                            int(n_bits), int(sign_bits), _p(mses))
     return mses
+
+
+def c_encode(x, maxval, mbits, n_bits=8, sign_bits=1):
+    """uint8 storage codes of c_quantize(x) (layout of fp8_quantizer.py:13-41)."""
+    x = _f32(x)
+    mv = _f32(np.atleast_1d(maxval)).reshape(-1)
+    x2 = _as_2d(x, mv.size != 1)
+    codes = np.empty(x2.shape, np.uint8)
+    rc = lib().orc_encode_u8(_p(x2), codes.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), x2.shape[0],
+                             x2.shape[1], _p(mv), mv.size, float(mbits), int(n_bits), int(sign_bits))
+    assert rc == 0
+    return codes.reshape(x.shape)
+
+
+def c_decode(codes, maxval, mbits, n_bits=8, sign_bits=1):
+    codes = np.ascontiguousarray(codes, dtype=np.uint8)
+    mv = _f32(np.atleast_1d(maxval)).reshape(-1)
+    c2 = codes.reshape(codes.shape[0], -1) if mv.size != 1 else codes.reshape(1, -1)
+    y = np.empty(c2.shape, np.float32)
+    rc = lib().orc_decode_u8(c2.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), _p(y), c2.shape[0], c2.shape[1],
+                             _p(mv), mv.size, float(mbits), int(n_bits), int(sign_bits))
+    assert rc == 0
+    return y.reshape(codes.shape)
 
 
 def c_fp_grid(n_bits, ebits, bias):

@@ -185,6 +185,58 @@ int orc_mse_grid_f32(const float *x, int64_t C, int64_t inner, const float *grid
     return 0;
 }
 
+/* N3: storage codes [sign | E exponent bits | M fraction bits] (layout of fp8_quantizer.py:13-41).
+ * code of x = the byte whose value is orc_quant1(x): from K1's integers p (binade, >= 1) and
+ * r = rint(|xc| / s_p):  r < 2^M -> exponent code 0, fraction r;  r == 2^(M+1) -> (p+1, 0);
+ * else (p, r - 2^M).  NaN results (NaN input, degenerate maxval) encode as 0. */
+static inline float orc_scale(const orc_chan_t *p, float ls) { return cr_exp2f((ls - p->M) - p->bias); }
+
+int orc_encode_u8(const float *x, uint8_t *codes, int64_t C, int64_t inner, const float *maxval,
+                  int64_t n_maxval, float mbits, int n_bits, int sign_bits)
+{
+    if ((n_maxval != 1 && n_maxval != C) || n_bits > 8) return -1;
+    for (int64_t c = 0; c < C; ++c) {
+        orc_chan_t p = orc_chan(maxval[n_maxval == 1 ? 0 : c], mbits, n_bits, sign_bits);
+        const int M = (int)p.M;
+        for (int64_t i = 0; i < inner; ++i) {
+            float xv = x[c * inner + i];
+            float xc = t_min(t_max(xv, p.minval), p.maxval);
+            float ls = floorf(cr_log2f(fabsf(xc)) + p.bias);
+            if (ls < 1.0f) ls = 1.0f;
+            float r = rintf(xc / orc_scale(&p, ls));
+            uint32_t code = 0;
+            if (r == r && ls == ls) {
+                uint32_t ri = (uint32_t)fabsf(r), m2 = 1u << M, e = (uint32_t)ls, f = ri - m2;
+                if (ri < m2) { e = 0; f = ri; }
+                else if (ri == 2 * m2) { e += 1; f = 0; }
+                code = (e << M) | f;
+                if (sign_bits == 1 && signbit(r)) code |= 1u << (n_bits - 1);
+            }
+            codes[c * inner + i] = (uint8_t)code;
+        }
+    }
+    return 0;
+}
+
+int orc_decode_u8(const uint8_t *codes, float *y, int64_t C, int64_t inner, const float *maxval,
+                  int64_t n_maxval, float mbits, int n_bits, int sign_bits)
+{
+    if ((n_maxval != 1 && n_maxval != C) || n_bits > 8) return -1;
+    for (int64_t c = 0; c < C; ++c) {
+        orc_chan_t p = orc_chan(maxval[n_maxval == 1 ? 0 : c], mbits, n_bits, sign_bits);
+        const int M = (int)p.M;
+        const uint32_t m2 = 1u << M;
+        for (int64_t i = 0; i < inner; ++i) {
+            uint32_t code = codes[c * inner + i];
+            uint32_t body = sign_bits == 1 ? (code & ((1u << (n_bits - 1)) - 1u)) : code;
+            uint32_t e = body >> M, f = body & (m2 - 1u);
+            float v = (float)(f + (e ? m2 : 0u)) * orc_scale(&p, (float)(e ? e : 1u));
+            y[c * inner + i] = (sign_bits == 1 && ((code >> (n_bits - 1)) & 1u)) ? -v : v;
+        }
+    }
+    return 0;
+}
+
 /* a9: every value of an (n_bits, ebits, bias) format, ascending (fp8_quantizer.py:13-41).
  * out must hold 2^n_bits doubles.  Codes: sign | exponent | fraction; exponent code 0 is
  * subnormal; the all-ones exponent is an ordinary binade (no inf/NaN). */

@@ -1,0 +1,97 @@
+"""N3: FP8 storage codes.  CPU: the oracle's codec against the reference's grid enumerator.
+GPU: HIP encode/decode bit-exact vs the oracle, decode(encode(x)) == quantize(x)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+
+def _default_maxval(M):
+    E = 7 - M
+    return float((2 - 2.0 ** (-M)) * 2.0 ** (2 ** E - 1 - 2 ** (E - 1)))
+
+
+@pytest.mark.parametrize("M", [2, 3, 4, 5])
+def test_all_codes_decode_to_the_reference_grid(golden_dir, M):
+    """With the default maxval the bias is the integer 2^(E-1): the 256 decoded codes are exactly the
+    values the reference's generate_all_values_fp enumerates (g2 golden), in sign-magnitude order."""
+    E = 7 - M
+    g2 = np.load(os.path.join(golden_dir, "g2_grids.npz"))
+    ref = g2[f"e{E}_b{2 ** (E - 1)}"]
+    codes = np.arange(256, dtype=np.uint8)
+    vals = oracle.c_decode(codes, [_default_maxval(M)], M)
+    # the reference forms `bias` with three fp32 roundings: for some formats (E3M4: maxval 15.5) it comes
+    # out as 4.0000005 instead of 4, so the emulated grid sits 4e-7 (relative) off the ideal one -- in the
+    # reference's quantizer as well.  Hence rtol, not equality.
+    np.testing.assert_allclose(np.sort(vals.astype(np.float64)), ref, rtol=1e-6, atol=0)
+    mag = vals[:128]
+    assert np.all(np.diff(mag) > 0) and vals[0] == 0.0                 # codes 0..127 ascend from +0
+    assert np.array_equal(vals[128:], -mag) and np.signbit(vals[128])    # 128..255 mirror them, 128 = -0
+    # code -> value -> code is the identity
+    np.testing.assert_array_equal(oracle.c_encode(vals, [_default_maxval(M)], M), codes)
+
+
+def test_oracle_roundtrip_equals_quantize():
+    rng = np.random.RandomState(0)
+    for M, mv, sb in ((2, 57344.0, 1), (3, 0.7361, 1), (5, 3.0, 1), (3, 2.5, 0), (1, 0.31, 0), (7, 1.0, 1)):
+        x = (rng.randn(20000) * mv / 2.2).astype(np.float32)
+        x[:6] = [0.0, -0.0, mv, -mv, mv * 3, 1e-30]
+        q = oracle.c_quantize(x, [mv], M, 8, sb)
+        rt = oracle.c_decode(oracle.c_encode(x, [mv], M, 8, sb), [mv], M, 8, sb)
+        assert np.array_equal(rt.view(np.int32), q.view(np.int32)), (M, mv, sb)
+
+
+pytestmark_gpu = pytest.mark.gpu
+
+
+def dev(a, dtype=np.float32):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=dtype)).cuda()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,sb,mv", [(2, 1, 57344.0), (3, 1, 240.0), (3, 1, 0.7361), (5, 1, 3.0), (3, 0, 2.5),
+                                     (1, 0, 0.31), (7, 1, 1.0)])
+@pytest.mark.parametrize("n", [5, 16, 1000, 4096 + 7, 1 << 20])
+def test_hip_codec_per_tensor(M, sb, mv, n):
+    import fp8q
+    ops = fp8q.ops
+    rng = np.random.RandomState(n % 977 + M)
+    x = (rng.randn(n) * mv / 2.2).astype(np.float32)
+    x[:5] = [0.0, -0.0, mv, -mv * 2, 1e-41]
+    xd, mvd = dev(x), dev([mv])
+    codes = ops.encode(xd, mvd, M, 8, sb)
+    assert codes.dtype == torch.uint8 and codes.shape == xd.shape
+    np.testing.assert_array_equal(codes.cpu().numpy(), oracle.c_encode(x, [mv], M, 8, sb))
+    y = ops.decode(codes, mvd, M, 8, sb)
+    q = ops.quantize(xd, mvd, M, 8, sb)
+    assert torch.equal(y.view(torch.int32), q.view(torch.int32))       # decode(encode(x)) == quantize(x)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(64, 3, 7, 7), (1000, 512), (33, 4099), (512, 512, 3, 3)])
+def test_hip_codec_per_channel(shape):
+    import fp8q
+    ops = fp8q.ops
+    rng = np.random.RandomState(shape[0])
+    mv = (np.abs(rng.randn(shape[0])) + 0.05).astype(np.float32)
+    x = (rng.randn(*shape) * (mv.reshape([-1] + [1] * (len(shape) - 1)) / 2)).astype(np.float32)
+    xd, mvd = dev(x), dev(mv)
+    codes = ops.encode(xd, mvd, 2, 8, 1)
+    np.testing.assert_array_equal(codes.cpu().numpy(), oracle.c_encode(x, mv, 2, 8, 1))
+    y = ops.decode(codes, mvd, 2, 8, 1)
+    assert torch.equal(y.view(torch.int32), ops.quantize(xd, mvd, 2, 8, 1).view(torch.int32))
+    np.testing.assert_array_equal(y.cpu().numpy().view(np.int32), oracle.c_decode(codes.cpu().numpy(), mv, 2, 8, 1).view(np.int32))
+
+
+@pytest.mark.gpu
+def test_hip_codec_nan_and_degenerate():
+    import fp8q
+    ops = fp8q.ops
+    x = np.array([[1.0, np.nan, -2.0, 0.5], [0.0, 0.0, 0.0, 0.0]], np.float32)
+    mv = np.array([2.0, 0.0], np.float32)                              # second channel: NaN in K1
+    codes = ops.encode(dev(x), dev(mv), 3, 8, 1).cpu().numpy()
+    np.testing.assert_array_equal(codes, oracle.c_encode(x, mv, 3, 8, 1))
+    assert codes[0, 1] == 0 and (codes[1] == 0).all()                  # no NaN code: documented as 0
