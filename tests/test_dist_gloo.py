@@ -36,6 +36,15 @@ class OracleOps:
         return torch.from_numpy(y), torch.from_numpy(mn), torch.from_numpy(mx), torch.from_numpy(mv)
 
 
+    @staticmethod
+    def encode(x, maxval, mbits, n_bits=8, sign_bits=1, out=None):
+        return torch.from_numpy(oracle.c_encode(x.numpy(), maxval.numpy(), mbits, n_bits, sign_bits))
+
+    @staticmethod
+    def decode(codes, maxval, mbits, n_bits=8, sign_bits=1, out=None):
+        return torch.from_numpy(oracle.c_decode(codes.numpy(), maxval.numpy(), mbits, n_bits, sign_bits))
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -83,6 +92,26 @@ def test_weight_channel_shard_allgather_bit_equal():
         assert np.array_equal(np.isnan(q), np.isnan(ref))
         assert np.array_equal(np.nan_to_num(q).view(np.int32), np.nan_to_num(ref).view(np.int32))
         np.testing.assert_array_equal(m, mv)
+
+
+def _w_codes_job(rank, world):
+    from fp8q import dist as fd
+    w = torch.from_numpy(_weights()[[0, 1, 2, 3, 5, 6, 7, 8, 9, 10, 11]])   # 11 channels, no zero channel
+    q, mv, codes = fd.quantize_weight_sharded_codes(w, 3, 8, 1, ops=OracleOps)
+    return q.numpy(), mv.numpy(), codes.numpy()
+
+
+def test_weight_shard_allgather_of_storage_codes():
+    """1-byte codes on the wire, decode after the gather: same bits as the single-process quantizer."""
+    w = _weights()[[0, 1, 2, 3, 5, 6, 7, 8, 9, 10, 11]]
+    mn, mx = oracle.c_minmax(w, True)
+    mv = oracle.c_absmax(mn, mx)
+    ref = oracle.c_quantize(w, mv, 3, 8, 1)
+    for q, m, codes in run(_w_codes_job):
+        assert codes.dtype == np.uint8 and codes.shape == w.shape
+        assert np.array_equal(q.view(np.int32), ref.view(np.int32))
+        np.testing.assert_array_equal(m, mv)
+        np.testing.assert_array_equal(codes, oracle.c_encode(w, mv, 3, 8, 1))
 
 
 def _batches():
