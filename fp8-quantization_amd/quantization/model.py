@@ -6,14 +6,70 @@ from .fp8 import QuantizerBase
 from .layers import QuantizedModule, _for_managers
 
 
+RANGES_KEY = "__fp8_quantizer_ranges__"
+
+
+def quantizer_ranges(model):
+    """{manager name: {maxval, mantissa_bits, sign_bits, state}} for every FP8 quantizer of `model`.
+
+    SURVEY.md 8f N4: in the reference `maxval` / `mantissa_bits` are plain attributes, not buffers
+    (fp8_quantizer.py:183-184), so a saved "quantized" checkpoint silently loses every calibrated
+    range.  This is the missing piece, kept OUT of the regular state-dict keys (which stay
+    identical to the reference's) and stored under one extra entry, RANGES_KEY."""
+    from .manager import QuantizationManager
+    from .fp8 import FPQuantizer
+    out, seen = {}, set()
+    for name, m in model.named_modules():
+        if isinstance(m, QuantizationManager) and isinstance(m.quantizer, FPQuantizer) and id(m) not in seen:
+            seen.add(id(m))
+            q = m.quantizer
+            out[name] = dict(maxval=q.maxval.detach().cpu().clone(),
+                             mantissa_bits=q.mantissa_bits.detach().cpu().clone(),
+                             sign_bits=int(q.sign_bits), state=m.state.name)
+    return out
+
+
+def load_quantizer_ranges(model, ranges, strict=True):
+    from .manager import QuantizationManager, Qstates
+    mgrs = {n: m for n, m in model.named_modules() if isinstance(m, QuantizationManager)}
+    missing = [n for n in ranges if n not in mgrs]
+    if strict and missing:
+        raise KeyError(f"quantizer ranges for unknown managers: {missing[:5]}")
+    for name, r in ranges.items():
+        m = mgrs.get(name)
+        if m is None:
+            continue
+        q = m.quantizer
+        dev = q.maxval.device
+        q.maxval = r["maxval"].to(dev).clone()
+        q.mantissa_bits = r["mantissa_bits"].clone()
+        q.sign_bits = int(r["sign_bits"])
+        m.state = q.state = Qstates[r["state"]]
+
+
 class QuantizedModel(nn.Module):
     def __init__(self, input_size=(1, 3, 224, 224)):
         super().__init__()
         self.input_size = input_size
 
+    def state_dict_with_ranges(self, *args, **kwargs):
+        """state_dict() plus the calibrated FP8 ranges (see quantizer_ranges)."""
+        sd = self.state_dict(*args, **kwargs)
+        sd[RANGES_KEY] = quantizer_ranges(self)
+        return sd
+
     def load_state_dict(self, state_dict, strict=True):
         """First restore the _quant_w/_quant_a flags, run one dummy forward so that every None
-        buffer (estimator ranges) gets its shape, then load everything (:34-62)."""
+        buffer (estimator ranges) gets its shape, then load everything (:34-62).  If the dict
+        carries RANGES_KEY the FP8 ranges and manager states are restored as well."""
+        state_dict = dict(state_dict)
+        ranges = state_dict.pop(RANGES_KEY, None)
+        res = self._load_reference_state_dict(state_dict, strict)
+        if ranges is not None:
+            load_quantizer_ranges(self, ranges, strict)
+        return res
+
+    def _load_reference_state_dict(self, state_dict, strict=True):
         flags = {k: v for k, v in state_dict.items() if k.endswith("_quant_a") or k.endswith("_quant_w")}
         if not flags:
             raise ValueError("The quantization states of activations or weights should be "

@@ -186,3 +186,68 @@ def test_quantize_model_tiny_cnn_vs_reference(golden_dir, tag, M, act_est):
         scale = np.abs(ref).max()
         np.testing.assert_allclose(got, ref, rtol=0, atol=0.05 * scale)
         assert np.mean(np.abs(got - ref)) < 0.01 * scale
+
+
+def test_quantized_checkpoint_restores_ranges(golden_dir, tmp_path):
+    """a saved quantized model keeps its calibrated FP8 ranges (the reference loses
+    them: maxval is not a buffer).  Save after calibration, load into a fresh model, same logits."""
+    from quantization.autoquant_utils import quantize_model
+    from quantization.base_quantized_model import QuantizedModel, RANGES_KEY
+    from quantization.quantization_manager import QMethods, QuantizationManager, Qstates
+    from quantization.range_estimators import RangeEstimators
+    g7 = np.load(os.path.join(golden_dir, "g7_tinycnn.npz"))
+    qparams = dict(method=QMethods.fp_quantizer.cls, weight_range_method=RangeEstimators.current_minmax.cls,
+                   act_range_method=RangeEstimators.allminmax.cls, n_bits=8, per_channel_weights=True,
+                   fp8_kwargs=dict(maxval=None, mantissa_bits=3, set_maxval=True))
+
+    class Net(QuantizedModel):
+        def __init__(self):
+            super().__init__(input_size=(1, 3, 16, 16))
+            self.body = quantize_model(_tiny_cnn(g7), tie_activation_quantizers=True, **qparams)
+
+        def forward(self, x):
+            return self.body(x)
+
+    a = Net().eval().cuda()
+    calib, val = dev(g7["calib"]), dev(g7["val"])
+    with torch.no_grad():
+        a.set_quant_state(True, True)
+        a(calib)
+        a.fix_ranges()
+        ref = a(val)
+    sd = a.state_dict_with_ranges()
+    assert RANGES_KEY in sd and len(sd[RANGES_KEY]) == 7 and RANGES_KEY not in a.state_dict()
+    path = tmp_path / "q.pt"
+    torch.save(sd, path)
+    b = Net().eval().cuda()
+    b.load_state_dict(torch.load(path, weights_only=False))
+    assert all(m.state == Qstates.fix_ranges for m in b.modules() if isinstance(m, QuantizationManager))
+    with torch.no_grad():
+        out = b(val)
+    assert torch.equal(out, ref)
+    # without the extra entry (a reference-style checkpoint) loading still works, ranges are re-estimated
+    c = Net().eval().cuda()
+    sd.pop(RANGES_KEY)
+    c.load_state_dict(sd)
+    assert c.body[0].weight_quantizer.state == Qstates.estimate_ranges
+
+
+def test_dist_helpers_single_process_on_hip():
+    """fp8q.dist with its default backend (the HIP ops), world size 1 (no process group)."""
+    import oracle
+    from fp8q import dist as fd
+    rng = np.random.RandomState(3)
+    w = (rng.randn(13, 3, 3, 3) * 0.1).astype(np.float32)
+    mn, mx = oracle.c_minmax(w, True)
+    mv = oracle.c_absmax(mn, mx)
+    ref = oracle.c_quantize(w, mv, 2, 8, 1)
+    q, m = fd.quantize_weight_sharded(dev(w), 2, 8, 1)
+    assert np.array_equal(q.cpu().numpy().view(np.int32), ref.view(np.int32))
+    q2, m2, codes = fd.quantize_weight_sharded_codes(dev(w), 2, 8, 1)
+    assert np.array_equal(q2.cpu().numpy().view(np.int32), ref.view(np.int32)) and codes.dtype == torch.uint8
+    np.testing.assert_array_equal(m2.cpu().numpy(), mv)
+    x = (rng.randn(4, 8, 5, 5)).astype(np.float32)
+    y, st = fd.calibrate_quantize_sharded(dev(x), 3, 8, 1)
+    pmn, pmx = oracle.c_minmax(x, False)
+    assert np.array_equal(y.cpu().numpy().view(np.int32),
+                          oracle.c_quantize(x, oracle.c_absmax(pmn, pmx), 3, 8, 1).view(np.int32))
