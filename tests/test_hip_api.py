@@ -216,7 +216,7 @@ def test_quantized_checkpoint_restores_ranges(golden_dir, tmp_path):
         a.fix_ranges()
         ref = a(val)
     sd = a.state_dict_with_ranges()
-    assert RANGES_KEY in sd and len(sd[RANGES_KEY]) == 7 and RANGES_KEY not in a.state_dict()
+    assert RANGES_KEY in sd and len(sd[RANGES_KEY]) == 8 and RANGES_KEY not in a.state_dict()
     path = tmp_path / "q.pt"
     torch.save(sd, path)
     b = Net().eval().cuda()
