@@ -591,6 +591,104 @@ k_mse_final(const double *__restrict__ ws, float *__restrict__ mses, int64_t C, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// N2: producer epilogue fused with the activation quantizer:
+//   t = fma(x, alpha_c, fma(-mean_c, alpha_c, beta_c)), alpha_c = invstd_c * gamma_c   (eval-mode BN, NCHW)
+//   t = t + residual                                          (optional)
+//   t = relu(t) / relu6(t)                                    (optional)
+//   QUANT:  y = quantize_to_fp8(t; per-tensor maxval)        MINMAX: min/max of t -> partials
+// i.e. quantized_folded_bn.py:39-55 and models/resnet_quantized.py:43-46 in one pass (8 B/element
+// instead of three 8 B passes).  Flat over N*C*HW; channel of a 16-byte group by two magic
+// divisions, per element only when a group crosses a plane boundary (HW % 4 != 0).
+// ---------------------------------------------------------------------------------------------
+struct AffineArgs {
+    int64_t image;      // C * HW elements per image (multiple of 4, < 2^31)
+    int C, HW;
+    int act;            // 0 none, 1 relu, 2 relu6
+    int has_bn, has_res;
+    uint64_t magic48;   // floor(2^48 / HW) + 1:  n / HW == (n * magic48) >> 48  for n * HW < 2^48
+};
+
+// Eval-mode batch norm exactly as ATen's CPU kernel evaluates it (probed: bit-identical on 100 % of
+// elements): alpha = invstd * gamma, beta' = fma(-mean, alpha, beta), out = fma(x, alpha, beta').
+__device__ __forceinline__ float affine_act(float x, float r, float m, float is, float g, float b,
+                                            const AffineArgs &a)
+{
+    float t = x;
+    if (a.has_bn) {
+        const float alpha = is * g;
+        t = fmaf(t, alpha, fmaf(-m, alpha, b));
+    }
+    if (a.has_res) t = t + r;
+    if (a.act >= 1) t = t < 0.0f ? 0.0f : t;         // NaN stays NaN (torch.relu)
+    if (a.act == 2) t = t > 6.0f ? 6.0f : t;
+    return t;
+}
+
+// blockIdx.y = image n; blockIdx.x strides over the image's C*HW elements in 16-byte groups
+template <bool QUANT>
+__global__ void __launch_bounds__(kBlock)
+k_affine_act(const float *__restrict__ x, const float *__restrict__ res, float *__restrict__ y,
+             const float *__restrict__ mean, const float *__restrict__ invstd,
+             const float *__restrict__ gamma, const float *__restrict__ beta,
+             const float *__restrict__ maxval, QFmt f, AffineArgs a, float *__restrict__ ws)
+{
+    __shared__ float2 lut[kLutMax];
+    const int tid = threadIdx.x;
+    ChanLite c = {};
+    float pmaxf = 0.0f;
+    if (QUANT) {
+        const Chan cfull = make_chan(maxval[0], f);
+        for (int i = tid; i <= f.pmax; i += kBlock) lut[i] = lut_entry(cfull, i, f.M);
+        __syncthreads();
+        c = lite(cfull);
+        pmaxf = (float)f.pmax;
+    }
+    MinMax mm;
+    mm_init(mm);
+    const int64_t base = (int64_t)blockIdx.y * a.image;
+    const int nvec = (int)(a.image >> 2);
+    const vf4 *xv = reinterpret_cast<const vf4 *>(x + base);
+    const vf4 *rv = reinterpret_cast<const vf4 *>(res + (a.has_res ? base : 0));
+    vf4 *yv = reinterpret_cast<vf4 *>(y + (QUANT ? base : 0));
+    for (int j = blockIdx.x * kBlock + tid; j < nvec; j += gridDim.x * kBlock) {
+        const vf4 v = xv[j];
+        vf4 r = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (a.has_res) r = rv[j];
+        float e[4] = {v.x, v.y, v.z, v.w};
+        const float rr[4] = {r.x, r.y, r.z, r.w};
+        if (a.has_bn) {
+            const uint32_t i0 = (uint32_t)j * 4u;
+            uint32_t ch = (uint32_t)(((uint64_t)i0 * a.magic48) >> 48);      // plane == channel
+            uint32_t off = i0 - ch * (uint32_t)a.HW;
+            float m = mean[ch], is = invstd[ch], g = gamma[ch], b = beta[ch];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                e[q] = affine_act(e[q], rr[q], m, is, g, b, a);
+                if (++off == (uint32_t)a.HW && q < 3) {      // the group crosses into the next plane
+                    off = 0;
+                    ++ch;                                     // still < C: the group ends inside the image
+                    m = mean[ch];
+                    is = invstd[ch];
+                    g = gamma[ch];
+                    b = beta[ch];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) e[q] = affine_act(e[q], rr[q], 0.0f, 1.0f, 1.0f, 0.0f, a);
+        }
+        if (QUANT) {
+            quant_group<4>(e, c, lut, pmaxf, f.qthr);
+            yv[j] = vf4{e[0], e[1], e[2], e[3]};
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) mm_acc(mm, e[q]);
+        }
+    }
+    if (!QUANT) block_reduce_store(mm, ws + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 2);
+}
+
+// ---------------------------------------------------------------------------------------------
 // N3: storage codes.  One row per blockIdx.y like k_quant_rows; a lane converts 16 consecutive
 // elements per step (4 x 16-byte fp32 accesses <-> one 16-byte access of codes).
 // encode: 4 B read + 1 B written per element; decode: 1 B read + 4 B written.
@@ -991,6 +1089,98 @@ int fp8q_mse_grid_f32(const float *x, int64_t C, int64_t inner, const float *gri
     if (fb > kTargetBlocks) fb = kTargetBlocks;
     hipLaunchKernelGGL(k_mse_final, dim3((unsigned)fb), dim3(kBlock), 0, st, (const double *)ws, mses, C,
                        n_m, (int)n_cand, a.nsplit, 1.0 / (double)inner);
+    return launch_rc();
+}
+
+static int affine_args(int64_t N, int64_t C, int64_t HW, int act, bool has_bn, bool has_res, AffineArgs *a)
+{
+    if (N < 0 || C <= 0 || HW <= 0 || act < 0 || act > 2) return FP8Q_EINVAL;
+    // 16-byte groups must not straddle images; the 48-bit magic division needs C*HW*HW < 2^48
+    if (((C * HW) & 3) != 0 || C * HW >= (1ll << 31) || HW >= (1 << 24) ||
+        (double)C * (double)HW * (double)HW >= 281474976710656.0)
+        return FP8Q_EUNSUPPORTED;
+    a->image = C * HW;
+    a->C = (int)C;
+    a->HW = (int)HW;
+    a->act = act;
+    a->has_bn = has_bn;
+    a->has_res = has_res;
+    a->magic48 = (1ull << 48) / (uint64_t)HW + 1ull;
+    return FP8Q_OK;
+}
+
+static void affine_grid(int64_t N, const AffineArgs &a, int64_t *bx, int64_t *by)
+{
+    *by = N < 65535 ? N : 65535;
+    int64_t b = cdiv(a.image >> 2, kBlock * 4);
+    const int64_t cap = (kTargetBlocks / *by) > 0 ? kTargetBlocks / *by : 1;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    *bx = b;
+}
+
+int fp8q_affine_act_quantize_f32(const float *x, const float *residual, float *y, int64_t N, int64_t C,
+                                 int64_t HW, const float *mean, const float *invstd, const float *gamma,
+                                 const float *beta, int act, const float *maxval, float mbits, int n_bits,
+                                 int sign_bits, fp8q_stream_t stream)
+{
+    const bool has_bn = mean != nullptr;
+    if (has_bn && (!invstd || !gamma || !beta)) return FP8Q_EINVAL;
+    AffineArgs a;
+    if (int rc = affine_args(N, C, HW, act, has_bn, residual != nullptr, &a)) return rc;
+    QFmt f;
+    if (int rc = make_fmt(mbits, n_bits, sign_bits, &f)) return rc;
+    if (N == 0) return FP8Q_OK;
+    if (!x || !y || !maxval) return FP8Q_EINVAL;
+    if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual) & 15) return FP8Q_EINVAL;
+    for (int64_t n0 = 0; n0 < N; n0 += 65535) {
+        int64_t bx, by;
+        affine_grid(N - n0, a, &bx, &by);
+        hipLaunchKernelGGL(k_affine_act<true>, dim3((unsigned)bx, (unsigned)by), dim3(kBlock), 0,
+                           (hipStream_t)stream, x + n0 * a.image, residual ? residual + n0 * a.image : nullptr,
+                           y + n0 * a.image, mean, invstd, gamma, beta, maxval, f, a, (float *)nullptr);
+    }
+    return launch_rc();
+}
+
+size_t fp8q_affine_act_minmax_workspace_bytes(int64_t N)
+{
+    const int64_t by = N < 65535 ? (N > 0 ? N : 1) : 65535;
+    const int64_t cap = (kTargetBlocks / by) > 0 ? kTargetBlocks / by : 1;
+    return (size_t)(by * cap) * 2 * sizeof(float) + 16;
+}
+
+int fp8q_affine_act_minmax_f32(const float *x, const float *residual, int64_t N, int64_t C, int64_t HW,
+                               const float *mean, const float *invstd, const float *gamma, const float *beta,
+                               int act, float *cur_min, float *cur_max, float *maxval_out, int fold_mode,
+                               double momentum, int first, void *ws, size_t ws_bytes, fp8q_stream_t stream)
+{
+    const bool has_bn = mean != nullptr;
+    if (has_bn && (!invstd || !gamma || !beta)) return FP8Q_EINVAL;
+    AffineArgs a;
+    if (int rc = affine_args(N, C, HW, act, has_bn, residual != nullptr, &a)) return rc;
+    if (N <= 0 || !x || !cur_min || !cur_max || fold_mode < 0 || fold_mode > 2) return FP8Q_EINVAL;
+    if (N > 65535) return FP8Q_EUNSUPPORTED;
+    if (!ws || ws_bytes < fp8q_affine_act_minmax_workspace_bytes(N)) return FP8Q_EWORKSPACE;
+    if (((uintptr_t)x | (uintptr_t)residual) & 15) return FP8Q_EINVAL;
+    int64_t bx, by;
+    affine_grid(N, a, &bx, &by);
+    QFmt f = {};
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_affine_act<false>, dim3((unsigned)bx, (unsigned)by), dim3(kBlock), 0, st, x, residual,
+                       (float *)nullptr, mean, invstd, gamma, beta, (const float *)nullptr, f, a, (float *)ws);
+    FoldArgs fa;
+    fa.mode = fold_mode;
+    fa.first = first != 0;
+    fa.om = (float)(1.0 - momentum);
+    fa.mo = (float)momentum;
+    const int nparts = (int)(bx * by);
+    if (nparts > 64)
+        hipLaunchKernelGGL(k_minmax_final_block, dim3(1), dim3(kBlock), 0, st, (const float *)ws, nparts, cur_min,
+                           cur_max, maxval_out, fa);
+    else
+        hipLaunchKernelGGL(k_minmax_final, dim3(1), dim3(kBlock), 0, st, (const float *)ws, (int64_t)1, nparts,
+                           cur_min, cur_max, maxval_out, fa);
     return launch_rc();
 }
 

@@ -213,3 +213,80 @@ def decode(codes, maxval, mbits, n_bits=8, sign_bits=1, out=None):
                                   int(n_bits), int(sign_bits), _stream(codes))
     check(rc, "fp8q_decode_u8")
     return y
+
+
+def _nchw(x):
+    """[N, C, *spatial] -> (N, C, HW)."""
+    if x.dim() < 2:
+        raise Fp8qError("fused epilogue expects [N, C, ...] tensors")
+    N, C = x.shape[0], x.shape[1]
+    return N, C, (x.numel() // (N * C) if N * C else 0)
+
+
+def _bn_ptrs(bn, C, dev):
+    if bn is None:
+        return (None, None, None, None), ()
+    keep = []
+    for t in bn:
+        _require(t, "bn parameter")
+        t = t.contiguous()
+        if t.numel() != C or t.device != dev:
+            raise Fp8qError("batch-norm vectors must be [C] tensors on x's device")
+        keep.append(t)
+    return tuple(t.data_ptr() for t in keep), tuple(keep)
+
+
+def affine_act_supported(x):
+    """fp8q_affine_act_* needs C*HW % 4 == 0 (16-byte groups never straddle images)."""
+    N, C, HW = _nchw(x)
+    return N > 0 and (C * HW) % 4 == 0 and x.data_ptr() % 16 == 0
+
+
+def affine_act_quantize(x, maxval, mbits, n_bits=8, sign_bits=1, bn=None, residual=None, act=0, out=None):
+    """N2: quantize(act(bn(x) + residual)) in one pass.  bn = (mean, invstd, gamma, beta), each [C];
+    act: 0 none, 1 ReLU, 2 ReLU6; per-tensor maxval [1]."""
+    _require(x, "x")
+    _require(maxval, "maxval")
+    x = x.contiguous()
+    N, C, HW = _nchw(x)
+    if residual is not None:
+        _require(residual, "residual")
+        residual = residual.contiguous()
+        if residual.shape != x.shape:
+            raise Fp8qError("residual must have x's shape")
+    ptrs, keep = _bn_ptrs(bn, C, x.device)
+    y = torch.empty_like(x) if out is None else out
+    with _on_device(x):
+        rc = lib().fp8q_affine_act_quantize_f32(
+            x.data_ptr(), residual.data_ptr() if residual is not None else None, y.data_ptr(), N, C, HW,
+            ptrs[0], ptrs[1], ptrs[2], ptrs[3], int(act), maxval.contiguous().data_ptr(), float(mbits),
+            int(n_bits), int(sign_bits), _stream(x))
+    check(rc, "fp8q_affine_act_quantize_f32")
+    return y
+
+
+def affine_act_minmax(x, cur_min=None, cur_max=None, mode=FOLD_CURRENT, momentum=0.9, bn=None, residual=None,
+                      act=0):
+    """N2: per-tensor min/max of act(bn(x) + residual), folded into the running estimate.
+    Returns (cur_min, cur_max, maxval) as [1] tensors."""
+    _require(x, "x")
+    x = x.contiguous()
+    N, C, HW = _nchw(x)
+    if residual is not None:
+        _require(residual, "residual")
+        residual = residual.contiguous()
+    ptrs, keep = _bn_ptrs(bn, C, x.device)
+    first = cur_min is None or cur_max is None
+    if first:
+        cur_min = torch.empty(1, dtype=torch.float32, device=x.device)
+        cur_max = torch.empty(1, dtype=torch.float32, device=x.device)
+    mv = torch.empty(1, dtype=torch.float32, device=x.device)
+    L = lib()
+    ws = _workspace(x.device, L.fp8q_affine_act_minmax_workspace_bytes(N))
+    with _on_device(x):
+        rc = L.fp8q_affine_act_minmax_f32(
+            x.data_ptr(), residual.data_ptr() if residual is not None else None, N, C, HW, ptrs[0], ptrs[1],
+            ptrs[2], ptrs[3], int(act), cur_min.data_ptr(), cur_max.data_ptr(), mv.data_ptr(), int(mode),
+            float(momentum), int(first), ws.data_ptr(), ws.numel(), _stream(x))
+    check(rc, "fp8q_affine_act_minmax_f32")
+    return cur_min, cur_max, mv

@@ -102,6 +102,26 @@ int fp8q_mse_grid_f32(const float *x, int64_t C, int64_t inner, const float *gri
                       void *ws, size_t ws_bytes, fp8q_stream_t stream);
 
 /*
+ * N2 -- producer epilogue fused with the activation quantizer: eval-mode batch norm
+ * (NCHW, per-channel mean / invstd = 1/sqrt(var+eps) / gamma / beta, all four NULL to skip),
+ * + optional residual add, + optional activation (act: 0 none, 1 ReLU, 2 ReLU6), then the
+ * per-tensor FP8 quantizer -- BNFusedHijacker.forward, quantization/quantized_folded_bn.py:39-55,
+ * and the residual tail of models/resnet_quantized.py:43-46, in one pass (8 B / element).
+ * The _minmax twin produces the range of the same pre-quantization tensor for calibration
+ * (same fold semantics as fp8q_minmax_f32).  x, residual, y: [N, C, HW] fp32, 16-byte aligned;
+ * C*HW must be a multiple of 4 (FP8Q_EUNSUPPORTED otherwise: use the unfused calls).
+ */
+int fp8q_affine_act_quantize_f32(const float *x, const float *residual, float *y, int64_t N, int64_t C,
+                                 int64_t HW, const float *mean, const float *invstd, const float *gamma,
+                                 const float *beta, int act, const float *maxval, float mbits, int n_bits,
+                                 int sign_bits, fp8q_stream_t stream);
+size_t fp8q_affine_act_minmax_workspace_bytes(int64_t N);
+int fp8q_affine_act_minmax_f32(const float *x, const float *residual, int64_t N, int64_t C, int64_t HW,
+                               const float *mean, const float *invstd, const float *gamma, const float *beta,
+                               int act, float *cur_min, float *cur_max, float *maxval_out, int fold_mode,
+                               double momentum, int first, void *ws, size_t ws_bytes, fp8q_stream_t stream);
+
+/*
  * N3 -- real FP8 storage codes.  The reference only simulates the format; its
  * enumerator generate_all_values_fp (fp8_quantizer.py:13-41) defines the byte layout
  * [sign | E exponent bits | M fraction bits] (exponent code 0 subnormal, no inf/NaN codes).
