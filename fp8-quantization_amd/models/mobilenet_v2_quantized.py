@@ -20,7 +20,11 @@ class QuantizedInvertedResidual(QuantizedActivation):
     def forward(self, x):
         if not self.use_res_connect:
             return self.conv(x)
-        return self.quantize_activations(x + self.conv(x))
+        out = self.conv(x)
+        aq = self.activation_quantizer
+        if self._qa and hasattr(aq, "can_fuse") and aq.can_fuse(out) and x.shape == out.shape:
+            return aq.forward_fused(out, residual=x.contiguous(), act=0)        # add + quantize
+        return self.quantize_activations(x + out)
 
 
 class QuantizedMobileNetV2(QuantizedModel):

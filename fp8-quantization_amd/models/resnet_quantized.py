@@ -24,6 +24,10 @@ class QuantizedBlock(QuantizedActivation):
     def forward(self, x):
         residual = x if self.downsample is None else self.downsample(x)
         out = self.features(x)
+        aq = self.activation_quantizer
+        if self._qa and isinstance(self.relu, nn.ReLU) and hasattr(aq, "can_fuse") and aq.can_fuse(out) \
+                and residual.shape == out.shape:
+            return aq.forward_fused(out, residual=residual.contiguous(), act=1)   # add + relu + quantize
         out += residual
         return self.quantize_activations(self.relu(out))
 

@@ -185,7 +185,23 @@ class QuantizationHijacker(QuantizedModule):
         out = self.run_forward(x, weight, bias, offsets=offsets)
         return self._finish(out)
 
-    def _finish(self, out):
+    def _act_code(self):
+        """0 none / 1 ReLU / 2 ReLU6 for the fused epilogue kernel, None for any other activation."""
+        a = self.activation_function
+        if a is None:
+            return 0
+        return {nn.ReLU: 1, nn.ReLU6: 2}.get(type(a))
+
+    def _finish(self, out, bn=None):
+        """activation (+ the batch norm handed over by BNFusedHijacker) and output quantization; one
+        fused kernel when possible, else the reference's op-by-op chain."""
+        act = self._act_code()
+        aq = self.activation_quantizer
+        if (not self.quantize_input and self._qa and act is not None and isinstance(aq, QuantizationManager)
+                and aq.can_fuse(out)):
+            return aq.forward_fused(out, bn=bn, act=act)
+        if bn is not None:
+            out = self._batch_norm(out)
         if self.activation_function is not None:
             out = self.activation_function(out)
         if not self.quantize_input and self._qa:
@@ -233,9 +249,22 @@ class BNFusedHijacker(QuantizationHijacker):
             x = self.activation_quantizer(x)
         weight, bias = self.get_params()
         out = self.run_forward(x, weight, bias)
-        out = F.batch_norm(out, self.running_mean, self.running_var, self.gamma, self.beta,
-                           self.training, self.momentum, self.epsilon)
-        return self._finish(out)
+        if self.training:                     # batch statistics: never fused
+            return self._finish(self._batch_norm(out))
+        return self._finish(out, bn=self._bn_vectors())
+
+    def _batch_norm(self, out):
+        return F.batch_norm(out, self.running_mean, self.running_var, self.gamma, self.beta,
+                            self.training, self.momentum, self.epsilon)
+
+    def _bn_vectors(self):
+        """(mean, invstd, gamma, beta) for the fused kernel; invstd = 1/sqrt(var + eps) as ATen forms it,
+        cached until the running variance changes."""
+        key = (self.running_var._version, self.running_var.data_ptr(), self.epsilon)
+        if getattr(self, "_invstd_key", None) != key:
+            self._invstd = 1 / torch.sqrt(self.running_var + self.epsilon)
+            self._invstd_key = key
+        return self.running_mean, self._invstd, self.gamma.detach(), self.beta.detach()
 
     def get_bn_dim(self):
         if isinstance(self, nn.Linear):

@@ -118,5 +118,41 @@ class QuantizationManager(nn.Module):
         q._set_maxval_tensor(est.last_maxval)        # == |max(|xmin|, xmax)| (fp8_quantizer.py:236)
         return q(x)
 
+    # ---- N2: producer epilogue fused into the quantizer ----------------------------
+    def can_fuse(self, x):
+        """True when quantize(act(bn(x) + residual)) can run as ONE kernel with the same result as the
+        unfused chain: FP8 per-tensor quantizer on a contiguous CUDA fp32 [N, C, ...] tensor, ranges
+        fixed or followed by a plain min/max estimator."""
+        import os
+        q, est = self.quantizer, self.range_estimator
+        if os.environ.get("FP8Q_FUSE_EPILOGUE", "1") == "0" or type(q) is not FPQuantizer or self.per_channel:
+            return False
+        if not (x.is_cuda and x.dtype.is_floating_point and x.dim() >= 2 and not x.requires_grad):
+            return False
+        if x.dtype != __import__("torch").float32 or not x.is_contiguous() or not _ops.affine_act_supported(x):
+            return False
+        if self._estimating():
+            return (type(est) in _MINMAX and not q.allow_unsigned and not getattr(est, "percentile", None))
+        return True
+
+    def forward_fused(self, x, bn=None, residual=None, act=0):
+        """quantize(act(bn(x) + residual)); range update first when estimating (reference order)."""
+        q, est = self.quantizer, self.range_estimator
+        if self._estimating():
+            cur_min, cur_max = est.current_xmin, est.current_xmax
+            if cur_min is not None and est._fold_mode != _ops.FOLD_CURRENT:
+                cur_min, cur_max = cur_min.reshape(-1), cur_max.reshape(-1)
+            else:
+                cur_min = cur_max = None
+            mn, mx, mv = _ops.affine_act_minmax(x, cur_min, cur_max, mode=est._fold_mode, momentum=est.momentum,
+                                                bn=bn, residual=residual, act=act)
+            est.current_xmin, est.current_xmax, est.last_maxval = mn.reshape(()), mx.reshape(()), mv
+            if q.set_maxval:
+                q._set_maxval_tensor(mv)
+        if q.maxval.device != x.device:
+            q.maxval = q.maxval.to(x.device)
+        return _ops.affine_act_quantize(x, q.maxval, float(q.mantissa_bits), q.n_bits, q.sign_bits, bn=bn,
+                                        residual=residual, act=act)
+
     def extra_repr(self):
         return f"state={self.state.name}"
