@@ -211,8 +211,28 @@ class QuantizationHijacker(QuantizedModule):
     def get_params(self):
         weight, bias = self.get_weight_bias()
         if self._qw:
-            weight = self.quantize_weights(weight)
+            weight = self._quantized_weight(weight)
         return weight, bias
+
+    def _quantized_weight(self, weight):
+        """The reference re-quantizes the weight on every forward (hijacker.py:88-98).  With FIXED
+        ranges and an unchanged weight tensor the result is bit-identical from call to call, so it is
+        computed once and reused (FP8Q_CACHE_WEIGHTS=0 restores the per-forward launch; bench.py times
+        the un-cached kernels).  Any in-place weight update, range change or state change invalidates."""
+        import os
+        from .manager import Qstates
+        mgr = self.weight_quantizer
+        q = getattr(mgr, "quantizer", None)
+        if (os.environ.get("FP8Q_CACHE_WEIGHTS", "1") == "0" or getattr(mgr, "state", None) != Qstates.fix_ranges
+                or not hasattr(q, "maxval") or weight.requires_grad and torch.is_grad_enabled()):
+            return self.quantize_weights(weight)
+        mv = q.maxval
+        key = (weight.data_ptr(), weight._version, tuple(weight.shape), mv.data_ptr(), mv._version,
+               float(q.mantissa_bits), q.sign_bits, q.n_bits)
+        if getattr(self, "_wq_key", None) != key:
+            self._wq_cache = self.quantize_weights(weight)
+            self._wq_key = key
+        return self._wq_cache
 
     def quantize_weights(self, weights):
         return self.weight_quantizer(weights)

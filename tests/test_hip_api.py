@@ -251,3 +251,30 @@ def test_dist_helpers_single_process_on_hip():
     pmn, pmx = oracle.c_minmax(x, False)
     assert np.array_equal(y.cpu().numpy().view(np.int32),
                           oracle.c_quantize(x, oracle.c_absmax(pmn, pmx), 3, 8, 1).view(np.int32))
+
+
+def test_fixed_range_weight_cache_is_invalidated_correctly(golden_dir):
+    """Cached quantized weights (fixed ranges) equal the per-forward result and follow weight updates."""
+    from quantization.autoquant_utils import QuantLinear
+    from quantization.quantization_manager import QMethods
+    from quantization.range_estimators import RangeEstimators
+    torch.manual_seed(0)
+    lin = QuantLinear(32, 16, method=QMethods.fp_quantizer.cls, weight_range_method=RangeEstimators.current_minmax.cls,
+                      act_range_method=RangeEstimators.allminmax.cls, per_channel_weights=True,
+                      fp8_kwargs=dict(mantissa_bits=3, set_maxval=True, maxval=None)).cuda().eval()
+    lin.quantized_weights()
+    x = torch.randn(4, 32, device="cuda")
+    with torch.no_grad():
+        lin(x)                              # estimate state: no caching
+        assert getattr(lin, "_wq_key", None) is None
+        lin.fix_ranges()
+        w1, _ = lin.get_params()
+        w2, _ = lin.get_params()
+        assert w1 is w2                     # reused
+        assert torch.equal(w1, lin.weight_quantizer(lin.weight))
+        lin.weight.mul_(0.5)                # in-place update bumps the version -> recomputed
+        w3, _ = lin.get_params()
+        assert w3 is not w1 and torch.equal(w3, lin.weight_quantizer(lin.weight))
+        lin.weight_quantizer.quantizer.maxval = lin.weight_quantizer.quantizer.maxval * 2   # new range tensor
+        w4, _ = lin.get_params()
+        assert w4 is not w3 and torch.equal(w4, lin.weight_quantizer(lin.weight))
