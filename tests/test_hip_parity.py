@@ -259,3 +259,36 @@ def test_per_channel_constants_fast_vs_libm(ops):
         x = (rng.randn(C, inner).astype(np.float32) * (np.where(np.isfinite(mv), mv, 1.0)[:, None] / 2))
         y = ops.quantize(dev(x), dev(mv), M, 8, 1).cpu().numpy()
         assert_bit_exact(y, oracle.c_quantize(x, mv, M, 8, 1), f"M={M} inner={inner}")
+
+
+def test_more_than_2_31_elements(ops):
+    """Maximum sizes: a per-tensor tensor with > 2^31 elements (8.6 GB in, 8.6 GB out) exercises the
+    64-bit indexing; chunks quantized separately must give the same bits, min/max must see the planted
+    extremes at both ends, and the tail is checked against the oracle."""
+    n = (1 << 31) + 12345
+    free, _ = torch.cuda.mem_get_info()
+    if free < 3 * n * 4:
+        pytest.skip("not enough free HBM for the 2^31-element case")
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.empty(n, device="cuda")
+    step = 1 << 28
+    for i in range(0, n, step):
+        x[i:i + step].normal_(generator=g)
+    x[7] = -123.0
+    x[n - 3] = 77.0
+    mv = torch.tensor([4.0], device="cuda")
+    y = ops.quantize(x, mv, 3, 8, 1)
+    for lo in (0, (1 << 31) - 4096, n - 65536):
+        hi = min(lo + 65536, n)
+        assert torch.equal(y[lo:hi], ops.quantize(x[lo:hi].clone(), mv, 3, 8, 1)), lo
+    tail = x[n - 4096:].cpu().numpy()
+    assert_bit_exact(y[n - 4096:].cpu().numpy(), oracle.c_quantize(tail, [4.0], 3, 8, 1), "tail")
+    mn, mx = ops.minmax(x, False)
+    assert mn.item() == -123.0 and mx.item() == 77.0
+    del y
+    # per-channel rows kernel across the 2^31 boundary: [2, n/2]
+    half = n // 2
+    xr = x[: 2 * half].view(2, half)
+    mvr = torch.tensor([3.0, 5.0], device="cuda")
+    yr = ops.quantize(xr, mvr, 2, 8, 1)
+    assert torch.equal(yr[1, half - 8192:], ops.quantize(xr[1, half - 8192:].clone(), mvr[1:], 2, 8, 1))
