@@ -145,6 +145,65 @@ def extras(ops, dev):
     return out
 
 
+def run_c5(args, ops, dev, rank, world):
+    """BASELINE config 5: batch-sharded activation calibration + quantization.  Per rank a slab
+    [512, 4096, 512] fp32 (1.07 G elements, seed 1234 + rank).  One step = running min/max fold of
+    the slab (4 B/elem) -> fused all-reduce of the 2-float range (RCCL; no-op at N = 1) -> E4M3
+    quantize of the slab with the global range (8 B/elem): 12 B/elem algorithmic, calibration order
+    of the reference (quantization_manager.py:119-122).  Not the contract line: a second data point."""
+    from fp8q import dist as fd
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    x = torch.empty(512, 4096, 512, device=dev)
+    for i in range(0, 512, 64):
+        x[i:i + 64].normal_(generator=g)
+    y = torch.empty_like(x)
+    state = None
+
+    def step():
+        nonlocal state
+        cur_min, cur_max = state if state is not None else (None, None)
+        cur_min, cur_max = ops.minmax(x, False, cur_min, cur_max, mode=1)[:2]
+        fd.allreduce_ranges(cur_min, cur_max)
+        maxval = torch.abs(torch.max(torch.abs(cur_min), cur_max))
+        ops.quantize(x, maxval, 3, 8, 1, out=y)
+        state = (cur_min, cur_max)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        n = x.numel()
+        print(json.dumps({
+            "metric": "FP8 calibrate(allminmax)+quant+dequant Gelems/sec", "value": round(n * world * args.steps / elapsed / 1e9, 2),
+            "unit": "Gelem/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE config 5: per-rank slab [512,4096,512] fp32, allminmax fold + range "
+                                   "all-reduce + E4M3 quantize", "elements_per_gpu": n,
+                       "parallelism": f"batch-sharded x{world}, one 16-byte all-reduce per step"},
+            "roofline": {"bound": "hbm", "kernel": "k_minmax_partial + k_quant_rows", "achieved":
+                         round(n * 12 / (elapsed / args.steps) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(n * 12 / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None}}),
+              flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -152,6 +211,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--workload", default="conv1", choices=["conv1", "c5"],
+                    help="conv1 (default, the contract line) or c5: BASELINE config 5 per-rank slab "
+                         "[512,4096,512] fp32, allminmax fold -> all-reduce of the range -> E4M3 quantize")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for --gpus N > 1 (nccl = RCCL; gloo only for smoke-testing the "
                          "multi-process path on a box with fewer GPUs than ranks)")
@@ -179,6 +241,9 @@ def main():
     import fp8q
     ops = fp8q.ops
     fp8q.lib()  # fail loudly if the HIP library is missing
+
+    if args.workload == "c5":
+        return run_c5(args, ops, dev, rank, world)
 
     # synthetic weights: this rank's shard of output channels (seed differs per rank)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
