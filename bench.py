@@ -9,7 +9,7 @@ Workload (BASELINE.json config 2, scaled as north_star allows: "synthetic NxCxKx
     (n_bits 8, 2 mantissa bits), ranges from current_minmax (computed once, outside the timed
     region: validation runs with fixed ranges, quantization_manager.py:93-98).
 One step = one pass of the hot path quantize_to_fp8_ste_MM (fp8_quantizer.py:91-133) over
-the tensor = one launch of the HIP kernel k_rows_direct (MODE 0) through the C ABI (fp8q_quantize_f32).
+the tensor = one launch of the HIP kernel k_rows_flat<0> (short rows cut into aligned 16 KiB chunks) through the C ABI (fp8q_quantize_f32).
 Inputs are resident in HBM before the timed region.
 
 N > 1 (one process per GPU, torch.distributed/RCCL): output channels are sharded across
@@ -35,6 +35,7 @@ for _p in (ROOT, os.path.join(ROOT, "fp8-quantization_amd")):
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+PREWARM_S = float(os.environ.get("FP8Q_BENCH_PREWARM_S", "0.25"))          # untimed clock warm-up before the W warm-up steps (setup, see main)
 HBM_PEAK_GBS = 8000.0       # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
 BYTES_PER_ELEM = 8          # K1: 4 B read + 4 B written
 N_CH = 1 << 21              # channels per GPU
@@ -255,6 +256,14 @@ def main():
     def step():
         ops.quantize(x, maxval, MBITS, NBITS, SIGN, out=y)
 
+    # Setup, before the W warm-up steps of the contract: the GPU's clocks need tens of milliseconds of
+    # sustained work to settle (the first ~40 launches after an idle period run 8-10 % slower), so the
+    # kernel is run for PREWARM_S first; disclosed in the JSON line as config.prewarm_ms.
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < PREWARM_S:
+        for _ in range(10):
+            step()
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -290,7 +299,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("k_rows_direct_bytes_per_launch")
+                traffic = json.load(open(tpath)).get("k1_bytes_per_launch")
             except Exception:
                 traffic = None
         line = {
@@ -301,8 +310,9 @@ def main():
             "config": {"workload": f"conv1-shaped weights [{N_CH},3,7,7] fp32 per GPU, per-channel E5M2 "
                                    "quantize+dequantize, fixed ranges from current_minmax (BASELINE config 2, "
                                    "synthetic NxCxKxK scale-up)",
-                       "elements_per_gpu": n_elem, "parallelism": f"channel-sharded x{world}, no data-path collective"},
-            "roofline": {"bound": "hbm", "kernel": "k_rows_direct<0,LUT,NT>", "achieved": round(achieved, 1),
+                       "elements_per_gpu": n_elem, "parallelism": f"channel-sharded x{world}, no data-path collective",
+                       "prewarm_ms": int(PREWARM_S * 1e3)},
+            "roofline": {"bound": "hbm", "kernel": "k_rows_flat<0,NT>", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "algorithmic_bytes_per_launch": n_elem * BYTES_PER_ELEM,
                          "avg_launch_us": round(kern_s * 1e6, 1)},

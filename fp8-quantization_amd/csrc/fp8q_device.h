@@ -79,29 +79,19 @@ __device__ __forceinline__ Chan finish_chan(float maxv, float l_mv, const QFmt &
     return c;
 }
 
-// reference implementation: device libm in double (used where it runs once per block)
-__device__ __forceinline__ Chan make_chan(float maxv, const QFmt &f)
-{
-    Chan c = finish_chan(maxv, (float)log2((double)maxv), f);   // correctly rounded fp32 log2
-    c.g = exp2(-(double)c.bf);
-    c.m0 = (float)c.g;
-    return c;
-}
-
-// Table-driven variant for the kernels that need one per row: the same two double-precision
-// functions at < 2^-50 absolute error (so the fp32 roundings are the same as with libm), in ~60
-// instead of ~300 instructions.  `tab` = kFastTab staged in LDS.
+// Correctly rounded fp32 log2 of a >= 0 (NaN and negative -> NaN, 0 -> -inf, inf -> inf) without
+// libm (ocml's double log2 costs ~100 VGPRs wherever it is inlined): table-driven double
+// evaluation at < 2^-50 absolute error, so the fp32 rounding is libm's.  `tab` = kFastTab (global,
+// or its LDS copy).  Works on the double's bits, so fp32 denormals need no special case.
 //   log2(m * 2^k), m in [1,2): i = top 7 mantissa bits, r = m * rc_i - 1 (|r| <= 2^-8),
 //                              log2 = k - log2(rc_i) + ln(1+r)/ln2, degree-7 series
-//   2^-bf, bf in [0,1):        j = floor(128 bf), 2^-bf = 2^(-j/128) * exp(-(bf - j/128) ln2), degree 6
-__device__ __forceinline__ Chan make_chan_fast(float maxv, const QFmt &f, const double *tab)
+__device__ __forceinline__ float log2_tab(float a, const double *tab)
 {
-    const uint32_t bits = __float_as_uint(maxv);
-    const uint32_t e8 = (bits >> 23) & 0xffu;
-    if (__builtin_expect((bits >> 31) != 0u || e8 == 0u || e8 == 255u, 0))
-        return make_chan(maxv, f);                  // zero, denormal, negative, inf, NaN
-    const int i = (int)((bits >> 16) & 0x7fu);
-    const double m = (double)__uint_as_float((bits & 0x7fffffu) | 0x3f800000u);
+    if (__builtin_expect(!(a > 0.0f) || a == __builtin_inff(), 0))
+        return a == 0.0f ? -__builtin_inff() : (a > 0.0f ? a : __builtin_nanf(""));
+    const uint64_t b = (uint64_t)__double_as_longlong((double)a);
+    const int i = (int)(b >> 45) & 0x7f;
+    const double m = __longlong_as_double((long long)((b & 0x000fffffffffffffull) | 0x3ff0000000000000ull));
     const double r = fma(m, tab[i], -1.0);
     double p = fma(r, 1.0 / 7.0, -1.0 / 6.0);
     p = fma(r, p, 1.0 / 5.0);
@@ -110,10 +100,17 @@ __device__ __forceinline__ Chan make_chan_fast(float maxv, const QFmt &f, const 
     p = fma(r, p, -1.0 / 2.0);
     p = fma(r, p, 1.0);
     p = p * r;                                      // ln(1 + r)
-    const double l2 = (double)((int)e8 - 127) + fma(p, 1.4426950408889634074, tab[128 + i]);
-    Chan c = finish_chan(maxv, (float)l2, f);
-    if (__builtin_expect(!(c.bf >= 0.0f && c.bf < 1.0f), 0)) {   // non-finite bias
-        c.g = exp2(-(double)c.bf);
+    const double l2 = (double)((int)(b >> 52) - 1023) + fma(p, 1.4426950408889634074, tab[128 + i]);
+    return (float)l2;
+}
+
+// Channel constants from maxval.  g = 2^-bf, bf in [0,1): j = floor(128 bf),
+// 2^-bf = 2^(-j/128) * exp(-(bf - j/128) ln2), degree 6; a non-finite bias has bf = NaN -> g = NaN.
+__device__ __forceinline__ Chan make_chan_fast(float maxv, const QFmt &f, const double *tab)
+{
+    Chan c = finish_chan(maxv, log2_tab(maxv, tab), f);
+    if (__builtin_expect(!(c.bf >= 0.0f && c.bf < 1.0f), 0)) {
+        c.g = (double)__builtin_nanf("");
     } else {
         const int j = (int)(c.bf * 128.0f);
         const double t = -((double)c.bf - (double)j * (1.0 / 128.0)) * 0.69314718055994530942;
@@ -129,6 +126,9 @@ __device__ __forceinline__ Chan make_chan_fast(float maxv, const QFmt &f, const 
     c.m0 = (float)c.g;
     return c;
 }
+
+// once-per-block callers: tables straight from global memory (L1/L2-resident, 3 KB)
+__device__ __forceinline__ Chan make_chan(float maxv, const QFmt &f) { return make_chan_fast(maxv, f, kFastTab); }
 
 // cooperative copy of the tables into LDS (call once per block, then __syncthreads())
 __device__ __forceinline__ void stage_fast_tab(double *dst)
@@ -166,6 +166,25 @@ __device__ __forceinline__ float2 lut_entry(const Chan &c, int p, float M)
     return make_float2(s, __builtin_amdgcn_rcpf(s));   // 1-ulp reciprocal: see QFmt::qthr
 }
 
+// The whole table of one channel, written by ONE thread (short-row kernels: thread <-> row).
+// When fl32(k - bias) is exact at both ends of the table it is exact in between (the rounding
+// error grows with |k - bias|), and every entry is ldexp(fl32(g), k - bi): see lut_entry().
+__device__ __forceinline__ void lut_row(float2 *lr, const Chan &c, const QFmt &f)
+{
+    const float k1 = 1.0f - f.M, kp = (float)f.pmax - f.M;
+    const bool lin = c.pthr >= 0.0f && (k1 - (k1 - c.bias)) == c.bias && (kp - (kp - c.bias)) == c.bias;
+    lr[0] = make_float2(__builtin_nanf(""), __builtin_nanf(""));
+    if (lin) {
+        const int j0 = (int)k1 - c.bi - 1;
+        for (int p = 1; p <= f.pmax; ++p) {
+            const float sc = ldexpf(c.m0, j0 + p);
+            lr[p] = make_float2(sc, __builtin_amdgcn_rcpf(sc));
+        }
+    } else {
+        for (int p = 1; p <= f.pmax; ++p) lr[p] = lut_entry(c, p, f.M);
+    }
+}
+
 // the three per-element channel constants the table kernels need
 struct ChanLite {
     float maxv, minv, bias, pthr;
@@ -187,7 +206,7 @@ __device__ __noinline__ float quant_exact(float x, float maxv, float minv, float
 {
     if (x != x) return x;
     const float xc = __builtin_amdgcn_fmed3f(x, minv, maxv);
-    float ls = floorf((float)log2((double)fabsf(xc)) + bias);
+    float ls = floorf(log2_tab(fabsf(xc), kFastTab) + bias);
     ls = __builtin_amdgcn_fmed3f(ls, 1.0f, pmaxf);   // NaN -> 1 (then every table entry is NaN)
     const float s = lut[(int)ls].x;
     return rintf(xc / s) * s;
@@ -254,7 +273,7 @@ __device__ __forceinline__ float quant_direct(float x, const Chan &c, float M)
     float fl = floorf(v);
     const float fr = v - fl;
     const bool risky = __builtin_amdgcn_classf(x, 0x90) | (fabsf(fr - 0.5f) > c.pthr) | (c.pthr < 0.0f);
-    if (__builtin_expect(risky, 0)) fl = floorf((float)log2((double)a) + c.bias);
+    if (__builtin_expect(risky, 0)) fl = floorf(log2_tab(a, kFastTab) + c.bias);
     const float ls = fmaxf(fl, 1.0f);
     const float s = scale_exact(c, ls, M);
     const float y = rintf(xc / s) * s;
@@ -285,7 +304,7 @@ __device__ __forceinline__ uint32_t encode_one(float x, const ChanLite &c, const
                        (fabsf(q0 - r) > qthr) | (c.pthr < 0.0f);
     if (__builtin_expect(risky, 0)) {
         if (x != x) return 0u;                      // the format has no NaN code: documented as +0
-        fl = floorf((float)log2((double)fabsf(xc)) + c.bias);
+        fl = floorf(log2_tab(fabsf(xc), kFastTab) + c.bias);
         ls = __builtin_amdgcn_fmed3f(fl, 1.0f, pmaxf);
         t = lut[(int)ls];
         r = rintf(xc / t.x);

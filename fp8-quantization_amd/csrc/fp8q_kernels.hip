@@ -264,15 +264,13 @@ k_rows_direct(const float *__restrict__ x, float *__restrict__ y, int64_t C,
         }
         {
             const float *mvsrc = MODE == kModeQuant ? maxval + r0 : rowmv;
-            for (int j = tid; j < R; j += BS) chans[j] = make_chan_fast(mvsrc[j], f, ftab);
-            __syncthreads();
-            if (LUT) {
-                for (int j = tid; j < R * a.lut_stride; j += BS) {
-                    const int cj = div_small((uint32_t)j, a.lmagic), pj = j - cj * a.lut_stride;
-                    lut[j] = lut_entry(chans[cj], pj, f.M);
-                }
-                __syncthreads();
+            // thread j <-> row j: channel constants, then the row's whole {s, 1/s} table from registers
+            for (int j = tid; j < R; j += BS) {
+                const Chan c = make_chan_fast(mvsrc[j], f, ftab);
+                chans[j] = c;
+                if (LUT) lut_row(lut + j * a.lut_stride, c, f);
             }
+            __syncthreads();
         }
         // ---- pass B: the R rows are one contiguous range -> flat, fully coalesced 16-byte I/O.
         // The channel of a 16-byte group comes from one magic division.  A group that straddles
@@ -326,6 +324,214 @@ k_rows_direct(const float *__restrict__ x, float *__restrict__ y, int64_t C,
                     }
                     st16u<NT>(yt + o, vf4{e[0], e[1], e[2], e[3]});
                 }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Short rows, flat: k_rows_flat (MODE 0 = K1, MODE 1 = fused K2+K5+K1), x and y 16-byte aligned.
+// HBM wants what a plain grid-stride copy does: every block moves one ALIGNED 16 KiB chunk per step
+// and concurrently running blocks touch neighbouring chunks (tools/pattern_sweep.hip: 6.3-6.4 TB/s;
+// a block that owns 128 contiguous KiB, or row-aligned chunks of 16 464 B: 5.2-5.7).  So the tensor
+// is cut by ADDRESS, not by rows: chunk c = elements [4096 c, 4096 (c+1)); a tile = nch chunks
+// (t*nch + i) * gridDim + blockIdx, i < nch; rows are whatever overlaps a chunk (a row cut by a chunk
+// border gets its table built by both neighbours).  Per tile:
+//   geometry  one thread per chunk: first row, phase within it, rows overlapped   (1 64-bit division)
+//   pass A    (MODE 1) min/max of every overlapping row, G lanes per row; the chunk in which a row
+//             STARTS writes row_min / row_max / maxval_out
+//   tables    thread <-> (chunk, row): channel constants + the {s, 1/s} table
+//   patches   first elements of a row up to the next 16-byte boundary, quantized with THAT row's
+//             constants (so the streaming loop only issues whole aligned 16-byte stores); tail scalars
+//   stream    one chunk per step: 4 x 16 B in flight per lane, channel of a group by magic division
+// LDS: ChunkInfo[8] | float4 patch[Rt] | float4 chanlite[Rt] | float2 lut[Rt * stride] | float rowmv[Rt]
+// ---------------------------------------------------------------------------------------------
+constexpr int kChunkElems = 4096, kChunkGroups = 1024, kFlatMaxCh = 8;
+constexpr int kFlatFusedMaxInner = 1024;   // fused: straddling rows are read twice (<= inner / 4096 extra)
+
+struct FlatArgs {
+    int inner;        // row length (>= 4)
+    int rpc;          // table rows per chunk: most rows a window of 4096 (+3 tail) elements can overlap
+    int nch;          // chunks per tile (<= kFlatMaxCh)
+    int lut_stride;   // pmax + 1
+    int group;        // pass A: lanes per row (power of two <= 64)
+    int tail;         // n - 4 * nvec: scalars after the last 16-byte group
+    uint32_t magic;   // o / inner
+    uint32_t rmagic;  // lr / rpc
+    int64_t nvec;     // 16-byte groups in the tensor (>= 1)
+    int64_t nchunks;  // ceil(nvec / 1024)
+};
+
+struct __attribute__((aligned(16))) ChunkInfo {
+    int64_t row_lo;   // first row overlapping the chunk
+    int phase;        // offset of the chunk's first element within that row
+    int nrows;        // rows overlapping the chunk (tail scalars included)
+    int len;          // elements in the chunk's aligned body (multiple of 4, <= 4096)
+    int tail;         // scalars after the body (last chunk of the tensor only)
+    int pad[2];
+};
+
+__device__ __forceinline__ ChanLite lite_of(const float4 h)
+{
+    ChanLite l;
+    l.maxv = h.x;
+    l.minv = h.y;
+    l.bias = h.z;
+    l.pthr = h.w;
+    return l;
+}
+
+template <int MODE, bool NT>
+__global__ void __launch_bounds__(kBlock, 4)
+k_rows_flat(const float *__restrict__ x, float *__restrict__ y, const float *__restrict__ maxval,
+            float *row_min, float *row_max, float *maxval_out, QFmt f, FlatArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ double ftab[kFastTabSize];
+    const int Rt = a.rpc * a.nch;
+    ChunkInfo *cinfo = reinterpret_cast<ChunkInfo *>(smem);
+    float4 *patch = reinterpret_cast<float4 *>(cinfo + kFlatMaxCh);
+    float4 *chl = patch + Rt;
+    float2 *lut = reinterpret_cast<float2 *>(chl + Rt);
+    float *rowmv = reinterpret_cast<float *>(lut + Rt * a.lut_stride);
+    const int tid = threadIdx.x;
+    const int inner = a.inner;
+    const int64_t G = gridDim.x;
+    const float pmaxf = (float)f.pmax;
+    for (int i = tid; i < kFastTabSize; i += kBlock) ftab[i] = kFastTab[i];
+
+    for (int64_t c0 = blockIdx.x; c0 < a.nchunks; c0 += G * a.nch) {
+        int nct = 1;
+        while (nct < a.nch && c0 + nct * G < a.nchunks) ++nct;
+        const int nlr = nct * a.rpc;
+        __syncthreads();   // the previous tile's tables are no longer read (and ftab is staged)
+        if (tid < nct) {
+            const int64_t c = c0 + tid * G;
+            const int64_t elo = c * kChunkElems;
+            const int64_t rem = a.nvec * 4 - elo;
+            ChunkInfo ci;
+            ci.len = rem < kChunkElems ? (int)rem : kChunkElems;
+            ci.tail = (c == a.nchunks - 1) ? a.tail : 0;
+            ci.row_lo = elo / inner;
+            ci.phase = (int)(elo - ci.row_lo * inner);
+            ci.nrows = (ci.phase + ci.len + ci.tail - 1) / inner + 1;
+            ci.pad[0] = ci.pad[1] = 0;
+            cinfo[tid] = ci;
+        }
+        __syncthreads();
+        if (MODE == kModeFused) {
+            const int Gl = a.group, rpp = kBlock / Gl, sub = tid & (Gl - 1), slot = tid / Gl;
+            const int inner4 = inner & ~3;
+            for (int lrb = 0; lrb < nlr; lrb += rpp) {
+                const int lr = lrb + slot;
+                const int i = div_small((uint32_t)lr, a.rmagic), r = lr - i * a.rpc;
+                const bool valid = lr < nlr && r < cinfo[i].nrows;
+                MinMax m;
+                mm_init(m);
+                if (valid) {
+                    const float *xr = x + (cinfo[i].row_lo + r) * inner;   // rows start at any 4-byte phase
+                    int j = sub * 4;
+                    for (; j + 3 * Gl * 4 < inner4; j += Gl * 16) {
+                        vf4 v[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) v[u] = ld16u<false>(xr + j + u * Gl * 4);   // stay in L2 for pass B
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            mm_acc(m, v[u].x);
+                            mm_acc(m, v[u].y);
+                            mm_acc(m, v[u].z);
+                            mm_acc(m, v[u].w);
+                        }
+                    }
+                    for (; j < inner4; j += Gl * 4) {
+                        const vf4 v = ld16u<false>(xr + j);
+                        mm_acc(m, v.x);
+                        mm_acc(m, v.y);
+                        mm_acc(m, v.z);
+                        mm_acc(m, v.w);
+                    }
+                    for (int k = inner4 + sub; k < inner; k += Gl) mm_acc(m, xr[k]);
+                }
+                for (int off = Gl >> 1; off >= 1; off >>= 1) {
+                    m.mn = fminf(m.mn, __shfl_xor(m.mn, off, 64));
+                    m.mx = fmaxf(m.mx, __shfl_xor(m.mx, off, 64));
+                    m.nan |= __shfl_xor(m.nan, off, 64);
+                }
+                if (valid && sub == 0) {
+                    if (m.nan) m.mn = m.mx = __builtin_nanf("");
+                    const float mv = fabsf(tmax(fabsf(m.mn), m.mx));   // fp8_quantizer.py:236
+                    rowmv[lr] = mv;
+                    if (r > 0 || cinfo[i].phase == 0) {   // the row starts in this chunk: this block reports it
+                        const int64_t grow = cinfo[i].row_lo + r;
+                        if (row_min) row_min[grow] = m.mn;
+                        if (row_max) row_max[grow] = m.mx;
+                        if (maxval_out) maxval_out[grow] = mv;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        for (int lr = tid; lr < nlr; lr += kBlock) {
+            const int i = div_small((uint32_t)lr, a.rmagic), r = lr - i * a.rpc;
+            if (r < cinfo[i].nrows) {
+                const float mv = MODE == kModeQuant ? maxval[cinfo[i].row_lo + r] : rowmv[lr];
+                const Chan c = make_chan_fast(mv, f, ftab);
+                chl[lr] = make_float4(c.maxv, c.minv, c.bias, c.pthr);
+                lut_row(lut + lr * a.lut_stride, c, f);
+            }
+        }
+        __syncthreads();
+        for (int lr = tid; lr < nlr; lr += kBlock) {
+            const int i = div_small((uint32_t)lr, a.rmagic), r = lr - i * a.rpc;
+            const ChunkInfo ci = cinfo[i];
+            float pv[3] = {0.0f, 0.0f, 0.0f};
+            if (r + 1 < ci.nrows) {
+                const int idx = (r + 1) * inner - ci.phase;   // chunk-local index of row r+1's first element
+                if (idx < ci.len && (idx & 3)) {
+                    const float *xc = x + (c0 + i * G) * kChunkElems;
+                    const ChanLite cl = lite_of(chl[lr + 1]);
+                    const float2 *lt = lut + (lr + 1) * a.lut_stride;
+                    for (int k = 0; k < 4 - (idx & 3); ++k) pv[k] = quant_one(xc[idx + k], cl, lt, pmaxf, f.qthr);
+                }
+            }
+            patch[lr] = make_float4(pv[0], pv[1], pv[2], 0.0f);
+        }
+        if (tid < cinfo[nct - 1].tail) {   // the tensor's last <= 3 elements
+            const ChunkInfo ci = cinfo[nct - 1];
+            const int e = ci.len + tid;
+            const int lr = (nct - 1) * a.rpc + div_small((uint32_t)(ci.phase + e), a.magic);
+            const int64_t at = (c0 + (nct - 1) * G) * kChunkElems + e;
+            y[at] = quant_one(x[at], lite_of(chl[lr]), lut + lr * a.lut_stride, pmaxf, f.qthr);
+        }
+        __syncthreads();
+        constexpr int U = 4;
+        for (int i = 0; i < nct; ++i) {
+            const int phase = cinfo[i].phase, ng = cinfo[i].len >> 2;
+            const int64_t base = (c0 + i * G) * kChunkElems;
+            const vf4 *xv = reinterpret_cast<const vf4 *>(x + base);
+            vf4 *yv = reinterpret_cast<vf4 *>(y + base);
+            const int lr0 = i * a.rpc;
+            vf4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (tid + u * kBlock < ng) v[u] = ld16<NT>(xv + tid + u * kBlock);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int q = tid + u * kBlock;
+                if (q >= ng) break;
+                const int o = phase + 4 * q;
+                const int lrow = div_small((uint32_t)o, a.magic);
+                const int b = inner - (o - lrow * inner);   // elements left in this row (>= 1)
+                const int lr = lr0 + lrow;
+                float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+                quant_group<4>(e, lite_of(chl[lr]), lut + lr * a.lut_stride, pmaxf, f.qthr);
+                if (b < 4) {   // e[b..3] belong to the next row: take them from its patch
+                    const float4 pt = patch[lr];
+                    e[3] = b == 3 ? pt.x : (b == 2 ? pt.y : pt.z);
+                    if (b < 3) e[2] = b == 2 ? pt.x : pt.y;
+                    if (b < 2) e[1] = pt.x;
+                }
+                st16<NT>(yv + q, vf4{e[0], e[1], e[2], e[3]});
             }
         }
     }
@@ -809,11 +1015,78 @@ int64_t direct_max_inner()
     return v;
 }
 
+// Launch k_rows_flat if the problem fits it; returns -1000 when the caller must use k_rows_direct
+// (pointers not 16-byte aligned, rows too short for per-row tables in LDS, in-place fused, ...).
+constexpr int kNotFlat = -1000;
+int launch_rows_flat(int mode, const float *x, float *y, int64_t C, int64_t inner, const float *maxval,
+                     float *row_min, float *row_max, float *maxval_out, const QFmt &f, hipStream_t st)
+{
+    static const int flat_env = [] {   // FP8Q_FLAT=0: round-1 row-tiled kernel everywhere (A/B)
+        const char *e = getenv("FP8Q_FLAT");
+        return e ? atoi(e) : 1;
+    }();
+    if (!flat_env || mode == kModeMinMax || inner < 4) return kNotFlat;
+    if ((((uintptr_t)x | (uintptr_t)y) & 15) != 0) return kNotFlat;
+    if (mode == kModeFused && (inner > kFlatFusedMaxInner || x == y)) return kNotFlat;
+    FlatArgs a = {};
+    a.inner = (int)inner;
+    a.lut_stride = f.pmax + 1;
+    a.magic = magic_of((int)inner);
+    const int64_t n = C * inner;
+    a.nvec = n >> 2;
+    a.tail = (int)(n & 3);
+    a.nchunks = cdiv(a.nvec, kChunkGroups);
+    a.rpc = (int)((inner + (kChunkElems + 3) - 2) / inner) + 1;
+    a.rmagic = magic_of(a.rpc);
+    const int64_t per_row = 16 + 16 + (int64_t)a.lut_stride * 8 + (mode == kModeFused ? 4 : 0);
+    static const int lds_kb_env = [] {
+        const char *e = getenv("FP8Q_FLAT_LDS_KB");
+        const int v = e ? atoi(e) : 0;
+        return v >= 4 && v <= 120 ? v : 36;
+    }();
+    const int64_t cap = (int64_t)lds_kb_env * 1024 - (int64_t)kFlatMaxCh * sizeof(ChunkInfo);
+    int64_t nch = cap / (a.rpc * per_row);
+    if (nch < 1) return kNotFlat;
+    static const int nch_env = [] {
+        const char *e = getenv("FP8Q_FLAT_NCH");
+        const int v = e ? atoi(e) : 0;
+        return v >= 1 && v <= kFlatMaxCh ? v : kFlatMaxCh;
+    }();
+    if (nch > nch_env) nch = nch_env;
+    while (nch > 1 && cdiv(a.nchunks, nch) < 1024) --nch;   // small tensors: more blocks, not longer tiles
+    a.nch = (int)nch;
+    int G = 1;
+    while (G < 64 && (int64_t)G * 24 < inner) G <<= 1;
+    a.group = G;
+    static const int grid_env = [] {
+        const char *e = getenv("FP8Q_FLAT_GRID");
+        const int v = e ? atoi(e) : 0;
+        return v >= 1 ? v : 32768;
+    }();
+    int64_t blocks = cdiv(a.nchunks, nch);
+    if (blocks > grid_env) blocks = grid_env;
+    const size_t shmem = (size_t)kFlatMaxCh * sizeof(ChunkInfo) + (size_t)a.rpc * nch * per_row;
+    const bool nt = n * 4 >= kNtBytes;
+    const dim3 g((unsigned)blocks), b(kBlock);
+    if (mode == kModeQuant) {
+        if (nt) hipLaunchKernelGGL((k_rows_flat<kModeQuant, true>), g, b, shmem, st, x, y, maxval, row_min, row_max, maxval_out, f, a);
+        else hipLaunchKernelGGL((k_rows_flat<kModeQuant, false>), g, b, shmem, st, x, y, maxval, row_min, row_max, maxval_out, f, a);
+    } else {
+        if (nt) hipLaunchKernelGGL((k_rows_flat<kModeFused, true>), g, b, shmem, st, x, y, maxval, row_min, row_max, maxval_out, f, a);
+        else hipLaunchKernelGGL((k_rows_flat<kModeFused, false>), g, b, shmem, st, x, y, maxval, row_min, row_max, maxval_out, f, a);
+    }
+    return launch_rc();
+}
+
 // Launch k_rows_direct for [C, inner], inner <= kDirectMaxInner (any 4-byte aligned pointers).
 int launch_rows_direct(int mode, const float *x, float *y, int64_t C, int64_t inner, const float *maxval,
                        float *row_min, float *row_max, float *maxval_out, const QFmt &f,
                        const FoldArgs &fa, hipStream_t st)
 {
+    {
+        const int rc = launch_rows_flat(mode, x, y, C, inner, maxval, row_min, row_max, maxval_out, f, st);
+        if (rc != kNotFlat) return rc;
+    }
     TileArgs a = {};
     a.inner = (int)inner;
     a.lut_stride = f.pmax + 1;

@@ -10,7 +10,8 @@ N = 1 << 21
 xw = (torch.randn(N * 147, device=dev) * 0.1).view(N, 3, 7, 7)
 yw = torch.empty_like(xw)
 mn, mx, mvw = ops.minmax(xw, True, want_maxval=True)
-tag = os.environ.get("FP8Q_DIRECT_ELEMS", "default")
+tag = os.environ.get("TAG", "default")
+timeit(lambda: ops.quantize(xw, mvw, 2, 8, 1, out=yw), iters=40)   # clocks / first-touch warm-up: discard
 report(f"[{tag}] K1 [2^21,3,7,7] E5M2", N * 147, 8, timeit(lambda: ops.quantize(xw, mvw, 2, 8, 1, out=yw)))
 report(f"[{tag}] K1 [2^21,3,7,7] E4M3", N * 147, 8, timeit(lambda: ops.quantize(xw, mvw, 3, 8, 1, out=yw)))
 report(f"[{tag}] K2 [2^21,3,7,7]", N * 147, 4, timeit(lambda: ops.minmax(xw, True)))

@@ -44,8 +44,8 @@ out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes
                  "--warmup 1 --no-cpu-baseline --no-extras",
        "correction": "FETCH_SIZE x2 on gfx950 for 16-B/lane coalesced streams (MI355X_MICROARCH.md HBM section: "
                      "FETCH_SIZE = TCC_EA0_RDREQ x 64 B, 128-B requests tallied at 64 B); WRITE_SIZE as reported; KB x1024",
-       "kernel": key, "k_rows_direct_fetch_bytes_per_launch": fetch_b, "k_rows_direct_write_bytes_per_launch": write_b,
-       "k_rows_direct_bytes_per_launch": fetch_b + write_b, "algorithmic_bytes_per_launch": 308281344 * 8, "raw": res}
+       "kernel": key, "k1_fetch_bytes_per_launch": fetch_b, "k1_write_bytes_per_launch": write_b,
+       "k1_bytes_per_launch": fetch_b + write_b, "algorithmic_bytes_per_launch": 308281344 * 8, "raw": res}
 json.dump(out, open("profiles/pmc_traffic.json", "w"), indent=1)
 json.dump(out, open(f"profiles/{tag}_pmc_traffic.json", "w"), indent=1)
 print(open(f"profiles/{tag}_bench_kernel_stats.csv").read())
