@@ -261,6 +261,36 @@ def test_per_channel_constants_fast_vs_libm(ops):
         assert_bit_exact(y, oracle.c_quantize(x, mv, M, 8, 1), f"M={M} inner={inner}")
 
 
+@pytest.mark.parametrize("C,inner", [(1, 4), (3, 5), (1, 4097), (2, 2049), (29, 147), (57, 147), (4096, 4), (700, 21),
+                                     (333, 36), (1000, 147), (9, 1023), (17, 1024), (5, 1025), (7, 2047),
+                                     (4, 1536), (100, 576), (31, 333)])
+@pytest.mark.parametrize("M", [2, 3, 4])
+def test_flat_short_row_kernel_geometries(ops, C, inner, M):
+    """k_rows_flat cuts the tensor into aligned 4096-element chunks regardless of the rows: chunk borders
+    inside rows, rows longer than a chunk, a partial last chunk, <= 3 tail scalars (C*inner % 4 != 0),
+    16-byte groups that straddle two rows (inner % 4 != 0).  K1 (also in place) and the fused
+    min/max + quantize, bit-exact against the oracle."""
+    rng = np.random.RandomState(C * 7 + inner + M)
+    x = (rng.randn(C, inner) * np.exp(rng.uniform(-3, 3, (C, 1)))).astype(np.float32)
+    x.reshape(-1)[:: 97] = 0.0
+    mn, mx = oracle.c_minmax(x, True)
+    mv = oracle.c_absmax(mn, mx)
+    ref = oracle.c_quantize(x, mv, M, 8, 1)
+    xd = dev(x)
+    assert_bit_exact(ops.quantize(xd, dev(mv), M, 8, 1).cpu().numpy(), ref, f"K1 {C}x{inner} M={M}")
+    y, gmn, gmx, gmv = ops.minmax_quantize(xd, M, 8, 1)
+    np.testing.assert_array_equal(gmn.cpu().numpy(), mn)
+    np.testing.assert_array_equal(gmx.cpu().numpy(), mx)
+    np.testing.assert_array_equal(gmv.cpu().numpy(), mv)
+    assert_bit_exact(y.cpu().numpy(), ref, f"fused {C}x{inner} M={M}")
+    xi = xd.clone()
+    ops.quantize(xi, dev(mv), M, 8, 1, out=xi)                 # in place
+    assert_bit_exact(xi.cpu().numpy(), ref, f"K1 in place {C}x{inner} M={M}")
+    xi = xd.clone()
+    ops.minmax_quantize(xi, M, 8, 1, out=xi)                   # in place: row-tiled kernel (rows owned whole)
+    assert_bit_exact(xi.cpu().numpy(), ref, f"fused in place {C}x{inner} M={M}")
+
+
 def test_more_than_2_31_elements(ops):
     """Maximum sizes: a per-tensor tensor with > 2^31 elements (8.6 GB in, 8.6 GB out) exercises the
     64-bit indexing; chunks quantized separately must give the same bits, min/max must see the planted
