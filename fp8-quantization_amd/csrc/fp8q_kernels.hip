@@ -35,6 +35,16 @@ constexpr int kDirectMaxInner = 16384; // k_rows_direct handles rows up to here 
 constexpr int kDirectElems = 32768;    // elements per k_rows_direct iteration (tables capped at 40 KiB)
 constexpr int64_t kNtBytes = 64ll << 20;  // tensors at least this big stream with nontemporal hints
 
+// Blocks for `pieces` equal pieces of work with at most `cap` blocks: every block gets the same number of
+// steps (a persistent grid of exactly `cap` blocks over 6.1 steps' worth of pieces runs 7 steps: -12 %).
+inline int64_t balanced_blocks(int64_t pieces, int64_t cap)
+{
+    if (cap < 1) cap = 1;
+    if (pieces <= cap) return pieces < 1 ? 1 : pieces;
+    const int64_t steps = (pieces + cap - 1) / cap;
+    return (pieces + steps - 1) / steps;
+}
+
 // n / d == umulhi(n, magic) for n * d < 2^32; magic == 0 encodes d == 1
 inline uint32_t magic_of(int d) { return d <= 1 ? 0u : (uint32_t)((1ull << 32) / (uint64_t)d) + 1u; }
 
@@ -812,51 +822,139 @@ struct AffineArgs {
     int C, HW;
     int act;            // 0 none, 1 relu, 2 relu6
     int has_bn, has_res;
-    uint64_t magic48;   // floor(2^48 / HW) + 1:  n / HW == (n * magic48) >> 48  for n * HW < 2^48
+    int cpp;            // most channels one 4096-element piece can overlap (size of the LDS constants)
+    uint32_t magic;     // o / HW for o < 4096 + HW (magic_of); unused when HW > kAffineMagicMaxHW
+    uint64_t magic48;   // floor(2^48 / HW) + 1:  n / HW == (n * magic48) >> 48  for n * HW < 2^48 (calibration twin)
 };
+constexpr int kAffinePiece = kBlock * 4 * 4;   // elements per block and step (16 KiB)
+constexpr int kAffineMagicMaxHW = 60000;       // (4096 + HW) * HW < 2^32; above: a piece spans <= 2 planes
 
-// Eval-mode batch norm exactly as ATen's CPU kernel evaluates it (probed: bit-identical on 100 % of
-// elements): alpha = invstd * gamma, beta' = fma(-mean, alpha, beta), out = fma(x, alpha, beta').
-__device__ __forceinline__ float affine_act(float x, float r, float m, float is, float g, float b,
-                                            const AffineArgs &a)
+// act(t + r) -- the non-affine part of the epilogue
+__device__ __forceinline__ float res_act(float t, float r, const AffineArgs &a)
 {
-    float t = x;
-    if (a.has_bn) {
-        const float alpha = is * g;
-        t = fmaf(t, alpha, fmaf(-m, alpha, b));
-    }
     if (a.has_res) t = t + r;
     if (a.act >= 1) t = t < 0.0f ? 0.0f : t;         // NaN stays NaN (torch.relu)
     if (a.act == 2) t = t > 6.0f ? 6.0f : t;
     return t;
 }
 
-// blockIdx.y = image n; blockIdx.x strides over the image's C*HW elements in 16-byte groups
-template <bool QUANT>
+// blockIdx.y = image n; blockIdx.x strides over the image's C*HW elements in aligned 16 KiB pieces
+// (one piece per block when the grid allows it: measured 6.1-6.3 TB/s against 5.0 for a persistent
+// grid of 2048 blocks).  Eval-mode batch norm exactly as ATen's CPU kernel evaluates it (probed:
+// bit-identical on 100 % of elements): alpha = invstd * gamma, beta' = fma(-mean, alpha, beta),
+// out = fma(x, alpha, beta'); {alpha, beta'} of the planes a piece overlaps are staged in LDS per
+// step, the plane of a 16-byte group comes from one 32-bit magic division of its piece-local offset.
+template <bool NT>
 __global__ void __launch_bounds__(kBlock)
 k_affine_act(const float *__restrict__ x, const float *__restrict__ res, float *__restrict__ y,
              const float *__restrict__ mean, const float *__restrict__ invstd,
              const float *__restrict__ gamma, const float *__restrict__ beta,
-             const float *__restrict__ maxval, QFmt f, AffineArgs a, float *__restrict__ ws)
+             const float *__restrict__ maxval, QFmt f, AffineArgs a)
 {
     __shared__ float2 lut[kLutMax];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float2 *cst = reinterpret_cast<float2 *>(smem);   // [cpp] {alpha, beta'} (has_bn only)
     const int tid = threadIdx.x;
-    ChanLite c = {};
-    float pmaxf = 0.0f;
-    if (QUANT) {
-        const Chan cfull = make_chan(maxval[0], f);
-        for (int i = tid; i <= f.pmax; i += kBlock) lut[i] = lut_entry(cfull, i, f.M);
-        __syncthreads();
-        c = lite(cfull);
-        pmaxf = (float)f.pmax;
+    constexpr int U = 4;
+    const Chan cfull = make_chan(maxval[0], f);
+    for (int i = tid; i <= f.pmax; i += kBlock) lut[i] = lut_entry(cfull, i, f.M);
+    const ChanLite c = lite(cfull);
+    const float pmaxf = (float)f.pmax;
+    const int64_t base0 = (int64_t)blockIdx.y * a.image;
+    const int nvec = (int)(a.image >> 2);
+    const vf4 *xv = reinterpret_cast<const vf4 *>(x + base0);
+    const vf4 *rv = reinterpret_cast<const vf4 *>(res + (a.has_res ? base0 : 0));
+    vf4 *yv = reinterpret_cast<vf4 *>(y + base0);
+    const uint32_t HW = (uint32_t)a.HW;
+    for (int base = blockIdx.x * (kBlock * U); base < nvec; base += gridDim.x * (kBlock * U)) {
+        uint32_t phase = 0;
+        __syncthreads();   // the previous step's constants are no longer read (first step: lut is complete)
+        if (a.has_bn) {
+            const uint32_t e0 = (uint32_t)base * 4u;
+            const uint32_t ch_lo = e0 / HW;
+            phase = e0 - ch_lo * HW;
+            for (int k = tid; k < a.cpp; k += kBlock) {
+                const uint32_t ch = ch_lo + (uint32_t)k;
+                if (ch < (uint32_t)a.C) {
+                    const float alpha = invstd[ch] * gamma[ch];
+                    cst[k] = make_float2(alpha, fmaf(-mean[ch], alpha, beta[ch]));
+                }
+            }
+            __syncthreads();
+        }
+        auto transform = [&](int q, float (&e)[4], const vf4 &r) {   // q: piece-local group index
+            const float rr[4] = {r.x, r.y, r.z, r.w};
+            if (a.has_bn) {
+                const uint32_t o = phase + 4u * (uint32_t)q;
+                uint32_t lch = HW > (uint32_t)kAffineMagicMaxHW ? (o >= HW ? 1u : 0u) : (uint32_t)div_small(o, a.magic);
+                uint32_t off = o - lch * HW;
+                float2 p = cst[lch];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    e[k] = res_act(fmaf(e[k], p.x, p.y), rr[k], a);
+                    if (++off == HW && k < 3) {      // the group crosses into the next plane
+                        off = 0;                     // (still inside the image: groups never straddle images)
+                        p = cst[++lch];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) e[k] = res_act(e[k], rr[k], a);
+            }
+        };
+        if (base + kBlock * U <= nvec) {   // whole piece: unpredicated loads, one branch for all its elements
+            vf4 vx[U], vr[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) vx[u] = ld16<NT>(xv + base + u * kBlock + tid);
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                vr[u] = a.has_res ? ld16<NT>(rv + base + u * kBlock + tid) : vf4{0.0f, 0.0f, 0.0f, 0.0f};
+            float e[U * 4];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float t[4] = {vx[u].x, vx[u].y, vx[u].z, vx[u].w};
+                transform(u * kBlock + tid, t, vr[u]);
+                e[4 * u] = t[0];
+                e[4 * u + 1] = t[1];
+                e[4 * u + 2] = t[2];
+                e[4 * u + 3] = t[3];
+            }
+            quant_group<U * 4>(e, c, lut, pmaxf, f.qthr);
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                st16<NT>(yv + base + u * kBlock + tid, vf4{e[4 * u], e[4 * u + 1], e[4 * u + 2], e[4 * u + 3]});
+        } else {
+            for (int u = 0; u < U; ++u) {
+                const int j = base + u * kBlock + tid;
+                if (j >= nvec) break;
+                const vf4 v = ld16<NT>(xv + j);
+                const vf4 r = a.has_res ? ld16<NT>(rv + j) : vf4{0.0f, 0.0f, 0.0f, 0.0f};
+                float e[4] = {v.x, v.y, v.z, v.w};
+                transform(u * kBlock + tid, e, r);
+                quant_group<4>(e, c, lut, pmaxf, f.qthr);
+                st16<NT>(yv + j, vf4{e[0], e[1], e[2], e[3]});
+            }
+        }
     }
+}
+
+// Calibration twin of k_affine_act: min / max of act(bn(x) + residual) per block -> ws.  Read-only, so the
+// trade-offs differ from the quantizing kernel: a persistent grid of <= 2048 blocks with 4 KiB steps, plain
+// loads and the constants straight from global measured best (36 us at [64,64,112,112]; 16 KiB steps, LDS-staged
+// constants, nontemporal loads or one piece per block: 42-55 us).
+__global__ void __launch_bounds__(kBlock)
+k_affine_minmax(const float *__restrict__ x, const float *__restrict__ res, const float *__restrict__ mean,
+                const float *__restrict__ invstd, const float *__restrict__ gamma,
+                const float *__restrict__ beta, AffineArgs a, float *__restrict__ ws)
+{
+    const int tid = threadIdx.x;
     MinMax mm;
     mm_init(mm);
     const int64_t base = (int64_t)blockIdx.y * a.image;
     const int nvec = (int)(a.image >> 2);
     const vf4 *xv = reinterpret_cast<const vf4 *>(x + base);
     const vf4 *rv = reinterpret_cast<const vf4 *>(res + (a.has_res ? base : 0));
-    vf4 *yv = reinterpret_cast<vf4 *>(y + (QUANT ? base : 0));
+    const uint32_t HW = (uint32_t)a.HW;
     for (int j = blockIdx.x * kBlock + tid; j < nvec; j += gridDim.x * kBlock) {
         const vf4 v = xv[j];
         vf4 r = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -866,33 +964,27 @@ k_affine_act(const float *__restrict__ x, const float *__restrict__ res, float *
         if (a.has_bn) {
             const uint32_t i0 = (uint32_t)j * 4u;
             uint32_t ch = (uint32_t)(((uint64_t)i0 * a.magic48) >> 48);      // plane == channel
-            uint32_t off = i0 - ch * (uint32_t)a.HW;
-            float m = mean[ch], is = invstd[ch], g = gamma[ch], b = beta[ch];
+            uint32_t off = i0 - ch * HW;
+            float alpha = invstd[ch] * gamma[ch];
+            float bp = fmaf(-mean[ch], alpha, beta[ch]);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                e[q] = affine_act(e[q], rr[q], m, is, g, b, a);
-                if (++off == (uint32_t)a.HW && q < 3) {      // the group crosses into the next plane
+                e[q] = res_act(fmaf(e[q], alpha, bp), rr[q], a);
+                if (++off == HW && q < 3) {      // the group crosses into the next plane
                     off = 0;
-                    ++ch;                                     // still < C: the group ends inside the image
-                    m = mean[ch];
-                    is = invstd[ch];
-                    g = gamma[ch];
-                    b = beta[ch];
+                    ++ch;                         // still < C: the group ends inside the image
+                    alpha = invstd[ch] * gamma[ch];
+                    bp = fmaf(-mean[ch], alpha, beta[ch]);
                 }
             }
         } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) e[q] = affine_act(e[q], rr[q], 0.0f, 1.0f, 1.0f, 0.0f, a);
+            for (int q = 0; q < 4; ++q) e[q] = res_act(e[q], rr[q], a);
         }
-        if (QUANT) {
-            quant_group<4>(e, c, lut, pmaxf, f.qthr);
-            yv[j] = vf4{e[0], e[1], e[2], e[3]};
-        } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) mm_acc(mm, e[q]);
-        }
+        for (int q = 0; q < 4; ++q) mm_acc(mm, e[q]);
     }
-    if (!QUANT) block_reduce_store(mm, ws + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 2);
+    block_reduce_store(mm, ws + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 2);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -900,7 +992,7 @@ k_affine_act(const float *__restrict__ x, const float *__restrict__ res, float *
 // elements per step (4 x 16-byte fp32 accesses <-> one 16-byte access of codes).
 // encode: 4 B read + 1 B written per element; decode: 1 B read + 4 B written.
 // ---------------------------------------------------------------------------------------------
-template <bool ENCODE>
+template <bool ENCODE, bool NT>
 __global__ void __launch_bounds__(kBlock)
 k_codec_rows(const float *__restrict__ x, uint8_t *__restrict__ codes, float *__restrict__ y, int64_t inner,
              const float *__restrict__ maxval, int per_channel, QFmt f, int n_bits)
@@ -916,15 +1008,23 @@ k_codec_rows(const float *__restrict__ x, uint8_t *__restrict__ codes, float *__
     const float *xr = ENCODE ? x + (int64_t)row * inner : nullptr;
     float *yr = ENCODE ? nullptr : y + (int64_t)row * inner;
     uint8_t *cr = codes + (int64_t)row * inner;
-    // 16-element groups whose fp32 side is 16-byte aligned and whose code side is 16-byte aligned:
-    // that needs (row*inner) % 16 == 0; otherwise everything goes through the scalar loop
+    // Vector paths need the row's fp32 side 16-byte aligned (and the code side 4 / 16-byte); otherwise scalar.
     const uintptr_t fa = (uintptr_t)(ENCODE ? (const void *)xr : (const void *)yr);
-    const bool vec = (fa & 15) == 0 && ((uintptr_t)cr & 15) == 0;
-    const int64_t ngrp = vec ? inner >> 4 : 0;
-    for (int64_t g = (int64_t)blockIdx.x * kBlock + tid; g < ngrp; g += (int64_t)gridDim.x * kBlock) {
-        if (ENCODE) {
-            const vf4 *xv = reinterpret_cast<const vf4 *>(xr + g * 16);
-            vf4 v[4] = {xv[0], xv[1], xv[2], xv[3]};
+    const bool vec = (fa & 15) == 0 && ((uintptr_t)cr & 3) == 0;
+    const int64_t ngrp = vec ? inner >> 2 : 0;
+    constexpr int U = 4;
+    const vf4 *xv = reinterpret_cast<const vf4 *>(xr);
+    vf4 *yv = reinterpret_cast<vf4 *>(yr);
+    uint32_t *cw = reinterpret_cast<uint32_t *>(cr);
+    if (ENCODE) {
+        // encode: the wide side is the LOAD (strided 16-byte loads of 64 consecutive bytes per lane are absorbed
+        // by L1); a lane converts 16 consecutive elements and stores their codes as one 16-byte word
+        const bool vec16 = vec && ((uintptr_t)cr & 15) == 0;
+        const int64_t ng16 = vec16 ? inner >> 4 : 0;
+        for (int64_t g = (int64_t)blockIdx.x * kBlock + tid; g < ng16; g += (int64_t)gridDim.x * kBlock) {
+            vf4 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = xv[g * 4 + k];   // not nontemporal: the line's other quarters hit L1
             uint32_t w[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k)
@@ -933,22 +1033,34 @@ k_codec_rows(const float *__restrict__ x, uint8_t *__restrict__ codes, float *__
                        (encode_one(v[k].z, c, lut, pmaxf, f.qthr, M, sign_shift) << 16) |
                        (encode_one(v[k].w, c, lut, pmaxf, f.qthr, M, sign_shift) << 24);
             *reinterpret_cast<uint4 *>(cr + g * 16) = make_uint4(w[0], w[1], w[2], w[3]);
-        } else {
-            const uint4 w4 = *reinterpret_cast<const uint4 *>(cr + g * 16);
-            const uint32_t w[4] = {w4.x, w4.y, w4.z, w4.w};
-            vf4 *yv = reinterpret_cast<vf4 *>(yr + g * 16);
+        }
+        for (int64_t i = (ng16 << 4) + (int64_t)blockIdx.x * kBlock + tid; i < inner; i += (int64_t)gridDim.x * kBlock)
+            cr[i] = (uint8_t)encode_one(xr[i], c, lut, pmaxf, f.qthr, M, sign_shift);
+        return;
+    }
+    // decode: the wide side is the STORE: lane <-> 4-element group, dword code loads (1 KiB per block and
+    // instruction), whole aligned 16-byte fp32 stores (4 KiB contiguous)
+    for (int64_t base = (int64_t)blockIdx.x * (kBlock * U); base < ngrp; base += (int64_t)gridDim.x * (kBlock * U)) {
+        {
+            uint32_t w[U];
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                yv[k] = vf4{decode_one(w[k] & 255u, lut, M, sign_shift), decode_one((w[k] >> 8) & 255u, lut, M, sign_shift),
-                            decode_one((w[k] >> 16) & 255u, lut, M, sign_shift), decode_one(w[k] >> 24, lut, M, sign_shift)};
+            for (int u = 0; u < U; ++u) {
+                const int64_t q = base + u * kBlock + tid;
+                if (q < ngrp) w[u] = cw[q];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t q = base + u * kBlock + tid;
+                if (q < ngrp)
+                    st16<NT>(yv + q, vf4{decode_one(w[u] & 255u, lut, M, sign_shift),
+                                         decode_one((w[u] >> 8) & 255u, lut, M, sign_shift),
+                                         decode_one((w[u] >> 16) & 255u, lut, M, sign_shift),
+                                         decode_one(w[u] >> 24, lut, M, sign_shift)});
+            }
         }
     }
-    for (int64_t i = (ngrp << 4) + (int64_t)blockIdx.x * kBlock + tid; i < inner; i += (int64_t)gridDim.x * kBlock) {
-        if (ENCODE)
-            cr[i] = (uint8_t)encode_one(xr[i], c, lut, pmaxf, f.qthr, M, sign_shift);
-        else
-            yr[i] = decode_one(cr[i], lut, M, sign_shift);
-    }
+    for (int64_t i = (ngrp << 2) + (int64_t)blockIdx.x * kBlock + tid; i < inner; i += (int64_t)gridDim.x * kBlock)
+        yr[i] = decode_one(cr[i], lut, M, sign_shift);
 }
 
 // 16-byte-per-lane copy with K1's launch shape: the achievable-HBM yardstick
@@ -1211,10 +1323,17 @@ int fp8q_quantize_f32(const float *x, float *y, int64_t C, int64_t inner, const 
         }
         return FP8Q_OK;
     }
-    int64_t bx = cdiv(cdiv(inner, 4), kBlock * kUnroll);
-    const int64_t cap = kTargetBlocks / C > 0 ? kTargetBlocks / C : 1;
-    if (bx > cap) bx = cap;
-    if (bx < 1) bx = 1;
+    static const int k1_blocks_env = [] {   // tuning knob
+        const char *e = getenv("FP8Q_K1_BLOCKS");
+        const int v = e ? atoi(e) : 0;
+        return v >= 1 ? v : 0;
+    }();
+    // One 16 KiB piece per block for big tensors (measured: 6.3 TB/s against 5.8 with a persistent grid of 2048
+    // blocks at 1 GiB; small tensors prefer the smaller grid); a partial last piece of a row gets no block of its own.
+    const int64_t pieces = inner / (4 * kBlock * kUnroll) > 0 ? inner / (4 * kBlock * kUnroll) : 1;
+    const int64_t total_cap = k1_blocks_env > 0 ? k1_blocks_env : (pieces * C > 4096 ? 65536 : kTargetBlocks);
+    const int64_t cap = total_cap / C > 0 ? total_cap / C : 1;
+    const int64_t bx = balanced_blocks(pieces, cap);
     if (aligned) {
         const dim3 g((unsigned)bx, (unsigned)C), b(kBlock);
         if (nt)
@@ -1232,12 +1351,7 @@ int fp8q_quantize_f32(const float *x, float *y, int64_t C, int64_t inner, const 
 
 static int minmax_nsplit(int64_t C, int64_t inner)
 {
-    int64_t ns = cdiv(cdiv(inner, 4), kBlock * 8);
-    int64_t cap = kTargetBlocks / (C > 0 ? C : 1);
-    if (cap < 1) cap = 1;
-    if (ns > cap) ns = cap;
-    if (ns < 1) ns = 1;
-    return (int)ns;
+    return (int)balanced_blocks(cdiv(cdiv(inner, 4), kBlock * 8), kTargetBlocks / (C > 0 ? C : 1));
 }
 
 size_t fp8q_minmax_workspace_bytes(int64_t C, int64_t inner)
@@ -1369,7 +1483,8 @@ int fp8q_mse_grid_f32(const float *x, int64_t C, int64_t inner, const float *gri
 static int affine_args(int64_t N, int64_t C, int64_t HW, int act, bool has_bn, bool has_res, AffineArgs *a)
 {
     if (N < 0 || C <= 0 || HW <= 0 || act < 0 || act > 2) return FP8Q_EINVAL;
-    // 16-byte groups must not straddle images; the 48-bit magic division needs C*HW*HW < 2^48
+    // 16-byte groups must not straddle images; 32-bit element indices within an image; the 48-bit magic
+    // division of the calibration twin needs C*HW*HW < 2^48
     if (((C * HW) & 3) != 0 || C * HW >= (1ll << 31) || HW >= (1 << 24) ||
         (double)C * (double)HW * (double)HW >= 281474976710656.0)
         return FP8Q_EUNSUPPORTED;
@@ -1379,18 +1494,29 @@ static int affine_args(int64_t N, int64_t C, int64_t HW, int act, bool has_bn, b
     a->act = act;
     a->has_bn = has_bn;
     a->has_res = has_res;
+    const int64_t cpp = (HW + kAffinePiece - 2) / HW + 1;   // planes a 4096-element window can overlap
+    a->cpp = (int)(cpp < C ? cpp : C);
+    a->magic = HW <= kAffineMagicMaxHW ? magic_of((int)HW) : 0u;
     a->magic48 = (1ull << 48) / (uint64_t)HW + 1ull;
     return FP8Q_OK;
 }
 
-static void affine_grid(int64_t N, const AffineArgs &a, int64_t *bx, int64_t *by)
+static void affine_grid(int64_t N, const AffineArgs &a, bool quant, int64_t *bx, int64_t *by)
 {
     *by = N < 65535 ? N : 65535;
-    int64_t b = cdiv(a.image >> 2, kBlock * 4);
-    const int64_t cap = (kTargetBlocks / *by) > 0 ? kTargetBlocks / *by : 1;
-    if (b > cap) b = cap;
-    if (b < 1) b = 1;
-    *bx = b;
+    const int64_t nvec = a.image >> 2;
+    if (quant) {
+        // one 16 KiB piece per block while the grid stays below 64 K blocks; a partial last piece of the
+        // image gets no block of its own
+        const int64_t pieces = nvec / (kBlock * 4) > 0 ? nvec / (kBlock * 4) : 1;
+        *bx = balanced_blocks(pieces, (pieces * *by > 4096 ? 65536 : kTargetBlocks) / *by);   // K1's grid rule
+    } else {
+        // read-only twin: a persistent grid of <= 2048 blocks with 4 KiB steps measured best (36 us against
+        // 43-55 us for 16 KiB steps or one piece per block at [64,64,112,112])
+        int64_t b = cdiv(nvec, kBlock * 4);
+        const int64_t cap = kTargetBlocks / *by > 0 ? kTargetBlocks / *by : 1;
+        *bx = b > cap ? cap : (b < 1 ? 1 : b);
+    }
 }
 
 int fp8q_affine_act_quantize_f32(const float *x, const float *residual, float *y, int64_t N, int64_t C,
@@ -1409,19 +1535,27 @@ int fp8q_affine_act_quantize_f32(const float *x, const float *residual, float *y
     if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual) & 15) return FP8Q_EINVAL;
     for (int64_t n0 = 0; n0 < N; n0 += 65535) {
         int64_t bx, by;
-        affine_grid(N - n0, a, &bx, &by);
-        hipLaunchKernelGGL(k_affine_act<true>, dim3((unsigned)bx, (unsigned)by), dim3(kBlock), 0,
-                           (hipStream_t)stream, x + n0 * a.image, residual ? residual + n0 * a.image : nullptr,
-                           y + n0 * a.image, mean, invstd, gamma, beta, maxval, f, a, (float *)nullptr);
+        affine_grid(N - n0, a, true, &bx, &by);
+        const size_t shm = has_bn ? (size_t)a.cpp * sizeof(float2) : 0;
+        if (N * a.image * 4 >= kNtBytes)
+            hipLaunchKernelGGL((k_affine_act<true>), dim3((unsigned)bx, (unsigned)by), dim3(kBlock), shm,
+                               (hipStream_t)stream, x + n0 * a.image, residual ? residual + n0 * a.image : nullptr,
+                               y + n0 * a.image, mean, invstd, gamma, beta, maxval, f, a);
+        else
+            hipLaunchKernelGGL((k_affine_act<false>), dim3((unsigned)bx, (unsigned)by), dim3(kBlock), shm,
+                               (hipStream_t)stream, x + n0 * a.image, residual ? residual + n0 * a.image : nullptr,
+                               y + n0 * a.image, mean, invstd, gamma, beta, maxval, f, a);
     }
     return launch_rc();
 }
 
-size_t fp8q_affine_act_minmax_workspace_bytes(int64_t N)
+size_t fp8q_affine_act_minmax_workspace_bytes(int64_t N, int64_t C, int64_t HW)
 {
-    const int64_t by = N < 65535 ? (N > 0 ? N : 1) : 65535;
-    const int64_t cap = (kTargetBlocks / by) > 0 ? kTargetBlocks / by : 1;
-    return (size_t)(by * cap) * 2 * sizeof(float) + 16;
+    AffineArgs a;
+    if (N <= 0 || N > 65535 || affine_args(N, C, HW, 0, false, false, &a) != FP8Q_OK) return 16;
+    int64_t bx, by;
+    affine_grid(N, a, false, &bx, &by);
+    return (size_t)(bx * by) * 2 * sizeof(float) + 16;   // one {min, max} per block
 }
 
 int fp8q_affine_act_minmax_f32(const float *x, const float *residual, int64_t N, int64_t C, int64_t HW,
@@ -1435,14 +1569,13 @@ int fp8q_affine_act_minmax_f32(const float *x, const float *residual, int64_t N,
     if (int rc = affine_args(N, C, HW, act, has_bn, residual != nullptr, &a)) return rc;
     if (N <= 0 || !x || !cur_min || !cur_max || fold_mode < 0 || fold_mode > 2) return FP8Q_EINVAL;
     if (N > 65535) return FP8Q_EUNSUPPORTED;
-    if (!ws || ws_bytes < fp8q_affine_act_minmax_workspace_bytes(N)) return FP8Q_EWORKSPACE;
+    if (!ws || ws_bytes < fp8q_affine_act_minmax_workspace_bytes(N, C, HW)) return FP8Q_EWORKSPACE;
     if (((uintptr_t)x | (uintptr_t)residual) & 15) return FP8Q_EINVAL;
     int64_t bx, by;
-    affine_grid(N, a, &bx, &by);
-    QFmt f = {};
+    affine_grid(N, a, false, &bx, &by);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_affine_act<false>, dim3((unsigned)bx, (unsigned)by), dim3(kBlock), 0, st, x, residual,
-                       (float *)nullptr, mean, invstd, gamma, beta, (const float *)nullptr, f, a, (float *)ws);
+    hipLaunchKernelGGL(k_affine_minmax, dim3((unsigned)bx, (unsigned)by), dim3(kBlock), 0, st, x, residual, mean, invstd,
+                       gamma, beta, a, (float *)ws);
     FoldArgs fa;
     fa.mode = fold_mode;
     fa.first = first != 0;
@@ -1475,18 +1608,22 @@ static int codec_launch(bool encode, const float *x, uint8_t *codes, float *y, i
     }
     for (int64_t c0 = 0; c0 < C; c0 += 65535) {
         const int64_t cn = (C - c0) < 65535 ? (C - c0) : 65535;
-        int64_t bx = cdiv(cdiv(inner, 16), kBlock);
-        const int64_t cap = kTargetBlocks / cn > 0 ? kTargetBlocks / cn : 1;
-        if (bx > cap) bx = cap;
-        if (bx < 1) bx = 1;
+        const int64_t bx = balanced_blocks(cdiv(cdiv(inner, 16), kBlock), kTargetBlocks / cn);   // 4096 elements per block and step
         const dim3 g((unsigned)bx, (unsigned)cn), b(kBlock);
-        if (encode)
-            hipLaunchKernelGGL(k_codec_rows<true>, g, b, 0, (hipStream_t)stream, x + c0 * inner, codes + c0 * inner,
-                               (float *)nullptr, inner, maxval + (per_channel ? c0 : 0), per_channel, f, n_bits);
+        const bool nt = C * inner * 4 >= kNtBytes;
+        const float *mvp = maxval + (per_channel ? c0 : 0);
+        if (encode && nt)
+            hipLaunchKernelGGL((k_codec_rows<true, true>), g, b, 0, (hipStream_t)stream, x + c0 * inner,
+                               codes + c0 * inner, (float *)nullptr, inner, mvp, per_channel, f, n_bits);
+        else if (encode)
+            hipLaunchKernelGGL((k_codec_rows<true, false>), g, b, 0, (hipStream_t)stream, x + c0 * inner,
+                               codes + c0 * inner, (float *)nullptr, inner, mvp, per_channel, f, n_bits);
+        else if (nt)
+            hipLaunchKernelGGL((k_codec_rows<false, true>), g, b, 0, (hipStream_t)stream, (const float *)nullptr,
+                               codes + c0 * inner, y + c0 * inner, inner, mvp, per_channel, f, n_bits);
         else
-            hipLaunchKernelGGL(k_codec_rows<false>, g, b, 0, (hipStream_t)stream, (const float *)nullptr,
-                               codes + c0 * inner, y + c0 * inner, inner, maxval + (per_channel ? c0 : 0),
-                               per_channel, f, n_bits);
+            hipLaunchKernelGGL((k_codec_rows<false, false>), g, b, 0, (hipStream_t)stream, (const float *)nullptr,
+                               codes + c0 * inner, y + c0 * inner, inner, mvp, per_channel, f, n_bits);
     }
     return launch_rc();
 }
@@ -1508,8 +1645,8 @@ int fp8q_copy_f32(const float *x, float *y, int64_t n, fp8q_stream_t stream)
 {
     if (!x || !y || n < 0 || (n & 3) || ((uintptr_t)x & 15) || ((uintptr_t)y & 15)) return FP8Q_EINVAL;
     if (n == 0) return FP8Q_OK;
-    int64_t bx = cdiv(n / 4, kBlock * kUnroll);
-    if (bx > kTargetBlocks) bx = kTargetBlocks;
+    const int64_t pieces = cdiv(n / 4, kBlock * kUnroll);
+    const int64_t bx = balanced_blocks(pieces, pieces > 4096 ? 65536 : kTargetBlocks);   // K1's grid rule
     if (n * 4 >= kNtBytes)
         hipLaunchKernelGGL(k_copy<true>, dim3((unsigned)bx), dim3(kBlock), 0, (hipStream_t)stream,
                            (const vf4 *)x, (vf4 *)y, n / 4);

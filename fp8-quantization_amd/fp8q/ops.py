@@ -282,7 +282,7 @@ def affine_act_minmax(x, cur_min=None, cur_max=None, mode=FOLD_CURRENT, momentum
         cur_max = torch.empty(1, dtype=torch.float32, device=x.device)
     mv = torch.empty(1, dtype=torch.float32, device=x.device)
     L = lib()
-    ws = _workspace(x.device, L.fp8q_affine_act_minmax_workspace_bytes(N))
+    ws = _workspace(x.device, L.fp8q_affine_act_minmax_workspace_bytes(N, C, HW))
     with _on_device(x):
         rc = L.fp8q_affine_act_minmax_f32(
             x.data_ptr(), residual.data_ptr() if residual is not None else None, N, C, HW, ptrs[0], ptrs[1],

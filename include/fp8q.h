@@ -115,7 +115,7 @@ int fp8q_affine_act_quantize_f32(const float *x, const float *residual, float *y
                                  int64_t HW, const float *mean, const float *invstd, const float *gamma,
                                  const float *beta, int act, const float *maxval, float mbits, int n_bits,
                                  int sign_bits, fp8q_stream_t stream);
-size_t fp8q_affine_act_minmax_workspace_bytes(int64_t N);
+size_t fp8q_affine_act_minmax_workspace_bytes(int64_t N, int64_t C, int64_t HW);
 int fp8q_affine_act_minmax_f32(const float *x, const float *residual, int64_t N, int64_t C, int64_t HW,
                                const float *mean, const float *invstd, const float *gamma, const float *beta,
                                int act, float *cur_min, float *cur_max, float *maxval_out, int fold_mode,
