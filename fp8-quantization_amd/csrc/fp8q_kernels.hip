@@ -741,20 +741,29 @@ k_mse_grid(const float *__restrict__ x, const float *__restrict__ grid, double *
     const int cand = (blockIdx.y - m * a.cgroups) * kMseBlock + tid;
     const int64_t c = blockIdx.z;
     const QFmt f = a.fmt[m];
-    const int stride = f.pmax + 2;             // odd or even, rows are read at lane-varying p
-    float *lut = xs + kMseTile + tid * stride;
-    float *ilut = lut + kMseBlock * stride;
+    const int stride = (f.pmax + 1) | 1;       // odd: lanes at the same p hit different banks
+    float *lut = xs + kMseTile + tid * stride;   // s_p of this candidate, exact (scale_exact)
     const bool active = cand < a.n_cand;
 
     // set_quant_range(-g, g): maxval = |max(|-g|, g)|  (fp8_quantizer.py:236)
     const float gv = active ? grid[(int64_t)cand * a.C + c] : 1.0f;
     const Chan ch = make_chan(fabsf(fmaxf(fabsf(-gv), gv)), f);
-    for (int p = 0; p <= f.pmax; ++p) {
-        const float sc = p == 0 ? __builtin_nanf("") : scale_exact(ch, (float)p, f.M);
-        lut[p] = sc;
-        ilut[p] = 1.0f / sc;
-    }
-    const float pmaxf = (float)f.pmax;
+    lut[0] = __builtin_nanf("");
+    for (int p = 1; p <= f.pmax; ++p) lut[p] = scale_exact(ch, (float)p, f.M);
+    // p = floor(log2|xc| + bias) without a logarithm: with bias = bi + bf, log2|xc| + bias = log2(|xc| 2^bf) + bi,
+    // so p is the exponent field of fl32(|xc| * 2^bf) plus a constant.  An element within a few ulps of a binade
+    // border can land on either side; both sides give the same grid point there (2^(M+1) steps of s_p = 2^M
+    // steps of s_(p+1)), so the squared error is unaffected beyond fp32 rounding.  A non-finite bias makes c1
+    // NaN -> exponent 255 -> p = pmax, whose entry is NaN, like the reference.
+    // 1/s_p is not tabulated (the table is what limits occupancy): 1/s_p = 2^bf * 2^(M + bi - p) up to the
+    // fp32 rounding of the table entry (<= 3e-6 relative), which can only move r = rint(xc / s_p) at an exact
+    // tie, where both neighbours are equally far from x.
+    const float c1 = (float)(1.0 / ch.g);      // 2^bf in [1, 2)
+    // in terms of the raw exponent field e8 of t = xc * c1:  p = clamp(e8 + koff, 1, pmax), koff = bi - 127
+    const int koff = ch.bi - 127;
+    const int e_lo = 1 - koff, e_hi = f.pmax - koff;          // clamp bounds for e8
+    const float *lutk = lut + koff;                             // lutk[e8] == lut[p]
+    const int jk = (int)f.M + ch.bi - koff;                     // ldexp exponent M + bi - p == jk - e8
     const float *xr = x + c * a.inner;
     double acc = 0.0;
 
@@ -774,13 +783,12 @@ k_mse_grid(const float *__restrict__ x, const float *__restrict__ grid, double *
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float xv = e[q];
-                    const float xc = fminf(fmaxf(xv, ch.minv), ch.maxv);
-                    const float vv = __builtin_amdgcn_logf(fabsf(xc)) + ch.bias;
-                    const float ls = fminf(fmaxf(floorf(vv), 1.0f), pmaxf);
-                    const int idx = (int)ls;
-                    const float r = rintf(xc * ilut[idx]);
-                    const float qv = r * lut[idx];
-                    const float d = xv - qv;
+                    const float xc = __builtin_amdgcn_fmed3f(xv, ch.minv, ch.maxv);
+                    const float tt = xc * c1;
+                    int e8 = (int)__builtin_amdgcn_ubfe(__float_as_uint(tt), 23u, 8u);
+                    e8 = max(min(e8, e_hi), e_lo);
+                    const float r = rintf(ldexpf(tt, jk - e8));
+                    const float d = xv - r * lutk[e8];
                     pa = fmaf(d, d, pa);
                 }
             }
@@ -1456,7 +1464,7 @@ int fp8q_mse_grid_f32(const float *x, int64_t C, int64_t inner, const float *gri
     a.inner = inner;
     a.C = C;
     hipStream_t st = (hipStream_t)stream;
-    const size_t shmem = (size_t)kMseTile * 4 + 2 * (size_t)kMseBlock * (pmax_all + 2) * 4;
+    const size_t shmem = (size_t)kMseTile * 4 + (size_t)kMseBlock * ((pmax_all + 1) | 1) * sizeof(float);
     if (shmem > 64 * 1024) {
         static int opted = 0;
         if (!opted) {
