@@ -142,6 +142,8 @@ def extras(ops, dev):
         for t, o, m in zip(ws, ys, mvs):
             ops.quantize(t, m, 2, 8, 1, out=o)
     rec("resnet18_all_21_weight_tensors_k1_e5m2", n_w, 8, all_weights, iters=50)
+    items = [(t, m, 2, 8, 1, o) for t, o, m in zip(ws, ys, mvs)]
+    rec("resnet18_all_21_weight_tensors_multi_launch_e5m2", n_w, 8, lambda: ops.multi_quantize(items), iters=50)
     del x, y
     return out
 

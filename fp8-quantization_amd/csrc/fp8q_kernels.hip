@@ -548,6 +548,120 @@ k_rows_flat(const float *__restrict__ x, float *__restrict__ y, const float *__r
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Multi-tensor K1: every weight tensor of a model in ONE launch (21 launches of ~7 us each for
+// ResNet-18's 11.7 M weights are launch-bound; the data is 47 MB).  One block = one aligned 4096-element
+// chunk of one tensor, processed exactly like a k_rows_flat<0> tile with a single chunk; the tensor of a
+// block comes from a <= 32-entry table passed by value in the kernel arguments (no device-side table,
+// no workspace, no host-to-device copy).
+// ---------------------------------------------------------------------------------------------
+constexpr int kMultiMax = 32;
+
+struct MultiDesc {
+    const float *x;
+    float *y;
+    const float *maxval;
+    int64_t nvec;        // 16-byte groups
+    int inner;           // row length; per-tensor entries: the whole tensor is one row (single_row)
+    int rpc;
+    int tail;
+    int single_row;
+    uint32_t magic;
+    uint32_t chunk0;     // first global chunk id of this tensor
+    QFmt f;
+};
+
+struct MultiArgs {
+    int n;
+    uint32_t total_chunks;
+    MultiDesc d[kMultiMax];
+};
+
+__global__ void __launch_bounds__(kBlock, 4)
+k_multi_flat(MultiArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ double ftab[kFastTabSize];
+    __shared__ ChunkInfo cinfo;
+    const int tid = threadIdx.x;
+    int t = 0;
+    while (t + 1 < a.n && a.d[t + 1].chunk0 <= blockIdx.x) ++t;   // uniform
+    const MultiDesc &d = a.d[t];
+    const QFmt f = d.f;
+    const int inner = d.inner, lut_stride = f.pmax + 1;
+    const int64_t c = (int64_t)blockIdx.x - d.chunk0;
+    const int64_t elo = c * kChunkElems;
+    const float *x = d.x + elo;
+    float *y = d.y + elo;
+    float4 *patch = reinterpret_cast<float4 *>(smem);
+    float4 *chl = patch + d.rpc;
+    float2 *lut = reinterpret_cast<float2 *>(chl + d.rpc);
+    const float pmaxf = (float)f.pmax;
+    for (int i = tid; i < kFastTabSize; i += kBlock) ftab[i] = kFastTab[i];
+    if (tid == 0) {
+        const int64_t rem = d.nvec * 4 - elo;
+        ChunkInfo ci;
+        ci.len = rem < kChunkElems ? (int)rem : kChunkElems;
+        ci.tail = (rem <= kChunkElems) ? d.tail : 0;
+        ci.row_lo = d.single_row ? 0 : elo / inner;
+        ci.phase = d.single_row ? 0 : (int)(elo - ci.row_lo * inner);
+        ci.nrows = d.single_row ? 1 : (ci.phase + ci.len + ci.tail - 1) / inner + 1;
+        ci.pad[0] = ci.pad[1] = 0;
+        cinfo = ci;
+    }
+    __syncthreads();
+    const ChunkInfo ci = cinfo;
+    for (int r = tid; r < ci.nrows; r += kBlock) {
+        const Chan ch = make_chan_fast(d.maxval[d.single_row ? 0 : ci.row_lo + r], f, ftab);
+        chl[r] = make_float4(ch.maxv, ch.minv, ch.bias, ch.pthr);
+        lut_row(lut + r * lut_stride, ch, f);
+    }
+    __syncthreads();
+    for (int r = tid; r < ci.nrows; r += kBlock) {
+        float pv[3] = {0.0f, 0.0f, 0.0f};
+        if (r + 1 < ci.nrows) {
+            const int idx = (r + 1) * inner - ci.phase;   // chunk-local index of row r+1's first element
+            if (idx < ci.len && (idx & 3)) {
+                const ChanLite cl = lite_of(chl[r + 1]);
+                const float2 *lt = lut + (r + 1) * lut_stride;
+                for (int k = 0; k < 4 - (idx & 3); ++k) pv[k] = quant_one(x[idx + k], cl, lt, pmaxf, f.qthr);
+            }
+        }
+        patch[r] = make_float4(pv[0], pv[1], pv[2], 0.0f);
+    }
+    if (tid < ci.tail) {   // the tensor's last <= 3 elements
+        const int e = ci.len + tid;
+        const int r = d.single_row ? 0 : div_small((uint32_t)(ci.phase + e), d.magic);
+        y[e] = quant_one(x[e], lite_of(chl[r]), lut + r * lut_stride, pmaxf, f.qthr);
+    }
+    __syncthreads();
+    constexpr int U = 4;
+    const vf4 *xv = reinterpret_cast<const vf4 *>(x);
+    vf4 *yv = reinterpret_cast<vf4 *>(y);
+    const int ng = ci.len >> 2;
+    vf4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+        if (tid + u * kBlock < ng) v[u] = ld16<false>(xv + tid + u * kBlock);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int q = tid + u * kBlock;
+        if (q >= ng) break;
+        const int o = ci.phase + 4 * q;
+        const int lrow = d.single_row ? 0 : div_small((uint32_t)o, d.magic);
+        const int b = d.single_row ? 4 : inner - (o - lrow * inner);   // elements left in this row (>= 1)
+        float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+        quant_group<4>(e, lite_of(chl[lrow]), lut + lrow * lut_stride, pmaxf, f.qthr);
+        if (b < 4) {   // e[b..3] belong to the next row: take them from its patch
+            const float4 pt = patch[lrow];
+            e[3] = b == 3 ? pt.x : (b == 2 ? pt.y : pt.z);
+            if (b < 3) e[2] = b == 2 ? pt.x : pt.y;
+            if (b < 2) e[1] = pt.x;
+        }
+        st16<false>(yv + q, vf4{e[0], e[1], e[2], e[3]});
+    }
+}
+
 // K1 scalar fallback (x / y not 16-byte co-aligned): one row per blockIdx.y, dword accesses
 __global__ void __launch_bounds__(kBlock)
 k_quant_scalar(const float *__restrict__ x, float *__restrict__ y, int64_t inner,
@@ -1647,6 +1761,71 @@ int fp8q_decode_u8(const uint8_t *codes, float *y, int64_t C, int64_t inner, con
 {
     return codec_launch(false, nullptr, const_cast<uint8_t *>(codes), y, C, inner, maxval, n_maxval, mbits,
                         n_bits, sign_bits, stream);
+}
+
+int fp8q_multi_quantize_f32(const fp8q_tensor_desc *descs, int n, fp8q_stream_t stream)
+{
+    if (n < 0 || (n > 0 && !descs)) return FP8Q_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    // validate everything first: nothing is enqueued if any descriptor is bad
+    for (int i = 0; i < n; ++i) {
+        const fp8q_tensor_desc &t = descs[i];
+        if (t.C < 0 || t.inner < 0 || (t.n_maxval != 1 && t.n_maxval != t.C)) return FP8Q_EINVAL;
+        QFmt f;
+        if (int rc = make_fmt(t.mbits, t.n_bits, t.sign_bits, &f)) return rc;
+        if (t.C > 0 && t.inner > 0 && (!t.x || !t.y || !t.maxval)) return FP8Q_EINVAL;
+    }
+    MultiArgs args;
+    args.n = 0;
+    args.total_chunks = 0;
+    size_t shmem = 0;
+    auto flush = [&]() -> int {
+        if (args.n == 0) return FP8Q_OK;
+        hipLaunchKernelGGL(k_multi_flat, dim3(args.total_chunks), dim3(kBlock), shmem, st, args);
+        args.n = 0;
+        args.total_chunks = 0;
+        shmem = 0;
+        return launch_rc();
+    };
+    for (int i = 0; i < n; ++i) {
+        const fp8q_tensor_desc &t = descs[i];
+        if (t.C == 0 || t.inner == 0) continue;
+        QFmt f;
+        make_fmt(t.mbits, t.n_bits, t.sign_bits, &f);
+        const bool per_channel = t.n_maxval != 1;
+        const int64_t nelem = t.C * t.inner;
+        const int64_t inner = per_channel ? t.inner : nelem;
+        const int64_t rpc = per_channel ? (inner + (kChunkElems + 3) - 2) / inner + 1 : 1;
+        const int64_t per_row = 16 + 16 + (int64_t)(f.pmax + 1) * 8;
+        const bool batchable = (((uintptr_t)t.x | (uintptr_t)t.y) & 15) == 0 && nelem >= 4 && nelem < (1ll << 31) &&
+                               (!per_channel || (inner >= 4 && inner <= kAffineMagicMaxHW)) &&
+                               rpc * per_row <= 36 * 1024 && nelem * 4 < kNtBytes;
+        if (!batchable) {   // unaligned, very short rows, or a tensor big enough to deserve its own launch
+            if (int rc = flush()) return rc;
+            if (int rc = fp8q_quantize_f32(t.x, t.y, t.C, t.inner, t.maxval, t.n_maxval, t.mbits, t.n_bits,
+                                           t.sign_bits, stream))
+                return rc;
+            continue;
+        }
+        if (args.n == kMultiMax)
+            if (int rc = flush()) return rc;
+        MultiDesc &d = args.d[args.n++];
+        d.x = t.x;
+        d.y = t.y;
+        d.maxval = t.maxval;
+        d.nvec = nelem >> 2;
+        d.tail = (int)(nelem & 3);
+        d.single_row = per_channel ? 0 : 1;
+        d.inner = per_channel ? (int)inner : 0;
+        d.rpc = (int)rpc;
+        d.magic = per_channel ? magic_of((int)inner) : 0u;
+        d.chunk0 = args.total_chunks;
+        d.f = f;
+        args.total_chunks += (uint32_t)cdiv(d.nvec, kChunkGroups);
+        const size_t need = (size_t)(rpc * per_row);
+        if (need > shmem) shmem = need;
+    }
+    return flush();
 }
 
 int fp8q_copy_f32(const float *x, float *y, int64_t n, fp8q_stream_t stream)

@@ -12,6 +12,14 @@ _vp = ctypes.c_void_p
 _f = ctypes.c_float
 _i = ctypes.c_int
 
+
+
+class TensorDesc(ctypes.Structure):
+    """fp8q_tensor_desc (include/fp8q.h)"""
+    _fields_ = [("x", _vp), ("y", _vp), ("maxval", _vp), ("C", _i64), ("inner", _i64), ("n_maxval", _i64),
+                ("mbits", _f), ("n_bits", _i), ("sign_bits", _i)]
+
+
 SIGNATURES = {
     "fp8q_version": (_i, []),
     "fp8q_strerror": (ctypes.c_char_p, [_i]),
@@ -31,6 +39,7 @@ SIGNATURES = {
                                         ctypes.c_double, _i, _vp, ctypes.c_size_t, _vp]),
     "fp8q_encode_u8": (_i, [_vp, _vp, _i64, _i64, _vp, _i64, _f, _i, _i, _vp]),
     "fp8q_decode_u8": (_i, [_vp, _vp, _i64, _i64, _vp, _i64, _f, _i, _i, _vp]),
+    "fp8q_multi_quantize_f32": (_i, [ctypes.POINTER(TensorDesc), _i, _vp]),
     "fp8q_copy_f32": (_i, [_vp, _vp, _i64, _vp]),
 }
 

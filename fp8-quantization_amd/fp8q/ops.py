@@ -84,6 +84,47 @@ def quantize(x, maxval, mbits, n_bits=8, sign_bits=1, out=None):
     return y
 
 
+def multi_quantize(items):
+    """Multi-tensor K1: quantize many tensors (all weights of a model) in one launch per 32 tensors.
+
+    items: iterable of (x, maxval, mbits[, n_bits[, sign_bits[, out]]]); every x on the same device.
+    Returns the list of outputs (bit-identical to quantize() on each item)."""
+    from ._lib import TensorDesc
+    items = [tuple(it) for it in items]
+    if not items:
+        return []
+    descs = (TensorDesc * len(items))()
+    outs, keep = [], []
+    dev0 = None
+    for d, it in zip(descs, items):
+        x, maxval, mbits = it[0], it[1], it[2]
+        n_bits = it[3] if len(it) > 3 else 8
+        sign_bits = it[4] if len(it) > 4 else 1
+        out = it[5] if len(it) > 5 else None
+        _require(x, "x")
+        _require(maxval, "maxval")
+        if dev0 is None:
+            dev0 = x.device
+        elif x.device != dev0:
+            raise Fp8qError("multi_quantize: all tensors must be on one device")
+        x = x.contiguous()
+        maxval = maxval.contiguous().view(-1)
+        n_mv = maxval.numel()
+        C, inner = _rows(x, n_mv != 1)
+        if n_mv != 1 and n_mv != C:
+            raise Fp8qError(f"maxval has {n_mv} elements, expected 1 or {C}")
+        y = torch.empty_like(x) if out is None else out
+        d.x, d.y, d.maxval = x.data_ptr(), y.data_ptr(), maxval.data_ptr()
+        d.C, d.inner, d.n_maxval = C, inner, n_mv
+        d.mbits, d.n_bits, d.sign_bits = float(mbits), int(n_bits), int(sign_bits)
+        outs.append(y)
+        keep.append((x, maxval))
+    with _on_device(keep[0][0]):
+        rc = lib().fp8q_multi_quantize_f32(descs, len(items), _stream(keep[0][0]))
+    check(rc, "fp8q_multi_quantize_f32")
+    return outs
+
+
 def minmax(x, per_channel, cur_min=None, cur_max=None, mode=FOLD_CURRENT, momentum=0.9,
            want_maxval=False):
     """K2/K3(/K5): batch min/max folded into the running estimate (range_estimators.py:61-125).

@@ -226,13 +226,17 @@ class QuantizationHijacker(QuantizedModule):
         if (os.environ.get("FP8Q_CACHE_WEIGHTS", "1") == "0" or getattr(mgr, "state", None) != Qstates.fix_ranges
                 or not hasattr(q, "maxval") or weight.requires_grad and torch.is_grad_enabled()):
             return self.quantize_weights(weight)
-        mv = q.maxval
-        key = (weight.data_ptr(), weight._version, tuple(weight.shape), mv.data_ptr(), mv._version,
-               float(q.mantissa_bits), q.sign_bits, q.n_bits)
+        key = self._weight_cache_key(weight, q)
         if getattr(self, "_wq_key", None) != key:
             self._wq_cache = self.quantize_weights(weight)
             self._wq_key = key
         return self._wq_cache
+
+    @staticmethod
+    def _weight_cache_key(weight, q):
+        mv = q.maxval
+        return (weight.data_ptr(), weight._version, tuple(weight.shape), mv.data_ptr(), mv._version,
+                float(q.mantissa_bits), q.sign_bits, q.n_bits)
 
     def quantize_weights(self, weights):
         return self.weight_quantizer(weights)

@@ -47,6 +47,51 @@ def load_quantizer_ranges(model, ranges, strict=True):
         m.state = q.state = Qstates[r["state"]]
 
 
+def prequantize_weights(model):
+    """With fixed ranges every layer's weight quantization is independent of the data: instead of one
+    small launch per layer in its first forward (the reference: hijacker.py:88-98, every forward), all FP8
+    weight tensors go through ONE multi-tensor launch (fp8q_multi_quantize_f32) and fill the layers' caches.
+    Bit-identical to the per-layer path; a no-op for anything it does not cover (CPU tensors, INT
+    quantizers, layers that override quantize_weights, FP8Q_CACHE_WEIGHTS=0).  Returns the number of layers."""
+    import os
+
+    import torch
+
+    from .fp8 import FPQuantizer
+    from .layers import QuantizationHijacker
+    from .manager import Qstates
+    if os.environ.get("FP8Q_CACHE_WEIGHTS", "1") == "0":
+        return 0
+    mods, items = [], []
+    for m in model.modules():
+        if not isinstance(m, QuantizationHijacker) or not getattr(m, "_qw", False):
+            continue
+        if type(m).quantize_weights is not QuantizationHijacker.quantize_weights:
+            continue   # transposed convolutions permute the weight around the quantizer
+        mgr = m.weight_quantizer
+        q = getattr(mgr, "quantizer", None)
+        if not isinstance(q, FPQuantizer) or mgr.state != Qstates.fix_ranges or q.maxval is None:
+            continue
+        w = m.get_weight_bias()[0]
+        if not (isinstance(w, torch.Tensor) and w.is_cuda and w.dtype == torch.float32 and w.is_contiguous()):
+            continue
+        if w.requires_grad and torch.is_grad_enabled():
+            continue
+        mv = q.maxval.detach()
+        if not (mv.is_cuda and mv.dtype == torch.float32) or mv.numel() not in (1, w.shape[0]):
+            continue
+        mods.append((m, w, q))
+        items.append((w.detach(), mv, float(q.mantissa_bits), int(q.n_bits), int(q.sign_bits)))
+    if not items:
+        return 0
+    import fp8q
+    outs = fp8q.ops.multi_quantize(items)
+    for (m, w, q), y in zip(mods, outs):
+        m._wq_cache = y
+        m._wq_key = m._weight_cache_key(w, q)
+    return len(outs)
+
+
 class QuantizedModel(nn.Module):
     def __init__(self, input_size=(1, 3, 224, 224)):
         super().__init__()
@@ -125,3 +170,7 @@ class QuantizedModel(nn.Module):
 
     def fix_ranges(self):
         _for_managers(self, lambda m: m.fix_ranges(), need_init=True)
+        self.prequantize_weights()
+
+    def prequantize_weights(self):
+        return prequantize_weights(self)

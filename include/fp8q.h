@@ -135,6 +135,25 @@ int fp8q_encode_u8(const float *x, uint8_t *codes, int64_t C, int64_t inner, con
 int fp8q_decode_u8(const uint8_t *codes, float *y, int64_t C, int64_t inner, const float *maxval,
                    int64_t n_maxval, float mbits, int n_bits, int sign_bits, fp8q_stream_t stream);
 
+/*
+ * Multi-tensor K1 -- all weight tensors of a model in one launch: the reference quantizes
+ * each layer's weight in that layer's forward (hijacker.py:70-108 -> quantize_weights), 21 tiny launches
+ * for ResNet-18; with fixed ranges they are independent and can be enqueued together.
+ *   descs  HOST array of n descriptors (read during the call only); every field as in fp8q_quantize_f32
+ * Tensors are batched 32 per launch; a tensor that cannot be batched (pointers not 16-byte aligned, rows
+ * shorter than 4 or too short for per-row tables, >= 64 MiB) gets its own fp8q_quantize_f32 launch, in order.
+ * Results are bit-identical to n separate fp8q_quantize_f32 calls.  Nothing is enqueued if a descriptor is bad.
+ */
+typedef struct fp8q_tensor_desc {
+    const float *x;
+    float *y;
+    const float *maxval;
+    int64_t C, inner, n_maxval;
+    float mbits;
+    int n_bits, sign_bits;
+} fp8q_tensor_desc;
+int fp8q_multi_quantize_f32(const fp8q_tensor_desc *descs, int n, fp8q_stream_t stream);
+
 /* Plain float4 copy kernel with the same launch shape as K1: the measured HBM ceiling that
  * bench.py reports next to the 8 TB/s spec figure. */
 int fp8q_copy_f32(const float *x, float *y, int64_t n, fp8q_stream_t stream);

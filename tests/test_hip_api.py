@@ -188,6 +188,44 @@ def test_quantize_model_tiny_cnn_vs_reference(golden_dir, tag, M, act_est):
         assert np.mean(np.abs(got - ref)) < 0.01 * scale
 
 
+def test_prequantize_weights_multi_tensor(golden_dir):
+    """After fix_ranges all FP8 weights can be quantized in one multi-tensor launch that fills the layers'
+    caches: same tensors, bit for bit, as each layer's own quantizer; the forward is unchanged."""
+    from quantization.autoquant_utils import quantize_model
+    from quantization.base_quantized_classes import QuantizedModule
+    from quantization.base_quantized_model import prequantize_weights
+    from quantization.hijacker import QuantizationHijacker
+    from quantization.quantization_manager import QMethods
+    from quantization.range_estimators import RangeEstimators
+    g7 = np.load(os.path.join(golden_dir, "g7_tinycnn.npz"))
+    qparams = dict(method=QMethods.fp_quantizer.cls, weight_range_method=RangeEstimators.current_minmax.cls,
+                   act_range_method=RangeEstimators.allminmax.cls, n_bits=8, per_channel_weights=True,
+                   fp8_kwargs=dict(maxval=None, mantissa_bits=2, set_maxval=True))
+    q = quantize_model(_tiny_cnn(g7), **qparams).eval().cuda()
+    calib, val = dev(g7["calib"]), dev(g7["val"])
+    with torch.no_grad():
+        for m in q.modules():
+            if isinstance(m, QuantizedModule):
+                m.quantized()
+        q(calib)
+        for m in q.modules():
+            if isinstance(m, QuantizedModule):
+                m.fix_ranges()
+        ref = q(val).clone()                  # per-layer launches fill the caches
+        per_layer = {n: m._wq_cache.clone() for n, m in q.named_modules() if isinstance(m, QuantizationHijacker)}
+        for m in q.modules():
+            if isinstance(m, QuantizationHijacker):
+                m._wq_key = m._wq_cache = None
+        n = prequantize_weights(q)
+        assert n == len(per_layer) == 4
+        for name, m in q.named_modules():
+            if isinstance(m, QuantizationHijacker):
+                assert m._wq_key is not None
+                assert torch.equal(m._wq_cache, per_layer[name]), name
+                assert m.get_params()[0] is m._wq_cache      # the forward uses the prequantized tensor
+        assert torch.equal(q(val), ref)
+
+
 def test_quantized_checkpoint_restores_ranges(golden_dir, tmp_path):
     """a saved quantized model keeps its calibrated FP8 ranges (the reference loses
     them: maxval is not a buffer).  Save after calibration, load into a fresh model, same logits."""

@@ -291,6 +291,45 @@ def test_flat_short_row_kernel_geometries(ops, C, inner, M):
     assert_bit_exact(xi.cpu().numpy(), ref, f"fused in place {C}x{inner} M={M}")
 
 
+def test_multi_tensor_quantize(ops):
+    """fp8q_multi_quantize_f32: every weight tensor of a model in one launch, bit-identical to one
+    fp8q_quantize_f32 per tensor (and to the oracle); mixed formats, per-tensor entries, tensors that fall back
+    to their own launch (depthwise 3x3 rows, unaligned views), empty tensors, > 32 tensors."""
+    rng = np.random.RandomState(5)
+    shapes = [(64, 3, 7, 7)] + [(64, 64, 3, 3)] * 4 + [(128, 64, 3, 3), (128, 128, 3, 3), (128, 64, 1, 1)] + \
+             [(128, 128, 3, 3)] * 2 + [(256, 128, 3, 3), (256, 256, 3, 3), (256, 128, 1, 1)] + [(256, 256, 3, 3)] * 2 + \
+             [(512, 256, 3, 3), (512, 512, 3, 3), (512, 256, 1, 1)] + [(512, 512, 3, 3)] * 2 + [(1000, 512)]
+    shapes += [(32, 1, 3, 3), (7, 5), (3, 4099), (1, 4), (0, 9), (96, 1, 3, 3), (24, 144, 1, 1), (1280, 320, 1, 1)]
+    shapes += [(16, 10 + i) for i in range(12)]
+    items, refs = [], []
+    for i, shp in enumerate(shapes):
+        x = (rng.randn(*shp) * 0.1).astype(np.float32)
+        M = (2, 3, 4)[i % 3]
+        per_tensor = i % 7 == 3
+        if per_tensor:
+            mv = np.array([np.abs(x).max() if x.size else 1.0], np.float32)
+        else:
+            mv = (np.abs(x.reshape(shp[0], -1)).max(1) if x.size else np.zeros(0)).astype(np.float32)
+        items.append((dev(x) if x.size else torch.empty(shp, device="cuda"), dev(mv) if mv.size else torch.empty(0, device="cuda"), M, 8, 1))
+        refs.append(oracle.c_quantize(x, mv, M, 8, 1) if x.size else x)
+    # one unaligned view (own launch)
+    base = dev((rng.randn(64 * 147 + 1) * 0.1).astype(np.float32))
+    xv = base[1:].view(64, 147)
+    mvv = xv.abs().amax(1)
+    items.append((xv, mvv, 2, 8, 1))
+    refs.append(oracle.c_quantize(xv.cpu().numpy(), mvv.cpu().numpy(), 2, 8, 1))
+    outs = ops.multi_quantize(items)
+    assert len(outs) == len(items)
+    for i, (it, y, ref) in enumerate(zip(items, outs, refs)):
+        if ref.size == 0:
+            assert y.numel() == 0
+            continue
+        assert_bit_exact(y.cpu().numpy(), ref, f"multi item {i} shape {tuple(it[0].shape)}")
+        assert_bit_exact(y.cpu().numpy(), ops.quantize(it[0], it[1], it[2], 8, 1).cpu().numpy(), f"multi vs single {i}")
+    with pytest.raises(Exception):
+        ops.multi_quantize([(items[0][0], items[0][1][:3], 2, 8, 1)])   # wrong maxval length
+
+
 def test_more_than_2_31_elements(ops):
     """Maximum sizes: a per-tensor tensor with > 2^31 elements (8.6 GB in, 8.6 GB out) exercises the
     64-bit indexing; chunks quantized separately must give the same bits, min/max must see the planted
