@@ -84,6 +84,9 @@ def build_parser():
     p.add_argument("--fp8-allow-unsigned", action=_BOOL, default=False)
     # qat option that validate-quantized reads (:184-213)
     p.add_argument("--reestimate-bn-stats", action=_BOOL, default=True)
+    p.add_argument("--hip-graph", action=_BOOL, default=False,
+                   help="replay the quantized validation forward from a HIP graph (fixed ranges; same results, "
+                        "faster for small batches)")
     return ap
 
 
@@ -195,8 +198,9 @@ def reestimate_bn_stats(model, loader, num_batches):
     model.eval()
 
 
-def evaluate(model, loader, device, fp_model=None):
+def evaluate(model, loader, device, fp_model=None, hip_graph=False):
     model.eval()
+    forward = model
     n = top1 = top5 = agree = 0
     loss_sum = 0.0
     ce = torch.nn.CrossEntropyLoss(reduction="sum")
@@ -204,7 +208,10 @@ def evaluate(model, loader, device, fp_model=None):
     with torch.no_grad():
         for x, y in loader:
             x, y = x.to(device), y.to(device)
-            out = model(x)
+            if hip_graph and forward is model and x.is_cuda:
+                from quantization.base_quantized_model import GraphedForward
+                forward = GraphedForward(model, x)
+            out = forward(x)
             n += y.numel()
             top = out.topk(5, dim=1).indices
             top1 += int((top[:, 0] == y).sum())
@@ -251,7 +258,7 @@ def validate_quantized(a):
     if a.reestimate_bn_stats:
         reestimate_bn_stats(model, train_loader, max(1, int(0.02 * len(train_loader))))
     print("Start quantized validation")
-    metrics = evaluate(model, val_loader, device, fp_model)
+    metrics = evaluate(model, val_loader, device, fp_model, hip_graph=a.hip_graph)
     print(metrics)
     return metrics
 

@@ -92,6 +92,38 @@ def prequantize_weights(model):
     return len(outs)
 
 
+class GraphedForward:
+    """HIP graph of `model(x)` for one input shape.  With FIXED ranges nothing in a quantized forward is decided on
+    the host (the engine's entry points only enqueue kernels on the current stream), so the whole forward can be
+    captured once and replayed: bit-identical to the eager forward, 2-3x faster where the eager one is
+    launch-bound (ResNet-18 batch 1: 1.31 -> 0.56 ms; batch 64 is GPU-bound: no change).
+    `gf(x)` copies x into the captured input and replays; the result lives in a buffer that the next call
+    overwrites.  Inputs of another shape (a ragged last batch) take the eager path."""
+
+    def __init__(self, model, example):
+        import torch
+        self.model = model
+        self.static_in = example.detach().clone()
+        with torch.no_grad():
+            side = torch.cuda.Stream(device=example.device)
+            side.wait_stream(torch.cuda.current_stream(example.device))
+            with torch.cuda.stream(side):
+                model(self.static_in)          # warm-up outside the capture: lazy initialisation, weight caches
+            torch.cuda.current_stream(example.device).wait_stream(side)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.static_out = model(self.static_in)
+
+    def __call__(self, x):
+        import torch
+        if x.shape != self.static_in.shape or x.dtype != self.static_in.dtype or x.device != self.static_in.device:
+            with torch.no_grad():
+                return self.model(x)
+        self.static_in.copy_(x)
+        self.graph.replay()
+        return self.static_out
+
+
 class QuantizedModel(nn.Module):
     def __init__(self, input_size=(1, 3, 224, 224)):
         super().__init__()

@@ -41,3 +41,16 @@ def test_validate_quantized_synthetic_resnet18():
     m = image_net.main(argv)
     assert m["images"] == 16 and 0.0 <= m["top_1_accuracy"] <= 1.0 and m["loss"] == m["loss"]
     assert 0.0 <= m["argmax_agreement_with_fp32"] <= 1.0
+
+
+@pytest.mark.gpu
+def test_validate_quantized_hip_graph_same_metrics():
+    """--hip-graph replays the validation forward from a captured HIP graph: same metrics as the eager loop."""
+    import image_net
+    argv = [f for f in README_FLAGS if not f.startswith("--batch-size") and f != "64"]
+    argv += ["--batch-size", "8", "--synthetic-batches", "3", "--image-size", "64", "--fp8-mantissa-bits=3"]
+    eager = image_net.main(argv)
+    graphed = image_net.main(argv + ["--hip-graph"])
+    for k in ("top_1_accuracy", "top_5_accuracy", "images", "argmax_agreement_with_fp32"):
+        assert eager[k] == graphed[k], k
+    assert abs(eager["loss"] - graphed["loss"]) <= 1e-6 * max(1.0, abs(eager["loss"]))

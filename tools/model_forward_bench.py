@@ -12,10 +12,10 @@ def qparams(M):
                 act_range_method=RangeEstimators.allminmax.cls, n_bits=8, per_channel_weights=True,
                 fp8_kwargs=dict(maxval=None, mantissa_bits=M, set_maxval=True))
 
-def run(arch, M):
+def run(arch, M, batch=64):
     torch.manual_seed(0)
     m = QuantArchitectures[arch](pretrained=False, load_type="fp32", **qparams(M)).cuda().eval()
-    x = torch.randn(64, 3, 224, 224, device="cuda")
+    x = torch.randn(batch, 3, 224, 224, device="cuda")
     out = {}
     with torch.no_grad():
         m.full_precision(); 
@@ -30,7 +30,27 @@ def run(arch, M):
             torch.cuda.synchronize(); t0 = time.perf_counter()
             for _ in range(10): m(x)
             torch.cuda.synchronize(); out["quant_fused" if fuse == "1" else "quant_unfused"] = (time.perf_counter() - t0) / 10
-    print(arch, {k: f"{v*1e3:.2f} ms" for k, v in out.items()}, flush=True)
+        # HIP graph of the whole quantized forward (fixed ranges: no host-side decisions in the forward)
+        os.environ["FP8Q_FUSE_EPILOGUE"] = "1"
+        try:
+            ref = m(x).clone()
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                for _ in range(3): m(x)
+            torch.cuda.current_stream().wait_stream(s)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                yg = m(x)
+            for _ in range(3): g.replay()
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(10): g.replay()
+            torch.cuda.synchronize(); out["quant_fused_hipgraph"] = (time.perf_counter() - t0) / 10
+            out["graph_bit_identical"] = float(torch.equal(yg, ref))
+        except Exception as e:   # noqa
+            print("graph capture failed:", repr(e)[:300])
+    print(arch, f"batch {batch}", {k: (f"{v*1e3:.2f} ms" if k != "graph_bit_identical" else bool(v)) for k, v in out.items()}, flush=True)
 
-run("resnet18_quantized", 2)
-run("mobilenet_v2_quantized", 3)
+for b in [int(v) for v in os.environ.get("BATCHES", "64").split(",")]:
+    run("resnet18_quantized", 2, b)
+    run("mobilenet_v2_quantized", 3, b)
