@@ -176,3 +176,56 @@ def quantize_weight_sharded(w, mbits, n_bits=8, sign_bits=1, maxval=None, group=
         parts.append(recv[r, : (b - a) * inner])
         mvs.append(recv[r, per * inner: per * inner + (b - a)])
     return torch.cat(parts).view_as(w), torch.cat(mvs)
+
+
+N_MSE_GRID = 111   # candidates of FP_MSE_Estimator (range_estimators.py:305)
+
+
+def mse_search_sharded(x_local, per_channel, mbit_list, n_bits=8, sign_bits=1, shard="batch", state=None,
+                       group=None, ops=None):
+    """FP_MSE_Estimator.forward (range_estimators.py:318-369) over a sharded tensor.
+
+    shard="batch"    activations, per tensor: every rank holds some images.  Two exchange steps: all-reduce(MAX)
+                     of the first batch's abs-max (it defines the 111-point search grid) and all-reduce(SUM) of
+                     the element-count-weighted partial MSEs [|m|, 111, 1] (<= 2.7 KB, combined in float64).
+    shard="channel"  weights, per channel: x_local = this rank's channels (channel_partition).  Channels are
+                     independent; the only exchange is the all-gather of the per-channel best mantissa width
+                     for the plurality vote (:350-354), C ints.
+    state            (grid, mses) from the previous call on this estimator (MSEs accumulate over batches)
+    Returns (maxval [C_local], best_mbits, state)."""
+    ops = ops or _default_ops()
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    n_m = len(mbit_list)
+    if state is None:
+        mx = ops.minmax(x_local, per_channel, want_maxval=True)[2]
+        if shard == "batch" and world > 1:
+            dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
+        cols = [torch.linspace(0.1 * m, 1.2 * m, N_MSE_GRID) for m in mx.detach().cpu().tolist()]
+        grid = torch.stack(cols).to(x_local.device).transpose(0, 1).contiguous()       # [111, C]
+        mses = torch.zeros(n_m, N_MSE_GRID, len(cols), device=x_local.device)
+    else:
+        grid, mses = state
+    inc = torch.zeros_like(mses)
+    ops.mse_grid(x_local, per_channel, grid, list(mbit_list), n_bits, sign_bits, inc)
+    if shard == "batch" and world > 1:
+        n_local = float(x_local.numel() // grid.shape[1])
+        packed = torch.cat([inc.double().reshape(-1) * n_local, torch.tensor([n_local], dtype=torch.float64,
+                                                                               device=inc.device)])
+        dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+        inc = (packed[:-1] / packed[-1]).to(mses.dtype).view_as(mses)
+    mses += inc
+    best_m_per_ch = mses.min(1)[0].argmin(0)                                           # [C_local]
+    votes = best_m_per_ch
+    if shard == "channel" and world > 1:
+        sizes = [torch.zeros(1, dtype=torch.int64, device=votes.device) for _ in range(world)]
+        dist.all_gather(sizes, torch.tensor([votes.numel()], dtype=torch.int64, device=votes.device), group=group)
+        per = int(max(int(s.item()) for s in sizes))
+        send = torch.full((max(per, 1),), -1, dtype=torch.int64, device=votes.device)
+        send[: votes.numel()] = votes
+        recv = [torch.empty_like(send) for _ in range(world)]
+        dist.all_gather(recv, send, group=group)
+        votes = torch.cat([r[: int(s.item())] for r, s in zip(recv, sizes)])
+    best_idx = int(torch.mode(votes).values.item())
+    arg = mses[best_idx].argmin(0)
+    maxval = grid.gather(0, arg.unsqueeze(0)).squeeze(0)
+    return maxval, float(mbit_list[best_idx]), (grid, mses)

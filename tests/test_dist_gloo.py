@@ -37,6 +37,11 @@ class OracleOps:
 
 
     @staticmethod
+    def mse_grid(x, per_channel, grid, mbits_list, n_bits, sign_bits, mses):
+        mses += torch.from_numpy(oracle.c_mse_grid(x.numpy(), per_channel, grid.numpy(), mbits_list, n_bits, sign_bits))
+        return mses
+
+    @staticmethod
     def encode(x, maxval, mbits, n_bits=8, sign_bits=1, out=None):
         return torch.from_numpy(oracle.c_encode(x.numpy(), maxval.numpy(), mbits, n_bits, sign_bits))
 
@@ -158,3 +163,58 @@ def test_allreduce_ranges_nan_propagates():
         assert mins[0] == -2.0 and maxs[0] == 3.0
         assert np.isnan(mins[1]) and maxs[1] == 4.0
         assert mins[2] == 0.5 and np.isnan(maxs[2])
+
+
+def _mse_acts():
+    rng = np.random.RandomState(3)
+    return [(rng.randn(6, 4, 5, 5) * s).astype(np.float32) for s in (1.0, 1.7)]   # two calibration batches
+
+
+def _mse_batch_job(rank, world):
+    from fp8q import dist as fd
+    state, out = None, None
+    for b in _mse_acts():
+        shard = torch.from_numpy(b[rank::world].copy())          # images of this rank (uneven: 3 + 3 of 6)
+        out = fd.mse_search_sharded(shard, False, [1.0, 2.0, 3.0, 4.0], 8, 1, "batch", state, ops=OracleOps)
+        state = out[2]
+    return out[0].numpy(), out[1], state[1].numpy()
+
+
+def test_mse_search_batch_sharded_matches_single_process():
+    """Activation MSE calibration, batch-sharded: grid from the all-reduced max, MSEs from the all-reduced
+    weighted partial sums -> same grid, same MSE table (fp32 rounding of the per-rank means), same winner."""
+    from fp8q import dist as fd
+    state = None
+    for b in _mse_acts():
+        ref = fd.mse_search_sharded(torch.from_numpy(b), False, [1.0, 2.0, 3.0, 4.0], 8, 1, "batch", state, ops=OracleOps)
+        state = ref[2]
+    for mv, m, mses in run(_mse_batch_job):
+        np.testing.assert_allclose(mses, state[1].numpy(), rtol=2e-6)
+        assert m == ref[1]
+        np.testing.assert_array_equal(mv, ref[0].numpy())
+
+
+def _mse_weights():
+    rng = np.random.RandomState(4)
+    return (rng.randn(11, 3, 3, 3) * np.exp(rng.uniform(-2, 0, (11, 1, 1, 1)))).astype(np.float32)
+
+
+def _mse_channel_job(rank, world):
+    from fp8q import dist as fd
+    w = _mse_weights()
+    lo, hi = fd.channel_partition(w.shape[0], world)[rank]
+    mv, m, st = fd.mse_search_sharded(torch.from_numpy(w[lo:hi].copy()), True, [1.0, 2.0, 3.0, 4.0, 5.0, 6.0], 8, 1,
+                                      "channel", None, ops=OracleOps)
+    return lo, hi, mv.numpy(), m
+
+
+def test_mse_search_channel_sharded_matches_single_process():
+    """Weight MSE search, channel-sharded (11 channels: 6 + 5): per-channel results are local, the mantissa
+    width is the plurality vote over ALL channels (one all-gather of C ints) -> identical to one process."""
+    from fp8q import dist as fd
+    w = _mse_weights()
+    ref_mv, ref_m, _ = fd.mse_search_sharded(torch.from_numpy(w), True, [1.0, 2.0, 3.0, 4.0, 5.0, 6.0], 8, 1,
+                                             "channel", None, ops=OracleOps)
+    for lo, hi, mv, m in run(_mse_channel_job):
+        assert m == ref_m
+        np.testing.assert_array_equal(mv, ref_mv.numpy()[lo:hi])

@@ -226,6 +226,22 @@ def test_prequantize_weights_multi_tensor(golden_dir):
         assert torch.equal(q(val), ref)
 
 
+def test_mse_search_sharded_single_process_equals_estimator(golden_dir):
+    """fp8q.dist.mse_search_sharded with one rank is FP_MSE_Estimator.forward (HIP ops on both sides)."""
+    from fp8q import dist as fd
+    from quantization.quantizers.fp8_quantizer import FPQuantizer
+    from quantization.range_estimators import RangeEstimators
+    g4 = np.load(os.path.join(golden_dir, "g4_mse.npz"))
+    x = dev(g4["w_pc_srchm_x0"])
+    q = FPQuantizer(n_bits=8, per_channel=True, mantissa_bits=3, set_maxval=True, maxval=None,
+                    mse_include_mantissa_bits=True)
+    est = RangeEstimators.MSE.cls(per_channel=True, quantizer=q)
+    mn, mx = est(x)
+    mv, m, state = fd.mse_search_sharded(x, True, [float(v) for v in range(1, 7)], 8, 1, "channel")
+    assert torch.equal(mv, mx) and m == float(q.mantissa_bits)
+    assert torch.equal(state[1], est.mses)
+
+
 def test_quantized_forward_in_a_hip_graph(golden_dir):
     """Every entry point only enqueues on the caller's stream (no sync, no allocation of its own), so a
     fixed-range quantized forward can be captured in a HIP graph and replayed; the replay reproduces the
