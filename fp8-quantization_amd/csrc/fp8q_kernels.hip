@@ -662,6 +662,95 @@ k_multi_flat(MultiArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fused K2+K5+K1 for rows of 257..8192 elements (a multiple of 4, 16-byte aligned): the row stays in
+// REGISTERS between the min/max pass and the quantize pass, so the tensor is read once (8 B/element of
+// HBM traffic for real).  WPR = 1: one wave per row (4 rows per block, rows <= 2048 elements);
+// WPR = 4: the whole block per row.  Rows are handed out grid-stride, so concurrently running blocks
+// work on neighbouring rows -- the access pattern of a copy.  Per row: EPT x 16 B per lane in flight,
+// wave (+ LDS) min/max reduction, the row's {s, 1/s} table written by its own lanes, quantize, store.
+// ---------------------------------------------------------------------------------------------
+template <int WPR, int EPT, bool NT>
+__global__ void __launch_bounds__(kBlock)
+k_rows_reg(const float *__restrict__ x, float *__restrict__ y, int64_t C, int inner, float *row_min,
+           float *row_max, float *maxval_out, QFmt f)
+{
+    constexpr int L = 64 * WPR;          // lanes per row
+    constexpr int RPB = 4 / WPR;         // rows per block and step
+    __shared__ float2 lut[RPB][kLutMax];
+    __shared__ double ftab[kFastTabSize];
+    __shared__ float s_mn[4], s_mx[4];
+    __shared__ int s_nan[4];
+    const int tid = threadIdx.x, sub = tid % L, rslot = tid / L, wave = tid >> 6;
+    const int nvec = inner >> 2;
+    const float pmaxf = (float)f.pmax;
+    for (int i = tid; i < kFastTabSize; i += kBlock) ftab[i] = kFastTab[i];
+    __syncthreads();
+    for (int64_t r0 = (int64_t)blockIdx.x * RPB; r0 < C; r0 += (int64_t)gridDim.x * RPB) {
+        const int64_t row = r0 + rslot;
+        const bool valid = row < C;
+        const vf4 *xv = reinterpret_cast<const vf4 *>(x + (valid ? row : 0) * inner);
+        vf4 v[EPT];
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            v[k] = vf4{0.0f, 0.0f, 0.0f, 0.0f};   // a group beyond the row: quantizes to 0 on the fast path, never stored
+            if (valid && k * L + sub < nvec) v[k] = ld16<NT>(xv + k * L + sub);
+        }
+        MinMax m;
+        mm_init(m);
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            if (valid && k * L + sub < nvec) {
+                mm_acc(m, v[k].x);
+                mm_acc(m, v[k].y);
+                mm_acc(m, v[k].z);
+                mm_acc(m, v[k].w);
+            }
+        }
+        mm_wave_reduce(m);
+        if (WPR == 4) {
+            if ((tid & 63) == 0) {
+                s_mn[wave] = m.mn;
+                s_mx[wave] = m.mx;
+                s_nan[wave] = m.nan;
+            }
+            __syncthreads();
+            m.mn = fminf(fminf(s_mn[0], s_mn[1]), fminf(s_mn[2], s_mn[3]));
+            m.mx = fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3]));
+            m.nan = s_nan[0] | s_nan[1] | s_nan[2] | s_nan[3];
+        }
+        if (m.nan) m.mn = m.mx = __builtin_nanf("");
+        const float mv = fabsf(tmax(fabsf(m.mn), m.mx));   // fp8_quantizer.py:236
+        if (valid && sub == 0) {
+            if (row_min) row_min[row] = m.mn;
+            if (row_max) row_max[row] = m.mx;
+            if (maxval_out) maxval_out[row] = mv;
+        }
+        const Chan c = make_chan_fast(mv, f, ftab);
+        for (int p = sub; p <= f.pmax; p += L) lut[rslot][p] = lut_entry(c, p, f.M);
+        __syncthreads();
+        {
+            // one branch for all groups of the lane (missing groups hold zeros: no rare-case work)
+            const ChanLite cl = lite(c);
+            vf4 *yv = reinterpret_cast<vf4 *>(y + (valid ? row : 0) * inner);
+            float e[EPT * 4];
+#pragma unroll
+            for (int k = 0; k < EPT; ++k) {
+                e[4 * k] = v[k].x;
+                e[4 * k + 1] = v[k].y;
+                e[4 * k + 2] = v[k].z;
+                e[4 * k + 3] = v[k].w;
+            }
+            quant_group<EPT * 4>(e, cl, lut[rslot], pmaxf, f.qthr);
+#pragma unroll
+            for (int k = 0; k < EPT; ++k)
+                if (valid && k * L + sub < nvec)
+                    st16<NT>(yv + k * L + sub, vf4{e[4 * k], e[4 * k + 1], e[4 * k + 2], e[4 * k + 3]});
+        }
+        __syncthreads();   // the tables are rewritten by the next step
+    }
+}
+
 // K1 scalar fallback (x / y not 16-byte co-aligned): one row per blockIdx.y, dword accesses
 __global__ void __launch_bounds__(kBlock)
 k_quant_scalar(const float *__restrict__ x, float *__restrict__ y, int64_t inner,
@@ -1534,9 +1623,49 @@ int fp8q_minmax_quantize_f32(const float *x, float *y, int64_t C, int64_t inner,
     if (!x || !y) return FP8Q_EINVAL;
     if (inner > kDirectMaxInner) return FP8Q_EUNSUPPORTED;
     if (((uintptr_t)x & 3) != 0 || ((uintptr_t)y & 3) != 0) return FP8Q_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    static const int reg_env = [] {   // FP8Q_FUSED_REG=0: row-tiled kernel for every row length (A/B)
+        const char *e = getenv("FP8Q_FUSED_REG");
+        return e ? atoi(e) : 1;
+    }();
+    const int64_t reg_lanes = inner <= 2048 ? 64 : 256;
+    const int64_t reg_ept = cdiv(inner >> 2, reg_lanes);
+    const int64_t reg_slots = (reg_ept <= 4 ? reg_ept : (reg_ept <= 6 ? 6 : 8)) * reg_lanes;   // instantiated EPT
+    if (reg_env && inner > kFlatFusedMaxInner && inner <= 8192 && (inner & 3) == 0 &&
+        (inner >> 2) * 100 >= reg_slots * (inner >= 1024 ? 70 : 95) &&   // lanes' slots that hold data (short rows:
+                                                                         // the per-row work only pays when full)
+        (((uintptr_t)x | (uintptr_t)y) & 15) == 0) {
+        // rows held in registers: one wave per row up to 2048 elements, one block per row above
+        const bool nt = C * inner * 4 >= kNtBytes;
+        const int nvec = (int)(inner >> 2);
+        const int wpr = inner <= 2048 ? 1 : 4;
+        const int ept = (int)cdiv(nvec, 64 * wpr);           // 2..8
+        const int64_t steps = cdiv(C, 4 / wpr);
+        const int64_t grid = balanced_blocks(steps, 65536);
+        const dim3 g((unsigned)grid), b(kBlock);
+#define FP8Q_LAUNCH_REG(W, E)                                                                                   \
+    do {                                                                                                        \
+        if (nt) hipLaunchKernelGGL((k_rows_reg<W, E, true>), g, b, 0, st, x, y, C, (int)inner, row_min, row_max, \
+                                   maxval_out, f);                                                              \
+        else hipLaunchKernelGGL((k_rows_reg<W, E, false>), g, b, 0, st, x, y, C, (int)inner, row_min, row_max,   \
+                                maxval_out, f);                                                                 \
+    } while (0)
+        if (wpr == 1) {
+            if (ept <= 2) FP8Q_LAUNCH_REG(1, 2);
+            else if (ept <= 3) FP8Q_LAUNCH_REG(1, 3);
+            else if (ept <= 4) FP8Q_LAUNCH_REG(1, 4);
+            else if (ept <= 6) FP8Q_LAUNCH_REG(1, 6);
+            else FP8Q_LAUNCH_REG(1, 8);
+        } else {
+            if (ept <= 4) FP8Q_LAUNCH_REG(4, 4);
+            else if (ept <= 6) FP8Q_LAUNCH_REG(4, 6);
+            else FP8Q_LAUNCH_REG(4, 8);
+        }
+#undef FP8Q_LAUNCH_REG
+        return launch_rc();
+    }
     const FoldArgs nofold = {0, 1, 0.0f, 0.0f};
-    return launch_rows_direct(kModeFused, x, y, C, inner, nullptr, row_min, row_max, maxval_out, f, nofold,
-                              (hipStream_t)stream);
+    return launch_rows_direct(kModeFused, x, y, C, inner, nullptr, row_min, row_max, maxval_out, f, nofold, st);
 }
 
 static int mse_nsplit(int64_t C, int64_t inner, int64_t n_cand, int n_m)

@@ -291,6 +291,32 @@ def test_flat_short_row_kernel_geometries(ops, C, inner, M):
     assert_bit_exact(xi.cpu().numpy(), ref, f"fused in place {C}x{inner} M={M}")
 
 
+@pytest.mark.parametrize("C,inner", [(9, 512), (33, 1024), (7, 1152), (5, 2048), (6, 2052), (3, 4608), (5, 8192),
+                                     (2, 8196), (13, 576), (4, 260), (1, 1024), (257, 1280)])
+@pytest.mark.parametrize("M", [2, 4])
+def test_fused_rows_in_registers(ops, C, inner, M):
+    """k_rows_reg (rows of 257..8192 elements held in registers between the min/max and the quantize pass): one
+    wave per row and one block per row, full and partly filled lanes, rows that fall back to the row-tiled
+    kernel, NaN / all-zero rows, in place; bit-exact against the oracle."""
+    rng = np.random.RandomState(C + inner + M)
+    x = (rng.randn(C, inner) * np.exp(rng.uniform(-3, 3, (C, 1)))).astype(np.float32)
+    if C > 2:
+        x[1] = 0.0
+        x[2, inner // 2] = np.nan
+    mn, mx = oracle.c_minmax(x, True)
+    mv = oracle.c_absmax(mn, mx)
+    ref = oracle.c_quantize(x, mv, M, 8, 1)
+    xd = dev(x)
+    y, gmn, gmx, gmv = ops.minmax_quantize(xd, M, 8, 1)
+    np.testing.assert_array_equal(gmn.cpu().numpy(), mn)
+    np.testing.assert_array_equal(gmx.cpu().numpy(), mx)
+    np.testing.assert_array_equal(gmv.cpu().numpy(), mv)
+    assert_bit_exact(y.cpu().numpy(), ref, f"fused {C}x{inner} M={M}")
+    xi = xd.clone()
+    ops.minmax_quantize(xi, M, 8, 1, out=xi)
+    assert_bit_exact(xi.cpu().numpy(), ref, f"fused in place {C}x{inner} M={M}")
+
+
 def test_multi_tensor_quantize(ops):
     """fp8q_multi_quantize_f32: every weight tensor of a model in one launch, bit-identical to one
     fp8q_quantize_f32 per tensor (and to the oracle); mixed formats, per-tensor entries, tensors that fall back
