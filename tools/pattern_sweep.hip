@@ -43,6 +43,24 @@ __global__ void __launch_bounds__(256) k_tile_copy(const vf4 *__restrict__ x, vf
     }
 }
 
+// one 16 KiB piece per block; MAP 0: piece = blockIdx (neighbouring blocks = different XCDs = neighbouring pieces),
+// MAP 1: XCD-partitioned (blocks are dealt round-robin to the 8 XCDs: XCD k streams the k-th eighth of the tensor)
+template <int MAP>
+__global__ void __launch_bounds__(256) k_piece_copy(const vf4 *__restrict__ x, vf4 *__restrict__ y, long npieces)
+{
+    const long b = blockIdx.x;
+    const long per = npieces / 8;
+    const long piece = MAP == 0 ? b : ((b & 7) * per + (b >> 3));
+    if (piece >= npieces) return;
+    const vf4 *xp = x + piece * 1024;
+    vf4 *yp = y + piece * 1024;
+    vf4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = __builtin_nontemporal_load(xp + u * 256 + threadIdx.x);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) __builtin_nontemporal_store(v[u], yp + u * 256 + threadIdx.x);
+}
+
 template <typename F>
 double time_ms(F launch, int iters = 10)
 {
@@ -64,6 +82,16 @@ int main()
     float *x, *y; CK(hipMalloc(&x, n * 4)); CK(hipMalloc(&y, n * 4));
     CK(hipMemset(x, 1, n * 4)); CK(hipMemset(y, 0, n * 4));
     const long nvec = n / 4;
+    {
+        const long np = (nvec / 1024) & ~7L;
+        for (int rep = 0; rep < 3; ++rep) {
+            double m0 = time_ms([&] { hipLaunchKernelGGL((k_piece_copy<0>), dim3(np), dim3(256), 0, 0, (const vf4 *)x, (vf4 *)y, np); });
+            double m1 = time_ms([&] { hipLaunchKernelGGL((k_piece_copy<1>), dim3(np), dim3(256), 0, 0, (const vf4 *)x, (vf4 *)y, np); });
+            printf("one piece per block (%ld blocks): linear %6.3f TB/s   XCD-partitioned %6.3f TB/s\n", np, 2.0 * np * 16384 / m0 / 1e9,
+                   2.0 * np * 16384 / m1 / 1e9);
+        }
+    }
+    if (getenv("PIECES_ONLY")) return 0;
     struct Cfg { int gpc, nch; };
     const Cfg cfgs[] = {{1029, 8}, {1029, 4}, {1024, 8}, {1024, 4}, {1024, 1}, {441, 9}, {735, 4}, {512, 8}, {256, 16}, {2048, 4}, {4096, 2}};
     const int ldss[] = {0, 36 * 1024};
