@@ -185,8 +185,8 @@ constexpr int kModeQuant = 0, kModeFused = 1, kModeMinMax = 2;
 //                     in MODE 1 this re-reads the rows, which are L2-resident
 // Dynamic LDS: float rowmv[R4] | float4 patch[R] | Chan chans[R] | float2 lut[R * lut_stride]
 // ---------------------------------------------------------------------------------------------
-template <int MODE, bool LUT, bool NT, int BS>
-__global__ void __launch_bounds__(BS, BS == 256 ? 4 : 1)   // <= 128 VGPRs: 4 blocks of 256 per CU
+template <int MODE, bool LUT, bool NT>
+__global__ void __launch_bounds__(kBlock, 4)   // <= 128 VGPRs: 4 blocks of 256 per CU
 k_rows_direct(const float *__restrict__ x, float *__restrict__ y, int64_t C,
               const float *__restrict__ maxval, float *row_min, float *row_max, float *maxval_out,
               QFmt f, TileArgs a, FoldArgs fa)
@@ -198,14 +198,15 @@ k_rows_direct(const float *__restrict__ x, float *__restrict__ y, int64_t C,
     Chan *chans = reinterpret_cast<Chan *>(patch + Rmax);
     float2 *lut = reinterpret_cast<float2 *>(chans + Rmax);
     const int tid = threadIdx.x;
+    constexpr int BS = kBlock;
     const int G = a.group, rpp = BS / G;
     const int sub = tid & (G - 1), slot = tid / G;
     const int inner = a.inner, inner4 = inner & ~3;
     const float pmaxf = (float)f.pmax;
     // log2/exp2 tables: staged in LDS for 256-thread blocks; single-wave blocks read them through L1
-    __shared__ double ftab_lds[BS == 64 ? 1 : kFastTabSize];
-    const double *ftab = BS == 64 ? kFastTab : ftab_lds;
-    if (MODE != kModeMinMax && BS != 64)
+    __shared__ double ftab_lds[kFastTabSize];
+    const double *ftab = ftab_lds;
+    if (MODE != kModeMinMax)
         for (int i = threadIdx.x; i < kFastTabSize; i += BS) ftab_lds[i] = kFastTab[i];
 
     for (int64_t r0 = (int64_t)blockIdx.x * Rmax; r0 < C; r0 += (int64_t)gridDim.x * Rmax) {
@@ -1425,11 +1426,7 @@ int launch_rows_direct(int mode, const float *x, float *y, int64_t C, int64_t in
         const int v = e ? atoi(e) : 0;
         return v >= 256 && v <= (1 << 20) ? v : kDirectElems;
     }();
-    static const int bs_env = [] {       // 64: one wave per block (no block-level barriers), 256: default
-        const char *e = getenv("FP8Q_DIRECT_BS");
-        return (e && atoi(e) == 64) ? 64 : 256;
-    }();
-    const int BSZ = (mode == kModeMinMax) ? 256 : bs_env;
+    const int BSZ = kBlock;
     const int rpp = BSZ / G;
     int64_t R = (elems_env * BSZ / 256) / inner;
     static const int mm_passes_env = [] { const char *e = getenv("FP8Q_K2_PASSES"); return e ? atoi(e) : 2; }();
@@ -1443,7 +1440,7 @@ int launch_rows_direct(int mode, const float *x, float *y, int64_t C, int64_t in
         const int v = e ? atoi(e) : 0;
         return v >= 4 && v <= 120 ? v : 36;
     }();
-    const int64_t lds_cap = BSZ == 64 ? 10 * 1024 - 64 : (int64_t)lds_kb_env * 1024;
+    const int64_t lds_cap = (int64_t)lds_kb_env * 1024;
     if (R * per_row > lds_cap) R = lds_cap / per_row;
     const int64_t want = cdiv(C, 1024);           // small tensors: spread over >= ~1024 blocks
     if (R > want) R = want;
@@ -1458,19 +1455,12 @@ int launch_rows_direct(int mode, const float *x, float *y, int64_t C, int64_t in
     // K2: many short blocks (two passes of rows each) measured best: 5.4 TB/s against 4.9 with 4096 x 4 passes
     static const int mm_blocks_env = [] { const char *e = getenv("FP8Q_K2_BLOCKS"); return e ? atoi(e) : 65536; }();
     const int64_t bcap = mode == kModeMinMax ? mm_blocks_env : 2 * kTargetBlocks;
-    if (blocks > bcap && BSZ != 64) blocks = balanced_blocks(blocks, bcap);
+    if (blocks > bcap) blocks = balanced_blocks(blocks, bcap);
     const bool nt = C * inner * 4 >= kNtBytes;
-    if (BSZ == 64 && blocks > 8 * kTargetBlocks) blocks = 8 * kTargetBlocks;
     const dim3 g((unsigned)blocks), b(BSZ);
-#define FP8Q_LAUNCH_DIRECT(M, L, N)                                                                      \
-    do {                                                                                                 \
-        if (BSZ == 64)                                                                                   \
-            hipLaunchKernelGGL((k_rows_direct<M, L, N, 64>), g, b, shmem, st, x, y, C, maxval, row_min,  \
-                               row_max, maxval_out, f, a, fa);                                           \
-        else                                                                                             \
-            hipLaunchKernelGGL((k_rows_direct<M, L, N, 256>), g, b, shmem, st, x, y, C, maxval, row_min, \
-                               row_max, maxval_out, f, a, fa);                                           \
-    } while (0)
+#define FP8Q_LAUNCH_DIRECT(M, L, N)                                                                    \
+    hipLaunchKernelGGL((k_rows_direct<M, L, N>), g, b, shmem, st, x, y, C, maxval, row_min, row_max,    \
+                       maxval_out, f, a, fa)
     if (mode == kModeMinMax) {
         FP8Q_LAUNCH_DIRECT(kModeMinMax, false, false);
     } else if (mode == kModeQuant) {
