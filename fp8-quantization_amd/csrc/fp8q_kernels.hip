@@ -1,22 +1,27 @@
 // fp8q_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels + the C ABI of include/fp8q.h.
 //
 // Every kernel here is elementwise or a reduction: the roofline is HBM bandwidth, not MFMA.
-// Common shape: 256-thread blocks (4 waves, one per SIMD), 16 B per lane per memory
-// instruction (1 KiB per wave-instruction), several independent loads in flight per lane,
-// persistent grids of ~8 blocks per CU that stride over the tensor.
+// Common shape: 256-thread blocks (4 waves, one per SIMD), 16 B per lane per memory instruction
+// (1 KiB per wave-instruction), 4 independent loads in flight per lane, and -- what HBM turned out to
+// care about most (tools/pattern_sweep.hip) -- every block moves ALIGNED 16 KiB pieces, neighbouring
+// blocks neighbouring pieces, one piece (or one short tile) per block rather than a persistent grid.
 //
-// Kernel inventory (SURVEY.md section 2.1):
-//   k_quant_rows     K1, one channel per blockIdx.y (per-tensor: one row).  Scale LUT in LDS.
-//   k_rows_direct    per-channel tensors with short rows (R rows per block iteration, per-row
-//                    tables in LDS): MODE 0 = K1, MODE 1 = K2+K5+K1 fused (weights in
-//                    estimate_ranges state: one read + one write of HBM per element, the second
-//                    read of a tile hits L2), MODE 2 = K2 (+fold).
-//   k_quant_scalar   K1 fallback for x / y that are not 16-byte co-aligned.
-//   k_minmax_partial K2/K3 stage 1: per-(row, split) min / max / NaN flag.
-//   k_minmax_final   K2/K3 stage 2 + K5: reduce the splits, fold into the running estimate
-//                    (current / all / EMA), write |max(|min|, max)|.
-//   k_mse_grid       K4: all candidate maxvals x mantissa widths in one pass over x.
-//   k_copy           float4 copy with K1's launch shape (measured HBM ceiling).
+// Kernel inventory (SURVEY.md section 2.1 / 8):
+//   k_quant_rows      K1, one channel per blockIdx.y (per-tensor: one row).  Scale LUT in LDS.
+//   k_rows_flat       per-channel tensors with short rows, cut into aligned 4096-element chunks regardless of
+//                     the rows (per-row tables in LDS): MODE 0 = K1, MODE 1 = K2+K5+K1 fused (rows <= 256).
+//   k_rows_reg        K2+K5+K1 fused for rows of 512..8192 elements: the row stays in registers.
+//   k_rows_direct     round-1 row-tiled kernel: K2 (+fold) for short rows, rows too short for per-row
+//                     tables, unaligned pointers, the fused cases the two kernels above do not take.
+//   k_multi_flat      multi-tensor K1: one block = one chunk of one of <= 32 tensors.
+//   k_quant_scalar    K1 fallback for x / y that are not 16-byte co-aligned.
+//   k_minmax_partial  K2/K3 stage 1: per-(row, split) min / max / NaN flag.
+//   k_minmax_final    K2/K3 stage 2 + K5: reduce the splits, fold into the running estimate
+//                     (current / all / EMA), write |max(|min|, max)|.
+//   k_mse_grid        K4: all candidate maxvals x mantissa widths in one pass over x.
+//   k_affine_act      N2: eval-BN + residual + ReLU/ReLU6 + per-tensor quantizer; k_affine_minmax: its range twin.
+//   k_codec_rows      N3: storage codes (encode / decode).
+//   k_copy            float4 copy with K1's launch geometry (measured HBM ceiling).
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
