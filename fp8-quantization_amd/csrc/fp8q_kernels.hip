@@ -1162,16 +1162,17 @@ k_affine_act(const float *__restrict__ x, const float *__restrict__ res, float *
 __global__ void __launch_bounds__(kBlock)
 k_affine_minmax(const float *__restrict__ x, const float *__restrict__ res, const float *__restrict__ mean,
                 const float *__restrict__ invstd, const float *__restrict__ gamma,
-                const float *__restrict__ beta, AffineArgs a, float *__restrict__ ws)
+                const float *__restrict__ beta, AffineArgs a, int64_t N, float *__restrict__ ws)
 {
     const int tid = threadIdx.x;
     MinMax mm;
     mm_init(mm);
-    const int64_t base = (int64_t)blockIdx.y * a.image;
     const int nvec = (int)(a.image >> 2);
+    const uint32_t HW = (uint32_t)a.HW;
+    for (int64_t img = blockIdx.y; img < N; img += gridDim.y) {   // more than 65535 images: several per block row
+    const int64_t base = img * a.image;
     const vf4 *xv = reinterpret_cast<const vf4 *>(x + base);
     const vf4 *rv = reinterpret_cast<const vf4 *>(res + (a.has_res ? base : 0));
-    const uint32_t HW = (uint32_t)a.HW;
     for (int j = blockIdx.x * kBlock + tid; j < nvec; j += gridDim.x * kBlock) {
         const vf4 v = xv[j];
         vf4 r = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -1200,6 +1201,7 @@ k_affine_minmax(const float *__restrict__ x, const float *__restrict__ res, cons
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) mm_acc(mm, e[q]);
+    }
     }
     block_reduce_store(mm, ws + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 2);
 }
@@ -1802,7 +1804,7 @@ int fp8q_affine_act_quantize_f32(const float *x, const float *residual, float *y
 size_t fp8q_affine_act_minmax_workspace_bytes(int64_t N, int64_t C, int64_t HW)
 {
     AffineArgs a;
-    if (N <= 0 || N > 65535 || affine_args(N, C, HW, 0, false, false, &a) != FP8Q_OK) return 16;
+    if (N <= 0 || affine_args(N, C, HW, 0, false, false, &a) != FP8Q_OK) return 16;
     int64_t bx, by;
     affine_grid(N, a, false, &bx, &by);
     return (size_t)(bx * by) * 2 * sizeof(float) + 16;   // one {min, max} per block
@@ -1818,14 +1820,13 @@ int fp8q_affine_act_minmax_f32(const float *x, const float *residual, int64_t N,
     AffineArgs a;
     if (int rc = affine_args(N, C, HW, act, has_bn, residual != nullptr, &a)) return rc;
     if (N <= 0 || !x || !cur_min || !cur_max || fold_mode < 0 || fold_mode > 2) return FP8Q_EINVAL;
-    if (N > 65535) return FP8Q_EUNSUPPORTED;
     if (!ws || ws_bytes < fp8q_affine_act_minmax_workspace_bytes(N, C, HW)) return FP8Q_EWORKSPACE;
     if (((uintptr_t)x | (uintptr_t)residual) & 15) return FP8Q_EINVAL;
     int64_t bx, by;
     affine_grid(N, a, false, &bx, &by);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_affine_minmax, dim3((unsigned)bx, (unsigned)by), dim3(kBlock), 0, st, x, residual, mean, invstd,
-                       gamma, beta, a, (float *)ws);
+                       gamma, beta, a, N, (float *)ws);
     FoldArgs fa;
     fa.mode = fold_mode;
     fa.first = first != 0;

@@ -31,7 +31,12 @@ def ref_chain(x, bn, res, act):
     return t.astype(np.float32)
 
 
-@pytest.mark.parametrize("shape", [(4, 16, 14, 14), (2, 8, 7, 7), (8, 64, 56, 56), (3, 12, 1, 1), (64, 1000)])
+@pytest.mark.parametrize("shape", [(4, 16, 14, 14), (2, 8, 7, 7), (8, 64, 56, 56), (3, 12, 1, 1), (64, 1000),
+                                   (1, 4, 256, 256),     # planes longer than a piece and than the 32-bit magic range
+                                   (2, 8, 5, 5),         # 16-byte groups that cross planes
+                                   (16, 5000),           # HW = 1: thousands of planes per piece
+                                   (3, 40, 33, 31),      # several pieces per image, ragged last piece
+                                   (70000, 4, 1, 1)])    # more images than gridDim.y allows
 @pytest.mark.parametrize("use_bn,use_res,act", [(True, False, 1), (True, True, 1), (False, True, 1), (True, False, 2),
                                                 (True, False, 0), (False, False, 0)])
 def test_fused_epilogue_bit_exact(shape, use_bn, use_res, act):
@@ -41,6 +46,8 @@ def test_fused_epilogue_bit_exact(shape, use_bn, use_res, act):
     C = shape[1]
     x = (rng.randn(*shape) * 2).astype(np.float32)
     x.reshape(-1)[:3] = [np.nan, np.inf, -0.0]
+    if shape[0] > 65535 and not (use_bn and act == 1 and not use_res):
+        pytest.skip("one combination is enough for the many-images shape")
     bn = None
     if use_bn:
         var = (rng.rand(C) + 0.5).astype(np.float32)
