@@ -24,6 +24,11 @@ if which in ("multi", "fused", "waverow"):
             ops.minmax_quantize(x, 2, 8, 1, out=y)
         else:
             ops.minmax(x, True)
+elif which == "fusedlong":
+    x = (torch.randn(58254, 4608, device=dev) * 0.1)
+    y = torch.empty_like(x)
+    for _ in range(reps):
+        ops.minmax_quantize(x, 2, 8, 1, out=y)
 elif which == "tensor":
     x = torch.randn(1 << 28, device=dev)
     y = torch.empty_like(x)
