@@ -245,6 +245,12 @@ def validate_quantized(a):
     model = QuantArchitectures[a.architecture](pretrained=pretrained, load_type=a.load_type,
                                                model_dir=a.model_dir, **qparams).to(device)
     fp_model = None
+    if synthetic and not pretrained:
+        # random-init weights with the default BN statistics (mean 0, var 1) give degenerate logits (all classes
+        # equal), which makes "argmax agreement with fp32" noise: take the BN statistics from synthetic batches
+        # first, in full precision -- only in this mode, which the reference does not have
+        model.full_precision()
+        reestimate_bn_stats(model, train_loader, 2)
     if synthetic:
         import copy
         fp_model = copy.deepcopy(model).eval()
