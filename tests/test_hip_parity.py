@@ -317,6 +317,52 @@ def test_fused_rows_in_registers(ops, C, inner, M):
     assert_bit_exact(xi.cpu().numpy(), ref, f"fused in place {C}x{inner} M={M}")
 
 
+def test_fuzz_geometries_against_oracle(ops):
+    """Seeded fuzz over the routing space of the per-channel kernels (k_rows_flat / k_rows_reg / k_rows_direct /
+    k_quant_rows / k_quant_scalar): random channel counts, row lengths, formats, sign bits, pointer phases (views
+    that start 0..3 elements into an allocation), in place or not; K1, fused min/max+quantize and the folding
+    min/max, all bit-exact against the oracle."""
+    rng = np.random.RandomState(2024)
+    lengths = [1, 2, 3, 4, 5, 7, 9, 16, 20, 21, 35, 36, 37, 64, 100, 147, 255, 256, 257, 300, 511, 512, 513, 576,
+               1000, 1023, 1024, 1028, 1152, 2044, 2047, 2048, 2049, 2052, 3000, 4096, 4100, 4608, 8192, 8196, 9000]
+    for case in range(160):
+        inner = int(lengths[rng.randint(len(lengths))])
+        C = int(rng.choice([1, 2, 3, 5, 17, 64, 130, 301])) if inner > 600 else int(rng.randint(1, 700))
+        M = int(rng.randint(1, 7))
+        sb = int(rng.rand() < 0.85)
+        off = int(rng.choice([0, 0, 0, 1, 2, 3]))
+        x = (rng.randn(C, inner) * np.exp(rng.uniform(-4, 4, (C, 1)))).astype(np.float32)
+        if sb == 0:
+            x = np.abs(x)
+        if rng.rand() < 0.3 and x.size > 10:
+            x.reshape(-1)[rng.randint(x.size, size=3)] = [0.0, -0.0, np.float32(1e-40)]
+        base = torch.empty(x.size + 4, device="cuda")
+        xd = base[off: off + x.size].view(C, inner)
+        xd.copy_(torch.from_numpy(x))
+        mn, mx = oracle.c_minmax(x, True)
+        mv = oracle.c_absmax(mn, mx)
+        what = f"case {case}: C={C} inner={inner} M={M} sb={sb} off={off}"
+        ref = oracle.c_quantize(x, mv, M, 8, sb)
+        y = ops.quantize(xd, dev(mv), M, 8, sb)
+        assert_bit_exact(y.cpu().numpy(), ref, "K1 " + what)
+        yf, gmn, gmx, gmv = ops.minmax_quantize(xd, M, 8, sb)
+        np.testing.assert_array_equal(gmn.cpu().numpy(), mn, err_msg=what)
+        np.testing.assert_array_equal(gmx.cpu().numpy(), mx, err_msg=what)
+        assert_bit_exact(yf.cpu().numpy(), ref, "fused " + what)
+        if case % 3 == 0:   # in place, through a view with the same phase
+            xi = base.clone()[off: off + x.size].view(C, inner)
+            ops.minmax_quantize(xi, M, 8, sb, out=xi)
+            assert_bit_exact(xi.cpu().numpy(), ref, "fused in place " + what)
+            pmn, pmx = ops.minmax(xd * 0.5, True)
+            fmn, fmx = ops.minmax(xd, True, pmn, pmx, mode=1)
+            rmn, rmx = oracle.c_fold(*oracle.c_minmax(x * np.float32(0.5), True), mn, mx, 1, 0.9)
+            np.testing.assert_array_equal(fmn.cpu().numpy(), rmn, err_msg=what)
+            np.testing.assert_array_equal(fmx.cpu().numpy(), rmx, err_msg=what)
+        one = np.array([np.abs(x).max() + np.float32(0.01)], np.float32)
+        assert_bit_exact(ops.quantize(xd, dev(one), M, 8, sb).cpu().numpy(), oracle.c_quantize(x, one, M, 8, sb),
+                         "per-tensor " + what)
+
+
 def test_multi_tensor_quantize(ops):
     """fp8q_multi_quantize_f32: every weight tensor of a model in one launch, bit-identical to one
     fp8q_quantize_f32 per tensor (and to the oracle); mixed formats, per-tensor entries, tensors that fall back
