@@ -92,6 +92,44 @@ def prequantize_weights(model):
     return len(outs)
 
 
+def export_fp8_weights(model):
+    """{layer name: {codes uint8 [like the weight], maxval [1] or [C], mantissa_bits, sign_bits, n_bits}} for every
+    layer whose weights go through an FP8 quantizer with fixed ranges: the 1-byte storage form of what the layer
+    computes with (the reference only simulates the format; its enumerator
+    fp8_quantizer.py:13-41 defines the byte layout).  decode(codes) == the layer's quantized weight, bit for bit."""
+    import torch
+
+    import fp8q
+    from .fp8 import FPQuantizer
+    from .layers import QuantizationHijacker
+    from .manager import Qstates
+    out = {}
+    for name, m in model.named_modules():
+        if not isinstance(m, QuantizationHijacker) or not getattr(m, "_qw", False):
+            continue
+        if type(m).quantize_weights is not QuantizationHijacker.quantize_weights:
+            continue
+        mgr = m.weight_quantizer
+        q = getattr(mgr, "quantizer", None)
+        if not isinstance(q, FPQuantizer) or mgr.state != Qstates.fix_ranges or q.maxval is None:
+            continue
+        w = m.get_weight_bias()[0].detach()
+        if not w.is_cuda:
+            continue
+        mv = q.maxval.detach().to(device=w.device, dtype=torch.float32).reshape(-1)
+        codes = fp8q.ops.encode(w.contiguous(), mv, float(q.mantissa_bits), int(q.n_bits), int(q.sign_bits))
+        out[name] = dict(codes=codes.cpu(), maxval=mv.cpu(), mantissa_bits=float(q.mantissa_bits),
+                         sign_bits=int(q.sign_bits), n_bits=int(q.n_bits))
+    return out
+
+
+def decode_fp8_weights(exported, device="cuda"):
+    """{layer name: fp32 tensor} from export_fp8_weights(): the values the layers compute with."""
+    import fp8q
+    return {name: fp8q.ops.decode(e["codes"].to(device), e["maxval"].to(device), e["mantissa_bits"], e["n_bits"],
+                                  e["sign_bits"]) for name, e in exported.items()}
+
+
 class GraphedForward:
     """HIP graph of `model(x)` for one input shape.  With FIXED ranges nothing in a quantized forward is decided on
     the host (the engine's entry points only enqueue kernels on the current stream), so the whole forward can be

@@ -95,3 +95,42 @@ def test_hip_codec_nan_and_degenerate():
     codes = ops.encode(dev(x), dev(mv), 3, 8, 1).cpu().numpy()
     np.testing.assert_array_equal(codes, oracle.c_encode(x, mv, 3, 8, 1))
     assert codes[0, 1] == 0 and (codes[1] == 0).all()                  # no NaN code: documented as 0
+
+
+@pytest.mark.gpu
+def test_export_fp8_weights_of_a_model(golden_dir):
+    """Model level: after calibration the weights of every FP8 layer can be exported as 1-byte codes + ranges;
+    decoding them gives exactly the tensors the layers compute with (4x smaller than the fp32 checkpoint)."""
+    import os
+    import torch.nn as nn
+    from quantization.autoquant_utils import quantize_model
+    from quantization.base_quantized_classes import QuantizedModule
+    from quantization.base_quantized_model import export_fp8_weights, decode_fp8_weights
+    from quantization.hijacker import QuantizationHijacker
+    from quantization.quantization_manager import QMethods
+    from quantization.range_estimators import RangeEstimators
+    g7 = np.load(os.path.join(golden_dir, "g7_tinycnn.npz"))
+    net = nn.Sequential(nn.Conv2d(3, 16, 3, padding=1, bias=False), nn.BatchNorm2d(16), nn.ReLU(),
+                        nn.Conv2d(16, 24, 3, stride=2, padding=1, bias=True), nn.ReLU6(),
+                        nn.Conv2d(24, 24, 3, padding=1, groups=24, bias=False), nn.BatchNorm2d(24), nn.ReLU(),
+                        nn.AdaptiveAvgPool2d(1), nn.Flatten(), nn.Linear(24, 10))
+    net.load_state_dict({k[3:]: torch.from_numpy(g7[k]) for k in g7.files if k.startswith("sd_")})
+    q = quantize_model(net.eval(), method=QMethods.fp_quantizer.cls,
+                       weight_range_method=RangeEstimators.current_minmax.cls,
+                       act_range_method=RangeEstimators.allminmax.cls, n_bits=8, per_channel_weights=True,
+                       fp8_kwargs=dict(maxval=None, mantissa_bits=3, set_maxval=True)).eval().cuda()
+    with torch.no_grad():
+        for m in q.modules():
+            if isinstance(m, QuantizedModule):
+                m.quantized()
+        q(torch.from_numpy(g7["calib"]).cuda())
+        for m in q.modules():
+            if isinstance(m, QuantizedModule):
+                m.fix_ranges()
+        exported = export_fp8_weights(q)
+        layers = {n: m for n, m in q.named_modules() if isinstance(m, QuantizationHijacker)}
+        assert set(exported) == set(layers) and len(exported) == 4
+        decoded = decode_fp8_weights(exported)
+        for name, m in layers.items():
+            assert exported[name]["codes"].dtype == torch.uint8 and exported[name]["codes"].shape == m.weight.shape
+            assert torch.equal(decoded[name], m.get_params()[0]), name
