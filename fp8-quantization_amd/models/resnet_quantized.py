@@ -5,7 +5,7 @@ from torch import nn
 from quantization.autoquant_utils import quantize_model, Flattener, QuantizedActivationWrapper
 from quantization.base_quantized_classes import QuantizedActivation, FP32Acts
 from quantization.base_quantized_model import QuantizedModel
-from .resnet import BasicBlock, Bottleneck, resnet18
+from .resnet import BasicBlock, Bottleneck, resnet18, resnet50
 
 
 class QuantizedBlock(QuantizedActivation):
@@ -14,9 +14,13 @@ class QuantizedBlock(QuantizedActivation):
 
     def __init__(self, block, **quant_params):
         super().__init__(**quant_params)
-        if not isinstance(block, BasicBlock):
-            raise NotImplementedError("only BasicBlock (ResNet-18/34) is in scope")
-        body = nn.Sequential(block.conv1, block.bn1, block.relu, block.conv2, block.bn2)
+        if isinstance(block, Bottleneck):
+            body = nn.Sequential(block.conv1, block.bn1, block.relu, block.conv2, block.bn2, block.relu,
+                                 block.conv3, block.bn3)
+        elif isinstance(block, BasicBlock):
+            body = nn.Sequential(block.conv1, block.bn1, block.relu, block.conv2, block.bn2)
+        else:
+            raise NotImplementedError(f"unknown residual block {type(block).__name__}")
         self.features = quantize_model(body, **quant_params)
         self.downsample = quantize_model(block.downsample, **quant_params) if block.downsample else None
         self.relu = block.relu
@@ -85,12 +89,12 @@ class QuantizedResNet(QuantizedModel):
         return self.fc(self.flattener(x))
 
 
-def resnet18_quantized(pretrained=True, model_dir=None, load_type="fp32", **qparams):
-    fp_model = resnet18()
+def _resnet_quantized(builder, what, pretrained, model_dir, load_type, qparams):
+    fp_model = builder()
     if load_type == "fp32":
         if pretrained:
             if not model_dir:
-                raise RuntimeError("pretrained=True needs --model-dir <torchvision resnet18 state dict>: "
+                raise RuntimeError(f"pretrained=True needs --model-dir <torchvision {what} state dict>: "
                                    "there is no network access to download weights")
             fp_model.load_state_dict(torch.load(model_dir, map_location="cpu"))
         return QuantizedResNet(fp_model, **qparams)
@@ -102,5 +106,10 @@ def resnet18_quantized(pretrained=True, model_dir=None, load_type="fp32", **qpar
     raise ValueError("wrong load_type specified")
 
 
-def resnet50_quantized(*args, **kwargs):
-    raise NotImplementedError("ResNet-50 is outside the scope of this build (SURVEY.md section 2)")
+def resnet18_quantized(pretrained=True, model_dir=None, load_type="fp32", **qparams):
+    return _resnet_quantized(resnet18, "resnet18", pretrained, model_dir, load_type, qparams)
+
+
+def resnet50_quantized(pretrained=True, model_dir=None, load_type="fp32", **qparams):
+    """reference models/resnet_quantized.py:153-170"""
+    return _resnet_quantized(resnet50, "resnet50", pretrained, model_dir, load_type, qparams)

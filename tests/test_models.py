@@ -78,8 +78,38 @@ def test_structure_and_fp32_forward_cpu(golden_dir, tag, fixture, n_mgr):
 def test_architecture_registry():
     from models import QuantArchitectures
     assert QuantArchitectures.list_names() == ["mobilenet_v2_quantized", "resnet18_quantized", "resnet50_quantized"]
-    with pytest.raises(NotImplementedError):
-        QuantArchitectures.resnet50_quantized()
+
+
+def test_resnet50_structure():
+    """The registry's third architecture (reference models/resnet_quantized.py:153-170): torchvision's ResNet-50
+    layout (25 557 032 parameters, same state-dict names, so its checkpoints load), Bottleneck blocks wrapped like
+    the reference's QuantizedBlock: 53 fused conv layers + fc, one extra activation quantizer per residual block."""
+    from models.resnet import resnet50
+    from models.resnet_quantized import QuantizedBlock, resnet50_quantized
+    from quantization.hijacker import QuantizationHijacker
+    from quantization.quantization_manager import QMethods
+    from quantization.range_estimators import RangeEstimators
+    fp = resnet50()
+    assert sum(p.numel() for p in fp.parameters()) == 25557032
+    keys = list(fp.state_dict().keys())
+    for k in ("conv1.weight", "layer1.0.conv3.weight", "layer1.0.downsample.1.running_var", "layer4.2.bn3.bias",
+              "fc.weight"):
+        assert k in keys
+    from models.resnet_quantized import QuantizedResNet
+    x = torch.randn(2, 3, 64, 64)
+    with torch.no_grad():
+        ref = fp.eval()(x).numpy()
+    q = QuantizedResNet(fp, method=QMethods.fp_quantizer.cls,
+                        weight_range_method=RangeEstimators.current_minmax.cls,
+                        act_range_method=RangeEstimators.allminmax.cls, n_bits=8, per_channel_weights=True,
+                        fp8_kwargs=dict(maxval=None, mantissa_bits=3, set_maxval=True))
+    assert sum(isinstance(m, QuantizedBlock) for m in q.modules()) == 16
+    assert sum(isinstance(m, QuantizationHijacker) for m in q.modules()) == 54
+    with torch.no_grad():
+        q.full_precision()
+        np.testing.assert_allclose(q.eval()(x).numpy(), ref, rtol=1e-4, atol=1e-4)
+    assert isinstance(resnet50_quantized(pretrained=False, method=QMethods.fp_quantizer.cls,
+                                         fp8_kwargs=dict(mantissa_bits=3)), QuantizedResNet)
 
 
 @pytest.mark.parametrize("tag,fixture", [("r18", "g8_resnet18.npz"), ("mbv2", "g9_mobilenetv2.npz")])
@@ -173,3 +203,27 @@ def test_calibrate_validate_vs_reference(golden_dir, tag, fixture):
     print(f"\n{tag}: weight ranges exact {w_exact / n_w:.4f}; agreeing activation prefix {a_prefix}/{a_total}")
     print(f"\n{tag}: {n_w} weight quantizers; logits mean|diff|/scale = "
           f"{np.mean(np.abs(val_logits - g[f'{tag}_val_logits'])) / np.abs(g[f'{tag}_val_logits']).max():.2e}")
+
+
+@pytest.mark.gpu
+def test_resnet50_quantized_forward_gpu():
+    """ResNet-50 through the FP8 engine: calibrate on one batch, fix ranges, validate; finite logits, every FP8
+    quantizer initialised, fused and unfused epilogues agree closely."""
+    from models import QuantArchitectures
+    from quantization.quantization_manager import QMethods, QuantizationManager
+    from quantization.range_estimators import RangeEstimators
+    torch.manual_seed(0)
+    q = QuantArchitectures.resnet50_quantized(pretrained=False, method=QMethods.fp_quantizer.cls,
+                                              weight_range_method=RangeEstimators.current_minmax.cls,
+                                              act_range_method=RangeEstimators.allminmax.cls, n_bits=8,
+                                              per_channel_weights=True,
+                                              fp8_kwargs=dict(maxval=None, mantissa_bits=3, set_maxval=True)).cuda().eval()
+    x = torch.randn(4, 3, 96, 96, device="cuda")
+    with torch.no_grad():
+        q.set_quant_state(True, True)
+        q(x)
+        q.fix_ranges()
+        y = q(x)
+    assert torch.isfinite(y).all() and y.shape == (4, 1000)
+    mgrs = [m for m in q.modules() if isinstance(m, QuantizationManager)]
+    assert len(mgrs) > 100 and all(m.quantizer.is_initialized for m in mgrs)
