@@ -106,9 +106,10 @@ int fp8q_mse_grid_f32(const float *x, int64_t C, int64_t inner, const float *gri
  * (NCHW, per-channel mean / invstd = 1/sqrt(var+eps) / gamma / beta, all four NULL to skip),
  * + optional residual add, + optional activation (act: 0 none, 1 ReLU, 2 ReLU6), then the
  * per-tensor FP8 quantizer -- BNFusedHijacker.forward, quantization/quantized_folded_bn.py:39-55,
- * and the residual tail of models/resnet_quantized.py:43-46, in one pass (8 B / element).
+ * and the residual tail of models/resnet_quantized.py:43-46, in one pass (8 B / element, 12 with a residual).
  * The _minmax twin produces the range of the same pre-quantization tensor for calibration
- * (same fold semantics as fp8q_minmax_f32).  x, residual, y: [N, C, HW] fp32, 16-byte aligned;
+ * (same fold semantics as fp8q_minmax_f32; ws of at least fp8q_affine_act_minmax_workspace_bytes(N, C, HW)
+ * bytes).  x, residual, y: [N, C, HW] fp32, 16-byte aligned;
  * C*HW must be a multiple of 4 (FP8Q_EUNSUPPORTED otherwise: use the unfused calls).
  */
 int fp8q_affine_act_quantize_f32(const float *x, const float *residual, float *y, int64_t N, int64_t C,
