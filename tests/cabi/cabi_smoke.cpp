@@ -1,0 +1,128 @@
+// cabi_smoke.cpp -- the drop-in boundary used the way a non-Python host would use it: plain HIP runtime
+// calls for memory, plain pointers and sizes into libfp8q_hip.so (include/fp8q.h), no torch anywhere.
+// Checks K1, the fused min/max+quantize, the folding min/max and the multi-tensor call against the CPU
+// oracle (libfp8q_oracle.so, test infrastructure) bit for bit.  Built by tests/test_cabi_and_host.py
+// (hipcc cross-compiles it on the CPU box); run by the -m gpu test of the same file.
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/fp8q.h"
+
+extern "C" {
+int orc_quantize_f32(const float *x, float *y, int64_t C, int64_t inner, const float *maxval, int64_t n_maxval,
+                     float mbits, int n_bits, int sign_bits);
+int orc_minmax_f32(const float *x, int64_t C, int64_t inner, float *mn, float *mx);
+int orc_absmax_f32(const float *mn, const float *mx, int64_t C, float *maxval);
+}
+
+#define CK(x) do { int e_ = (int)(x); if (e_ != 0) { printf("FAIL %s -> %d (%s) at line %d\n", #x, e_, fp8q_strerror(e_), __LINE__); return 1; } } while (0)
+
+static int same_bits(const float *a, const float *b, size_t n, const char *what)
+{
+    for (size_t i = 0; i < n; ++i) {
+        uint32_t ua, ub;
+        memcpy(&ua, a + i, 4);
+        memcpy(&ub, b + i, 4);
+        const int nan_a = a[i] != a[i], nan_b = b[i] != b[i];
+        if (nan_a != nan_b || (!nan_a && ua != ub)) {
+            printf("FAIL %s: element %zu: %a vs %a\n", what, i, a[i], b[i]);
+            return 0;
+        }
+    }
+    printf("ok   %s (%zu elements bit-identical)\n", what, n);
+    return 1;
+}
+
+int main()
+{
+    const int64_t C = 300, inner = 147, n = C * inner;
+    float *x = (float *)malloc(n * 4), *y = (float *)malloc(n * 4), *ref = (float *)malloc(n * 4);
+    float mn[300], mx[300], mv[300], gmn[300], gmx[300], gmv[300];
+    uint32_t s = 12345u;
+    for (int64_t i = 0; i < n; ++i) {   // LCG, two uniforms -> roughly bell-shaped, scaled per row
+        s = s * 1664525u + 1013904223u;
+        const float u1 = (float)(s >> 8) / 16777216.0f;
+        s = s * 1664525u + 1013904223u;
+        const float u2 = (float)(s >> 8) / 16777216.0f;
+        x[i] = (u1 + u2 - 1.0f) * (0.05f + 0.01f * (float)(i / inner % 17));
+    }
+    x[5] = 0.0f;
+    x[6] = -0.0f;
+    orc_minmax_f32(x, C, inner, mn, mx);
+    orc_absmax_f32(mn, mx, C, mv);
+
+    float *dx, *dy, *dmv, *dmn, *dmx, *dmvo;
+    void *ws;
+    CK(hipMalloc((void **)&dx, n * 4));
+    CK(hipMalloc((void **)&dy, n * 4));
+    CK(hipMalloc((void **)&dmv, C * 4));
+    CK(hipMalloc((void **)&dmn, C * 4));
+    CK(hipMalloc((void **)&dmx, C * 4));
+    CK(hipMalloc((void **)&dmvo, C * 4));
+    const size_t wsb = fp8q_minmax_workspace_bytes(C, inner);
+    CK(hipMalloc(&ws, wsb));
+    CK(hipMemcpy(dx, x, n * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dmv, mv, C * 4, hipMemcpyHostToDevice));
+    hipStream_t st;
+    CK(hipStreamCreate(&st));
+    int ok = 1;
+    printf("libfp8q version %d\n", fp8q_version());
+
+    for (int M = 2; M <= 4; ++M) {   // K1, per-channel fixed ranges
+        CK(fp8q_quantize_f32(dx, dy, C, inner, dmv, C, (float)M, 8, 1, st));
+        CK(hipStreamSynchronize(st));
+        CK(hipMemcpy(y, dy, n * 4, hipMemcpyDeviceToHost));
+        orc_quantize_f32(x, ref, C, inner, mv, C, (float)M, 8, 1);
+        char what[64];
+        snprintf(what, sizeof what, "fp8q_quantize_f32 per-channel M=%d", M);
+        ok &= same_bits(y, ref, n, what);
+    }
+    // fused min/max + quantize
+    CK(fp8q_minmax_quantize_f32(dx, dy, C, inner, dmn, dmx, dmvo, 2.0f, 8, 1, st));
+    CK(hipStreamSynchronize(st));
+    CK(hipMemcpy(y, dy, n * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(gmn, dmn, C * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(gmx, dmx, C * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(gmv, dmvo, C * 4, hipMemcpyDeviceToHost));
+    orc_quantize_f32(x, ref, C, inner, mv, C, 2.0f, 8, 1);
+    ok &= same_bits(y, ref, n, "fp8q_minmax_quantize_f32 values");
+    ok &= same_bits(gmn, mn, C, "fp8q_minmax_quantize_f32 row_min");
+    ok &= same_bits(gmx, mx, C, "fp8q_minmax_quantize_f32 row_max");
+    ok &= same_bits(gmv, mv, C, "fp8q_minmax_quantize_f32 maxval");
+    // per-tensor min/max with the split kernels + workspace, then per-tensor K1
+    float tmn, tmx, tmv, rmn, rmx, rmv;
+    CK(fp8q_minmax_f32(dx, 1, n, dmn, dmx, dmvo, FP8Q_FOLD_CURRENT, 0.9, 1, ws, fp8q_minmax_workspace_bytes(1, n), st));
+    CK(hipStreamSynchronize(st));
+    CK(hipMemcpy(&tmn, dmn, 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(&tmx, dmx, 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(&tmv, dmvo, 4, hipMemcpyDeviceToHost));
+    orc_minmax_f32(x, 1, n, &rmn, &rmx);
+    orc_absmax_f32(&rmn, &rmx, 1, &rmv);
+    ok &= same_bits(&tmn, &rmn, 1, "fp8q_minmax_f32 per-tensor min");
+    ok &= same_bits(&tmx, &rmx, 1, "fp8q_minmax_f32 per-tensor max");
+    ok &= same_bits(&tmv, &rmv, 1, "fp8q_minmax_f32 per-tensor maxval");
+    CK(fp8q_quantize_f32(dx, dy, C, inner, dmvo, 1, 3.0f, 8, 1, st));
+    CK(hipStreamSynchronize(st));
+    CK(hipMemcpy(y, dy, n * 4, hipMemcpyDeviceToHost));
+    orc_quantize_f32(x, ref, C, inner, &rmv, 1, 3.0f, 8, 1);
+    ok &= same_bits(y, ref, n, "fp8q_quantize_f32 per-tensor M=3");
+    // multi-tensor: the same buffer as two tensors with different formats
+    fp8q_tensor_desc d[2];
+    const int64_t C0 = 100, C1 = C - C0;
+    d[0] = fp8q_tensor_desc{dx, dy, dmv, C0, inner, C0, 2.0f, 8, 1};
+    d[1] = fp8q_tensor_desc{dx + C0 * inner, dy + C0 * inner, dmv + C0, C1, inner, C1, 4.0f, 8, 1};
+    CK(fp8q_multi_quantize_f32(d, 2, st));
+    CK(hipStreamSynchronize(st));
+    CK(hipMemcpy(y, dy, n * 4, hipMemcpyDeviceToHost));
+    orc_quantize_f32(x, ref, C0, inner, mv, C0, 2.0f, 8, 1);
+    orc_quantize_f32(x + C0 * inner, ref + C0 * inner, C1, inner, mv + C0, C1, 4.0f, 8, 1);
+    ok &= same_bits(y, ref, n, "fp8q_multi_quantize_f32 (2 tensors, E5M2 + E3M4)");
+    // error behaviour: bad arguments are reported, nothing throws
+    if (fp8q_quantize_f32(dx, dy, C, inner, dmv, C - 1, 2.0f, 8, 1, st) != FP8Q_EINVAL) { printf("FAIL: EINVAL expected\n"); ok = 0; }
+    if (fp8q_quantize_f32(dx, dy, C, inner, dmv, C, 0.0f, 16, 1, st) != FP8Q_EUNSUPPORTED) { printf("FAIL: EUNSUPPORTED expected\n"); ok = 0; }
+    printf(ok ? "CABI SMOKE PASSED\n" : "CABI SMOKE FAILED\n");
+    return ok ? 0 : 1;
+}
