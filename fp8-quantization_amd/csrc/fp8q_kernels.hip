@@ -671,18 +671,17 @@ k_multi_flat(MultiArgs a)
 // ---------------------------------------------------------------------------------------------
 // Fused K2+K5+K1 for rows of 257..8192 elements (a multiple of 4, 16-byte aligned): the row stays in
 // REGISTERS between the min/max pass and the quantize pass, so the tensor is read once (8 B/element of
-// HBM traffic for real).  WPR = 1: one wave per row (4 rows per block, rows <= 2048 elements);
-// WPR = 4: the whole block per row.  Rows are handed out grid-stride, so concurrently running blocks
+// HBM traffic for real).  L lanes per row: 16 or 32 (16 / 8 rows per block), 64 (one wave per row) or 256
+// (the whole block per row); the host picks the L whose lanes are best filled.  Rows are handed out grid-stride, so concurrently running blocks
 // work on neighbouring rows -- the access pattern of a copy.  Per row: EPT x 16 B per lane in flight,
 // wave (+ LDS) min/max reduction, the row's {s, 1/s} table written by its own lanes, quantize, store.
 // ---------------------------------------------------------------------------------------------
-template <int WPR, int EPT, bool NT>
+template <int L, int EPT, bool NT>
 __global__ void __launch_bounds__(kBlock)
 k_rows_reg(const float *__restrict__ x, float *__restrict__ y, int64_t C, int inner, float *row_min,
            float *row_max, float *maxval_out, QFmt f)
 {
-    constexpr int L = 64 * WPR;          // lanes per row
-    constexpr int RPB = 4 / WPR;         // rows per block and step
+    constexpr int RPB = kBlock / L;      // rows per block and step (L = lanes per row: 16, 32, 64 or 256)
     __shared__ float2 lut[RPB][kLutMax];
     __shared__ double ftab[kFastTabSize];
     __shared__ float s_mn[4], s_mx[4];
@@ -713,8 +712,13 @@ k_rows_reg(const float *__restrict__ x, float *__restrict__ y, int64_t C, int in
                 mm_acc(m, v[k].w);
             }
         }
-        mm_wave_reduce(m);
-        if (WPR == 4) {
+#pragma unroll
+        for (int off = (L < 64 ? L : 64) >> 1; off >= 1; off >>= 1) {
+            m.mn = fminf(m.mn, __shfl_xor(m.mn, off, 64));
+            m.mx = fmaxf(m.mx, __shfl_xor(m.mx, off, 64));
+            m.nan |= __shfl_xor(m.nan, off, 64);
+        }
+        if (L == 256) {
             if ((tid & 63) == 0) {
                 s_mn[wave] = m.mn;
                 s_mx[wave] = m.mx;
@@ -1629,39 +1633,52 @@ int fp8q_minmax_quantize_f32(const float *x, float *y, int64_t C, int64_t inner,
         const char *e = getenv("FP8Q_FUSED_REG");
         return e ? atoi(e) : 1;
     }();
-    const int64_t reg_lanes = inner <= 2048 ? 64 : 256;
-    const int64_t reg_ept = cdiv(inner >> 2, reg_lanes);
-    const int64_t reg_slots = (reg_ept <= 4 ? reg_ept : (reg_ept <= 6 ? 6 : 8)) * reg_lanes;   // instantiated EPT
-    if (reg_env && inner > kFlatFusedMaxInner && inner <= 8192 && (inner & 3) == 0 &&
-        (inner >> 2) * 100 >= reg_slots * (inner >= 1024 ? 70 : 95) &&   // lanes' slots that hold data (short rows:
-                                                                         // the per-row work only pays when full)
+    // lanes per row and 16-byte slots per lane (EPT, instantiated for 2..8): pick the widest row group whose lanes
+    // are well filled -- rows of 576 elements run 8 per block on 32 lanes x 5 slots (90 % filled)
+    int reg_lanes = 0, reg_ept = 0;
+    if (reg_env && inner >= 128 && inner <= 8192 && (inner & 3) == 0 &&
         (((uintptr_t)x | (uintptr_t)y) & 15) == 0) {
-        // rows held in registers: one wave per row up to 2048 elements, one block per row above
+        const int64_t nvec = inner >> 2;
+        int64_t best = 0;
+        for (int lanes : {16, 32, 64, 256}) {
+            const int64_t ept = cdiv(nvec, lanes);
+            if (ept < 2 || ept > 8) continue;
+            const int64_t fill = nvec * 1000 / (ept * lanes);
+            if (fill > best) {
+                best = fill;
+                reg_lanes = lanes;
+                reg_ept = (int)ept;
+            }
+        }
+        if (best < 800) reg_lanes = 0;
+    }
+    if (reg_lanes) {
         const bool nt = C * inner * 4 >= kNtBytes;
-        const int nvec = (int)(inner >> 2);
-        const int wpr = inner <= 2048 ? 1 : 4;
-        const int ept = (int)cdiv(nvec, 64 * wpr);           // 2..8
-        const int64_t steps = cdiv(C, 4 / wpr);
+        const int64_t steps = cdiv(C, kBlock / reg_lanes);
         const int64_t grid = balanced_blocks(steps, 65536);
         const dim3 g((unsigned)grid), b(kBlock);
-#define FP8Q_LAUNCH_REG(W, E)                                                                                   \
-    do {                                                                                                        \
-        if (nt) hipLaunchKernelGGL((k_rows_reg<W, E, true>), g, b, 0, st, x, y, C, (int)inner, row_min, row_max, \
-                                   maxval_out, f);                                                              \
-        else hipLaunchKernelGGL((k_rows_reg<W, E, false>), g, b, 0, st, x, y, C, (int)inner, row_min, row_max,   \
-                                maxval_out, f);                                                                 \
+#define FP8Q_LAUNCH_REG(LN, E)                                                                                   \
+    do {                                                                                                         \
+        if (nt) hipLaunchKernelGGL((k_rows_reg<LN, E, true>), g, b, 0, st, x, y, C, (int)inner, row_min, row_max, \
+                                   maxval_out, f);                                                               \
+        else hipLaunchKernelGGL((k_rows_reg<LN, E, false>), g, b, 0, st, x, y, C, (int)inner, row_min, row_max,   \
+                                maxval_out, f);                                                                  \
     } while (0)
-        if (wpr == 1) {
-            if (ept <= 2) FP8Q_LAUNCH_REG(1, 2);
-            else if (ept <= 3) FP8Q_LAUNCH_REG(1, 3);
-            else if (ept <= 4) FP8Q_LAUNCH_REG(1, 4);
-            else if (ept <= 6) FP8Q_LAUNCH_REG(1, 6);
-            else FP8Q_LAUNCH_REG(1, 8);
-        } else {
-            if (ept <= 4) FP8Q_LAUNCH_REG(4, 4);
-            else if (ept <= 6) FP8Q_LAUNCH_REG(4, 6);
-            else FP8Q_LAUNCH_REG(4, 8);
-        }
+#define FP8Q_LAUNCH_REG_E(LN)                                  \
+    switch (reg_ept) {                                         \
+        case 2: FP8Q_LAUNCH_REG(LN, 2); break;                 \
+        case 3: FP8Q_LAUNCH_REG(LN, 3); break;                 \
+        case 4: FP8Q_LAUNCH_REG(LN, 4); break;                 \
+        case 5: FP8Q_LAUNCH_REG(LN, 5); break;                 \
+        case 6: FP8Q_LAUNCH_REG(LN, 6); break;                 \
+        case 7: FP8Q_LAUNCH_REG(LN, 7); break;                 \
+        default: FP8Q_LAUNCH_REG(LN, 8); break;                \
+    }
+        if (reg_lanes == 16) { FP8Q_LAUNCH_REG_E(16) }
+        else if (reg_lanes == 32) { FP8Q_LAUNCH_REG_E(32) }
+        else if (reg_lanes == 64) { FP8Q_LAUNCH_REG_E(64) }
+        else { FP8Q_LAUNCH_REG_E(256) }
+#undef FP8Q_LAUNCH_REG_E
 #undef FP8Q_LAUNCH_REG
         return launch_rc();
     }

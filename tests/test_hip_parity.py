@@ -292,7 +292,8 @@ def test_flat_short_row_kernel_geometries(ops, C, inner, M):
 
 
 @pytest.mark.parametrize("C,inner", [(9, 512), (33, 1024), (7, 1152), (5, 2048), (6, 2052), (3, 4608), (5, 8192),
-                                     (2, 8196), (13, 576), (4, 260), (1, 1024), (257, 1280)])
+                                     (2, 8196), (13, 576), (4, 260), (1, 1024), (257, 1280), (50, 128), (35, 192),
+                                     (19, 288), (70, 384), (3, 7168), (17, 124)])
 @pytest.mark.parametrize("M", [2, 4])
 def test_fused_rows_in_registers(ops, C, inner, M):
     """k_rows_reg (rows of 257..8192 elements held in registers between the min/max and the quantize pass): one
@@ -323,9 +324,10 @@ def test_fuzz_geometries_against_oracle(ops):
     that start 0..3 elements into an allocation), in place or not; K1, fused min/max+quantize and the folding
     min/max, all bit-exact against the oracle."""
     rng = np.random.RandomState(2024)
-    lengths = [1, 2, 3, 4, 5, 7, 9, 16, 20, 21, 35, 36, 37, 64, 100, 147, 255, 256, 257, 300, 511, 512, 513, 576,
+    lengths = [1, 2, 3, 4, 5, 7, 9, 16, 20, 21, 35, 36, 37, 64, 100, 124, 128, 132, 147, 192, 255, 256, 257, 288, 300,
+               384, 388, 448, 511, 512, 513, 576, 640, 896,
                1000, 1023, 1024, 1028, 1152, 2044, 2047, 2048, 2049, 2052, 3000, 4096, 4100, 4608, 8192, 8196, 9000]
-    for case in range(160):
+    for case in range(200):
         inner = int(lengths[rng.randint(len(lengths))])
         C = int(rng.choice([1, 2, 3, 5, 17, 64, 130, 301])) if inner > 600 else int(rng.randint(1, 700))
         M = int(rng.randint(1, 7))

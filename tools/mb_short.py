@@ -22,7 +22,7 @@ mv6 = torch.rand(x6.shape[0], device=dev) + 0.5
 report(f"[{tag}] K1 [2^19,64,3,3] E5M2", x6.numel(), 8, timeit(lambda: ops.quantize(x6, mv6, 2, 8, 1, out=y6)))
 report(f"[{tag}] fused [2^19,64,3,3] E5M2", x6.numel(), 8, timeit(lambda: ops.minmax_quantize(x6, 2, 8, 1, out=y6)))
 
-for rows, inner in ((1 << 19, 288), (1 << 19, 512), (1 << 18, 1024), (1 << 18, 1152), (58254, 4608), (1 << 17, 2048), (32768, 8192)):
+for rows, inner in ((1 << 21, 128), (1 << 20, 192), (1 << 20, 256), (1 << 19, 384), (1 << 19, 288), (1 << 19, 512), (1 << 18, 1024), (1 << 18, 1152), (58254, 4608), (1 << 17, 2048), (32768, 8192)):
     xk = xw.view(-1)[: rows * inner].view(rows, inner)
     yk = yw.view(-1)[: rows * inner].view(rows, inner)
     mvk = torch.rand(rows, device=dev) + 0.5
