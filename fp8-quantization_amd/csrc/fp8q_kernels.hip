@@ -676,10 +676,10 @@ k_multi_flat(MultiArgs a)
 // work on neighbouring rows -- the access pattern of a copy.  Per row: EPT x 16 B per lane in flight,
 // wave (+ LDS) min/max reduction, the row's {s, 1/s} table written by its own lanes, quantize, store.
 // ---------------------------------------------------------------------------------------------
-template <int L, int EPT, bool NT>
+template <int L, int EPT, bool NT, bool QUANT>
 __global__ void __launch_bounds__(kBlock)
 k_rows_reg(const float *__restrict__ x, float *__restrict__ y, int64_t C, int inner, float *row_min,
-           float *row_max, float *maxval_out, QFmt f)
+           float *row_max, float *maxval_out, QFmt f, FoldArgs fa)
 {
     constexpr int RPB = kBlock / L;      // rows per block and step (L = lanes per row: 16, 32, 64 or 256)
     __shared__ float2 lut[RPB][kLutMax];
@@ -689,8 +689,10 @@ k_rows_reg(const float *__restrict__ x, float *__restrict__ y, int64_t C, int in
     const int tid = threadIdx.x, sub = tid % L, rslot = tid / L, wave = tid >> 6;
     const int nvec = inner >> 2;
     const float pmaxf = (float)f.pmax;
-    for (int i = tid; i < kFastTabSize; i += kBlock) ftab[i] = kFastTab[i];
-    __syncthreads();
+    if (QUANT) {
+        for (int i = tid; i < kFastTabSize; i += kBlock) ftab[i] = kFastTab[i];
+        __syncthreads();
+    }
     for (int64_t r0 = (int64_t)blockIdx.x * RPB; r0 < C; r0 += (int64_t)gridDim.x * RPB) {
         const int64_t row = r0 + rslot;
         const bool valid = row < C;
@@ -730,6 +732,11 @@ k_rows_reg(const float *__restrict__ x, float *__restrict__ y, int64_t C, int in
             m.nan = s_nan[0] | s_nan[1] | s_nan[2] | s_nan[3];
         }
         if (m.nan) m.mn = m.mx = __builtin_nanf("");
+        if (!QUANT) {   // K2: fold into the running estimate and go on (no tables, no stores)
+            if (valid && sub == 0) fold_store(m.mn, m.mx, row, row_min, row_max, maxval_out, fa);
+            if (L == 256) __syncthreads();   // s_mn / s_mx are rewritten by the next step
+            continue;
+        }
         const float mv = fabsf(tmax(fabsf(m.mn), m.mx));   // fp8_quantizer.py:236
         if (valid && sub == 0) {
             if (row_min) row_min[row] = m.mn;
@@ -1414,6 +1421,67 @@ int launch_rows_flat(int mode, const float *x, float *y, int64_t C, int64_t inne
     return launch_rc();
 }
 
+// k_rows_reg for [C, inner] if the rows suit it (128..8192 elements, a multiple of 4, 16-byte aligned, lanes well
+// filled); kNotFlat otherwise.  quant: fused min/max + quantize; else K2 (min/max + fold).
+int launch_rows_reg(bool quant, const float *x, float *y, int64_t C, int64_t inner, float *row_min, float *row_max,
+                    float *maxval_out, const QFmt &f, const FoldArgs &fa, hipStream_t st)
+{
+    static const int reg_env = [] {   // FP8Q_FUSED_REG=0: never (A/B against the row-tiled kernels)
+        const char *e = getenv("FP8Q_FUSED_REG");
+        return e ? atoi(e) : 1;
+    }();
+    if (!reg_env || inner < 128 || inner > 8192 || (inner & 3) != 0 || (((uintptr_t)x | (uintptr_t)y) & 15) != 0)
+        return kNotFlat;
+    // lanes per row and 16-byte slots per lane (EPT, instantiated for 2..8): the best-filled combination --
+    // rows of 576 elements run 8 per block on 32 lanes x 5 slots (90 % filled)
+    int reg_lanes = 0, reg_ept = 0;
+    const int64_t nvec = inner >> 2;
+    int64_t best = 0;
+    for (int lanes : {16, 32, 64, 256}) {
+        const int64_t ept = cdiv(nvec, lanes);
+        if (ept < 2 || ept > 8) continue;
+        const int64_t fill = nvec * 1000 / (ept * lanes);
+        if (fill > best) {
+            best = fill;
+            reg_lanes = lanes;
+            reg_ept = (int)ept;
+        }
+    }
+    if (best < 800) return kNotFlat;
+    const bool nt = C * inner * 4 >= kNtBytes;
+    const int64_t steps = cdiv(C, kBlock / reg_lanes);
+    const int64_t grid = balanced_blocks(steps, 65536);
+    const dim3 g((unsigned)grid), b(kBlock);
+#define FP8Q_LAUNCH_REG(LN, E)                                                                                       \
+    do {                                                                                                             \
+        if (quant && nt) hipLaunchKernelGGL((k_rows_reg<LN, E, true, true>), g, b, 0, st, x, y, C, (int)inner,      \
+                                            row_min, row_max, maxval_out, f, fa);                                    \
+        else if (quant) hipLaunchKernelGGL((k_rows_reg<LN, E, false, true>), g, b, 0, st, x, y, C, (int)inner,      \
+                                           row_min, row_max, maxval_out, f, fa);                                     \
+        else if (nt) hipLaunchKernelGGL((k_rows_reg<LN, E, true, false>), g, b, 0, st, x, y, C, (int)inner,         \
+                                        row_min, row_max, maxval_out, f, fa);                                        \
+        else hipLaunchKernelGGL((k_rows_reg<LN, E, false, false>), g, b, 0, st, x, y, C, (int)inner, row_min,        \
+                                row_max, maxval_out, f, fa);                                                         \
+    } while (0)
+#define FP8Q_LAUNCH_REG_E(LN)                                  \
+    switch (reg_ept) {                                         \
+        case 2: FP8Q_LAUNCH_REG(LN, 2); break;                 \
+        case 3: FP8Q_LAUNCH_REG(LN, 3); break;                 \
+        case 4: FP8Q_LAUNCH_REG(LN, 4); break;                 \
+        case 5: FP8Q_LAUNCH_REG(LN, 5); break;                 \
+        case 6: FP8Q_LAUNCH_REG(LN, 6); break;                 \
+        case 7: FP8Q_LAUNCH_REG(LN, 7); break;                 \
+        default: FP8Q_LAUNCH_REG(LN, 8); break;                \
+    }
+    if (reg_lanes == 16) { FP8Q_LAUNCH_REG_E(16) }
+    else if (reg_lanes == 32) { FP8Q_LAUNCH_REG_E(32) }
+    else if (reg_lanes == 64) { FP8Q_LAUNCH_REG_E(64) }
+    else { FP8Q_LAUNCH_REG_E(256) }
+#undef FP8Q_LAUNCH_REG_E
+#undef FP8Q_LAUNCH_REG
+    return launch_rc();
+}
+
 // Launch k_rows_direct for [C, inner], inner <= kDirectMaxInner (any 4-byte aligned pointers).
 int launch_rows_direct(int mode, const float *x, float *y, int64_t C, int64_t inner, const float *maxval,
                        float *row_min, float *row_max, float *maxval_out, const QFmt &f,
@@ -1589,6 +1657,11 @@ int fp8q_minmax_f32(const float *x, int64_t C, int64_t inner, float *cur_min, fl
     fa.first = first != 0;
     fa.om = (float)(1.0 - momentum);
     fa.mo = (float)momentum;
+    if (C > 1) {   // per-channel rows of 128..8192 elements: one launch, the row in registers
+        QFmt f = {};
+        const int rc = launch_rows_reg(false, x, nullptr, C, inner, cur_min, cur_max, maxval_out, f, fa, st);
+        if (rc != kNotFlat) return rc;
+    }
     if (inner <= direct_max_inner() && C > 1 && ((uintptr_t)x & 3) == 0) {
         QFmt f = {};
         return launch_rows_direct(kModeMinMax, x, nullptr, C, inner, nullptr, cur_min, cur_max, maxval_out,
@@ -1629,58 +1702,10 @@ int fp8q_minmax_quantize_f32(const float *x, float *y, int64_t C, int64_t inner,
     if (inner > kDirectMaxInner) return FP8Q_EUNSUPPORTED;
     if (((uintptr_t)x & 3) != 0 || ((uintptr_t)y & 3) != 0) return FP8Q_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    static const int reg_env = [] {   // FP8Q_FUSED_REG=0: row-tiled kernel for every row length (A/B)
-        const char *e = getenv("FP8Q_FUSED_REG");
-        return e ? atoi(e) : 1;
-    }();
-    // lanes per row and 16-byte slots per lane (EPT, instantiated for 2..8): pick the widest row group whose lanes
-    // are well filled -- rows of 576 elements run 8 per block on 32 lanes x 5 slots (90 % filled)
-    int reg_lanes = 0, reg_ept = 0;
-    if (reg_env && inner >= 128 && inner <= 8192 && (inner & 3) == 0 &&
-        (((uintptr_t)x | (uintptr_t)y) & 15) == 0) {
-        const int64_t nvec = inner >> 2;
-        int64_t best = 0;
-        for (int lanes : {16, 32, 64, 256}) {
-            const int64_t ept = cdiv(nvec, lanes);
-            if (ept < 2 || ept > 8) continue;
-            const int64_t fill = nvec * 1000 / (ept * lanes);
-            if (fill > best) {
-                best = fill;
-                reg_lanes = lanes;
-                reg_ept = (int)ept;
-            }
-        }
-        if (best < 800) reg_lanes = 0;
-    }
-    if (reg_lanes) {
-        const bool nt = C * inner * 4 >= kNtBytes;
-        const int64_t steps = cdiv(C, kBlock / reg_lanes);
-        const int64_t grid = balanced_blocks(steps, 65536);
-        const dim3 g((unsigned)grid), b(kBlock);
-#define FP8Q_LAUNCH_REG(LN, E)                                                                                   \
-    do {                                                                                                         \
-        if (nt) hipLaunchKernelGGL((k_rows_reg<LN, E, true>), g, b, 0, st, x, y, C, (int)inner, row_min, row_max, \
-                                   maxval_out, f);                                                               \
-        else hipLaunchKernelGGL((k_rows_reg<LN, E, false>), g, b, 0, st, x, y, C, (int)inner, row_min, row_max,   \
-                                maxval_out, f);                                                                  \
-    } while (0)
-#define FP8Q_LAUNCH_REG_E(LN)                                  \
-    switch (reg_ept) {                                         \
-        case 2: FP8Q_LAUNCH_REG(LN, 2); break;                 \
-        case 3: FP8Q_LAUNCH_REG(LN, 3); break;                 \
-        case 4: FP8Q_LAUNCH_REG(LN, 4); break;                 \
-        case 5: FP8Q_LAUNCH_REG(LN, 5); break;                 \
-        case 6: FP8Q_LAUNCH_REG(LN, 6); break;                 \
-        case 7: FP8Q_LAUNCH_REG(LN, 7); break;                 \
-        default: FP8Q_LAUNCH_REG(LN, 8); break;                \
-    }
-        if (reg_lanes == 16) { FP8Q_LAUNCH_REG_E(16) }
-        else if (reg_lanes == 32) { FP8Q_LAUNCH_REG_E(32) }
-        else if (reg_lanes == 64) { FP8Q_LAUNCH_REG_E(64) }
-        else { FP8Q_LAUNCH_REG_E(256) }
-#undef FP8Q_LAUNCH_REG_E
-#undef FP8Q_LAUNCH_REG
-        return launch_rc();
+    {
+        const FoldArgs nofold = {0, 1, 0.0f, 0.0f};
+        const int rc = launch_rows_reg(true, x, y, C, inner, row_min, row_max, maxval_out, f, nofold, st);
+        if (rc != kNotFlat) return rc;
     }
     const FoldArgs nofold = {0, 1, 0.0f, 0.0f};
     return launch_rows_direct(kModeFused, x, y, C, inner, nullptr, row_min, row_max, maxval_out, f, nofold, st);

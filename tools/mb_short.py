@@ -28,3 +28,4 @@ for rows, inner in ((1 << 21, 128), (1 << 20, 192), (1 << 20, 256), (1 << 19, 38
     mvk = torch.rand(rows, device=dev) + 0.5
     report(f"[{tag}] K1 [{rows},{inner}] E5M2", xk.numel(), 8, timeit(lambda: ops.quantize(xk, mvk, 2, 8, 1, out=yk)))
     report(f"[{tag}] fused [{rows},{inner}] E5M2", xk.numel(), 8, timeit(lambda: ops.minmax_quantize(xk, 2, 8, 1, out=yk)))
+    report(f"[{tag}] K2min/max [{rows},{inner}]", xk.numel(), 4, timeit(lambda: ops.minmax(xk, True)))
