@@ -139,6 +139,10 @@ __device__ __forceinline__ void stage_fast_tab(double *dst)
 // correctly rounded fp32 value of 2^(fl32((ls - M) - bias)); ls is an integer-valued float
 __device__ __forceinline__ float scale_exact(const Chan &c, float ls, float M)
 {
+    // degenerate channel (maxval 0 / inf / NaN or negative -> bias +inf / -inf / NaN): 2^(k - bias) as the reference
+    // chain evaluates it (0, inf, NaN).  K1 is NaN there either way; the decoder's value of such a channel follows.
+    if (__builtin_expect(!(fabsf(c.bias) < __builtin_inff()), 0))
+        return c.bias != c.bias ? c.bias : (c.bias > 0.0f ? 0.0f : __builtin_inff());
     const float k = ls - M;                         // exact
     const float e = k - c.bias;                     // the reference's fp32 rounding
     const double d = (double)k - c.bias_d;          // exact k - bias

@@ -881,9 +881,12 @@ k_minmax_final(const float *__restrict__ ws, int64_t C, int nsplit, float *cur_m
     MinMax m;
     mm_init(m);
     for (int s = lane; s < nsplit; s += 64) {
+        // {min, max} of one split; an EMPTY split (a row a few elements longer than a whole number of steps) holds
+        // {+inf, -inf}, so the two halves must not be mixed
         const float2 ab = *reinterpret_cast<const float2 *>(ws + (row * nsplit + s) * 2);
-        mm_acc(m, ab.x);
-        mm_acc(m, ab.y);
+        m.nan |= (ab.x != ab.x) | (ab.y != ab.y);
+        m.mn = fminf(m.mn, ab.x);
+        m.mx = fmaxf(m.mx, ab.y);
     }
     mm_wave_reduce(m);
     if (lane == 0) {
@@ -919,8 +922,9 @@ k_minmax_final_block(const float *__restrict__ ws, int nsplit, float *cur_min, f
     }
     for (int s2 = tid + 8 * kBlock; s2 < nsplit; s2 += kBlock) {
         const float2 ab = w[s2];
-        mm_acc(m, ab.x);
-        mm_acc(m, ab.y);
+        m.nan |= (ab.x != ab.x) | (ab.y != ab.y);
+        m.mn = fminf(m.mn, ab.x);
+        m.mx = fmaxf(m.mx, ab.y);
     }
     mm_wave_reduce(m);
     if ((tid & 63) == 0) {

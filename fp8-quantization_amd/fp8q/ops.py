@@ -238,7 +238,9 @@ def encode(x, maxval, mbits, n_bits=8, sign_bits=1, out=None):
 
 
 def decode(codes, maxval, mbits, n_bits=8, sign_bits=1, out=None):
-    """N3: fp32 values of uint8 storage codes; decode(encode(x)) == quantize(x) bit for bit."""
+    """N3: fp32 values of uint8 storage codes; decode(encode(x)) == quantize(x) bit for bit when the channel's
+    scale table is exactly geometric in fp32 (all weight-sized ranges), else within a few ULP (<= 5e-6 relative) on elements that round up
+    into the next binade (see include/fp8q.h)."""
     if not isinstance(codes, torch.Tensor) or not codes.is_cuda or codes.dtype != torch.uint8:
         raise Fp8qError("codes must be a CUDA(HIP) uint8 tensor")
     _require(maxval, "maxval")

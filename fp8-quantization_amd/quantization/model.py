@@ -96,7 +96,8 @@ def export_fp8_weights(model):
     """{layer name: {codes uint8 [like the weight], maxval [1] or [C], mantissa_bits, sign_bits, n_bits}} for every
     layer whose weights go through an FP8 quantizer with fixed ranges: the 1-byte storage form of what the layer
     computes with (the reference only simulates the format; its enumerator
-    fp8_quantizer.py:13-41 defines the byte layout).  decode(codes) == the layer's quantized weight, bit for bit."""
+    fp8_quantizer.py:13-41 defines the byte layout).  decode(codes) == the layer's quantized weight (bit for bit for weight-sized
+    ranges; within a few ULP on round-ups into the next binade otherwise, see include/fp8q.h)."""
     import torch
 
     import fp8q

@@ -127,7 +127,12 @@ int fp8q_affine_act_minmax_f32(const float *x, const float *residual, int64_t N,
  * enumerator generate_all_values_fp (fp8_quantizer.py:13-41) defines the byte layout
  * [sign | E exponent bits | M fraction bits] (exponent code 0 subnormal, no inf/NaN codes).
  *   fp8q_encode_u8: codes[i] = the byte whose value is quantize_to_fp8_ste_MM(x)[i]
- *   fp8q_decode_u8: y[i] = value of codes[i]; decode(encode(x)) == fp8q_quantize_f32(x) bit for bit
+ *   fp8q_decode_u8: y[i] = value of codes[i].  decode(encode(x)) == fp8q_quantize_f32(x) bit for bit whenever
+ *                   the channel's scales are exactly geometric in fp32 (s_(p+1) == 2 s_p: true for every range
+ *                   with |k - bias| below bias's binade, e.g. all weight-sized ranges); otherwise an element
+ *                   that rounds UP into the next binade is 2^(M+1) s_p in K1 and 2^M s_(p+1) after decoding,
+ *                   two fp32 renderings of the same grid point that can differ by ulp(k - bias) ln 2 relative (a few ULP, <= 5e-6 for |bias| < 100; the reference has the
+ *                   same ambiguity: it emits either, depending on which side x came from)
  * n_bits <= 8.  The format has no NaN: NaN inputs and degenerate channels (maxval 0/inf/NaN, whose
  * K1 output is NaN) encode as 0.  HBM traffic: 5 B / element each.
  */

@@ -44,6 +44,30 @@ def test_oracle_roundtrip_equals_quantize():
         assert np.array_equal(rt.view(np.int32), q.view(np.int32)), (M, mv, sb)
 
 
+def test_roundtrip_on_non_geometric_scale_tables():
+    """Where the reference's fp32 (p - M) - bias rounds differently in neighbouring binades (small |bias|, e.g.
+    E3M4 with maxval 207), s_(p+1) != 2 s_p in the last bit.  K1 renders an element that rounds UP into the next
+    binade as 2^(M+1) s_p, the decoder (like the reference's enumerator: one value per code) as 2^M s_(p+1): the same
+    grid point, a few fp32 ULP apart (ulp(k - bias) ln 2 relative); everything else round-trips bit for bit.  Found by tools/soak.py."""
+    rng = np.random.RandomState(3)
+    worst = 0
+    for M, mv, sb in ((4, 207.11018, 1), (5, 7.1219254, 1), (6, 12.418949, 0), (4, 305.43573, 1)):
+        x = (rng.randn(200000) * mv / 2.5).astype(np.float32)
+        if sb == 0:
+            x = np.abs(x)
+        q = oracle.c_quantize(x, [mv], M, 8, sb)
+        rt = oracle.c_decode(oracle.c_encode(x, [mv], M, 8, sb), [mv], M, 8, sb)
+        ulp = np.abs(rt.view(np.int32).astype(np.int64) - q.view(np.int32).astype(np.int64))
+        assert ulp.max() <= 8, (M, mv, int(ulp.max()))     # < 1e-6 relative
+        worst = max(worst, int(ulp.max()))
+        # the differing elements sit exactly on binade tops: |q| / s is a power of two there
+        diff = ulp > 0
+        if diff.any():
+            grid = np.unique(np.abs(rt[diff]))
+            assert len(grid) <= 8            # a handful of grid points (one per affected binade), many elements
+    assert worst >= 1                        # the fixture does exercise the caveat
+
+
 pytestmark_gpu = pytest.mark.gpu
 
 
@@ -95,6 +119,15 @@ def test_hip_codec_nan_and_degenerate():
     codes = ops.encode(dev(x), dev(mv), 3, 8, 1).cpu().numpy()
     np.testing.assert_array_equal(codes, oracle.c_encode(x, mv, 3, 8, 1))
     assert codes[0, 1] == 0 and (codes[1] == 0).all()                  # no NaN code: documented as 0
+    # decoding a degenerate channel follows the reference chain's 2^(k - bias): 0 for maxval 0 (bias = +inf)
+    dec = ops.decode(dev(codes, np.uint8), dev(mv), 3, 8, 1).cpu().numpy()
+    np.testing.assert_array_equal(dec.view(np.int32), oracle.c_decode(codes, mv, 3, 8, 1).view(np.int32))
+    for bad in (np.inf, np.nan):
+        mvb = np.array([2.0, bad], np.float32)
+        cb = ops.encode(dev(x), dev(mvb), 3, 8, 1)
+        got = ops.decode(cb, dev(mvb), 3, 8, 1).cpu().numpy()
+        ref = oracle.c_decode(cb.cpu().numpy(), mvb, 3, 8, 1)
+        assert np.array_equal(np.isnan(got), np.isnan(ref)) and np.array_equal(got[~np.isnan(ref)], ref[~np.isnan(ref)])
 
 
 @pytest.mark.gpu

@@ -318,6 +318,21 @@ def test_fused_rows_in_registers(ops, C, inner, M):
     assert_bit_exact(xi.cpu().numpy(), ref, f"fused in place {C}x{inner} M={M}")
 
 
+@pytest.mark.parametrize("C,inner", [(35, 8193), (2, 8195), (3, 16385), (1, 8193), (1, 2048 * 4 * 7 + 1), (5, 24577)])
+def test_minmax_with_an_empty_split(ops, C, inner):
+    """Rows a few elements longer than a whole number of 8192-element steps leave the last split of the
+    two-stage min/max without any aligned group: its partial is {+inf, -inf} and must not leak into the result
+    (found by tools/soak.py: all-positive rows came back with max = +inf)."""
+    rng = np.random.RandomState(C + inner)
+    for x in (np.abs(rng.randn(C, inner)).astype(np.float32) + 0.5, -np.abs(rng.randn(C, inner)).astype(np.float32) - 0.5,
+              rng.randn(C, inner).astype(np.float32)):
+        for pc in (True, False):
+            mn, mx = ops.minmax(dev(x), pc)
+            rmn, rmx = oracle.c_minmax(x, pc)
+            np.testing.assert_array_equal(mn.cpu().numpy(), rmn)
+            np.testing.assert_array_equal(mx.cpu().numpy(), rmx)
+
+
 def test_fuzz_geometries_against_oracle(ops):
     """Seeded fuzz over the routing space of the per-channel kernels (k_rows_flat / k_rows_reg / k_rows_direct /
     k_quant_rows / k_quant_scalar): random channel counts, row lengths, formats, sign bits, pointer phases (views
@@ -326,7 +341,8 @@ def test_fuzz_geometries_against_oracle(ops):
     rng = np.random.RandomState(2024)
     lengths = [1, 2, 3, 4, 5, 7, 9, 16, 20, 21, 35, 36, 37, 64, 100, 124, 128, 132, 147, 192, 255, 256, 257, 288, 300,
                384, 388, 448, 511, 512, 513, 576, 640, 896,
-               1000, 1023, 1024, 1028, 1152, 2044, 2047, 2048, 2049, 2052, 3000, 4096, 4100, 4608, 8192, 8196, 9000]
+               1000, 1023, 1024, 1028, 1152, 2044, 2047, 2048, 2049, 2052, 3000, 4096, 4100, 4608, 8192, 8193, 8195, 8196, 9000,
+               16385]
     for case in range(200):
         inner = int(lengths[rng.randint(len(lengths))])
         C = int(rng.choice([1, 2, 3, 5, 17, 64, 130, 301])) if inner > 600 else int(rng.randint(1, 700))
@@ -347,11 +363,16 @@ def test_fuzz_geometries_against_oracle(ops):
         ref = oracle.c_quantize(x, mv, M, 8, sb)
         y = ops.quantize(xd, dev(mv), M, 8, sb)
         assert_bit_exact(y.cpu().numpy(), ref, "K1 " + what)
-        yf, gmn, gmx, gmv = ops.minmax_quantize(xd, M, 8, sb)
-        np.testing.assert_array_equal(gmn.cpu().numpy(), mn, err_msg=what)
-        np.testing.assert_array_equal(gmx.cpu().numpy(), mx, err_msg=what)
-        assert_bit_exact(yf.cpu().numpy(), ref, "fused " + what)
-        if case % 3 == 0:   # in place, through a view with the same phase
+        fusable = inner <= ops.fused_max_inner()   # longer rows: the manager calls min/max + quantize
+        if fusable:
+            yf, gmn, gmx, gmv = ops.minmax_quantize(xd, M, 8, sb)
+            np.testing.assert_array_equal(gmn.cpu().numpy(), mn, err_msg=what)
+            np.testing.assert_array_equal(gmx.cpu().numpy(), mx, err_msg=what)
+            assert_bit_exact(yf.cpu().numpy(), ref, "fused " + what)
+        kmn, kmx = ops.minmax(xd, True)
+        np.testing.assert_array_equal(kmn.cpu().numpy(), mn, err_msg=what)
+        np.testing.assert_array_equal(kmx.cpu().numpy(), mx, err_msg=what)
+        if case % 3 == 0 and fusable:   # in place, through a view with the same phase
             xi = base.clone()[off: off + x.size].view(C, inner)
             ops.minmax_quantize(xi, M, 8, sb, out=xi)
             assert_bit_exact(xi.cpu().numpy(), ref, "fused in place " + what)
