@@ -178,6 +178,48 @@ def quantize_weight_sharded(w, mbits, n_bits=8, sign_bits=1, maxval=None, group=
     return torch.cat(parts).view_as(w), torch.cat(mvs)
 
 
+def quantize_weights_sharded_bucketed(weights, mbits, n_bits=8, sign_bits=1, group=None, ops=None):
+    """All weight tensors of a model, channel-sharded, with ONE collective: every rank quantizes its channels of
+    every tensor (current_minmax ranges) straight into one packed send buffer, the ranks exchange that buffer with
+    a single all-gather (ResNet-18: 46.7 MB in total, 5.8 MB per peer link on the xGMI mesh -- one large
+    transfer instead of 21 small ones), and every rank unpacks the full quantized tensors and ranges.
+    Result per tensor identical to quantize_weight_sharded.  Returns [(w_q, maxval), ...]."""
+    ops = ops or _default_ops()
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if not weights:
+        return []
+    dev0, dt = weights[0].device, weights[0].dtype
+    geo, total = [], 0                       # per tensor: (C, inner, per, offset of values, offset of ranges)
+    for w in weights:
+        C = w.shape[0]
+        inner = w.numel() // max(C, 1)
+        per = -(-C // world)
+        geo.append((C, inner, per, total, total + per * inner))
+        total += per * (inner + 1)
+    send = torch.zeros(total, dtype=dt, device=dev0)
+    for w, (C, inner, per, off_v, off_m) in zip(weights, geo):
+        lo, hi = channel_partition(C, world)[rank]
+        if hi > lo:
+            q, _, _, mv = ops.minmax_quantize(w[lo:hi].contiguous(), mbits, n_bits, sign_bits)
+            send[off_v: off_v + (hi - lo) * inner] = q.reshape(-1)
+            send[off_m: off_m + (hi - lo)] = mv
+    if world > 1:
+        recv = torch.empty(world * total, dtype=dt, device=dev0)
+        dist.all_gather_into_tensor(recv, send, group=group)
+        recv = recv.view(world, total)
+    else:
+        recv = send.view(1, total)
+    out = []
+    for w, (C, inner, per, off_v, off_m) in zip(weights, geo):
+        parts, mvs = [], []
+        for r, (a, b) in enumerate(channel_partition(C, world)):
+            parts.append(recv[r, off_v: off_v + (b - a) * inner])
+            mvs.append(recv[r, off_m: off_m + (b - a)])
+        out.append((torch.cat(parts).view_as(w), torch.cat(mvs)))
+    return out
+
+
 N_MSE_GRID = 111   # candidates of FP_MSE_Estimator (range_estimators.py:305)
 
 
