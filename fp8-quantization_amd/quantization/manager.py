@@ -12,6 +12,7 @@ it (:114-122) -- but picks the cheapest kernel sequence for it:
 """
 from enum import auto
 
+import torch
 from torch import nn
 
 from fp8q import ops as _ops
@@ -99,7 +100,8 @@ class QuantizationManager(nn.Module):
         if not self._estimating():
             return q(x)
         fast = (type(q) is FPQuantizer and type(est) in _MINMAX and not q.allow_unsigned
-                and not getattr(est, "percentile", None) and x.is_cuda and not x.requires_grad)
+                and not getattr(est, "percentile", None) and x.is_cuda
+                and not (x.requires_grad and torch.is_grad_enabled()))   # weights are Parameters: fine under no_grad
         if not fast:
             xmin, xmax = est(x)                      # generic protocol, reference order
             self.set_quant_range(xmin, xmax)

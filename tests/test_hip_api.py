@@ -226,6 +226,51 @@ def test_prequantize_weights_multi_tensor(golden_dir):
         assert torch.equal(q(val), ref)
 
 
+def test_kernel_sequence_of_the_model_flow(golden_dir, monkeypatch):
+    """The manager picks the cheapest kernel sequence (module docstring of quantization/manager.py): calibration =
+    ONE fused min/max+quantize launch per weight tensor (weights are Parameters: the fast path must not be lost to
+    requires_grad under no_grad) and min/max + quantize epilogues per activation; fix_ranges = one multi-tensor
+    launch; validation = no weight launches at all (cache) and one launch per activation quantizer."""
+    import collections
+    from fp8q import ops
+    from quantization.autoquant_utils import quantize_model
+    from quantization.base_quantized_classes import QuantizedModule
+    from quantization.base_quantized_model import prequantize_weights
+    from quantization.quantization_manager import QMethods
+    from quantization.range_estimators import RangeEstimators
+    cnt = collections.Counter()
+    for name in ("minmax", "minmax_quantize", "quantize", "affine_act_quantize", "affine_act_minmax", "multi_quantize"):
+        def mk(name, f):
+            def w(*a, **k):
+                cnt[name + ("_per_channel" if name == "minmax" and a[1] else "")] += 1
+                return f(*a, **k)
+            return w
+        monkeypatch.setattr(ops, name, mk(name, getattr(ops, name)))
+    g7 = np.load(os.path.join(golden_dir, "g7_tinycnn.npz"))
+    q = quantize_model(_tiny_cnn(g7), method=QMethods.fp_quantizer.cls,
+                       weight_range_method=RangeEstimators.current_minmax.cls,
+                       act_range_method=RangeEstimators.allminmax.cls, n_bits=8, per_channel_weights=True,
+                       fp8_kwargs=dict(maxval=None, mantissa_bits=2, set_maxval=True)).eval().cuda()
+    x = dev(g7["calib"])
+    with torch.no_grad():
+        for m in q.modules():
+            if isinstance(m, QuantizedModule):
+                m.quantized()
+        q(x)
+        assert cnt["minmax_quantize"] == 4 and cnt["minmax_per_channel"] == 0, dict(cnt)   # 4 weight tensors, fused
+        n_act = cnt["affine_act_quantize"] + cnt["quantize"]
+        assert n_act >= 4 and cnt["affine_act_minmax"] + cnt["minmax"] <= n_act
+        cnt.clear()
+        for m in q.modules():
+            if isinstance(m, QuantizedModule):
+                m.fix_ranges()
+        assert prequantize_weights(q) == 4 and cnt["multi_quantize"] == 1
+        cnt.clear()
+        q(x)
+        assert cnt["minmax_quantize"] == cnt["minmax"] == cnt["minmax_per_channel"] == cnt["affine_act_minmax"] == 0
+        assert cnt["affine_act_quantize"] + cnt["quantize"] == n_act, dict(cnt)   # activations only: weights are cached
+
+
 def test_mse_search_sharded_single_process_equals_estimator(golden_dir):
     """fp8q.dist.mse_search_sharded with one rank is FP_MSE_Estimator.forward (HIP ops on both sides)."""
     from fp8q import dist as fd
