@@ -1110,10 +1110,26 @@ k_affine_act(const float *__restrict__ x, const float *__restrict__ res, float *
     const vf4 *rv = reinterpret_cast<const vf4 *>(res + (a.has_res ? base0 : 0));
     vf4 *yv = reinterpret_cast<vf4 *>(y + base0);
     const uint32_t HW = (uint32_t)a.HW;
+    // planes of >= 4096 elements: a piece overlaps at most two, whose constants every thread keeps in registers
+    // (uniform addresses: scalar loads) -- no LDS staging and no barrier per step, which is what separates the BN
+    // variant from the plain one on the large early layers (75 -> 70 us at [64,64,112,112]; the same with up to
+    // four planes in registers, for 56x56 planes, was measured and rejected: 94 us)
+    const bool direct = a.has_bn && a.cpp <= 2;
+    __syncthreads();       // lut is complete
     for (int base = blockIdx.x * (kBlock * U); base < nvec; base += gridDim.x * (kBlock * U)) {
         uint32_t phase = 0;
-        __syncthreads();   // the previous step's constants are no longer read (first step: lut is complete)
-        if (a.has_bn) {
+        float2 p0 = make_float2(1.0f, 0.0f), p1 = p0;
+        if (direct) {
+            const uint32_t e0 = (uint32_t)base * 4u;
+            const uint32_t ch_lo = e0 / HW;
+            phase = e0 - ch_lo * HW;
+            const uint32_t ch_hi = ch_lo + 1u < (uint32_t)a.C ? ch_lo + 1u : ch_lo;
+            const float al0 = invstd[ch_lo] * gamma[ch_lo], al1 = invstd[ch_hi] * gamma[ch_hi];
+            p0 = make_float2(al0, fmaf(-mean[ch_lo], al0, beta[ch_lo]));
+            p1 = make_float2(al1, fmaf(-mean[ch_hi], al1, beta[ch_hi]));
+        }
+        if (a.has_bn && !direct) {
+            __syncthreads();   // the previous step's constants are no longer read
             const uint32_t e0 = (uint32_t)base * 4u;
             const uint32_t ch_lo = e0 / HW;
             phase = e0 - ch_lo * HW;
@@ -1128,7 +1144,20 @@ k_affine_act(const float *__restrict__ x, const float *__restrict__ res, float *
         }
         auto transform = [&](int q, float (&e)[4], const vf4 &r) {   // q: piece-local group index
             const float rr[4] = {r.x, r.y, r.z, r.w};
-            if (a.has_bn) {
+            if (direct) {
+                const uint32_t o = phase + 4u * (uint32_t)q;
+                const bool hi = o >= HW;                    // second plane of the piece
+                uint32_t off = hi ? o - HW : o;
+                float2 p = hi ? p1 : p0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    e[k] = res_act(fmaf(e[k], p.x, p.y), rr[k], a);
+                    if (++off == HW && k < 3) {
+                        off = 0;
+                        p = p1;
+                    }
+                }
+            } else if (a.has_bn) {
                 const uint32_t o = phase + 4u * (uint32_t)q;
                 uint32_t lch = HW > (uint32_t)kAffineMagicMaxHW ? (o >= HW ? 1u : 0u) : (uint32_t)div_small(o, a.magic);
                 uint32_t off = o - lch * HW;
