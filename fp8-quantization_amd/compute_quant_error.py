@@ -25,45 +25,67 @@ from quantization.quantizers.uniform_quantizers import SymmetricUniformQuantizer
 from quantization.range_estimators import estimate_range_line_search  # noqa: E402
 
 
+FORMATS = ((5, "E5M2"), (4, "E4M3"), (3, "E3M4"), (2, "E2M5"), (0, "INT8"))   # exponent bits; 0 = uniform grid
+
+
 def seed_all(seed):
     random.seed(seed)
     np.random.seed(seed)
     torch.manual_seed(seed)
 
 
+def _db(mse):
+    return -10.0 * np.log10(mse)
+
+
+def _make_quantizer(exp_bits, n_bits):
+    if exp_bits == 0:
+        return SymmetricUniformQuantizer(n_bits=n_bits)
+    return FPQuantizer(n_bits=8, mantissa_bits=n_bits - 1 - exp_bits, set_maxval=True)
+
+
+def format_row(row):
+    """The two console lines the reference prints per format (compute_quant_error.py:47-58)."""
+    e, m, _, q_mse, q_db, d_mse, d_db = row
+    head = "FP8 {} E {} M Quantization: expected MSE {:.2e}".format(e, m, q_mse)
+    return " ".join([head, " SQNR ", "{:.2e}\n".format(q_db), "Dot product:".rjust(23),
+                     " expected MSE {:.2e}".format(d_mse), " SQNR ", "{:.2e}".format(d_db)])
+
+
 def compute_quant_error(distr, n_bits=8, n_samples=5000000, seed=10, device="cuda", verbose=True):
-    """Returns [(exp_bits, mantissa_bits, range_max, quant_mse, quant_sqnr, dot_mse, dot_sqnr)]."""
+    """One row per format: (exp_bits, mantissa_bits, range_max, quant_mse, quant_sqnr, dot_mse, dot_sqnr).
+    The samples live on the GPU; each format's clipping range comes from ONE pass of the MSE-grid kernel over them
+    (1000 candidates), the expected errors are the analytic integrals over the format's grid."""
     seed_all(seed)
-    sample = torch.tensor(distr.sample((n_samples,))).to(device, torch.float32)
-    rows = []
-    for exp_bits in [5, 4, 3, 2, 0]:
-        mantissa_bits = n_bits - 1 - exp_bits
-        quant = FPQuantizer(n_bits=8, mantissa_bits=mantissa_bits, set_maxval=True) if exp_bits > 0 \
-            else SymmetricUniformQuantizer(n_bits=n_bits)
-        rmin, rmax = estimate_range_line_search(sample, quant)
-        mse = compute_expected_quant_mse(distr, quant, rmin, rmax, n_samples)
-        dp = compute_expected_dot_prod_mse(distr, distr, quant, quant, rmin, rmax, rmin, rmax)
-        sqnr, dp_sqnr = -10.0 * np.log10(mse), -10.0 * np.log10(dp)
-        rows.append((exp_bits, mantissa_bits, float(rmax), mse, sqnr, dp, dp_sqnr))
+    samples = torch.as_tensor(distr.sample((n_samples,))).to(device=device, dtype=torch.float32)
+    table = []
+    for exp_bits, _name in FORMATS:
+        q = _make_quantizer(exp_bits, n_bits)
+        lo, hi = estimate_range_line_search(samples, q)
+        q_mse = compute_expected_quant_mse(distr, q, lo, hi, n_samples)
+        d_mse = compute_expected_dot_prod_mse(distr, distr, q, q, lo, hi, lo, hi)
+        table.append((exp_bits, n_bits - 1 - exp_bits, float(hi), q_mse, _db(q_mse), d_mse, _db(d_mse)))
         if verbose:
-            print("FP8 {} E {} M Quantization: expected MSE {:.2e}".format(exp_bits, mantissa_bits, mse),
-                  " SQNR ", "{:.2e}\n".format(sqnr), "Dot product:".rjust(23),
-                  " expected MSE {:.2e}".format(dp), " SQNR ", "{:.2e}".format(dp_sqnr))
-    return rows
+            print(format_row(table[-1]))
+    return table
 
 
 def default_distributions():
-    return [UniformDistr(range_min=-1.0, range_max=1.0, params_dict={}),
-            ClippedGaussDistr(params_dict={"mu": 0.0, "sigma": 1.0}, range_min=-10.0, range_max=10.0),
-            ClippedStudentTDistr(params_dict={"nu": 8.0}, range_min=-100.0, range_max=100.0)]
+    spec = ((UniformDistr, {}, (-1.0, 1.0)), (ClippedGaussDistr, {"mu": 0.0, "sigma": 1.0}, (-10.0, 10.0)),
+            (ClippedStudentTDistr, {"nu": 8.0}, (-100.0, 100.0)))
+    return [cls(params_dict=params, range_min=lo, range_max=hi) for cls, params, (lo, hi) in spec]
 
 
-if __name__ == "__main__":
-    ap = argparse.ArgumentParser()
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__)
     ap.add_argument("--n-samples", type=int, default=5000000)
     ap.add_argument("--seed", type=int, default=10)
-    a = ap.parse_args()
+    a = ap.parse_args(argv)
     for d in default_distributions():
         print("*" * 80)
         d.print()
         compute_quant_error(d, n_samples=a.n_samples, seed=a.seed)
+
+
+if __name__ == "__main__":
+    main()

@@ -4,8 +4,9 @@ import os
 import torch
 
 from quantization.autoquant_utils import quantize_sequential, Flattener, quantize_model, BNQConv
-from quantization.base_quantized_classes import QuantizedActivation, FP32Acts
+from quantization.base_quantized_classes import QuantizedActivation
 from quantization.base_quantized_model import QuantizedModel
+from ._setups import apply_preset, weight_bits, act_bits, fp32_output, fp32_all_activations
 from .mobilenet_v2 import MobileNetV2, InvertedResidual
 
 
@@ -18,74 +19,67 @@ class QuantizedInvertedResidual(QuantizedActivation):
         self.conv = quantize_sequential(inv_res_orig.conv, **quant_params)
 
     def forward(self, x):
+        branch = self.conv(x)
         if not self.use_res_connect:
-            return self.conv(x)
-        out = self.conv(x)
+            return branch
         aq = self.activation_quantizer
-        if self._qa and hasattr(aq, "can_fuse") and aq.can_fuse(out) and x.shape == out.shape:
-            return aq.forward_fused(out, residual=x.contiguous(), act=0)        # add + quantize
-        return self.quantize_activations(x + out)
+        if self._qa and hasattr(aq, "can_fuse") and aq.can_fuse(branch) and x.shape == branch.shape:
+            return aq.forward_fused(branch, residual=x.contiguous(), act=0)        # add + quantize
+        return self.quantize_activations(x + branch)
+
+
+def _stem(net):
+    return net.features[0][0]
+
+
+def _fc(net):
+    return net.classifier[1]
+
+
+def _depthwise(net):
+    hits = [(n, m) for n, m in net.named_modules() if isinstance(m, BNQConv) and m.groups == m.in_channels]
+    for n, _ in hits:
+        print(f"Set layer {n} to 8 bits")
+    return [m for _, m in hits]
+
+
+_PRESETS = {
+    "FP_logits": ("Do not quantize output of FC layer", [(_fc, fp32_output)]),
+    "fc4": (None, [(_stem, weight_bits(8)), (_fc, weight_bits(4))]),
+    "fc4_dw8": (None, [(_stem, weight_bits(8)), (_fc, weight_bits(4)), (_depthwise, weight_bits(8))]),
+    "LSQ": ("Set quantization to LSQ (first+last layer in 8 bits)",
+            [(_stem, weight_bits(8)), (lambda net: net.features[-2][0], act_bits(8)), (_fc, weight_bits(8)),
+             (_fc, fp32_output)]),
+    "LSQ_paper": (None, [(_stem, fp32_output), (_stem, weight_bits(8)), (_fc, weight_bits(8)), (_fc, act_bits(8)),
+                         (lambda net: net.features, fp32_all_activations)]),
+}
 
 
 class QuantizedMobileNetV2(QuantizedModel):
     def __init__(self, model_fp, input_size=(1, 3, 224, 224), quant_setup=None, **quant_params):
         super().__init__(input_size)
-        quantize_input = bool(quant_setup) and quant_setup == "LSQ_paper"
-        self.features = quantize_sequential(
-            model_fp.features, tie_activation_quantizers=not quantize_input,
-            specials={InvertedResidual: QuantizedInvertedResidual}, **quant_params)
+        # LSQ_paper quantizes layer inputs instead of outputs: then the stem's activation quantizers are not tied
+        tie = not (bool(quant_setup) and quant_setup == "LSQ_paper")
+        self.features = quantize_sequential(model_fp.features, tie_activation_quantizers=tie,
+                                            specials={InvertedResidual: QuantizedInvertedResidual}, **quant_params)
         self.flattener = Flattener()
         self.classifier = quantize_model(model_fp.classifier, **quant_params)
-        self._apply_setup(quant_setup)
-
-    def _apply_setup(self, setup):
-        stem, fc = self.features[0][0], self.classifier[1]
-        if setup in (None, "all"):
-            return
-        if setup == "FP_logits":
-            print("Do not quantize output of FC layer")
-            fc.activation_quantizer = FP32Acts()
-        elif setup in ("fc4", "fc4_dw8"):
-            stem.weight_quantizer.quantizer.n_bits = 8
-            fc.weight_quantizer.quantizer.n_bits = 4
-            if setup == "fc4_dw8":
-                for name, m in self.named_modules():
-                    if isinstance(m, BNQConv) and m.groups == m.in_channels:
-                        m.weight_quantizer.quantizer.n_bits = 8
-                        print(f"Set layer {name} to 8 bits")
-        elif setup == "LSQ":
-            print("Set quantization to LSQ (first+last layer in 8 bits)")
-            stem.weight_quantizer.quantizer.n_bits = 8
-            self.features[-2][0].activation_quantizer.quantizer.n_bits = 8
-            fc.weight_quantizer.quantizer.n_bits = 8
-            fc.activation_quantizer = FP32Acts()
-        elif setup == "LSQ_paper":
-            stem.activation_quantizer = FP32Acts()
-            stem.weight_quantizer.quantizer.n_bits = 8
-            fc.weight_quantizer.quantizer.n_bits = 8
-            fc.activation_quantizer.quantizer.n_bits = 8
-            for layer in self.features.modules():
-                if isinstance(layer, QuantizedActivation):
-                    layer.activation_quantizer = FP32Acts()
-        else:
-            raise ValueError(f"Quantization setup '{setup}' not supported for MobilenetV2")
+        apply_preset(self, quant_setup, _PRESETS, "MobilenetV2")
 
     def forward(self, x):
         return self.classifier(self.flattener(self.features(x)))
 
 
 def mobilenetv2_quantized(pretrained=True, model_dir=None, load_type="fp32", **qparams):
+    if load_type not in ("fp32", "quantized"):
+        raise ValueError("wrong load_type specified")
     fp_model = MobileNetV2()
-    if pretrained and load_type == "fp32":
+    if load_type == "fp32" and pretrained:
         assert model_dir and os.path.exists(model_dir), "pretrained MobileNetV2 needs --model-dir"
         print(f"Loading pretrained weights from {model_dir}")
         fp_model.load_state_dict(torch.load(model_dir, map_location="cpu"))
-        return QuantizedMobileNetV2(fp_model, **qparams)
-    if load_type == "fp32":
-        return QuantizedMobileNetV2(fp_model, **qparams)    # random init (synthetic runs)
+    model = QuantizedMobileNetV2(fp_model, **qparams)          # fp32 without a checkpoint: random init (synthetic runs)
     if load_type == "quantized":
         print(f"Loading pretrained quantized model from {model_dir}")
-        model = QuantizedMobileNetV2(fp_model, **qparams)
         model.load_state_dict(torch.load(model_dir, map_location="cpu"), strict=False)
-        return model
-    raise ValueError("wrong load_type specified")
+    return model

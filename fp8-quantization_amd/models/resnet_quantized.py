@@ -3,8 +3,9 @@ import torch
 from torch import nn
 
 from quantization.autoquant_utils import quantize_model, Flattener, QuantizedActivationWrapper
-from quantization.base_quantized_classes import QuantizedActivation, FP32Acts
+from quantization.base_quantized_classes import QuantizedActivation
 from quantization.base_quantized_model import QuantizedModel
+from ._setups import apply_preset, weight_bits, act_bits, fp32_output, fp32_all_activations
 from .resnet import BasicBlock, Bottleneck, resnet18, resnet50
 
 
@@ -36,6 +37,26 @@ class QuantizedBlock(QuantizedActivation):
         return self.quantize_activations(self.relu(out))
 
 
+def _first(net):
+    return net.features[0]
+
+
+def _last_block(net):
+    return net.features[-1][-1]
+
+
+_PRESETS = {
+    "LSQ": ("Set quantization to LSQ (first+last layer in 8 bits)",
+            [(_first, weight_bits(8)), (_last_block, act_bits(8)),
+             (lambda net: _last_block(net).features[-1], act_bits(8)),
+             (lambda net: net.fc, weight_bits(8)), (lambda net: net.fc, fp32_output)]),
+    "LSQ_paper": (None, [(_first, fp32_output), (_first, weight_bits(8)), (lambda net: net.fc, act_bits(8)),
+                         (lambda net: net.fc, weight_bits(8)), (lambda net: net.features, fp32_all_activations)]),
+    "FP_logits": ("Do not quantize output of FC layer", [(lambda net: net.fc, fp32_output)]),
+    "fc4": (None, [(_first, weight_bits(8)), (lambda net: net.fc, weight_bits(4))]),
+}
+
+
 class QuantizedResNet(QuantizedModel):
     def __init__(self, resnet, input_size=(1, 3, 224, 224), quant_setup=None, **quant_params):
         super().__init__(input_size)
@@ -54,35 +75,7 @@ class QuantizedResNet(QuantizedModel):
                 input_quantizer=self.features[-1][-1].activation_quantizer, **quant_params)
         self.flattener = Flattener()
         self.fc = quantize_model(resnet.fc, **quant_params)
-        self._apply_setup(quant_setup)
-
-    def _apply_setup(self, setup):
-        first, last_block = self.features[0], self.features[-1][-1]
-        if setup in (None, "all"):
-            return
-        if setup == "LSQ":
-            print("Set quantization to LSQ (first+last layer in 8 bits)")
-            first.weight_quantizer.quantizer.n_bits = 8
-            last_block.activation_quantizer.quantizer.n_bits = 8
-            last_block.features[-1].activation_quantizer.quantizer.n_bits = 8
-            self.fc.weight_quantizer.quantizer.n_bits = 8
-            self.fc.activation_quantizer = FP32Acts()
-        elif setup == "LSQ_paper":
-            first.activation_quantizer = FP32Acts()
-            first.weight_quantizer.quantizer.n_bits = 8
-            self.fc.activation_quantizer.quantizer.n_bits = 8
-            self.fc.weight_quantizer.quantizer.n_bits = 8
-            for layer in self.features.modules():
-                if isinstance(layer, QuantizedActivation):
-                    layer.activation_quantizer = FP32Acts()
-        elif setup == "FP_logits":
-            print("Do not quantize output of FC layer")
-            self.fc.activation_quantizer = FP32Acts()
-        elif setup == "fc4":
-            first.weight_quantizer.quantizer.n_bits = 8
-            self.fc.weight_quantizer.quantizer.n_bits = 4
-        else:
-            raise ValueError(f"Quantization setup '{setup}' not supported for Resnet")
+        apply_preset(self, quant_setup, _PRESETS, "Resnet")
 
     def forward(self, x):
         x = self.avgpool(self.features(x))

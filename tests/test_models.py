@@ -227,3 +227,39 @@ def test_resnet50_quantized_forward_gpu():
     assert torch.isfinite(y).all() and y.shape == (4, 1000)
     mgrs = [m for m in q.modules() if isinstance(m, QuantizationManager)]
     assert len(mgrs) > 100 and all(m.quantizer.is_initialized for m in mgrs)
+
+
+@pytest.mark.parametrize("arch,presets", [("resnet18_quantized", ["all", "LSQ", "LSQ_paper", "FP_logits", "fc4"]),
+                                          ("mobilenet_v2_quantized", ["all", "LSQ", "LSQ_paper", "FP_logits", "fc4", "fc4_dw8"])])
+def test_quant_setup_presets(arch, presets):
+    """--quant-setup presets (reference models/resnet_quantized.py:73-122, models/mobilenet_v2_quantized.py:49-101):
+    which layers end up at 4 / 8 bits or with fp32 outputs."""
+    from models import QuantArchitectures
+    from quantization.base_quantized_classes import FP32Acts
+    from quantization.quantization_manager import QMethods
+    from quantization.range_estimators import RangeEstimators
+    qp = dict(method=QMethods.fp_quantizer.cls, weight_range_method=RangeEstimators.current_minmax.cls,
+              act_range_method=RangeEstimators.allminmax.cls, n_bits=6, n_bits_act=6, per_channel_weights=True,
+              fp8_kwargs=dict(maxval=None, mantissa_bits=2, set_maxval=True))
+    for preset in presets:
+        m = QuantArchitectures[arch](pretrained=False, load_type="fp32", quant_setup=preset, **qp)
+        first = m.features[0] if arch.startswith("resnet") else m.features[0][0]
+        fc = m.fc if arch.startswith("resnet") else m.classifier[1]
+        wb = lambda layer: layer.weight_quantizer.quantizer.n_bits   # noqa: E731
+        if preset == "all":
+            assert wb(first) == 6 and wb(fc) == 6 and not isinstance(fc.activation_quantizer, FP32Acts)
+        elif preset == "FP_logits":
+            assert isinstance(fc.activation_quantizer, FP32Acts) and wb(fc) == 6
+        elif preset == "fc4":
+            assert wb(first) == 8 and wb(fc) == 4
+        elif preset == "fc4_dw8":
+            assert wb(first) == 8 and wb(fc) == 4
+            dw = [x for x in m.modules() if getattr(x, "groups", 1) > 1 and hasattr(x, "weight_quantizer")]
+            assert dw and all(wb(x) == 8 for x in dw)
+        elif preset == "LSQ":
+            assert wb(first) == 8 and wb(fc) == 8 and isinstance(fc.activation_quantizer, FP32Acts)
+        elif preset == "LSQ_paper":
+            assert wb(first) == 8 and wb(fc) == 8 and isinstance(first.activation_quantizer, FP32Acts)
+            assert fc.activation_quantizer.quantizer.n_bits == 8
+    with pytest.raises(ValueError):
+        QuantArchitectures[arch](pretrained=False, load_type="fp32", quant_setup="no_such_preset", **qp)
