@@ -312,8 +312,9 @@ __device__ __forceinline__ uint32_t encode_one(float x, const ChanLite &c, const
         ls = __builtin_amdgcn_fmed3f(fl, 1.0f, pmaxf);
         t = lut[(int)ls];
         r = rintf(xc / t.x);
-        if (r != r) return 0u;                      // degenerate channel (maxval 0 / inf / NaN)
     }
+    // r is an integer in [0, 2^(M+1)] unless the channel is degenerate (s = 0 / NaN: K1 gives NaN): code 0
+    if (__builtin_expect(!(fabsf(r) <= (float)(2u << M)), 0)) return 0u;
     const uint32_t ri = (uint32_t)fabsf(r);
     const uint32_t m2 = 1u << M;
     uint32_t e = (uint32_t)ls, f = ri - m2;

@@ -1937,7 +1937,7 @@ static int codec_launch(bool encode, const float *x, uint8_t *codes, float *y, i
     if (C < 0 || inner < 0 || (n_maxval != 1 && n_maxval != C) || n_bits > 8) return FP8Q_EINVAL;
     QFmt f;
     if (int rc = make_fmt(mbits, n_bits, sign_bits, &f)) return rc;
-    if ((int)f.M > 7 || (sign_bits == 1 && (int)f.M > n_bits - 1)) return FP8Q_EINVAL;
+    if (n_bits - sign_bits - (int)f.M < 1) return FP8Q_EUNSUPPORTED;   // no exponent bit: 2^(M+1) steps do not fit M bits
     if (C == 0 || inner == 0) return FP8Q_OK;
     if (!codes || !maxval || (encode ? !x : !y)) return FP8Q_EINVAL;
     const int per_channel = n_maxval != 1;

@@ -133,7 +133,7 @@ int fp8q_affine_act_minmax_f32(const float *x, const float *residual, int64_t N,
  *                   that rounds UP into the next binade is 2^(M+1) s_p in K1 and 2^M s_(p+1) after decoding,
  *                   two fp32 renderings of the same grid point that can differ by ulp(k - bias) ln 2 relative (a few ULP, <= 5e-6 for |bias| < 100; the reference has the
  *                   same ambiguity: it emits either, depending on which side x came from)
- * n_bits <= 8.  The format has no NaN: NaN inputs and degenerate channels (maxval 0/inf/NaN, whose
+ * n_bits <= 8 and at least one exponent bit (FP8Q_EUNSUPPORTED otherwise).  The format has no NaN: NaN inputs and degenerate channels (maxval 0/inf/NaN, whose
  * K1 output is NaN) encode as 0.  HBM traffic: 5 B / element each.
  */
 int fp8q_encode_u8(const float *x, uint8_t *codes, int64_t C, int64_t inner, const float *maxval,

@@ -195,6 +195,10 @@ int orc_encode_u8(const float *x, uint8_t *codes, int64_t C, int64_t inner, cons
                   int64_t n_maxval, float mbits, int n_bits, int sign_bits)
 {
     if ((n_maxval != 1 && n_maxval != C) || n_bits > 8) return -1;
+    {   /* a format without an exponent bit has no code for a value that rounds up to 2^(M+1) steps */
+        orc_chan_t p0 = orc_chan(1.0f, mbits, n_bits, sign_bits);
+        if (n_bits - sign_bits - (int)p0.M < 1) return -2;
+    }
     for (int64_t c = 0; c < C; ++c) {
         orc_chan_t p = orc_chan(maxval[n_maxval == 1 ? 0 : c], mbits, n_bits, sign_bits);
         const int M = (int)p.M;
@@ -205,7 +209,9 @@ int orc_encode_u8(const float *x, uint8_t *codes, int64_t C, int64_t inner, cons
             if (ls < 1.0f) ls = 1.0f;
             float r = rintf(xc / orc_scale(&p, ls));
             uint32_t code = 0;
-            if (r == r && ls == ls) {
+            /* r is an integer in [0, 2^(M+1)] unless the channel is degenerate (s = 0 or NaN: K1 gives NaN there):
+               those, like NaN inputs, take code 0 */
+            if (ls == ls && fabsf(r) <= (float)(2u << M)) {
                 uint32_t ri = (uint32_t)fabsf(r), m2 = 1u << M, e = (uint32_t)ls, f = ri - m2;
                 if (ri < m2) { e = 0; f = ri; }
                 else if (ri == 2 * m2) { e += 1; f = 0; }

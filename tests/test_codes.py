@@ -36,12 +36,21 @@ def test_all_codes_decode_to_the_reference_grid(golden_dir, M):
 
 def test_oracle_roundtrip_equals_quantize():
     rng = np.random.RandomState(0)
-    for M, mv, sb in ((2, 57344.0, 1), (3, 0.7361, 1), (5, 3.0, 1), (3, 2.5, 0), (1, 0.31, 0), (7, 1.0, 1)):
+    for M, mv, sb in ((2, 57344.0, 1), (3, 0.7361, 1), (5, 3.0, 1), (3, 2.5, 0), (1, 0.31, 0), (6, 1.0, 1), (7, 1.0, 0)):
         x = (rng.randn(20000) * mv / 2.2).astype(np.float32)
         x[:6] = [0.0, -0.0, mv, -mv, mv * 3, 1e-30]
         q = oracle.c_quantize(x, [mv], M, 8, sb)
         rt = oracle.c_decode(oracle.c_encode(x, [mv], M, 8, sb), [mv], M, 8, sb)
         assert np.array_equal(rt.view(np.int32), q.view(np.int32)), (M, mv, sb)
+
+
+def test_formats_without_an_exponent_bit_are_not_encodable():
+    """E = n_bits - sign - M = 0 (a uniform grid): K1 supports it, but a value that rounds up to 2^M steps has no
+    code in M fraction bits -- encode / decode refuse instead of emitting colliding codes."""
+    x = np.linspace(-1, 1, 64, dtype=np.float32)
+    with pytest.raises(AssertionError):
+        oracle.c_encode(x, [1.0], 7, 8, 1)
+    assert oracle.c_quantize(x, [1.0], 7, 8, 1).shape == x.shape      # K1 itself is fine
 
 
 def test_roundtrip_on_non_geometric_scale_tables():
@@ -77,7 +86,7 @@ def dev(a, dtype=np.float32):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("M,sb,mv", [(2, 1, 57344.0), (3, 1, 240.0), (3, 1, 0.7361), (5, 1, 3.0), (3, 0, 2.5),
-                                     (1, 0, 0.31), (7, 1, 1.0)])
+                                     (1, 0, 0.31), (6, 1, 1.0), (7, 0, 1.0)])
 @pytest.mark.parametrize("n", [5, 16, 1000, 4096 + 7, 1 << 20])
 def test_hip_codec_per_tensor(M, sb, mv, n):
     import fp8q
@@ -119,6 +128,14 @@ def test_hip_codec_nan_and_degenerate():
     codes = ops.encode(dev(x), dev(mv), 3, 8, 1).cpu().numpy()
     np.testing.assert_array_equal(codes, oracle.c_encode(x, mv, 3, 8, 1))
     assert codes[0, 1] == 0 and (codes[1] == 0).all()                  # no NaN code: documented as 0
+    with pytest.raises(Exception):                                     # no exponent bit: refused (EUNSUPPORTED)
+        ops.encode(dev(x), dev(mv), 7, 8, 1)
+    # a denormal maxval makes every scale underflow to 0 (K1: NaN everywhere): code 0, like the oracle
+    mvd = np.array([2.0, 1e-45], np.float32)
+    xd = np.array([[1.0, -1.0, 0.25, 3.0], [1.0, -1.0, np.inf, 1e-45]], np.float32)
+    cd = ops.encode(dev(xd), dev(mvd), 3, 8, 1).cpu().numpy()
+    np.testing.assert_array_equal(cd, oracle.c_encode(xd, mvd, 3, 8, 1))
+    assert (cd[1] == 0).all()
     # decoding a degenerate channel follows the reference chain's 2^(k - bias): 0 for maxval 0 (bias = +inf)
     dec = ops.decode(dev(codes, np.uint8), dev(mv), 3, 8, 1).cpu().numpy()
     np.testing.assert_array_equal(dec.view(np.int32), oracle.c_decode(codes, mv, 3, 8, 1).view(np.int32))
