@@ -118,10 +118,12 @@ class FP_MSE_Estimator(RangeEstimatorBase):
         super().__init__(*args, **kwargs)
         self.num_candidates = num_candidates
         self.mses = self.search_grid = None
+        self._mbit_list = None
 
     def reset(self):
         super().reset()
         self.mses = self.search_grid = None
+        self._mbit_list = None
 
     def _define_search_range(self, x, n_m):
         if self.search_grid is None:
@@ -138,6 +140,12 @@ class FP_MSE_Estimator(RangeEstimatorBase):
         mbit_list = [float(q.mantissa_bits)]
         if q.mse_include_mantissa_bits:
             mbit_list = [float(m) for m in range(1, q.n_bits - q.sign_bits)]
+        if self.mses is not None and len(mbit_list) != self.mses.shape[0]:
+            # allow_unsigned flipped sign_bits after the first batch (one-sided data), which changes the number of
+            # candidate mantissa widths; the reference indexes past its accumulated [|m|, 111, C] table here
+            # (range_estimators.py:337-347: IndexError).  Keep the candidate set of the first batch.
+            mbit_list = self._mbit_list
+        self._mbit_list = mbit_list
         grid, mses = self._define_search_range(x, len(mbit_list))
         assert mses.shape[1:] == grid.shape, f"{mses.shape}, {grid.shape}"
 
