@@ -32,6 +32,10 @@ for _p in (ROOT, os.path.join(ROOT, "fp8-quantization_amd")):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
+# multi-process GPU work on this pool needs dmabuf IPC; must be in the environment before the HIP runtime starts
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
@@ -234,8 +238,6 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
