@@ -1,0 +1,331 @@
+// fp8q_epilogue.hip -- N2: eval-BN + residual + ReLU/ReLU6 fused with the per-tensor activation quantizer, and its range twin.
+#include "fp8q_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// N2: producer epilogue fused with the activation quantizer:
+//   t = fma(x, alpha_c, fma(-mean_c, alpha_c, beta_c)), alpha_c = invstd_c * gamma_c   (eval-mode BN, NCHW)
+//   t = t + residual                                          (optional)
+//   t = relu(t) / relu6(t)                                    (optional)
+//   QUANT:  y = quantize_to_fp8(t; per-tensor maxval)        MINMAX: min/max of t -> partials
+// i.e. quantized_folded_bn.py:39-55 and models/resnet_quantized.py:43-46 in one pass (8 B/element
+// instead of three 8 B passes).  Flat over N*C*HW; channel of a 16-byte group by two magic
+// divisions, per element only when a group crosses a plane boundary (HW % 4 != 0).
+// ---------------------------------------------------------------------------------------------
+struct AffineArgs {
+    int64_t image;      // C * HW elements per image (multiple of 4, < 2^31)
+    int C, HW;
+    int act;            // 0 none, 1 relu, 2 relu6
+    int has_bn, has_res;
+    int cpp;            // most channels one 4096-element piece can overlap (size of the LDS constants)
+    uint32_t magic;     // o / HW for o < 4096 + HW (magic_of); unused when HW > kAffineMagicMaxHW
+    uint64_t magic48;   // floor(2^48 / HW) + 1:  n / HW == (n * magic48) >> 48  for n * HW < 2^48 (calibration twin)
+};
+constexpr int kAffinePiece = kBlock * 4 * 4;   // elements per block and step (16 KiB)
+constexpr int kAffineMagicMaxHW = kMagicMaxDivisor;   // above: a piece spans <= 2 planes (compare instead of divide)
+
+// act(t + r) -- the non-affine part of the epilogue
+__device__ __forceinline__ float res_act(float t, float r, const AffineArgs &a)
+{
+    if (a.has_res) t = t + r;
+    if (a.act >= 1) t = t < 0.0f ? 0.0f : t;         // NaN stays NaN (torch.relu)
+    if (a.act == 2) t = t > 6.0f ? 6.0f : t;
+    return t;
+}
+
+// blockIdx.y = image n; blockIdx.x strides over the image's C*HW elements in aligned 16 KiB pieces
+// (one piece per block when the grid allows it: measured 6.1-6.3 TB/s against 5.0 for a persistent
+// grid of 2048 blocks).  Eval-mode batch norm exactly as ATen's CPU kernel evaluates it (probed:
+// bit-identical on 100 % of elements): alpha = invstd * gamma, beta' = fma(-mean, alpha, beta),
+// out = fma(x, alpha, beta'); {alpha, beta'} of the planes a piece overlaps are staged in LDS per
+// step, the plane of a 16-byte group comes from one 32-bit magic division of its piece-local offset.
+template <bool NT>
+__global__ void __launch_bounds__(kBlock)
+k_affine_act(const float *__restrict__ x, const float *__restrict__ res, float *__restrict__ y,
+             const float *__restrict__ mean, const float *__restrict__ invstd,
+             const float *__restrict__ gamma, const float *__restrict__ beta,
+             const float *__restrict__ maxval, QFmt f, AffineArgs a)
+{
+    __shared__ float2 lut[kLutMax];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float2 *cst = reinterpret_cast<float2 *>(smem);   // [cpp] {alpha, beta'} (has_bn only)
+    const int tid = threadIdx.x;
+    constexpr int U = 4;
+    const Chan cfull = make_chan(maxval[0], f);
+    for (int i = tid; i <= f.pmax; i += kBlock) lut[i] = lut_entry(cfull, i, f.M);
+    const ChanLite c = lite(cfull);
+    const float pmaxf = (float)f.pmax;
+    const int64_t base0 = (int64_t)blockIdx.y * a.image;
+    const int nvec = (int)(a.image >> 2);
+    const vf4 *xv = reinterpret_cast<const vf4 *>(x + base0);
+    const vf4 *rv = reinterpret_cast<const vf4 *>(res + (a.has_res ? base0 : 0));
+    vf4 *yv = reinterpret_cast<vf4 *>(y + base0);
+    const uint32_t HW = (uint32_t)a.HW;
+    // planes of >= 4096 elements: a piece overlaps at most two, whose constants every thread keeps in registers
+    // (uniform addresses: scalar loads) -- no LDS staging and no barrier per step, which is what separates the BN
+    // variant from the plain one on the large early layers (75 -> 70 us at [64,64,112,112]; the same with up to
+    // four planes in registers, for 56x56 planes, was measured and rejected: 94 us)
+    const bool direct = a.has_bn && a.cpp <= 2;
+    __syncthreads();       // lut is complete
+    for (int base = blockIdx.x * (kBlock * U); base < nvec; base += gridDim.x * (kBlock * U)) {
+        uint32_t phase = 0;
+        float2 p0 = make_float2(1.0f, 0.0f), p1 = p0;
+        if (direct) {
+            const uint32_t e0 = (uint32_t)base * 4u;
+            const uint32_t ch_lo = e0 / HW;
+            phase = e0 - ch_lo * HW;
+            const uint32_t ch_hi = ch_lo + 1u < (uint32_t)a.C ? ch_lo + 1u : ch_lo;
+            const float al0 = invstd[ch_lo] * gamma[ch_lo], al1 = invstd[ch_hi] * gamma[ch_hi];
+            p0 = make_float2(al0, fmaf(-mean[ch_lo], al0, beta[ch_lo]));
+            p1 = make_float2(al1, fmaf(-mean[ch_hi], al1, beta[ch_hi]));
+        }
+        if (a.has_bn && !direct) {
+            __syncthreads();   // the previous step's constants are no longer read
+            const uint32_t e0 = (uint32_t)base * 4u;
+            const uint32_t ch_lo = e0 / HW;
+            phase = e0 - ch_lo * HW;
+            for (int k = tid; k < a.cpp; k += kBlock) {
+                const uint32_t ch = ch_lo + (uint32_t)k;
+                if (ch < (uint32_t)a.C) {
+                    const float alpha = invstd[ch] * gamma[ch];
+                    cst[k] = make_float2(alpha, fmaf(-mean[ch], alpha, beta[ch]));
+                }
+            }
+            __syncthreads();
+        }
+        auto transform = [&](int q, float (&e)[4], const vf4 &r) {   // q: piece-local group index
+            const float rr[4] = {r.x, r.y, r.z, r.w};
+            if (direct) {
+                const uint32_t o = phase + 4u * (uint32_t)q;
+                const bool hi = o >= HW;                    // second plane of the piece
+                uint32_t off = hi ? o - HW : o;
+                float2 p = hi ? p1 : p0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    e[k] = res_act(fmaf(e[k], p.x, p.y), rr[k], a);
+                    if (++off == HW && k < 3) {
+                        off = 0;
+                        p = p1;
+                    }
+                }
+            } else if (a.has_bn) {
+                const uint32_t o = phase + 4u * (uint32_t)q;
+                uint32_t lch = HW > (uint32_t)kAffineMagicMaxHW ? (o >= HW ? 1u : 0u) : (uint32_t)div_small(o, a.magic);
+                uint32_t off = o - lch * HW;
+                float2 p = cst[lch];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    e[k] = res_act(fmaf(e[k], p.x, p.y), rr[k], a);
+                    if (++off == HW && k < 3) {      // the group crosses into the next plane
+                        off = 0;                     // (still inside the image: groups never straddle images)
+                        p = cst[++lch];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) e[k] = res_act(e[k], rr[k], a);
+            }
+        };
+        if (base + kBlock * U <= nvec) {   // whole piece: unpredicated loads, one branch for all its elements
+            vf4 vx[U], vr[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) vx[u] = ld16<NT>(xv + base + u * kBlock + tid);
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                vr[u] = a.has_res ? ld16<NT>(rv + base + u * kBlock + tid) : vf4{0.0f, 0.0f, 0.0f, 0.0f};
+            float e[U * 4];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float t[4] = {vx[u].x, vx[u].y, vx[u].z, vx[u].w};
+                transform(u * kBlock + tid, t, vr[u]);
+                e[4 * u] = t[0];
+                e[4 * u + 1] = t[1];
+                e[4 * u + 2] = t[2];
+                e[4 * u + 3] = t[3];
+            }
+            quant_group<U * 4>(e, c, lut, pmaxf, f.qthr);
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                st16<NT>(yv + base + u * kBlock + tid, vf4{e[4 * u], e[4 * u + 1], e[4 * u + 2], e[4 * u + 3]});
+        } else {
+            for (int u = 0; u < U; ++u) {
+                const int j = base + u * kBlock + tid;
+                if (j >= nvec) break;
+                const vf4 v = ld16<NT>(xv + j);
+                const vf4 r = a.has_res ? ld16<NT>(rv + j) : vf4{0.0f, 0.0f, 0.0f, 0.0f};
+                float e[4] = {v.x, v.y, v.z, v.w};
+                transform(u * kBlock + tid, e, r);
+                quant_group<4>(e, c, lut, pmaxf, f.qthr);
+                st16<NT>(yv + j, vf4{e[0], e[1], e[2], e[3]});
+            }
+        }
+    }
+}
+
+// Calibration twin of k_affine_act: min / max of act(bn(x) + residual) per block -> ws.  Read-only, so the
+// trade-offs differ from the quantizing kernel: a persistent grid of <= 2048 blocks with 4 KiB steps, plain
+// loads and the constants straight from global measured best (36 us at [64,64,112,112]; 16 KiB steps, LDS-staged
+// constants, nontemporal loads or one piece per block: 42-55 us).
+__global__ void __launch_bounds__(kBlock)
+k_affine_minmax(const float *__restrict__ x, const float *__restrict__ res, const float *__restrict__ mean,
+                const float *__restrict__ invstd, const float *__restrict__ gamma,
+                const float *__restrict__ beta, AffineArgs a, int64_t N, float *__restrict__ ws)
+{
+    const int tid = threadIdx.x;
+    MinMax mm;
+    mm_init(mm);
+    const int nvec = (int)(a.image >> 2);
+    const uint32_t HW = (uint32_t)a.HW;
+    for (int64_t img = blockIdx.y; img < N; img += gridDim.y) {   // more than 65535 images: several per block row
+    const int64_t base = img * a.image;
+    const vf4 *xv = reinterpret_cast<const vf4 *>(x + base);
+    const vf4 *rv = reinterpret_cast<const vf4 *>(res + (a.has_res ? base : 0));
+    for (int j = blockIdx.x * kBlock + tid; j < nvec; j += gridDim.x * kBlock) {
+        const vf4 v = xv[j];
+        vf4 r = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (a.has_res) r = rv[j];
+        float e[4] = {v.x, v.y, v.z, v.w};
+        const float rr[4] = {r.x, r.y, r.z, r.w};
+        if (a.has_bn) {
+            const uint32_t i0 = (uint32_t)j * 4u;
+            uint32_t ch = (uint32_t)(((uint64_t)i0 * a.magic48) >> 48);      // plane == channel
+            uint32_t off = i0 - ch * HW;
+            float alpha = invstd[ch] * gamma[ch];
+            float bp = fmaf(-mean[ch], alpha, beta[ch]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                e[q] = res_act(fmaf(e[q], alpha, bp), rr[q], a);
+                if (++off == HW && q < 3) {      // the group crosses into the next plane
+                    off = 0;
+                    ++ch;                         // still < C: the group ends inside the image
+                    alpha = invstd[ch] * gamma[ch];
+                    bp = fmaf(-mean[ch], alpha, beta[ch]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) e[q] = res_act(e[q], rr[q], a);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) mm_acc(mm, e[q]);
+    }
+    }
+    block_reduce_store(mm, ws + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 2);
+}
+
+}  // namespace
+
+extern "C" {
+
+static int affine_args(int64_t N, int64_t C, int64_t HW, int act, bool has_bn, bool has_res, AffineArgs *a)
+{
+    if (N < 0 || C <= 0 || HW <= 0 || act < 0 || act > 2) return FP8Q_EINVAL;
+    // 16-byte groups must not straddle images; 32-bit element indices within an image; the 48-bit magic
+    // division of the calibration twin needs C*HW*HW < 2^48
+    if (((C * HW) & 3) != 0 || C * HW >= (1ll << 31) || HW >= (1 << 24) ||
+        (double)C * (double)HW * (double)HW >= 281474976710656.0)
+        return FP8Q_EUNSUPPORTED;
+    a->image = C * HW;
+    a->C = (int)C;
+    a->HW = (int)HW;
+    a->act = act;
+    a->has_bn = has_bn;
+    a->has_res = has_res;
+    const int64_t cpp = (HW + kAffinePiece - 2) / HW + 1;   // planes a 4096-element window can overlap
+    a->cpp = (int)(cpp < C ? cpp : C);
+    a->magic = HW <= kAffineMagicMaxHW ? magic_of((int)HW) : 0u;
+    a->magic48 = (1ull << 48) / (uint64_t)HW + 1ull;
+    return FP8Q_OK;
+}
+
+static void affine_grid(int64_t N, const AffineArgs &a, bool quant, int64_t *bx, int64_t *by)
+{
+    *by = N < 65535 ? N : 65535;
+    const int64_t nvec = a.image >> 2;
+    if (quant) {
+        // one 16 KiB piece per block while the grid stays below 64 K blocks; a partial last piece of the
+        // image gets no block of its own
+        const int64_t pieces = nvec / (kBlock * 4) > 0 ? nvec / (kBlock * 4) : 1;
+        *bx = balanced_blocks(pieces, (pieces * *by > 4096 ? 65536 : kTargetBlocks) / *by);   // K1's grid rule
+    } else {
+        // read-only twin: a persistent grid of <= 2048 blocks with 4 KiB steps measured best (36 us against
+        // 43-55 us for 16 KiB steps or one piece per block at [64,64,112,112])
+        int64_t b = cdiv(nvec, kBlock * 4);
+        const int64_t cap = kTargetBlocks / *by > 0 ? kTargetBlocks / *by : 1;
+        *bx = b > cap ? cap : (b < 1 ? 1 : b);
+    }
+}
+
+int fp8q_affine_act_quantize_f32(const float *x, const float *residual, float *y, int64_t N, int64_t C,
+                                 int64_t HW, const float *mean, const float *invstd, const float *gamma,
+                                 const float *beta, int act, const float *maxval, float mbits, int n_bits,
+                                 int sign_bits, fp8q_stream_t stream)
+{
+    const bool has_bn = mean != nullptr;
+    if (has_bn && (!invstd || !gamma || !beta)) return FP8Q_EINVAL;
+    AffineArgs a;
+    if (int rc = affine_args(N, C, HW, act, has_bn, residual != nullptr, &a)) return rc;
+    QFmt f;
+    if (int rc = make_fmt(mbits, n_bits, sign_bits, &f)) return rc;
+    if (N == 0) return FP8Q_OK;
+    if (!x || !y || !maxval) return FP8Q_EINVAL;
+    if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual) & 15) return FP8Q_EINVAL;
+    for (int64_t n0 = 0; n0 < N; n0 += 65535) {
+        int64_t bx, by;
+        affine_grid(N - n0, a, true, &bx, &by);
+        const size_t shm = has_bn ? (size_t)a.cpp * sizeof(float2) : 0;
+        if (N * a.image * 4 >= kNtBytes)
+            hipLaunchKernelGGL((k_affine_act<true>), dim3((unsigned)bx, (unsigned)by), dim3(kBlock), shm,
+                               (hipStream_t)stream, x + n0 * a.image, residual ? residual + n0 * a.image : nullptr,
+                               y + n0 * a.image, mean, invstd, gamma, beta, maxval, f, a);
+        else
+            hipLaunchKernelGGL((k_affine_act<false>), dim3((unsigned)bx, (unsigned)by), dim3(kBlock), shm,
+                               (hipStream_t)stream, x + n0 * a.image, residual ? residual + n0 * a.image : nullptr,
+                               y + n0 * a.image, mean, invstd, gamma, beta, maxval, f, a);
+    }
+    return launch_rc();
+}
+
+size_t fp8q_affine_act_minmax_workspace_bytes(int64_t N, int64_t C, int64_t HW)
+{
+    AffineArgs a;
+    if (N <= 0 || affine_args(N, C, HW, 0, false, false, &a) != FP8Q_OK) return 16;
+    int64_t bx, by;
+    affine_grid(N, a, false, &bx, &by);
+    return (size_t)(bx * by) * 2 * sizeof(float) + 16;   // one {min, max} per block
+}
+
+int fp8q_affine_act_minmax_f32(const float *x, const float *residual, int64_t N, int64_t C, int64_t HW,
+                               const float *mean, const float *invstd, const float *gamma, const float *beta,
+                               int act, float *cur_min, float *cur_max, float *maxval_out, int fold_mode,
+                               double momentum, int first, void *ws, size_t ws_bytes, fp8q_stream_t stream)
+{
+    const bool has_bn = mean != nullptr;
+    if (has_bn && (!invstd || !gamma || !beta)) return FP8Q_EINVAL;
+    AffineArgs a;
+    if (int rc = affine_args(N, C, HW, act, has_bn, residual != nullptr, &a)) return rc;
+    if (N <= 0 || !x || !cur_min || !cur_max || fold_mode < 0 || fold_mode > 2) return FP8Q_EINVAL;
+    if (!ws || ws_bytes < fp8q_affine_act_minmax_workspace_bytes(N, C, HW)) return FP8Q_EWORKSPACE;
+    if (((uintptr_t)x | (uintptr_t)residual) & 15) return FP8Q_EINVAL;
+    int64_t bx, by;
+    affine_grid(N, a, false, &bx, &by);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_affine_minmax, dim3((unsigned)bx, (unsigned)by), dim3(kBlock), 0, st, x, residual, mean, invstd,
+                       gamma, beta, a, N, (float *)ws);
+    FoldArgs fa;
+    fa.mode = fold_mode;
+    fa.first = first != 0;
+    fa.om = (float)(1.0 - momentum);
+    fa.mo = (float)momentum;
+    const int nparts = (int)(bx * by);
+    if (nparts > 64)
+        hipLaunchKernelGGL(k_minmax_final_block, dim3(1), dim3(kBlock), 0, st, (const float *)ws, nparts, cur_min,
+                           cur_max, maxval_out, fa);
+    else
+        hipLaunchKernelGGL(k_minmax_final, dim3(1), dim3(kBlock), 0, st, (const float *)ws, (int64_t)1, nparts,
+                           cur_min, cur_max, maxval_out, fa);
+    return launch_rc();
+}
+
+}  // extern "C"

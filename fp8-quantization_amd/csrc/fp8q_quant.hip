@@ -1,4 +1,6 @@
-// fp8q_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels + the C ABI of include/fp8q.h.
+// fp8q_quant.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the quantize / min-max family + their C ABI
+// (include/fp8q.h).  The library has four translation units: this one, fp8q_mse.hip (K4), fp8q_epilogue.hip (N2) and
+// fp8q_codec.hip (N3); fp8q_common.h holds what they share, fp8q_device.h the per-element arithmetic.
 //
 // Every kernel here is elementwise or a reduction: the roofline is HBM bandwidth, not MFMA.
 // Common shape: 256-thread blocks (4 waves, one per SIMD), 16 B per lane per memory instruction
@@ -6,57 +8,20 @@
 // care about most (tools/pattern_sweep.hip) -- every block moves ALIGNED 16 KiB pieces, neighbouring
 // blocks neighbouring pieces, one piece (or one short tile) per block rather than a persistent grid.
 //
-// Kernel inventory:
+// Kernels of this file:
 //   k_quant_rows      K1, one channel per blockIdx.y (per-tensor: one row).  Scale LUT in LDS.
 //   k_rows_flat       per-channel tensors with short rows, cut into aligned 4096-element chunks regardless of
 //                     the rows (per-row tables in LDS): MODE 0 = K1, MODE 1 = K2+K5+K1 fused (rows <= 256).
-//   k_rows_reg        K2+K5+K1 fused for rows of 512..8192 elements: the row stays in registers.
+//   k_rows_reg        K2+K5+K1 fused, or K2 alone, for rows of 128..8192 elements: the row stays in registers.
 //   k_rows_direct     round-1 row-tiled kernel: K2 (+fold) for short rows, rows too short for per-row
 //                     tables, unaligned pointers, the fused cases the two kernels above do not take.
 //   k_multi_flat      multi-tensor K1: one block = one chunk of one of <= 32 tensors.
 //   k_quant_scalar    K1 fallback for x / y that are not 16-byte co-aligned.
-//   k_minmax_partial  K2/K3 stage 1: per-(row, split) min / max / NaN flag.
-//   k_minmax_final    K2/K3 stage 2 + K5: reduce the splits, fold into the running estimate
-//                     (current / all / EMA), write |max(|min|, max)|.
-//   k_mse_grid        K4: all candidate maxvals x mantissa widths in one pass over x.
-//   k_affine_act      N2: eval-BN + residual + ReLU/ReLU6 + per-tensor quantizer; k_affine_minmax: its range twin.
-//   k_codec_rows      N3: storage codes (encode / decode).
+//   k_minmax_partial  K2/K3 stage 1: per-(row, split) min / max / NaN flag  (stage 2 + K5: fp8q_common.h).
 //   k_copy            float4 copy with K1's launch geometry (measured HBM ceiling).
-#include <hip/hip_runtime.h>
-#include <math.h>
-#include <stdint.h>
-#include <stdlib.h>
-
-#include "../../include/fp8q.h"
-#include "fp8q_device.h"
-
-using namespace fp8q;
+#include "fp8q_common.h"
 
 namespace {
-
-constexpr int kUnroll = 4;           // 16-byte loads in flight per lane
-constexpr int kTargetBlocks = 2048;  // 256 CUs x 8 blocks
-constexpr int kDirectMaxInner = 16384; // k_rows_direct handles rows up to here (magic division: n*inner < 2^32)
-constexpr int kDirectElems = 32768;    // elements per k_rows_direct iteration (tables capped at 40 KiB)
-constexpr int64_t kNtBytes = 64ll << 20;  // tensors at least this big stream with nontemporal hints
-
-// Blocks for `pieces` equal pieces of work with at most `cap` blocks: every block gets the same number of
-// steps (a persistent grid of exactly `cap` blocks over 6.1 steps' worth of pieces runs 7 steps: -12 %).
-inline int64_t balanced_blocks(int64_t pieces, int64_t cap)
-{
-    if (cap < 1) cap = 1;
-    if (pieces <= cap) return pieces < 1 ? 1 : pieces;
-    const int64_t steps = (pieces + cap - 1) / cap;
-    return (pieces + steps - 1) / steps;
-}
-
-// n / d == umulhi(n, magic) for n * d < 2^32; magic == 0 encodes d == 1
-inline uint32_t magic_of(int d) { return d <= 1 ? 0u : (uint32_t)((1ull << 32) / (uint64_t)d) + 1u; }
-
-__device__ __forceinline__ int div_small(uint32_t n, uint32_t magic)
-{
-    return magic == 0u ? (int)n : (int)__umulhi(n, magic);
-}
 
 // ---------------------------------------------------------------------------------------------
 // K1 rows: blockIdx.y = row (channel), blockIdx.x strides over the row.  {s, 1/s} table in LDS.
@@ -137,32 +102,6 @@ struct TileArgs {
     uint32_t lmagic;    // n / lut_stride
 };
 
-// torch.min / torch.max of two values (NaN from either side wins)
-__device__ __forceinline__ float tmin(float a, float b) { return (a != a) ? a : ((b != b) ? b : fminf(a, b)); }
-__device__ __forceinline__ float tmax(float a, float b) { return (a != a) ? a : ((b != b) ? b : fmaxf(a, b)); }
-
-struct FoldArgs {
-    int mode;     // FP8Q_FOLD_*
-    int first;    // no previous estimate
-    float om;     // fl32(1 - momentum)   (python double arithmetic, then cast: range_estimators.py:122)
-    float mo;     // fl32(momentum)
-};
-
-__device__ __forceinline__ void fold_store(float mn, float mx, int64_t row, float *cur_min,
-                                           float *cur_max, float *maxval_out, const FoldArgs &fa)
-{
-    if (!fa.first && fa.mode == FP8Q_FOLD_ALL) {
-        mn = tmin(cur_min[row], mn);
-        mx = tmax(cur_max[row], mx);
-    } else if (!fa.first && fa.mode == FP8Q_FOLD_RUNNING) {
-        // (1-m)*new + m*cur as three separately rounded fp32 ops (no FMA: -ffp-contract=off)
-        mn = fa.om * mn + fa.mo * cur_min[row];
-        mx = fa.om * mx + fa.mo * cur_max[row];
-    }
-    if (cur_min) cur_min[row] = mn;
-    if (cur_max) cur_max[row] = mx;
-    if (maxval_out) maxval_out[row] = fabsf(tmax(fabsf(mn), mx));  // fp8_quantizer.py:236
-}
 
 __device__ __forceinline__ ChanLite lite_lds(const Chan *c)
 {
@@ -799,30 +738,9 @@ k_quant_scalar(const float *__restrict__ x, float *__restrict__ y, int64_t inner
 }
 
 // ---------------------------------------------------------------------------------------------
-// K2/K3 stage 1: min / max / NaN of x[row, split range] -> ws[(row * nsplit + split) * 4 ..]
+// K2/K3 stage 1: min / max / NaN of x[row, split range] -> ws[(row * nsplit + split) * 2 ..]
+// (stage 2: k_minmax_final / k_minmax_final_block in fp8q_common.h)
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void block_reduce_store(MinMax m, float *out)
-{
-    __shared__ float s_mn[4], s_mx[4];
-    __shared__ int s_nan[4];
-    mm_wave_reduce(m);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (lane == 0) {
-        s_mn[wave] = m.mn;
-        s_mx[wave] = m.mx;
-        s_nan[wave] = m.nan;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float mn = fminf(fminf(s_mn[0], s_mn[1]), fminf(s_mn[2], s_mn[3]));
-        float mx = fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3]));
-        const int nan = s_nan[0] | s_nan[1] | s_nan[2] | s_nan[3];
-        if (nan) mn = mx = __builtin_nanf("");
-        out[0] = mn;
-        out[1] = mx;
-    }
-}
-
 template <bool NT>
 __global__ void __launch_bounds__(kBlock)
 k_minmax_partial(const float *__restrict__ x, int64_t inner, int nsplit, float *__restrict__ ws)
@@ -870,474 +788,6 @@ k_minmax_partial(const float *__restrict__ x, int64_t inner, int nsplit, float *
     block_reduce_store(m, ws + ((int64_t)row * nsplit + split) * 2);
 }
 
-// K2/K3 stage 2: one wave per row reduces the row's splits (many rows, few splits)
-__global__ void __launch_bounds__(kBlock)
-k_minmax_final(const float *__restrict__ ws, int64_t C, int nsplit, float *cur_min, float *cur_max,
-               float *maxval_out, FoldArgs fa)
-{
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (row >= C) return;
-    MinMax m;
-    mm_init(m);
-    for (int s = lane; s < nsplit; s += 64) {
-        // {min, max} of one split; an EMPTY split (a row a few elements longer than a whole number of steps) holds
-        // {+inf, -inf}, so the two halves must not be mixed
-        const float2 ab = *reinterpret_cast<const float2 *>(ws + (row * nsplit + s) * 2);
-        m.nan |= (ab.x != ab.x) | (ab.y != ab.y);
-        m.mn = fminf(m.mn, ab.x);
-        m.mx = fmaxf(m.mx, ab.y);
-    }
-    mm_wave_reduce(m);
-    if (lane == 0) {
-        if (m.nan) m.mn = m.mx = __builtin_nanf("");
-        fold_store(m.mn, m.mx, row, cur_min, cur_max, maxval_out, fa);
-    }
-}
-
-// K2/K3 stage 2 for few rows with many splits (per-tensor): one block per row, all partial loads
-// independent (the per-tensor activation path is latency-bound here: 2048 partials, one row)
-__global__ void __launch_bounds__(kBlock)
-k_minmax_final_block(const float *__restrict__ ws, int nsplit, float *cur_min, float *cur_max,
-                     float *maxval_out, FoldArgs fa)
-{
-    __shared__ float s_mn[4], s_mx[4];
-    __shared__ int s_nan[4];
-    const int64_t row = blockIdx.x;
-    const int tid = threadIdx.x;
-    MinMax m;
-    mm_init(m);
-    const float2 *w = reinterpret_cast<const float2 *>(ws) + row * nsplit;
-    float2 v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const int s2 = tid + u * kBlock;
-        v[u] = s2 < nsplit ? w[s2] : make_float2(__builtin_inff(), -__builtin_inff());
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        m.nan |= (v[u].x != v[u].x);
-        m.mn = fminf(m.mn, v[u].x);
-        m.mx = fmaxf(m.mx, v[u].y);
-    }
-    for (int s2 = tid + 8 * kBlock; s2 < nsplit; s2 += kBlock) {
-        const float2 ab = w[s2];
-        m.nan |= (ab.x != ab.x) | (ab.y != ab.y);
-        m.mn = fminf(m.mn, ab.x);
-        m.mx = fmaxf(m.mx, ab.y);
-    }
-    mm_wave_reduce(m);
-    if ((tid & 63) == 0) {
-        s_mn[tid >> 6] = m.mn;
-        s_mx[tid >> 6] = m.mx;
-        s_nan[tid >> 6] = m.nan;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        float mn = fminf(fminf(s_mn[0], s_mn[1]), fminf(s_mn[2], s_mn[3]));
-        float mx = fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3]));
-        if (s_nan[0] | s_nan[1] | s_nan[2] | s_nan[3]) mn = mx = __builtin_nanf("");
-        fold_store(mn, mx, row, cur_min, cur_max, maxval_out, fa);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// K4: FP-MSE grid search (range_estimators.py:337-347), ALU-bound.
-// One lane = one candidate maxval; every lane walks the SAME x tile, broadcast out of LDS, so a
-// candidate's squared error accumulates in one register and no cross-lane reduction exists.
-// Block = 128 lanes (candidates i0..i0+127 of one mantissa width m, one row c, one split of the
-// row).  Per-candidate scale LUT (and its reciprocal) in LDS, built with scale_exact(): the
-// scales are the same numbers K1 uses; rint(xc * (1/s)) differs from rint(xc / s) only at exact
-// ties, where |x - q| is the same either way.
-// Dynamic LDS: float xs[kMseTile] | float lut[128 * stride] | float ilut[128 * stride]
-// ---------------------------------------------------------------------------------------------
-constexpr int kMseBlock = 128;
-constexpr int kMseTile = 2048;
-constexpr int kMseMaxM = 8;
-
-struct MseArgs {
-    QFmt fmt[kMseMaxM];
-    int n_m;
-    int n_cand;
-    int cgroups;   // ceil(n_cand / 128)
-    int nsplit;
-    int64_t inner;
-    int64_t C;
-};
-
-__global__ void __launch_bounds__(kMseBlock)
-k_mse_grid(const float *__restrict__ x, const float *__restrict__ grid, double *__restrict__ ws,
-           MseArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float *xs = reinterpret_cast<float *>(smem);
-    const int tid = threadIdx.x;
-    const int split = blockIdx.x;
-    const int m = blockIdx.y / a.cgroups;
-    const int cand = (blockIdx.y - m * a.cgroups) * kMseBlock + tid;
-    const int64_t c = blockIdx.z;
-    const QFmt f = a.fmt[m];
-    const int stride = (f.pmax + 1) | 1;       // odd: lanes at the same p hit different banks
-    float *lut = xs + kMseTile + tid * stride;   // s_p of this candidate, exact (scale_exact)
-    const bool active = cand < a.n_cand;
-
-    // set_quant_range(-g, g): maxval = |max(|-g|, g)|  (fp8_quantizer.py:236)
-    const float gv = active ? grid[(int64_t)cand * a.C + c] : 1.0f;
-    const Chan ch = make_chan(fabsf(fmaxf(fabsf(-gv), gv)), f);
-    lut[0] = __builtin_nanf("");
-    for (int p = 1; p <= f.pmax; ++p) lut[p] = scale_exact(ch, (float)p, f.M);
-    // p = floor(log2|xc| + bias) without a logarithm: with bias = bi + bf, log2|xc| + bias = log2(|xc| 2^bf) + bi,
-    // so p is the exponent field of fl32(|xc| * 2^bf) plus a constant.  An element within a few ulps of a binade
-    // border can land on either side; both sides give the same grid point there (2^(M+1) steps of s_p = 2^M
-    // steps of s_(p+1)), so the squared error is unaffected beyond fp32 rounding.  A non-finite bias makes c1
-    // NaN -> exponent 255 -> p = pmax, whose entry is NaN, like the reference.
-    // 1/s_p is not tabulated (the table is what limits occupancy): 1/s_p = 2^bf * 2^(M + bi - p) up to the
-    // fp32 rounding of the table entry (<= 3e-6 relative), which can only move r = rint(xc / s_p) at an exact
-    // tie, where both neighbours are equally far from x.
-    const float c1 = (float)(1.0 / ch.g);      // 2^bf in [1, 2)
-    // in terms of the raw exponent field e8 of t = xc * c1:  p = clamp(e8 + koff, 1, pmax), koff = bi - 127
-    const int koff = ch.bi - 127;
-    const int e_lo = 1 - koff, e_hi = f.pmax - koff;          // clamp bounds for e8
-    const float *lutk = lut + koff;                             // lutk[e8] == lut[p]
-    const int jk = (int)f.M + ch.bi - koff;                     // ldexp exponent M + bi - p == jk - e8
-    const float *xr = x + c * a.inner;
-    double acc = 0.0;
-
-    for (int64_t t0 = (int64_t)split * kMseTile; t0 < a.inner; t0 += (int64_t)a.nsplit * kMseTile) {
-        const int n = (int)((a.inner - t0) < kMseTile ? (a.inner - t0) : kMseTile);
-        __syncthreads();
-        for (int i = tid; i < kMseTile; i += kMseBlock) xs[i] = i < n ? xr[t0 + i] : 0.0f;
-        __syncthreads();
-        // zero padding: q(0) = 0 exactly, contributes nothing (degenerate maxval -> NaN anyway)
-        const int n32 = (n + 31) & ~31;
-        for (int j = 0; j < n32; j += 32) {
-            float pa = 0.0f;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const float4 v = *reinterpret_cast<const float4 *>(xs + j + u * 4);
-                const float e[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float xv = e[q];
-                    const float xc = __builtin_amdgcn_fmed3f(xv, ch.minv, ch.maxv);
-                    const float tt = xc * c1;
-                    int e8 = (int)__builtin_amdgcn_ubfe(__float_as_uint(tt), 23u, 8u);
-                    e8 = max(min(e8, e_hi), e_lo);
-                    const float r = rintf(ldexpf(tt, jk - e8));
-                    const float d = xv - r * lutk[e8];
-                    pa = fmaf(d, d, pa);
-                }
-            }
-            acc += (double)pa;
-        }
-    }
-    if (active) ws[((c * a.n_m + m) * a.n_cand + cand) * a.nsplit + split] = acc;
-}
-
-// mses[m, i, c] += sum_over_splits / inner
-__global__ void __launch_bounds__(kBlock)
-k_mse_final(const double *__restrict__ ws, float *__restrict__ mses, int64_t C, int n_m, int n_cand,
-            int nsplit, double inv_inner)
-{
-    const int64_t total = C * n_m * n_cand;
-    for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < total;
-         j += (int64_t)gridDim.x * kBlock) {
-        // j indexes ws rows: ((c * n_m + m) * n_cand + i)
-        const int64_t c = j / ((int64_t)n_m * n_cand);
-        const int64_t mi = j - c * n_m * n_cand;   // m * n_cand + i
-        double sum = 0.0;
-        for (int s2 = 0; s2 < nsplit; ++s2) sum += ws[j * nsplit + s2];
-        mses[mi * C + c] += (float)(sum * inv_inner);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// N2: producer epilogue fused with the activation quantizer:
-//   t = fma(x, alpha_c, fma(-mean_c, alpha_c, beta_c)), alpha_c = invstd_c * gamma_c   (eval-mode BN, NCHW)
-//   t = t + residual                                          (optional)
-//   t = relu(t) / relu6(t)                                    (optional)
-//   QUANT:  y = quantize_to_fp8(t; per-tensor maxval)        MINMAX: min/max of t -> partials
-// i.e. quantized_folded_bn.py:39-55 and models/resnet_quantized.py:43-46 in one pass (8 B/element
-// instead of three 8 B passes).  Flat over N*C*HW; channel of a 16-byte group by two magic
-// divisions, per element only when a group crosses a plane boundary (HW % 4 != 0).
-// ---------------------------------------------------------------------------------------------
-struct AffineArgs {
-    int64_t image;      // C * HW elements per image (multiple of 4, < 2^31)
-    int C, HW;
-    int act;            // 0 none, 1 relu, 2 relu6
-    int has_bn, has_res;
-    int cpp;            // most channels one 4096-element piece can overlap (size of the LDS constants)
-    uint32_t magic;     // o / HW for o < 4096 + HW (magic_of); unused when HW > kAffineMagicMaxHW
-    uint64_t magic48;   // floor(2^48 / HW) + 1:  n / HW == (n * magic48) >> 48  for n * HW < 2^48 (calibration twin)
-};
-constexpr int kAffinePiece = kBlock * 4 * 4;   // elements per block and step (16 KiB)
-constexpr int kAffineMagicMaxHW = 60000;       // (4096 + HW) * HW < 2^32; above: a piece spans <= 2 planes
-
-// act(t + r) -- the non-affine part of the epilogue
-__device__ __forceinline__ float res_act(float t, float r, const AffineArgs &a)
-{
-    if (a.has_res) t = t + r;
-    if (a.act >= 1) t = t < 0.0f ? 0.0f : t;         // NaN stays NaN (torch.relu)
-    if (a.act == 2) t = t > 6.0f ? 6.0f : t;
-    return t;
-}
-
-// blockIdx.y = image n; blockIdx.x strides over the image's C*HW elements in aligned 16 KiB pieces
-// (one piece per block when the grid allows it: measured 6.1-6.3 TB/s against 5.0 for a persistent
-// grid of 2048 blocks).  Eval-mode batch norm exactly as ATen's CPU kernel evaluates it (probed:
-// bit-identical on 100 % of elements): alpha = invstd * gamma, beta' = fma(-mean, alpha, beta),
-// out = fma(x, alpha, beta'); {alpha, beta'} of the planes a piece overlaps are staged in LDS per
-// step, the plane of a 16-byte group comes from one 32-bit magic division of its piece-local offset.
-template <bool NT>
-__global__ void __launch_bounds__(kBlock)
-k_affine_act(const float *__restrict__ x, const float *__restrict__ res, float *__restrict__ y,
-             const float *__restrict__ mean, const float *__restrict__ invstd,
-             const float *__restrict__ gamma, const float *__restrict__ beta,
-             const float *__restrict__ maxval, QFmt f, AffineArgs a)
-{
-    __shared__ float2 lut[kLutMax];
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float2 *cst = reinterpret_cast<float2 *>(smem);   // [cpp] {alpha, beta'} (has_bn only)
-    const int tid = threadIdx.x;
-    constexpr int U = 4;
-    const Chan cfull = make_chan(maxval[0], f);
-    for (int i = tid; i <= f.pmax; i += kBlock) lut[i] = lut_entry(cfull, i, f.M);
-    const ChanLite c = lite(cfull);
-    const float pmaxf = (float)f.pmax;
-    const int64_t base0 = (int64_t)blockIdx.y * a.image;
-    const int nvec = (int)(a.image >> 2);
-    const vf4 *xv = reinterpret_cast<const vf4 *>(x + base0);
-    const vf4 *rv = reinterpret_cast<const vf4 *>(res + (a.has_res ? base0 : 0));
-    vf4 *yv = reinterpret_cast<vf4 *>(y + base0);
-    const uint32_t HW = (uint32_t)a.HW;
-    // planes of >= 4096 elements: a piece overlaps at most two, whose constants every thread keeps in registers
-    // (uniform addresses: scalar loads) -- no LDS staging and no barrier per step, which is what separates the BN
-    // variant from the plain one on the large early layers (75 -> 70 us at [64,64,112,112]; the same with up to
-    // four planes in registers, for 56x56 planes, was measured and rejected: 94 us)
-    const bool direct = a.has_bn && a.cpp <= 2;
-    __syncthreads();       // lut is complete
-    for (int base = blockIdx.x * (kBlock * U); base < nvec; base += gridDim.x * (kBlock * U)) {
-        uint32_t phase = 0;
-        float2 p0 = make_float2(1.0f, 0.0f), p1 = p0;
-        if (direct) {
-            const uint32_t e0 = (uint32_t)base * 4u;
-            const uint32_t ch_lo = e0 / HW;
-            phase = e0 - ch_lo * HW;
-            const uint32_t ch_hi = ch_lo + 1u < (uint32_t)a.C ? ch_lo + 1u : ch_lo;
-            const float al0 = invstd[ch_lo] * gamma[ch_lo], al1 = invstd[ch_hi] * gamma[ch_hi];
-            p0 = make_float2(al0, fmaf(-mean[ch_lo], al0, beta[ch_lo]));
-            p1 = make_float2(al1, fmaf(-mean[ch_hi], al1, beta[ch_hi]));
-        }
-        if (a.has_bn && !direct) {
-            __syncthreads();   // the previous step's constants are no longer read
-            const uint32_t e0 = (uint32_t)base * 4u;
-            const uint32_t ch_lo = e0 / HW;
-            phase = e0 - ch_lo * HW;
-            for (int k = tid; k < a.cpp; k += kBlock) {
-                const uint32_t ch = ch_lo + (uint32_t)k;
-                if (ch < (uint32_t)a.C) {
-                    const float alpha = invstd[ch] * gamma[ch];
-                    cst[k] = make_float2(alpha, fmaf(-mean[ch], alpha, beta[ch]));
-                }
-            }
-            __syncthreads();
-        }
-        auto transform = [&](int q, float (&e)[4], const vf4 &r) {   // q: piece-local group index
-            const float rr[4] = {r.x, r.y, r.z, r.w};
-            if (direct) {
-                const uint32_t o = phase + 4u * (uint32_t)q;
-                const bool hi = o >= HW;                    // second plane of the piece
-                uint32_t off = hi ? o - HW : o;
-                float2 p = hi ? p1 : p0;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    e[k] = res_act(fmaf(e[k], p.x, p.y), rr[k], a);
-                    if (++off == HW && k < 3) {
-                        off = 0;
-                        p = p1;
-                    }
-                }
-            } else if (a.has_bn) {
-                const uint32_t o = phase + 4u * (uint32_t)q;
-                uint32_t lch = HW > (uint32_t)kAffineMagicMaxHW ? (o >= HW ? 1u : 0u) : (uint32_t)div_small(o, a.magic);
-                uint32_t off = o - lch * HW;
-                float2 p = cst[lch];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    e[k] = res_act(fmaf(e[k], p.x, p.y), rr[k], a);
-                    if (++off == HW && k < 3) {      // the group crosses into the next plane
-                        off = 0;                     // (still inside the image: groups never straddle images)
-                        p = cst[++lch];
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) e[k] = res_act(e[k], rr[k], a);
-            }
-        };
-        if (base + kBlock * U <= nvec) {   // whole piece: unpredicated loads, one branch for all its elements
-            vf4 vx[U], vr[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) vx[u] = ld16<NT>(xv + base + u * kBlock + tid);
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-                vr[u] = a.has_res ? ld16<NT>(rv + base + u * kBlock + tid) : vf4{0.0f, 0.0f, 0.0f, 0.0f};
-            float e[U * 4];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                float t[4] = {vx[u].x, vx[u].y, vx[u].z, vx[u].w};
-                transform(u * kBlock + tid, t, vr[u]);
-                e[4 * u] = t[0];
-                e[4 * u + 1] = t[1];
-                e[4 * u + 2] = t[2];
-                e[4 * u + 3] = t[3];
-            }
-            quant_group<U * 4>(e, c, lut, pmaxf, f.qthr);
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-                st16<NT>(yv + base + u * kBlock + tid, vf4{e[4 * u], e[4 * u + 1], e[4 * u + 2], e[4 * u + 3]});
-        } else {
-            for (int u = 0; u < U; ++u) {
-                const int j = base + u * kBlock + tid;
-                if (j >= nvec) break;
-                const vf4 v = ld16<NT>(xv + j);
-                const vf4 r = a.has_res ? ld16<NT>(rv + j) : vf4{0.0f, 0.0f, 0.0f, 0.0f};
-                float e[4] = {v.x, v.y, v.z, v.w};
-                transform(u * kBlock + tid, e, r);
-                quant_group<4>(e, c, lut, pmaxf, f.qthr);
-                st16<NT>(yv + j, vf4{e[0], e[1], e[2], e[3]});
-            }
-        }
-    }
-}
-
-// Calibration twin of k_affine_act: min / max of act(bn(x) + residual) per block -> ws.  Read-only, so the
-// trade-offs differ from the quantizing kernel: a persistent grid of <= 2048 blocks with 4 KiB steps, plain
-// loads and the constants straight from global measured best (36 us at [64,64,112,112]; 16 KiB steps, LDS-staged
-// constants, nontemporal loads or one piece per block: 42-55 us).
-__global__ void __launch_bounds__(kBlock)
-k_affine_minmax(const float *__restrict__ x, const float *__restrict__ res, const float *__restrict__ mean,
-                const float *__restrict__ invstd, const float *__restrict__ gamma,
-                const float *__restrict__ beta, AffineArgs a, int64_t N, float *__restrict__ ws)
-{
-    const int tid = threadIdx.x;
-    MinMax mm;
-    mm_init(mm);
-    const int nvec = (int)(a.image >> 2);
-    const uint32_t HW = (uint32_t)a.HW;
-    for (int64_t img = blockIdx.y; img < N; img += gridDim.y) {   // more than 65535 images: several per block row
-    const int64_t base = img * a.image;
-    const vf4 *xv = reinterpret_cast<const vf4 *>(x + base);
-    const vf4 *rv = reinterpret_cast<const vf4 *>(res + (a.has_res ? base : 0));
-    for (int j = blockIdx.x * kBlock + tid; j < nvec; j += gridDim.x * kBlock) {
-        const vf4 v = xv[j];
-        vf4 r = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (a.has_res) r = rv[j];
-        float e[4] = {v.x, v.y, v.z, v.w};
-        const float rr[4] = {r.x, r.y, r.z, r.w};
-        if (a.has_bn) {
-            const uint32_t i0 = (uint32_t)j * 4u;
-            uint32_t ch = (uint32_t)(((uint64_t)i0 * a.magic48) >> 48);      // plane == channel
-            uint32_t off = i0 - ch * HW;
-            float alpha = invstd[ch] * gamma[ch];
-            float bp = fmaf(-mean[ch], alpha, beta[ch]);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                e[q] = res_act(fmaf(e[q], alpha, bp), rr[q], a);
-                if (++off == HW && q < 3) {      // the group crosses into the next plane
-                    off = 0;
-                    ++ch;                         // still < C: the group ends inside the image
-                    alpha = invstd[ch] * gamma[ch];
-                    bp = fmaf(-mean[ch], alpha, beta[ch]);
-                }
-            }
-        } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) e[q] = res_act(e[q], rr[q], a);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) mm_acc(mm, e[q]);
-    }
-    }
-    block_reduce_store(mm, ws + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 2);
-}
-
-// ---------------------------------------------------------------------------------------------
-// N3: storage codes.  One row per blockIdx.y like k_quant_rows; a lane converts 16 consecutive
-// elements per step (4 x 16-byte fp32 accesses <-> one 16-byte access of codes).
-// encode: 4 B read + 1 B written per element; decode: 1 B read + 4 B written.
-// ---------------------------------------------------------------------------------------------
-template <bool ENCODE, bool NT>
-__global__ void __launch_bounds__(kBlock)
-k_codec_rows(const float *__restrict__ x, uint8_t *__restrict__ codes, float *__restrict__ y, int64_t inner,
-             const float *__restrict__ maxval, int per_channel, QFmt f, int n_bits)
-{
-    __shared__ float2 lut[kLutMax];
-    const int row = blockIdx.y, tid = threadIdx.x;
-    const Chan cfull = make_chan(maxval[per_channel ? row : 0], f);
-    for (int i = tid; i <= f.pmax; i += kBlock) lut[i] = lut_entry(cfull, i, f.M);
-    __syncthreads();
-    const ChanLite c = lite(cfull);
-    const float pmaxf = (float)f.pmax;
-    const int M = (int)f.M, sign_shift = f.sign_bits == 1 ? n_bits - 1 : -1;
-    const float *xr = ENCODE ? x + (int64_t)row * inner : nullptr;
-    float *yr = ENCODE ? nullptr : y + (int64_t)row * inner;
-    uint8_t *cr = codes + (int64_t)row * inner;
-    // Vector paths need the row's fp32 side 16-byte aligned (and the code side 4 / 16-byte); otherwise scalar.
-    const uintptr_t fa = (uintptr_t)(ENCODE ? (const void *)xr : (const void *)yr);
-    const bool vec = (fa & 15) == 0 && ((uintptr_t)cr & 3) == 0;
-    const int64_t ngrp = vec ? inner >> 2 : 0;
-    constexpr int U = 4;
-    const vf4 *xv = reinterpret_cast<const vf4 *>(xr);
-    vf4 *yv = reinterpret_cast<vf4 *>(yr);
-    uint32_t *cw = reinterpret_cast<uint32_t *>(cr);
-    if (ENCODE) {
-        // encode: the wide side is the LOAD (strided 16-byte loads of 64 consecutive bytes per lane are absorbed
-        // by L1); a lane converts 16 consecutive elements and stores their codes as one 16-byte word
-        const bool vec16 = vec && ((uintptr_t)cr & 15) == 0;
-        const int64_t ng16 = vec16 ? inner >> 4 : 0;
-        for (int64_t g = (int64_t)blockIdx.x * kBlock + tid; g < ng16; g += (int64_t)gridDim.x * kBlock) {
-            vf4 v[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = xv[g * 4 + k];   // not nontemporal: the line's other quarters hit L1
-            uint32_t w[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                w[k] = encode_one(v[k].x, c, lut, pmaxf, f.qthr, M, sign_shift) |
-                       (encode_one(v[k].y, c, lut, pmaxf, f.qthr, M, sign_shift) << 8) |
-                       (encode_one(v[k].z, c, lut, pmaxf, f.qthr, M, sign_shift) << 16) |
-                       (encode_one(v[k].w, c, lut, pmaxf, f.qthr, M, sign_shift) << 24);
-            *reinterpret_cast<uint4 *>(cr + g * 16) = make_uint4(w[0], w[1], w[2], w[3]);
-        }
-        for (int64_t i = (ng16 << 4) + (int64_t)blockIdx.x * kBlock + tid; i < inner; i += (int64_t)gridDim.x * kBlock)
-            cr[i] = (uint8_t)encode_one(xr[i], c, lut, pmaxf, f.qthr, M, sign_shift);
-        return;
-    }
-    // decode: the wide side is the STORE: lane <-> 4-element group, dword code loads (1 KiB per block and
-    // instruction), whole aligned 16-byte fp32 stores (4 KiB contiguous)
-    for (int64_t base = (int64_t)blockIdx.x * (kBlock * U); base < ngrp; base += (int64_t)gridDim.x * (kBlock * U)) {
-        {
-            uint32_t w[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int64_t q = base + u * kBlock + tid;
-                if (q < ngrp) w[u] = cw[q];
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int64_t q = base + u * kBlock + tid;
-                if (q < ngrp)
-                    st16<NT>(yv + q, vf4{decode_one(w[u] & 255u, lut, M, sign_shift),
-                                         decode_one((w[u] >> 8) & 255u, lut, M, sign_shift),
-                                         decode_one((w[u] >> 16) & 255u, lut, M, sign_shift),
-                                         decode_one(w[u] >> 24, lut, M, sign_shift)});
-            }
-        }
-    }
-    for (int64_t i = (ngrp << 2) + (int64_t)blockIdx.x * kBlock + tid; i < inner; i += (int64_t)gridDim.x * kBlock)
-        yr[i] = decode_one(cr[i], lut, M, sign_shift);
-}
-
 // 16-byte-per-lane copy with K1's launch shape: the achievable-HBM yardstick
 template <bool NT>
 __global__ void __launch_bounds__(kBlock)
@@ -1360,35 +810,6 @@ k_copy(const vf4 *__restrict__ x, vf4 *__restrict__ y, int64_t nvec)
         }
     }
 }
-
-// ---------------------------------------------------------------------------------------------
-// host side
-// ---------------------------------------------------------------------------------------------
-int make_fmt(float mbits, int n_bits, int sign_bits, QFmt *f)
-{
-    if (!(mbits == mbits) || n_bits < 2 || n_bits > 16 || (sign_bits != 0 && sign_bits != 1))
-        return FP8Q_EINVAL;
-    float M = nearbyintf(mbits);  // round half to even (default rounding mode) = torch.round
-    const float hi = (float)(n_bits - sign_bits);
-    if (M < 1.0f) M = 1.0f;
-    if (M > hi) M = hi;
-    const int E = n_bits - sign_bits - (int)M;
-    if (E < 0) return FP8Q_EINVAL;
-    if (E > 7) return FP8Q_EUNSUPPORTED;
-    f->M = M;
-    f->two_E = (float)(1 << E);
-    f->l_c = (float)log2((double)(2.0f - exp2f(-M)));
-    f->qthr = 0.5f - ldexpf(1.0f, (int)M - 20);
-    f->sign_bits = sign_bits;
-    f->pmax = 1 << E;
-    return FP8Q_OK;
-}
-
-inline int hip_rc(hipError_t e) { return e == hipSuccess ? FP8Q_OK : (int)e; }
-inline int launch_rc() { return hip_rc(hipGetLastError()); }
-
-
-inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // K1 / K2: rows up to this length take k_rows_direct, longer ones the 2-D row kernels (measured
 // cross-over: [58254,4608] K1 6.3 TB/s with k_quant_rows vs 5.5 with k_rows_direct).  The fused
@@ -1757,229 +1178,6 @@ int fp8q_minmax_quantize_f32(const float *x, float *y, int64_t C, int64_t inner,
     return launch_rows_direct(kModeFused, x, y, C, inner, nullptr, row_min, row_max, maxval_out, f, nofold, st);
 }
 
-static int mse_nsplit(int64_t C, int64_t inner, int64_t n_cand, int n_m)
-{
-    const int64_t cg = cdiv(n_cand, kMseBlock);
-    int64_t ns = cdiv(inner, kMseTile);
-    int64_t cap = (4 * kTargetBlocks) / (C * n_m * cg > 0 ? C * n_m * cg : 1);
-    if (cap < 1) cap = 1;
-    if (ns > cap) ns = cap;
-    if (ns < 1) ns = 1;
-    return (int)ns;
-}
-
-size_t fp8q_mse_workspace_bytes(int64_t C, int64_t inner, int64_t n_cand, int n_m)
-{
-    if (C <= 0 || inner <= 0 || n_cand <= 0 || n_m <= 0) return 16;
-    return (size_t)C * n_m * n_cand * mse_nsplit(C, inner, n_cand, n_m) * sizeof(double) + 16;
-}
-
-int fp8q_mse_grid_f32(const float *x, int64_t C, int64_t inner, const float *grid, int64_t n_cand,
-                      const float *mbits_host, int n_m, int n_bits, int sign_bits, float *mses,
-                      void *ws, size_t ws_bytes, fp8q_stream_t stream)
-{
-    if (!x || !grid || !mbits_host || !mses || C <= 0 || inner <= 0 || n_cand <= 0 || n_m <= 0 ||
-        n_m > kMseMaxM || n_cand > (1 << 20))
-        return FP8Q_EINVAL;
-    if (!ws || ws_bytes < fp8q_mse_workspace_bytes(C, inner, n_cand, n_m) || ((uintptr_t)ws & 7))
-        return FP8Q_EWORKSPACE;
-    MseArgs a;
-    int pmax_all = 0;
-    for (int m = 0; m < n_m; ++m) {
-        if (int rc = make_fmt(mbits_host[m], n_bits, sign_bits, &a.fmt[m])) return rc;
-        if (a.fmt[m].pmax > pmax_all) pmax_all = a.fmt[m].pmax;
-    }
-    a.n_m = n_m;
-    a.n_cand = (int)n_cand;
-    a.cgroups = (int)cdiv(n_cand, kMseBlock);
-    a.nsplit = mse_nsplit(C, inner, n_cand, n_m);
-    a.inner = inner;
-    a.C = C;
-    hipStream_t st = (hipStream_t)stream;
-    const size_t shmem = (size_t)kMseTile * 4 + (size_t)kMseBlock * ((pmax_all + 1) | 1) * sizeof(float);
-    if (shmem > 64 * 1024) {
-        static int opted = 0;
-        if (!opted) {
-            hipError_t e = hipFuncSetAttribute((const void *)k_mse_grid,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return (int)e;
-            opted = 1;
-        }
-    }
-    for (int64_t c0 = 0; c0 < C; c0 += 65535) {
-        // gridDim.z limit: rows are processed in slabs; ws/grid/mses keep their global indexing
-        const int64_t cn = (C - c0) < 65535 ? (C - c0) : 65535;
-        if (c0 != 0) return FP8Q_EUNSUPPORTED;  // > 65535 channels: not needed by any model here
-        hipLaunchKernelGGL(k_mse_grid, dim3((unsigned)a.nsplit, (unsigned)(n_m * a.cgroups), (unsigned)cn),
-                           dim3(kMseBlock), shmem, st, x, grid, (double *)ws, a);
-    }
-    int64_t fb = cdiv(C * n_m * n_cand, kBlock);
-    if (fb > kTargetBlocks) fb = kTargetBlocks;
-    hipLaunchKernelGGL(k_mse_final, dim3((unsigned)fb), dim3(kBlock), 0, st, (const double *)ws, mses, C,
-                       n_m, (int)n_cand, a.nsplit, 1.0 / (double)inner);
-    return launch_rc();
-}
-
-static int affine_args(int64_t N, int64_t C, int64_t HW, int act, bool has_bn, bool has_res, AffineArgs *a)
-{
-    if (N < 0 || C <= 0 || HW <= 0 || act < 0 || act > 2) return FP8Q_EINVAL;
-    // 16-byte groups must not straddle images; 32-bit element indices within an image; the 48-bit magic
-    // division of the calibration twin needs C*HW*HW < 2^48
-    if (((C * HW) & 3) != 0 || C * HW >= (1ll << 31) || HW >= (1 << 24) ||
-        (double)C * (double)HW * (double)HW >= 281474976710656.0)
-        return FP8Q_EUNSUPPORTED;
-    a->image = C * HW;
-    a->C = (int)C;
-    a->HW = (int)HW;
-    a->act = act;
-    a->has_bn = has_bn;
-    a->has_res = has_res;
-    const int64_t cpp = (HW + kAffinePiece - 2) / HW + 1;   // planes a 4096-element window can overlap
-    a->cpp = (int)(cpp < C ? cpp : C);
-    a->magic = HW <= kAffineMagicMaxHW ? magic_of((int)HW) : 0u;
-    a->magic48 = (1ull << 48) / (uint64_t)HW + 1ull;
-    return FP8Q_OK;
-}
-
-static void affine_grid(int64_t N, const AffineArgs &a, bool quant, int64_t *bx, int64_t *by)
-{
-    *by = N < 65535 ? N : 65535;
-    const int64_t nvec = a.image >> 2;
-    if (quant) {
-        // one 16 KiB piece per block while the grid stays below 64 K blocks; a partial last piece of the
-        // image gets no block of its own
-        const int64_t pieces = nvec / (kBlock * 4) > 0 ? nvec / (kBlock * 4) : 1;
-        *bx = balanced_blocks(pieces, (pieces * *by > 4096 ? 65536 : kTargetBlocks) / *by);   // K1's grid rule
-    } else {
-        // read-only twin: a persistent grid of <= 2048 blocks with 4 KiB steps measured best (36 us against
-        // 43-55 us for 16 KiB steps or one piece per block at [64,64,112,112])
-        int64_t b = cdiv(nvec, kBlock * 4);
-        const int64_t cap = kTargetBlocks / *by > 0 ? kTargetBlocks / *by : 1;
-        *bx = b > cap ? cap : (b < 1 ? 1 : b);
-    }
-}
-
-int fp8q_affine_act_quantize_f32(const float *x, const float *residual, float *y, int64_t N, int64_t C,
-                                 int64_t HW, const float *mean, const float *invstd, const float *gamma,
-                                 const float *beta, int act, const float *maxval, float mbits, int n_bits,
-                                 int sign_bits, fp8q_stream_t stream)
-{
-    const bool has_bn = mean != nullptr;
-    if (has_bn && (!invstd || !gamma || !beta)) return FP8Q_EINVAL;
-    AffineArgs a;
-    if (int rc = affine_args(N, C, HW, act, has_bn, residual != nullptr, &a)) return rc;
-    QFmt f;
-    if (int rc = make_fmt(mbits, n_bits, sign_bits, &f)) return rc;
-    if (N == 0) return FP8Q_OK;
-    if (!x || !y || !maxval) return FP8Q_EINVAL;
-    if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual) & 15) return FP8Q_EINVAL;
-    for (int64_t n0 = 0; n0 < N; n0 += 65535) {
-        int64_t bx, by;
-        affine_grid(N - n0, a, true, &bx, &by);
-        const size_t shm = has_bn ? (size_t)a.cpp * sizeof(float2) : 0;
-        if (N * a.image * 4 >= kNtBytes)
-            hipLaunchKernelGGL((k_affine_act<true>), dim3((unsigned)bx, (unsigned)by), dim3(kBlock), shm,
-                               (hipStream_t)stream, x + n0 * a.image, residual ? residual + n0 * a.image : nullptr,
-                               y + n0 * a.image, mean, invstd, gamma, beta, maxval, f, a);
-        else
-            hipLaunchKernelGGL((k_affine_act<false>), dim3((unsigned)bx, (unsigned)by), dim3(kBlock), shm,
-                               (hipStream_t)stream, x + n0 * a.image, residual ? residual + n0 * a.image : nullptr,
-                               y + n0 * a.image, mean, invstd, gamma, beta, maxval, f, a);
-    }
-    return launch_rc();
-}
-
-size_t fp8q_affine_act_minmax_workspace_bytes(int64_t N, int64_t C, int64_t HW)
-{
-    AffineArgs a;
-    if (N <= 0 || affine_args(N, C, HW, 0, false, false, &a) != FP8Q_OK) return 16;
-    int64_t bx, by;
-    affine_grid(N, a, false, &bx, &by);
-    return (size_t)(bx * by) * 2 * sizeof(float) + 16;   // one {min, max} per block
-}
-
-int fp8q_affine_act_minmax_f32(const float *x, const float *residual, int64_t N, int64_t C, int64_t HW,
-                               const float *mean, const float *invstd, const float *gamma, const float *beta,
-                               int act, float *cur_min, float *cur_max, float *maxval_out, int fold_mode,
-                               double momentum, int first, void *ws, size_t ws_bytes, fp8q_stream_t stream)
-{
-    const bool has_bn = mean != nullptr;
-    if (has_bn && (!invstd || !gamma || !beta)) return FP8Q_EINVAL;
-    AffineArgs a;
-    if (int rc = affine_args(N, C, HW, act, has_bn, residual != nullptr, &a)) return rc;
-    if (N <= 0 || !x || !cur_min || !cur_max || fold_mode < 0 || fold_mode > 2) return FP8Q_EINVAL;
-    if (!ws || ws_bytes < fp8q_affine_act_minmax_workspace_bytes(N, C, HW)) return FP8Q_EWORKSPACE;
-    if (((uintptr_t)x | (uintptr_t)residual) & 15) return FP8Q_EINVAL;
-    int64_t bx, by;
-    affine_grid(N, a, false, &bx, &by);
-    hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_affine_minmax, dim3((unsigned)bx, (unsigned)by), dim3(kBlock), 0, st, x, residual, mean, invstd,
-                       gamma, beta, a, N, (float *)ws);
-    FoldArgs fa;
-    fa.mode = fold_mode;
-    fa.first = first != 0;
-    fa.om = (float)(1.0 - momentum);
-    fa.mo = (float)momentum;
-    const int nparts = (int)(bx * by);
-    if (nparts > 64)
-        hipLaunchKernelGGL(k_minmax_final_block, dim3(1), dim3(kBlock), 0, st, (const float *)ws, nparts, cur_min,
-                           cur_max, maxval_out, fa);
-    else
-        hipLaunchKernelGGL(k_minmax_final, dim3(1), dim3(kBlock), 0, st, (const float *)ws, (int64_t)1, nparts,
-                           cur_min, cur_max, maxval_out, fa);
-    return launch_rc();
-}
-
-static int codec_launch(bool encode, const float *x, uint8_t *codes, float *y, int64_t C, int64_t inner,
-                        const float *maxval, int64_t n_maxval, float mbits, int n_bits, int sign_bits,
-                        fp8q_stream_t stream)
-{
-    if (C < 0 || inner < 0 || (n_maxval != 1 && n_maxval != C) || n_bits > 8) return FP8Q_EINVAL;
-    QFmt f;
-    if (int rc = make_fmt(mbits, n_bits, sign_bits, &f)) return rc;
-    if (n_bits - sign_bits - (int)f.M < 1) return FP8Q_EUNSUPPORTED;   // no exponent bit: 2^(M+1) steps do not fit M bits
-    if (C == 0 || inner == 0) return FP8Q_OK;
-    if (!codes || !maxval || (encode ? !x : !y)) return FP8Q_EINVAL;
-    const int per_channel = n_maxval != 1;
-    if (!per_channel) {
-        inner *= C;
-        C = 1;
-    }
-    for (int64_t c0 = 0; c0 < C; c0 += 65535) {
-        const int64_t cn = (C - c0) < 65535 ? (C - c0) : 65535;
-        const int64_t bx = balanced_blocks(cdiv(cdiv(inner, 16), kBlock), kTargetBlocks / cn);   // 4096 elements per block and step
-        const dim3 g((unsigned)bx, (unsigned)cn), b(kBlock);
-        const bool nt = C * inner * 4 >= kNtBytes;
-        const float *mvp = maxval + (per_channel ? c0 : 0);
-        if (encode && nt)
-            hipLaunchKernelGGL((k_codec_rows<true, true>), g, b, 0, (hipStream_t)stream, x + c0 * inner,
-                               codes + c0 * inner, (float *)nullptr, inner, mvp, per_channel, f, n_bits);
-        else if (encode)
-            hipLaunchKernelGGL((k_codec_rows<true, false>), g, b, 0, (hipStream_t)stream, x + c0 * inner,
-                               codes + c0 * inner, (float *)nullptr, inner, mvp, per_channel, f, n_bits);
-        else if (nt)
-            hipLaunchKernelGGL((k_codec_rows<false, true>), g, b, 0, (hipStream_t)stream, (const float *)nullptr,
-                               codes + c0 * inner, y + c0 * inner, inner, mvp, per_channel, f, n_bits);
-        else
-            hipLaunchKernelGGL((k_codec_rows<false, false>), g, b, 0, (hipStream_t)stream, (const float *)nullptr,
-                               codes + c0 * inner, y + c0 * inner, inner, mvp, per_channel, f, n_bits);
-    }
-    return launch_rc();
-}
-
-int fp8q_encode_u8(const float *x, uint8_t *codes, int64_t C, int64_t inner, const float *maxval,
-                   int64_t n_maxval, float mbits, int n_bits, int sign_bits, fp8q_stream_t stream)
-{
-    return codec_launch(true, x, codes, nullptr, C, inner, maxval, n_maxval, mbits, n_bits, sign_bits, stream);
-}
-
-int fp8q_decode_u8(const uint8_t *codes, float *y, int64_t C, int64_t inner, const float *maxval,
-                   int64_t n_maxval, float mbits, int n_bits, int sign_bits, fp8q_stream_t stream)
-{
-    return codec_launch(false, nullptr, const_cast<uint8_t *>(codes), y, C, inner, maxval, n_maxval, mbits,
-                        n_bits, sign_bits, stream);
-}
-
 int fp8q_multi_quantize_f32(const fp8q_tensor_desc *descs, int n, fp8q_stream_t stream)
 {
     if (n < 0 || (n > 0 && !descs)) return FP8Q_EINVAL;
@@ -2015,7 +1213,7 @@ int fp8q_multi_quantize_f32(const fp8q_tensor_desc *descs, int n, fp8q_stream_t 
         const int64_t rpc = per_channel ? (inner + (kChunkElems + 3) - 2) / inner + 1 : 1;
         const int64_t per_row = 16 + 16 + (int64_t)(f.pmax + 1) * 8;
         const bool batchable = (((uintptr_t)t.x | (uintptr_t)t.y) & 15) == 0 && nelem >= 4 && nelem < (1ll << 31) &&
-                               (!per_channel || (inner >= 4 && inner <= kAffineMagicMaxHW)) &&
+                               (!per_channel || (inner >= 4 && inner <= kMagicMaxDivisor)) &&
                                rpc * per_row <= 36 * 1024 && nelem * 4 < kNtBytes;
         if (!batchable) {   // unaligned, very short rows, or a tensor big enough to deserve its own launch
             if (int rc = flush()) return rc;
