@@ -30,9 +30,24 @@ class RangeEstimatorBase(nn.Module):
         self.per_channel = per_channel
         self.quantizer = quantizer
         self.last_maxval = None   # |max(|xmin|, xmax)| of the latest estimate (device tensor)
+        self.dist_group = None    # set by fp8q.dist.enable_distributed_calibration: data-parallel calibration
 
     def forward(self, x):
         raise NotImplementedError()
+
+    def _sync(self):
+        """Data-parallel calibration (batch sharded over the ranks of `dist_group`): after this rank's update,
+        all-reduce the estimate so that every rank holds what ONE process would have computed on the
+        concatenated batch.  Exact for all three folds: min / max commute with the union, and the EMA
+        (1-m)*new + m*cur is monotone in `new` with the same `cur` on every rank, so max-over-ranks of the folded
+        value equals the fold of the max-over-ranks.  One 16-byte collective per quantizer and batch."""
+        if self.dist_group is None or self.current_xmin is None or self.per_channel:
+            return
+        from fp8q import dist as _fd
+        mn, mx = self.current_xmin.reshape(1).clone(), self.current_xmax.reshape(1).clone()
+        _fd.allreduce_ranges(mn, mx, None if self.dist_group is True else self.dist_group)
+        self.current_xmin, self.current_xmax = mn.reshape(()), mx.reshape(())
+        self.last_maxval = torch.abs(torch.max(torch.abs(mn), mx))      # fp8_quantizer.py:236
 
     def reset(self):
         self.current_xmin = None
@@ -61,6 +76,7 @@ class RangeEstimatorBase(nn.Module):
         if not self.per_channel:      # reference returns 0-dim tensors for per-tensor ranges
             mn, mx = mn.reshape(()), mx.reshape(())
         self.current_xmin, self.current_xmax, self.last_maxval = mn, mx, mv
+        self._sync()
         return self.current_xmin, self.current_xmax
 
 

@@ -149,8 +149,9 @@ class QuantizationManager(nn.Module):
             mn, mx, mv = _ops.affine_act_minmax(x, cur_min, cur_max, mode=est._fold_mode, momentum=est.momentum,
                                                 bn=bn, residual=residual, act=act)
             est.current_xmin, est.current_xmax, est.last_maxval = mn.reshape(()), mx.reshape(()), mv
+            est._sync()                              # data-parallel calibration: global range before quantizing
             if q.set_maxval:
-                q._set_maxval_tensor(mv)
+                q._set_maxval_tensor(est.last_maxval)
         if q.maxval.device != x.device:
             q.maxval = q.maxval.to(x.device)
         return _ops.affine_act_quantize(x, q.maxval, float(q.mantissa_bits), q.n_bits, q.sign_bits, bn=bn,

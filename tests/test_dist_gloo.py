@@ -242,3 +242,74 @@ def test_bucketed_weight_quantization_one_all_gather():
             np.testing.assert_array_equal(mv, rmv)
             ref = oracle.c_quantize(w, rmv, 2, 8, 1)
             assert np.array_equal(np.isnan(q), np.isnan(ref)) and np.array_equal(q[~np.isnan(ref)], ref[~np.isnan(ref)])
+
+
+def _dp_model():
+    import torch.nn as nn
+    from quantization.autoquant_utils import quantize_model
+    from quantization.quantization_manager import QMethods
+    from quantization.range_estimators import RangeEstimators
+    torch.manual_seed(5)
+    net = nn.Sequential(nn.Conv2d(3, 8, 3, padding=1, bias=False), nn.BatchNorm2d(8), nn.ReLU(),
+                        nn.Conv2d(8, 12, 3, stride=2, padding=1, bias=True), nn.ReLU6(),
+                        nn.AdaptiveAvgPool2d(1), nn.Flatten(), nn.Linear(12, 5)).eval()
+    with torch.no_grad():
+        net[1].running_mean.uniform_(-0.2, 0.2)
+        net[1].running_var.uniform_(0.5, 1.5)
+    return net, dict(method=QMethods.fp_quantizer.cls, weight_range_method=RangeEstimators.current_minmax.cls,
+                     n_bits=8, per_channel_weights=True, fp8_kwargs=dict(maxval=None, mantissa_bits=3, set_maxval=True))
+
+
+def _dp_batches():
+    rng = np.random.RandomState(11)
+    return [(rng.randn(6, 3, 10, 10) * s).astype(np.float32) for s in (1.0, 1.6)]      # two calibration steps
+
+
+def _dp_calibrate(act_est, shard=None, world=1):
+    """Calibrate on two steps; with `shard` every rank sees only its images of each step."""
+    import oracle_ops
+    from fp8q import dist as fd
+    from quantization.autoquant_utils import quantize_model
+    from quantization.base_quantized_classes import QuantizedModule
+    from quantization.quantization_manager import QuantizationManager
+    from quantization.range_estimators import RangeEstimators
+    net, qp = _dp_model()
+    q = quantize_model(net, act_range_method=RangeEstimators[act_est].cls, **qp).eval()
+    if shard is not None:
+        assert fd.enable_distributed_calibration(q) > 0
+    outs = []
+    with oracle_ops.patched(), torch.no_grad():
+        for m in q.modules():
+            if isinstance(m, QuantizedModule):
+                m.quantized()
+        for b in _dp_batches():
+            xb = torch.from_numpy(b if shard is None else b[shard::world].copy())
+            outs.append(q(xb).numpy())
+    ranges = {n: (m.range_estimator.current_xmin.numpy().copy(), m.range_estimator.current_xmax.numpy().copy(),
+                  m.quantizer.maxval.numpy().copy())
+              for n, m in q.named_modules() if isinstance(m, QuantizationManager) and m.range_estimator is not None
+              and m.range_estimator.current_xmin is not None}
+    return outs, ranges
+
+
+def _dp_job_all(rank, world):
+    return _dp_calibrate("allminmax", rank, world)
+
+
+def _dp_job_run(rank, world):
+    return _dp_calibrate("running_minmax", rank, world)
+
+
+@pytest.mark.parametrize("est,job", [("allminmax", _dp_job_all), ("running_minmax", _dp_job_run)])
+def test_data_parallel_calibration_equals_single_process(est, job):
+    """enable_distributed_calibration: two ranks, each with half of the images of every calibration step, end up with
+    exactly the ranges -- and produce exactly the activations / logits for their images -- that one process computes
+    on the whole batches (per-layer all-reduce before the batch is quantized; exact for min/max AND for the EMA)."""
+    ref_outs, ref_ranges = _dp_calibrate(est)
+    for rank, (outs, ranges) in enumerate(run(job)):
+        assert ranges.keys() == ref_ranges.keys() and len(ranges) >= 6
+        for name in ranges:
+            for a, b in zip(ranges[name], ref_ranges[name]):
+                np.testing.assert_array_equal(a, b, err_msg=name)
+        for step, (o, r) in enumerate(zip(outs, ref_outs)):
+            np.testing.assert_array_equal(o, r[rank::2], err_msg=f"step {step}")
