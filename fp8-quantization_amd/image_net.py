@@ -84,6 +84,10 @@ def build_parser():
     p.add_argument("--fp8-allow-unsigned", action=_BOOL, default=False)
     # qat option that validate-quantized reads (:184-213)
     p.add_argument("--reestimate-bn-stats", action=_BOOL, default=True)
+    p.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                   help="under torch.distributed.run (WORLD_SIZE > 1): every rank takes its images of each batch; "
+                        "calibration all-reduces the activation ranges per layer (exactly the single-process "
+                        "result), the metrics are summed over the ranks.  nccl = RCCL; gloo for smoke tests")
     p.add_argument("--hip-graph", action=_BOOL, default=False,
                    help="replay the quantized validation forward from a HIP graph (fixed ranges; same results, "
                         "faster for small batches)")
@@ -136,6 +140,20 @@ class SyntheticLoader:
         for _ in range(self.n):
             yield (torch.randn(self.bs, 3, self.size, self.size, generator=g),
                    torch.randint(0, 1000, (self.bs,), generator=g))
+
+
+class RankShard:
+    """Every rank sees images rank::world of each batch of `loader` (all ranks iterate the same batches)."""
+
+    def __init__(self, loader, rank, world):
+        self.loader, self.rank, self.world = loader, rank, world
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        for x, y in self.loader:
+            yield x[self.rank::self.world], y[self.rank::self.world]
 
 
 def imagenet_loaders(images_dir, size, batch_size, workers):
@@ -219,6 +237,11 @@ def evaluate(model, loader, device, fp_model=None, hip_graph=False):
             loss_sum += float(ce(out, y))
             if fp_model is not None:
                 agree += int((fp_model(x).argmax(1) == top[:, 0]).sum())
+    if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+        t = torch.tensor([n, top1, top5, agree, loss_sum], dtype=torch.float64,
+                         device=device if torch.distributed.get_backend() == "nccl" else "cpu")
+        torch.distributed.all_reduce(t)
+        n, top1, top5, agree, loss_sum = int(t[0]), int(t[1]), int(t[2]), int(t[3]), float(t[4])
     res = {"top_1_accuracy": top1 / n, "top_5_accuracy": top5 / n, "loss": loss_sum / n,
            "images": n, "seconds": round(time.time() - t0, 3)}
     if fp_model is not None:
@@ -233,7 +256,16 @@ def validate_quantized(a):
     elif a.deterministic:
         raise ValueError("Enforcing determinism without providing a seed is not supported")
     qparams = quant_params_dict(a)
-    device = torch.device("cuda" if a.cuda else "cpu")
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        if a.cuda:
+            torch.cuda.set_device(local % torch.cuda.device_count())
+        if not dist.is_initialized():
+            dist.init_process_group(a.dist_backend)
+    device = torch.device("cuda", torch.cuda.current_device()) if a.cuda else torch.device("cpu")
     synthetic = a.images_dir is None
     if synthetic:
         n = a.synthetic_batches or 4
@@ -241,6 +273,9 @@ def validate_quantized(a):
         val_loader = SyntheticLoader(n, a.batch_size, a.image_size, 4321)
     else:
         train_loader, val_loader = imagenet_loaders(a.images_dir, a.image_size, a.batch_size, a.num_workers)
+    bn_loader = train_loader          # BN statistics: every rank runs the SAME full batches (replicated, no exchange)
+    if world > 1:
+        train_loader, val_loader = RankShard(train_loader, rank, world), RankShard(val_loader, rank, world)
     pretrained = a.pretrained and a.model_dir is not None
     model = QuantArchitectures[a.architecture](pretrained=pretrained, load_type=a.load_type,
                                                model_dir=a.model_dir, **qparams).to(device)
@@ -250,11 +285,14 @@ def validate_quantized(a):
         # equal), which makes "argmax agreement with fp32" noise: take the BN statistics from synthetic batches
         # first, in full precision -- only in this mode, which the reference does not have
         model.full_precision()
-        reestimate_bn_stats(model, train_loader, 2)
+        reestimate_bn_stats(model, bn_loader, 2)
     if synthetic:
         import copy
         fp_model = copy.deepcopy(model).eval()
         fp_model.full_precision()
+    if world > 1:
+        from fp8q.dist import enable_distributed_calibration
+        enable_distributed_calibration(model)
     if a.load_type == "fp32":
         pass_data_for_range_estimation(loader=train_loader, model=model, act_quant=a.act_quant,
                                        weight_quant=a.weight_quant, max_num_batches=a.num_est_batches)
@@ -262,10 +300,11 @@ def validate_quantized(a):
     model.fix_ranges()
     print("Model with the ranges estimated:\n{}".format(model))
     if a.reestimate_bn_stats:
-        reestimate_bn_stats(model, train_loader, max(1, int(0.02 * len(train_loader))))
+        reestimate_bn_stats(model, bn_loader, max(1, int(0.02 * len(bn_loader))))
     print("Start quantized validation")
     metrics = evaluate(model, val_loader, device, fp_model, hip_graph=a.hip_graph)
-    print(metrics)
+    if rank == 0:
+        print(metrics)
     return metrics
 
 

@@ -1,5 +1,7 @@
 """validate-quantized command: flag names of the reference's README repro line parse, map to the same
 quantization kwargs, and (GPU) the procedure runs end to end on synthetic batches."""
+import os
+
 import pytest
 import torch
 
@@ -58,3 +60,30 @@ def test_validate_quantized_hip_graph_same_metrics():
     for k in ("top_1_accuracy", "top_5_accuracy", "argmax_agreement_with_fp32"):
         assert 0.0 <= graphed[k] <= 1.0
     assert abs(eager["loss"] - graphed["loss"]) <= 0.05 * abs(eager["loss"])
+
+
+@pytest.mark.gpu
+def test_validate_quantized_two_ranks_equal_one_process(tmp_path):
+    """validate-quantized under torch.distributed.run with two ranks (gloo, both on the one GPU of the test box): every
+    rank takes its images of each batch, calibration all-reduces the ranges per layer, metrics are summed -- the
+    result must be the single-process one (same images overall, same ranges)."""
+    import json
+    import subprocess
+    import sys
+    import image_net
+    argv = [f for f in README_FLAGS if not f.startswith("--batch-size") and f != "64"]
+    argv += ["--batch-size", "8", "--synthetic-batches", "3", "--image-size", "64", "--fp8-mantissa-bits=3"]
+    single = image_net.main(argv)
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(here, "fp8-quantization_amd", "image_net.py")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29541", script] + argv + ["--dist-backend", "gloo"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{'top_1_accuracy'")][-1]
+    multi = eval(line)   # noqa: S307  (the script prints a python dict literal)
+    assert multi["images"] == single["images"] == 24
+    # same images, ranges identical by construction; MIOpen may pick other algorithms for the smaller per-rank batch
+    assert abs(multi["loss"] - single["loss"]) <= 0.05 * abs(single["loss"])
+    for k in ("top_1_accuracy", "top_5_accuracy"):
+        assert abs(multi[k] - single[k]) <= 2.0 / 24 + 1e-12
