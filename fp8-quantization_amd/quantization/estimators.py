@@ -141,10 +141,22 @@ class FP_MSE_Estimator(RangeEstimatorBase):
         self.mses = self.search_grid = None
         self._mbit_list = None
 
+    def _dist_batch(self):
+        if self.dist_group is None or self.per_channel:
+            return False
+        import torch.distributed as dist
+        return dist.is_initialized() and dist.get_world_size(self._group()) > 1
+
+    def _group(self):
+        return None if self.dist_group is True else self.dist_group
+
     def _define_search_range(self, x, n_m):
         if self.search_grid is None:
             assert self.mses is None
             _, _, mx = _ops.minmax(x, self.per_channel, want_maxval=True)
+            if self._dist_batch():                          # batch-sharded: the grid comes from the global max
+                import torch.distributed as dist
+                dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=self._group())
             mx_host = mx.detach().cpu().tolist()            # one sync, first batch only
             cols = [torch.linspace(0.1 * m, 1.2 * m, self.N_GRID) for m in mx_host]
             self.search_grid = torch.stack(cols).to(x.device).transpose(0, 1).contiguous()  # [111, C]
@@ -166,11 +178,27 @@ class FP_MSE_Estimator(RangeEstimatorBase):
         assert mses.shape[1:] == grid.shape, f"{mses.shape}, {grid.shape}"
 
         sign_bits = int(torch.any(x < 0)) if q.allow_unsigned else 1
+        if q.allow_unsigned and self._dist_batch():          # any negative value on any rank
+            import torch.distributed as dist
+            flag = torch.tensor([sign_bits], dtype=torch.int32, device=x.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self._group())
+            sign_bits = int(flag.item())
         # the reference calls set_quant_range(-sign*g, g) per candidate: with allow_unsigned and
         # one-sided data that flips the live quantizer to unsigned before the first evaluation
         if q.allow_unsigned and sign_bits == 0:
             q.sign_bits = 0
-        if q.set_maxval:
+        if q.set_maxval and self._dist_batch():
+            # data-parallel calibration: this rank's mean squared errors, weighted by its element count, summed
+            # over the ranks in float64 (<= 2.7 KB) -> the mean over the concatenated batch
+            import torch.distributed as dist
+            inc = torch.zeros_like(mses)
+            _ops.mse_grid(x, self.per_channel, grid, mbit_list, q.n_bits, q.sign_bits, inc)
+            n_local = float(x.numel())
+            packed = torch.cat([inc.double().reshape(-1) * n_local,
+                                torch.tensor([n_local], dtype=torch.float64, device=inc.device)])
+            dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=self._group())
+            mses += (packed[:-1] / packed[-1]).to(mses.dtype).view_as(mses)
+        elif q.set_maxval:
             _ops.mse_grid(x, self.per_channel, grid, mbit_list, q.n_bits, q.sign_bits, mses)
         else:
             # set_maxval=False: set_quant_range is a no-op, every candidate scores the same

@@ -313,3 +313,19 @@ def test_data_parallel_calibration_equals_single_process(est, job):
                 np.testing.assert_array_equal(a, b, err_msg=name)
         for step, (o, r) in enumerate(zip(outs, ref_outs)):
             np.testing.assert_array_equal(o, r[rank::2], err_msg=f"step {step}")
+
+
+def _dp_job_mse(rank, world):
+    return _dp_calibrate("MSE", rank, world)
+
+
+def test_data_parallel_mse_calibration():
+    """The MSE estimator under enable_distributed_calibration: grid from the all-reduced maximum, MSE table from the
+    all-reduced weighted partial sums -> the same ranges as one process on the whole batches (the fixture has no
+    near-ties), hence the same logits."""
+    ref_outs, ref_ranges = _dp_calibrate("MSE")
+    for rank, (outs, ranges) in enumerate(run(_dp_job_mse)):
+        for name in ref_ranges:
+            np.testing.assert_allclose(ranges[name][2], ref_ranges[name][2], rtol=1e-6, err_msg=name)
+        for step, (o, r) in enumerate(zip(outs, ref_outs)):
+            np.testing.assert_allclose(o, r[rank::2], rtol=1e-5, atol=1e-6, err_msg=f"step {step}")
