@@ -189,6 +189,23 @@ __device__ __forceinline__ void lut_row(float2 *lr, const Chan &c, const QFmt &f
     }
 }
 
+// lut_row split over `step` lanes that all hold the channel's constants: lane `sub` writes entries sub, sub + step, ...
+__device__ __forceinline__ void lut_part(float2 *lr, const Chan &c, const QFmt &f, int sub, int step)
+{
+    const float k1 = 1.0f - f.M, kp = (float)f.pmax - f.M;
+    const bool lin = c.pthr >= 0.0f && (k1 - (k1 - c.bias)) == c.bias && (kp - (kp - c.bias)) == c.bias;
+    if (sub == 0) lr[0] = make_float2(__builtin_nanf(""), __builtin_nanf(""));
+    if (lin) {
+        const int j0 = (int)k1 - c.bi - 1;
+        for (int p = sub ? sub : step; p <= f.pmax; p += step) {
+            const float sc = ldexpf(c.m0, j0 + p);
+            lr[p] = make_float2(sc, __builtin_amdgcn_rcpf(sc));
+        }
+    } else {
+        for (int p = sub ? sub : step; p <= f.pmax; p += step) lr[p] = lut_entry(c, p, f.M);
+    }
+}
+
 // the three per-element channel constants the table kernels need
 struct ChanLite {
     float maxv, minv, bias, pthr;
@@ -392,6 +409,17 @@ __device__ __forceinline__ void mm_acc(MinMax &m, float v)
     m.nan |= (v != v);
     m.mn = fminf(m.mn, v);   // fminf/fmaxf drop NaN operands; the flag restores torch semantics
     m.mx = fmaxf(m.mx, v);
+}
+
+// one butterfly step inside a row of 16 lanes (DPP: no LDS crossbar latency); CTRL = quad_perm / row_half_mirror code
+template <int CTRL>
+__device__ __forceinline__ void mm_dpp(MinMax &m)
+{
+    const float mn = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m.mn), CTRL, 0xF, 0xF, true));
+    const float mx = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m.mx), CTRL, 0xF, 0xF, true));
+    m.nan |= __builtin_amdgcn_update_dpp(0, m.nan, CTRL, 0xF, 0xF, true);
+    m.mn = fminf(m.mn, mn);
+    m.mx = fmaxf(m.mx, mx);
 }
 
 __device__ __forceinline__ void mm_wave_reduce(MinMax &m)

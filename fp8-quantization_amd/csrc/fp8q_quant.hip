@@ -310,7 +310,7 @@ struct FlatArgs {
     int rpc;          // table rows per chunk: most rows a window of 4096 (+3 tail) elements can overlap
     int nch;          // chunks per tile (<= kFlatMaxCh)
     int lut_stride;   // pmax + 1
-    int group;        // pass A: lanes per row (power of two <= 64)
+    int group;        // pass A: lanes per row (power of two <= 64); k_rows_staged: log2 of it
     int tail;         // n - 4 * nvec: scalars after the last 16-byte group
     uint32_t magic;   // o / inner
     uint32_t rmagic;  // lr / rpc
@@ -490,6 +490,191 @@ k_rows_flat(const float *__restrict__ x, float *__restrict__ y, const float *__r
                 st16<NT>(yv + q, vf4{e[0], e[1], e[2], e[3]});
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Short rows, fused, staged: k_rows_staged does what k_rows_flat<1> does but fetches every element ONCE.
+// k_rows_flat<1> finds the row ranges with a first pass over global memory and streams the chunk a
+// second time; with ~1000 tiles in flight that second read has left L2 (PMC: 1.86x the tensor fetched,
+// profiles/r01_pmc_other_kernels.json).  Here a block loads its aligned 4096-element chunk once
+// (16 B per lane, coalesced, nontemporal) and parks it in LDS together with the head of the first and
+// the tail of the last overlapping row (<= 255 scalars each, the neighbouring chunks' data); the row
+// min/max, the boundary patches and the quantize pass all read LDS.  The loop is software-pipelined:
+// the next chunk's loads are issued right after the current chunk is parked, so they fly during the
+// four barrier phases.
+// LDS: float win[kStagePad | 4096 | kStagePad] | float4 patch[rpc] | float4 chanlite[rpc] |
+//      float2 lut[rpc * stride]
+// patch[r] = the first (4 - start % 4) % 4 elements of row r, quantized: what the 16-byte group shared with row r-1 stores
+// ---------------------------------------------------------------------------------------------
+constexpr int kStagePad = 256;                                  // >= kFlatFusedMaxInner - 1, multiple of 4
+constexpr int kStageWin = kStagePad + kChunkElems + kStagePad;  // floats
+constexpr size_t kStageMaxLds = 36 * 1024;                      // dynamic LDS per block: 4 blocks per CU with the 3 KiB of statics
+constexpr int kStageGrid = 2048;                                // persistent blocks (FP8Q_STAGED_GRID)
+static_assert(kStagePad >= kFlatFusedMaxInner - 1 && kStagePad % 4 == 0, "border rows must fit the pads");
+
+__device__ __forceinline__ ChunkInfo stage_geometry(int64_t c, const FlatArgs &a)
+{
+    ChunkInfo ci;
+    const int64_t elo = c * kChunkElems;
+    const int64_t rem = a.nvec * 4 - elo;
+    ci.len = rem < kChunkElems ? (int)rem : kChunkElems;
+    ci.tail = (c == a.nchunks - 1) ? a.tail : 0;
+    ci.row_lo = elo / a.inner;
+    ci.phase = (int)(elo - ci.row_lo * a.inner);
+    ci.nrows = (ci.phase + ci.len + ci.tail - 1) / a.inner + 1;
+    ci.pad[0] = ci.nrows * a.inner - ci.phase - ci.len;   // elements of the last row behind the body (tail scalars included)
+    ci.pad[1] = 0;
+    return ci;
+}
+
+template <bool NT>
+__global__ void __launch_bounds__(kBlock, 4)
+k_rows_staged(const float *__restrict__ x, float *__restrict__ y, float *row_min, float *row_max,
+              float *maxval_out, QFmt f, FlatArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ double ftab[kFastTabSize];
+    __shared__ ChunkInfo cinfo[2];
+    float *win = reinterpret_cast<float *>(smem);
+    float4 *patch = reinterpret_cast<float4 *>(win + kStageWin);
+    float4 *chl = patch + a.rpc;
+    float2 *lut = reinterpret_cast<float2 *>(chl + a.rpc);
+    const int tid = threadIdx.x;
+    const int inner = a.inner;
+    const int64_t G = gridDim.x;
+    const float pmaxf = (float)f.pmax;
+    constexpr int U = 4;
+    for (int i = tid; i < kFastTabSize; i += kBlock) ftab[i] = kFastTab[i];
+
+    int64_t c = blockIdx.x;   // gridDim.x <= nchunks
+    vf4 v[U];
+    float bh = 0.0f, bt = 0.0f;
+    {   // prologue: the first chunk's loads
+        const int64_t elo = c * kChunkElems;
+        const int64_t rem = a.nvec * 4 - elo;
+        const int ng = (rem < kChunkElems ? (int)rem : kChunkElems) >> 2;
+        const vf4 *xv = reinterpret_cast<const vf4 *>(x + elo);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (tid + u * kBlock < ng) v[u] = ld16<NT>(xv + tid + u * kBlock);
+        if (tid == 0) cinfo[0] = stage_geometry(c, a);
+        __syncthreads();
+        const int ph = cinfo[0].phase, tb = cinfo[0].pad[0];
+        if (tid < ph) bh = x[elo - ph + tid];
+        if (tid < tb) bt = x[elo + 4 * ng + tid];
+    }
+    int slot = 0;
+    for (;;) {
+        const int64_t elo = c * kChunkElems;
+        const int phase = cinfo[slot].phase, nrows = cinfo[slot].nrows, len = cinfo[slot].len;
+        const int ng = len >> 2;
+        // park the chunk and its two border pieces
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (tid + u * kBlock < ng) *reinterpret_cast<vf4 *>(win + kStagePad + 4 * (tid + u * kBlock)) = v[u];
+        if (tid < phase) win[kStagePad - phase + tid] = bh;
+        if (tid < cinfo[slot].pad[0]) win[kStagePad + len + tid] = bt;
+        const int64_t cn = c + G;
+        const bool more = cn < a.nchunks;
+        if (more && tid == 0) cinfo[slot ^ 1] = stage_geometry(cn, a);
+        __syncthreads();
+        if (more) {   // next chunk: in flight during the phases below
+            const int64_t en = cn * kChunkElems;
+            const int ngn = cinfo[slot ^ 1].len >> 2;
+            const vf4 *xv = reinterpret_cast<const vf4 *>(x + en);
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (tid + u * kBlock < ngn) v[u] = ld16<NT>(xv + tid + u * kBlock);
+            const int ph = cinfo[slot ^ 1].phase, tb = cinfo[slot ^ 1].pad[0];
+            if (tid < ph) bh = x[en - ph + tid];
+            if (tid < tb) bt = x[en + 4 * ngn + tid];
+        }
+        {   // per row, Gl (<= 8) lanes: range from LDS -> channel constants -> table -> the row's head patch
+            const int gs = a.group, Gl = 1 << gs, rpp = kBlock >> gs, sub = tid & (Gl - 1), rs = tid >> gs;
+            const float *w0 = win + (kStagePad - phase);
+            const int last = inner - 1;
+            for (int rb = 0; rb < nrows; rb += rpp) {
+                const int r = rb + rs;
+                const bool valid = r < nrows;
+                MinMax m;
+                mm_init(m);
+                if (valid) {
+                    const float *wr = w0 + r * inner;
+                    for (int j = sub; j < inner; j += 4 * Gl) {   // clamped indices re-read the last element: no remainder loop
+                        const float t0 = wr[j], t1 = wr[min(j + Gl, last)], t2 = wr[min(j + 2 * Gl, last)],
+                                    t3 = wr[min(j + 3 * Gl, last)];
+                        mm_acc(m, t0);
+                        mm_acc(m, t1);
+                        mm_acc(m, t2);
+                        mm_acc(m, t3);
+                    }
+                }
+                if (gs >= 1) mm_dpp<0xB1>(m);    // quad_perm [1,0,3,2]
+                if (gs >= 2) mm_dpp<0x4E>(m);    // quad_perm [2,3,0,1]
+                if (gs >= 3) mm_dpp<0x141>(m);   // row_half_mirror: every lane of the 8 now holds the row's range
+                if (valid) {
+                    if (m.nan) m.mn = m.mx = __builtin_nanf("");
+                    const float mv = fabsf(tmax(fabsf(m.mn), m.mx));   // fp8_quantizer.py:236
+                    if (sub == 0 && (r > 0 || phase == 0)) {   // the row starts in this chunk: this block reports it
+                        const int64_t grow = cinfo[slot].row_lo + r;
+                        if (row_min) row_min[grow] = m.mn;
+                        if (row_max) row_max[grow] = m.mx;
+                        if (maxval_out) maxval_out[grow] = mv;
+                    }
+                    const Chan ch = make_chan_fast(mv, f, ftab);   // the same in all Gl lanes (lockstep: no extra issue slots)
+                    if (sub == 0) chl[r] = make_float4(ch.maxv, ch.minv, ch.bias, ch.pthr);
+                    lut_part(lut + r * a.lut_stride, ch, f, sub, Gl);
+                }
+                // the table was written by this wave's own lanes: DS operations of a wave complete in order
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (valid) {
+                    const int idx = r * inner - phase;   // chunk-local index of the row's first element
+                    if (idx > 0 && idx < len && (idx & 3)) {   // it shares a 16-byte group with the previous row
+                        const ChanLite cl = lite_of(chl[r]);
+                        for (int k = sub; k < 4 - (idx & 3); k += Gl)
+                            reinterpret_cast<float *>(patch)[4 * r + k] =
+                                quant_one(win[kStagePad + idx + k], cl, lut + r * a.lut_stride, pmaxf, f.qthr);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < cinfo[slot].tail) {   // the tensor's last <= 3 elements
+            const int e = len + tid;
+            const int r = div_small((uint32_t)(phase + e), a.magic);
+            y[elo + e] = quant_one(win[kStagePad + e], lite_of(chl[r]), lut + r * a.lut_stride, pmaxf, f.qthr);
+        }
+        {
+            vf4 *yv = reinterpret_cast<vf4 *>(y + elo);
+            vf4 w[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (tid + u * kBlock < ng) w[u] = *reinterpret_cast<const vf4 *>(win + kStagePad + 4 * (tid + u * kBlock));
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int q = tid + u * kBlock;
+                if (q >= ng) break;
+                const int o = phase + 4 * q;
+                const int lrow = div_small((uint32_t)o, a.magic);
+                const int b = inner - (o - lrow * inner);   // elements left in this row (>= 1)
+                float e[4] = {w[u].x, w[u].y, w[u].z, w[u].w};
+                quant_group<4>(e, lite_of(chl[lrow]), lut + lrow * a.lut_stride, pmaxf, f.qthr);
+                if (b < 4) {   // e[b..3] belong to the next row: its head patch
+                    const float4 pt = patch[lrow + 1];
+                    e[3] = b == 3 ? pt.x : (b == 2 ? pt.y : pt.z);
+                    if (b < 3) e[2] = b == 2 ? pt.x : pt.y;
+                    if (b < 2) e[1] = pt.x;
+                }
+                st16<NT>(yv + q, vf4{e[0], e[1], e[2], e[3]});
+            }
+        }
+        if (!more) break;
+        __syncthreads();   // the window and the tables are rewritten by the next chunk
+        c = cn;
+        slot ^= 1;
     }
 }
 
@@ -862,6 +1047,30 @@ int launch_rows_flat(int mode, const float *x, float *y, int64_t C, int64_t inne
         return v >= 1 && v <= kFlatMaxCh ? v : kFlatMaxCh;
     }();
     if (nch > nch_env) nch = nch_env;
+    const bool nt = n * 4 >= kNtBytes;
+    if (mode == kModeFused) {   // one fetch per element: k_rows_staged, if window + tables leave room for 4 blocks per CU
+        static const int staged_env = [] {   // FP8Q_STAGED=0: two-pass k_rows_flat<1> (A/B)
+            const char *e = getenv("FP8Q_STAGED");
+            return e ? atoi(e) : 1;
+        }();
+        static const int staged_grid = [] {   // persistent grid cap; 0 = one chunk per block
+            const char *e = getenv("FP8Q_STAGED_GRID");
+            const int v = e ? atoi(e) : -1;
+            return v >= 0 ? v : kStageGrid;
+        }();
+        const size_t sh = (size_t)kStageWin * sizeof(float) + (size_t)a.rpc * per_row;
+        if (staged_env && sh <= kStageMaxLds) {
+            int gs = 0;
+            while (gs < 6 && (2 << gs) * a.rpc <= kBlock) ++gs;
+            a.group = gs;   // log2(lanes per row) here
+            a.nch = 1;
+            const int64_t blocks = staged_grid ? balanced_blocks(a.nchunks, staged_grid) : a.nchunks;
+            const dim3 g((unsigned)blocks), b(kBlock);
+            if (nt) hipLaunchKernelGGL((k_rows_staged<true>), g, b, sh, st, x, y, row_min, row_max, maxval_out, f, a);
+            else hipLaunchKernelGGL((k_rows_staged<false>), g, b, sh, st, x, y, row_min, row_max, maxval_out, f, a);
+            return launch_rc();
+        }
+    }
     while (nch > 1 && cdiv(a.nchunks, nch) < 1024) --nch;   // small tensors: more blocks, not longer tiles
     a.nch = (int)nch;
     int G = 1;
@@ -875,7 +1084,6 @@ int launch_rows_flat(int mode, const float *x, float *y, int64_t C, int64_t inne
     int64_t blocks = cdiv(a.nchunks, nch);
     if (blocks > grid_env) blocks = grid_env;
     const size_t shmem = (size_t)kFlatMaxCh * sizeof(ChunkInfo) + (size_t)a.rpc * nch * per_row;
-    const bool nt = n * 4 >= kNtBytes;
     const dim3 g((unsigned)blocks), b(kBlock);
     if (mode == kModeQuant) {
         if (nt) hipLaunchKernelGGL((k_rows_flat<kModeQuant, true>), g, b, shmem, st, x, y, maxval, row_min, row_max, maxval_out, f, a);
