@@ -266,7 +266,7 @@ def test_per_channel_constants_fast_vs_libm(ops):
                                      (4, 1536), (100, 576), (31, 333)])
 @pytest.mark.parametrize("M", [2, 3, 4])
 def test_flat_short_row_kernel_geometries(ops, C, inner, M):
-    """k_rows_flat cuts the tensor into aligned 4096-element chunks regardless of the rows: chunk borders
+    """k_rows_flat / k_rows_staged cut the tensor into aligned 4096-element chunks regardless of the rows: chunk borders
     inside rows, rows longer than a chunk, a partial last chunk, <= 3 tail scalars (C*inner % 4 != 0),
     16-byte groups that straddle two rows (inner % 4 != 0).  K1 (also in place) and the fused
     min/max + quantize, bit-exact against the oracle."""
@@ -289,6 +289,28 @@ def test_flat_short_row_kernel_geometries(ops, C, inner, M):
     xi = xd.clone()
     ops.minmax_quantize(xi, M, 8, 1, out=xi)                   # in place: row-tiled kernel (rows owned whole)
     assert_bit_exact(xi.cpu().numpy(), ref, f"fused in place {C}x{inner} M={M}")
+
+
+@pytest.mark.parametrize("C,inner,M", [(200003, 147, 2), (150001, 99, 3), (70001, 255, 2), (300007, 39, 3), (90001, 201, 1)])
+def test_staged_fused_short_rows_many_chunks(ops, C, inner, M):
+    """k_rows_staged (fused min/max + quantize of rows <= 256 elements, the chunk parked in LDS and fetched once): tensors
+    of more chunks than the persistent grid has blocks, so every block runs the software-pipelined loop several times
+    (next chunk's loads in flight during the range / table / patch phase); NaN rows, all-zero rows, rows cut by chunk
+    borders, tail scalars.  Bit-exact against the oracle, reported ranges included."""
+    rng = np.random.RandomState(C % 1000 + inner + M)
+    x = (rng.randn(C, inner) * np.exp(rng.uniform(-3, 3, (C, 1)))).astype(np.float32)
+    x[1] = 0.0
+    x[C // 2, inner // 2] = np.nan
+    x[C - 1, inner - 1] = np.nan
+    x[27:31, 0] = 1e30                                  # rows around the first chunk border
+    mn, mx = oracle.c_minmax(x, True)
+    mv = oracle.c_absmax(mn, mx)
+    ref = oracle.c_quantize(x, mv, M, 8, 1)
+    y, gmn, gmx, gmv = ops.minmax_quantize(dev(x), M, 8, 1)
+    np.testing.assert_array_equal(gmn.cpu().numpy(), mn)
+    np.testing.assert_array_equal(gmx.cpu().numpy(), mx)
+    np.testing.assert_array_equal(gmv.cpu().numpy(), mv)
+    assert_bit_exact(y.cpu().numpy(), ref, f"staged fused {C}x{inner} M={M}")
 
 
 @pytest.mark.parametrize("C,inner", [(9, 512), (33, 1024), (7, 1152), (5, 2048), (6, 2052), (3, 4608), (5, 8192),
