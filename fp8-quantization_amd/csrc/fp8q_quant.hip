@@ -12,9 +12,11 @@
 //   k_quant_rows      K1, one channel per blockIdx.y (per-tensor: one row).  Scale LUT in LDS.
 //   k_rows_flat       per-channel tensors with short rows, cut into aligned 4096-element chunks regardless of
 //                     the rows (per-row tables in LDS): MODE 0 = K1, MODE 1 = K2+K5+K1 fused (rows <= 256).
+//   k_rows_staged     K2+K5+K1 fused for rows <= 256 elements of any length (147): the aligned chunk is fetched once and
+//                     parked in LDS; k_rows_staged_mm = its K2 (+fold) twin for rows of 4..256 elements.
 //   k_rows_reg        K2+K5+K1 fused, or K2 alone, for rows of 128..8192 elements: the row stays in registers.
-//   k_rows_direct     round-1 row-tiled kernel: K2 (+fold) for short rows, rows too short for per-row
-//                     tables, unaligned pointers, the fused cases the two kernels above do not take.
+//   k_rows_direct     round-1 row-tiled kernel: rows too short for per-row tables, unaligned pointers, the
+//                     fused / K2 cases the kernels above do not take.
 //   k_multi_flat      multi-tensor K1: one block = one chunk of one of <= 32 tensors.
 //   k_quant_scalar    K1 fallback for x / y that are not 16-byte co-aligned.
 //   k_minmax_partial  K2/K3 stage 1: per-(row, split) min / max / NaN flag  (stage 2 + K5: fp8q_common.h).
@@ -678,6 +680,98 @@ k_rows_staged(const float *__restrict__ x, float *__restrict__ y, float *row_min
     }
 }
 
+// K2 twin of k_rows_staged: per-row min/max (+ fold into the running estimate) of rows <= 256 elements at any row
+// length and phase.  Loads are the aligned, coalesced 16 KiB chunks of a plain copy (the row-tiled kernel reads
+// row-aligned tiles: 5.2-5.4 TB/s); LDS only transposes them for the G-lanes-per-row reduction.  No tables: 18.4 KiB of
+// LDS and < 64 VGPRs, 8 blocks per CU.
+template <bool NT>
+__global__ void __launch_bounds__(kBlock, 8)
+k_rows_staged_mm(const float *__restrict__ x, float *row_min, float *row_max, float *maxval_out, FoldArgs fa, FlatArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float win[kStageWin];
+    __shared__ ChunkInfo cinfo[2];
+    const int tid = threadIdx.x;
+    const int inner = a.inner;
+    const int64_t G = gridDim.x;
+    constexpr int U = 4;
+    int64_t c = blockIdx.x;   // gridDim.x <= nchunks
+    vf4 v[U];
+    float bh = 0.0f, bt = 0.0f;
+    {
+        const int64_t elo = c * kChunkElems;
+        const int64_t rem = a.nvec * 4 - elo;
+        const int ng = (rem < kChunkElems ? (int)rem : kChunkElems) >> 2;
+        const vf4 *xv = reinterpret_cast<const vf4 *>(x + elo);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (tid + u * kBlock < ng) v[u] = ld16<NT>(xv + tid + u * kBlock);
+        if (tid == 0) cinfo[0] = stage_geometry(c, a);
+        __syncthreads();
+        const int ph = cinfo[0].phase, tb = cinfo[0].pad[0];
+        if (tid < ph) bh = x[elo - ph + tid];
+        if (tid < tb) bt = x[elo + 4 * ng + tid];
+    }
+    int slot = 0;
+    for (;;) {
+        const int phase = cinfo[slot].phase, nrows = cinfo[slot].nrows, len = cinfo[slot].len;
+        const int ng = len >> 2;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (tid + u * kBlock < ng) *reinterpret_cast<vf4 *>(win + kStagePad + 4 * (tid + u * kBlock)) = v[u];
+        if (tid < phase) win[kStagePad - phase + tid] = bh;
+        if (tid < cinfo[slot].pad[0]) win[kStagePad + len + tid] = bt;
+        const int64_t cn = c + G;
+        const bool more = cn < a.nchunks;
+        if (more && tid == 0) cinfo[slot ^ 1] = stage_geometry(cn, a);
+        __syncthreads();
+        if (more) {
+            const int64_t en = cn * kChunkElems;
+            const int ngn = cinfo[slot ^ 1].len >> 2;
+            const vf4 *xv = reinterpret_cast<const vf4 *>(x + en);
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (tid + u * kBlock < ngn) v[u] = ld16<NT>(xv + tid + u * kBlock);
+            const int ph = cinfo[slot ^ 1].phase, tb = cinfo[slot ^ 1].pad[0];
+            if (tid < ph) bh = x[en - ph + tid];
+            if (tid < tb) bt = x[en + 4 * ngn + tid];
+        }
+        {
+            const int gs = a.group, Gl = 1 << gs, rpp = kBlock >> gs, sub = tid & (Gl - 1), rs = tid >> gs;
+            const float *w0 = win + (kStagePad - phase);
+            const int last = inner - 1;
+            const int64_t row_lo = cinfo[slot].row_lo;
+            for (int rb = 0; rb < nrows; rb += rpp) {
+                const int r = rb + rs;
+                const bool valid = r < nrows;
+                MinMax m;
+                mm_init(m);
+                if (valid) {
+                    const float *wr = w0 + r * inner;
+                    for (int j = sub; j < inner; j += 4 * Gl) {
+                        const float t0 = wr[j], t1 = wr[min(j + Gl, last)], t2 = wr[min(j + 2 * Gl, last)],
+                                    t3 = wr[min(j + 3 * Gl, last)];
+                        mm_acc(m, t0);
+                        mm_acc(m, t1);
+                        mm_acc(m, t2);
+                        mm_acc(m, t3);
+                    }
+                }
+                if (gs >= 1) mm_dpp<0xB1>(m);
+                if (gs >= 2) mm_dpp<0x4E>(m);
+                if (gs >= 3) mm_dpp<0x141>(m);
+                if (valid && sub == 0 && (r > 0 || phase == 0)) {   // the chunk in which a row starts reports it
+                    if (m.nan) m.mn = m.mx = __builtin_nanf("");
+                    fold_store(m.mn, m.mx, row_lo + r, row_min, row_max, maxval_out, fa);
+                }
+            }
+        }
+        if (!more) break;
+        __syncthreads();   // the window is rewritten by the next chunk
+        c = cn;
+        slot ^= 1;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Multi-tensor K1: every weight tensor of a model in ONE launch (21 launches of ~7 us each for
 // ResNet-18's 11.7 M weights are launch-bound; the data is 47 MB).  One block = one aligned 4096-element
@@ -1095,6 +1189,37 @@ int launch_rows_flat(int mode, const float *x, float *y, int64_t C, int64_t inne
     return launch_rc();
 }
 
+// k_rows_staged_mm for [C, inner]: rows of 4..256 elements, x 16-byte aligned; kNotFlat otherwise
+int launch_rows_staged_mm(const float *x, int64_t C, int64_t inner, float *row_min, float *row_max, float *maxval_out,
+                          const FoldArgs &fa, hipStream_t st)
+{
+    static const int staged_env = [] {   // FP8Q_STAGED=0: row-tiled k_rows_direct<2> (A/B)
+        const char *e = getenv("FP8Q_STAGED");
+        return e ? atoi(e) : 1;
+    }();
+    if (!staged_env || inner < 4 || inner > kFlatFusedMaxInner || ((uintptr_t)x & 15) != 0) return kNotFlat;
+    FlatArgs a = {};
+    a.inner = (int)inner;
+    const int64_t n = C * inner;
+    a.nvec = n >> 2;
+    a.tail = (int)(n & 3);
+    a.nchunks = cdiv(a.nvec, kChunkGroups);
+    a.rpc = (int)((inner + (kChunkElems + 3) - 2) / inner) + 1;
+    int gs = 0;
+    while (gs < 3 && (2 << gs) * a.rpc <= kBlock) ++gs;
+    a.group = gs;
+    static const int grid_env = [] {
+        const char *e = getenv("FP8Q_STAGED_MM_GRID");   // persistent-grid cap; 0 = one chunk per block (measured best: no stores to wait for)
+        const int v = e ? atoi(e) : -1;
+        return v >= 0 ? v : 0;
+    }();
+    const int64_t blocks = grid_env ? balanced_blocks(a.nchunks, grid_env) : a.nchunks;
+    const dim3 g((unsigned)blocks), b(kBlock);
+    if (n * 4 >= kNtBytes) hipLaunchKernelGGL((k_rows_staged_mm<true>), g, b, 0, st, x, row_min, row_max, maxval_out, fa, a);
+    else hipLaunchKernelGGL((k_rows_staged_mm<false>), g, b, 0, st, x, row_min, row_max, maxval_out, fa, a);
+    return launch_rc();
+}
+
 // k_rows_reg for [C, inner] if the rows suit it (128..8192 elements, a multiple of 4, 16-byte aligned, lanes well
 // filled); kNotFlat otherwise.  quant: fused min/max + quantize; else K2 (min/max + fold).
 int launch_rows_reg(bool quant, const float *x, float *y, int64_t C, int64_t inner, float *row_min, float *row_max,
@@ -1335,6 +1460,10 @@ int fp8q_minmax_f32(const float *x, int64_t C, int64_t inner, float *cur_min, fl
     if (C > 1) {   // per-channel rows of 128..8192 elements: one launch, the row in registers
         QFmt f = {};
         const int rc = launch_rows_reg(false, x, nullptr, C, inner, cur_min, cur_max, maxval_out, f, fa, st);
+        if (rc != kNotFlat) return rc;
+    }
+    if (C > 1) {   // short rows: aligned chunks through LDS
+        const int rc = launch_rows_staged_mm(x, C, inner, cur_min, cur_max, maxval_out, fa, st);
         if (rc != kNotFlat) return rc;
     }
     if (inner <= direct_max_inner() && C > 1 && ((uintptr_t)x & 3) == 0) {

@@ -313,6 +313,31 @@ def test_staged_fused_short_rows_many_chunks(ops, C, inner, M):
     assert_bit_exact(y.cpu().numpy(), ref, f"staged fused {C}x{inner} M={M}")
 
 
+@pytest.mark.parametrize("C,inner", [(2, 147), (29, 147), (70001, 147), (333, 255), (7001, 99), (50021, 41), (100003, 9),
+                                     (40000, 5), (77777, 4), (5, 250), (300007, 27), (28, 256)])
+def test_staged_minmax_short_rows(ops, C, inner):
+    """k_rows_staged_mm (per-channel min/max of rows <= 256 elements through aligned chunks parked in LDS): rows cut by
+    chunk borders, several rows-per-pass geometries (1..8 lanes per row), tail scalars, NaN rows; overwrite, all-min/max
+    and EMA folds into a running estimate.  Equal to the oracle bit for bit."""
+    rng = np.random.RandomState(C % 977 + inner)
+    x = rng.randn(C, inner).astype(np.float32)
+    x[C // 2, inner // 2] = np.nan
+    x[0] = 0.0
+    rmn, rmx = oracle.c_minmax(x, True)
+    mn, mx, mv = ops.minmax(dev(x), True, want_maxval=True)
+    np.testing.assert_array_equal(mn.cpu().numpy(), rmn)
+    np.testing.assert_array_equal(mx.cpu().numpy(), rmx)
+    np.testing.assert_array_equal(mv.cpu().numpy(), oracle.c_absmax(rmn, rmx))
+    x2 = (rng.randn(C, inner) * 1.5).astype(np.float32)
+    r2 = oracle.c_minmax(x2, True)
+    for mode in (1, 2):
+        cur = ops.minmax(dev(x), True, mode=mode, momentum=0.9)
+        cur = ops.minmax(dev(x2), True, cur[0], cur[1], mode=mode, momentum=0.9)
+        emn, emx = oracle.c_fold(rmn, rmx, r2[0], r2[1], mode, 0.9)
+        np.testing.assert_array_equal(cur[0].cpu().numpy(), emn)
+        np.testing.assert_array_equal(cur[1].cpu().numpy(), emx)
+
+
 @pytest.mark.parametrize("C,inner", [(9, 512), (33, 1024), (7, 1152), (5, 2048), (6, 2052), (3, 4608), (5, 8192),
                                      (2, 8196), (13, 576), (4, 260), (1, 1024), (257, 1280), (50, 128), (35, 192),
                                      (19, 288), (70, 384), (3, 7168), (17, 124)])

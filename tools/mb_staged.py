@@ -51,3 +51,25 @@ for rows, inner, M in (((1 << 21) + 77, 99, 3), (1 << 20, 201, 2), (1 << 20, 255
     xk = xw.view(-1)[: rows * inner].view(rows, inner)
     yk = yw.view(-1)[: rows * inner].view(rows, inner)
     report(f"[{tag}] fused [{rows},{inner}] M={M}", xk.numel(), 8, timeit(lambda: ops.minmax_quantize(xk, M, 8, 1, out=yk)))
+
+# K2 twin (k_rows_staged_mm): row ranges against torch, then timings
+if CHECK:
+    n_ok = n = 0
+    for i, (C, inner) in enumerate([(2, 147), (29, 147), (1000, 147), (65537, 147), (333, 255), (7001, 99), (9000, 67), (50021, 41),
+                                    (100003, 9), (300000, 27), (40000, 5), (77777, 4), (12345, 131), (5, 250), (1 << 16, 98)]):
+        g = torch.Generator(device=dev).manual_seed(500 + i)
+        x = torch.randn(C, inner, device=dev, generator=g)
+        if i % 3 == 0:
+            x[C // 2, inner // 2] = float("nan")
+        mn, mx, mv = ops.minmax(x, True, want_maxval=True)
+        rmn, rmx = x.amin(1), x.amax(1)
+        ok = (torch.equal(mn.view(torch.int32), rmn.view(torch.int32)) and torch.equal(mx.view(torch.int32), rmx.view(torch.int32))
+              and torch.equal(mv.view(torch.int32), torch.maximum(rmn.abs(), rmx).abs().view(torch.int32)))
+        n += 1
+        n_ok += ok
+        if not ok:
+            print(f"[{tag}] K2 MISMATCH C={C} inner={inner}: {(mn != rmn).sum().item()} mins, {(mx != rmx).sum().item()} maxs", flush=True)
+    print(f"[{tag}] K2 check: {n_ok}/{n} geometries equal to torch amin/amax", flush=True)
+for rows, inner in ((1 << 21, 147), ((1 << 21) + 77, 99), (1 << 20, 201), (1 << 22, 70), (1 << 24, 9), (1 << 23, 27), (1 << 17, 147)):
+    xk = xw.view(-1)[: rows * inner].view(rows, inner)
+    report(f"[{tag}] K2 [{rows},{inner}]", xk.numel(), 4, timeit(lambda: ops.minmax(xk, True)))
