@@ -35,4 +35,9 @@ elif which == "tensor":
     mv = torch.tensor([3.0], device=dev)
     for _ in range(reps):
         ops.quantize(x, mv, 3, 8, 1, out=y)
+elif which == "k3":
+    x = torch.randn(64, 64, 112, 112, device=dev)
+    cur = ops.minmax(x, False)
+    for _ in range(reps):
+        cur = ops.minmax(x, False, cur[0], cur[1], mode=1)
 torch.cuda.synchronize()
