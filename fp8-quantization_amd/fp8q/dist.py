@@ -83,14 +83,16 @@ def sync_activation_ranges(model, group=None):
 
 
 def enable_distributed_calibration(model, group=None, enable=True):
-    """Batch-sharded (data-parallel) calibration that is EXACTLY the single-process calibration on the concatenated
-    batch: every per-tensor min/max estimator of `model` all-reduces its estimate right after each update, i.e.
-    before the batch is quantized with it (the reference's order, quantization_manager.py:119-122), so downstream
-    layers see the same activations as in one process.  One 16-byte all-reduce per activation quantizer and batch
-    (ResNet-18: 30); the MSE estimator exchanges its grid maximum once and its partial MSE table (<= 2.7 KB) per batch,
-    equal to the single-process table up to the fp32 rounding of the per-rank means; use sync_activation_ranges instead for a single collective at the end when the activations seen
-    DURING calibration may differ.  Weights need nothing: every rank holds all channels.  Returns the number of
-    estimators switched."""
+    """Batch-sharded (data-parallel) calibration that is EXACTLY the single-process calibration on the
+    concatenated batch: every per-tensor min/max estimator of `model` all-reduces its estimate right after each
+    update, i.e. before the batch is quantized with it (the reference's order, quantization_manager.py:119-122),
+    so downstream layers see the same activations as in one process.
+
+    Cost: one 16-byte all-reduce per activation quantizer and batch (ResNet-18: 30).  The MSE estimator exchanges
+    its grid maximum once and its partial MSE table (<= 2.7 KB) per batch; the combined table equals the
+    single-process one up to the fp32 rounding of the per-rank means.  Weights need nothing: every rank holds all
+    channels.  Use sync_activation_ranges() instead for a single collective at the end, when it is acceptable that
+    the activations seen DURING calibration differ between ranks.  Returns the number of estimators switched."""
     from quantization.manager import QuantizationManager
     from quantization.estimators import (AllMinMaxEstimator, CurrentMinMaxEstimator, RunningMinMaxEstimator,
                                          FP_MSE_Estimator)
