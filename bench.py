@@ -121,6 +121,11 @@ def extras(ops, dev):
     ya = y[: a.numel()].view_as(a)
     rec("k1_act_64x64x112x112_e5m2", a.numel(), 8, lambda: ops.quantize(a, mv1, 2, 8, 1, out=ya))
     rec("k3_act_64x64x112x112_allminmax", a.numel(), 4, lambda: ops.minmax(a, False))
+    # the headline shape in estimate state: current_minmax + quantize fused (k_rows_staged), and the estimator alone
+    xc = x[: (1 << 20) * 147].view(1 << 20, 3, 7, 7)
+    yc = y[: xc.numel()].view_as(xc)
+    rec("fused_minmax_quant_Nx3x7x7_e5m2", xc.numel(), 8, lambda: ops.minmax_quantize(xc, 2, 8, 1, out=yc))
+    rec("k2_minmax_per_channel_Nx3x7x7", xc.numel(), 4, lambda: ops.minmax(xc, True))
     # other ResNet-18 filter shapes, scaled up the same way (per-channel E5M2, fixed ranges / fused estimate)
     for name, rows, shape in (("64x3x3", 1 << 18, (64, 3, 3)), ("512x3x3", 58254, (512, 3, 3))):
         inner = shape[0] * shape[1] * shape[2]
