@@ -225,23 +225,34 @@ def _bucket_weights():
     return [(rng.randn(*shp) * 0.1).astype(np.float32) for shp in ((13, 3, 3, 3), (8, 13, 1, 1), (5, 8), (1, 7), (16, 4, 3, 3))]
 
 
-def _bucket_job(rank, world):
+def _bucket_job(rank, world, bucket_bytes=None):
     from fp8q import dist as fd
-    out = fd.quantize_weights_sharded_bucketed([torch.from_numpy(w) for w in _bucket_weights()], 2, 8, 1, ops=OracleOps)
+    out = fd.quantize_weights_sharded_bucketed([torch.from_numpy(w) for w in _bucket_weights()], 2, 8, 1, ops=OracleOps,
+                                               bucket_bytes=bucket_bytes)
     return [(q.numpy(), mv.numpy()) for q, mv in out]
+
+
+def _bucket_job_small(rank, world):
+    return _bucket_job(rank, world, bucket_bytes=600)      # 5 tensors -> 3 buckets, async all-gathers
+
+
+def _bucket_job_tiny(rank, world):
+    return _bucket_job(rank, world, bucket_bytes=1)        # every tensor its own bucket
 
 
 def test_bucketed_weight_quantization_one_all_gather():
     """All layers' channel shards in one packed buffer and ONE all-gather (uneven splits, a 1-channel tensor that
-    only rank 0 owns): every rank ends up with exactly the single-process quantized tensors and ranges."""
+    only rank 0 owns), or packed into several buckets whose all-gathers are launched asynchronously while the next
+    bucket is quantized: every rank ends up with exactly the single-process quantized tensors and ranges."""
     ws = _bucket_weights()
-    for res in run(_bucket_job):
-        for w, (q, mv) in zip(ws, res):
-            mn, mx = oracle.c_minmax(w, True)
-            rmv = oracle.c_absmax(mn, mx)
-            np.testing.assert_array_equal(mv, rmv)
-            ref = oracle.c_quantize(w, rmv, 2, 8, 1)
-            assert np.array_equal(np.isnan(q), np.isnan(ref)) and np.array_equal(q[~np.isnan(ref)], ref[~np.isnan(ref)])
+    for job in (_bucket_job, _bucket_job_small, _bucket_job_tiny):
+        for res in run(job):
+            for w, (q, mv) in zip(ws, res):
+                mn, mx = oracle.c_minmax(w, True)
+                rmv = oracle.c_absmax(mn, mx)
+                np.testing.assert_array_equal(mv, rmv)
+                ref = oracle.c_quantize(w, rmv, 2, 8, 1)
+                assert np.array_equal(np.isnan(q), np.isnan(ref)) and np.array_equal(q[~np.isnan(ref)], ref[~np.isnan(ref)])
 
 
 def _dp_model():
