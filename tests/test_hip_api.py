@@ -387,6 +387,15 @@ def test_dist_helpers_single_process_on_hip():
     q2, m2, codes = fd.quantize_weight_sharded_codes(dev(w), 2, 8, 1)
     assert np.array_equal(q2.cpu().numpy().view(np.int32), ref.view(np.int32)) and codes.dtype == torch.uint8
     np.testing.assert_array_equal(m2.cpu().numpy(), mv)
+    ws = [w, (rng.randn(8, 13) * 0.3).astype(np.float32), (rng.randn(1, 7)).astype(np.float32),
+          (rng.randn(64, 3, 7, 7) * 0.1).astype(np.float32)]
+    for bucket_bytes in (None, 1, 4096):                      # one bucket / one per tensor / packed by size
+        outs = fd.quantize_weights_sharded_bucketed([dev(t) for t in ws], 2, 8, 1, bucket_bytes=bucket_bytes)
+        for t, (qb, mb) in zip(ws, outs):
+            tmn, tmx = oracle.c_minmax(t, True)
+            tmv = oracle.c_absmax(tmn, tmx)
+            np.testing.assert_array_equal(mb.cpu().numpy(), tmv)
+            assert np.array_equal(qb.cpu().numpy().view(np.int32), oracle.c_quantize(t, tmv, 2, 8, 1).view(np.int32))
     x = (rng.randn(4, 8, 5, 5)).astype(np.float32)
     y, st = fd.calibrate_quantize_sharded(dev(x), 3, 8, 1)
     pmn, pmx = oracle.c_minmax(x, False)
