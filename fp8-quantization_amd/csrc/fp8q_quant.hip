@@ -530,6 +530,65 @@ __device__ __forceinline__ ChunkInfo stage_geometry(int64_t c, const FlatArgs &a
     return ci;
 }
 
+// ---- pieces shared by k_rows_staged and k_rows_staged_mm (one 4096-element chunk per step, 256 threads) --------------
+constexpr int kStageU = 4;   // 16-byte groups per lane and chunk
+
+// the chunk's aligned body: 4 x 16 B per lane, coalesced (needs only the chunk index)
+template <bool NT>
+__device__ __forceinline__ void stage_load_body(const float *x, int64_t c, const FlatArgs &a, vf4 (&v)[kStageU])
+{
+    const int64_t elo = c * kChunkElems;
+    const int64_t rem = a.nvec * 4 - elo;
+    const int ng = (rem < kChunkElems ? (int)rem : kChunkElems) >> 2;
+    const vf4 *xv = reinterpret_cast<const vf4 *>(x + elo);
+#pragma unroll
+    for (int u = 0; u < kStageU; ++u)
+        if ((int)threadIdx.x + u * kBlock < ng) v[u] = ld16<NT>(xv + threadIdx.x + u * kBlock);
+}
+
+// head of the first and tail of the last overlapping row: <= 255 scalars each, one per thread (needs the geometry)
+__device__ __forceinline__ void stage_load_borders(const float *x, int64_t c, const ChunkInfo &ci, float &bh, float &bt)
+{
+    const int64_t elo = c * kChunkElems;
+    const int tid = threadIdx.x;
+    if (tid < ci.phase) bh = x[elo - ci.phase + tid];
+    if (tid < ci.pad[0]) bt = x[elo + ci.len + tid];
+}
+
+// registers -> LDS window: body at [kStagePad, kStagePad + len), the border pieces right before / behind it
+__device__ __forceinline__ void stage_park(float *win, const ChunkInfo &ci, const vf4 (&v)[kStageU], float bh, float bt)
+{
+    const int tid = threadIdx.x, ng = ci.len >> 2;
+#pragma unroll
+    for (int u = 0; u < kStageU; ++u)
+        if (tid + u * kBlock < ng) *reinterpret_cast<vf4 *>(win + kStagePad + 4 * (tid + u * kBlock)) = v[u];
+    if (tid < ci.phase) win[kStagePad - ci.phase + tid] = bh;
+    if (tid < ci.pad[0]) win[kStagePad + ci.len + tid] = bt;
+}
+
+// min / max / NaN of row `wr[0, inner)` in the window over Gl = 2^gs (<= 8) adjacent lanes; every lane gets the result.
+// Clamped indices re-read the last element: no remainder loop.  DPP butterflies: no LDS crossbar latency.
+__device__ __forceinline__ MinMax stage_row_range(const float *wr, bool valid, int inner, int sub, int gs)
+{
+    const int Gl = 1 << gs, last = inner - 1;
+    MinMax m;
+    mm_init(m);
+    if (valid) {
+        for (int j = sub; j < inner; j += 4 * Gl) {
+            const float t0 = wr[j], t1 = wr[min(j + Gl, last)], t2 = wr[min(j + 2 * Gl, last)], t3 = wr[min(j + 3 * Gl, last)];
+            mm_acc(m, t0);
+            mm_acc(m, t1);
+            mm_acc(m, t2);
+            mm_acc(m, t3);
+        }
+    }
+    if (gs >= 1) mm_dpp<0xB1>(m);    // quad_perm [1,0,3,2]
+    if (gs >= 2) mm_dpp<0x4E>(m);    // quad_perm [2,3,0,1]
+    if (gs >= 3) mm_dpp<0x141>(m);   // row_half_mirror
+    if (m.nan) m.mn = m.mx = __builtin_nanf("");
+    return m;
+}
+
 template <bool NT>
 __global__ void __launch_bounds__(kBlock, 4)
 k_rows_staged(const float *__restrict__ x, float *__restrict__ y, float *row_min, float *row_max,
@@ -546,77 +605,38 @@ k_rows_staged(const float *__restrict__ x, float *__restrict__ y, float *row_min
     const int inner = a.inner;
     const int64_t G = gridDim.x;
     const float pmaxf = (float)f.pmax;
-    constexpr int U = 4;
+    constexpr int U = kStageU;
     for (int i = tid; i < kFastTabSize; i += kBlock) ftab[i] = kFastTab[i];
 
     int64_t c = blockIdx.x;   // gridDim.x <= nchunks
     vf4 v[U];
     float bh = 0.0f, bt = 0.0f;
-    {   // prologue: the first chunk's loads
-        const int64_t elo = c * kChunkElems;
-        const int64_t rem = a.nvec * 4 - elo;
-        const int ng = (rem < kChunkElems ? (int)rem : kChunkElems) >> 2;
-        const vf4 *xv = reinterpret_cast<const vf4 *>(x + elo);
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-            if (tid + u * kBlock < ng) v[u] = ld16<NT>(xv + tid + u * kBlock);
-        if (tid == 0) cinfo[0] = stage_geometry(c, a);
-        __syncthreads();
-        const int ph = cinfo[0].phase, tb = cinfo[0].pad[0];
-        if (tid < ph) bh = x[elo - ph + tid];
-        if (tid < tb) bt = x[elo + 4 * ng + tid];
-    }
+    stage_load_body<NT>(x, c, a, v);   // prologue: the first chunk's loads
+    if (tid == 0) cinfo[0] = stage_geometry(c, a);
+    __syncthreads();
+    stage_load_borders(x, c, cinfo[0], bh, bt);
     int slot = 0;
     for (;;) {
         const int64_t elo = c * kChunkElems;
         const int phase = cinfo[slot].phase, nrows = cinfo[slot].nrows, len = cinfo[slot].len;
         const int ng = len >> 2;
-        // park the chunk and its two border pieces
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-            if (tid + u * kBlock < ng) *reinterpret_cast<vf4 *>(win + kStagePad + 4 * (tid + u * kBlock)) = v[u];
-        if (tid < phase) win[kStagePad - phase + tid] = bh;
-        if (tid < cinfo[slot].pad[0]) win[kStagePad + len + tid] = bt;
+        stage_park(win, cinfo[slot], v, bh, bt);
         const int64_t cn = c + G;
         const bool more = cn < a.nchunks;
         if (more && tid == 0) cinfo[slot ^ 1] = stage_geometry(cn, a);
         __syncthreads();
         if (more) {   // next chunk: in flight during the phases below
-            const int64_t en = cn * kChunkElems;
-            const int ngn = cinfo[slot ^ 1].len >> 2;
-            const vf4 *xv = reinterpret_cast<const vf4 *>(x + en);
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (tid + u * kBlock < ngn) v[u] = ld16<NT>(xv + tid + u * kBlock);
-            const int ph = cinfo[slot ^ 1].phase, tb = cinfo[slot ^ 1].pad[0];
-            if (tid < ph) bh = x[en - ph + tid];
-            if (tid < tb) bt = x[en + 4 * ngn + tid];
+            stage_load_body<NT>(x, cn, a, v);
+            stage_load_borders(x, cn, cinfo[slot ^ 1], bh, bt);
         }
         {   // per row, Gl (<= 8) lanes: range from LDS -> channel constants -> table -> the row's head patch
             const int gs = a.group, Gl = 1 << gs, rpp = kBlock >> gs, sub = tid & (Gl - 1), rs = tid >> gs;
             const float *w0 = win + (kStagePad - phase);
-            const int last = inner - 1;
             for (int rb = 0; rb < nrows; rb += rpp) {
                 const int r = rb + rs;
                 const bool valid = r < nrows;
-                MinMax m;
-                mm_init(m);
+                const MinMax m = stage_row_range(w0 + r * inner, valid, inner, sub, gs);   // in every lane of the row
                 if (valid) {
-                    const float *wr = w0 + r * inner;
-                    for (int j = sub; j < inner; j += 4 * Gl) {   // clamped indices re-read the last element: no remainder loop
-                        const float t0 = wr[j], t1 = wr[min(j + Gl, last)], t2 = wr[min(j + 2 * Gl, last)],
-                                    t3 = wr[min(j + 3 * Gl, last)];
-                        mm_acc(m, t0);
-                        mm_acc(m, t1);
-                        mm_acc(m, t2);
-                        mm_acc(m, t3);
-                    }
-                }
-                if (gs >= 1) mm_dpp<0xB1>(m);    // quad_perm [1,0,3,2]
-                if (gs >= 2) mm_dpp<0x4E>(m);    // quad_perm [2,3,0,1]
-                if (gs >= 3) mm_dpp<0x141>(m);   // row_half_mirror: every lane of the 8 now holds the row's range
-                if (valid) {
-                    if (m.nan) m.mn = m.mx = __builtin_nanf("");
                     const float mv = fabsf(tmax(fabsf(m.mn), m.mx));   // fp8_quantizer.py:236
                     if (sub == 0 && (r > 0 || phase == 0)) {   // the row starts in this chunk: this block reports it
                         const int64_t grow = cinfo[slot].row_lo + r;
@@ -693,76 +713,35 @@ k_rows_staged_mm(const float *__restrict__ x, float *row_min, float *row_max, fl
     const int tid = threadIdx.x;
     const int inner = a.inner;
     const int64_t G = gridDim.x;
-    constexpr int U = 4;
     int64_t c = blockIdx.x;   // gridDim.x <= nchunks
-    vf4 v[U];
+    vf4 v[kStageU];
     float bh = 0.0f, bt = 0.0f;
-    {
-        const int64_t elo = c * kChunkElems;
-        const int64_t rem = a.nvec * 4 - elo;
-        const int ng = (rem < kChunkElems ? (int)rem : kChunkElems) >> 2;
-        const vf4 *xv = reinterpret_cast<const vf4 *>(x + elo);
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-            if (tid + u * kBlock < ng) v[u] = ld16<NT>(xv + tid + u * kBlock);
-        if (tid == 0) cinfo[0] = stage_geometry(c, a);
-        __syncthreads();
-        const int ph = cinfo[0].phase, tb = cinfo[0].pad[0];
-        if (tid < ph) bh = x[elo - ph + tid];
-        if (tid < tb) bt = x[elo + 4 * ng + tid];
-    }
+    stage_load_body<NT>(x, c, a, v);
+    if (tid == 0) cinfo[0] = stage_geometry(c, a);
+    __syncthreads();
+    stage_load_borders(x, c, cinfo[0], bh, bt);
     int slot = 0;
     for (;;) {
-        const int phase = cinfo[slot].phase, nrows = cinfo[slot].nrows, len = cinfo[slot].len;
-        const int ng = len >> 2;
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-            if (tid + u * kBlock < ng) *reinterpret_cast<vf4 *>(win + kStagePad + 4 * (tid + u * kBlock)) = v[u];
-        if (tid < phase) win[kStagePad - phase + tid] = bh;
-        if (tid < cinfo[slot].pad[0]) win[kStagePad + len + tid] = bt;
+        const int phase = cinfo[slot].phase, nrows = cinfo[slot].nrows;
+        stage_park(win, cinfo[slot], v, bh, bt);
         const int64_t cn = c + G;
         const bool more = cn < a.nchunks;
         if (more && tid == 0) cinfo[slot ^ 1] = stage_geometry(cn, a);
         __syncthreads();
         if (more) {
-            const int64_t en = cn * kChunkElems;
-            const int ngn = cinfo[slot ^ 1].len >> 2;
-            const vf4 *xv = reinterpret_cast<const vf4 *>(x + en);
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (tid + u * kBlock < ngn) v[u] = ld16<NT>(xv + tid + u * kBlock);
-            const int ph = cinfo[slot ^ 1].phase, tb = cinfo[slot ^ 1].pad[0];
-            if (tid < ph) bh = x[en - ph + tid];
-            if (tid < tb) bt = x[en + 4 * ngn + tid];
+            stage_load_body<NT>(x, cn, a, v);
+            stage_load_borders(x, cn, cinfo[slot ^ 1], bh, bt);
         }
         {
             const int gs = a.group, Gl = 1 << gs, rpp = kBlock >> gs, sub = tid & (Gl - 1), rs = tid >> gs;
             const float *w0 = win + (kStagePad - phase);
-            const int last = inner - 1;
             const int64_t row_lo = cinfo[slot].row_lo;
             for (int rb = 0; rb < nrows; rb += rpp) {
                 const int r = rb + rs;
                 const bool valid = r < nrows;
-                MinMax m;
-                mm_init(m);
-                if (valid) {
-                    const float *wr = w0 + r * inner;
-                    for (int j = sub; j < inner; j += 4 * Gl) {
-                        const float t0 = wr[j], t1 = wr[min(j + Gl, last)], t2 = wr[min(j + 2 * Gl, last)],
-                                    t3 = wr[min(j + 3 * Gl, last)];
-                        mm_acc(m, t0);
-                        mm_acc(m, t1);
-                        mm_acc(m, t2);
-                        mm_acc(m, t3);
-                    }
-                }
-                if (gs >= 1) mm_dpp<0xB1>(m);
-                if (gs >= 2) mm_dpp<0x4E>(m);
-                if (gs >= 3) mm_dpp<0x141>(m);
-                if (valid && sub == 0 && (r > 0 || phase == 0)) {   // the chunk in which a row starts reports it
-                    if (m.nan) m.mn = m.mx = __builtin_nanf("");
+                const MinMax m = stage_row_range(w0 + r * inner, valid, inner, sub, gs);
+                if (valid && sub == 0 && (r > 0 || phase == 0))   // the chunk in which a row starts reports it
                     fold_store(m.mn, m.mx, row_lo + r, row_min, row_max, maxval_out, fa);
-                }
             }
         }
         if (!more) break;
