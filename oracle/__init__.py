@@ -50,6 +50,7 @@ def lib():
         L.orc_absmax_f32.argtypes = [f32p, f32p, i64, f32p]
         L.orc_mse_grid_f32.argtypes = [f32p, i64, i64, f32p, i64, f32p, ctypes.c_int,
                                        ctypes.c_int, ctypes.c_int, f32p]
+        L.orc_affine_act_f32.argtypes = [f32p, f32p, f32p, i64, i64, i64, f32p, f32p, f32p, f32p, ctypes.c_int]
         u8p = ctypes.POINTER(ctypes.c_uint8)
         L.orc_encode_u8.argtypes = [f32p, u8p, i64, i64, f32p, i64, ctypes.c_float, ctypes.c_int, ctypes.c_int]
         L.orc_decode_u8.argtypes = [u8p, f32p, i64, i64, f32p, i64, ctypes.c_float, ctypes.c_int, ctypes.c_int]
@@ -80,6 +81,8 @@ def c_quantize(x, maxval, mbits, n_bits=8, sign_bits=1):
     """quantize_to_fp8_ste_MM (fp8_quantizer.py:91-133).  maxval: scalar/[1] or [C] (dim 0)."""
     x = _f32(x)
     mv = _f32(np.atleast_1d(maxval)).reshape(-1)
+    if mv.size == 1 and x.size >= (1 << 16):   # one long row: the element-parallel twin (same orc_quant1 per element)
+        return c_quantize_flat(x, mv[0], mbits, n_bits, sign_bits).reshape(x.shape)
     x2 = _as_2d(x, mv.size != 1)
     assert mv.size in (1, x2.shape[0])
     y = np.empty_like(x2)
@@ -119,6 +122,22 @@ def c_absmax(mn, mx):
     out = np.empty_like(mn)
     lib().orc_absmax_f32(_p(mn), _p(mx), mn.size, _p(out))
     return out
+
+
+def c_affine_act(x, bn=None, residual=None, act=0):
+    """act(batch_norm_eval(x) + residual) on [N, C, ...] (quantized_folded_bn.py:39-55); bn = (mean, invstd, gamma,
+    beta) or None; act 0 none / 1 ReLU / 2 ReLU6."""
+    x = _f32(x)
+    N, C = x.shape[0], x.shape[1]
+    HW = x.size // max(N * C, 1)
+    y = np.empty_like(x)
+    null = ctypes.POINTER(ctypes.c_float)()
+    b = [_f32(t) for t in bn] if bn is not None else None
+    r = _f32(residual) if residual is not None else None
+    rc = lib().orc_affine_act_f32(_p(x), _p(r) if r is not None else null, _p(y), N, C, HW,
+                                  *([_p(t) for t in b] if b else [null] * 4), int(act))
+    assert rc == 0
+    return y
 
 
 def c_mse_grid(x, per_channel, grid, mbits_list, n_bits=8, sign_bits=1, mses=None):

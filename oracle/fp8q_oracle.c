@@ -112,6 +112,20 @@ int orc_quantize_flat_f32(const float *x, float *y, int64_t n, float maxval, flo
  * range_estimators.py:62-74, 84-98 */
 int orc_minmax_f32(const float *x, int64_t C, int64_t inner, float *mn, float *mx)
 {
+    if (C == 1 && inner >= (1 << 20)) {   /* one long row (per-tensor activations): split it over the threads */
+        float lo = INFINITY, hi = -INFINITY;
+        int nan = 0;
+#pragma omp parallel for schedule(static) reduction(min : lo) reduction(max : hi) reduction(| : nan)
+        for (int64_t i = 0; i < inner; ++i) {
+            float v = x[i];
+            nan |= (v != v);
+            lo = v < lo ? v : lo;
+            hi = v > hi ? v : hi;
+        }
+        mn[0] = nan ? NAN : lo;
+        mx[0] = nan ? NAN : hi;
+        return 0;
+    }
 #pragma omp parallel for schedule(static)
     for (int64_t c = 0; c < C; ++c) {
         const float *xr = x + c * inner;
@@ -181,6 +195,35 @@ int orc_mse_grid_f32(const float *x, int64_t C, int64_t inner, const float *grid
             acc += (double)(d * d);
         }
         mses[j] += (float)(acc / (double)inner);
+    }
+    return 0;
+}
+
+/* N2: what precedes the activation quantizer in a fused layer -- eval-mode batch norm (+ residual) (+ ReLU / ReLU6):
+ * BNFusedHijacker.forward, quantization/quantized_folded_bn.py:39-55 (F.batch_norm(..., training=False) then the
+ * activation function) and the residual tail of models/resnet_quantized.py:43-46.  The batch norm is ATen's CPU eval
+ * kernel (probed bit for bit, tests/test_epilogue.py::test_fused_bn_matches_aten_cpu_batch_norm):
+ *   alpha = invstd * gamma;  beta' = fma(-mean, alpha, beta);  out = fma(x, alpha, beta').
+ * x, res, y: [N, C, HW]; mean/invstd/gamma/beta: [C] or all NULL (no batch norm); res may be NULL.
+ * act: 0 none, 1 ReLU, 2 ReLU6 (NaN passes through, as torch.relu / hardtanh do). */
+int orc_affine_act_f32(const float *x, const float *res, float *y, int64_t N, int64_t C, int64_t HW,
+                       const float *mean, const float *invstd, const float *gamma, const float *beta, int act)
+{
+#pragma omp parallel for schedule(static)
+    for (int64_t p = 0; p < N * C; ++p) {
+        const int64_t c = p % C;
+        float alpha = 1.0f, bp = 0.0f;
+        if (mean) {
+            alpha = invstd[c] * gamma[c];
+            bp = fmaf(-mean[c], alpha, beta[c]);
+        }
+        for (int64_t i = p * HW; i < (p + 1) * HW; ++i) {
+            float t = mean ? fmaf(x[i], alpha, bp) : x[i];
+            if (res) t = t + res[i];
+            if (act >= 1) t = t < 0.0f ? 0.0f : t;
+            if (act == 2) t = t > 6.0f ? 6.0f : t;
+            y[i] = t;
+        }
     }
     return 0;
 }

@@ -1,0 +1,326 @@
+"""Parity at the sizes BASELINE.json states (the small-shape tests live in test_hip_parity / test_models).
+
+* config 5: per-rank slab [512, 4096, 512] fp32 -- allminmax fold -> range exchange -> E4M3 quantize
+  (fp8q.dist.calibrate_quantize_sharded), one rank and two gloo ranks sharing the one GPU of the test box;
+* configs 3 / 4: ResNet-18 (E5M2, per-channel current_minmax + per-tensor allminmax) and MobileNetV2 (E4M3, MSE
+  estimator) at batch 64 x 224 x 224 with a hook on every fp8q.ops launch of the calibration pass, of fix_ranges()
+  and of the validation pass: each launch's output is compared with the CPU oracle evaluated on the very tensor that
+  launch read.  MIOpen's convolutions sit between the quantizers and round differently from the CPU's, so logits
+  cannot be compared bit for bit with a CPU run -- but every quantizer launch can, on its own input.
+
+Reference flow: quantization_manager.py:114-122 (estimate -> set_quant_range -> quantize),
+quantized_folded_bn.py:30-56 (batch norm + activation in front of the activation quantizer),
+range_estimators.py:83-100 / :318-369, fp8_quantizer.py:91-133.
+"""
+import inspect
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _bits_equal(got, ref, what):
+    got, ref = np.ascontiguousarray(got, np.float32), np.ascontiguousarray(ref, np.float32)
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    a, b = got.reshape(-1).view(np.int32), ref.reshape(-1).view(np.int32)
+    if np.array_equal(a, b):
+        return
+    nan_a, nan_b = np.isnan(got.reshape(-1)), np.isnan(ref.reshape(-1))
+    assert np.array_equal(nan_a, nan_b), f"{what}: NaN pattern differs"
+    bad = np.flatnonzero((a != b) & ~nan_a)
+    assert bad.size == 0, f"{what}: {bad.size} of {a.size} elements differ, first at {bad[:5]}: " \
+                          f"{got.reshape(-1)[bad[:5]]} vs {ref.reshape(-1)[bad[:5]]}"
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# config 5
+# ---------------------------------------------------------------------------------------------------------------------
+SLAB = (512, 4096, 512)
+N_WIN, WIN = 64, 1 << 16
+
+
+def _slab(seed, shape=SLAB):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    x = torch.empty(*shape, device="cuda")
+    for i in range(0, shape[0], 64):
+        x[i:i + 64].normal_(generator=g)
+    return x
+
+
+def _check_windows(x, y, maxval, mbits, seed, what):
+    """y == oracle(x) bit for bit on N_WIN random windows of WIN elements (plus the first and the last window)."""
+    n = x.numel()
+    rng = np.random.RandomState(seed)
+    starts = [0, n - WIN] + [int(s) for s in rng.randint(0, n - WIN, N_WIN - 2)]
+    xf, yf = x.view(-1), y.view(-1)
+    idx = torch.tensor(starts, device=x.device).view(-1, 1) + torch.arange(WIN, device=x.device).view(1, -1)
+    xs, ys = _np(xf[idx]), _np(yf[idx])
+    ref = oracle.c_quantize(xs.reshape(-1), np.asarray(maxval, np.float32).reshape(1), mbits, 8, 1)
+    _bits_equal(ys.reshape(-1), ref, what)
+
+
+def test_config5_slab_fold_exchange_quantize():
+    """Two sequential slabs through calibrate_quantize_sharded (world 1): the running range after each batch is the
+    oracle's min/max fold of the slabs, the quantized slab is the oracle's E4M3 result with that range on 64 windows
+    of 64 Ki elements, and the whole flow equals the one-shot path (min/max over both slabs at once, direct quantize)."""
+    from fp8q import dist as fd, ops
+    state = None
+    ref_mn = ref_mx = None
+    slabs = []
+    for b in range(2):
+        x = _slab(1234 + b)
+        y, state = fd.calibrate_quantize_sharded(x, 3, 8, 1, state=state)
+        mn, mx = oracle.c_minmax(_np(x).reshape(-1), False)
+        if ref_mn is None:
+            ref_mn, ref_mx = mn, mx
+        else:
+            ref_mn, ref_mx = oracle.c_fold(ref_mn, ref_mx, mn, mx, 1)
+        _bits_equal(_np(state[0]), ref_mn, f"batch {b}: running min")
+        _bits_equal(_np(state[1]), ref_mx, f"batch {b}: running max")
+        mv = oracle.c_absmax(ref_mn, ref_mx)
+        _check_windows(x, y, mv, 3, 100 + b, f"batch {b}: E4M3 slab")
+        # the same slab through the plain quantizer with the same range: identical everywhere, on the device
+        y2 = ops.quantize(x, torch.from_numpy(mv).cuda(), 3, 8, 1)
+        assert torch.equal(y.view(-1).view(torch.int32), y2.view(-1).view(torch.int32))
+        del y, y2
+        slabs.append(x)
+    both = torch.cat(slabs)                       # 8.6 GB: one-shot estimate over the union of the batches
+    del slabs
+    mn1, mx1 = ops.minmax(both, False)
+    assert torch.equal(mn1, state[0]) and torch.equal(mx1, state[1])
+
+
+def test_config5_two_gloo_ranks_on_one_gpu():
+    """The same flow batch-sharded over two ranks (gloo, both on cuda:0, half a slab each): every rank ends with the
+    global range = the oracle's min/max over both half-slabs and quantizes its half with it, bit for bit."""
+    port = 29500 + (os.getpid() % 400)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(HERE, "c5_rank_worker.py")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    oks = [ln for ln in r.stdout.splitlines() if ln.startswith("C5_RANK_OK")]
+    assert len(oks) == 2, r.stdout[-2000:]
+    # both ranks report the same global range
+    assert len({ln.split("range=")[1] for ln in oks}) == 1, oks
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# configs 3 / 4: every launch of a full-size model pass against the oracle
+# ---------------------------------------------------------------------------------------------------------------------
+MSE_FULL_ORACLE_MAX = 1 << 22     # K4 on activations: the oracle walks 111 candidates per element
+MSE_SLICE = 1 << 20
+
+
+class LaunchChecker:
+    """Wraps fp8q.ops.*: runs the real launch, then recomputes it with the oracle from the launch's own inputs."""
+
+    NAMES = ("quantize", "minmax", "minmax_quantize", "affine_act_quantize", "affine_act_minmax", "mse_grid",
+             "multi_quantize")
+
+    def __init__(self, ops, monkeypatch):
+        self.ops = ops
+        self.count = {n: 0 for n in self.NAMES}
+        self.elements = 0
+        self.real = {n: getattr(ops, n) for n in self.NAMES}
+        for n in self.NAMES:
+            monkeypatch.setattr(ops, n, self._wrap(n))
+
+    def _wrap(self, name):
+        real, sig = self.real[name], inspect.signature(self.real[name])
+        check = getattr(self, "_check_" + name)
+
+        def wrapper(*a, **k):
+            b = sig.bind(*a, **k)
+            b.apply_defaults()
+            args = b.arguments
+            pre = None
+            if name in ("minmax", "affine_act_minmax") and args["cur_min"] is not None:
+                pre = (_np(args["cur_min"]).copy(), _np(args["cur_max"]).copy())
+            if name == "mse_grid":
+                pre = _np(args["mses"]).copy()
+            out = real(*a, **k)
+            self.count[name] += 1
+            check(args, out, pre)
+            return out
+        return wrapper
+
+    # -- one checker per entry point -----------------------------------------------------------------------------
+    def _check_quantize(self, a, out, pre):
+        x = _np(a["x"])
+        ref = oracle.c_quantize(x, _np(a["maxval"]).reshape(-1), a["mbits"], a["n_bits"], a["sign_bits"])
+        _bits_equal(_np(out), ref, f"quantize {tuple(x.shape)}")
+        self.elements += x.size
+
+    def _fold(self, mn, mx, pre, a):
+        if pre is not None and a["mode"] != 0:
+            mn, mx = oracle.c_fold(pre[0].reshape(-1), pre[1].reshape(-1), mn, mx, a["mode"], a["momentum"])
+        return mn, mx
+
+    def _check_minmax(self, a, out, pre):
+        x = _np(a["x"])
+        mn, mx = self._fold(*oracle.c_minmax(x, a["per_channel"]), pre, a)
+        _bits_equal(_np(out[0]).reshape(-1), mn, f"minmax {tuple(x.shape)} min")
+        _bits_equal(_np(out[1]).reshape(-1), mx, f"minmax {tuple(x.shape)} max")
+        if a["want_maxval"]:
+            _bits_equal(_np(out[2]).reshape(-1), oracle.c_absmax(mn, mx), f"minmax {tuple(x.shape)} maxval")
+        self.elements += x.size
+
+    def _check_minmax_quantize(self, a, out, pre):
+        x = _np(a["x"])
+        mn, mx = oracle.c_minmax(x, True)
+        mv = oracle.c_absmax(mn, mx)
+        _bits_equal(_np(out[1]), mn, f"minmax_quantize {tuple(x.shape)} min")
+        _bits_equal(_np(out[2]), mx, f"minmax_quantize {tuple(x.shape)} max")
+        _bits_equal(_np(out[3]), mv, f"minmax_quantize {tuple(x.shape)} maxval")
+        _bits_equal(_np(out[0]), oracle.c_quantize(x, mv, a["mbits"], a["n_bits"], a["sign_bits"]),
+                    f"minmax_quantize {tuple(x.shape)}")
+        self.elements += x.size
+
+    @staticmethod
+    def _pre_activation(a):
+        bn = tuple(_np(t) for t in a["bn"]) if a["bn"] is not None else None
+        res = _np(a["residual"]) if a["residual"] is not None else None
+        return oracle.c_affine_act(_np(a["x"]), bn, res, a["act"])
+
+    def _check_affine_act_quantize(self, a, out, pre):
+        t = self._pre_activation(a)
+        ref = oracle.c_quantize(t, _np(a["maxval"]).reshape(-1), a["mbits"], a["n_bits"], a["sign_bits"])
+        _bits_equal(_np(out), ref, f"affine_act_quantize {tuple(t.shape)} bn={a['bn'] is not None} "
+                                   f"res={a['residual'] is not None} act={a['act']}")
+        self.elements += t.size
+
+    def _check_affine_act_minmax(self, a, out, pre):
+        t = self._pre_activation(a)
+        mn, mx = self._fold(*oracle.c_minmax(t, False), pre, a)
+        _bits_equal(_np(out[0]).reshape(-1), mn, f"affine_act_minmax {tuple(t.shape)} min")
+        _bits_equal(_np(out[1]).reshape(-1), mx, f"affine_act_minmax {tuple(t.shape)} max")
+        _bits_equal(_np(out[2]).reshape(-1), oracle.c_absmax(mn, mx), f"affine_act_minmax {tuple(t.shape)} maxval")
+        self.elements += t.size
+
+    def _check_multi_quantize(self, a, out, pre):
+        for it, y in zip(a["items"], out):
+            x, mv, mbits = it[0], it[1], it[2]
+            n_bits = it[3] if len(it) > 3 else 8
+            sign_bits = it[4] if len(it) > 4 else 1
+            _bits_equal(_np(y), oracle.c_quantize(_np(x), _np(mv).reshape(-1), mbits, n_bits, sign_bits),
+                        f"multi_quantize {tuple(x.shape)}")
+            self.elements += x.numel()
+
+    def _check_mse_grid(self, a, out, pre):
+        x, grid = a["x"].contiguous(), a["grid"]
+        assert not pre.any(), "one calibration batch: the table starts at zero, so the increment is the table"
+        got = _np(out)
+        kw = dict(n_bits=a["n_bits"], sign_bits=a["sign_bits"])
+        mb = list(a["mbits_list"])
+        what = f"mse_grid {tuple(x.shape)} per_channel={a['per_channel']}"
+        if a["per_channel"] or x.numel() <= MSE_FULL_ORACLE_MAX:
+            ref = oracle.c_mse_grid(_np(x), a["per_channel"], _np(grid), mb, **kw)
+            np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-30, err_msg=what)
+        else:
+            # a long per-tensor row: (i) the launch equals the element-weighted mean of launches over 1 Mi-element
+            # slices (its split / accumulate logic at this size), (ii) two of those slices against the oracle
+            flat = x.view(-1)
+            n = flat.numel()
+            acc = np.zeros(got.shape, np.float64)
+            rng = np.random.RandomState(n % 9973)
+            nsl = -(-n // MSE_SLICE)
+            picks = set(int(v) for v in rng.choice(nsl, size=min(2, nsl), replace=False))
+            for s in range(nsl):
+                sl = flat[s * MSE_SLICE:(s + 1) * MSE_SLICE]
+                part = torch.zeros_like(a["mses"])
+                self.real["mse_grid"](sl, False, grid, mb, a["n_bits"], a["sign_bits"], part)
+                p = _np(part)
+                acc += p.astype(np.float64) * sl.numel()
+                if s in picks:
+                    ref = oracle.c_mse_grid(_np(sl), False, _np(grid), mb, **kw)
+                    np.testing.assert_allclose(p, ref, rtol=1e-5, atol=1e-30, err_msg=what + f" slice {s}")
+            np.testing.assert_allclose(got, acc / n, rtol=2e-6, atol=1e-30, err_msg=what + " vs its slices")
+        self.elements += x.numel()
+
+
+def _qparams(M, w_est, a_est):
+    from quantization.quantization_manager import QMethods
+    from quantization.range_estimators import RangeEstimators
+    return dict(method=QMethods.fp_quantizer.cls, weight_range_method=RangeEstimators[w_est].cls,
+                act_range_method=RangeEstimators[a_est].cls, n_bits=8, n_bits_act=8, per_channel_weights=True,
+                fp8_kwargs=dict(maxval=None, mantissa_bits=M, set_maxval=True, learn_maxval=False,
+                                learn_mantissa_bits=False, mse_include_mantissa_bits=False, allow_unsigned=False))
+
+
+def _build_full_size(tag):
+    from torch import nn
+    torch.manual_seed(0)
+    if tag == "r18":
+        from models.resnet import resnet18
+        fp = resnet18()
+    else:
+        from models.mobilenet_v2 import MobileNetV2
+        fp = MobileNetV2(input_size=224)
+    # random-init weights (no checkpoints on the box): batch-norm statistics from one synthetic batch, so that
+    # activations have the scale of a trained network's
+    fp = fp.cuda()
+    bns = [m for m in fp.modules() if isinstance(m, nn.BatchNorm2d)]
+    for m in bns:
+        m.momentum = 1.0
+    fp.train()
+    with torch.no_grad():
+        fp(torch.randn(16, 3, 224, 224, device="cuda"))
+    fp.eval()
+    for m in bns:
+        m.momentum = 0.1
+    if tag == "r18":
+        from models.resnet_quantized import QuantizedResNet
+        q = QuantizedResNet(fp, input_size=(1, 3, 224, 224), **_qparams(2, "current_minmax", "allminmax"))
+    else:
+        from models.mobilenet_v2_quantized import QuantizedMobileNetV2
+        q = QuantizedMobileNetV2(fp, input_size=(1, 3, 224, 224), **_qparams(3, "MSE", "MSE"))
+    return q.cuda().eval()
+
+
+@pytest.mark.parametrize("tag,n_weight,n_act_min", [("r18", 21, 29), ("mbv2", 53, 60)])
+def test_every_launch_of_a_full_size_model_pass(tag, n_weight, n_act_min, monkeypatch):
+    """BASELINE configs 3 / 4 at batch 64 x 224 x 224: calibration pass, fix_ranges(), validation pass, every
+    fp8q.ops launch checked against the oracle on its own input."""
+    from fp8q import ops
+    q = _build_full_size(tag)
+    torch.manual_seed(1)
+    calib = torch.randn(64, 3, 224, 224, device="cuda")
+    val = torch.randn(64, 3, 224, 224, device="cuda")
+    chk = LaunchChecker(ops, monkeypatch)
+    with torch.no_grad():
+        q.set_quant_state(True, True)
+        q(calib)
+        cal = dict(chk.count)
+        q.fix_ranges()
+        fixed = dict(chk.count)
+        out = q(val)
+    assert torch.isfinite(out).all() and out.shape == (64, 1000)
+    c = chk.count
+    print(f"\n{tag} @ 64x3x224x224: launches checked {c}; {chk.elements / 1e6:.0f} M elements through the oracle")
+    if tag == "r18":
+        # calibration: one fused min/max+quantize launch per weight tensor, range + quantize per activation
+        assert cal["minmax_quantize"] == n_weight, cal
+        assert cal["affine_act_minmax"] + cal["minmax"] >= n_act_min, cal
+    else:
+        # MSE estimator: grid maximum + one grid-search launch per quantizer (weights and activations)
+        assert cal["mse_grid"] >= n_weight + n_act_min, cal
+    assert cal["affine_act_quantize"] + cal["quantize"] >= n_act_min, cal
+    # fix_ranges: all weights in the multi-tensor launch; validation: activations only (weights come from the cache)
+    assert fixed["multi_quantize"] - cal["multi_quantize"] >= 1, fixed
+    n_val = (c["affine_act_quantize"] + c["quantize"]) - (fixed["affine_act_quantize"] + fixed["quantize"])
+    assert n_val >= n_act_min, (c, fixed)
+    assert c["minmax"] == fixed["minmax"] and c["mse_grid"] == fixed["mse_grid"] \
+        and c["minmax_quantize"] == fixed["minmax_quantize"], (c, fixed)
