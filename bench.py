@@ -3,7 +3,7 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json config 2, scaled as north_star allows: "synthetic NxCxKxK tensors"):
+Headline workload (BASELINE.json config 2, scaled as north_star allows: "synthetic NxCxKxK tensors"):
     a conv1-shaped weight tensor [2^21, 3, 7, 7] fp32 per GPU (308 M elements, 1.23 GB in +
     1.23 GB out -- far beyond the 256 MB Infinity Cache), per-output-channel E5M2
     (n_bits 8, 2 mantissa bits), ranges from current_minmax (computed once, outside the timed
@@ -12,9 +12,17 @@ One step = one pass of the hot path quantize_to_fp8_ste_MM (fp8_quantizer.py:91-
 the tensor = one launch of the HIP kernel k_rows_flat<0> (short rows cut into aligned 16 KiB chunks) through the C ABI (fp8q_quantize_f32).
 Inputs are resident in HBM before the timed region.
 
-N > 1 (one process per GPU, torch.distributed/RCCL): output channels are sharded across
-ranks -- channels are independent, so the data path has no collective (weak scaling: every
-rank owns 2^21 channels).  `value` = channels*147 of ALL ranks / max-over-ranks time.
+N > 1 (one process per GPU, torch.distributed/RCCL).  `value` is the channel-sharded K1 rate: every rank owns 2^21
+channels, channels are independent, no data-path collective (weak scaling) -- channels*147 of ALL ranks / max-over-ranks
+time.  Next to it, in the same JSON line, `north_star_path` times the two exchange steps north_star names, at any N
+(N = 1: the collectives are no-ops and the figures are the kernels' own):
+  weights_allgather  one [N * 2^18, 3, 7, 7] weight tensor held by every rank; rank r finds the ranges of and quantizes
+                     channels channel_partition(C, N)[r] (fused min/max+quantize), then the shards and their per-channel
+                     ranges are re-assembled with RCCL all-gathers -- fp32 on the wire, and 1-byte storage codes
+                     (encode -> all-gather -> decode: 4x less xGMI traffic); kernel / collective time split by events
+  c5                 BASELINE config 5: per-rank slab [512, 4096, 512], allminmax fold -> all-reduce of the 2-float
+                     range -> E4M3 quantize with the global range
+  ranks_seen         sum over ranks of 1 through an RCCL all-reduce: proves the collective spanned N processes
 
 The JSON line also carries:
   roofline      the dominant kernel's algorithmic bytes (8 B/element) / its HIP-event launch time
@@ -153,67 +161,138 @@ def extras(ops, dev):
     rec("resnet18_all_21_weight_tensors_k1_e5m2", n_w, 8, all_weights, iters=50)
     items = [(t, m, 2, 8, 1, o) for t, o, m in zip(ws, ys, mvs)]
     rec("resnet18_all_21_weight_tensors_multi_launch_e5m2", n_w, 8, lambda: ops.multi_quantize(items), iters=50)
+    if hasattr(ops, "MultiPlan"):
+        # prepared plan (descriptors validated and packed once, as QuantizedModel.fix_ranges() does): per call one
+        # ctypes call; device time by events, host time = wall time of the enqueue alone
+        plan = ops.MultiPlan(items)
+        rec("resnet18_all_21_weight_tensors_plan_e5m2", n_w, 8, plan.launch, iters=200)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(200):
+            plan.launch()
+        host = (time.perf_counter() - t0) / 200
+        torch.cuda.synchronize()
+        out["resnet18_all_21_weight_tensors_plan_e5m2"]["host_enqueue_us"] = round(host * 1e6, 1)
+    # K4: the grid search of FP_MSE_Estimator (range_estimators.py:337-347) on a MobileNetV2 activation, 111 candidate
+    # ranges x {1, 6} mantissa widths in one pass (the reference: 111 * |m| full quantizer passes).  ALU-bound: the
+    # inner loop issues 7 VALU instructions per candidate-element (k_mse_row: 1 v_med3 + 3 integer + 3 packed fp32
+    # that process two elements each = 10 lane-operations); peak issue rate 256 CU x 4 SIMD x 16 lanes x 2.4 GHz =
+    # 39.3 T instruction-lanes/s (78.6 T lane-operations/s if everything were packed).
+    a4 = x[: 64 * 32 * 112 * 112].view(64, 32, 112, 112)
+    mx4 = float(a4.abs().max())
+    grid = torch.linspace(0.1 * mx4, 1.2 * mx4, 111, device=dev).view(111, 1).contiguous()
+    for mb in ([3.0], [1.0, 2.0, 3.0, 4.0, 5.0, 6.0]):
+        mses = torch.zeros(len(mb), 111, 1, device=dev)
+        med, _ = ev_time(lambda: ops.mse_grid(a4, False, grid, mb, 8, 1, mses), 5)
+        ce = a4.numel() * 111 * len(mb)
+        out[f"k4_mse_111cand_{len(mb)}m_64x32x112x112"] = dict(
+            us=round(med * 1e6, 1), t_cand_elem_s=round(ce / med / 1e12, 3), hbm_gb_s=round(a4.numel() * 4 / med / 1e9, 1),
+            valu_issue_frac_of_39_3T=round(ce * 7 / med / 39.3e12, 3), lane_ops_frac_of_78_6T=round(ce * 10 / med / 78.6e12, 3))
     del x, y
     return out
 
 
-def run_c5(args, ops, dev, rank, world):
-    """BASELINE config 5: batch-sharded activation calibration + quantization.  Per rank a slab
-    [512, 4096, 512] fp32 (1.07 G elements, seed 1234 + rank).  One step = running min/max fold of
-    the slab (4 B/elem) -> fused all-reduce of the 2-float range (RCCL; no-op at N = 1) -> E4M3
-    quantize of the slab with the global range (8 B/elem): 12 B/elem algorithmic, calibration order
-    of the reference (quantization_manager.py:119-122).  Not the contract line: a second data point."""
+def _phase_us(timing, names, reps):
+    """mean microseconds of every phase between consecutive events recorded by fp8q.dist (_mark), over `reps` calls."""
+    evs = timing["events"]
+    per = len(evs) // reps
+    acc = [0.0] * (per - 1)
+    for r in range(reps):
+        e = evs[r * per:(r + 1) * per]
+        for i in range(per - 1):
+            acc[i] += e[i].elapsed_time(e[i + 1]) * 1e3
+    return {n: round(v / reps, 1) for n, v in zip(names, acc)}
+
+
+def north_star_path(args, ops, dev, rank, world, backend):
+    """The two exchange steps of the path (see the module docstring); every rank runs this, rank 0 reports."""
     from fp8q import dist as fd
+    res = {}
+    sync_dev = dev if backend == "nccl" else "cpu"
+
+    def wall(fn, reps):
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=sync_dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt / reps
+
+    if world > 1:
+        one = torch.ones(1, device=dev)
+        dist.all_reduce(one)
+        res["ranks_seen"] = int(one.item())
+    else:
+        res["ranks_seen"] = 1
+    res["backend"] = {"nccl": "RCCL", "gloo": "gloo (smoke test only)"}[backend] if world > 1 else "none (1 rank)"
+
+    # ---- weights: channel shard -> fused min/max + quantize -> all-gather (fp32, and 1-byte codes) ----
+    C = world * (1 << 18)
+    g = torch.Generator(device=dev).manual_seed(99)          # the same full tensor on every rank
+    w = torch.empty(C, 3, 7, 7, device=dev)
+    for i in range(0, C, 1 << 18):
+        w[i:i + (1 << 18)].normal_(generator=g)
+    w *= 0.1
+    reps = max(3, min(args.steps, 10))
+    n_w = w.numel()
+    wa = {"tensor": f"[{C},3,7,7] fp32 on every rank, rank r quantizes channels channel_partition({C},{world})[r] "
+                    f"(E5M2, current_minmax)", "elements": n_w}
+    for name, fn, names, wire in (
+            ("fp32", lambda t: fd.quantize_weight_sharded(w, MBITS, NBITS, SIGN, timing=t), ("kernel_us", "collective_us"), 4),
+            ("codes_u8", lambda t: fd.quantize_weight_sharded_codes(w, MBITS, NBITS, SIGN, timing=t),
+             ("kernel_us", "collective_us", "decode_us"), 1)):
+        for _ in range(2):
+            fn(None)
+        timing = {}
+        for _ in range(reps):
+            fn(timing)
+        torch.cuda.synchronize()
+        ph = _phase_us(timing, names, reps)
+        dt = wall(lambda: fn(None), reps)
+        ph.update(step_us=round(dt * 1e6, 1), gelem_s=round(n_w / dt / 1e9, 1),
+                  xgmi_bytes_received_per_rank=int((n_w // world) * (world - 1) * wire + (C // world) * (world - 1) * 4))
+        wa[name] = ph
+    res["weights_allgather"] = wa
+    del w
+    torch.cuda.empty_cache()
+
+    # ---- config 5: allminmax fold -> range all-reduce -> E4M3 quantize of the per-rank slab ----
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     x = torch.empty(512, 4096, 512, device=dev)
     for i in range(0, 512, 64):
         x[i:i + 64].normal_(generator=g)
     y = torch.empty_like(x)
-    state = None
+    state = [None]
 
-    def step():
-        nonlocal state
-        cur_min, cur_max = state if state is not None else (None, None)
-        cur_min, cur_max = ops.minmax(x, False, cur_min, cur_max, mode=1)[:2]
-        fd.allreduce_ranges(cur_min, cur_max)
-        maxval = torch.abs(torch.max(torch.abs(cur_min), cur_max))
-        ops.quantize(x, maxval, 3, 8, 1, out=y)
-        state = (cur_min, cur_max)
+    def c5(t=None):
+        _, state[0] = fd.calibrate_quantize_sharded(x, 3, 8, 1, state=state[0], out=y, timing=t)
 
-    for _ in range(args.warmup):
-        step()
+    for _ in range(2):
+        c5()
+    timing = {}
+    for _ in range(reps):
+        c5(timing)
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    if rank == 0:
-        n = x.numel()
-        print(json.dumps({
-            "metric": "FP8 calibrate(allminmax)+quant+dequant Gelems/sec", "value": round(n * world * args.steps / elapsed / 1e9, 2),
-            "unit": "Gelem/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE config 5: per-rank slab [512,4096,512] fp32, allminmax fold + range "
-                                   "all-reduce + E4M3 quantize", "elements_per_gpu": n,
-                       "parallelism": f"batch-sharded x{world}, one 16-byte all-reduce per step"},
-            "roofline": {"bound": "hbm", "kernel": "k_minmax_partial + k_quant_rows", "achieved":
-                         round(n * 12 / (elapsed / args.steps) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(n * 12 / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None}}),
-              flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    ph = _phase_us(timing, ("minmax_us", "collective_us", "quantize_us"), reps)
+    dt = wall(c5, reps)
+    n = x.numel()
+    ph.update(step_ms=round(dt * 1e3, 4), gelem_s=round(n * world / dt / 1e9, 1), elements_per_gpu=n,
+              hbm_gb_s_per_gpu=round(n * 12 / dt / 1e9, 1), frac_of_8tbs=round(n * 12 / dt / 1e9 / HBM_PEAK_GBS, 4),
+              flow="BASELINE config 5: per-rank slab [512,4096,512] fp32, running min/max fold (4 B/elem) -> one "
+                   "all-reduce of the 2-float range -> E4M3 quantize with the global range (8 B/elem)")
+    res["c5"] = ph
+    del x, y
+    torch.cuda.empty_cache()
+    return res
 
 
 def main():
@@ -223,9 +302,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
-    ap.add_argument("--workload", default="conv1", choices=["conv1", "c5"],
-                    help="conv1 (default, the contract line) or c5: BASELINE config 5 per-rank slab "
-                         "[512,4096,512] fp32, allminmax fold -> all-reduce of the range -> E4M3 quantize")
+    ap.add_argument("--no-north-star-path", action="store_true",
+                    help="skip the sharded-weights / config-5 section (profiling runs of the headline kernel)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for --gpus N > 1 (nccl = RCCL; gloo only for smoke-testing the "
                          "multi-process path on a box with fewer GPUs than ranks)")
@@ -251,9 +329,6 @@ def main():
     import fp8q
     ops = fp8q.ops
     fp8q.lib()  # fail loudly if the HIP library is missing
-
-    if args.workload == "c5":
-        return run_c5(args, ops, dev, rank, world)
 
     # synthetic weights: this rank's shard of output channels (seed differs per rank)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -296,19 +371,24 @@ def main():
         t = torch.tensor([elapsed], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    kern_s = sum(a.elapsed_time(b) for a, b in evs) * 1e-3 / max(len(evs), 1)
+    step_s = sorted(a.elapsed_time(b) * 1e-3 for a, b in evs)
+    kern_s = sum(step_s) / max(len(step_s), 1)
 
     n_elem = x.numel()
     total_elem = n_elem * world
     value = total_elem * args.steps / elapsed / 1e9
     achieved = n_elem * BYTES_PER_ELEM / kern_s / 1e9
+    wall_gbs = n_elem * BYTES_PER_ELEM / (elapsed / args.steps) / 1e9
 
+    line = None
     if rank == 0:
-        traffic = None
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
                 traffic = json.load(open(tpath)).get("k1_bytes_per_launch")
+                traffic_source = ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of "
+                                  "this command, recorded when the profile was taken -- NOT measured in this run")
             except Exception:
                 traffic = None
         line = {
@@ -319,12 +399,17 @@ def main():
             "config": {"workload": f"conv1-shaped weights [{N_CH},3,7,7] fp32 per GPU, per-channel E5M2 "
                                    "quantize+dequantize, fixed ranges from current_minmax (BASELINE config 2, "
                                    "synthetic NxCxKxK scale-up)",
-                       "elements_per_gpu": n_elem, "parallelism": f"channel-sharded x{world}, no data-path collective",
+                       "elements_per_gpu": n_elem, "parallelism": f"channel-sharded x{world}, no data-path collective "
+                       "in `value`; the all-gather / all-reduce steps are timed in north_star_path",
                        "prewarm_ms": int(PREWARM_S * 1e3)},
             "roofline": {"bound": "hbm", "kernel": "k_rows_flat<0,NT>", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": traffic, "algorithmic_bytes_per_launch": n_elem * BYTES_PER_ELEM,
-                         "avg_launch_us": round(kern_s * 1e6, 1)},
+                         "frac_wall": round(wall_gbs / HBM_PEAK_GBS, 4),
+                         "traffic": traffic, "traffic_source": traffic_source,
+                         "algorithmic_bytes_per_launch": n_elem * BYTES_PER_ELEM,
+                         "avg_launch_us": round(kern_s * 1e6, 1),
+                         "median_launch_us": round(step_s[len(step_s) // 2] * 1e6, 1),
+                         "min_launch_us": round(step_s[0] * 1e6, 1), "max_launch_us": round(step_s[-1] * 1e6, 1)},
         }
         if world == 1 and not args.no_cpu_baseline:
             # bounded sample: generate only what the CPU leg needs
@@ -339,9 +424,14 @@ def main():
             line["cpu_baseline"]["gpu_output_bit_exact_on_sample"] = bool(
                 np.array_equal(got.view(np.int32), ref.view(np.int32)))
             line["cpu_eager_torch"] = torch_eager_cpu(xc, mvc, min(n_ch, 1 << 16))
+    del x, y
+    torch.cuda.empty_cache()
+    if not args.no_north_star_path:
+        nsp = north_star_path(args, ops, dev, rank, world, args.backend)     # every rank takes part
+        if rank == 0:
+            line["north_star_path"] = nsp
+    if rank == 0:
         if world == 1 and not args.no_extras:
-            del x, y
-            torch.cuda.empty_cache()
             line["extras"] = extras(ops, dev)
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -68,91 +68,75 @@ __device__ __forceinline__ void fold_store(float mn, float mx, int64_t row, floa
 }
 
 // ---------------------------------------------------------------------------------------------
-// K2/K3 stage 1: min / max / NaN of x[row, split range] -> ws[(row * nsplit + split) * 4 ..]
+// K2/K3 two-stage min/max in ONE launch.  Block (split, row) publishes {min, max} of its part of the row in the
+// workspace and draws a ticket of the row; the block that draws the row's LAST ticket reduces the row's partials,
+// folds them into the running estimate (+ K5) and returns the ticket counter to zero.  A separate stage-2 launch cost
+// 4.6 us of the 38 us of a [64,64,112,112] activation (profiles/r01_*).  Workspace contract (include/fp8q.h): the
+// first FP8Q_WS_TICKET_BYTES of ws are the counters -- zero before the first use of a buffer, zero after every call;
+// the partials behind them need no initialisation.  nsplit == 1: no workspace traffic at all.
+// Visibility across the 8 XCDs (one L2 each): release fence (agent scope: L2 write-back) before the ticket atomic,
+// acquire fence (L1/L2 invalidate) after it in the last block -- the LLVM gfx942/gfx950 memory model's recipe.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void block_reduce_store(MinMax m, float *out)
+constexpr int kTicketRows = FP8Q_WS_TICKET_BYTES / 4;   // nsplit > 1 implies C <= kTargetBlocks / 2 rows
+
+__device__ __forceinline__ void block_minmax_fold(MinMax m, float2 *parts /* [nsplit] of this row */, int split, int nsplit,
+                                                  unsigned *ticket, int64_t row, float *cur_min, float *cur_max,
+                                                  float *maxval_out, const FoldArgs &fa)
 {
     __shared__ float s_mn[4], s_mx[4];
     __shared__ int s_nan[4];
+    __shared__ int s_last;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     mm_wave_reduce(m);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (lane == 0) {
         s_mn[wave] = m.mn;
         s_mx[wave] = m.mx;
         s_nan[wave] = m.nan;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
         float mn = fminf(fminf(s_mn[0], s_mn[1]), fminf(s_mn[2], s_mn[3]));
         float mx = fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3]));
-        const int nan = s_nan[0] | s_nan[1] | s_nan[2] | s_nan[3];
-        if (nan) mn = mx = __builtin_nanf("");
-        out[0] = mn;
-        out[1] = mx;
+        if (s_nan[0] | s_nan[1] | s_nan[2] | s_nan[3]) mn = mx = __builtin_nanf("");
+        if (nsplit == 1) {
+            fold_store(mn, mx, row, cur_min, cur_max, maxval_out, fa);
+        } else {
+            parts[split] = make_float2(mn, mx);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            const unsigned old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = old == (unsigned)(nsplit - 1);
+        }
     }
-}
-
-// K2/K3 stage 2: one wave per row reduces the row's splits (many rows, few splits)
-__global__ void __launch_bounds__(kBlock)
-k_minmax_final(const float *__restrict__ ws, int64_t C, int nsplit, float *cur_min, float *cur_max,
-               float *maxval_out, FoldArgs fa)
-{
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (row >= C) return;
-    MinMax m;
+    if (nsplit == 1) return;
+    __syncthreads();
+    if (!s_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    // the row's partials: independent loads (<= 2048 of them per row).  An EMPTY split (a row a few elements longer
+    // than a whole number of steps) holds {+inf, -inf}, so the two halves must not be mixed.
     mm_init(m);
-    for (int s = lane; s < nsplit; s += 64) {
-        // {min, max} of one split; an EMPTY split (a row a few elements longer than a whole number of steps) holds
-        // {+inf, -inf}, so the two halves must not be mixed
-        const float2 ab = *reinterpret_cast<const float2 *>(ws + (row * nsplit + s) * 2);
+    float2 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int s2 = tid + u * kBlock;
+        v[u] = s2 < nsplit ? parts[s2] : make_float2(__builtin_inff(), -__builtin_inff());
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        m.nan |= (v[u].x != v[u].x) | (v[u].y != v[u].y);
+        m.mn = fminf(m.mn, v[u].x);
+        m.mx = fmaxf(m.mx, v[u].y);
+    }
+    for (int s2 = tid + 8 * kBlock; s2 < nsplit; s2 += kBlock) {
+        const float2 ab = parts[s2];
         m.nan |= (ab.x != ab.x) | (ab.y != ab.y);
         m.mn = fminf(m.mn, ab.x);
         m.mx = fmaxf(m.mx, ab.y);
     }
     mm_wave_reduce(m);
     if (lane == 0) {
-        if (m.nan) m.mn = m.mx = __builtin_nanf("");
-        fold_store(m.mn, m.mx, row, cur_min, cur_max, maxval_out, fa);
-    }
-}
-
-// K2/K3 stage 2 for few rows with many splits (per-tensor): one block per row, all partial loads
-// independent (the per-tensor activation path is latency-bound here: 2048 partials, one row)
-__global__ void __launch_bounds__(kBlock)
-k_minmax_final_block(const float *__restrict__ ws, int nsplit, float *cur_min, float *cur_max,
-                     float *maxval_out, FoldArgs fa)
-{
-    __shared__ float s_mn[4], s_mx[4];
-    __shared__ int s_nan[4];
-    const int64_t row = blockIdx.x;
-    const int tid = threadIdx.x;
-    MinMax m;
-    mm_init(m);
-    const float2 *w = reinterpret_cast<const float2 *>(ws) + row * nsplit;
-    float2 v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const int s2 = tid + u * kBlock;
-        v[u] = s2 < nsplit ? w[s2] : make_float2(__builtin_inff(), -__builtin_inff());
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        m.nan |= (v[u].x != v[u].x);
-        m.mn = fminf(m.mn, v[u].x);
-        m.mx = fmaxf(m.mx, v[u].y);
-    }
-    for (int s2 = tid + 8 * kBlock; s2 < nsplit; s2 += kBlock) {
-        const float2 ab = w[s2];
-        m.nan |= (ab.x != ab.x) | (ab.y != ab.y);
-        m.mn = fminf(m.mn, ab.x);
-        m.mx = fmaxf(m.mx, ab.y);
-    }
-    mm_wave_reduce(m);
-    if ((tid & 63) == 0) {
-        s_mn[tid >> 6] = m.mn;
-        s_mx[tid >> 6] = m.mx;
-        s_nan[tid >> 6] = m.nan;
+        s_mn[wave] = m.mn;
+        s_mx[wave] = m.mx;
+        s_nan[wave] = m.nan;
     }
     __syncthreads();
     if (tid == 0) {
@@ -160,6 +144,7 @@ k_minmax_final_block(const float *__restrict__ ws, int nsplit, float *cur_min, f
         float mx = fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3]));
         if (s_nan[0] | s_nan[1] | s_nan[2] | s_nan[3]) mn = mx = __builtin_nanf("");
         fold_store(mn, mx, row, cur_min, cur_max, maxval_out, fa);
+        *ticket = 0u;   // the next call on this workspace is ordered behind this kernel (same stream)
     }
 }
 

@@ -163,14 +163,16 @@ k_affine_act(const float *__restrict__ x, const float *__restrict__ res, float *
     }
 }
 
-// Calibration twin of k_affine_act: min / max of act(bn(x) + residual) per block -> ws.  Read-only, so the
+// Calibration twin of k_affine_act: min / max of act(bn(x) + residual); the block that finishes last folds all blocks'
+// partials into the running estimate (block_minmax_fold: one launch).  Read-only, so the
 // trade-offs differ from the quantizing kernel: a persistent grid of <= 2048 blocks with 4 KiB steps, plain
 // loads and the constants straight from global measured best (36 us at [64,64,112,112]; 16 KiB steps, LDS-staged
 // constants, nontemporal loads or one piece per block: 42-55 us).
 __global__ void __launch_bounds__(kBlock)
 k_affine_minmax(const float *__restrict__ x, const float *__restrict__ res, const float *__restrict__ mean,
                 const float *__restrict__ invstd, const float *__restrict__ gamma,
-                const float *__restrict__ beta, AffineArgs a, int64_t N, float *__restrict__ ws)
+                const float *__restrict__ beta, AffineArgs a, int64_t N, float2 *parts, unsigned *ticket,
+                float *cur_min, float *cur_max, float *maxval_out, FoldArgs fa)
 {
     const int tid = threadIdx.x;
     MinMax mm;
@@ -211,7 +213,8 @@ k_affine_minmax(const float *__restrict__ x, const float *__restrict__ res, cons
         for (int q = 0; q < 4; ++q) mm_acc(mm, e[q]);
     }
     }
-    block_reduce_store(mm, ws + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 2);
+    block_minmax_fold(mm, parts, (int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y), ticket, 0,
+                      cur_min, cur_max, maxval_out, fa);
 }
 
 }  // namespace
@@ -293,7 +296,7 @@ size_t fp8q_affine_act_minmax_workspace_bytes(int64_t N, int64_t C, int64_t HW)
     if (N <= 0 || affine_args(N, C, HW, 0, false, false, &a) != FP8Q_OK) return 16;
     int64_t bx, by;
     affine_grid(N, a, false, &bx, &by);
-    return (size_t)(bx * by) * 2 * sizeof(float) + 16;   // one {min, max} per block
+    return FP8Q_WS_TICKET_BYTES + (size_t)(bx * by) * 2 * sizeof(float) + 16;   // tickets + one {min, max} per block
 }
 
 int fp8q_affine_act_minmax_f32(const float *x, const float *residual, int64_t N, int64_t C, int64_t HW,
@@ -306,25 +309,19 @@ int fp8q_affine_act_minmax_f32(const float *x, const float *residual, int64_t N,
     AffineArgs a;
     if (int rc = affine_args(N, C, HW, act, has_bn, residual != nullptr, &a)) return rc;
     if (N <= 0 || !x || !cur_min || !cur_max || fold_mode < 0 || fold_mode > 2) return FP8Q_EINVAL;
-    if (!ws || ws_bytes < fp8q_affine_act_minmax_workspace_bytes(N, C, HW)) return FP8Q_EWORKSPACE;
+    if (!ws || ws_bytes < fp8q_affine_act_minmax_workspace_bytes(N, C, HW) || ((uintptr_t)ws & 7)) return FP8Q_EWORKSPACE;
     if (((uintptr_t)x | (uintptr_t)residual) & 15) return FP8Q_EINVAL;
     int64_t bx, by;
     affine_grid(N, a, false, &bx, &by);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_affine_minmax, dim3((unsigned)bx, (unsigned)by), dim3(kBlock), 0, st, x, residual, mean, invstd,
-                       gamma, beta, a, N, (float *)ws);
     FoldArgs fa;
     fa.mode = fold_mode;
     fa.first = first != 0;
     fa.om = (float)(1.0 - momentum);
     fa.mo = (float)momentum;
-    const int nparts = (int)(bx * by);
-    if (nparts > 64)
-        hipLaunchKernelGGL(k_minmax_final_block, dim3(1), dim3(kBlock), 0, st, (const float *)ws, nparts, cur_min,
-                           cur_max, maxval_out, fa);
-    else
-        hipLaunchKernelGGL(k_minmax_final, dim3(1), dim3(kBlock), 0, st, (const float *)ws, (int64_t)1, nparts,
-                           cur_min, cur_max, maxval_out, fa);
+    hipLaunchKernelGGL(k_affine_minmax, dim3((unsigned)bx, (unsigned)by), dim3(kBlock), 0, st, x, residual, mean, invstd,
+                       gamma, beta, a, N, (float2 *)((char *)ws + FP8Q_WS_TICKET_BYTES), (unsigned *)ws, cur_min, cur_max,
+                       maxval_out, fa);
     return launch_rc();
 }
 

@@ -96,19 +96,173 @@ k_mse_grid(const float *__restrict__ x, const float *__restrict__ grid, double *
     if (active) ws[((c * a.n_m + m) * a.n_cand + cand) * a.nsplit + split] = acc;
 }
 
-// mses[m, i, c] += sum_over_splits / inner
+// ---------------------------------------------------------------------------------------------
+// K4 for LONG rows (per-tensor activations: 99 % of config 4's grid-search work): lane = ELEMENT.
+// One wave = one block owns tiles of 2048 consecutive elements of one row (32 per lane, in registers) and walks the
+// candidates of its group one after the other; a candidate's constants are wave-uniform (broadcast LDS reads), its
+// squared error is summed over the lane's 32 elements in two fp32 accumulators, reduced across the wave with DPP adds
+// and added to the candidate's double accumulator in LDS.  No per-candidate table and no logarithm: with
+// bias = bi + bf, t = xc * 2^bf has the element's binade p - bi in its exponent field, so rounding xc to the format's
+// grid is rounding t to M fraction bits -- the float magic-number trick (t + C) - C with C = 1.5 * 2^(e' + 23 - M),
+// e' = max(exponent(t), exponent of binade 1) (subnormal range: fixed step) -- and y = round(t) * fl32(2^-bf) is the
+// very product r * s_p K1 forms whenever the channel's scales are ldexp(fl32(2^-bf), .) ("lin", lut_row(): every
+// range with |k - bias| inside bias's binade).  Per candidate-element: 1 v_med3 + 3 integer ops + 6 fp32 ops that run
+// two-wide (v_pk_mul / v_pk_add / v_pk_fma) = 7 issue slots instead of 12 + a ds_read; candidates that are not "lin"
+// (or out of the fast range) take an exact per-element path -- same results as the table kernel either way.
+// Rounding differs from IEEE x / s_p only where the quotient is within ~2.4e-7 relative of a tie (see k_mse_grid).
+// ---------------------------------------------------------------------------------------------
+constexpr int kMseRowTile = 2048;     // elements per wave and tile: 32 per lane
+constexpr int kMseRowEpl = 32;
+constexpr int kMseRowGroup = 256;     // candidates per block (LDS: 40 B each)
+constexpr int kMseRowMinInner = 2048; // shorter rows: k_mse_grid (lane = candidate)
+
+typedef float vf2 __attribute__((ext_vector_type(2)));
+
+struct __attribute__((aligned(16))) CandK {
+    float maxv, minv, c1, m0;     // clamp bounds, 2^bf, fl32(2^-bf)
+    uint32_t lo, kadd;            // exponent field of binade 1 in t's domain (<< 23); ((23 - M) << 23) | 0x400000
+    int fast;                     // 0: exact path (m, grid value re-derived there)
+    int m;                        // index into MseArgs::fmt
+};
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+    // DPP adds inside each row of 16 lanes, then the four row sums through readlane (wave-uniform result)
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
+    const int b = __builtin_bit_cast(int, v);
+    return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16))) +
+           (__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48)));
+}
+
+__global__ void __launch_bounds__(64)
+k_mse_row(const float *__restrict__ x, const float *__restrict__ grid, double *__restrict__ ws, MseArgs a,
+          int64_t ntiles, int tpb, int ngroup, int gsize)
+{
+    __shared__ CandK cst[kMseRowGroup];
+    __shared__ double acc[kMseRowGroup];
+    const int lane = threadIdx.x;
+    const int64_t c = blockIdx.z;
+    const int total = a.n_m * a.n_cand;
+    const int j0 = blockIdx.y * gsize;
+    const int ng = min(gsize, total - j0);
+    // ---- candidate constants of this group (lane <-> candidate) ----
+    for (int j = lane; j < ng; j += 64) {
+        const int jj = j0 + j, m = jj / a.n_cand, cand = jj - m * a.n_cand;
+        const QFmt f = a.fmt[m];
+        const float gv = grid[(int64_t)cand * a.C + c];
+        const Chan ch = make_chan(fabsf(fmaxf(fabsf(-gv), gv)), f);   // set_quant_range(-g, g): fp8_quantizer.py:236
+        CandK k;
+        k.maxv = ch.maxv;
+        k.minv = ch.minv;
+        k.c1 = (float)(1.0 / ch.g);
+        k.m0 = ch.m0;
+        const int e_lo = 128 - ch.bi;                 // exponent field of t for binade p = 1
+        k.lo = (uint32_t)e_lo << 23;
+        k.kadd = ((uint32_t)(23 - (int)f.M) << 23) | 0x00400000u;
+        const float k1 = 1.0f - f.M, kp = (float)f.pmax - f.M;
+        const bool lin = (k1 - (k1 - ch.bias)) == ch.bias && (kp - (kp - ch.bias)) == ch.bias;
+        // magic constant stays a normal float: exponent field of t (<= that of binade pmax) + 23 - M <= 254
+        k.fast = ch.pthr >= 0.0f && lin && e_lo >= 24 && f.M <= 22.0f && (e_lo - 1 + f.pmax) + 23 - (int)f.M <= 254;
+        k.m = m;
+        cst[j] = k;
+        acc[j] = 0.0;
+    }
+    __syncthreads();   // one wave: this is only the LDS ordering point
+    const float *xr = x + c * a.inner;
+    const int64_t t_begin = (int64_t)blockIdx.x * tpb;
+    const int64_t t_end = min(t_begin + tpb, ntiles);
+    for (int64_t t = t_begin; t < t_end; ++t) {
+        const int64_t e0 = t * kMseRowTile;
+        vf2 xv[kMseRowEpl / 2];
+        if (e0 + kMseRowTile <= a.inner) {
+#pragma unroll
+            for (int u = 0; u < kMseRowEpl / 4; ++u) {
+                const vf4 v = ld16u<false>(xr + e0 + u * 256 + lane * 4);
+                xv[2 * u] = vf2{v.x, v.y};
+                xv[2 * u + 1] = vf2{v.z, v.w};
+            }
+        } else {   // last tile of the row: zero padding (q(0) = 0: contributes nothing)
+#pragma unroll
+            for (int u = 0; u < kMseRowEpl / 4; ++u) {
+                const int64_t i = e0 + u * 256 + lane * 4;
+                float e[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) e[q] = i + q < a.inner ? xr[i + q] : 0.0f;
+                xv[2 * u] = vf2{e[0], e[1]};
+                xv[2 * u + 1] = vf2{e[2], e[3]};
+            }
+        }
+        for (int j = 0; j < ng; ++j) {
+            const CandK k = cst[j];
+            vf2 pa = {0.0f, 0.0f};
+            if (__builtin_expect(k.fast, 1)) {
+                const vf2 c1 = {k.c1, k.c1}, m0 = {k.m0, k.m0};
+#pragma unroll
+                for (int u = 0; u < kMseRowEpl / 2; ++u) {
+                    const vf2 xx = xv[u];
+                    const vf2 xc = {__builtin_amdgcn_fmed3f(xx.x, k.minv, k.maxv), __builtin_amdgcn_fmed3f(xx.y, k.minv, k.maxv)};
+                    const vf2 tt = xc * c1;
+                    const uint32_t b0 = max(__float_as_uint(tt.x) & 0x7f800000u, k.lo) + k.kadd;
+                    const uint32_t b1 = max(__float_as_uint(tt.y) & 0x7f800000u, k.lo) + k.kadd;
+                    const vf2 cc = {__uint_as_float(b0), __uint_as_float(b1)};
+                    const vf2 rr = (tt + cc) - cc;          // t rounded to M fraction bits, half to even
+                    const vf2 d = xx - rr * m0;
+                    pa = __builtin_elementwise_fma(d, d, pa);
+                }
+            } else {
+                // exact per-element path (scales not exactly geometric in fp32, tiny / huge / degenerate ranges)
+                const QFmt f = a.fmt[k.m];
+                const Chan ch = make_chan(k.maxv, f);
+                const int koff = ch.bi - 127;
+                const int e_lo = 1 - koff, e_hi = f.pmax - koff;
+                const int jk = (int)f.M + ch.bi - koff;
+#pragma unroll 1
+                for (int u = 0; u < kMseRowEpl / 2; ++u) {
+                    const float e[2] = {xv[u].x, xv[u].y};
+                    float dd[2];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const float xc = __builtin_amdgcn_fmed3f(e[q], ch.minv, ch.maxv);
+                        const float tt = xc * k.c1;
+                        int e8 = (int)__builtin_amdgcn_ubfe(__float_as_uint(tt), 23u, 8u);
+                        e8 = max(min(e8, e_hi), e_lo);
+                        const float r = rintf(ldexpf(tt, jk - e8));
+                        dd[q] = e[q] - r * scale_exact(ch, (float)(e8 + koff), f.M);
+                    }
+                    pa = __builtin_elementwise_fma(vf2{dd[0], dd[1]}, vf2{dd[0], dd[1]}, pa);
+                }
+            }
+            const float s = wave_sum(pa.x + pa.y);
+            if (lane == 0) acc[j] += (double)s;
+        }
+    }
+    __syncthreads();
+    const int64_t nblk = gridDim.x;
+    for (int j = lane; j < ng; j += 64) {
+        const int jj = j0 + j;                    // == m * n_cand + cand
+        ws[((c * total) + jj) * nblk + blockIdx.x] = acc[j];
+    }
+}
+
+// mses[m, i, c] += (sum over the splits of row (c, m, i)) / inner: one wave per row of partial sums, in double
 __global__ void __launch_bounds__(kBlock)
 k_mse_final(const double *__restrict__ ws, float *__restrict__ mses, int64_t C, int n_m, int n_cand,
-            int nsplit, double inv_inner)
+            int64_t nsplit, double inv_inner)
 {
     const int64_t total = C * n_m * n_cand;
-    for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < total;
-         j += (int64_t)gridDim.x * kBlock) {
-        // j indexes ws rows: ((c * n_m + m) * n_cand + i)
+    const int lane = threadIdx.x & 63;
+    const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // ws row: ((c * n_m + m) * n_cand + i)
+    if (j >= total) return;
+    double sum = 0.0;
+    for (int64_t s2 = lane; s2 < nsplit; s2 += 64) sum += ws[j * nsplit + s2];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    if (lane == 0) {
         const int64_t c = j / ((int64_t)n_m * n_cand);
         const int64_t mi = j - c * n_m * n_cand;   // m * n_cand + i
-        double sum = 0.0;
-        for (int s2 = 0; s2 < nsplit; ++s2) sum += ws[j * nsplit + s2];
         mses[mi * C + c] += (float)(sum * inv_inner);
     }
 }
@@ -128,10 +282,40 @@ static int mse_nsplit(int64_t C, int64_t inner, int64_t n_cand, int n_m)
     return (int)ns;
 }
 
+// k_mse_row geometry: tiles per block (so that a row is cut into <= 16384 blocks) and candidate groups
+struct RowGeo {
+    int64_t ntiles, nblk;
+    int tpb, ngroup, gsize;
+};
+
+static bool mse_use_row(int64_t C, int64_t inner)
+{
+    static const int env = [] {   // FP8Q_MSE_ROW=0: the lane-per-candidate kernel everywhere (A/B)
+        const char *e = getenv("FP8Q_MSE_ROW");
+        return e ? atoi(e) : 1;
+    }();
+    return env && inner >= kMseRowMinInner && C <= 65535;
+}
+
+static RowGeo mse_row_geo(int64_t C, int64_t inner, int64_t n_cand, int n_m)
+{
+    RowGeo g;
+    g.ntiles = cdiv(inner, kMseRowTile);
+    int64_t cap = 16384 / (C > 0 ? C : 1);
+    if (cap < 64) cap = 64;
+    g.tpb = (int)cdiv(g.ntiles, cap);
+    g.nblk = cdiv(g.ntiles, g.tpb);
+    const int64_t total = n_cand * n_m;
+    g.ngroup = (int)cdiv(total, kMseRowGroup);
+    g.gsize = (int)cdiv(total, g.ngroup);
+    return g;
+}
+
 size_t fp8q_mse_workspace_bytes(int64_t C, int64_t inner, int64_t n_cand, int n_m)
 {
     if (C <= 0 || inner <= 0 || n_cand <= 0 || n_m <= 0) return 16;
-    return (size_t)C * n_m * n_cand * mse_nsplit(C, inner, n_cand, n_m) * sizeof(double) + 16;
+    const int64_t ns = mse_use_row(C, inner) ? mse_row_geo(C, inner, n_cand, n_m).nblk : mse_nsplit(C, inner, n_cand, n_m);
+    return (size_t)C * n_m * n_cand * ns * sizeof(double) + 16;
 }
 
 int fp8q_mse_grid_f32(const float *x, int64_t C, int64_t inner, const float *grid, int64_t n_cand,
@@ -141,6 +325,7 @@ int fp8q_mse_grid_f32(const float *x, int64_t C, int64_t inner, const float *gri
     if (!x || !grid || !mbits_host || !mses || C <= 0 || inner <= 0 || n_cand <= 0 || n_m <= 0 ||
         n_m > kMseMaxM || n_cand > (1 << 20))
         return FP8Q_EINVAL;
+    if (C > 65535) return FP8Q_ETOOMANY;   // gridDim.z; no model of this path has that many channels
     if (!ws || ws_bytes < fp8q_mse_workspace_bytes(C, inner, n_cand, n_m) || ((uintptr_t)ws & 7))
         return FP8Q_EWORKSPACE;
     MseArgs a;
@@ -156,27 +341,27 @@ int fp8q_mse_grid_f32(const float *x, int64_t C, int64_t inner, const float *gri
     a.inner = inner;
     a.C = C;
     hipStream_t st = (hipStream_t)stream;
-    const size_t shmem = (size_t)kMseTile * 4 + (size_t)kMseBlock * ((pmax_all + 1) | 1) * sizeof(float);
-    if (shmem > 64 * 1024) {
-        static int opted = 0;
-        if (!opted) {
-            hipError_t e = hipFuncSetAttribute((const void *)k_mse_grid,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    int64_t nsplit = a.nsplit;
+    if (mse_use_row(C, inner) && ((uintptr_t)x & 3) == 0) {
+        const RowGeo g = mse_row_geo(C, inner, n_cand, n_m);
+        nsplit = g.nblk;
+        hipLaunchKernelGGL(k_mse_row, dim3((unsigned)g.nblk, (unsigned)g.ngroup, (unsigned)C), dim3(64), 0, st, x, grid,
+                           (double *)ws, a, g.ntiles, g.tpb, g.ngroup, g.gsize);
+    } else {
+        const size_t shmem = (size_t)kMseTile * 4 + (size_t)kMseBlock * ((pmax_all + 1) | 1) * sizeof(float);
+        if (shmem > 64 * 1024) {
+            // per device, cheap: a process may drive several GPUs (fp8q.ops._on_device)
+            hipError_t e = hipFuncSetAttribute((const void *)k_mse_grid, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               160 * 1024);
             if (e != hipSuccess) return (int)e;
-            opted = 1;
         }
-    }
-    for (int64_t c0 = 0; c0 < C; c0 += 65535) {
-        // gridDim.z limit: rows are processed in slabs; ws/grid/mses keep their global indexing
-        const int64_t cn = (C - c0) < 65535 ? (C - c0) : 65535;
-        if (c0 != 0) return FP8Q_EUNSUPPORTED;  // > 65535 channels: not needed by any model here
-        hipLaunchKernelGGL(k_mse_grid, dim3((unsigned)a.nsplit, (unsigned)(n_m * a.cgroups), (unsigned)cn),
+        hipLaunchKernelGGL(k_mse_grid, dim3((unsigned)a.nsplit, (unsigned)(n_m * a.cgroups), (unsigned)C),
                            dim3(kMseBlock), shmem, st, x, grid, (double *)ws, a);
     }
-    int64_t fb = cdiv(C * n_m * n_cand, kBlock);
-    if (fb > kTargetBlocks) fb = kTargetBlocks;
-    hipLaunchKernelGGL(k_mse_final, dim3((unsigned)fb), dim3(kBlock), 0, st, (const double *)ws, mses, C,
-                       n_m, (int)n_cand, a.nsplit, 1.0 / (double)inner);
+    if (int rc = launch_rc()) return rc;
+    const int64_t rows = C * n_m * n_cand;
+    hipLaunchKernelGGL(k_mse_final, dim3((unsigned)cdiv(rows, 4)), dim3(kBlock), 0, st, (const double *)ws, mses, C,
+                       n_m, (int)n_cand, nsplit, 1.0 / (double)inner);
     return launch_rc();
 }
 

@@ -21,6 +21,8 @@
 //   k_quant_scalar    K1 fallback for x / y that are not 16-byte co-aligned.
 //   k_minmax_partial  K2/K3 stage 1: per-(row, split) min / max / NaN flag  (stage 2 + K5: fp8q_common.h).
 //   k_copy            float4 copy with K1's launch geometry (measured HBM ceiling).
+#include <vector>
+
 #include "fp8q_common.h"
 
 namespace {
@@ -996,12 +998,13 @@ k_quant_scalar(const float *__restrict__ x, float *__restrict__ y, int64_t inner
 }
 
 // ---------------------------------------------------------------------------------------------
-// K2/K3 stage 1: min / max / NaN of x[row, split range] -> ws[(row * nsplit + split) * 2 ..]
-// (stage 2: k_minmax_final / k_minmax_final_block in fp8q_common.h)
+// K2/K3: min / max / NaN of x[row, split range]; the block that finishes a row last folds the row's partials into
+// the running estimate (block_minmax_fold, fp8q_common.h): one launch.
 // ---------------------------------------------------------------------------------------------
 template <bool NT>
 __global__ void __launch_bounds__(kBlock)
-k_minmax_partial(const float *__restrict__ x, int64_t inner, int nsplit, float *__restrict__ ws)
+k_minmax_partial(const float *__restrict__ x, int64_t inner, int nsplit, float2 *parts, unsigned *tickets,
+                 float *cur_min, float *cur_max, float *maxval_out, FoldArgs fa)
 {
     const int row = blockIdx.y, split = blockIdx.x, tid = threadIdx.x;
     const float *xr = x + (int64_t)row * inner;
@@ -1043,7 +1046,8 @@ k_minmax_partial(const float *__restrict__ x, int64_t inner, int nsplit, float *
             }
         }
     }
-    block_reduce_store(m, ws + ((int64_t)row * nsplit + split) * 2);
+    block_minmax_fold(m, parts + (int64_t)row * nsplit, split, nsplit, tickets + (nsplit > 1 ? row : 0), row, cur_min,
+                      cur_max, maxval_out, fa);
 }
 
 // 16-byte-per-lane copy with K1's launch shape: the achievable-HBM yardstick
@@ -1348,7 +1352,9 @@ const char *fp8q_strerror(int code)
         case FP8Q_OK: return "ok";
         case FP8Q_EINVAL: return "invalid argument";
         case FP8Q_EUNSUPPORTED: return "unsupported format (more than 7 exponent bits)";
-        case FP8Q_EWORKSPACE: return "workspace too small";
+        case FP8Q_EWORKSPACE: return "workspace too small or misaligned";
+        case FP8Q_ETOOLONG: return "rows longer than fp8q_fused_max_inner(): use fp8q_minmax_f32 + fp8q_quantize_f32";
+        case FP8Q_ETOOMANY: return "more than 65535 channels in one MSE grid-search call";
         default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
     }
 }
@@ -1419,9 +1425,9 @@ static int minmax_nsplit(int64_t C, int64_t inner)
 
 size_t fp8q_minmax_workspace_bytes(int64_t C, int64_t inner)
 {
-    if (C <= 0 || inner <= 0) return 16;
-    if (inner <= direct_max_inner() && C > 1) return 16;  // short-row path needs none
-    return (size_t)C * (size_t)minmax_nsplit(C, inner) * 2 * sizeof(float) + 16;
+    if (C <= 0 || inner <= 0) return FP8Q_WS_TICKET_BYTES + 16;
+    if (inner <= direct_max_inner() && C > 1) return FP8Q_WS_TICKET_BYTES + 16;  // short-row path needs none
+    return FP8Q_WS_TICKET_BYTES + (size_t)C * (size_t)minmax_nsplit(C, inner) * 2 * sizeof(float) + 16;
 }
 
 int fp8q_minmax_f32(const float *x, int64_t C, int64_t inner, float *cur_min, float *cur_max,
@@ -1450,24 +1456,22 @@ int fp8q_minmax_f32(const float *x, int64_t C, int64_t inner, float *cur_min, fl
         return launch_rows_direct(kModeMinMax, x, nullptr, C, inner, nullptr, cur_min, cur_max, maxval_out,
                                   f, fa, st);
     }
-    if (ws_bytes < fp8q_minmax_workspace_bytes(C, inner) || !ws) return FP8Q_EWORKSPACE;
+    if (ws_bytes < fp8q_minmax_workspace_bytes(C, inner) || !ws || ((uintptr_t)ws & 7)) return FP8Q_EWORKSPACE;
     const int ns = minmax_nsplit(C, inner);
+    if (ns > 1 && C > kTicketRows) return FP8Q_EINVAL;   // cannot happen: ns > 1 only for C <= kTargetBlocks / 2
+    unsigned *tickets = (unsigned *)ws;
+    float2 *parts = (float2 *)((char *)ws + FP8Q_WS_TICKET_BYTES);
     for (int64_t c0 = 0; c0 < C; c0 += 65535) {
         const int64_t cn = (C - c0) < 65535 ? (C - c0) : 65535;
-        float *w = (float *)ws + c0 * ns * 2;
         if (C * inner * 4 >= kNtBytes)
-            hipLaunchKernelGGL(k_minmax_partial<true>, dim3((unsigned)ns, (unsigned)cn), dim3(kBlock), 0,
-                               st, x + c0 * inner, inner, ns, w);
+            hipLaunchKernelGGL(k_minmax_partial<true>, dim3((unsigned)ns, (unsigned)cn), dim3(kBlock), 0, st,
+                               x + c0 * inner, inner, ns, parts + c0 * ns, tickets, cur_min + c0, cur_max + c0,
+                               maxval_out ? maxval_out + c0 : nullptr, fa);
         else
-            hipLaunchKernelGGL(k_minmax_partial<false>, dim3((unsigned)ns, (unsigned)cn), dim3(kBlock), 0,
-                               st, x + c0 * inner, inner, ns, w);
+            hipLaunchKernelGGL(k_minmax_partial<false>, dim3((unsigned)ns, (unsigned)cn), dim3(kBlock), 0, st,
+                               x + c0 * inner, inner, ns, parts + c0 * ns, tickets, cur_min + c0, cur_max + c0,
+                               maxval_out ? maxval_out + c0 : nullptr, fa);
     }
-    if (ns > 64 && C <= 65535)
-        hipLaunchKernelGGL(k_minmax_final_block, dim3((unsigned)C), dim3(kBlock), 0, st, (const float *)ws,
-                           ns, cur_min, cur_max, maxval_out, fa);
-    else
-        hipLaunchKernelGGL(k_minmax_final, dim3((unsigned)cdiv(C, 4)), dim3(kBlock), 0, st,
-                           (const float *)ws, C, ns, cur_min, cur_max, maxval_out, fa);
     return launch_rc();
 }
 
@@ -1482,7 +1486,7 @@ int fp8q_minmax_quantize_f32(const float *x, float *y, int64_t C, int64_t inner,
     if (int rc = make_fmt(mbits, n_bits, sign_bits, &f)) return rc;
     if (C == 0 || inner == 0) return FP8Q_OK;
     if (!x || !y) return FP8Q_EINVAL;
-    if (inner > kDirectMaxInner) return FP8Q_EUNSUPPORTED;
+    if (inner > kDirectMaxInner) return FP8Q_ETOOLONG;
     if (((uintptr_t)x & 3) != 0 || ((uintptr_t)y & 3) != 0) return FP8Q_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     {
@@ -1494,11 +1498,24 @@ int fp8q_minmax_quantize_f32(const float *x, float *y, int64_t C, int64_t inner,
     return launch_rows_direct(kModeFused, x, y, C, inner, nullptr, row_min, row_max, maxval_out, f, nofold, st);
 }
 
-int fp8q_multi_quantize_f32(const fp8q_tensor_desc *descs, int n, fp8q_stream_t stream)
+// A prepared multi-tensor launch: the descriptors validated, classified and packed into kernel arguments once.
+struct PlanStep {
+    bool batched;              // true: one k_multi_flat launch of `args`; false: one fp8q_quantize_f32 call of `single`
+    MultiArgs args;
+    size_t shmem;
+    fp8q_tensor_desc single;
+};
+
+}  // extern "C"
+
+struct fp8q_multi_plan {
+    std::vector<PlanStep> steps;
+};
+
+static int plan_build(const fp8q_tensor_desc *descs, int n, fp8q_multi_plan &plan)
 {
     if (n < 0 || (n > 0 && !descs)) return FP8Q_EINVAL;
-    hipStream_t st = (hipStream_t)stream;
-    // validate everything first: nothing is enqueued if any descriptor is bad
+    // validate everything first: nothing is built (or enqueued) if any descriptor is bad
     for (int i = 0; i < n; ++i) {
         const fp8q_tensor_desc &t = descs[i];
         if (t.C < 0 || t.inner < 0 || (t.n_maxval != 1 && t.n_maxval != t.C)) return FP8Q_EINVAL;
@@ -1506,17 +1523,17 @@ int fp8q_multi_quantize_f32(const fp8q_tensor_desc *descs, int n, fp8q_stream_t 
         if (int rc = make_fmt(t.mbits, t.n_bits, t.sign_bits, &f)) return rc;
         if (t.C > 0 && t.inner > 0 && (!t.x || !t.y || !t.maxval)) return FP8Q_EINVAL;
     }
-    MultiArgs args;
-    args.n = 0;
-    args.total_chunks = 0;
-    size_t shmem = 0;
-    auto flush = [&]() -> int {
-        if (args.n == 0) return FP8Q_OK;
-        hipLaunchKernelGGL(k_multi_flat, dim3(args.total_chunks), dim3(kBlock), shmem, st, args);
-        args.n = 0;
-        args.total_chunks = 0;
-        shmem = 0;
-        return launch_rc();
+    PlanStep cur;
+    cur.batched = true;
+    cur.args.n = 0;
+    cur.args.total_chunks = 0;
+    cur.shmem = 0;
+    auto flush = [&]() {
+        if (cur.args.n == 0) return;
+        plan.steps.push_back(cur);
+        cur.args.n = 0;
+        cur.args.total_chunks = 0;
+        cur.shmem = 0;
     };
     for (int i = 0; i < n; ++i) {
         const fp8q_tensor_desc &t = descs[i];
@@ -1532,15 +1549,18 @@ int fp8q_multi_quantize_f32(const fp8q_tensor_desc *descs, int n, fp8q_stream_t 
                                (!per_channel || (inner >= 4 && inner <= kMagicMaxDivisor)) &&
                                rpc * per_row <= 36 * 1024 && nelem * 4 < kNtBytes;
         if (!batchable) {   // unaligned, very short rows, or a tensor big enough to deserve its own launch
-            if (int rc = flush()) return rc;
-            if (int rc = fp8q_quantize_f32(t.x, t.y, t.C, t.inner, t.maxval, t.n_maxval, t.mbits, t.n_bits,
-                                           t.sign_bits, stream))
-                return rc;
+            flush();
+            PlanStep one;
+            one.batched = false;
+            one.args.n = 0;
+            one.args.total_chunks = 0;
+            one.shmem = 0;
+            one.single = t;
+            plan.steps.push_back(one);
             continue;
         }
-        if (args.n == kMultiMax)
-            if (int rc = flush()) return rc;
-        MultiDesc &d = args.d[args.n++];
+        if (cur.args.n == kMultiMax) flush();
+        MultiDesc &d = cur.args.d[cur.args.n++];
         d.x = t.x;
         d.y = t.y;
         d.maxval = t.maxval;
@@ -1550,14 +1570,71 @@ int fp8q_multi_quantize_f32(const fp8q_tensor_desc *descs, int n, fp8q_stream_t 
         d.inner = per_channel ? (int)inner : 0;
         d.rpc = (int)rpc;
         d.magic = per_channel ? magic_of((int)inner) : 0u;
-        d.chunk0 = args.total_chunks;
+        d.chunk0 = cur.args.total_chunks;
         d.f = f;
-        args.total_chunks += (uint32_t)cdiv(d.nvec, kChunkGroups);
+        cur.args.total_chunks += (uint32_t)cdiv(d.nvec, kChunkGroups);
         const size_t need = (size_t)(rpc * per_row);
-        if (need > shmem) shmem = need;
+        if (need > cur.shmem) cur.shmem = need;
     }
-    return flush();
+    flush();
+    return FP8Q_OK;
 }
+
+static int plan_launch(const fp8q_multi_plan &plan, hipStream_t st)
+{
+    for (const PlanStep &s : plan.steps) {
+        if (s.batched) {
+            hipLaunchKernelGGL(k_multi_flat, dim3(s.args.total_chunks), dim3(kBlock), s.shmem, st, s.args);
+            if (int rc = launch_rc()) return rc;
+        } else {
+            const fp8q_tensor_desc &t = s.single;
+            if (int rc = fp8q_quantize_f32(t.x, t.y, t.C, t.inner, t.maxval, t.n_maxval, t.mbits, t.n_bits,
+                                           t.sign_bits, (fp8q_stream_t)st))
+                return rc;
+        }
+    }
+    return FP8Q_OK;
+}
+
+extern "C" {
+
+int fp8q_multi_quantize_f32(const fp8q_tensor_desc *descs, int n, fp8q_stream_t stream)
+{
+    try {
+        fp8q_multi_plan plan;
+        if (int rc = plan_build(descs, n, plan)) return rc;
+        return plan_launch(plan, (hipStream_t)stream);
+    } catch (...) {
+        return (int)hipErrorOutOfMemory;
+    }
+}
+
+int fp8q_multi_plan_create(const fp8q_tensor_desc *descs, int n, fp8q_multi_plan **plan_out)
+{
+    if (!plan_out) return FP8Q_EINVAL;
+    *plan_out = nullptr;
+    try {
+        fp8q_multi_plan *plan = new fp8q_multi_plan();
+        if (int rc = plan_build(descs, n, *plan)) {
+            delete plan;
+            return rc;
+        }
+        *plan_out = plan;
+        return FP8Q_OK;
+    } catch (...) {
+        return (int)hipErrorOutOfMemory;
+    }
+}
+
+int fp8q_multi_plan_launch(const fp8q_multi_plan *plan, fp8q_stream_t stream)
+{
+    if (!plan) return FP8Q_EINVAL;
+    return plan_launch(*plan, (hipStream_t)stream);
+}
+
+int fp8q_multi_plan_launches(const fp8q_multi_plan *plan) { return plan ? (int)plan->steps.size() : FP8Q_EINVAL; }
+
+void fp8q_multi_plan_destroy(fp8q_multi_plan *plan) { delete plan; }
 
 int fp8q_copy_f32(const float *x, float *y, int64_t n, fp8q_stream_t stream)
 {

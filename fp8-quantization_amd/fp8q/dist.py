@@ -25,6 +25,27 @@ def _default_ops():
     return ops
 
 
+def _mark(timing):
+    """Optional phase timing for bench.py: append a recorded event of the current stream to timing["events"]
+    (collectives issued with async_op=False make the current stream wait for them, so the events bracket them)."""
+    if timing is not None:
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        timing.setdefault("events", []).append(ev)
+
+
+def _local_minmax_quantize(ops, shard, mbits, n_bits, sign_bits):
+    """current_minmax range + quantize of this rank's channels: the fused launch when the rows fit it
+    (fp8q_fused_max_inner), else min/max then quantize (e.g. Linear(25088, 4096): rows of 25088 elements)."""
+    inner = shard.numel() // max(shard.shape[0], 1)
+    limit = getattr(ops, "fused_max_inner", None)
+    if limit is None or inner <= limit():
+        q, _, _, mv = ops.minmax_quantize(shard, mbits, n_bits, sign_bits)
+        return q, mv
+    mv = ops.minmax(shard, True, want_maxval=True)[2]
+    return ops.quantize(shard, mv, mbits, n_bits, sign_bits), mv
+
+
 def channel_partition(n_channels, world_size):
     """[lo, hi) of every rank; the first (C mod W) ranks get one extra channel."""
     base, extra = divmod(n_channels, world_size)
@@ -106,7 +127,8 @@ def enable_distributed_calibration(model, group=None, enable=True):
     return n
 
 
-def calibrate_quantize_sharded(x_local, mbits, n_bits=8, sign_bits=1, state=None, group=None, ops=None):
+def calibrate_quantize_sharded(x_local, mbits, n_bits=8, sign_bits=1, state=None, group=None, ops=None, out=None,
+                               timing=None):
     """BASELINE config 5: this rank's slab of a batch-sharded activation tensor.
 
     local allminmax fold -> all-reduce of the 2-float running range -> quantize the slab with the
@@ -114,14 +136,18 @@ def calibrate_quantize_sharded(x_local, mbits, n_bits=8, sign_bits=1, state=None
     quantization_manager.py:119-122).  Returns (y_local, state); state = (min, max) tensors [1]."""
     ops = ops or _default_ops()
     cur_min, cur_max = state if state is not None else (None, None)
+    _mark(timing)
     cur_min, cur_max = ops.minmax(x_local, False, cur_min, cur_max, mode=1)[:2]
+    _mark(timing)
     allreduce_ranges(cur_min, cur_max, group)
+    _mark(timing)
     maxval = torch.abs(torch.max(torch.abs(cur_min), cur_max))      # fp8_quantizer.py:236
-    y = ops.quantize(x_local, maxval, mbits, n_bits, sign_bits)
+    y = ops.quantize(x_local, maxval, mbits, n_bits, sign_bits, out=out)
+    _mark(timing)
     return y, (cur_min, cur_max)
 
 
-def quantize_weight_sharded_codes(w, mbits, n_bits=8, sign_bits=1, group=None, ops=None):
+def quantize_weight_sharded_codes(w, mbits, n_bits=8, sign_bits=1, group=None, ops=None, timing=None):
     """Channel-sharded weight quantization that ships 1-byte storage codes instead of fp32 values
     (SURVEY.md 8f N3): rank r finds the ranges of its channels and encodes them (fp8q_encode_u8),
     the ranks all-gather codes (1 B/element: 4x less xGMI traffic than fp32) and per-channel
@@ -135,13 +161,21 @@ def quantize_weight_sharded_codes(w, mbits, n_bits=8, sign_bits=1, group=None, o
     inner = w.numel() // max(C, 1)
     lo, hi = channel_partition(C, world)[rank]
     shard = w[lo:hi].contiguous()
+    _mark(timing)
     if hi > lo:
         mv_shard = ops.minmax(shard, True, want_maxval=True)[2]
         c_shard = ops.encode(shard, mv_shard, mbits, n_bits, sign_bits)
     else:
         mv_shard = w.new_empty(0)
         c_shard = torch.empty(0, dtype=torch.uint8, device=w.device)
-    if world > 1:
+    _mark(timing)
+    if world > 1 and C % world == 0:
+        # even split: gather straight into the final tensors (no padding, no re-assembly copies)
+        codes = torch.empty(w.shape, dtype=torch.uint8, device=w.device)
+        maxval = w.new_empty(C)
+        dist.all_gather_into_tensor(codes.view(-1), c_shard.reshape(-1), group=group)
+        dist.all_gather_into_tensor(maxval, mv_shard, group=group)
+    elif world > 1:
         per = -(-C // world)
         send_c = torch.zeros(per * inner, dtype=torch.uint8, device=w.device)
         send_c[: (hi - lo) * inner] = c_shard.reshape(-1)
@@ -158,11 +192,14 @@ def quantize_weight_sharded_codes(w, mbits, n_bits=8, sign_bits=1, group=None, o
         codes, maxval = torch.cat(parts_c).view(w.shape), torch.cat(parts_m)
     else:
         codes, maxval = c_shard.view(w.shape), mv_shard
-    return ops.decode(codes, maxval, mbits, n_bits, sign_bits), maxval, codes
+    _mark(timing)
+    y = ops.decode(codes, maxval, mbits, n_bits, sign_bits)
+    _mark(timing)
+    return y, maxval, codes
 
 
 def quantize_weight_sharded(w, mbits, n_bits=8, sign_bits=1, maxval=None, group=None, ops=None,
-                            gather=True):
+                            gather=True, timing=None):
     """Per-output-channel weight quantization sharded over the ranks of `group`.
 
     Every rank holds the full fp32 weight `w` ([C, ...]); rank r quantizes channels
@@ -176,18 +213,28 @@ def quantize_weight_sharded(w, mbits, n_bits=8, sign_bits=1, maxval=None, group=
     inner = w.numel() // max(C, 1)
     lo, hi = channel_partition(C, world)[rank]
     shard = w[lo:hi].contiguous()
+    _mark(timing)
     if hi > lo:
         if maxval is None:
-            q_shard, _, _, mv_shard = ops.minmax_quantize(shard, mbits, n_bits, sign_bits)
+            q_shard, mv_shard = _local_minmax_quantize(ops, shard, mbits, n_bits, sign_bits)
         else:
             mv_shard = maxval[lo:hi].contiguous()
             q_shard = ops.quantize(shard, mv_shard, mbits, n_bits, sign_bits)
     else:
         q_shard = shard
         mv_shard = w.new_empty(0)
+    _mark(timing)
     if not gather or world == 1:
+        _mark(timing)
         return q_shard, mv_shard
-    # equal-size exchange: pad every shard to ceil(C / W) channels
+    if C % world == 0:
+        # even split: gather straight into the final tensors (no padding, no re-assembly copies)
+        out, mv_out = torch.empty_like(w), w.new_empty(C)
+        dist.all_gather_into_tensor(out.view(-1), q_shard.reshape(-1), group=group)
+        dist.all_gather_into_tensor(mv_out, mv_shard, group=group)
+        _mark(timing)
+        return out, mv_out
+    # uneven split: equal-size exchange, every shard padded to ceil(C / W) channels
     per = -(-C // world)
     send = w.new_zeros(per * (inner + 1))
     send[: (hi - lo) * inner] = q_shard.reshape(-1)
@@ -199,7 +246,9 @@ def quantize_weight_sharded(w, mbits, n_bits=8, sign_bits=1, maxval=None, group=
     for r, (a, b) in enumerate(channel_partition(C, world)):
         parts.append(recv[r, : (b - a) * inner])
         mvs.append(recv[r, per * inner: per * inner + (b - a)])
-    return torch.cat(parts).view_as(w), torch.cat(mvs)
+    out = torch.cat(parts).view_as(w), torch.cat(mvs)
+    _mark(timing)
+    return out
 
 
 def quantize_weights_sharded_bucketed(weights, mbits, n_bits=8, sign_bits=1, group=None, ops=None, bucket_bytes=None):
@@ -246,7 +295,7 @@ def quantize_weights_sharded_bucketed(weights, mbits, n_bits=8, sign_bits=1, gro
     for i, (w, (bi, C, inner, per, off_v, off_m)) in enumerate(zip(weights, geo)):
         lo, hi = channel_partition(C, world)[rank]
         if hi > lo:
-            q, _, _, mv = ops.minmax_quantize(w[lo:hi].contiguous(), mbits, n_bits, sign_bits)
+            q, mv = _local_minmax_quantize(ops, w[lo:hi].contiguous(), mbits, n_bits, sign_bits)
             sends[bi][off_v: off_v + (hi - lo) * inner] = q.reshape(-1)
             sends[bi][off_m: off_m + (hi - lo)] = mv
         if i + 1 == len(weights) or geo[i + 1][0] != bi:   # bucket complete: ship it, go on quantizing the next

@@ -57,11 +57,15 @@ def _rows(x, per_channel):
     return 1, x.numel()
 
 
-def _workspace(dev, nbytes):
-    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+def _workspace(dev, nbytes, ticketed=False):
+    """Per-(device, stream) scratch buffer.  ticketed=True: the min/max entry points' workspace, whose leading ticket
+    counters must be zero on first use and are left zero by every call (include/fp8q.h) -- allocated zero-filled and
+    never shared with the kernels that scribble over their scratch (MSE partial sums)."""
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, ticketed)
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(max(int(nbytes), 1 << 16), dtype=torch.uint8, device=dev)
+        alloc = torch.zeros if ticketed else torch.empty
+        ws = alloc(max(int(nbytes), 1 << 16), dtype=torch.uint8, device=dev)
         _ws_cache[key] = ws
     return ws
 
@@ -84,15 +88,9 @@ def quantize(x, maxval, mbits, n_bits=8, sign_bits=1, out=None):
     return y
 
 
-def multi_quantize(items):
-    """Multi-tensor K1: quantize many tensors (all weights of a model) in one launch per 32 tensors.
-
-    items: iterable of (x, maxval, mbits[, n_bits[, sign_bits[, out]]]); every x on the same device.
-    Returns the list of outputs (bit-identical to quantize() on each item)."""
+def _pack_descs(items):
+    """ctypes descriptor array of (x, maxval, mbits[, n_bits[, sign_bits[, out]]]) items; returns (descs, outs, keep)."""
     from ._lib import TensorDesc
-    items = [tuple(it) for it in items]
-    if not items:
-        return []
     descs = (TensorDesc * len(items))()
     outs, keep = [], []
     dev0 = None
@@ -119,10 +117,66 @@ def multi_quantize(items):
         d.mbits, d.n_bits, d.sign_bits = float(mbits), int(n_bits), int(sign_bits)
         outs.append(y)
         keep.append((x, maxval))
+    return descs, outs, keep
+
+
+def multi_quantize(items):
+    """Multi-tensor K1: quantize many tensors (all weights of a model) in one launch per 32 tensors.
+
+    items: iterable of (x, maxval, mbits[, n_bits[, sign_bits[, out]]]); every x on the same device.
+    Returns the list of outputs (bit-identical to quantize() on each item)."""
+    items = [tuple(it) for it in items]
+    if not items:
+        return []
+    descs, outs, keep = _pack_descs(items)
     with _on_device(keep[0][0]):
         rc = lib().fp8q_multi_quantize_f32(descs, len(items), _stream(keep[0][0]))
     check(rc, "fp8q_multi_quantize_f32")
     return outs
+
+
+class MultiPlan:
+    """Prepared multi-tensor K1 (fp8q_multi_plan_*): the descriptors of `items` are validated and packed once;
+    launch() re-quantizes every tensor into its output with one ctypes call and one kernel launch per 32 tensors.
+    The plan records addresses: it keeps the tensors alive, their contents may change between launches (in-place
+    weight / range updates), their storage and shapes may not.  `outs` are the output tensors, in item order."""
+
+    def __init__(self, items):
+        import ctypes
+        items = [tuple(it) for it in items]
+        if not items:
+            raise Fp8qError("MultiPlan needs at least one tensor")
+        descs, self.outs, self._keep = _pack_descs(items)
+        for (x, mv), it in zip(self._keep, items):
+            if x.data_ptr() != it[0].data_ptr() or mv.data_ptr() != it[1].data_ptr():
+                raise Fp8qError("MultiPlan needs contiguous tensors (a copy would be quantized instead of the tensor)")
+        self._dev = self._keep[0][0]
+        self._h = ctypes.c_void_p()
+        check(lib().fp8q_multi_plan_create(descs, len(items), ctypes.byref(self._h)), "fp8q_multi_plan_create")
+        self._launch = lib().fp8q_multi_plan_launch
+        self._idx = self._dev.device.index
+
+    @property
+    def launches(self):
+        return int(lib().fp8q_multi_plan_launches(self._h))
+
+    def launch(self):
+        if torch.cuda.current_device() != self._idx:
+            with _on_device(self._dev):
+                rc = self._launch(self._h, _stream(self._dev))
+        else:
+            rc = self._launch(self._h, _raw_stream(self._idx) if _raw_stream is not None else _stream(self._dev))
+        if rc:
+            check(rc, "fp8q_multi_plan_launch")
+        return self.outs
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                lib().fp8q_multi_plan_destroy(h)
+            except Exception:
+                pass
 
 
 def minmax(x, per_channel, cur_min=None, cur_max=None, mode=FOLD_CURRENT, momentum=0.9,
@@ -150,7 +204,7 @@ def minmax(x, per_channel, cur_min=None, cur_max=None, mode=FOLD_CURRENT, moment
     mv = torch.empty(C, dtype=torch.float32, device=x.device) if want_maxval else None
     L = lib()
     nbytes = L.fp8q_minmax_workspace_bytes(C, inner)
-    ws = _workspace(x.device, nbytes)
+    ws = _workspace(x.device, nbytes, ticketed=True)
     with _on_device(x):
         rc = L.fp8q_minmax_f32(x.data_ptr(), C, inner, cur_min.data_ptr(), cur_max.data_ptr(),
                                mv.data_ptr() if mv is not None else None, int(mode), float(momentum),
@@ -325,7 +379,7 @@ def affine_act_minmax(x, cur_min=None, cur_max=None, mode=FOLD_CURRENT, momentum
         cur_max = torch.empty(1, dtype=torch.float32, device=x.device)
     mv = torch.empty(1, dtype=torch.float32, device=x.device)
     L = lib()
-    ws = _workspace(x.device, L.fp8q_affine_act_minmax_workspace_bytes(N, C, HW))
+    ws = _workspace(x.device, L.fp8q_affine_act_minmax_workspace_bytes(N, C, HW), ticketed=True)
     with _on_device(x):
         rc = L.fp8q_affine_act_minmax_f32(
             x.data_ptr(), residual.data_ptr() if residual is not None else None, N, C, HW, ptrs[0], ptrs[1],

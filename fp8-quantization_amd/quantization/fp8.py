@@ -36,16 +36,43 @@ round_ste_func = _RoundSTE.apply
 
 
 class _FakeQuantSTE(torch.autograd.Function):
-    """HIP forward; straight-through gradient w.r.t. x inside the clamp range is what the
-    reference's STE chain yields for the PTQ path (backward is unused under no_grad)."""
+    """HIP forward; the backward the reference's autograd chain yields (fp8_quantizer.py:105-133):
+
+      d/dx       straight-through inside the clamp range, 0 outside (torch.min / torch.max route the gradient to the
+                 bound there; an element exactly ON a bound splits it half / half, as ATen does for ties);
+      d/dmaxval  +-1 per element clipped at +-maxval (minval = -maxval is tied to it for signed formats), plus the
+                 scale term: y = round_ste(xc / s) * s gives dy/ds = round(xc / s) - xc / s, and s = 2^(p - M - bias)
+                 with bias = 2^E - log2(maxval) + const (the floor(log2|xc| + bias) part is detached) gives
+                 ds/dmaxval = s / maxval, i.e. (y - xc) / maxval per element; reduced to maxval's shape.
+
+    The backward runs as a handful of torch ops (PTQ, the path this engine accelerates, never calls it).  Mantissa
+    bits are a by-value kernel argument: no gradient (FPQuantizer.learn_mantissa_bits raises)."""
 
     @staticmethod
     def forward(ctx, x, maxval, mbits, n_bits, sign_bits):
-        return _ops.quantize(x, maxval, mbits, n_bits, sign_bits)
+        y = _ops.quantize(x.detach(), maxval.detach(), mbits, n_bits, sign_bits)
+        ctx.save_for_backward(x, maxval, y)
+        ctx.sign_bits = sign_bits
+        return y
 
     @staticmethod
     def backward(ctx, grad):
-        return grad, None, None, None, None
+        x, maxval, y = ctx.saved_tensors
+        mv = maxval.view([-1] + [1] * (x.dim() - 1)) if maxval.numel() != 1 else maxval
+        lo = -mv if ctx.sign_bits == 1 else torch.zeros_like(mv)
+        at_hi, at_lo = (x == mv), (x == lo)
+        w_x = ((x > lo) & (x < mv)).to(grad.dtype) + 0.5 * (at_hi | at_lo).to(grad.dtype)
+        grad_x = grad * w_x if ctx.needs_input_grad[0] else None
+        grad_mv = None
+        if ctx.needs_input_grad[1]:
+            xc = torch.min(torch.max(x, lo), mv)
+            w = (y - xc) / mv + (x > mv).to(grad.dtype) + 0.5 * at_hi.to(grad.dtype)
+            if ctx.sign_bits == 1:
+                w = w - (x < lo).to(grad.dtype) - 0.5 * at_lo.to(grad.dtype)
+            g = grad * w
+            grad_mv = g.sum().reshape(maxval.shape) if maxval.numel() == 1 else \
+                g.reshape(maxval.numel(), -1).sum(1).reshape(maxval.shape)
+        return grad_x, grad_mv, None, None, None
 
 
 def _host_float(t):
@@ -60,10 +87,10 @@ def quantize_to_fp8_ste_MM(x_float, n_bits, maxval, num_mantissa_bits, sign_bits
     mbits = _host_float(num_mantissa_bits)
     if not isinstance(maxval, torch.Tensor):
         maxval = torch.tensor([float(maxval)], dtype=torch.float32)
-    maxval = maxval.detach().to(device=x_float.device, dtype=torch.float32).reshape(-1)
-    if x_float.requires_grad and torch.is_grad_enabled():
+    maxval = maxval.to(device=x_float.device, dtype=torch.float32).reshape(-1)
+    if torch.is_grad_enabled() and (x_float.requires_grad or maxval.requires_grad):
         return _FakeQuantSTE.apply(x_float, maxval, mbits, int(n_bits), int(sign_bits))
-    return _ops.quantize(x_float, maxval, mbits, int(n_bits), int(sign_bits))
+    return _ops.quantize(x_float, maxval.detach(), mbits, int(n_bits), int(sign_bits))
 
 
 # ---- format enumeration (independent definition of the grid, fp8_quantizer.py:13-50) ------------
@@ -146,6 +173,15 @@ class FPQuantizer(QuantizerBase):
         self.allow_unsigned = allow_unsigned
         self.sign_bits = 1
 
+    _RANGE_ATTRS = ("maxval", "mantissa_bits", "sign_bits")
+
+    def __setattr__(self, name, value):
+        # every assignment of a range attribute starts a new range epoch: consumers that cache results computed with
+        # these ranges (the layers' quantized-weight cache) key on it instead of on tensor addresses
+        if name in FPQuantizer._RANGE_ATTRS:
+            object.__setattr__(self, "_range_epoch", getattr(self, "_range_epoch", 0) + 1)
+        super().__setattr__(name, value)
+
     # -- hot path ---------------------------------------------------------------------------
     def forward(self, x_float):
         if self.maxval.device != x_float.device:
@@ -198,8 +234,11 @@ class FPQuantizer(QuantizerBase):
         self.maxval = nn.Parameter(self.maxval)
 
     def learn_mantissa_bits(self):
-        self.learning_mantissa_bits = True
-        self.mantissa_bits = nn.Parameter(self.mantissa_bits)
+        # The reference makes mantissa_bits an nn.Parameter and lets autograd differentiate 2^E, log2(2 - 2^-M) and
+        # the scales with respect to it (fp8_quantizer.py:105-110).  Here the mantissa width is a by-value kernel
+        # argument: there is no gradient path, so say so instead of creating a Parameter that never trains.
+        raise NotImplementedError("learnable mantissa bits are a QAT feature outside this engine's path (PTQ): the HIP "
+                                  "quantizer takes the mantissa width by value and provides no gradient for it")
 
     def fix_ranges(self):
         for name in ("maxval", "mantissa_bits"):

@@ -234,9 +234,20 @@ class QuantizationHijacker(QuantizedModule):
 
     @staticmethod
     def _weight_cache_key(weight, q):
+        """What the cached quantized weight depends on.  Ranges: the quantizer's `_range_epoch` (bumped by every
+        assignment of maxval / mantissa_bits / sign_bits: set_quant_range, the estimators, load_state_dict) and the
+        range tensor's in-place version -- never a raw address alone, which a freed-and-reallocated tensor can
+        repeat.  Weights: address + autograd version, which in-place ops (optimizer steps, mul_) bump; edits
+        through `.data` do NOT -- call invalidate_weight_cache() after those (or run with FP8Q_CACHE_WEIGHTS=0)."""
         mv = q.maxval
-        return (weight.data_ptr(), weight._version, tuple(weight.shape), mv.data_ptr(), mv._version,
-                float(q.mantissa_bits), q.sign_bits, q.n_bits)
+        return (weight.data_ptr(), weight._version, tuple(weight.shape), getattr(q, "_range_epoch", None),
+                mv.data_ptr(), mv._version, float(q.mantissa_bits), q.sign_bits, q.n_bits)
+
+    def invalidate_weight_cache(self):
+        """Forget the cached quantized weight / batch-norm vectors (after `.data` edits, which bump no version)."""
+        self._wq_key = None
+        self._wq_cache = None
+        self._invstd_key = None
 
     def quantize_weights(self, weights):
         return self.weight_quantizer(weights)

@@ -83,13 +83,38 @@ def prequantize_weights(model):
         mods.append((m, w, q))
         items.append((w.detach(), mv, float(q.mantissa_bits), int(q.n_bits), int(q.sign_bits)))
     if not items:
+        model._wq_plan = None
         return 0
     import fp8q
-    outs = fp8q.ops.multi_quantize(items)
+    # a prepared plan (fp8q_multi_plan_*): descriptors validated and packed once here; requantize_weights() replays
+    # it with one launch whenever the weights' or the ranges' CONTENTS change (QAT steps, range updates in place)
+    plan = fp8q.ops.MultiPlan(items)
+    outs = plan.launch()
     for (m, w, q), y in zip(mods, outs):
         m._wq_cache = y
         m._wq_key = m._weight_cache_key(w, q)
+    model._wq_plan = (plan, mods)
     return len(outs)
+
+
+def requantize_weights(model):
+    """Refresh every layer's cached quantized weight after the weights (or the range tensors) changed IN PLACE: one
+    call into the prepared plan built by prequantize_weights() = one kernel launch for all layers (the reference
+    re-quantizes layer by layer in every forward, hijacker.py:88-98).  Falls back to a fresh prequantize_weights()
+    when a tensor was replaced rather than updated.  Returns the number of layers refreshed."""
+    held = getattr(model, "_wq_plan", None)
+    if held is None:
+        return prequantize_weights(model)
+    plan, mods = held
+    for (m, w, q), (x, mv) in zip(mods, plan._keep):
+        cur = m.get_weight_bias()[0]
+        if cur.data_ptr() != x.data_ptr() or tuple(cur.shape) != tuple(x.shape) or q.maxval.data_ptr() != mv.data_ptr():
+            return prequantize_weights(model)
+    plan.launch()
+    for (m, w, q), y in zip(mods, plan.outs):
+        m._wq_cache = y
+        m._wq_key = m._weight_cache_key(m.get_weight_bias()[0], q)
+    return len(mods)
 
 
 def export_fp8_weights(model):
@@ -245,3 +270,6 @@ class QuantizedModel(nn.Module):
 
     def prequantize_weights(self):
         return prequantize_weights(self)
+
+    def requantize_weights(self):
+        return requantize_weights(self)

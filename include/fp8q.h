@@ -27,17 +27,29 @@
 extern "C" {
 #endif
 
-#define FP8Q_VERSION 100 /* 0.1.0 */
+#define FP8Q_VERSION 200 /* 0.2.0: ticketed single-launch min/max workspaces, multi-tensor plans */
 
 #define FP8Q_OK 0
 #define FP8Q_EINVAL (-1)       /* null pointer, negative size, n_maxval not in {1, C}, ... */
 #define FP8Q_EUNSUPPORTED (-2) /* n_bits - sign_bits - M > 7 (more than 7 exponent bits) */
-#define FP8Q_EWORKSPACE (-3)   /* workspace too small */
+#define FP8Q_EWORKSPACE (-3)   /* workspace too small or misaligned */
+#define FP8Q_ETOOLONG (-4)     /* fused min/max+quantize: rows longer than fp8q_fused_max_inner() */
+#define FP8Q_ETOOMANY (-5)     /* MSE grid search: more than 65535 channels in one call */
 
 /* range-estimator fold modes (how a new batch estimate is merged into the running one) */
 #define FP8Q_FOLD_CURRENT 0 /* overwrite          range_estimators.py:72-73  CurrentMinMaxEstimator */
 #define FP8Q_FOLD_ALL 1     /* min / max          range_estimators.py:97-98  AllMinMaxEstimator     */
 #define FP8Q_FOLD_RUNNING 2 /* EMA (1-m)*new+m*cur range_estimators.py:122-123 RunningMinMaxEstimator */
+
+/*
+ * Workspaces of the min/max entry points (fp8q_minmax_f32, fp8q_affine_act_minmax_f32) begin with
+ * FP8Q_WS_TICKET_BYTES of ticket counters: the two-stage reduction runs in ONE launch, the block that draws the last
+ * ticket of a row folds the row's partial results.  Contract: those first bytes are ZERO before the first call that
+ * uses a buffer (hipMemset once after allocating it) and every call leaves them zero, so a buffer that is only ever
+ * handed to these entry points, by one stream at a time, never needs clearing again.  The rest of the workspace needs
+ * no initialisation.  Do not share one buffer between launches that may run concurrently.
+ */
+#define FP8Q_WS_TICKET_BYTES 8192
 
 typedef void *fp8q_stream_t; /* hipStream_t */
 
@@ -66,7 +78,8 @@ int fp8q_quantize_f32(const float *x, float *y, int64_t C, int64_t inner, const 
  *   x         [C, inner] fp32 (C == 1: per tensor)
  *   cur_min, cur_max [C] running estimate, updated in place;  `first` != 0: no previous estimate
  *   maxval_out [C] or NULL: |max(|cur_min|, cur_max)| after the fold
- *   ws        scratch of at least fp8q_minmax_workspace_bytes(C, inner) bytes (need not be zeroed)
+ *   ws        8-byte aligned scratch of at least fp8q_minmax_workspace_bytes(C, inner) bytes; its first
+ *             FP8Q_WS_TICKET_BYTES must be zero on first use (see above), the rest need not be
  * NaN anywhere in a row makes that row's min and max NaN (torch semantics).
  * HBM traffic: 4 B / element.
  */
@@ -159,6 +172,22 @@ typedef struct fp8q_tensor_desc {
     int n_bits, sign_bits;
 } fp8q_tensor_desc;
 int fp8q_multi_quantize_f32(const fp8q_tensor_desc *descs, int n, fp8q_stream_t stream);
+
+/*
+ * Prepared multi-tensor launch.  fp8q_multi_quantize_f32 validates, classifies and packs its descriptors on every
+ * call; for a fixed set of tensors (a model's weights after fix_ranges(), re-quantized whenever the weights change)
+ * that work is done ONCE here and a call costs one kernel launch per 32 tensors.  The plan is a small HOST object
+ * (the only allocation this library ever makes; no device memory); it records pointers, so the tensors must stay
+ * where they are and keep their shapes -- their CONTENTS (weights, ranges) may change between launches.
+ *   create    0 and *plan on success; a negative FP8Q_E* / positive hipError_t (out of host memory) otherwise
+ *   launch    bit-identical to fp8q_multi_quantize_f32 on the same descriptors; enqueue-only; thread-safe
+ *   launches  kernel launches one fp8q_multi_plan_launch enqueues
+ */
+typedef struct fp8q_multi_plan fp8q_multi_plan;
+int fp8q_multi_plan_create(const fp8q_tensor_desc *descs, int n, fp8q_multi_plan **plan);
+int fp8q_multi_plan_launch(const fp8q_multi_plan *plan, fp8q_stream_t stream);
+int fp8q_multi_plan_launches(const fp8q_multi_plan *plan);
+void fp8q_multi_plan_destroy(fp8q_multi_plan *plan);
 
 /* Plain float4 copy kernel with the same launch shape as K1: the measured HBM ceiling that
  * bench.py reports next to the 8 TB/s spec figure. */

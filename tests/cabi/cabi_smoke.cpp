@@ -62,8 +62,10 @@ int main()
     CK(hipMalloc((void **)&dmn, C * 4));
     CK(hipMalloc((void **)&dmx, C * 4));
     CK(hipMalloc((void **)&dmvo, C * 4));
-    const size_t wsb = fp8q_minmax_workspace_bytes(C, inner);
+    size_t wsb = fp8q_minmax_workspace_bytes(C, inner);
+    if (fp8q_minmax_workspace_bytes(1, n) > wsb) wsb = fp8q_minmax_workspace_bytes(1, n);
     CK(hipMalloc(&ws, wsb));
+    CK(hipMemset(ws, 0, FP8Q_WS_TICKET_BYTES));   // ticket counters: zero once, every call leaves them zero (fp8q.h)
     CK(hipMemcpy(dx, x, n * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dmv, mv, C * 4, hipMemcpyHostToDevice));
     hipStream_t st;

@@ -21,6 +21,8 @@ Fixture files:
   g7_tinycnn.npz     quantize_model on a tiny CNN (autoquant_utils.py:292-381), config-3 settings
   g8_resnet18.npz    QuantizedResNet (models/resnet_quantized.py:49-133), BASELINE config 3 at 64x64
   g9_mobilenetv2.npz QuantizedMobileNetV2 (models/mobilenet_v2_quantized.py:29-92) + MSE, config 4 at 64x64
+  g1b_bulk.npz       quantize_to_fp8_ste_MM on 4 x 4 M seeded normals: output hash + sparse difference to the C oracle
+  g10_autograd.npz   backward of quantize_to_fp8_ste_MM (d/dx, d/dmaxval)
 """
 import os
 import sys
@@ -479,7 +481,98 @@ def make_g9():
     print("g9 ok", len(out["mbv2_mgr_names"]), "managers")
 
 
+def bulk_cases():
+    """(name, seed, M, shape, maxval) of the bulk flip-rate fixture g1b; inputs are regenerated from the seed by the
+    tests (numpy's legacy RandomState stream is stable across versions): x = standard_normal(shape) as fp32."""
+    cases = []
+    for M, tag in ((2, "e5m2"), (3, "e4m3")):
+        cases.append((f"{tag}_tensor", 4100 + M, M, (1 << 22,), np.array([2.7361], np.float32)))
+        rng = np.random.RandomState(4200 + M)
+        cases.append((f"{tag}_channel", 4300 + M, M, (4096, 1024),
+                      (np.abs(rng.standard_normal(4096)) * 2 + 0.05).astype(np.float32)))
+    return cases
+
+
+def bulk_input(seed, shape):
+    return np.random.RandomState(seed).standard_normal(int(np.prod(shape))).astype(np.float32).reshape(shape)
+
+
+def ulp_key(a):
+    """monotone integer image of fp32 values (distance = ULP distance)"""
+    i = a.view(np.int32).astype(np.int64)
+    return np.where(i < 0, np.int64(-2147483648) - i, i)
+
+
+def make_g1b():
+    """4 M seeded normals x {E5M2, E4M3} x {per-tensor arbitrary maxval, per-channel} through the reference's
+    quantize_to_fp8_ste_MM.  Stored: the SHA-256 of the reference's output bytes and the sparse difference between
+    that output and the C oracle's (index deltas + ULP deltas), so the tests can rebuild the reference's output bit
+    for bit from the oracle's and pin the oracle's flip rate on bulk data -- in a few hundred KB instead of 64 MB."""
+    import hashlib
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    import oracle
+    out = {}
+    names = []
+    for name, seed, M, shape, mv in bulk_cases():
+        x = bulk_input(seed, shape)
+        with torch.no_grad():
+            y_ref = quantize_to_fp8_ste_MM(torch.from_numpy(x.copy()), 8, torch.from_numpy(mv.copy()),
+                                           torch.Tensor([float(M)]), 1).numpy()
+        y_orc = oracle.c_quantize(x, mv, M, 8, 1)
+        assert not np.isnan(y_ref).any() and not np.isnan(y_orc).any()
+        d = (ulp_key(y_ref.reshape(-1)) - ulp_key(y_orc.reshape(-1)))
+        idx = np.flatnonzero(d)
+        small = np.abs(d[idx]) <= 100
+        out[f"{name}_sha256"] = np.frombuffer(hashlib.sha256(y_ref.tobytes()).digest(), np.uint8)
+        out[f"{name}_idx_delta"] = np.diff(idx[small], prepend=0).astype(np.uint32)
+        out[f"{name}_ulp_delta"] = d[idx[small]].astype(np.int8)
+        out[f"{name}_big_idx"] = idx[~small].astype(np.int64)            # grid-step flips: stored as values
+        out[f"{name}_big_val"] = y_ref.reshape(-1)[idx[~small]]
+        names.append(name)
+        print(f"g1b {name}: {x.size} elements, {idx.size} differ from the C oracle ({idx.size / x.size:.3%}), "
+              f"{int((~small).sum())} by more than 100 ULP")
+    out["names"] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, "g1b_bulk.npz"), **out)
+
+
+def make_g10():
+    """Autograd of quantize_to_fp8_ste_MM (fp8_quantizer.py:105-133: STE rounding, clamp through torch.min/max, the
+    scale's dependence on maxval through the bias): d/dx and d/dmaxval for a fixed upstream gradient."""
+    out, cases = {}, []
+    rng = np.random.RandomState(77)
+    cid = 0
+    for M in (2, 3):
+        for sb in (1, 0):
+            for per_channel in (False, True):
+                mv = (np.abs(rng.randn(6)) + 0.3).astype(np.float32) if per_channel else np.array([1.3], np.float32)
+                x = (rng.randn(6, 50) * 0.8).astype(np.float32)
+                x[:, 0] = mv if per_channel else mv[0]            # exactly at the clamp bounds (tie in torch.min)
+                x[:, 1] = -(mv if per_channel else mv[0])
+                x[:, 2] = 0.0
+                g = rng.randn(6, 50).astype(np.float32)
+                xt = torch.from_numpy(x.copy()).requires_grad_(True)
+                mt = torch.from_numpy(mv.copy()).requires_grad_(True)
+                y = quantize_to_fp8_ste_MM(xt, 8, mt, torch.Tensor([float(M)]), sb)
+                y.backward(torch.from_numpy(g))
+                out[f"c{cid}_x"], out[f"c{cid}_maxval"], out[f"c{cid}_g"] = x, mv, g
+                out[f"c{cid}_y"] = y.detach().numpy()
+                out[f"c{cid}_gx"], out[f"c{cid}_gmaxval"] = xt.grad.numpy(), mt.grad.numpy()
+                cases.append((cid, M, sb, int(per_channel)))
+                cid += 1
+    out["cases"] = np.array(cases, dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, "g10_autograd.npz"), **out)
+    print("g10:", cid, "cases")
+
+
 if __name__ == "__main__":
+    only = sys.argv[1:]
+    if only:          # e.g.  python -B make_golden.py g1b g10
+        for name in only:
+            globals()["make_" + name]()
+        assert not os.path.exists(os.path.join(REF, "quantization", "__pycache__")), "pycache leaked"
+        sys.exit(0)
+    make_g1b()
+    make_g10()
     make_g1()
     make_g2()
     make_g3()

@@ -137,6 +137,20 @@ class LaunchChecker:
         self.real = {n: getattr(ops, n) for n in self.NAMES}
         for n in self.NAMES:
             monkeypatch.setattr(ops, n, self._wrap(n))
+        self.count["plan_launch"] = 0
+        checker = self
+
+        class CheckedPlan(ops.MultiPlan):      # the prepared multi-tensor launch fix_ranges() builds
+            def __init__(self, items):
+                self._items = [tuple(it) for it in items]
+                super().__init__(self._items)
+
+            def launch(self):
+                outs = super().launch()
+                checker.count["plan_launch"] += 1
+                checker._check_multi_quantize({"items": self._items}, outs, None)
+                return outs
+        monkeypatch.setattr(ops, "MultiPlan", CheckedPlan)
 
     def _wrap(self, name):
         real, sig = self.real[name], inspect.signature(self.real[name])
@@ -228,7 +242,14 @@ class LaunchChecker:
         what = f"mse_grid {tuple(x.shape)} per_channel={a['per_channel']}"
         if a["per_channel"] or x.numel() <= MSE_FULL_ORACLE_MAX:
             ref = oracle.c_mse_grid(_np(x), a["per_channel"], _np(grid), mb, **kw)
-            np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-30, err_msg=what)
+            # K4 forms x / s_p as x * 2^frac(bias) * 2^j (fp8q_mse.hip): the quotient can differ from the IEEE division
+            # by ~2.4e-7 relative, which moves rint() only for an element that close to the midpoint of two grid
+            # points -- where both are (almost) equally far, so that element's squared error changes by <= 2^(M+3) *
+            # 2.4e-7 relative.  On a 9-element depthwise filter one such element can be most of the row's mean.
+            inner = x.numel() // x.shape[0] if a["per_channel"] else x.numel()
+            np.testing.assert_allclose(got, ref, rtol=1e-5 if inner >= 256 else 1e-4, atol=1e-30, err_msg=what)
+            close = np.isclose(got, ref, rtol=1e-5, atol=1e-30) | ~np.isfinite(ref)
+            assert close.mean() >= 0.999, (what, close.mean())
         else:
             # a long per-tensor row: (i) the launch equals the element-weighted mean of launches over 1 Mi-element
             # slices (its split / accumulate logic at this size), (ii) two of those slices against the oracle
@@ -319,7 +340,7 @@ def test_every_launch_of_a_full_size_model_pass(tag, n_weight, n_act_min, monkey
         assert cal["mse_grid"] >= n_weight + n_act_min, cal
     assert cal["affine_act_quantize"] + cal["quantize"] >= n_act_min, cal
     # fix_ranges: all weights in the multi-tensor launch; validation: activations only (weights come from the cache)
-    assert fixed["multi_quantize"] - cal["multi_quantize"] >= 1, fixed
+    assert fixed["plan_launch"] - cal["plan_launch"] >= 1, fixed
     n_val = (c["affine_act_quantize"] + c["quantize"]) - (fixed["affine_act_quantize"] + fixed["quantize"])
     assert n_val >= n_act_min, (c, fixed)
     assert c["minmax"] == fixed["minmax"] and c["mse_grid"] == fixed["mse_grid"] \

@@ -99,6 +99,47 @@ def test_weight_channel_shard_allgather_bit_equal():
         np.testing.assert_array_equal(m, mv)
 
 
+def _w_even_job(rank, world):
+    """12 channels over 2 ranks: the even split gathers straight into the final tensors (no padding); plus rows longer
+    than the fused kernel's limit (min/max then quantize instead of the fused launch)."""
+    from fp8q import dist as fd
+    w = torch.from_numpy(_weights()[:12])
+
+    class ShortFused(OracleOps):
+        calls = []
+
+        @staticmethod
+        def fused_max_inner():
+            return 8           # 27-element rows do not fit: the guard must take the two-launch path
+
+        @staticmethod
+        def minmax_quantize(*a, **k):
+            raise AssertionError("fused launch used for rows longer than fused_max_inner()")
+
+    q, mv = fd.quantize_weight_sharded(w, 2, 8, 1, ops=OracleOps)
+    q2, mv2 = fd.quantize_weight_sharded(w, 2, 8, 1, ops=ShortFused)
+    qc, mvc, codes = fd.quantize_weight_sharded_codes(w[[0, 1, 2, 3, 5, 6, 7, 8]].contiguous(), 3, 8, 1, ops=OracleOps)
+    return q.numpy(), mv.numpy(), q2.numpy(), mv2.numpy(), qc.numpy(), mvc.numpy(), codes.numpy()
+
+
+def test_weight_even_split_and_long_rows():
+    w = _weights()[:12]
+    mn, mx = oracle.c_minmax(w, True)
+    mv = oracle.c_absmax(mn, mx)
+    ref = oracle.c_quantize(w, mv, 2, 8, 1)
+    w8 = w[[0, 1, 2, 3, 5, 6, 7, 8]]
+    mn8, mx8 = oracle.c_minmax(w8, True)
+    mv8 = oracle.c_absmax(mn8, mx8)
+    for q, m, q2, m2, qc, mc, codes in run(_w_even_job):
+        for got, gm in ((q, m), (q2, m2)):
+            assert np.array_equal(np.isnan(got), np.isnan(ref))
+            assert np.array_equal(np.nan_to_num(got).view(np.int32), np.nan_to_num(ref).view(np.int32))
+            np.testing.assert_array_equal(gm, mv)
+        assert np.array_equal(qc.view(np.int32), oracle.c_quantize(w8, mv8, 3, 8, 1).view(np.int32))
+        np.testing.assert_array_equal(mc, mv8)
+        np.testing.assert_array_equal(codes, oracle.c_encode(w8, mv8, 3, 8, 1))
+
+
 def _w_codes_job(rank, world):
     from fp8q import dist as fd
     w = torch.from_numpy(_weights()[[0, 1, 2, 3, 5, 6, 7, 8, 9, 10, 11]])   # 11 channels, no zero channel

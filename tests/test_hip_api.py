@@ -226,6 +226,76 @@ def test_prequantize_weights_multi_tensor(golden_dir):
         assert torch.equal(q(val), ref)
 
 
+def test_multi_plan_replays_and_follows_in_place_updates():
+    """fp8q_multi_plan_*: built once, launch() is bit-identical to fp8q_multi_quantize_f32 / to the oracle; in-place
+    changes of the weights or of the ranges are picked up by the next launch; tensors that cannot be batched
+    (unaligned storage, >= 64 MiB) get their own launch inside the plan."""
+    import fp8q
+    ops = fp8q.ops
+    rng = np.random.RandomState(5)
+    shapes = [(64, 3, 7, 7), (128, 64, 3, 3), (10, 33), (1, 5), (3, 4099)]
+    ws = [dev((rng.randn(*sh) * 0.1).astype(np.float32)) for sh in shapes]
+    base = torch.zeros(1000 * 7 + 1, device="cuda")
+    odd = base[1:].view(1000, 7)                     # 4-byte aligned only: not batchable
+    odd.copy_(dev(rng.randn(1000, 7).astype(np.float32)))
+    ws.append(odd)
+    mvs = [ops.minmax(w, True, want_maxval=True)[2] for w in ws[:-1]] + [torch.tensor([1.25], device="cuda")]
+    items = [(w, mv, 2 + (i % 2), 8, 1) for i, (w, mv) in enumerate(zip(ws, mvs))]
+    plan = ops.MultiPlan(items)
+    assert plan.launches == 2                        # one batched launch + the unaligned tensor
+    ref = ops.multi_quantize(items)
+    outs = plan.launch()
+    for (w, mv, M, _, _), a, b in zip(items, outs, ref):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+        want = oracle.c_quantize(w.cpu().numpy(), mv.cpu().numpy(), M, 8, 1)
+        assert np.array_equal(a.cpu().numpy().view(np.int32), want.view(np.int32))
+    with torch.no_grad():
+        ws[1].mul_(0.5)                              # weights updated in place (an optimizer step)
+        mvs[1].mul_(0.5)                             # ... and a range tensor
+    outs2 = plan.launch()
+    assert outs2[1] is outs[1]                       # same buffers
+    want = oracle.c_quantize(ws[1].cpu().numpy(), mvs[1].cpu().numpy(), 3, 8, 1)
+    assert np.array_equal(outs2[1].cpu().numpy().view(np.int32), want.view(np.int32))
+    with pytest.raises(fp8q.Fp8qError):
+        ops.MultiPlan([(ws[0].permute(1, 0, 2, 3), mvs[0], 2)])       # non-contiguous: a copy would be quantized
+
+
+def test_requantize_weights_uses_the_plan(golden_dir):
+    """QuantizedModel.requantize_weights(): after in-place weight updates every layer's cached quantized weight is
+    refreshed by ONE plan launch and equals the layer's own quantizer."""
+    from quantization.autoquant_utils import quantize_model
+    from quantization.base_quantized_classes import QuantizedModule
+    from quantization.base_quantized_model import prequantize_weights
+    from quantization.model import requantize_weights
+    from quantization.hijacker import QuantizationHijacker
+    from quantization.quantization_manager import QMethods
+    from quantization.range_estimators import RangeEstimators
+    g7 = np.load(os.path.join(golden_dir, "g7_tinycnn.npz"))
+    q = quantize_model(_tiny_cnn(g7), method=QMethods.fp_quantizer.cls,
+                       weight_range_method=RangeEstimators.current_minmax.cls,
+                       act_range_method=RangeEstimators.allminmax.cls, n_bits=8, per_channel_weights=True,
+                       fp8_kwargs=dict(maxval=None, mantissa_bits=2, set_maxval=True)).eval().cuda()
+    with torch.no_grad():
+        for m in q.modules():
+            if isinstance(m, QuantizedModule):
+                m.quantized()
+        q(dev(g7["calib"]))
+        for m in q.modules():
+            if isinstance(m, QuantizedModule):
+                m.fix_ranges()
+        assert prequantize_weights(q) == 4
+        plan = q._wq_plan[0]
+        layers = [m for m in q.modules() if isinstance(m, QuantizationHijacker)]
+        for m in layers:
+            m.weight.mul_(0.9)                       # in place: same storage, new contents
+        assert requantize_weights(q) == 4 and q._wq_plan[0] is plan
+        for m in layers:
+            assert m.get_params()[0] is m._wq_cache
+            assert torch.equal(m._wq_cache, m.weight_quantizer(m.weight))
+        layers[0].weight.data = layers[0].weight.data.clone()     # storage replaced: the plan is rebuilt
+        assert requantize_weights(q) == 4 and q._wq_plan[0] is not plan
+
+
 def test_kernel_sequence_of_the_model_flow(golden_dir, monkeypatch):
     """The manager picks the cheapest kernel sequence (module docstring of quantization/manager.py): calibration =
     ONE fused min/max+quantize launch per weight tensor (weights are Parameters: the fast path must not be lost to
@@ -246,6 +316,12 @@ def test_kernel_sequence_of_the_model_flow(golden_dir, monkeypatch):
                 return f(*a, **k)
             return w
         monkeypatch.setattr(ops, name, mk(name, getattr(ops, name)))
+
+    class CountedPlan(ops.MultiPlan):          # fix_ranges(): one prepared multi-tensor launch
+        def launch(self):
+            cnt["plan_launch"] += 1
+            return super().launch()
+    monkeypatch.setattr(ops, "MultiPlan", CountedPlan)
     g7 = np.load(os.path.join(golden_dir, "g7_tinycnn.npz"))
     q = quantize_model(_tiny_cnn(g7), method=QMethods.fp_quantizer.cls,
                        weight_range_method=RangeEstimators.current_minmax.cls,
@@ -264,7 +340,7 @@ def test_kernel_sequence_of_the_model_flow(golden_dir, monkeypatch):
         for m in q.modules():
             if isinstance(m, QuantizedModule):
                 m.fix_ranges()
-        assert prequantize_weights(q) == 4 and cnt["multi_quantize"] == 1
+        assert prequantize_weights(q) == 4 and cnt["plan_launch"] == 1
         cnt.clear()
         q(x)
         assert cnt["minmax_quantize"] == cnt["minmax"] == cnt["minmax_per_channel"] == cnt["affine_act_minmax"] == 0

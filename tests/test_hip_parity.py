@@ -41,8 +41,30 @@ def assert_bit_exact(y, y_ref, what=""):
 
 def test_library_loaded(ops):
     import fp8q
-    assert fp8q.lib().fp8q_version() == 100
+    assert fp8q.lib().fp8q_version() == 200
     assert os.path.exists(fp8q.so_path())
+
+
+def test_bulk_flip_rate_vs_reference(ops, golden_dir):
+    """HIP vs the REFERENCE on bulk data (g1b: 4 x 4 M seeded normals, {E5M2, E4M3} x {per-tensor, per-channel}):
+    <= 1 grid step everywhere, no more than 1e-5 of the elements a grid step off, the rest within 2 fp32 ULP -- and
+    bit-exact against the C oracle.  The reference's output is rebuilt from the fixture (hash-checked)."""
+    from test_oracle_golden import bulk_cases, bulk_input, reference_from_oracle
+    g = np.load(os.path.join(golden_dir, "g1b_bulk.npz"))
+    for name, seed, M, shape, mv in bulk_cases():
+        x = bulk_input(seed, shape)
+        y_orc = oracle.c_quantize(x, mv, M, 8, 1)
+        y = ops.quantize(dev(x), dev(mv), M, 8, 1).cpu().numpy()
+        assert_bit_exact(y, y_orc, f"{name} vs oracle")
+        y_ref, _, _ = reference_from_oracle(g, name, y_orc)
+        r = assert_parity(y, y_ref, elem_step(x, mv, M, 8, 1), max_flip_frac=1e-5, max_ulp=2, what=f"{name} vs reference")
+        if name.endswith("channel"):       # the fused estimate-state launch on the same rows, ranges from the data
+            yf, mn, mx, mvf = ops.minmax_quantize(dev(x), M, 8, 1)
+            rmn, rmx = oracle.c_minmax(x, True)
+            rmv = oracle.c_absmax(rmn, rmx)
+            assert_bit_exact(mvf.cpu().numpy(), rmv, f"{name} fused maxval")
+            assert_bit_exact(yf.cpu().numpy(), oracle.c_quantize(x, rmv, M, 8, 1), f"{name} fused vs oracle")
+        print(f"\n{name}: HIP vs reference bit-exact {r['exact_frac']:.4%}, flips {r['n_flips']}, max ULP {r['max_ulp_nonflip']}")
 
 
 def test_quantize_golden_and_oracle(ops, golden_dir):
@@ -54,7 +76,7 @@ def test_quantize_golden_and_oracle(ops, golden_dir):
         maxval = g1[f"c{cid}_maxval"] if mv < 0 else np.array([mv], np.float32)
         y = ops.quantize(dev(x), dev(maxval), float(mbits), 8, sb).cpu().numpy()
         assert_bit_exact(y, oracle.c_quantize(x, maxval, float(mbits), 8, sb), f"case {cid} vs oracle")
-        r = assert_parity(y, y_ref, elem_step(x, maxval, float(mbits), 8, sb), max_flip_frac=2e-2,
+        r = assert_parity(y, y_ref, elem_step(x, maxval, float(mbits), 8, sb), max_flip_frac=0.0,
                           max_ulp=2, what=f"case {cid} vs reference")
         tot += r["n"]
         exact += r["exact_frac"] * r["n"]
