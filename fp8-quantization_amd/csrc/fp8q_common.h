@@ -74,12 +74,23 @@ __device__ __forceinline__ void fold_store(float mn, float mx, int64_t row, floa
 // 4.6 us of the 38 us of a [64,64,112,112] activation (profiles/r01_*).  Workspace contract (include/fp8q.h): the
 // first FP8Q_WS_TICKET_BYTES of ws are the counters -- zero before the first use of a buffer, zero after every call;
 // the partials behind them need no initialisation.  nsplit == 1: no workspace traffic at all.
-// Visibility across the 8 XCDs (one L2 each): release fence (agent scope: L2 write-back) before the ticket atomic,
-// acquire fence (L1/L2 invalidate) after it in the last block -- the LLVM gfx942/gfx950 memory model's recipe.
+// Visibility across the 8 XCDs (one L2 each): partials are written and read with 8-byte agent-scope atomics (sc1:
+// write-through / L1-bypassing), the store is waited for before the ticket atomic; no fences (an agent-scope release
+// writes back the whole XCD L2 -- per block, that tripled the kernel's time).
 // ---------------------------------------------------------------------------------------------
 constexpr int kTicketRows = FP8Q_WS_TICKET_BYTES / 4;   // nsplit > 1 implies C <= kTargetBlocks / 2 rows
 
-__device__ __forceinline__ void block_minmax_fold(MinMax m, float2 *parts /* [nsplit] of this row */, int split, int nsplit,
+__device__ __forceinline__ unsigned long long pack_mm(float mn, float mx)
+{
+    return (unsigned long long)__float_as_uint(mn) | ((unsigned long long)__float_as_uint(mx) << 32);
+}
+
+__device__ __forceinline__ float2 unpack_mm(unsigned long long v)
+{
+    return make_float2(__uint_as_float((unsigned)v), __uint_as_float((unsigned)(v >> 32)));
+}
+
+__device__ __forceinline__ void block_minmax_fold(MinMax m, unsigned long long *parts /* [nsplit] of this row */, int split, int nsplit,
                                                   unsigned *ticket, int64_t row, float *cur_min, float *cur_max,
                                                   float *maxval_out, const FoldArgs &fa)
 {
@@ -101,8 +112,11 @@ __device__ __forceinline__ void block_minmax_fold(MinMax m, float2 *parts /* [ns
         if (nsplit == 1) {
             fold_store(mn, mx, row, cur_min, cur_max, maxval_out, fa);
         } else {
-            parts[split] = make_float2(mn, mx);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            // publish {min, max} as ONE 8-byte agent-scope atomic store (global_store_dwordx2 sc1: write-through, the
+            // line leaves this XCD's L2), wait for it, then draw the ticket.  An agent-scope release fence here would
+            // write back the whole L2 from every block (measured: 38 -> 105 us on [64,64,112,112]).
+            __hip_atomic_store(parts + split, pack_mm(mn, mx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const unsigned old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_last = old == (unsigned)(nsplit - 1);
         }
@@ -110,15 +124,17 @@ __device__ __forceinline__ void block_minmax_fold(MinMax m, float2 *parts /* [ns
     if (nsplit == 1) return;
     __syncthreads();
     if (!s_last) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    // the row's partials: independent loads (<= 2048 of them per row).  An EMPTY split (a row a few elements longer
-    // than a whole number of steps) holds {+inf, -inf}, so the two halves must not be mixed.
+    // the row's partials: independent 8-byte agent-scope atomic loads (sc1: bypass this CU's L1; no block of this launch
+    // has read these lines before, so this XCD's L2 holds no older copy) -- no acquire fence needed (guide: "sc1 loads
+    // may replace the acquire when the producer stored sc1").  An EMPTY split (a row a few elements longer than a whole
+    // number of steps) holds {+inf, -inf}, so the two halves must not be mixed.
     mm_init(m);
     float2 v[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
         const int s2 = tid + u * kBlock;
-        v[u] = s2 < nsplit ? parts[s2] : make_float2(__builtin_inff(), -__builtin_inff());
+        v[u] = s2 < nsplit ? unpack_mm(__hip_atomic_load(parts + s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                           : make_float2(__builtin_inff(), -__builtin_inff());
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -127,7 +143,7 @@ __device__ __forceinline__ void block_minmax_fold(MinMax m, float2 *parts /* [ns
         m.mx = fmaxf(m.mx, v[u].y);
     }
     for (int s2 = tid + 8 * kBlock; s2 < nsplit; s2 += kBlock) {
-        const float2 ab = parts[s2];
+        const float2 ab = unpack_mm(__hip_atomic_load(parts + s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         m.nan |= (ab.x != ab.x) | (ab.y != ab.y);
         m.mn = fminf(m.mn, ab.x);
         m.mx = fmaxf(m.mx, ab.y);
@@ -144,7 +160,9 @@ __device__ __forceinline__ void block_minmax_fold(MinMax m, float2 *parts /* [ns
         float mx = fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3]));
         if (s_nan[0] | s_nan[1] | s_nan[2] | s_nan[3]) mn = mx = __builtin_nanf("");
         fold_store(mn, mx, row, cur_min, cur_max, maxval_out, fa);
-        *ticket = 0u;   // the next call on this workspace is ordered behind this kernel (same stream)
+        // back to zero for the next call on this workspace (ordered behind this kernel: same stream); atomic so that it
+        // lands where the ticket atomics operate, not in this XCD's L2
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

@@ -171,7 +171,7 @@ k_affine_act(const float *__restrict__ x, const float *__restrict__ res, float *
 __global__ void __launch_bounds__(kBlock)
 k_affine_minmax(const float *__restrict__ x, const float *__restrict__ res, const float *__restrict__ mean,
                 const float *__restrict__ invstd, const float *__restrict__ gamma,
-                const float *__restrict__ beta, AffineArgs a, int64_t N, float2 *parts, unsigned *ticket,
+                const float *__restrict__ beta, AffineArgs a, int64_t N, unsigned long long *parts, unsigned *ticket,
                 float *cur_min, float *cur_max, float *maxval_out, FoldArgs fa)
 {
     const int tid = threadIdx.x;
@@ -320,7 +320,7 @@ int fp8q_affine_act_minmax_f32(const float *x, const float *residual, int64_t N,
     fa.om = (float)(1.0 - momentum);
     fa.mo = (float)momentum;
     hipLaunchKernelGGL(k_affine_minmax, dim3((unsigned)bx, (unsigned)by), dim3(kBlock), 0, st, x, residual, mean, invstd,
-                       gamma, beta, a, N, (float2 *)((char *)ws + FP8Q_WS_TICKET_BYTES), (unsigned *)ws, cur_min, cur_max,
+                       gamma, beta, a, N, (unsigned long long *)((char *)ws + FP8Q_WS_TICKET_BYTES), (unsigned *)ws, cur_min, cur_max,
                        maxval_out, fa);
     return launch_rc();
 }

@@ -113,7 +113,7 @@ k_mse_grid(const float *__restrict__ x, const float *__restrict__ grid, double *
 // ---------------------------------------------------------------------------------------------
 constexpr int kMseRowTile = 2048;     // elements per wave and tile: 32 per lane
 constexpr int kMseRowEpl = 32;
-constexpr int kMseRowGroup = 256;     // candidates per block (LDS: 40 B each)
+constexpr int kMseRowGroup = 128;     // candidates per block (LDS: 32 B each; two double accumulators per lane)
 constexpr int kMseRowMinInner = 2048; // shorter rows: k_mse_grid (lane = candidate)
 
 typedef float vf2 __attribute__((ext_vector_type(2)));
@@ -142,7 +142,6 @@ k_mse_row(const float *__restrict__ x, const float *__restrict__ grid, double *_
           int64_t ntiles, int tpb, int ngroup, int gsize)
 {
     __shared__ CandK cst[kMseRowGroup];
-    __shared__ double acc[kMseRowGroup];
     const int lane = threadIdx.x;
     const int64_t c = blockIdx.z;
     const int total = a.n_m * a.n_cand;
@@ -168,9 +167,13 @@ k_mse_row(const float *__restrict__ x, const float *__restrict__ grid, double *_
         k.fast = ch.pthr >= 0.0f && lin && e_lo >= 24 && f.M <= 22.0f && (e_lo - 1 + f.pmax) + 23 - (int)f.M <= 254;
         k.m = m;
         cst[j] = k;
-        acc[j] = 0.0;
     }
     __syncthreads();   // one wave: this is only the LDS ordering point
+    // candidate (64 q + L) of the group accumulates, in double, in register dacc[q] of lane L: no LDS read-modify-write
+    // (and no wait for one) per candidate
+    double dacc[kMseRowGroup / 64];
+#pragma unroll
+    for (int q = 0; q < kMseRowGroup / 64; ++q) dacc[q] = 0.0;
     const float *xr = x + c * a.inner;
     const int64_t t_begin = (int64_t)blockIdx.x * tpb;
     const int64_t t_end = min(t_begin + tpb, ntiles);
@@ -195,55 +198,65 @@ k_mse_row(const float *__restrict__ x, const float *__restrict__ grid, double *_
                 xv[2 * u + 1] = vf2{e[2], e[3]};
             }
         }
-        for (int j = 0; j < ng; ++j) {
-            const CandK k = cst[j];
-            vf2 pa = {0.0f, 0.0f};
-            if (__builtin_expect(k.fast, 1)) {
-                const vf2 c1 = {k.c1, k.c1}, m0 = {k.m0, k.m0};
 #pragma unroll
-                for (int u = 0; u < kMseRowEpl / 2; ++u) {
-                    const vf2 xx = xv[u];
-                    const vf2 xc = {__builtin_amdgcn_fmed3f(xx.x, k.minv, k.maxv), __builtin_amdgcn_fmed3f(xx.y, k.minv, k.maxv)};
-                    const vf2 tt = xc * c1;
-                    const uint32_t b0 = max(__float_as_uint(tt.x) & 0x7f800000u, k.lo) + k.kadd;
-                    const uint32_t b1 = max(__float_as_uint(tt.y) & 0x7f800000u, k.lo) + k.kadd;
-                    const vf2 cc = {__uint_as_float(b0), __uint_as_float(b1)};
-                    const vf2 rr = (tt + cc) - cc;          // t rounded to M fraction bits, half to even
-                    const vf2 d = xx - rr * m0;
-                    pa = __builtin_elementwise_fma(d, d, pa);
-                }
-            } else {
-                // exact per-element path (scales not exactly geometric in fp32, tiny / huge / degenerate ranges)
-                const QFmt f = a.fmt[k.m];
-                const Chan ch = make_chan(k.maxv, f);
-                const int koff = ch.bi - 127;
-                const int e_lo = 1 - koff, e_hi = f.pmax - koff;
-                const int jk = (int)f.M + ch.bi - koff;
-#pragma unroll 1
-                for (int u = 0; u < kMseRowEpl / 2; ++u) {
-                    const float e[2] = {xv[u].x, xv[u].y};
-                    float dd[2];
+        for (int jq = 0; jq < kMseRowGroup / 64; ++jq) {
+            const int jb = jq * 64;
+            if (jb >= ng) break;   // wave-uniform
+            const int jn = min(64, ng - jb);
+            double acc = dacc[jq];
+            CandK k = cst[jb];
+            for (int jl = 0; jl < jn; ++jl) {
+                const CandK kn = cst[jb + min(jl + 1, jn - 1)];   // next candidate's constants: in flight during this one
+                vf2 pa = {0.0f, 0.0f};
+                if (__builtin_expect(k.fast, 1)) {
+                    const vf2 c1 = {k.c1, k.c1}, m0 = {k.m0, k.m0};
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const float xc = __builtin_amdgcn_fmed3f(e[q], ch.minv, ch.maxv);
-                        const float tt = xc * k.c1;
-                        int e8 = (int)__builtin_amdgcn_ubfe(__float_as_uint(tt), 23u, 8u);
-                        e8 = max(min(e8, e_hi), e_lo);
-                        const float r = rintf(ldexpf(tt, jk - e8));
-                        dd[q] = e[q] - r * scale_exact(ch, (float)(e8 + koff), f.M);
+                    for (int u = 0; u < kMseRowEpl / 2; ++u) {
+                        const vf2 xx = xv[u];
+                        const vf2 xc = {__builtin_amdgcn_fmed3f(xx.x, k.minv, k.maxv), __builtin_amdgcn_fmed3f(xx.y, k.minv, k.maxv)};
+                        const vf2 tt = xc * c1;
+                        const uint32_t b0 = max(__float_as_uint(tt.x) & 0x7f800000u, k.lo) + k.kadd;
+                        const uint32_t b1 = max(__float_as_uint(tt.y) & 0x7f800000u, k.lo) + k.kadd;
+                        const vf2 cc = {__uint_as_float(b0), __uint_as_float(b1)};
+                        const vf2 rr = (tt + cc) - cc;          // t rounded to M fraction bits, half to even
+                        const vf2 d = xx - rr * m0;
+                        pa = __builtin_elementwise_fma(d, d, pa);
                     }
-                    pa = __builtin_elementwise_fma(vf2{dd[0], dd[1]}, vf2{dd[0], dd[1]}, pa);
+                } else {
+                    // exact per-element path (scales not exactly geometric in fp32, tiny / huge / degenerate ranges)
+                    const QFmt f = a.fmt[k.m];
+                    const Chan ch = make_chan(k.maxv, f);
+                    const int koff = ch.bi - 127;
+                    const int e_lo = 1 - koff, e_hi = f.pmax - koff;
+                    const int jk = (int)f.M + ch.bi - koff;
+#pragma unroll 1
+                    for (int u = 0; u < kMseRowEpl / 2; ++u) {
+                        const float e[2] = {xv[u].x, xv[u].y};
+                        float dd[2];
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const float xc = __builtin_amdgcn_fmed3f(e[q], ch.minv, ch.maxv);
+                            const float tt = xc * k.c1;
+                            int e8 = (int)__builtin_amdgcn_ubfe(__float_as_uint(tt), 23u, 8u);
+                            e8 = max(min(e8, e_hi), e_lo);
+                            const float r = rintf(ldexpf(tt, jk - e8));
+                            dd[q] = e[q] - r * scale_exact(ch, (float)(e8 + koff), f.M);
+                        }
+                        pa = __builtin_elementwise_fma(vf2{dd[0], dd[1]}, vf2{dd[0], dd[1]}, pa);
+                    }
                 }
+                const float s = wave_sum(pa.x + pa.y);       // wave-uniform
+                acc += lane == jl ? (double)s : 0.0;
+                k = kn;
             }
-            const float s = wave_sum(pa.x + pa.y);
-            if (lane == 0) acc[j] += (double)s;
+            dacc[jq] = acc;
         }
     }
-    __syncthreads();
     const int64_t nblk = gridDim.x;
-    for (int j = lane; j < ng; j += 64) {
-        const int jj = j0 + j;                    // == m * n_cand + cand
-        ws[((c * total) + jj) * nblk + blockIdx.x] = acc[j];
+#pragma unroll
+    for (int jq = 0; jq < kMseRowGroup / 64; ++jq) {
+        const int j = jq * 64 + lane;
+        if (j < ng) ws[((c * total) + (j0 + j)) * nblk + blockIdx.x] = dacc[jq];   // j0 + j == m * n_cand + cand
     }
 }
 

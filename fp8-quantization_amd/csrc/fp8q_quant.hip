@@ -1003,7 +1003,7 @@ k_quant_scalar(const float *__restrict__ x, float *__restrict__ y, int64_t inner
 // ---------------------------------------------------------------------------------------------
 template <bool NT>
 __global__ void __launch_bounds__(kBlock)
-k_minmax_partial(const float *__restrict__ x, int64_t inner, int nsplit, float2 *parts, unsigned *tickets,
+k_minmax_partial(const float *__restrict__ x, int64_t inner, int nsplit, unsigned long long *parts, unsigned *tickets,
                  float *cur_min, float *cur_max, float *maxval_out, FoldArgs fa)
 {
     const int row = blockIdx.y, split = blockIdx.x, tid = threadIdx.x;
@@ -1460,7 +1460,7 @@ int fp8q_minmax_f32(const float *x, int64_t C, int64_t inner, float *cur_min, fl
     const int ns = minmax_nsplit(C, inner);
     if (ns > 1 && C > kTicketRows) return FP8Q_EINVAL;   // cannot happen: ns > 1 only for C <= kTargetBlocks / 2
     unsigned *tickets = (unsigned *)ws;
-    float2 *parts = (float2 *)((char *)ws + FP8Q_WS_TICKET_BYTES);
+    unsigned long long *parts = (unsigned long long *)((char *)ws + FP8Q_WS_TICKET_BYTES);
     for (int64_t c0 = 0; c0 < C; c0 += 65535) {
         const int64_t cn = (C - c0) < 65535 ? (C - c0) : 65535;
         if (C * inner * 4 >= kNtBytes)
