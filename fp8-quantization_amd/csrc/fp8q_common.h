@@ -4,6 +4,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <math.h>
+
+#include <atomic>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -68,35 +70,29 @@ __device__ __forceinline__ void fold_store(float mn, float mx, int64_t row, floa
 }
 
 // ---------------------------------------------------------------------------------------------
-// K2/K3 two-stage min/max in ONE launch.  Block (split, row) publishes {min, max} of its part of the row in the
-// workspace and draws a ticket of the row; the block that draws the row's LAST ticket reduces the row's partials,
-// folds them into the running estimate (+ K5) and returns the ticket counter to zero.  A separate stage-2 launch cost
-// 4.6 us of the 38 us of a [64,64,112,112] activation (profiles/r01_*).  Workspace contract (include/fp8q.h): the
-// first FP8Q_WS_TICKET_BYTES of ws are the counters -- zero before the first use of a buffer, zero after every call;
-// the partials behind them need no initialisation.  nsplit == 1: no workspace traffic at all.
-// Visibility across the 8 XCDs (one L2 each): partials are written and read with 8-byte agent-scope atomics (sc1:
-// write-through / L1-bypassing), the store is waited for before the ticket atomic; no fences (an agent-scope release
-// writes back the whole XCD L2 -- per block, that tripled the kernel's time).
+// K2/K3 two-stage min/max in ONE launch (a separate stage-2 launch cost ~8 of the 38 us of a [64,64,112,112]
+// activation).  Every streaming block publishes {min, max} of its part of a row as two tagged 8-byte granules
+// {value, tag} with agent-scope atomic stores (global_store_dwordx2 sc1: write-through, untorn) and exits -- no wait,
+// no ticket.  One extra block per row (blockIdx.x == nsplit) is the reducer: it polls the row's granules until every
+// tag has arrived, reduces, folds into the running estimate (+ K5) and clears the granules again.
+// Measured and rejected: last-block-done tickets -- an agent-scope release fence per block writes back the XCD's whole
+// L2 (38 -> 105 us); sc1 partials + a ticket atomic per block serialise ~1600 same-address atomics behind two memory
+// round trips at every block's end (45 us).
+// Workspace contract (include/fp8q.h): zero before the first use of a buffer, zero again after every call.  `tag` is a
+// per-call nonzero value from the host, so a stale or foreign word is not mistaken for an arrival.
+// The reducer spins: bounded (~2 s), after which it reports NaN instead of hanging the queue.  It cannot starve the
+// streaming blocks: they never wait for anything, and it holds one workgroup slot.
 // ---------------------------------------------------------------------------------------------
-constexpr int kTicketRows = FP8Q_WS_TICKET_BYTES / 4;   // nsplit > 1 implies C <= kTargetBlocks / 2 rows
-
-__device__ __forceinline__ unsigned long long pack_mm(float mn, float mx)
+__device__ __forceinline__ unsigned long long pack_tagged(float v, unsigned tag)
 {
-    return (unsigned long long)__float_as_uint(mn) | ((unsigned long long)__float_as_uint(mx) << 32);
+    return (unsigned long long)__float_as_uint(v) | ((unsigned long long)tag << 32);
 }
 
-__device__ __forceinline__ float2 unpack_mm(unsigned long long v)
-{
-    return make_float2(__uint_as_float((unsigned)v), __uint_as_float((unsigned)(v >> 32)));
-}
-
-__device__ __forceinline__ void block_minmax_fold(MinMax m, unsigned long long *parts /* [nsplit] of this row */, int split, int nsplit,
-                                                  unsigned *ticket, int64_t row, float *cur_min, float *cur_max,
-                                                  float *maxval_out, const FoldArgs &fa)
+// block-level reduction of m -> thread 0 holds {mn, mx} (NaN-propagating); returns true in thread 0 only
+__device__ __forceinline__ bool block_minmax(MinMax m, float &mn, float &mx)
 {
     __shared__ float s_mn[4], s_mx[4];
     __shared__ int s_nan[4];
-    __shared__ int s_last;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     mm_wave_reduce(m);
     if (lane == 0) {
@@ -105,65 +101,68 @@ __device__ __forceinline__ void block_minmax_fold(MinMax m, unsigned long long *
         s_nan[wave] = m.nan;
     }
     __syncthreads();
-    if (tid == 0) {
-        float mn = fminf(fminf(s_mn[0], s_mn[1]), fminf(s_mn[2], s_mn[3]));
-        float mx = fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3]));
-        if (s_nan[0] | s_nan[1] | s_nan[2] | s_nan[3]) mn = mx = __builtin_nanf("");
-        if (nsplit == 1) {
-            fold_store(mn, mx, row, cur_min, cur_max, maxval_out, fa);
-        } else {
-            // publish {min, max} as ONE 8-byte agent-scope atomic store (global_store_dwordx2 sc1: write-through, the
-            // line leaves this XCD's L2), wait for it, then draw the ticket.  An agent-scope release fence here would
-            // write back the whole L2 from every block (measured: 38 -> 105 us on [64,64,112,112]).
-            __hip_atomic_store(parts + split, pack_mm(mn, mx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const unsigned old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_last = old == (unsigned)(nsplit - 1);
-        }
-    }
-    if (nsplit == 1) return;
-    __syncthreads();
-    if (!s_last) return;
-    // the row's partials: independent 8-byte agent-scope atomic loads (sc1: bypass this CU's L1; no block of this launch
-    // has read these lines before, so this XCD's L2 holds no older copy) -- no acquire fence needed (guide: "sc1 loads
-    // may replace the acquire when the producer stored sc1").  An EMPTY split (a row a few elements longer than a whole
-    // number of steps) holds {+inf, -inf}, so the two halves must not be mixed.
-    mm_init(m);
-    float2 v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const int s2 = tid + u * kBlock;
-        v[u] = s2 < nsplit ? unpack_mm(__hip_atomic_load(parts + s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-                           : make_float2(__builtin_inff(), -__builtin_inff());
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        m.nan |= (v[u].x != v[u].x) | (v[u].y != v[u].y);
-        m.mn = fminf(m.mn, v[u].x);
-        m.mx = fmaxf(m.mx, v[u].y);
-    }
-    for (int s2 = tid + 8 * kBlock; s2 < nsplit; s2 += kBlock) {
-        const float2 ab = unpack_mm(__hip_atomic_load(parts + s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        m.nan |= (ab.x != ab.x) | (ab.y != ab.y);
-        m.mn = fminf(m.mn, ab.x);
-        m.mx = fmaxf(m.mx, ab.y);
-    }
-    mm_wave_reduce(m);
-    if (lane == 0) {
-        s_mn[wave] = m.mn;
-        s_mx[wave] = m.mx;
-        s_nan[wave] = m.nan;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        float mn = fminf(fminf(s_mn[0], s_mn[1]), fminf(s_mn[2], s_mn[3]));
-        float mx = fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3]));
-        if (s_nan[0] | s_nan[1] | s_nan[2] | s_nan[3]) mn = mx = __builtin_nanf("");
+    if (tid != 0) return false;
+    mn = fminf(fminf(s_mn[0], s_mn[1]), fminf(s_mn[2], s_mn[3]));
+    mx = fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3]));
+    if (s_nan[0] | s_nan[1] | s_nan[2] | s_nan[3]) mn = mx = __builtin_nanf("");
+    return true;
+}
+
+// a streaming block's exit: publish (or, when the row has a single block, fold directly)
+__device__ __forceinline__ void block_minmax_publish(MinMax m, unsigned long long *slots /* [2 * nsplit] of this row */,
+                                                     int split, int nsplit, unsigned tag, int64_t row, float *cur_min,
+                                                     float *cur_max, float *maxval_out, const FoldArgs &fa)
+{
+    float mn, mx;
+    if (!block_minmax(m, mn, mx)) return;
+    if (nsplit == 1) {
         fold_store(mn, mx, row, cur_min, cur_max, maxval_out, fa);
-        // back to zero for the next call on this workspace (ordered behind this kernel: same stream); atomic so that it
-        // lands where the ticket atomics operate, not in this XCD's L2
-        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        __hip_atomic_store(slots + 2 * split, pack_tagged(mn, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(slots + 2 * split + 1, pack_tagged(mx, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+}
+
+// the reducer block of a row
+__device__ __forceinline__ void block_minmax_collect(unsigned long long *slots, int nsplit, unsigned tag, int64_t row,
+                                                     float *cur_min, float *cur_max, float *maxval_out, const FoldArgs &fa)
+{
+    const int tid = threadIdx.x;
+    MinMax m;
+    mm_init(m);
+    int lost = 0;
+    for (int s2 = tid; s2 < nsplit; s2 += kBlock) {
+        unsigned long long a = 0, b = 0;
+        int spins = 0;
+        for (;;) {   // agent-scope atomic loads (sc1): served past this CU's L1, see other XCDs' write-through stores
+            a = __hip_atomic_load(slots + 2 * s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            b = __hip_atomic_load(slots + 2 * s2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (((unsigned)(a >> 32) == tag) & ((unsigned)(b >> 32) == tag)) break;
+            if (++spins > (1 << 21)) {   // ~2 s: something upstream died; do not hang the queue
+                lost = 1;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(16);
+        }
+        const float mn = __uint_as_float((unsigned)a), mx = __uint_as_float((unsigned)b);
+        // an EMPTY split (a row a few elements longer than a whole number of steps) holds {+inf, -inf}
+        m.nan |= (mn != mn) | (mx != mx) | lost;
+        m.mn = fminf(m.mn, mn);
+        m.mx = fmaxf(m.mx, mx);
+        // consumed: back to zero for the next call on this workspace (ordered behind this kernel: same stream)
+        __hip_atomic_store(slots + 2 * s2, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(slots + 2 * s2 + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    float mn, mx;
+    if (block_minmax(m, mn, mx)) fold_store(mn, mx, row, cur_min, cur_max, maxval_out, fa);
+}
+
+// per-call tag of the granules: nonzero, different from call to call (a multiplicative hash of a process-wide counter)
+inline unsigned next_minmax_tag()
+{
+    static std::atomic<unsigned> counter{0};
+    const unsigned t = (counter.fetch_add(1, std::memory_order_relaxed) + 1u) * 0x9E3779B1u;
+    return t ? t : 0x9E3779B1u;
 }
 
 // ---------------------------------------------------------------------------------------------

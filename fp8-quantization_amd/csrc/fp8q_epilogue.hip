@@ -171,15 +171,20 @@ k_affine_act(const float *__restrict__ x, const float *__restrict__ res, float *
 __global__ void __launch_bounds__(kBlock)
 k_affine_minmax(const float *__restrict__ x, const float *__restrict__ res, const float *__restrict__ mean,
                 const float *__restrict__ invstd, const float *__restrict__ gamma,
-                const float *__restrict__ beta, AffineArgs a, int64_t N, unsigned long long *parts, unsigned *ticket,
-                float *cur_min, float *cur_max, float *maxval_out, FoldArgs fa)
+                const float *__restrict__ beta, AffineArgs a, int64_t N, unsigned long long *slots, int nparts,
+                unsigned tag, float *cur_min, float *cur_max, float *maxval_out, FoldArgs fa)
 {
+    const int nby = nparts / (int)gridDim.x;   // block rows that stream; one more row holds the reducer (nparts > 1)
+    if ((int)blockIdx.y == nby) {
+        if (blockIdx.x == 0) block_minmax_collect(slots, nparts, tag, 0, cur_min, cur_max, maxval_out, fa);
+        return;
+    }
     const int tid = threadIdx.x;
     MinMax mm;
     mm_init(mm);
     const int nvec = (int)(a.image >> 2);
     const uint32_t HW = (uint32_t)a.HW;
-    for (int64_t img = blockIdx.y; img < N; img += gridDim.y) {   // more than 65535 images: several per block row
+    for (int64_t img = blockIdx.y; img < N; img += nby) {   // more than 65535 images: several per block row
     const int64_t base = img * a.image;
     const vf4 *xv = reinterpret_cast<const vf4 *>(x + base);
     const vf4 *rv = reinterpret_cast<const vf4 *>(res + (a.has_res ? base : 0));
@@ -213,8 +218,8 @@ k_affine_minmax(const float *__restrict__ x, const float *__restrict__ res, cons
         for (int q = 0; q < 4; ++q) mm_acc(mm, e[q]);
     }
     }
-    block_minmax_fold(mm, parts, (int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y), ticket, 0,
-                      cur_min, cur_max, maxval_out, fa);
+    block_minmax_publish(mm, slots, (int)(blockIdx.y * gridDim.x + blockIdx.x), nparts, tag, 0, cur_min, cur_max,
+                         maxval_out, fa);
 }
 
 }  // namespace
@@ -244,7 +249,7 @@ static int affine_args(int64_t N, int64_t C, int64_t HW, int act, bool has_bn, b
 
 static void affine_grid(int64_t N, const AffineArgs &a, bool quant, int64_t *bx, int64_t *by)
 {
-    *by = N < 65535 ? N : 65535;
+    *by = N < 65534 ? N : 65534;   // the calibration twin adds one block row for its reducer
     const int64_t nvec = a.image >> 2;
     if (quant) {
         // one 16 KiB piece per block while the grid stays below 64 K blocks; a partial last piece of the
@@ -296,7 +301,7 @@ size_t fp8q_affine_act_minmax_workspace_bytes(int64_t N, int64_t C, int64_t HW)
     if (N <= 0 || affine_args(N, C, HW, 0, false, false, &a) != FP8Q_OK) return 16;
     int64_t bx, by;
     affine_grid(N, a, false, &bx, &by);
-    return FP8Q_WS_TICKET_BYTES + (size_t)(bx * by) * 2 * sizeof(float) + 16;   // tickets + one {min, max} per block
+    return (size_t)(bx * by) * 2 * sizeof(unsigned long long) + 16;   // two tagged granules per streaming block
 }
 
 int fp8q_affine_act_minmax_f32(const float *x, const float *residual, int64_t N, int64_t C, int64_t HW,
@@ -319,9 +324,11 @@ int fp8q_affine_act_minmax_f32(const float *x, const float *residual, int64_t N,
     fa.first = first != 0;
     fa.om = (float)(1.0 - momentum);
     fa.mo = (float)momentum;
-    hipLaunchKernelGGL(k_affine_minmax, dim3((unsigned)bx, (unsigned)by), dim3(kBlock), 0, st, x, residual, mean, invstd,
-                       gamma, beta, a, N, (unsigned long long *)((char *)ws + FP8Q_WS_TICKET_BYTES), (unsigned *)ws, cur_min, cur_max,
-                       maxval_out, fa);
+    const int nparts = (int)(bx * by);
+    // one more block row for the reducer when there is more than one streaming block (by <= 65535 - 1: affine_grid)
+    hipLaunchKernelGGL(k_affine_minmax, dim3((unsigned)bx, (unsigned)(nparts > 1 ? by + 1 : by)), dim3(kBlock), 0, st, x,
+                       residual, mean, invstd, gamma, beta, a, N, (unsigned long long *)ws, nparts, next_minmax_tag(),
+                       cur_min, cur_max, maxval_out, fa);
     return launch_rc();
 }
 

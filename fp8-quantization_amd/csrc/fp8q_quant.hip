@@ -998,14 +998,19 @@ k_quant_scalar(const float *__restrict__ x, float *__restrict__ y, int64_t inner
 }
 
 // ---------------------------------------------------------------------------------------------
-// K2/K3: min / max / NaN of x[row, split range]; the block that finishes a row last folds the row's partials into
-// the running estimate (block_minmax_fold, fp8q_common.h): one launch.
+// K2/K3: min / max / NaN of x[row, split range], published as tagged granules; block nsplit of a row is the row's
+// reducer (block_minmax_publish / block_minmax_collect, fp8q_common.h): one launch.
 // ---------------------------------------------------------------------------------------------
 template <bool NT>
 __global__ void __launch_bounds__(kBlock)
-k_minmax_partial(const float *__restrict__ x, int64_t inner, int nsplit, unsigned long long *parts, unsigned *tickets,
+k_minmax_partial(const float *__restrict__ x, int64_t inner, int nsplit, unsigned long long *slots, unsigned tag,
                  float *cur_min, float *cur_max, float *maxval_out, FoldArgs fa)
 {
+    if ((int)blockIdx.x == nsplit) {   // only launched when nsplit > 1
+        block_minmax_collect(slots + (int64_t)blockIdx.y * nsplit * 2, nsplit, tag, blockIdx.y, cur_min, cur_max,
+                             maxval_out, fa);
+        return;
+    }
     const int row = blockIdx.y, split = blockIdx.x, tid = threadIdx.x;
     const float *xr = x + (int64_t)row * inner;
     MinMax m;
@@ -1046,8 +1051,7 @@ k_minmax_partial(const float *__restrict__ x, int64_t inner, int nsplit, unsigne
             }
         }
     }
-    block_minmax_fold(m, parts + (int64_t)row * nsplit, split, nsplit, tickets + (nsplit > 1 ? row : 0), row, cur_min,
-                      cur_max, maxval_out, fa);
+    block_minmax_publish(m, slots + (int64_t)row * nsplit * 2, split, nsplit, tag, row, cur_min, cur_max, maxval_out, fa);
 }
 
 // 16-byte-per-lane copy with K1's launch shape: the achievable-HBM yardstick
@@ -1425,9 +1429,10 @@ static int minmax_nsplit(int64_t C, int64_t inner)
 
 size_t fp8q_minmax_workspace_bytes(int64_t C, int64_t inner)
 {
-    if (C <= 0 || inner <= 0) return FP8Q_WS_TICKET_BYTES + 16;
-    if (inner <= direct_max_inner() && C > 1) return FP8Q_WS_TICKET_BYTES + 16;  // short-row path needs none
-    return FP8Q_WS_TICKET_BYTES + (size_t)C * (size_t)minmax_nsplit(C, inner) * 2 * sizeof(float) + 16;
+    if (C <= 0 || inner <= 0) return 16;
+    if (inner <= direct_max_inner() && C > 1) return 16;  // short-row path needs none
+    const int ns = minmax_nsplit(C, inner);
+    return ns > 1 ? (size_t)C * (size_t)ns * 2 * sizeof(unsigned long long) + 16 : 16;   // two tagged granules per part
 }
 
 int fp8q_minmax_f32(const float *x, int64_t C, int64_t inner, float *cur_min, float *cur_max,
@@ -1458,18 +1463,17 @@ int fp8q_minmax_f32(const float *x, int64_t C, int64_t inner, float *cur_min, fl
     }
     if (ws_bytes < fp8q_minmax_workspace_bytes(C, inner) || !ws || ((uintptr_t)ws & 7)) return FP8Q_EWORKSPACE;
     const int ns = minmax_nsplit(C, inner);
-    if (ns > 1 && C > kTicketRows) return FP8Q_EINVAL;   // cannot happen: ns > 1 only for C <= kTargetBlocks / 2
-    unsigned *tickets = (unsigned *)ws;
-    unsigned long long *parts = (unsigned long long *)((char *)ws + FP8Q_WS_TICKET_BYTES);
-    for (int64_t c0 = 0; c0 < C; c0 += 65535) {
+    const unsigned tag = next_minmax_tag();
+    const unsigned gx = ns > 1 ? (unsigned)ns + 1u : 1u;   // + the row's reducer block
+    for (int64_t c0 = 0; c0 < C; c0 += 65535) {   // ns > 1 implies C <= kTargetBlocks / 2: a single slab
         const int64_t cn = (C - c0) < 65535 ? (C - c0) : 65535;
         if (C * inner * 4 >= kNtBytes)
-            hipLaunchKernelGGL(k_minmax_partial<true>, dim3((unsigned)ns, (unsigned)cn), dim3(kBlock), 0, st,
-                               x + c0 * inner, inner, ns, parts + c0 * ns, tickets, cur_min + c0, cur_max + c0,
+            hipLaunchKernelGGL(k_minmax_partial<true>, dim3(gx, (unsigned)cn), dim3(kBlock), 0, st, x + c0 * inner, inner,
+                               ns, (unsigned long long *)ws, tag, cur_min + c0, cur_max + c0,
                                maxval_out ? maxval_out + c0 : nullptr, fa);
         else
-            hipLaunchKernelGGL(k_minmax_partial<false>, dim3((unsigned)ns, (unsigned)cn), dim3(kBlock), 0, st,
-                               x + c0 * inner, inner, ns, parts + c0 * ns, tickets, cur_min + c0, cur_max + c0,
+            hipLaunchKernelGGL(k_minmax_partial<false>, dim3(gx, (unsigned)cn), dim3(kBlock), 0, st, x + c0 * inner, inner,
+                               ns, (unsigned long long *)ws, tag, cur_min + c0, cur_max + c0,
                                maxval_out ? maxval_out + c0 : nullptr, fa);
     }
     return launch_rc();

@@ -57,14 +57,14 @@ def _rows(x, per_channel):
     return 1, x.numel()
 
 
-def _workspace(dev, nbytes, ticketed=False):
-    """Per-(device, stream) scratch buffer.  ticketed=True: the min/max entry points' workspace, whose leading ticket
+def _workspace(dev, nbytes, zeroed=False):
+    """Per-(device, stream) scratch buffer.  zeroed=True: the min/max entry points' workspace, whose leading ticket
     counters must be zero on first use and are left zero by every call (include/fp8q.h) -- allocated zero-filled and
     never shared with the kernels that scribble over their scratch (MSE partial sums)."""
-    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, ticketed)
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, zeroed)
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
-        alloc = torch.zeros if ticketed else torch.empty
+        alloc = torch.zeros if zeroed else torch.empty
         ws = alloc(max(int(nbytes), 1 << 16), dtype=torch.uint8, device=dev)
         _ws_cache[key] = ws
     return ws
@@ -204,7 +204,7 @@ def minmax(x, per_channel, cur_min=None, cur_max=None, mode=FOLD_CURRENT, moment
     mv = torch.empty(C, dtype=torch.float32, device=x.device) if want_maxval else None
     L = lib()
     nbytes = L.fp8q_minmax_workspace_bytes(C, inner)
-    ws = _workspace(x.device, nbytes, ticketed=True)
+    ws = _workspace(x.device, nbytes, zeroed=True)
     with _on_device(x):
         rc = L.fp8q_minmax_f32(x.data_ptr(), C, inner, cur_min.data_ptr(), cur_max.data_ptr(),
                                mv.data_ptr() if mv is not None else None, int(mode), float(momentum),
@@ -379,7 +379,7 @@ def affine_act_minmax(x, cur_min=None, cur_max=None, mode=FOLD_CURRENT, momentum
         cur_max = torch.empty(1, dtype=torch.float32, device=x.device)
     mv = torch.empty(1, dtype=torch.float32, device=x.device)
     L = lib()
-    ws = _workspace(x.device, L.fp8q_affine_act_minmax_workspace_bytes(N, C, HW), ticketed=True)
+    ws = _workspace(x.device, L.fp8q_affine_act_minmax_workspace_bytes(N, C, HW), zeroed=True)
     with _on_device(x):
         rc = L.fp8q_affine_act_minmax_f32(
             x.data_ptr(), residual.data_ptr() if residual is not None else None, N, C, HW, ptrs[0], ptrs[1],

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define FP8Q_VERSION 200 /* 0.2.0: ticketed single-launch min/max workspaces, multi-tensor plans */
+#define FP8Q_VERSION 200 /* 0.2.0: single-launch min/max (zeroed workspaces), multi-tensor plans */
 
 #define FP8Q_OK 0
 #define FP8Q_EINVAL (-1)       /* null pointer, negative size, n_maxval not in {1, C}, ... */
@@ -42,14 +42,13 @@ extern "C" {
 #define FP8Q_FOLD_RUNNING 2 /* EMA (1-m)*new+m*cur range_estimators.py:122-123 RunningMinMaxEstimator */
 
 /*
- * Workspaces of the min/max entry points (fp8q_minmax_f32, fp8q_affine_act_minmax_f32) begin with
- * FP8Q_WS_TICKET_BYTES of ticket counters: the two-stage reduction runs in ONE launch, the block that draws the last
- * ticket of a row folds the row's partial results.  Contract: those first bytes are ZERO before the first call that
- * uses a buffer (hipMemset once after allocating it) and every call leaves them zero, so a buffer that is only ever
- * handed to these entry points, by one stream at a time, never needs clearing again.  The rest of the workspace needs
- * no initialisation.  Do not share one buffer between launches that may run concurrently.
+ * Workspaces of the min/max entry points (fp8q_minmax_f32, fp8q_affine_act_minmax_f32).  The two-stage reduction
+ * runs in ONE launch: streaming blocks publish tagged partial results in the workspace, a reducer block collects them
+ * and clears them again.  Contract: the workspace is ZERO before the first call that uses it (hipMemset once after
+ * allocating it) and every call leaves it zero, so a buffer that is only ever handed to these two entry points, by one
+ * stream at a time, never needs clearing again.  Do not share one buffer between launches that may run concurrently,
+ * and do not let other kernels scribble over it.
  */
-#define FP8Q_WS_TICKET_BYTES 8192
 
 typedef void *fp8q_stream_t; /* hipStream_t */
 
@@ -78,8 +77,7 @@ int fp8q_quantize_f32(const float *x, float *y, int64_t C, int64_t inner, const 
  *   x         [C, inner] fp32 (C == 1: per tensor)
  *   cur_min, cur_max [C] running estimate, updated in place;  `first` != 0: no previous estimate
  *   maxval_out [C] or NULL: |max(|cur_min|, cur_max)| after the fold
- *   ws        8-byte aligned scratch of at least fp8q_minmax_workspace_bytes(C, inner) bytes; its first
- *             FP8Q_WS_TICKET_BYTES must be zero on first use (see above), the rest need not be
+ *   ws        8-byte aligned scratch of at least fp8q_minmax_workspace_bytes(C, inner) bytes, zero on first use (see above)
  * NaN anywhere in a row makes that row's min and max NaN (torch semantics).
  * HBM traffic: 4 B / element.
  */

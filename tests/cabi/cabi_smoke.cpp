@@ -65,7 +65,7 @@ int main()
     size_t wsb = fp8q_minmax_workspace_bytes(C, inner);
     if (fp8q_minmax_workspace_bytes(1, n) > wsb) wsb = fp8q_minmax_workspace_bytes(1, n);
     CK(hipMalloc(&ws, wsb));
-    CK(hipMemset(ws, 0, FP8Q_WS_TICKET_BYTES));   // ticket counters: zero once, every call leaves them zero (fp8q.h)
+    CK(hipMemset(ws, 0, wsb));   // min/max workspace: zero once, every call leaves it zero (fp8q.h)
     CK(hipMemcpy(dx, x, n * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dmv, mv, C * 4, hipMemcpyHostToDevice));
     hipStream_t st;
