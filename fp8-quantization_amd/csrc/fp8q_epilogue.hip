@@ -249,7 +249,8 @@ static int affine_args(int64_t N, int64_t C, int64_t HW, int act, bool has_bn, b
 
 static void affine_grid(int64_t N, const AffineArgs &a, bool quant, int64_t *bx, int64_t *by)
 {
-    *by = N < 65534 ? N : 65534;   // the calibration twin adds one block row for its reducer
+    const int64_t ymax = quant ? 65535 : 65534;   // the calibration twin adds one block row for its reducer
+    *by = N < ymax ? N : ymax;
     const int64_t nvec = a.image >> 2;
     if (quant) {
         // one 16 KiB piece per block while the grid stays below 64 K blocks; a partial last piece of the

@@ -1424,7 +1424,12 @@ int fp8q_quantize_f32(const float *x, float *y, int64_t C, int64_t inner, const 
 
 static int minmax_nsplit(int64_t C, int64_t inner)
 {
-    return (int)balanced_blocks(cdiv(cdiv(inner, 4), kBlock * 8), kTargetBlocks / (C > 0 ? C : 1));
+    static const int cap_env = [] {   // FP8Q_K3_BLOCKS: streaming blocks of the two-stage min/max (tuning knob)
+        const char *e = getenv("FP8Q_K3_BLOCKS");
+        const int v = e ? atoi(e) : 0;
+        return v >= 1 && v <= 65535 ? v : kTargetBlocks;
+    }();
+    return (int)balanced_blocks(cdiv(cdiv(inner, 4), kBlock * 8), cap_env / (C > 0 ? C : 1));
 }
 
 size_t fp8q_minmax_workspace_bytes(int64_t C, int64_t inner)

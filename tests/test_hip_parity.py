@@ -239,6 +239,34 @@ def test_mse_grid_large_tensor(ops):
     assert mses.cpu().numpy().argmin(1).tolist() == ref.argmin(1).tolist()
 
 
+def test_mse_row_kernel_all_paths(ops):
+    """k_mse_row (lane = element; rows >= 2048 elements) over ranges that take each of its per-candidate paths: one scale
+    mantissa (the usual case), two (ranges whose low binades round k - bias differently), the exact path (tiny / huge /
+    degenerate ranges, many exponent bits), unsigned formats, several rows with their own grids, a ragged last tile."""
+    rng = np.random.RandomState(11)
+    for C, inner, sign in ((1, 70001, 1), (3, 5000, 1), (2, 4099, 0)):
+        x = (rng.randn(C, inner) * rng.uniform(0.3, 3.0, (C, 1))).astype(np.float32)
+        if sign == 0:
+            x = np.abs(x)
+        base = np.exp(np.linspace(np.log(2e-3), np.log(3e3), 61)).astype(np.float32)
+        grid = np.concatenate([base, np.float32([1e-30, 1e-12, 3e37, 0.0, 1.0, 2.0, 4.0])])[:, None] * np.ones((1, C), np.float32)
+        grid = (grid * rng.uniform(0.9, 1.1, grid.shape)).astype(np.float32)
+        mb = [1.0, 2.0, 3.0, 4.0, 5.0, 6.0, 7.0]
+        mses = torch.zeros(len(mb), grid.shape[0], C, device="cuda")
+        ops.mse_grid(dev(x), C > 1, dev(grid), mb, 8, sign, mses)
+        ref = oracle.c_mse_grid(x if C > 1 else x.reshape(-1), C > 1, grid, mb, 8, sign)
+        got = mses.cpu().numpy()
+        assert np.array_equal(np.isnan(got), np.isnan(ref)), (C, inner)
+        ok = np.isfinite(ref)
+        np.testing.assert_allclose(got[ok], ref[ok], rtol=1e-5, atol=1e-37)
+        assert np.array_equal(np.isinf(got), np.isinf(ref))
+    # a second call accumulates
+    mses2 = mses.clone()
+    ops.mse_grid(dev(x), True, dev(grid), mb, 8, 0, mses2)
+    ok = np.isfinite(ref)
+    np.testing.assert_allclose(mses2.cpu().numpy()[ok], 2 * ref[ok], rtol=1e-5, atol=1e-37)
+
+
 def test_full_size_properties(ops):
     """Size-independent properties at a BASELINE-scale tensor ([2^20,3,7,7], 154 M elements)."""
     n_ch = 1 << 20
