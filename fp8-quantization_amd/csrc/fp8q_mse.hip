@@ -63,6 +63,7 @@ k_mse_grid(const float *__restrict__ x, const float *__restrict__ grid, double *
     const float *lutk = lut + koff;                             // lutk[e8] == lut[p]
     const int jk = (int)f.M + ch.bi - koff;                     // ldexp exponent M + bi - p == jk - e8
     const float *xr = x + c * a.inner;
+    const bool tie_at_bound = f.pmax == 1;
     double acc = 0.0;
 
     for (int64_t t0 = (int64_t)split * kMseTile; t0 < a.inner; t0 += (int64_t)a.nsplit * kMseTile) {
@@ -85,8 +86,12 @@ k_mse_grid(const float *__restrict__ x, const float *__restrict__ grid, double *
                     const float tt = xc * c1;
                     int e8 = (int)__builtin_amdgcn_ubfe(__float_as_uint(tt), 23u, 8u);
                     e8 = max(min(e8, e_hi), e_lo);
-                    const float r = rintf(ldexpf(tt, jk - e8));
-                    const float d = xv - r * lutk[e8];
+                    const float sc = lutk[e8];
+                    // E = 0 (mantissa bits = n_bits - sign_bits): maxval / s_1 = 2^M - 0.5 is an exact TIE, so every
+                    // clipped element sits on one and the fp32 rounding of the quotient decides all of them at
+                    // once: there the IEEE division of the reference is reproduced (uniform branch per block)
+                    const float r = tie_at_bound ? rintf(xc / sc) : rintf(ldexpf(tt, jk - e8));
+                    const float d = xv - r * sc;
                     pa = fmaf(d, d, pa);
                 }
             }
@@ -203,8 +208,10 @@ k_mse_row(const float *__restrict__ x, const float *__restrict__ grid, double *_
         k.m0b = ch.m0;
         k.thr = 0u;
         k.pad[0] = k.pad[1] = 0;
-        // magic constant stays a normal float: exponent field of t (<= that of binade pmax) + 23 - M <= 254
-        if (ch.pthr >= 0.0f && e_lo >= 24 && f.M <= 22.0f && (e_lo - 1 + f.pmax) + 23 - (int)f.M <= 254) {
+        // magic constant stays a normal float: exponent field of t (<= that of binade pmax) + 23 - M <= 254.
+        // E = 0 formats (pmax == 1) always take the exact path: maxval / s_1 = 2^M - 0.5 is an exact tie, every clipped
+        // element sits on it, and only the reference's own IEEE division decides them the reference's way.
+        if (ch.pthr >= 0.0f && f.pmax > 1 && e_lo >= 24 && f.M <= 22.0f && (e_lo - 1 + f.pmax) + 23 - (int)f.M <= 254) {
             float m1, m2;
             int psw;
             const int runs = scale_mantissa_runs(ch, f, m1, m2, psw);
@@ -291,7 +298,6 @@ k_mse_row(const float *__restrict__ x, const float *__restrict__ grid, double *_
                     const Chan ch = make_chan(k.maxv, f);
                     const int koff = ch.bi - 127;
                     const int e_lo = 1 - koff, e_hi = f.pmax - koff;
-                    const int jk = (int)f.M + ch.bi - koff;
 #pragma unroll 1
                     for (int u = 0; u < kMseRowEpl / 2; ++u) {
                         const float e[2] = {xv[u].x, xv[u].y};
@@ -302,8 +308,8 @@ k_mse_row(const float *__restrict__ x, const float *__restrict__ grid, double *_
                             const float tt = xc * k.c1;
                             int e8 = (int)__builtin_amdgcn_ubfe(__float_as_uint(tt), 23u, 8u);
                             e8 = max(min(e8, e_hi), e_lo);
-                            const float r = rintf(ldexpf(tt, jk - e8));
-                            dd[q] = e[q] - r * scale_exact(ch, (float)(e8 + koff), f.M);
+                            const float sc = scale_exact(ch, (float)(e8 + koff), f.M);
+                            dd[q] = e[q] - rintf(xc / sc) * sc;   // IEEE division, as the reference: exact at ties too
                         }
                         pa = __builtin_elementwise_fma(vf2{dd[0], dd[1]}, vf2{dd[0], dd[1]}, pa);
                     }

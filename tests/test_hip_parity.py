@@ -244,7 +244,7 @@ def test_mse_row_kernel_all_paths(ops):
     mantissa (the usual case), two (ranges whose low binades round k - bias differently), the exact path (tiny / huge /
     degenerate ranges, many exponent bits), unsigned formats, several rows with their own grids, a ragged last tile."""
     rng = np.random.RandomState(11)
-    for C, inner, sign in ((1, 70001, 1), (3, 5000, 1), (2, 4099, 0)):
+    for C, inner, sign in ((1, 70001, 1), (3, 5000, 1), (4, 300, 1), (2, 4099, 0)):   # (4, 300): the lane-per-candidate kernel
         x = (rng.randn(C, inner) * rng.uniform(0.3, 3.0, (C, 1))).astype(np.float32)
         if sign == 0:
             x = np.abs(x)
