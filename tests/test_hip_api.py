@@ -7,6 +7,8 @@ import pytest
 import torch
 from torch import nn
 
+import oracle
+
 from parity import assert_parity, elem_step
 
 pytestmark = pytest.mark.gpu
