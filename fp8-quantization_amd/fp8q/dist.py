@@ -330,7 +330,12 @@ def mse_search_sharded(x_local, per_channel, mbit_list, n_bits=8, sign_bits=1, s
     ops = ops or _default_ops()
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     n_m = len(mbit_list)
-    if state is None:
+    empty = shard == "channel" and per_channel and x_local.shape[0] == 0   # more ranks than channels: this rank has none
+    if empty:
+        # no local work, but the vote exchange below is a collective: take part with zero votes
+        grid = x_local.new_zeros(N_MSE_GRID, 0)
+        mses = x_local.new_zeros(n_m, N_MSE_GRID, 0)
+    elif state is None:
         mx = ops.minmax(x_local, per_channel, want_maxval=True)[2]
         if shard == "batch" and world > 1:
             dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
@@ -340,7 +345,8 @@ def mse_search_sharded(x_local, per_channel, mbit_list, n_bits=8, sign_bits=1, s
     else:
         grid, mses = state
     inc = torch.zeros_like(mses)
-    ops.mse_grid(x_local, per_channel, grid, list(mbit_list), n_bits, sign_bits, inc)
+    if not empty:
+        ops.mse_grid(x_local, per_channel, grid, list(mbit_list), n_bits, sign_bits, inc)
     if shard == "batch" and world > 1:
         n_local = float(x_local.numel() // grid.shape[1])
         packed = torch.cat([inc.double().reshape(-1) * n_local, torch.tensor([n_local], dtype=torch.float64,

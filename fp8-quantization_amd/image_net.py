@@ -143,7 +143,13 @@ class SyntheticLoader:
 
 
 class RankShard:
-    """Every rank sees images rank::world of each batch of `loader` (all ranks iterate the same batches)."""
+    """Every rank sees images rank::world of each batch of `loader` (all ranks iterate the same batches).
+
+    A ragged last batch with fewer images than ranks would leave some ranks without data while the others wait for
+    them in the per-quantizer range all-reduce (a hang, not an error).  Such a rank gets a DUPLICATE of one of the
+    batch's images instead, labelled IGNORE: min/max estimates are unchanged by duplicates, and evaluate() leaves
+    IGNORE-labelled images out of every metric."""
+    IGNORE = -100   # F.cross_entropy's ignore_index
 
     def __init__(self, loader, rank, world):
         self.loader, self.rank, self.world = loader, rank, world
@@ -153,7 +159,13 @@ class RankShard:
 
     def __iter__(self):
         for x, y in self.loader:
-            yield x[self.rank::self.world], y[self.rank::self.world]
+            n = x.shape[0]
+            if n == 0:
+                continue                       # nothing for anybody: every rank skips it alike
+            if self.rank < n:
+                yield x[self.rank::self.world], y[self.rank::self.world]
+            else:
+                yield x[self.rank % n: self.rank % n + 1], torch.full_like(y[:1], self.IGNORE)
 
 
 def imagenet_loaders(images_dir, size, batch_size, workers):
@@ -230,13 +242,15 @@ def evaluate(model, loader, device, fp_model=None, hip_graph=False):
                 from quantization.base_quantized_model import GraphedForward
                 forward = GraphedForward(model, x)
             out = forward(x)
-            n += y.numel()
+            keep = y != RankShard.IGNORE      # padding duplicates of a ragged sharded batch count nowhere
+            n += int(keep.sum())
             top = out.topk(5, dim=1).indices
-            top1 += int((top[:, 0] == y).sum())
-            top5 += int((top == y[:, None]).any(1).sum())
-            loss_sum += float(ce(out, y))
+            top1 += int(((top[:, 0] == y) & keep).sum())
+            top5 += int(((top == y[:, None]).any(1) & keep).sum())
+            if bool(keep.any()):
+                loss_sum += float(ce(out, y))
             if fp_model is not None:
-                agree += int((fp_model(x).argmax(1) == top[:, 0]).sum())
+                agree += int(((fp_model(x).argmax(1) == top[:, 0]) & keep).sum())
     if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
         t = torch.tensor([n, top1, top5, agree, loss_sum], dtype=torch.float64,
                          device=device if torch.distributed.get_backend() == "nccl" else "cpu")

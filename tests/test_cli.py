@@ -87,3 +87,25 @@ def test_validate_quantized_two_ranks_equal_one_process(tmp_path):
     assert abs(multi["loss"] - single["loss"]) <= 0.05 * abs(single["loss"])
     for k in ("top_1_accuracy", "top_5_accuracy"):
         assert abs(multi[k] - single[k]) <= 2.0 / 24 + 1e-12
+
+
+def test_rank_shard_pads_ragged_batches():
+    """A batch with fewer images than ranks: the rank without an image gets an IGNORE-labelled duplicate (so it still
+    joins the per-quantizer collectives) and evaluate() counts it nowhere."""
+    import image_net
+    x = torch.arange(3 * 2 * 2 * 2, dtype=torch.float32).view(3, 2, 2, 2)
+    y = torch.tensor([5, 6, 7])
+    loader = [(x, y), (x[:1], y[:1]), (x[:0], y[:0])]
+    got = [[(bx.shape[0], by.tolist()) for bx, by in image_net.RankShard(loader, r, 2)] for r in range(2)]
+    assert got[0] == [(2, [5, 7]), (1, [5])]
+    assert got[1] == [(1, [6]), (1, [image_net.RankShard.IGNORE])]
+    bx, _ = list(image_net.RankShard(loader, 1, 2))[1]
+    assert torch.equal(bx, x[:1])
+
+    class Net(torch.nn.Module):
+        def forward(self, t):
+            out = torch.zeros(t.shape[0], 10)
+            out[:, 5] = 1.0
+            return out
+    res = image_net.evaluate(Net(), list(image_net.RankShard(loader, 1, 2)), torch.device("cpu"))
+    assert res["images"] == 1 and res["top_1_accuracy"] == 0.0          # the duplicate (a "5") is not counted

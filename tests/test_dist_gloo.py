@@ -261,6 +261,28 @@ def test_mse_search_channel_sharded_matches_single_process():
         np.testing.assert_array_equal(mv, ref_mv.numpy()[lo:hi])
 
 
+def _mse_one_channel_job(rank, world):
+    from fp8q import dist as fd
+    w = _mse_weights()[:1]                      # one channel, two ranks: rank 1 owns nothing
+    lo, hi = fd.channel_partition(1, world)[rank]
+    mv, m, st = fd.mse_search_sharded(torch.from_numpy(w[lo:hi].copy()), True, [2.0, 3.0], 8, 1, "channel", None,
+                                      ops=OracleOps)
+    return lo, hi, mv.numpy(), m
+
+
+def test_mse_search_channel_sharded_rank_without_channels():
+    """More ranks than channels: the rank that owns none still takes part in the vote exchange (no hang, no error) and
+    every rank reports the single-process mantissa width."""
+    from fp8q import dist as fd
+    w = _mse_weights()[:1]
+    ref_mv, ref_m, _ = fd.mse_search_sharded(torch.from_numpy(w), True, [2.0, 3.0], 8, 1, "channel", None, ops=OracleOps)
+    res = run(_mse_one_channel_job)
+    assert [r[:2] for r in res] == [(0, 1), (1, 1)]
+    assert all(r[3] == ref_m for r in res)
+    np.testing.assert_array_equal(res[0][2], ref_mv.numpy())
+    assert res[1][2].size == 0
+
+
 def _bucket_weights():
     rng = np.random.RandomState(7)
     return [(rng.randn(*shp) * 0.1).astype(np.float32) for shp in ((13, 3, 3, 3), (8, 13, 1, 1), (5, 8), (1, 7), (16, 4, 3, 3))]
