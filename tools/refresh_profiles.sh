@@ -1,22 +1,33 @@
 #!/bin/bash
-# Regenerate the judged artefacts on a GPU box: bench line, rocprofv3 kernel stats of the same command, PMC traffic.
-# usage (from the repo root, on the GPU box): bash tools/refresh_profiles.sh r01     -> gpurun_out/<tag>_*
+# Regenerate the judged artefacts on a GPU box: bench line, rocprofv3 kernel stats of the same command, PMC traffic,
+# and the per-kernel profiles of K3 / K4 / the fused short-row kernel.
+# usage (from the repo root, on the GPU box): bash tools/refresh_profiles.sh r02     -> gpurun_out/<tag>_*
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=$PWD
 export TMPDIR=/tmp
 mkdir -p $R/gpurun_out
 python bench.py 2> $R/gpurun_out/${TAG}_bench.err | tail -1 > $R/gpurun_out/${TAG}_bench_n1.json
+HEAD="--no-extras --no-cpu-baseline --no-north-star-path"     # the headline kernel alone
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_kt -o bench -- python $R/bench.py --no-extras --no-cpu-baseline > $R/gpurun_out/${TAG}_kt.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_kt -o bench -- python $R/bench.py $HEAD > $R/gpurun_out/${TAG}_kt.log 2>&1
 export FP8Q_BENCH_PREWARM_S=0
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/${TAG}_pf -o bench -- python $R/bench.py --steps 5 --warmup 1 --no-extras --no-cpu-baseline > $R/gpurun_out/${TAG}_pf.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/${TAG}_pw -o bench -- python $R/bench.py --steps 5 --warmup 1 --no-extras --no-cpu-baseline > $R/gpurun_out/${TAG}_pw.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/${TAG}_pf -o bench -- python $R/bench.py --steps 5 --warmup 1 $HEAD > $R/gpurun_out/${TAG}_pf.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/${TAG}_pw -o bench -- python $R/bench.py --steps 5 --warmup 1 $HEAD > $R/gpurun_out/${TAG}_pw.log 2>&1
+unset FP8Q_BENCH_PREWARM_S
+# K4 (MSE grid search), K3 (single-launch min/max), fused short rows: kernel stats + VALU / traffic counters
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_mse_kt -o mse -- python $R/tools/mb_mse.py > $R/gpurun_out/${TAG}_mse_kt.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/${TAG}_mse_pmc -o mse -- python $R/tools/mb_mse.py > $R/gpurun_out/${TAG}_mse_pmc.log 2>&1
+rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_WAIT_INST_LDS --output-format csv -d $R/gpurun_out/${TAG}_mse_pmc2 -o mse -- python $R/tools/mb_mse.py > $R/gpurun_out/${TAG}_mse_pmc2.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_k3_kt -o k3 -- python $R/tools/mb_k3.py > $R/gpurun_out/${TAG}_k3_kt.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_staged_kt -o staged -- python $R/tools/mb_staged.py > $R/gpurun_out/${TAG}_staged_kt.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/${TAG}_staged_pf -o staged -- python $R/tools/mb_staged.py > $R/gpurun_out/${TAG}_staged_pf.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/${TAG}_staged_pw -o staged -- python $R/tools/mb_staged.py > $R/gpurun_out/${TAG}_staged_pw.log 2>&1
 cd $R
-for d in kt pf pw; do   # rocprofv3 nests its files under <dir>/<host>/: flatten
-    find gpurun_out/${TAG}_$d -mindepth 2 -name "bench_*.csv" -exec cp {} gpurun_out/${TAG}_$d/ \;
+for d in kt pf pw mse_kt mse_pmc mse_pmc2 k3_kt staged_kt staged_pf staged_pw; do   # rocprofv3 nests its files under <dir>/<host>/: flatten
+    find gpurun_out/${TAG}_$d -mindepth 2 -name "*.csv" -exec cp {} gpurun_out/${TAG}_$d/ \;
 done
 # gpurun merges only gpurun_out/ back; afterwards, in the container:
 #   python tools/summarize_profiles.py gpurun_out/${TAG}_kt gpurun_out/${TAG}_pf gpurun_out/${TAG}_pw $TAG "k_rows_flat<0"
-#   cp gpurun_out/${TAG}_bench_n1.json profiles/${TAG}_bench_n1.json
-tail -c 400 gpurun_out/${TAG}_bench_n1.json; echo; head -4 gpurun_out/${TAG}_kt/bench_kernel_stats.csv | cut -c1-200
+#   python tools/summarize_kernels.py $TAG
+tail -c 600 gpurun_out/${TAG}_bench_n1.json; echo; head -4 gpurun_out/${TAG}_kt/bench_kernel_stats.csv | cut -c1-200
