@@ -382,6 +382,8 @@ def test_validation_logits_identical_with_oracle_quantizers(tag, monkeypatch):
     GPU in both) give bit-identical logits -- so top-1 / top-5 of the engine ARE those of the reference arithmetic the
     oracle restates: the top-1 delta attributable to the kernels is exactly zero."""
     from fp8q import ops
+    monkeypatch.setattr(torch.backends.cudnn, "deterministic", True)
+    monkeypatch.setattr(torch.backends.cudnn, "benchmark", False)
     q = _build_full_size(tag)
     torch.manual_seed(1)
     calib = torch.randn(64, 3, 224, 224, device="cuda")
@@ -390,6 +392,8 @@ def test_validation_logits_identical_with_oracle_quantizers(tag, monkeypatch):
         q.set_quant_state(True, True)
         q(calib)
         q.fix_ranges()
+        for _ in range(2):          # MIOpen settles on its convolution algorithms during the first passes over a shape
+            q(val)
         hip = q(val).clone()
         hip_again = q(val).clone()
         assert torch.equal(hip, hip_again), "the GPU pass itself must be reproducible for this comparison to mean anything"
