@@ -517,6 +517,17 @@ constexpr size_t kStageMaxLds = 36 * 1024;                      // dynamic LDS p
 constexpr int kStageGrid = 2048;                                // persistent blocks (FP8Q_STAGED_GRID)
 static_assert(kStagePad >= kFlatFusedMaxInner - 1 && kStagePad % 4 == 0, "border rows must fit the pads");
 
+// elo / inner for 0 <= elo < 2^52, 1 <= inner < 2^31 without the ~200-instruction software 64-bit division: the double
+// quotient is within 1 of the integer one; an exact integer remainder fixes it up
+__device__ __forceinline__ int64_t div_rows(int64_t elo, int inner)
+{
+    int64_t q = (int64_t)((double)elo / (double)inner);
+    int64_t r = elo - q * inner;
+    if (r < 0) --q, r += inner;
+    if (r >= inner) ++q;
+    return q;
+}
+
 __device__ __forceinline__ ChunkInfo stage_geometry(int64_t c, const FlatArgs &a)
 {
     ChunkInfo ci;
@@ -524,10 +535,31 @@ __device__ __forceinline__ ChunkInfo stage_geometry(int64_t c, const FlatArgs &a
     const int64_t rem = a.nvec * 4 - elo;
     ci.len = rem < kChunkElems ? (int)rem : kChunkElems;
     ci.tail = (c == a.nchunks - 1) ? a.tail : 0;
-    ci.row_lo = elo / a.inner;
+    ci.row_lo = div_rows(elo, a.inner);
     ci.phase = (int)(elo - ci.row_lo * a.inner);
-    ci.nrows = (ci.phase + ci.len + ci.tail - 1) / a.inner + 1;
+    ci.nrows = div_small((uint32_t)(ci.phase + ci.len + ci.tail - 1), a.magic) + 1;
     ci.pad[0] = ci.nrows * a.inner - ci.phase - ci.len;   // elements of the last row behind the body (tail scalars included)
+    ci.pad[1] = 0;
+    return ci;
+}
+
+// The same geometry advanced from chunk c to chunk c + G WITHOUT a 64-bit division: the division of stage_geometry()
+// is ~200 instructions of software long division, and with one thread computing it per chunk, ahead of a barrier, it sat
+// on every chunk's critical path.  phase + G * 4096 < 2^32 / inner (checked by the caller), so the 32-bit magic division
+// is exact; every thread computes the (wave-uniform) result itself: no LDS hand-off, no single-thread section.
+__device__ __forceinline__ ChunkInfo stage_geometry_next(const ChunkInfo &cur, int64_t cn, uint32_t adv, const FlatArgs &a)
+{
+    ChunkInfo ci;
+    const int64_t elo = cn * kChunkElems;
+    const int64_t rem = a.nvec * 4 - elo;
+    ci.len = rem < kChunkElems ? (int)rem : kChunkElems;
+    ci.tail = (cn == a.nchunks - 1) ? a.tail : 0;
+    const uint32_t t = (uint32_t)cur.phase + adv;
+    const uint32_t q = (uint32_t)div_small(t, a.magic);
+    ci.row_lo = cur.row_lo + q;
+    ci.phase = (int)(t - q * (uint32_t)a.inner);
+    ci.nrows = div_small((uint32_t)(ci.phase + ci.len + ci.tail - 1), a.magic) + 1;
+    ci.pad[0] = ci.nrows * a.inner - ci.phase - ci.len;
     ci.pad[1] = 0;
     return ci;
 }
@@ -598,7 +630,6 @@ k_rows_staged(const float *__restrict__ x, float *__restrict__ y, float *row_min
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ double ftab[kFastTabSize];
-    __shared__ ChunkInfo cinfo[2];
     float *win = reinterpret_cast<float *>(smem);
     float4 *patch = reinterpret_cast<float4 *>(win + kStageWin);
     float4 *chl = patch + a.rpc;
@@ -611,25 +642,27 @@ k_rows_staged(const float *__restrict__ x, float *__restrict__ y, float *row_min
     for (int i = tid; i < kFastTabSize; i += kBlock) ftab[i] = kFastTab[i];
 
     int64_t c = blockIdx.x;   // gridDim.x <= nchunks
+    // chunk geometry lives in registers (wave-uniform), advanced incrementally: see stage_geometry_next()
+    const uint32_t adv = (uint32_t)G * (uint32_t)kChunkElems;
+    const bool inc_ok = (uint64_t)(G * kChunkElems + 256) * (uint64_t)inner < (1ull << 32);
+    ChunkInfo cur = stage_geometry(c, a);
     vf4 v[U];
     float bh = 0.0f, bt = 0.0f;
     stage_load_body<NT>(x, c, a, v);   // prologue: the first chunk's loads
-    if (tid == 0) cinfo[0] = stage_geometry(c, a);
-    __syncthreads();
-    stage_load_borders(x, c, cinfo[0], bh, bt);
-    int slot = 0;
+    stage_load_borders(x, c, cur, bh, bt);
     for (;;) {
         const int64_t elo = c * kChunkElems;
-        const int phase = cinfo[slot].phase, nrows = cinfo[slot].nrows, len = cinfo[slot].len;
+        const int phase = cur.phase, nrows = cur.nrows, len = cur.len;
         const int ng = len >> 2;
-        stage_park(win, cinfo[slot], v, bh, bt);
+        stage_park(win, cur, v, bh, bt);
         const int64_t cn = c + G;
         const bool more = cn < a.nchunks;
-        if (more && tid == 0) cinfo[slot ^ 1] = stage_geometry(cn, a);
+        ChunkInfo nxt = cur;
+        if (more) nxt = inc_ok ? stage_geometry_next(cur, cn, adv, a) : stage_geometry(cn, a);
         __syncthreads();
         if (more) {   // next chunk: in flight during the phases below
             stage_load_body<NT>(x, cn, a, v);
-            stage_load_borders(x, cn, cinfo[slot ^ 1], bh, bt);
+            stage_load_borders(x, cn, nxt, bh, bt);
         }
         {   // per row, Gl (<= 8) lanes: range from LDS -> channel constants -> table -> the row's head patch
             const int gs = a.group, Gl = 1 << gs, rpp = kBlock >> gs, sub = tid & (Gl - 1), rs = tid >> gs;
@@ -641,7 +674,7 @@ k_rows_staged(const float *__restrict__ x, float *__restrict__ y, float *row_min
                 if (valid) {
                     const float mv = fabsf(tmax(fabsf(m.mn), m.mx));   // fp8_quantizer.py:236
                     if (sub == 0 && (r > 0 || phase == 0)) {   // the row starts in this chunk: this block reports it
-                        const int64_t grow = cinfo[slot].row_lo + r;
+                        const int64_t grow = cur.row_lo + r;
                         if (row_min) row_min[grow] = m.mn;
                         if (row_max) row_max[grow] = m.mx;
                         if (maxval_out) maxval_out[grow] = mv;
@@ -666,7 +699,7 @@ k_rows_staged(const float *__restrict__ x, float *__restrict__ y, float *row_min
             }
         }
         __syncthreads();
-        if (tid < cinfo[slot].tail) {   // the tensor's last <= 3 elements
+        if (tid < cur.tail) {   // the tensor's last <= 3 elements
             const int e = len + tid;
             const int r = div_small((uint32_t)(phase + e), a.magic);
             y[elo + e] = quant_one(win[kStagePad + e], lite_of(chl[r]), lut + r * a.lut_stride, pmaxf, f.qthr);
@@ -698,7 +731,7 @@ k_rows_staged(const float *__restrict__ x, float *__restrict__ y, float *row_min
         if (!more) break;
         __syncthreads();   // the window and the tables are rewritten by the next chunk
         c = cn;
-        slot ^= 1;
+        cur = nxt;
     }
 }
 
@@ -711,33 +744,33 @@ __global__ void __launch_bounds__(kBlock, 8)
 k_rows_staged_mm(const float *__restrict__ x, float *row_min, float *row_max, float *maxval_out, FoldArgs fa, FlatArgs a)
 {
     __shared__ __attribute__((aligned(16))) float win[kStageWin];
-    __shared__ ChunkInfo cinfo[2];
     const int tid = threadIdx.x;
     const int inner = a.inner;
     const int64_t G = gridDim.x;
     int64_t c = blockIdx.x;   // gridDim.x <= nchunks
+    const uint32_t adv = (uint32_t)G * (uint32_t)kChunkElems;
+    const bool inc_ok = (uint64_t)(G * kChunkElems + 256) * (uint64_t)inner < (1ull << 32);
+    ChunkInfo cur = stage_geometry(c, a);   // registers, wave-uniform (no single-thread section, no LDS hand-off)
     vf4 v[kStageU];
     float bh = 0.0f, bt = 0.0f;
     stage_load_body<NT>(x, c, a, v);
-    if (tid == 0) cinfo[0] = stage_geometry(c, a);
-    __syncthreads();
-    stage_load_borders(x, c, cinfo[0], bh, bt);
-    int slot = 0;
+    stage_load_borders(x, c, cur, bh, bt);
     for (;;) {
-        const int phase = cinfo[slot].phase, nrows = cinfo[slot].nrows;
-        stage_park(win, cinfo[slot], v, bh, bt);
+        const int phase = cur.phase, nrows = cur.nrows;
+        stage_park(win, cur, v, bh, bt);
         const int64_t cn = c + G;
         const bool more = cn < a.nchunks;
-        if (more && tid == 0) cinfo[slot ^ 1] = stage_geometry(cn, a);
+        ChunkInfo nxt = cur;
+        if (more) nxt = inc_ok ? stage_geometry_next(cur, cn, adv, a) : stage_geometry(cn, a);
         __syncthreads();
         if (more) {
             stage_load_body<NT>(x, cn, a, v);
-            stage_load_borders(x, cn, cinfo[slot ^ 1], bh, bt);
+            stage_load_borders(x, cn, nxt, bh, bt);
         }
         {
             const int gs = a.group, Gl = 1 << gs, rpp = kBlock >> gs, sub = tid & (Gl - 1), rs = tid >> gs;
             const float *w0 = win + (kStagePad - phase);
-            const int64_t row_lo = cinfo[slot].row_lo;
+            const int64_t row_lo = cur.row_lo;
             for (int rb = 0; rb < nrows; rb += rpp) {
                 const int r = rb + rs;
                 const bool valid = r < nrows;
@@ -749,7 +782,7 @@ k_rows_staged_mm(const float *__restrict__ x, float *row_min, float *row_max, fl
         if (!more) break;
         __syncthreads();   // the window is rewritten by the next chunk
         c = cn;
-        slot ^= 1;
+        cur = nxt;
     }
 }
 
@@ -1187,6 +1220,7 @@ int launch_rows_staged_mm(const float *x, int64_t C, int64_t inner, float *row_m
     if (!staged_env || inner < 4 || inner > kFlatFusedMaxInner || ((uintptr_t)x & 15) != 0) return kNotFlat;
     FlatArgs a = {};
     a.inner = (int)inner;
+    a.magic = magic_of((int)inner);
     const int64_t n = C * inner;
     a.nvec = n >> 2;
     a.tail = (int)(n & 3);
