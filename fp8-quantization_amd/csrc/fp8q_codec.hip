@@ -99,6 +99,12 @@ static int codec_launch(bool encode, const float *x, uint8_t *codes, float *y, i
         inner *= C;
         C = 1;
     }
+    if (per_channel && inner < 2048) {   // short rows (weights): aligned chunks with per-row tables, not a block per row
+        const int rc = fp8q_codec_flat_launch(encode, encode ? (const void *)x : (const void *)codes,
+                                              encode ? (void *)codes : (void *)y, C, inner, maxval, f, n_bits,
+                                              (hipStream_t)stream);
+        if (rc != FP8Q_CODEC_NOT_FLAT) return rc;
+    }
     for (int64_t c0 = 0; c0 < C; c0 += 65535) {
         const int64_t cn = (C - c0) < 65535 ? (C - c0) : 65535;
         const int64_t bx = balanced_blocks(cdiv(cdiv(inner, 16), kBlock), kTargetBlocks / cn);   // 4096 elements per block and step

@@ -14,6 +14,11 @@
 
 using namespace fp8q;
 
+// short-row path of the storage codec: lives with k_rows_flat in fp8q_quant.hip, called from fp8q_codec.hip
+constexpr int FP8Q_CODEC_NOT_FLAT = -1000;
+int fp8q_codec_flat_launch(bool encode, const void *in, void *out, int64_t C, int64_t inner, const float *maxval,
+                           const QFmt &f, int n_bits, hipStream_t st);
+
 namespace {
 
 constexpr int kUnroll = 4;           // 16-byte loads in flight per lane

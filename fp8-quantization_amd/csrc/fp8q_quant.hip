@@ -119,6 +119,7 @@ __device__ __forceinline__ ChanLite lite_lds(const Chan *c)
 }
 
 constexpr int kModeQuant = 0, kModeFused = 1, kModeMinMax = 2;
+constexpr int kModeEncode = 3, kModeDecode = 4;   // k_rows_flat only: storage codes (N3) of per-channel short rows
 
 // ---------------------------------------------------------------------------------------------
 // Short rows, register-streamed: k_rows_direct (inner <= kDirectMaxInner).
@@ -320,6 +321,8 @@ struct FlatArgs {
     uint32_t rmagic;  // lr / rpc
     int64_t nvec;     // 16-byte groups in the tensor (>= 1)
     int64_t nchunks;  // ceil(nvec / 1024)
+    int n_bits;       // encode / decode: position of the sign bit
+    int pad0;
 };
 
 struct __attribute__((aligned(16))) ChunkInfo {
@@ -434,37 +437,109 @@ k_rows_flat(const float *__restrict__ x, float *__restrict__ y, const float *__r
         for (int lr = tid; lr < nlr; lr += kBlock) {
             const int i = div_small((uint32_t)lr, a.rmagic), r = lr - i * a.rpc;
             if (r < cinfo[i].nrows) {
-                const float mv = MODE == kModeQuant ? maxval[cinfo[i].row_lo + r] : rowmv[lr];
+                const float mv = MODE != kModeFused ? maxval[cinfo[i].row_lo + r] : rowmv[lr];
                 const Chan c = make_chan_fast(mv, f, ftab);
                 chl[lr] = make_float4(c.maxv, c.minv, c.bias, c.pthr);
                 lut_row(lut + lr * a.lut_stride, c, f);
             }
         }
         __syncthreads();
-        for (int lr = tid; lr < nlr; lr += kBlock) {
-            const int i = div_small((uint32_t)lr, a.rmagic), r = lr - i * a.rpc;
-            const ChunkInfo ci = cinfo[i];
-            float pv[3] = {0.0f, 0.0f, 0.0f};
-            if (r + 1 < ci.nrows) {
-                const int idx = (r + 1) * inner - ci.phase;   // chunk-local index of row r+1's first element
-                if (idx < ci.len && (idx & 3)) {
-                    const float *xc = x + (c0 + i * G) * kChunkElems;
-                    const ChanLite cl = lite_of(chl[lr + 1]);
-                    const float2 *lt = lut + (lr + 1) * a.lut_stride;
-                    for (int k = 0; k < 4 - (idx & 3); ++k) pv[k] = quant_one(xc[idx + k], cl, lt, pmaxf, f.qthr);
+        // storage codes (N3): `x` / `y` are the fp32 side, the other pointer is a byte array of codes
+        const int Mi = (int)f.M, sign_shift = f.sign_bits == 1 ? a.n_bits - 1 : -1;
+        const uint8_t *codes_in = reinterpret_cast<const uint8_t *>(x);    // kModeDecode
+        uint8_t *codes_out = reinterpret_cast<uint8_t *>(y);               // kModeEncode
+        if (MODE != kModeDecode) {
+            for (int lr = tid; lr < nlr; lr += kBlock) {
+                const int i = div_small((uint32_t)lr, a.rmagic), r = lr - i * a.rpc;
+                const ChunkInfo ci = cinfo[i];
+                float pv[3] = {0.0f, 0.0f, 0.0f};
+                if (r + 1 < ci.nrows) {
+                    const int idx = (r + 1) * inner - ci.phase;   // chunk-local index of row r+1's first element
+                    if (idx < ci.len && (idx & 3)) {
+                        const float *xc = x + (c0 + i * G) * kChunkElems;
+                        const ChanLite cl = lite_of(chl[lr + 1]);
+                        const float2 *lt = lut + (lr + 1) * a.lut_stride;
+                        for (int k = 0; k < 4 - (idx & 3); ++k)
+                            pv[k] = MODE == kModeEncode
+                                        ? __uint_as_float(encode_one(xc[idx + k], cl, lt, pmaxf, f.qthr, Mi, sign_shift))
+                                        : quant_one(xc[idx + k], cl, lt, pmaxf, f.qthr);
+                    }
                 }
+                patch[lr] = make_float4(pv[0], pv[1], pv[2], 0.0f);
             }
-            patch[lr] = make_float4(pv[0], pv[1], pv[2], 0.0f);
         }
         if (tid < cinfo[nct - 1].tail) {   // the tensor's last <= 3 elements
             const ChunkInfo ci = cinfo[nct - 1];
             const int e = ci.len + tid;
             const int lr = (nct - 1) * a.rpc + div_small((uint32_t)(ci.phase + e), a.magic);
             const int64_t at = (c0 + (nct - 1) * G) * kChunkElems + e;
-            y[at] = quant_one(x[at], lite_of(chl[lr]), lut + lr * a.lut_stride, pmaxf, f.qthr);
+            if (MODE == kModeEncode)
+                codes_out[at] = (uint8_t)encode_one(x[at], lite_of(chl[lr]), lut + lr * a.lut_stride, pmaxf, f.qthr, Mi, sign_shift);
+            else if (MODE == kModeDecode)
+                y[at] = decode_one(codes_in[at], lut + lr * a.lut_stride, Mi, sign_shift);
+            else
+                y[at] = quant_one(x[at], lite_of(chl[lr]), lut + lr * a.lut_stride, pmaxf, f.qthr);
         }
         __syncthreads();
         constexpr int U = 4;
+        if (MODE == kModeEncode || MODE == kModeDecode) {
+            for (int i = 0; i < nct; ++i) {
+                const int phase = cinfo[i].phase, ng = cinfo[i].len >> 2;
+                const int64_t base = (c0 + i * G) * kChunkElems;
+                const int lr0 = i * a.rpc;
+                if (MODE == kModeEncode) {
+                    const vf4 *xv = reinterpret_cast<const vf4 *>(x + base);
+                    uint32_t *cw = reinterpret_cast<uint32_t *>(codes_out + base);
+                    vf4 v[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+                        if (tid + u * kBlock < ng) v[u] = ld16<NT>(xv + tid + u * kBlock);
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int q = tid + u * kBlock;
+                        if (q >= ng) break;
+                        const int o = phase + 4 * q;
+                        const int lrow = div_small((uint32_t)o, a.magic);
+                        const int b = inner - (o - lrow * inner);   // elements left in this row (>= 1)
+                        const int lr = lr0 + lrow;
+                        const ChanLite cl = lite_of(chl[lr]);
+                        const float2 *lt = lut + lr * a.lut_stride;
+                        uint32_t cd[4] = {encode_one(v[u].x, cl, lt, pmaxf, f.qthr, Mi, sign_shift),
+                                          encode_one(v[u].y, cl, lt, pmaxf, f.qthr, Mi, sign_shift),
+                                          encode_one(v[u].z, cl, lt, pmaxf, f.qthr, Mi, sign_shift),
+                                          encode_one(v[u].w, cl, lt, pmaxf, f.qthr, Mi, sign_shift)};
+                        if (b < 4) {   // elements b..3 belong to the next row: its head patch holds their codes
+                            const float4 pt = patch[lr];
+                            cd[3] = __float_as_uint(b == 3 ? pt.x : (b == 2 ? pt.y : pt.z));
+                            if (b < 3) cd[2] = __float_as_uint(b == 2 ? pt.x : pt.y);
+                            if (b < 2) cd[1] = __float_as_uint(pt.x);
+                        }
+                        cw[q] = cd[0] | (cd[1] << 8) | (cd[2] << 16) | (cd[3] << 24);
+                    }
+                } else {
+                    const uint32_t *cw = reinterpret_cast<const uint32_t *>(codes_in + base);
+                    vf4 *yv = reinterpret_cast<vf4 *>(y + base);
+                    uint32_t w[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+                        if (tid + u * kBlock < ng) w[u] = cw[tid + u * kBlock];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int q = tid + u * kBlock;
+                        if (q >= ng) break;
+                        const int o = phase + 4 * q;
+                        const int lrow = div_small((uint32_t)o, a.magic);
+                        const int b = inner - (o - lrow * inner);
+                        const float2 *la = lut + (lr0 + lrow) * a.lut_stride, *lb = la + a.lut_stride;   // this row / the next
+                        st16<NT>(yv + q, vf4{decode_one(w[u] & 255u, la, Mi, sign_shift),
+                                             decode_one((w[u] >> 8) & 255u, b > 1 ? la : lb, Mi, sign_shift),
+                                             decode_one((w[u] >> 16) & 255u, b > 2 ? la : lb, Mi, sign_shift),
+                                             decode_one(w[u] >> 24, b > 3 ? la : lb, Mi, sign_shift)});
+                    }
+                }
+            }
+            continue;
+        }
         for (int i = 0; i < nct; ++i) {
             const int phase = cinfo[i].phase, ng = cinfo[i].len >> 2;
             const int64_t base = (c0 + i * G) * kChunkElems;
@@ -1234,6 +1309,48 @@ int launch_rows_flat(int mode, const float *x, float *y, int64_t C, int64_t inne
     return launch_rc();
 }
 
+// Storage codes of per-channel tensors with short rows through k_rows_flat (aligned 16 KiB chunks of the fp32 side,
+// per-row tables in LDS): the row-per-block codec kernel spends a 256-thread block, a double-precision constant
+// evaluation and a 33-entry table on every 147-element filter.  kNotFlat when the shape does not fit.
+int launch_codec_flat(bool encode, const void *in, void *out, int64_t C, int64_t inner, const float *maxval, const QFmt &f,
+                      int n_bits, hipStream_t st)
+{
+    const void *fp = encode ? in : (const void *)out;       // the fp32 side
+    const void *cp = encode ? (const void *)out : in;       // the code side
+    if (inner < 4 || inner > direct_max_inner() || ((uintptr_t)fp & 15) != 0 || ((uintptr_t)cp & 3) != 0) return kNotFlat;
+    FlatArgs a = {};
+    a.inner = (int)inner;
+    a.lut_stride = f.pmax + 1;
+    a.magic = magic_of((int)inner);
+    a.n_bits = n_bits;
+    const int64_t n = C * inner;
+    a.nvec = n >> 2;
+    a.tail = (int)(n & 3);
+    a.nchunks = cdiv(a.nvec, kChunkGroups);
+    a.rpc = (int)((inner + (kChunkElems + 3) - 2) / inner) + 1;
+    a.rmagic = magic_of(a.rpc);
+    const int64_t per_row = 16 + 16 + (int64_t)a.lut_stride * 8;
+    const int64_t cap = 36 * 1024 - (int64_t)kFlatMaxCh * sizeof(ChunkInfo);
+    int64_t nch = cap / (a.rpc * per_row);
+    if (nch < 1) return kNotFlat;
+    if (nch > kFlatMaxCh) nch = kFlatMaxCh;
+    while (nch > 1 && cdiv(a.nchunks, nch) < 1024) --nch;
+    a.nch = (int)nch;
+    a.group = 1;
+    int64_t blocks = cdiv(a.nchunks, nch);
+    if (blocks > 32768) blocks = 32768;
+    const size_t shmem = (size_t)kFlatMaxCh * sizeof(ChunkInfo) + (size_t)a.rpc * nch * per_row;
+    const bool nt = n * 4 >= kNtBytes;
+    const dim3 g((unsigned)blocks), b(kBlock);
+    const float *xf = (const float *)in;    // encode: fp32 in; decode: the codes, reinterpreted inside the kernel
+    float *yf = (float *)out;               // decode: fp32 out; encode: the codes
+    if (encode && nt) hipLaunchKernelGGL((k_rows_flat<kModeEncode, true>), g, b, shmem, st, xf, yf, maxval, nullptr, nullptr, nullptr, f, a);
+    else if (encode) hipLaunchKernelGGL((k_rows_flat<kModeEncode, false>), g, b, shmem, st, xf, yf, maxval, nullptr, nullptr, nullptr, f, a);
+    else if (nt) hipLaunchKernelGGL((k_rows_flat<kModeDecode, true>), g, b, shmem, st, xf, yf, maxval, nullptr, nullptr, nullptr, f, a);
+    else hipLaunchKernelGGL((k_rows_flat<kModeDecode, false>), g, b, shmem, st, xf, yf, maxval, nullptr, nullptr, nullptr, f, a);
+    return launch_rc();
+}
+
 // k_rows_staged_mm for [C, inner]: rows of 4..256 elements, x 16-byte aligned; kNotFlat otherwise
 int launch_rows_staged_mm(const float *x, int64_t C, int64_t inner, float *row_min, float *row_max, float *maxval_out,
                           const FoldArgs &fa, hipStream_t st)
@@ -1404,6 +1521,15 @@ int launch_rows_direct(int mode, const float *x, float *y, int64_t C, int64_t in
 }
 
 }  // namespace
+
+// used by fp8q_codec.hip (same library, not part of the C ABI)
+__attribute__((visibility("hidden"))) int fp8q_codec_flat_launch(bool encode, const void *in, void *out, int64_t C,
+                                                                 int64_t inner, const float *maxval, const QFmt &f,
+                                                                 int n_bits, hipStream_t st)
+{
+    const int rc = launch_codec_flat(encode, in, out, C, inner, maxval, f, n_bits, st);
+    return rc == kNotFlat ? FP8Q_CODEC_NOT_FLAT : rc;
+}
 
 extern "C" {
 

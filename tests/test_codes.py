@@ -120,6 +120,31 @@ def test_hip_codec_per_channel(shape):
 
 
 @pytest.mark.gpu
+def test_hip_codec_short_row_geometries():
+    """Per-channel tensors with short rows take the chunked kernel (k_rows_flat encode / decode modes): odd row
+    lengths whose rows straddle 16-byte groups and 16 KiB chunks, a ragged tail, tiles of several chunks, every
+    format with an exponent bit, unsigned, NaN / inf / -0 inputs -- codes and decoded values equal to the oracle's."""
+    import fp8q
+    ops = fp8q.ops
+    rng = np.random.RandomState(21)
+    cases = [(1, 147), (27, 147), (29, 147), (1000, 147), (70001, 147), (333, 255), (7001, 99), (9001, 70), (50021, 41),
+             (40000, 5), (77777, 4), (3, 2047), (4099, 27), (20000, 9), (1 << 17, 36)]
+    for i, (C, inner) in enumerate(cases):
+        M, sb = 1 + i % 6, 1 if i % 4 else 0
+        mv = (np.abs(rng.randn(C)) * 2 + 0.05).astype(np.float32)
+        x = (rng.randn(C, inner) * (mv[:, None] / 2)).astype(np.float32)
+        if sb == 0:
+            x = np.abs(x)
+        x.reshape(-1)[:4] = [np.nan, np.inf, -0.0, -np.inf]
+        xd, mvd = dev(x), dev(mv)
+        codes = ops.encode(xd, mvd, M, 8, sb)
+        np.testing.assert_array_equal(codes.cpu().numpy(), oracle.c_encode(x, mv, M, 8, sb), err_msg=f"encode {C}x{inner} M={M}")
+        y = ops.decode(codes, mvd, M, 8, sb).cpu().numpy()
+        ref = oracle.c_decode(codes.cpu().numpy(), mv, M, 8, sb)
+        assert np.array_equal(y.view(np.int32), ref.view(np.int32)), f"decode {C}x{inner} M={M}"
+
+
+@pytest.mark.gpu
 def test_hip_codec_nan_and_degenerate():
     import fp8q
     ops = fp8q.ops
