@@ -829,6 +829,188 @@ k_rows_staged(const float *__restrict__ x, float *__restrict__ y, float *row_min
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Short rows, fused, WAVE-LOCAL: k_rows_wave.  The same single-fetch idea as k_rows_staged, without a single block-level
+// barrier in the data path: every WAVE owns one aligned piece of 1024 elements (4 KiB; a block's four waves = one aligned
+// 16 KiB chunk, neighbouring blocks neighbouring chunks: the access pattern of the copy), keeps its 4 x 16 B per lane in
+// registers, and parks a copy -- plus the head of the first and the tail of the last overlapping row, fetched as one extra
+// 16-byte load per lane on either side (the neighbouring waves' data: L2 hits) -- in a wave-private LDS window.  Row
+// ranges (Gl lanes per row, DPP butterflies), channel constants, tables and head patches are then built by the wave for
+// itself, ordered by wave-level fences only, and the wave quantizes its own registers and stores.  Rows cut by a piece
+// border are evaluated by both neighbours (each has the whole row in its window): same range, same table.
+// k_rows_staged spends 3 block barriers per 16 KiB on the same work; here a wave never waits for another wave.
+// EXPERIMENT, off by default (FP8Q_WAVE=1): bit-exact on every geometry of tools/mb_staged.py, but SLOWER than
+// k_rows_staged on [2^21,147]: 570 us with one piece per wave, 625-635 us persistent with a register prefetch (128 VGPRs,
+// spills), against 482-494 us -- rows cut by the 4 KiB piece borders are evaluated twice (8 rows per piece instead of
+// 7.0), the borders cost two more load instructions per piece, and the block barriers it removes were not what
+// k_rows_staged waits for.  Kept as the A/B partner that shows it.
+// Dynamic LDS per wave: float win[kWavePad | 1024 | kWavePad + 4] | float4 patch[rpc] | float4 chanlite[rpc] | float2 lut[rpc * stride]
+// ---------------------------------------------------------------------------------------------
+constexpr int kWavePiece = 1024, kWavePad = 256, kWaveWin = kWavePad + kWavePiece + kWavePad + 4;
+
+struct WaveArgs {
+    int inner, rpc, lut_stride, group;   // rpc: table rows per piece; group: log2(lanes per row)
+    int tail;                            // n - 4 * nvec
+    int wave_bytes;                      // LDS bytes per wave (multiple of 16)
+    uint32_t magic;                      // o / inner
+    int pad0;
+    int64_t nvec, npieces;
+};
+
+struct WaveGeo {
+    int64_t e0, row_lo;
+    int len, tail, phase, nrows, after, ng, nbg, nag;
+};
+
+__device__ __forceinline__ WaveGeo wave_geometry(int64_t piece, const WaveArgs &a)
+{
+    WaveGeo g;
+    const int64_t nbody = a.nvec * 4;
+    g.e0 = piece * kWavePiece;
+    g.len = (int)(nbody - g.e0 < kWavePiece ? nbody - g.e0 : kWavePiece);   // multiple of 4 (0 only for a tail-only piece)
+    g.tail = piece == a.npieces - 1 ? a.tail : 0;
+    g.row_lo = div_rows(g.e0, a.inner);
+    g.phase = (int)(g.e0 - g.row_lo * a.inner);
+    g.nrows = div_small((uint32_t)(g.phase + g.len + g.tail - 1), a.magic) + 1;
+    g.after = g.nrows * a.inner - g.phase - g.len;   // elements of the last row behind the body (tail scalars included)
+    g.ng = g.len >> 2;
+    g.nbg = (g.phase + 3) >> 2;                      // groups in front of the piece that hold the first row's head
+    g.nag = (g.after + 3) >> 2;
+    return g;
+}
+
+// a piece's loads: 4 x 16 B per lane of the body, one 16-B group per lane of either border (the last <= 3 elements of the
+// tensor, which are not a whole group, come as scalars)
+template <bool NT>
+__device__ __forceinline__ void wave_load(const float *x, const WaveGeo &g, const WaveArgs &a, int lane, vf4 (&v)[4], vf4 &vb,
+                                          vf4 &va)
+{
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (u * 64 + lane < g.ng) v[u] = ld16<NT>(reinterpret_cast<const vf4 *>(x + g.e0) + u * 64 + lane);
+    if (lane < g.nbg) vb = ld16<false>(reinterpret_cast<const vf4 *>(x + g.e0) - 1 - lane);
+    if (lane < g.nag) {
+        const int64_t nbody = a.nvec * 4, o = g.e0 + g.len + 4 * (int64_t)lane;
+        if (o + 4 <= nbody) {
+            va = ld16<false>(reinterpret_cast<const vf4 *>(x + o));
+        } else {
+            const int64_t n = nbody + a.tail;
+            va = vf4{o < n ? x[o] : 0.0f, o + 1 < n ? x[o + 1] : 0.0f, o + 2 < n ? x[o + 2] : 0.0f, 0.0f};
+        }
+    }
+}
+
+template <bool NT>
+__global__ void __launch_bounds__(kBlock, 4)
+k_rows_wave(const float *__restrict__ x, float *__restrict__ y, float *row_min, float *row_max, float *maxval_out,
+            QFmt f, WaveArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ double ftab[kFastTabSize];
+    for (int i = threadIdx.x; i < kFastTabSize; i += kBlock) ftab[i] = kFastTab[i];
+    __syncthreads();   // the only block-level barrier: the log2 / exp2 tables
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int64_t piece = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    if (piece >= a.npieces) return;
+    float *win = reinterpret_cast<float *>(smem + (size_t)wave * a.wave_bytes);
+    float4 *patch = reinterpret_cast<float4 *>(win + kWaveWin);
+    float4 *chl = patch + a.rpc;
+    float2 *lut = reinterpret_cast<float2 *>(chl + a.rpc);
+    const int inner = a.inner;
+    const float pmaxf = (float)f.pmax;
+    WaveGeo g = wave_geometry(piece, a);
+    vf4 v[4], vb = {0.0f, 0.0f, 0.0f, 0.0f}, va = {0.0f, 0.0f, 0.0f, 0.0f};
+    wave_load<NT>(x, g, a, lane, v, vb, va);   // prologue: the first piece's loads
+    for (;;) {
+        // ---- park (waits for the loads issued one iteration ago) ----
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (u * 64 + lane < g.ng) *reinterpret_cast<vf4 *>(win + kWavePad + 4 * (u * 64 + lane)) = v[u];
+        if (lane < g.nbg) *reinterpret_cast<vf4 *>(win + kWavePad - 4 * (lane + 1)) = vb;
+        if (lane < g.nag) *reinterpret_cast<vf4 *>(win + kWavePad + g.len + 4 * lane) = va;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int64_t next = piece + stride;
+        const bool more = next < a.npieces;
+        WaveGeo gn = g;
+        if (more) {   // the next piece: in flight during everything below
+            gn = wave_geometry(next, a);
+            wave_load<NT>(x, gn, a, lane, v, vb, va);
+        }
+        const int phase = g.phase, nrows = g.nrows, len = g.len;
+        // ---- per row, Gl lanes: range from the window -> channel constants -> table -> the row's head patch ----
+        {
+            const int gs = a.group, Gl = 1 << gs, rpp = 64 >> gs, sub = lane & (Gl - 1), rs = lane >> gs;
+            const float *w0 = win + (kWavePad - phase);
+            for (int rb = 0; rb < nrows; rb += rpp) {
+                const int r = rb + rs;
+                const bool valid = r < nrows;
+                const MinMax m = stage_row_range(w0 + r * inner, valid, inner, sub, gs);   // in every lane of the row
+                if (valid) {
+                    const float mv = fabsf(tmax(fabsf(m.mn), m.mx));   // fp8_quantizer.py:236
+                    if (sub == 0 && (r > 0 || phase == 0)) {   // the row starts in this piece: this wave reports it
+                        const int64_t grow = g.row_lo + r;
+                        if (row_min) row_min[grow] = m.mn;
+                        if (row_max) row_max[grow] = m.mx;
+                        if (maxval_out) maxval_out[grow] = mv;
+                    }
+                    const Chan ch = make_chan_fast(mv, f, ftab);
+                    if (sub == 0) chl[r] = make_float4(ch.maxv, ch.minv, ch.bias, ch.pthr);
+                    lut_part(lut + r * a.lut_stride, ch, f, sub, Gl);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (valid) {
+                    const int idx = r * inner - phase;   // piece-local index of the row's first element
+                    if (idx > 0 && idx < len && (idx & 3)) {   // it shares a 16-byte group with the previous row
+                        const ChanLite cl = lite_of(chl[r]);
+                        for (int k = sub; k < 4 - (idx & 3); k += Gl)
+                            reinterpret_cast<float *>(patch)[4 * r + k] =
+                                quant_one(win[kWavePad + idx + k], cl, lut + r * a.lut_stride, pmaxf, f.qthr);
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < g.tail) {   // the tensor's last <= 3 elements
+            const int e = len + lane;
+            const int r = div_small((uint32_t)(phase + e), a.magic);
+            y[g.e0 + e] = quant_one(win[kWavePad + e], lite_of(chl[r]), lut + r * a.lut_stride, pmaxf, f.qthr);
+        }
+        vf4 *yv = reinterpret_cast<vf4 *>(y + g.e0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int q = u * 64 + lane;
+            if (q >= g.ng) break;
+            const vf4 w = *reinterpret_cast<const vf4 *>(win + kWavePad + 4 * q);   // own group back from the window
+            const int o = phase + 4 * q;
+            const int lrow = div_small((uint32_t)o, a.magic);
+            const int b = inner - (o - lrow * inner);   // elements left in this row (>= 1)
+            float e[4] = {w.x, w.y, w.z, w.w};
+            quant_group<4>(e, lite_of(chl[lrow]), lut + lrow * a.lut_stride, pmaxf, f.qthr);
+            if (b < 4) {   // e[b..3] belong to the next row: its head patch
+                const float4 pt = patch[lrow + 1];
+                e[3] = b == 3 ? pt.x : (b == 2 ? pt.y : pt.z);
+                if (b < 3) e[2] = b == 2 ? pt.x : pt.y;
+                if (b < 2) e[1] = pt.x;
+            }
+            st16<NT>(yv + q, vf4{e[0], e[1], e[2], e[3]});
+        }
+        if (!more) break;
+        // the window and the tables are rewritten by the next piece: every lane is done reading them
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        piece = next;
+        g = gn;
+    }
+}
+
 // K2 twin of k_rows_staged: per-row min/max (+ fold into the running estimate) of rows <= 256 elements at any row
 // length and phase.  Loads are the aligned, coalesced 16 KiB chunks of a plain copy (the row-tiled kernel reads
 // row-aligned tiles: 5.2-5.4 TB/s); LDS only transposes them for the G-lanes-per-row reduction.  No tables: 18.4 KiB of
@@ -1266,6 +1448,38 @@ int launch_rows_flat(int mode, const float *x, float *y, int64_t C, int64_t inne
             const int v = e ? atoi(e) : -1;
             return v >= 0 ? v : kStageGrid;
         }();
+        static const int wave_env = [] {   // FP8Q_WAVE=1: the barrier-free k_rows_wave instead of k_rows_staged (A/B: slower)
+            const char *e = getenv("FP8Q_WAVE");
+            return e ? atoi(e) : 0;
+        }();
+        {
+            WaveArgs w = {};
+            w.inner = (int)inner;
+            w.lut_stride = a.lut_stride;
+            w.magic = a.magic;
+            w.tail = a.tail;
+            w.nvec = a.nvec;
+            w.npieces = cdiv(n, kWavePiece);
+            w.rpc = (int)((inner + (kWavePiece + 3) - 2) / inner) + 1;
+            int gs = 0;
+            while (gs < 3 && (2 << gs) * w.rpc <= 64) ++gs;
+            w.group = gs;
+            w.wave_bytes = (int)(((size_t)kWaveWin * sizeof(float) + (size_t)w.rpc * (per_row - 4) + 15) & ~(size_t)15);
+            // 4 waves per block, 4 blocks per CU next to the 3 KiB of statics: <= 9.25 KiB per wave
+            if (wave_env && staged_env && w.wave_bytes <= 9472 && n < (1ll << 52)) {
+                static const int wave_grid = [] {   // FP8Q_WAVE_GRID: persistent-grid cap (blocks); 0 = one piece per wave
+                    const char *e = getenv("FP8Q_WAVE_GRID");
+                    const int v = e ? atoi(e) : -1;
+                    return v >= 0 ? v : 2048;
+                }();
+                const int64_t nblk = cdiv(w.npieces, 4);
+                const dim3 g((unsigned)(wave_grid ? balanced_blocks(nblk, wave_grid) : nblk)), b(kBlock);
+                const size_t wsh = (size_t)w.wave_bytes * 4;
+                if (nt) hipLaunchKernelGGL((k_rows_wave<true>), g, b, wsh, st, x, y, row_min, row_max, maxval_out, f, w);
+                else hipLaunchKernelGGL((k_rows_wave<false>), g, b, wsh, st, x, y, row_min, row_max, maxval_out, f, w);
+                return launch_rc();
+            }
+        }
         const size_t sh = (size_t)kStageWin * sizeof(float) + (size_t)a.rpc * per_row;
         if (staged_env && sh <= kStageMaxLds) {
             int gs = 0;
