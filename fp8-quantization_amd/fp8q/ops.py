@@ -192,16 +192,22 @@ def minmax(x, per_channel, cur_min=None, cur_max=None, mode=FOLD_CURRENT, moment
     if C == 0 or inner == 0:
         raise Fp8qError("min/max of an empty tensor")
     first = cur_min is None or cur_max is None
+    mv = None
     if first:
-        cur_min = torch.empty(C, dtype=torch.float32, device=x.device)
-        cur_max = torch.empty(C, dtype=torch.float32, device=x.device)
+        # one allocation for the two (three) result vectors: tiny tensors are host-bound, every torch.empty is ~2 us
+        stats = torch.empty((3 if want_maxval else 2, C), dtype=torch.float32, device=x.device)
+        if want_maxval:
+            cur_min, cur_max, mv = stats.unbind(0)
+        else:
+            cur_min, cur_max = stats.unbind(0)
     else:
         _require(cur_min, "cur_min")
         _require(cur_max, "cur_max")
         if cur_min.numel() != C or cur_max.numel() != C or not cur_min.is_contiguous() \
                 or not cur_max.is_contiguous():
             raise Fp8qError("running estimate has the wrong shape")
-    mv = torch.empty(C, dtype=torch.float32, device=x.device) if want_maxval else None
+    if want_maxval and mv is None:
+        mv = torch.empty(C, dtype=torch.float32, device=x.device)
     L = lib()
     nbytes = L.fp8q_minmax_workspace_bytes(C, inner)
     ws = _workspace(x.device, nbytes, zeroed=True)
@@ -225,9 +231,7 @@ def minmax_quantize(x, mbits, n_bits=8, sign_bits=1, out=None):
     x = x.contiguous()
     C, inner = _rows(x, True)
     y = torch.empty_like(x) if out is None else out
-    mn = torch.empty(C, dtype=torch.float32, device=x.device)
-    mx = torch.empty_like(mn)
-    mv = torch.empty_like(mn)
+    mn, mx, mv = torch.empty((3, C), dtype=torch.float32, device=x.device).unbind(0)   # one allocation (host-bound sizes)
     with _on_device(x):
         rc = lib().fp8q_minmax_quantize_f32(x.data_ptr(), y.data_ptr(), C, inner, mn.data_ptr(),
                                             mx.data_ptr(), mv.data_ptr(), float(mbits), int(n_bits),

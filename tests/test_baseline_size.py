@@ -258,7 +258,7 @@ class LaunchChecker:
             acc = np.zeros(got.shape, np.float64)
             rng = np.random.RandomState(n % 9973)
             nsl = -(-n // MSE_SLICE)
-            picks = set(int(v) for v in rng.choice(nsl, size=min(2, nsl), replace=False))
+            picks = set(int(v) for v in rng.choice(nsl, size=min(2 if len(mb) == 1 else 1, nsl), replace=False))
             for s in range(nsl):
                 sl = flat[s * MSE_SLICE:(s + 1) * MSE_SLICE]
                 part = torch.zeros_like(a["mses"])
@@ -266,19 +266,24 @@ class LaunchChecker:
                 p = _np(part)
                 acc += p.astype(np.float64) * sl.numel()
                 if s in picks:
+                    if len(mb) > 1:     # mantissa search: 6 x the oracle's work per element -> a quarter of the slice
+                        sl = sl[: MSE_SLICE // 4]
+                        part = torch.zeros_like(a["mses"])
+                        self.real["mse_grid"](sl, False, grid, mb, a["n_bits"], a["sign_bits"], part)
+                        p = _np(part)
                     ref = oracle.c_mse_grid(_np(sl), False, _np(grid), mb, **kw)
                     np.testing.assert_allclose(p, ref, rtol=1e-5, atol=1e-30, err_msg=what + f" slice {s}")
             np.testing.assert_allclose(got, acc / n, rtol=2e-6, atol=1e-30, err_msg=what + " vs its slices")
         self.elements += x.numel()
 
 
-def _qparams(M, w_est, a_est):
+def _qparams(M, w_est, a_est, incl=False):
     from quantization.quantization_manager import QMethods
     from quantization.range_estimators import RangeEstimators
     return dict(method=QMethods.fp_quantizer.cls, weight_range_method=RangeEstimators[w_est].cls,
                 act_range_method=RangeEstimators[a_est].cls, n_bits=8, n_bits_act=8, per_channel_weights=True,
                 fp8_kwargs=dict(maxval=None, mantissa_bits=M, set_maxval=True, learn_maxval=False,
-                                learn_mantissa_bits=False, mse_include_mantissa_bits=False, allow_unsigned=False))
+                                learn_mantissa_bits=False, mse_include_mantissa_bits=incl, allow_unsigned=False))
 
 
 def _build_full_size(tag):
@@ -287,7 +292,7 @@ def _build_full_size(tag):
     if tag == "r18":
         from models.resnet import resnet18
         fp = resnet18()
-    else:
+    else:   # "mbv2", "mbv2m"
         from models.mobilenet_v2 import MobileNetV2
         fp = MobileNetV2(input_size=224)
     # random-init weights (no checkpoints on the box): batch-norm statistics from one synthetic batch, so that
@@ -307,14 +312,15 @@ def _build_full_size(tag):
         q = QuantizedResNet(fp, input_size=(1, 3, 224, 224), **_qparams(2, "current_minmax", "allminmax"))
     else:
         from models.mobilenet_v2_quantized import QuantizedMobileNetV2
-        q = QuantizedMobileNetV2(fp, input_size=(1, 3, 224, 224), **_qparams(3, "MSE", "MSE"))
+        q = QuantizedMobileNetV2(fp, input_size=(1, 3, 224, 224), **_qparams(3, "MSE", "MSE", incl=tag == "mbv2m"))
     return q.cuda().eval()
 
 
-@pytest.mark.parametrize("tag,n_weight,n_act_min", [("r18", 21, 29), ("mbv2", 53, 60)])
+@pytest.mark.parametrize("tag,n_weight,n_act_min", [("r18", 21, 29), ("mbv2", 53, 60), ("mbv2m", 53, 60)])
 def test_every_launch_of_a_full_size_model_pass(tag, n_weight, n_act_min, monkeypatch):
     """BASELINE configs 3 / 4 at batch 64 x 224 x 224: calibration pass, fix_ranges(), validation pass, every
-    fp8q.ops launch checked against the oracle on its own input."""
+    fp8q.ops launch checked against the oracle on its own input.  mbv2m = config 4 with the mantissa search of the
+    reference's CLI default (--fp8-mse-include-mantissa-bits: 6 widths x 111 ranges per quantizer)."""
     from fp8q import ops
     q = _build_full_size(tag)
     torch.manual_seed(1)
