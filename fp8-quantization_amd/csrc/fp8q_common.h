@@ -143,11 +143,11 @@ __device__ __forceinline__ void block_minmax_collect(unsigned long long *slots, 
             a = __hip_atomic_load(slots + 2 * s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             b = __hip_atomic_load(slots + 2 * s2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (((unsigned)(a >> 32) == tag) & ((unsigned)(b >> 32) == tag)) break;
-            if (++spins > (1 << 21)) {   // ~2 s: something upstream died; do not hang the queue
+            if (++spins > (1 << 23)) {   // ~2 s: something upstream died; do not hang the queue
                 lost = 1;
                 break;
             }
-            __builtin_amdgcn_s_sleep(16);
+            __builtin_amdgcn_s_sleep(2);
         }
         const float mn = __uint_as_float((unsigned)a), mx = __uint_as_float((unsigned)b);
         // an EMPTY split (a row a few elements longer than a whole number of steps) holds {+inf, -inf}

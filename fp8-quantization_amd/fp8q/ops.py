@@ -9,6 +9,7 @@ from ._lib import Fp8qError, check, lib
 FOLD_CURRENT, FOLD_ALL, FOLD_RUNNING = 0, 1, 2
 
 _ws_cache = {}
+_mm_ws_bytes = {}
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
@@ -61,7 +62,8 @@ def _workspace(dev, nbytes, zeroed=False):
     """Per-(device, stream) scratch buffer.  zeroed=True: the min/max entry points' workspace, whose leading ticket
     counters must be zero on first use and are left zero by every call (include/fp8q.h) -- allocated zero-filled and
     never shared with the kernels that scribble over their scratch (MSE partial sums)."""
-    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, zeroed)
+    key = (dev.index, _raw_stream(dev.index) if _raw_stream is not None else torch.cuda.current_stream(dev).cuda_stream,
+           zeroed)
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
         alloc = torch.zeros if zeroed else torch.empty
@@ -209,7 +211,9 @@ def minmax(x, per_channel, cur_min=None, cur_max=None, mode=FOLD_CURRENT, moment
     if want_maxval and mv is None:
         mv = torch.empty(C, dtype=torch.float32, device=x.device)
     L = lib()
-    nbytes = L.fp8q_minmax_workspace_bytes(C, inner)
+    nbytes = _mm_ws_bytes.get((C, inner))
+    if nbytes is None:     # a pure function of the shape: one ctypes call per shape, not per launch
+        nbytes = _mm_ws_bytes[(C, inner)] = L.fp8q_minmax_workspace_bytes(C, inner)
     ws = _workspace(x.device, nbytes, zeroed=True)
     with _on_device(x):
         rc = L.fp8q_minmax_f32(x.data_ptr(), C, inner, cur_min.data_ptr(), cur_max.data_ptr(),
