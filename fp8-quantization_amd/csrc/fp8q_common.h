@@ -162,11 +162,13 @@ __device__ __forceinline__ void block_minmax_collect(unsigned long long *slots, 
     if (block_minmax(m, mn, mx)) fold_store(mn, mx, row, cur_min, cur_max, maxval_out, fa);
 }
 
-// per-call tag of the granules: nonzero, different from call to call (a multiplicative hash of a process-wide counter)
+// per-call tag of the granules: nonzero, different from call to call (a multiplicative hash of a counter; this header is
+// compiled into several translation units, each with its own counter, so the counter's address salts the hash)
 inline unsigned next_minmax_tag()
 {
     static std::atomic<unsigned> counter{0};
-    const unsigned t = (counter.fetch_add(1, std::memory_order_relaxed) + 1u) * 0x9E3779B1u;
+    const unsigned salt = (unsigned)((uintptr_t)&counter >> 4);
+    const unsigned t = ((counter.fetch_add(1, std::memory_order_relaxed) + 1u) ^ salt) * 0x9E3779B1u;
     return t ? t : 0x9E3779B1u;
 }
 
