@@ -403,10 +403,18 @@ def test_validation_logits_identical_with_oracle_quantizers(tag, monkeypatch):
         hip = q(val).clone()
         hip_again = q(val).clone()
         assert torch.equal(hip, hip_again), "the GPU pass itself must be reproducible for this comparison to mean anything"
-        # the layers' cached quantized weights came from the HIP multi-tensor launch: recompute them through the oracle too
+        # the layers' cached quantized weights came from the HIP multi-tensor launch: the oracle must give the very same
+        # tensors (checked in place, so that the weight buffers -- and with them MIOpen's choices -- stay what they were)
+        n_w = 0
         for m in q.modules():
-            if hasattr(m, "invalidate_weight_cache"):
-                m.invalidate_weight_cache()
+            wq = getattr(m, "_wq_cache", None)
+            if wq is not None:
+                qz = m.weight_quantizer.quantizer
+                ref_w = OracleInTheLoop.quantize(m.get_weight_bias()[0].detach(), qz.maxval, float(qz.mantissa_bits),
+                                                 qz.n_bits, qz.sign_bits)
+                assert torch.equal(ref_w.view(torch.int32), wq.view(torch.int32)), type(m).__name__
+                n_w += 1
+        assert n_w >= 21
         monkeypatch.setattr(ops, "quantize", OracleInTheLoop.quantize)
         monkeypatch.setattr(ops, "affine_act_quantize", OracleInTheLoop.affine_act_quantize)
         ref = q(val)
