@@ -276,6 +276,23 @@ def north_star_path(args, ops, dev, rank, world, backend):
     del w
     torch.cuda.empty_cache()
 
+    # ---- the real thing, strong-scaled: ResNet-18's 21 weight tensors (11.68 M elements, 46.7 MB), every tensor
+    # channel-sharded, ONE packed all-gather for the whole model (fp8q.dist.quantize_weights_sharded_bucketed) ----
+    shapes = [(64, 3, 7, 7)] + [(64, 64, 3, 3)] * 4 + [(128, 64, 3, 3), (128, 128, 3, 3), (128, 64, 1, 1)] + \
+        [(128, 128, 3, 3)] * 2 + [(256, 128, 3, 3), (256, 256, 3, 3), (256, 128, 1, 1)] + [(256, 256, 3, 3)] * 2 + \
+        [(512, 256, 3, 3), (512, 512, 3, 3), (512, 256, 1, 1)] + [(512, 512, 3, 3)] * 2 + [(1000, 512)]
+    g = torch.Generator(device=dev).manual_seed(7)
+    ws = [torch.randn(*sh, device=dev, generator=g) * 0.05 for sh in shapes]
+    for _ in range(2):
+        fd.quantize_weights_sharded_bucketed(ws, MBITS, NBITS, SIGN)
+    dt = wall(lambda: fd.quantize_weights_sharded_bucketed(ws, MBITS, NBITS, SIGN), reps)
+    n_r18 = sum(t.numel() for t in ws)
+    res["resnet18_weights_one_allgather"] = dict(
+        tensors=len(ws), elements=n_r18, step_us=round(dt * 1e6, 1), gelem_s=round(n_r18 / dt / 1e9, 2),
+        scaling="strong (the model is fixed; every rank quantizes 1/N of every tensor's channels)",
+        xgmi_bytes_received_per_rank=int(n_r18 * 4 * (world - 1) / world))
+    del ws
+
     # ---- config 5: allminmax fold -> range all-reduce -> E4M3 quantize of the per-rank slab ----
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     x = torch.empty(512, 4096, 512, device=dev)
