@@ -34,16 +34,18 @@ def _mark(timing):
         timing.setdefault("events", []).append(ev)
 
 
-def _local_minmax_quantize(ops, shard, mbits, n_bits, sign_bits):
+def _local_minmax_quantize(ops, shard, mbits, n_bits, sign_bits, out=None):
     """current_minmax range + quantize of this rank's channels: the fused launch when the rows fit it
-    (fp8q_fused_max_inner), else min/max then quantize (e.g. Linear(25088, 4096): rows of 25088 elements)."""
+    (fp8q_fused_max_inner), else min/max then quantize (e.g. Linear(25088, 4096): rows of 25088 elements).
+    `out`: where the quantized shard should land (a view of a send buffer); a backend may ignore it (the caller
+    checks and copies)."""
     inner = shard.numel() // max(shard.shape[0], 1)
     limit = getattr(ops, "fused_max_inner", None)
     if limit is None or inner <= limit():
-        q, _, _, mv = ops.minmax_quantize(shard, mbits, n_bits, sign_bits)
+        q, _, _, mv = ops.minmax_quantize(shard, mbits, n_bits, sign_bits, out=out)
         return q, mv
     mv = ops.minmax(shard, True, want_maxval=True)[2]
-    return ops.quantize(shard, mv, mbits, n_bits, sign_bits), mv
+    return ops.quantize(shard, mv, mbits, n_bits, sign_bits, out=out), mv
 
 
 def channel_partition(n_channels, world_size):
@@ -274,7 +276,7 @@ def quantize_weights_sharded_bucketed(weights, mbits, n_bits=8, sign_bits=1, gro
         C = w.shape[0]
         inner = w.numel() // max(C, 1)
         per = -(-C // world)
-        need = per * (inner + 1)
+        need = -(-(per * (inner + 1)) // 4) * 4        # regions start on 16-byte boundaries: the aligned kernels apply
         if bucket_bytes is not None and totals[-1] > 0 and (totals[-1] + need) * esz > bucket_bytes:
             totals.append(0)
         geo.append((len(totals) - 1, C, inner, per, totals[-1], totals[-1] + per * inner))
@@ -295,8 +297,11 @@ def quantize_weights_sharded_bucketed(weights, mbits, n_bits=8, sign_bits=1, gro
     for i, (w, (bi, C, inner, per, off_v, off_m)) in enumerate(zip(weights, geo)):
         lo, hi = channel_partition(C, world)[rank]
         if hi > lo:
-            q, mv = _local_minmax_quantize(ops, w[lo:hi].contiguous(), mbits, n_bits, sign_bits)
-            sends[bi][off_v: off_v + (hi - lo) * inner] = q.reshape(-1)
+            shard = w[lo:hi].contiguous()
+            dst = sends[bi][off_v: off_v + (hi - lo) * inner].view(shard.shape)    # quantize straight into the send buffer
+            q, mv = _local_minmax_quantize(ops, shard, mbits, n_bits, sign_bits, out=dst)
+            if q.data_ptr() != dst.data_ptr():
+                dst.copy_(q)
             sends[bi][off_m: off_m + (hi - lo)] = mv
         if i + 1 == len(weights) or geo[i + 1][0] != bi:   # bucket complete: ship it, go on quantizing the next
             exchange(bi)
@@ -304,6 +309,9 @@ def quantize_weights_sharded_bucketed(weights, mbits, n_bits=8, sign_bits=1, gro
         h.wait()
     out = []
     for w, (bi, C, inner, per, off_v, off_m) in zip(weights, geo):
+        if world == 1:      # nothing to re-assemble: views of the packed buffer
+            out.append((recvs[bi][0, off_v: off_v + C * inner].view_as(w), recvs[bi][0, off_m: off_m + C]))
+            continue
         parts, mvs = [], []
         for r, (a_, b_) in enumerate(channel_partition(C, world)):
             parts.append(recvs[bi][r, off_v: off_v + (b_ - a_) * inner])
