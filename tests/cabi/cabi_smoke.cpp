@@ -1,6 +1,7 @@
 // cabi_smoke.cpp -- the drop-in boundary used the way a non-Python host would use it: plain HIP runtime
 // calls for memory, plain pointers and sizes into libfp8q_hip.so (include/fp8q.h), no torch anywhere.
-// Checks K1, the fused min/max+quantize, the folding min/max and the multi-tensor call against the CPU
+// Checks K1, the fused min/max+quantize, the folding min/max (zeroed workspace), the multi-tensor call and its prepared
+// plan, the storage codec and the FP-MSE grid search against the CPU
 // oracle (libfp8q_oracle.so, test infrastructure) bit for bit.  Built by tests/test_cabi_and_host.py
 // (hipcc cross-compiles it on the CPU box); run by the -m gpu test of the same file.
 #include <hip/hip_runtime_api.h>
@@ -16,6 +17,12 @@ int orc_quantize_f32(const float *x, float *y, int64_t C, int64_t inner, const f
                      float mbits, int n_bits, int sign_bits);
 int orc_minmax_f32(const float *x, int64_t C, int64_t inner, float *mn, float *mx);
 int orc_absmax_f32(const float *mn, const float *mx, int64_t C, float *maxval);
+int orc_encode_u8(const float *x, uint8_t *codes, int64_t C, int64_t inner, const float *maxval, int64_t n_maxval,
+                  float mbits, int n_bits, int sign_bits);
+int orc_decode_u8(const uint8_t *codes, float *y, int64_t C, int64_t inner, const float *maxval, int64_t n_maxval,
+                  float mbits, int n_bits, int sign_bits);
+int orc_mse_grid_f32(const float *x, int64_t C, int64_t inner, const float *grid, int64_t n_cand, const float *mbits,
+                     int n_m, int n_bits, int sign_bits, float *mses);
 }
 
 #define CK(x) do { int e_ = (int)(x); if (e_ != 0) { printf("FAIL %s -> %d (%s) at line %d\n", #x, e_, fp8q_strerror(e_), __LINE__); return 1; } } while (0)
@@ -122,6 +129,66 @@ int main()
     orc_quantize_f32(x, ref, C0, inner, mv, C0, 2.0f, 8, 1);
     orc_quantize_f32(x + C0 * inner, ref + C0 * inner, C1, inner, mv + C0, C1, 4.0f, 8, 1);
     ok &= same_bits(y, ref, n, "fp8q_multi_quantize_f32 (2 tensors, E5M2 + E3M4)");
+    // prepared multi-tensor plan: built once, launched twice (the second time after the input changed in place)
+    {
+        fp8q_multi_plan *plan = nullptr;
+        CK(fp8q_multi_plan_create(d, 2, &plan));
+        if (fp8q_multi_plan_launches(plan) != 1) { printf("FAIL: one launch expected for two batchable tensors\n"); ok = 0; }
+        CK(hipMemset(dy, 0, n * 4));
+        CK(fp8q_multi_plan_launch(plan, st));
+        CK(hipStreamSynchronize(st));
+        CK(hipMemcpy(y, dy, n * 4, hipMemcpyDeviceToHost));
+        ok &= same_bits(y, ref, n, "fp8q_multi_plan_launch");
+        for (int64_t i = 0; i < n; ++i) x[i] *= 0.5f;                 // "an optimizer step": same storage, new contents
+        CK(hipMemcpy(dx, x, n * 4, hipMemcpyHostToDevice));
+        CK(fp8q_multi_plan_launch(plan, st));
+        CK(hipStreamSynchronize(st));
+        CK(hipMemcpy(y, dy, n * 4, hipMemcpyDeviceToHost));
+        orc_quantize_f32(x, ref, C0, inner, mv, C0, 2.0f, 8, 1);
+        orc_quantize_f32(x + C0 * inner, ref + C0 * inner, C1, inner, mv + C0, C1, 4.0f, 8, 1);
+        ok &= same_bits(y, ref, n, "fp8q_multi_plan_launch after an in-place update");
+        fp8q_multi_plan_destroy(plan);
+    }
+    // storage codes (per-channel short rows: the chunked kernel) against the oracle's bytes and decoded values
+    {
+        uint8_t *codes = (uint8_t *)malloc(n), *rcodes = (uint8_t *)malloc(n), *dcodes;
+        CK(hipMalloc((void **)&dcodes, n));
+        CK(fp8q_encode_u8(dx, dcodes, C, inner, dmv, C, 2.0f, 8, 1, st));
+        CK(fp8q_decode_u8(dcodes, dy, C, inner, dmv, C, 2.0f, 8, 1, st));
+        CK(hipStreamSynchronize(st));
+        CK(hipMemcpy(codes, dcodes, n, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(y, dy, n * 4, hipMemcpyDeviceToHost));
+        orc_encode_u8(x, rcodes, C, inner, mv, C, 2.0f, 8, 1);
+        orc_decode_u8(rcodes, ref, C, inner, mv, C, 2.0f, 8, 1);
+        if (memcmp(codes, rcodes, n) != 0) { printf("FAIL fp8q_encode_u8: codes differ\n"); ok = 0; }
+        else printf("ok   fp8q_encode_u8 (%lld codes identical)\n", (long long)n);
+        ok &= same_bits(y, ref, n, "fp8q_decode_u8");
+    }
+    // FP-MSE grid search: 7 candidate ranges x 2 mantissa widths, per tensor (the long-row kernel) and per channel
+    {
+        const int n_cand = 7, n_m = 2;
+        const float mb[2] = {2.0f, 3.0f};
+        float grid1[7], mses[14], rm[14];
+        for (int i = 0; i < n_cand; ++i) grid1[i] = 0.02f * (float)(i + 1);
+        float *dgrid, *dmses;
+        void *mws;
+        const size_t mwsb = fp8q_mse_workspace_bytes(1, n, n_cand, n_m);
+        CK(hipMalloc((void **)&dgrid, sizeof(grid1)));
+        CK(hipMalloc((void **)&dmses, sizeof(mses)));
+        CK(hipMalloc(&mws, mwsb));
+        CK(hipMemcpy(dgrid, grid1, sizeof(grid1), hipMemcpyHostToDevice));
+        CK(hipMemset(dmses, 0, sizeof(mses)));
+        CK(fp8q_mse_grid_f32(dx, 1, n, dgrid, n_cand, mb, n_m, 8, 1, dmses, mws, mwsb, st));
+        CK(hipStreamSynchronize(st));
+        CK(hipMemcpy(mses, dmses, sizeof(mses), hipMemcpyDeviceToHost));
+        memset(rm, 0, sizeof(rm));
+        orc_mse_grid_f32(x, 1, n, grid1, n_cand, mb, n_m, 8, 1, rm);
+        int good = 1;
+        for (int i = 0; i < 14; ++i)
+            if (!(mses[i] >= rm[i] * (1.0f - 1e-5f) && mses[i] <= rm[i] * (1.0f + 1e-5f))) { printf("FAIL fp8q_mse_grid_f32[%d]: %g vs %g\n", i, mses[i], rm[i]); good = 0; }
+        if (good) printf("ok   fp8q_mse_grid_f32 (14 mean squared errors within 1e-5 of the oracle)\n");
+        ok &= good;
+    }
     // error behaviour: bad arguments are reported, nothing throws
     if (fp8q_quantize_f32(dx, dy, C, inner, dmv, C - 1, 2.0f, 8, 1, st) != FP8Q_EINVAL) { printf("FAIL: EINVAL expected\n"); ok = 0; }
     if (fp8q_quantize_f32(dx, dy, C, inner, dmv, C, 0.0f, 16, 1, st) != FP8Q_EUNSUPPORTED) { printf("FAIL: EUNSUPPORTED expected\n"); ok = 0; }
