@@ -1434,7 +1434,10 @@ int launch_rows_flat(int mode, const float *x, float *y, int64_t C, int64_t inne
     static const int nch_env = [] {
         const char *e = getenv("FP8Q_FLAT_NCH");
         const int v = e ? atoi(e) : 0;
-        return v >= 1 && v <= kFlatMaxCh ? v : kFlatMaxCh;
+        // default 4: measured on K1 (tools/mb_flat_nch.py, one box, rows of 147 / 288 / 576 / 1152 / 2047 elements):
+        // 4 chunks per tile 5.69 / 5.86 / 5.88 / 5.84 / 5.76 TB/s, 8 chunks 5.66 / 5.66 / 5.75 / 5.74 / 5.66, 2 chunks
+        // 5.22 / 5.90 / 5.92 / 5.91 / 5.63, 1 chunk 4.27 / 5.44 / 5.44 / 5.41 / 4.62
+        return v >= 1 && v <= kFlatMaxCh ? v : 4;
     }();
     if (nch > nch_env) nch = nch_env;
     const bool nt = n * 4 >= kNtBytes;
@@ -1547,7 +1550,7 @@ int launch_codec_flat(bool encode, const void *in, void *out, int64_t C, int64_t
     const int64_t cap = 36 * 1024 - (int64_t)kFlatMaxCh * sizeof(ChunkInfo);
     int64_t nch = cap / (a.rpc * per_row);
     if (nch < 1) return kNotFlat;
-    if (nch > kFlatMaxCh) nch = kFlatMaxCh;
+    if (nch > 4) nch = 4;   // as K1's tiles (launch_rows_flat)
     while (nch > 1 && cdiv(a.nchunks, nch) < 1024) --nch;
     a.nch = (int)nch;
     a.group = 1;
