@@ -236,6 +236,11 @@ __device__ __noinline__ float quant_exact(float x, float maxv, float minv, float
 // Fast path of one element; sets `risky` when the exact path must redo it.
 // class mask 0x93: sNaN | qNaN | -denormal | +denormal (v_log_f32 flushes denormals; a denormal
 // xc can only come from a denormal x unless maxval itself is denormal, and then pthr == -1).
+// CHECK_X = false: the caller guarantees that a NaN input implies an always-exact channel (the fused min/max+quantize
+// kernels: a NaN anywhere in a row makes the row's maxval NaN, hence pthr = -1), so the per-element class test can go;
+// denormal inputs need no exact path either: v_log_f32 flushes them to -inf -> p = 1, and with every scale normal
+// (pthr >= 0) their quotient rounds to +-0 exactly as the reference's does.
+template <bool CHECK_X = true>
 __device__ __forceinline__ float quant_fast(float x, const ChanLite &c, const float2 *lut, float pmaxf,
                                             float qthr, bool &risky)
 {
@@ -248,13 +253,13 @@ __device__ __forceinline__ float quant_fast(float x, const ChanLite &c, const fl
     const float q0 = xc * t.y;
     const float r = rintf(q0);
     // (x == 0: v = -inf, fr = NaN, the comparison is false and p = 1 is already exact)
-    risky = __builtin_amdgcn_classf(x, 0x93) | (fabsf(fr - 0.5f) > c.pthr) | (fabsf(q0 - r) > qthr) |
+    risky = (CHECK_X && __builtin_amdgcn_classf(x, 0x93)) | (fabsf(fr - 0.5f) > c.pthr) | (fabsf(q0 - r) > qthr) |
             (c.pthr < 0.0f);
     return r * t.x;
 }
 
 // N elements of one channel, in place: one branch for the whole group
-template <int N>
+template <int N, bool CHECK_X = true>
 __device__ __forceinline__ void quant_group(float (&v)[N], const ChanLite &c, const float2 *lut,
                                             float pmaxf, float qthr)
 {
@@ -263,7 +268,7 @@ __device__ __forceinline__ void quant_group(float (&v)[N], const ChanLite &c, co
     bool any = false;
 #pragma unroll
     for (int j = 0; j < N; ++j) {
-        y[j] = quant_fast(v[j], c, lut, pmaxf, qthr, rk[j]);
+        y[j] = quant_fast<CHECK_X>(v[j], c, lut, pmaxf, qthr, rk[j]);
         any |= rk[j];
     }
     if (__builtin_expect(any, 0)) {

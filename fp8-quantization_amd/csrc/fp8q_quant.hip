@@ -809,7 +809,7 @@ k_rows_staged(const float *__restrict__ x, float *__restrict__ y, float *row_min
                 const int lrow = div_small((uint32_t)o, a.magic);
                 const int b = inner - (o - lrow * inner);   // elements left in this row (>= 1)
                 float e[4] = {w[u].x, w[u].y, w[u].z, w[u].w};
-                quant_group<4>(e, lite_of(chl[lrow]), lut + lrow * a.lut_stride, pmaxf, f.qthr);
+                quant_group<4, false>(e, lite_of(chl[lrow]), lut + lrow * a.lut_stride, pmaxf, f.qthr);   // fused: NaN rows are all-exact
                 if (b < 4) {   // e[b..3] belong to the next row: its head patch
                     const float4 pt = patch[lrow + 1];
                     e[3] = b == 3 ? pt.x : (b == 2 ? pt.y : pt.z);
@@ -1278,7 +1278,7 @@ k_rows_reg(const float *__restrict__ x, float *__restrict__ y, int64_t C, int in
                 e[4 * k + 2] = v[k].z;
                 e[4 * k + 3] = v[k].w;
             }
-            quant_group<EPT * 4>(e, cl, lut[rslot], pmaxf, f.qthr);
+            quant_group<EPT * 4, false>(e, cl, lut[rslot], pmaxf, f.qthr);   // fused: a NaN makes the row's range NaN -> all-exact
 #pragma unroll
             for (int k = 0; k < EPT; ++k)
                 if (valid && k * L + sub < nvec)
