@@ -25,7 +25,12 @@ constexpr int kUnroll = 4;           // 16-byte loads in flight per lane
 constexpr int kTargetBlocks = 2048;  // 256 CUs x 8 blocks
 constexpr int kDirectMaxInner = 16384; // k_rows_direct handles rows up to here (magic division: n*inner < 2^32)
 constexpr int kDirectElems = 32768;    // elements per k_rows_direct iteration (tables capped at 40 KiB)
-constexpr int64_t kNtBytes = 64ll << 20;  // tensors at least this big stream with nontemporal hints
+// tensors at least this big stream with nontemporal hints (FP8Q_NT_MB: the threshold in MiB, a tuning knob)
+static const int64_t kNtBytes = [] {
+    const char *e = getenv("FP8Q_NT_MB");
+    const long v = e ? atol(e) : 0;
+    return (int64_t)(v >= 1 ? v : 64) << 20;
+}();
 
 // Blocks for `pieces` equal pieces of work with at most `cap` blocks: every block gets the same number of
 // steps (a persistent grid of exactly `cap` blocks over 6.1 steps' worth of pieces runs 7 steps: -12 %).
