@@ -94,19 +94,63 @@ def cpu_baseline(x_cpu, maxval_cpu):
                        f"oracle/fp8q_oracle.c (OpenMP, {threads} threads), {dt:.2f} s wall"), ref, xs.shape[0]
 
 
+def physical_cores():
+    """physical cores of the host (not SMT threads): the thread count of the reference-equivalent leg"""
+    try:
+        import psutil
+        n = psutil.cpu_count(logical=False)
+        if n:
+            return int(n)
+    except Exception:
+        pass
+    try:
+        cores = set()
+        phys = core = None
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("physical id"):
+                phys = ln.split(":")[1].strip()
+            elif ln.startswith("core id"):
+                core = ln.split(":")[1].strip()
+            elif not ln.strip():
+                if phys is not None and core is not None:
+                    cores.add((phys, core))
+                phys = core = None
+        if cores:
+            return len(cores)
+    except Exception:
+        pass
+    return max(1, (os.cpu_count() or 2) // 2)
+
+
 def torch_eager_cpu(x_cpu, maxval_cpu, n_ch):
-    """The reference-equivalent eager ATen path on the host cores (informational)."""
+    """The reference-equivalent path on the host: the reference's own eager ATen op chain (oracle/torch_eager.py
+    restates fp8_quantizer.py:91-133 op for op; the reference files themselves do not travel to the GPU box), one
+    thread per physical core, one warm-up pass, then the MEDIAN of >= 3 timed passes (bounded to ~10 s)."""
     from oracle import torch_eager as te
-    torch.set_num_threads(os.cpu_count() or 1)
-    xs = x_cpu[:n_ch]
-    mv = maxval_cpu[:n_ch]
-    mb = torch.tensor([float(MBITS)])
-    te.fake_quant(xs[:1024], NBITS, mv[:1024], mb, SIGN)
-    t0 = time.perf_counter()
-    te.fake_quant(xs, NBITS, mv, mb, SIGN)
-    dt = time.perf_counter() - t0
-    return dict(value=round(xs.numel() / dt / 1e9, 4), unit="Gelem/s", cores=torch.get_num_threads(),
-                sample=f"{n_ch} channels, torch {torch.__version__} CPU eager op chain")
+    cores = physical_cores()
+    prev = torch.get_num_threads()
+    torch.set_num_threads(cores)
+    try:
+        xs = x_cpu[:n_ch]
+        mv = maxval_cpu[:n_ch]
+        mb = torch.tensor([float(MBITS)])
+        t0 = time.perf_counter()
+        te.fake_quant(xs, NBITS, mv, mb, SIGN)                  # warm-up (allocator, thread pool, page faults)
+        warm = time.perf_counter() - t0
+        passes = max(3, min(9, int(10.0 / max(warm, 1e-3))))
+        ts = []
+        for _ in range(passes):
+            t0 = time.perf_counter()
+            te.fake_quant(xs, NBITS, mv, mb, SIGN)
+            ts.append(time.perf_counter() - t0)
+        ts.sort()
+        med = ts[len(ts) // 2]
+    finally:
+        torch.set_num_threads(prev)
+    return dict(value=round(xs.numel() / med / 1e9, 4), unit="Gelem/s", cores=cores, kind="reference-equivalent",
+                sample=f"first {n_ch} channels ({xs.numel()} elements) of the bench tensor, torch {torch.__version__} CPU "
+                       f"eager op chain of fp8_quantizer.py:91-133, {cores} threads (physical cores), warm-up pass "
+                       f"{warm:.2f} s, median of {passes} passes ({med:.3f} s; min {ts[0]:.3f}, max {ts[-1]:.3f})")
 
 
 def extras(ops, dev):
@@ -200,6 +244,242 @@ def extras(ops, dev):
             us=round(med * 1e6, 1), t_cand_elem_s=round(ce / med / 1e12, 3), hbm_gb_s=round(a4.numel() * 4 / med / 1e9, 1),
             valu_issue_frac_of_39_3T=round(ce * 7 / med / 39.3e12, 3), lane_ops_frac_of_78_6T=round(ce * 10 / med / 78.6e12, 3))
     del x, y
+    return out
+
+
+class LaunchTimer:
+    """HIP-event pairs around every call into fp8q.ops (the torch-facing wrappers of the C ABI), on the stream the
+    kernels are launched on: per pass, the time the GPU spent in THIS library's launches, their elements and their
+    algorithmic bytes (K1 8 B/elem, min/max 4, fused min/max+quantize 8, MSE search 4, producer epilogue
+    8 [+4 with a residual]).  The events cost a marker each on the stream; `forward_ms` is taken with the timer off."""
+    BPE = {"quantize": 8, "minmax": 4, "minmax_quantize": 8, "mse_grid": 4, "affine_act_quantize": 8,
+           "affine_act_minmax": 4, "multi_quantize": 8, "plan_launch": 8}
+
+    def __init__(self, ops):
+        self.ops, self.on, self.rec = ops, False, []
+        self.saved = {n: getattr(ops, n) for n in self.BPE if hasattr(ops, n)}
+        for n, real in self.saved.items():
+            setattr(ops, n, self._wrap(n, real))
+        timer, base = self, ops.MultiPlan
+        self.saved["MultiPlan"] = base
+
+        class TimedPlan(base):
+            def __init__(self, items):
+                items = [tuple(it) for it in items]
+                self._n = sum(it[0].numel() for it in items)
+                super().__init__(items)
+
+            def launch(self):
+                if not timer.on:
+                    return super().launch()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                out = super().launch()
+                e1.record()
+                timer.rec.append(("plan_launch", e0, e1, self._n, self._n * 8))
+                return out
+        ops.MultiPlan = TimedPlan
+
+    def _wrap(self, name, real):
+        bpe = self.BPE[name]
+
+        def f(*a, **k):
+            if not self.on:
+                return real(*a, **k)
+            if name == "multi_quantize":
+                n = sum(it[0].numel() for it in a[0])
+                extra = 0
+            else:
+                n = a[0].numel()
+                extra = 4 * n if k.get("residual") is not None else 0
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = real(*a, **k)
+            e1.record()
+            self.rec.append((name, e0, e1, n, n * bpe + extra))
+            return out
+        return f
+
+    def restore(self):
+        for n, real in self.saved.items():
+            setattr(self.ops, n, real)
+
+    def measure(self, fn):
+        """run fn() once with the timer on -> {library_us, launches, elements, algorithmic_gb, by_entry}"""
+        torch.cuda.synchronize()
+        self.rec, self.on = [], True
+        try:
+            fn()
+        finally:
+            self.on = False
+        torch.cuda.synchronize()
+        by = {}
+        for name, e0, e1, n, b in self.rec:
+            d = by.setdefault(name, dict(calls=0, us=0.0, elements=0, bytes=0))
+            d["calls"] += 1
+            d["us"] += e0.elapsed_time(e1) * 1e3
+            d["elements"] += n
+            d["bytes"] += b
+        tot_us = sum(d["us"] for d in by.values())
+        tot_b = sum(d["bytes"] for d in by.values())
+        for d in by.values():
+            d["us"] = round(d["us"], 1)
+            d["gb_s"] = round(d["bytes"] / max(d["us"], 1e-3) / 1e3, 1)
+        return dict(library_us=round(tot_us, 1), launches=sum(d["calls"] for d in by.values()),
+                    elements=sum(d["elements"] for d in by.values()), algorithmic_gb=round(tot_b / 1e9, 4),
+                    gb_s=round(tot_b / max(tot_us, 1e-3) / 1e3, 1), frac_of_8tbs=round(tot_b / max(tot_us, 1e-3) / 1e3 / HBM_PEAK_GBS, 3),
+                    by_entry=by)
+
+
+def _median_pass(timer, fn, reps=5):
+    """fn() `reps` times under the timer; the pass with the median library time"""
+    runs = sorted((timer.measure(fn) for _ in range(reps)), key=lambda r: r["library_us"])
+    return runs[len(runs) // 2]
+
+
+def _wall_ms(fn, reps=10):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return round((time.perf_counter() - t0) / reps * 1e3, 3)
+
+
+def model_configs(ops, dev, only=None):
+    """BASELINE configs 3 and 4 at their full size (batch 64 x 3 x 224 x 224, synthetic images, random-init weights with
+    BN statistics re-estimated on synthetic batches, as `image_net.py validate-quantized --synthetic-batches` does):
+    one calibration batch (estimate_ranges) -> fix_ranges -> validation forwards.
+
+      c3  ResNet-18, fp_quantizer E5M2, per-channel current_minmax weights, per-tensor allminmax activations
+          reference work per forward: 21 weight + 30 activation quantizer calls, 218.9 M elements,
+          1.75 GB algorithmic (hijacker.py:88-108 re-quantizes every weight on every forward)
+      c4  MobileNetV2, E4M3, MSE range estimator for weights and activations (range_estimators.py:318-369), with the
+          mantissa search of the reference CLI's default (--fp8-mse-include-mantissa-bits: 6 widths) and without
+          reference work per forward: 53 weight + 64 activation calls, 444.9 M elements, 3.56 GB
+
+    Per pass: wall time, and -- by HIP events around every call into this library -- the GPU time of its launches,
+    their elements and algorithmic bytes -> effective GB/s.  Validation forwards in three launch patterns:
+      reference_pattern   FP8Q_CACHE_WEIGHTS=0 FP8Q_FUSE_EPILOGUE=0: one quantizer launch wherever the reference runs
+                          its 13-op chain (all weights every forward, every activation after BN/ReLU as torch ops)
+      cache0_fused        weights still re-quantized every forward, BN+ReLU(+residual)+quantizer in one kernel (N2)
+      default             weights quantized once at fix_ranges() (cached), N2 fused
+    """
+    import image_net
+    from models import QuantArchitectures
+    from quantization.quantization_manager import QMethods
+    from quantization.range_estimators import RangeEstimators
+
+    timer = LaunchTimer(ops)
+    out = {}
+    g = torch.Generator(device=dev).manual_seed(4321)
+    x = torch.randn(64, 3, 224, 224, device=dev, generator=g)
+    xc = torch.randn(64, 3, 224, 224, device=dev, generator=g)         # the calibration batch
+
+    def build(arch, mbits, w_est, a_est, search):
+        torch.manual_seed(0)
+        m = QuantArchitectures[arch](
+            pretrained=False, load_type="fp32", method=QMethods.fp_quantizer.cls, n_bits=8, per_channel_weights=True,
+            weight_range_method=RangeEstimators[w_est].cls, act_range_method=RangeEstimators[a_est].cls,
+            fp8_kwargs=dict(maxval=None, mantissa_bits=mbits, set_maxval=True, learn_maxval=False,
+                            learn_mantissa_bits=False, mse_include_mantissa_bits=search, allow_unsigned=False)).to(dev).eval()
+        with torch.no_grad():
+            m.full_precision()
+            image_net.reestimate_bn_stats(m, image_net.SyntheticLoader(2, 64, 224, 1234), 2)
+            for _ in range(2):
+                m(x)                                  # MIOpen algorithm selection etc., outside every timed pass
+        return m
+
+    def calibrate(m):
+        with torch.no_grad():
+            m.set_quant_state(True, True)
+            m.estimate_ranges()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            rec = timer.measure(lambda: m(xc))
+            rec["wall_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
+            t0 = time.perf_counter()
+            m.fix_ranges()
+            torch.cuda.synchronize()
+            rec["fix_ranges_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
+        return rec
+
+    def validation(m, ref_gb):
+        res = {}
+        with torch.no_grad():
+            for name, cache, fuse in (("reference_pattern", "0", "0"), ("cache0_fused", "0", "1"), ("default", "1", "1")):
+                os.environ["FP8Q_CACHE_WEIGHTS"], os.environ["FP8Q_FUSE_EPILOGUE"] = cache, fuse
+                try:
+                    if cache == "1":
+                        m.requantize_weights()
+                    for _ in range(3):
+                        m(x)
+                    r = _median_pass(timer, lambda: m(x))
+                    r["forward_ms"] = _wall_ms(lambda: m(x))
+                    r["env"] = f"FP8Q_CACHE_WEIGHTS={cache} FP8Q_FUSE_EPILOGUE={fuse}"
+                    # the reference's quantizer work for this forward, done in the time this library's launches took
+                    r["reference_work_gb_s"] = round(ref_gb * 1e3 / max(r["library_us"], 1e-3), 1)
+                    res[name] = r
+                finally:
+                    os.environ.pop("FP8Q_CACHE_WEIGHTS", None)
+                    os.environ.pop("FP8Q_FUSE_EPILOGUE", None)
+        return res
+
+    import contextlib
+    import io
+    quiet = contextlib.redirect_stdout(io.StringIO())       # the CLI helpers print progress lines
+    try:
+        with quiet:
+            if only in (None, "c3"):
+                m = build("resnet18_quantized", 2, "current_minmax", "allminmax", False)
+                fp32_ms = _wall_ms(lambda: m(x))
+                cal = calibrate(m)
+                if only == "c3":
+                    with torch.no_grad():
+                        for _ in range(20):
+                            m(x)
+                    torch.cuda.synchronize()
+                    return {"c3_resnet18_b64": {"profiled": "1 calibration batch + fix_ranges + 20 default validation forwards",
+                                                "calibration_batch": cal}}
+                out["c3_resnet18_b64"] = dict(
+                    workload="ResNet-18, batch 64 x 3 x 224 x 224 synthetic, fp_quantizer E5M2 (8 bit, 2 mantissa bits), "
+                             "per-channel current_minmax weights, per-tensor allminmax activations",
+                    reference_work_per_forward=dict(quantizer_calls=51, elements=218.9e6, algorithmic_gb=1.751),
+                    fp32_forward_ms=fp32_ms, calibration_batch=cal, validation_forward=validation(m, 1.751))
+                del m
+                torch.cuda.empty_cache()
+            if only in (None, "c4", "c4_search"):
+                entry = dict(
+                    workload="MobileNetV2, batch 64 x 3 x 224 x 224 synthetic, fp_quantizer E4M3 (3 mantissa bits), MSE range "
+                             "estimator (111-candidate grid search, K4) for per-channel weights and per-tensor activations",
+                    reference_work_per_forward=dict(quantizer_calls=117, elements=444.9e6, algorithmic_gb=3.559))
+                for key, search in (("calibration_batch_fixed_mantissa", False), ("calibration_batch_mantissa_search_6", True)):
+                    if only == "c4" and search or only == "c4_search" and not search:
+                        continue
+                    m = build("mobilenet_v2_quantized", 3, "MSE", "MSE", search)
+                    if "fp32_forward_ms" not in entry:
+                        entry["fp32_forward_ms"] = _wall_ms(lambda: m(x))
+                    cal = calibrate(m)
+                    k4 = cal["by_entry"].get("mse_grid")
+                    if k4:
+                        n_m = 6 if search else 1
+                        cal["k4_share_of_library_time"] = round(k4["us"] / max(cal["library_us"], 1e-3), 3)
+                        cal["k4_t_cand_elem_s"] = round(k4["elements"] * 111 * n_m / max(k4["us"], 1e-3) / 1e6, 3)
+                    entry[key] = cal
+                    if only is not None:
+                        with torch.no_grad():
+                            for _ in range(20):
+                                m(x)
+                        torch.cuda.synchronize()
+                        entry["profiled"] = "1 calibration batch + fix_ranges + 20 default validation forwards"
+                        return {"c4_mobilenetv2_b64": entry}
+                    if not search:
+                        entry["validation_forward"] = validation(m, 3.559)
+                    del m
+                    torch.cuda.empty_cache()
+                out["c4_mobilenetv2_b64"] = entry
+    finally:
+        timer.restore()
     return out
 
 
@@ -326,10 +606,15 @@ def north_star_path(args, ops, dev, rank, world, backend):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=500)      # 0.2 s timed region by default
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--no-model-configs", action="store_true",
+                    help="skip extras.c3_resnet18_b64 / extras.c4_mobilenetv2_b64 (BASELINE configs 3 and 4)")
+    ap.add_argument("--only-model-config", choices=["c3", "c4", "c4_search"], default=None,
+                    help="profiling aid: run ONLY that model configuration's passes (for rocprofv3 --kernel-trace) "
+                         "and print its entry")
     ap.add_argument("--no-north-star-path", action="store_true",
                     help="skip the sharded-weights / config-5 section (profiling runs of the headline kernel)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -340,11 +625,24 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        sys.exit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 "
-                 "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # bare `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU) through the same launcher
+        # the driver uses; its rank 0 prints the JSON line, this process only relays the exit code
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the FP8 engine has no CPU path)")
+    if args.backend == "nccl" and world > torch.cuda.device_count():
+        sys.exit(f"bench.py: {world} RCCL ranks need {world} GPUs, this node shows {torch.cuda.device_count()} "
+                 "(--backend gloo lets several ranks share a GPU: smoke test of the multi-process path only)")
     dev_index = local_rank if args.backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -357,6 +655,9 @@ def main():
     import fp8q
     ops = fp8q.ops
     fp8q.lib()  # fail loudly if the HIP library is missing
+    if args.only_model_config:
+        print(json.dumps(model_configs(ops, dev, only=args.only_model_config)), flush=True)
+        return
 
     # synthetic weights: this rank's shard of output channels (seed differs per rank)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -451,19 +752,31 @@ def main():
             got = y[:n_ch].cpu().numpy()
             line["cpu_baseline"]["gpu_output_bit_exact_on_sample"] = bool(
                 np.array_equal(got.view(np.int32), ref.view(np.int32)))
-            line["cpu_eager_torch"] = torch_eager_cpu(xc, mvc, min(n_ch, 1 << 16))
+            # same object, next to the port: the reference's own op chain on the host cores (reported, not a target)
+            line["cpu_baseline"]["reference_equivalent"] = torch_eager_cpu(xc, mvc, min(n_ch, 1 << 16))
     del x, y
     torch.cuda.empty_cache()
     if not args.no_north_star_path:
         nsp = north_star_path(args, ops, dev, rank, world, args.backend)     # every rank takes part
         if rank == 0:
             line["north_star_path"] = nsp
+    # every rank must have been seen by a collective: an all-reduce of ones before anything is reported
+    seen = world
+    if world > 1:
+        one = torch.ones(1, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(one)
+        seen = int(one.item())
     if rank == 0:
+        line["ranks_seen"] = seen
         if world == 1 and not args.no_extras:
             line["extras"] = extras(ops, dev)
+            if not args.no_model_configs:
+                line["extras"].update(model_configs(ops, dev))
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    if seen != args.gpus:
+        sys.exit(f"bench.py: the collectives spanned {seen} ranks, expected {args.gpus}")
 
 
 if __name__ == "__main__":

@@ -8,6 +8,7 @@
 #include <atomic>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "../../include/fp8q.h"
 #include "fp8q_device.h"
@@ -61,7 +62,30 @@ struct FoldArgs {
     int first;    // no previous estimate
     float om;     // fl32(1 - momentum)   (python double arithmetic, then cast: range_estimators.py:122)
     float mo;     // fl32(momentum)
+    float *packed = nullptr;     // optional [C, 4] {-min, max, isnan(min), isnan(max)} of the folded estimate: the operand of
+                                 // ONE all-reduce(MAX) in batch-sharded calibration (fp8q_minmax_packed_f32, include/fp8q.h)
+    unsigned *status = nullptr;  // workspace header word: the reducer counts its timeouts here (FP8Q_ETIMEDOUT)
+    int spin_limit = 1 << 23;    // polls before the reducer gives up (~2 s); FP8Q_K3_SPIN_LIMIT
+    int fault = 0;               // FP8Q_TEST_FAULT=drop_publish: split 0 never publishes (exercises the timeout path)
 };
+
+// spin limit / fault injection of the single-launch min/max, read once (tests shorten the 2 s and drop a publisher)
+inline void fold_debug_env(FoldArgs &fa)
+{
+    static const int limit = [] {
+        const char *e = getenv("FP8Q_K3_SPIN_LIMIT");
+        const long v = e ? atol(e) : 0;
+        return v >= 1 && v <= (1l << 30) ? (int)v : 1 << 23;
+    }();
+    static const int fault = [] {
+        const char *e = getenv("FP8Q_TEST_FAULT");
+        return e && !strcmp(e, "drop_publish") ? 1 : 0;
+    }();
+    fa.spin_limit = limit;
+    fa.fault = fault;
+}
+
+constexpr size_t kMinmaxWsHeader = 16;   // bytes in front of the granules: {timeout count, 3 reserved words}
 
 __device__ __forceinline__ void fold_store(float mn, float mx, int64_t row, float *cur_min,
                                            float *cur_max, float *maxval_out, const FoldArgs &fa)
@@ -77,6 +101,14 @@ __device__ __forceinline__ void fold_store(float mn, float mx, int64_t row, floa
     if (cur_min) cur_min[row] = mn;
     if (cur_max) cur_max[row] = mx;
     if (maxval_out) maxval_out[row] = fabsf(tmax(fabsf(mn), mx));  // fp8_quantizer.py:236
+    if (fa.packed) {
+        // NaN must win on every rank (torch.min / torch.max): it travels as a flag, the value as -inf, so that the
+        // collective itself never sees a NaN (what MAX does with one is the communication library's business)
+        const bool nmn = mn != mn, nmx = mx != mx;
+        const float ninf = -__builtin_inff();
+        reinterpret_cast<float4 *>(fa.packed)[row] =
+            make_float4(nmn ? ninf : -mn, nmx ? ninf : mx, nmn ? 1.0f : 0.0f, nmx ? 1.0f : 0.0f);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -90,8 +122,13 @@ __device__ __forceinline__ void fold_store(float mn, float mx, int64_t row, floa
 // round trips at every block's end (45 us).
 // Workspace contract (include/fp8q.h): zero before the first use of a buffer, zero again after every call.  `tag` is a
 // per-call nonzero value from the host, so a stale or foreign word is not mistaken for an arrival.
-// The reducer spins: bounded (~2 s), after which it reports NaN instead of hanging the queue.  It cannot starve the
-// streaming blocks: they never wait for anything, and it holds one workgroup slot.
+// The reducer spins: bounded (~2 s), after which it reports NaN instead of hanging the queue AND counts the event in the
+// workspace's header word (fp8q_minmax_workspace_check -> FP8Q_ETIMEDOUT: the enqueue-only entry point itself cannot know).
+// Progress does not depend on the dispatch order: streaming blocks never wait for anything, and the reducers (one per
+// row; rows are split only when C <= 1024) can hold at most half of the chip's 2048 resident 256-thread workgroup
+// slots, so streaming blocks always find a slot even if every reducer were dispatched first.  What in-order dispatch
+// (blockIdx.x == nsplit last: what the hardware does, not something HIP promises) buys is only that the reducer spins
+// briefly instead of for the whole kernel.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned long long pack_tagged(float v, unsigned tag)
 {
@@ -127,7 +164,7 @@ __device__ __forceinline__ void block_minmax_publish(MinMax m, unsigned long lon
     if (!block_minmax(m, mn, mx)) return;
     if (nsplit == 1) {
         fold_store(mn, mx, row, cur_min, cur_max, maxval_out, fa);
-    } else {
+    } else if (!(fa.fault && split == 0)) {
         __hip_atomic_store(slots + 2 * split, pack_tagged(mn, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(slots + 2 * split + 1, pack_tagged(mx, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -148,8 +185,9 @@ __device__ __forceinline__ void block_minmax_collect(unsigned long long *slots, 
             a = __hip_atomic_load(slots + 2 * s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             b = __hip_atomic_load(slots + 2 * s2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (((unsigned)(a >> 32) == tag) & ((unsigned)(b >> 32) == tag)) break;
-            if (++spins > (1 << 23)) {   // ~2 s: something upstream died; do not hang the queue
+            if (++spins > fa.spin_limit) {   // ~2 s: something upstream died; do not hang the queue
                 lost = 1;
+                if (fa.status) atomicAdd(fa.status, 1u);
                 break;
             }
             __builtin_amdgcn_s_sleep(2);

@@ -302,13 +302,13 @@ size_t fp8q_affine_act_minmax_workspace_bytes(int64_t N, int64_t C, int64_t HW)
     if (N <= 0 || affine_args(N, C, HW, 0, false, false, &a) != FP8Q_OK) return 16;
     int64_t bx, by;
     affine_grid(N, a, false, &bx, &by);
-    return (size_t)(bx * by) * 2 * sizeof(unsigned long long) + 16;   // two tagged granules per streaming block
+    return kMinmaxWsHeader + (size_t)(bx * by) * 2 * sizeof(unsigned long long);   // header + two tagged granules per streaming block
 }
 
-int fp8q_affine_act_minmax_f32(const float *x, const float *residual, int64_t N, int64_t C, int64_t HW,
-                               const float *mean, const float *invstd, const float *gamma, const float *beta,
-                               int act, float *cur_min, float *cur_max, float *maxval_out, int fold_mode,
-                               double momentum, int first, void *ws, size_t ws_bytes, fp8q_stream_t stream)
+static int affine_minmax_impl(const float *x, const float *residual, int64_t N, int64_t C, int64_t HW,
+                              const float *mean, const float *invstd, const float *gamma, const float *beta,
+                              int act, float *cur_min, float *cur_max, float *maxval_out, float *packed, int fold_mode,
+                              double momentum, int first, void *ws, size_t ws_bytes, fp8q_stream_t stream)
 {
     const bool has_bn = mean != nullptr;
     if (has_bn && (!invstd || !gamma || !beta)) return FP8Q_EINVAL;
@@ -316,7 +316,15 @@ int fp8q_affine_act_minmax_f32(const float *x, const float *residual, int64_t N,
     if (int rc = affine_args(N, C, HW, act, has_bn, residual != nullptr, &a)) return rc;
     if (N <= 0 || !x || !cur_min || !cur_max || fold_mode < 0 || fold_mode > 2) return FP8Q_EINVAL;
     if (!ws || ws_bytes < fp8q_affine_act_minmax_workspace_bytes(N, C, HW) || ((uintptr_t)ws & 7)) return FP8Q_EWORKSPACE;
-    if (((uintptr_t)x | (uintptr_t)residual) & 15) return FP8Q_EINVAL;
+    if ((((uintptr_t)x | (uintptr_t)residual) & 15) || ((uintptr_t)packed & 15)) return FP8Q_EINVAL;
+    {
+        static const bool debug_ws = [] {
+            const char *e = getenv("FP8Q_DEBUG_WS");
+            return e && atoi(e) != 0;
+        }();
+        if (debug_ws)
+            if (int rc = fp8q_minmax_workspace_check(ws, fp8q_affine_act_minmax_workspace_bytes(N, C, HW), 0, stream)) return rc;
+    }
     int64_t bx, by;
     affine_grid(N, a, false, &bx, &by);
     hipStream_t st = (hipStream_t)stream;
@@ -325,12 +333,35 @@ int fp8q_affine_act_minmax_f32(const float *x, const float *residual, int64_t N,
     fa.first = first != 0;
     fa.om = (float)(1.0 - momentum);
     fa.mo = (float)momentum;
+    fa.packed = packed;
+    fa.status = (unsigned *)ws;
+    fold_debug_env(fa);
     const int nparts = (int)(bx * by);
     // one more block row for the reducer when there is more than one streaming block (by <= 65535 - 1: affine_grid)
     hipLaunchKernelGGL(k_affine_minmax, dim3((unsigned)bx, (unsigned)(nparts > 1 ? by + 1 : by)), dim3(kBlock), 0, st, x,
-                       residual, mean, invstd, gamma, beta, a, N, (unsigned long long *)ws, nparts, next_minmax_tag(),
-                       cur_min, cur_max, maxval_out, fa);
+                       residual, mean, invstd, gamma, beta, a, N, (unsigned long long *)((char *)ws + kMinmaxWsHeader), nparts,
+                       next_minmax_tag(), cur_min, cur_max, maxval_out, fa);
     return launch_rc();
+}
+
+int fp8q_affine_act_minmax_f32(const float *x, const float *residual, int64_t N, int64_t C, int64_t HW,
+                               const float *mean, const float *invstd, const float *gamma, const float *beta,
+                               int act, float *cur_min, float *cur_max, float *maxval_out, int fold_mode,
+                               double momentum, int first, void *ws, size_t ws_bytes, fp8q_stream_t stream)
+{
+    return affine_minmax_impl(x, residual, N, C, HW, mean, invstd, gamma, beta, act, cur_min, cur_max, maxval_out, nullptr,
+                              fold_mode, momentum, first, ws, ws_bytes, stream);
+}
+
+int fp8q_affine_act_minmax_packed_f32(const float *x, const float *residual, int64_t N, int64_t C, int64_t HW,
+                                      const float *mean, const float *invstd, const float *gamma, const float *beta,
+                                      int act, float *cur_min, float *cur_max, float *maxval_out, float *packed,
+                                      int fold_mode, double momentum, int first, void *ws, size_t ws_bytes,
+                                      fp8q_stream_t stream)
+{
+    if (!packed) return FP8Q_EINVAL;
+    return affine_minmax_impl(x, residual, N, C, HW, mean, invstd, gamma, beta, act, cur_min, cur_max, maxval_out, packed,
+                              fold_mode, momentum, first, ws, ws_bytes, stream);
 }
 
 }  // extern "C"

@@ -1363,6 +1363,21 @@ k_minmax_partial(const float *__restrict__ x, int64_t inner, int nsplit, unsigne
     block_minmax_publish(m, slots + (int64_t)row * nsplit * 2, split, nsplit, tag, row, cur_min, cur_max, maxval_out, fa);
 }
 
+// After the all-reduce(MAX) of the packed ranges of batch-sharded calibration (FoldArgs::packed, fold_store): back to
+// {min, max} (+ K5: maxval = |max(|min|, max)|, fp8_quantizer.py:236) -- one launch instead of ~8 tiny tensor ops.
+__global__ void __launch_bounds__(kBlock)
+k_ranges_unpack(const float *__restrict__ packed, int64_t n, float *cur_min, float *cur_max, float *maxval_out)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = reinterpret_cast<const float4 *>(packed)[i];
+    const float nan = __builtin_nanf("");
+    const float mn = p.z > 0.0f ? nan : -p.x, mx = p.w > 0.0f ? nan : p.y;
+    if (cur_min) cur_min[i] = mn;
+    if (cur_max) cur_max[i] = mx;
+    if (maxval_out) maxval_out[i] = fabsf(tmax(fabsf(mn), mx));
+}
+
 // 16-byte-per-lane copy with K1's launch shape: the achievable-HBM yardstick
 template <bool NT>
 __global__ void __launch_bounds__(kBlock)
@@ -1761,6 +1776,7 @@ const char *fp8q_strerror(int code)
         case FP8Q_EWORKSPACE: return "workspace too small or misaligned";
         case FP8Q_ETOOLONG: return "rows longer than fp8q_fused_max_inner(): use fp8q_minmax_f32 + fp8q_quantize_f32";
         case FP8Q_ETOOMANY: return "more than 65535 channels in one MSE grid-search call";
+        case FP8Q_ETIMEDOUT: return "a min/max reducer block timed out waiting for its streaming blocks (that call's range is NaN)";
         default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
     }
 }
@@ -1829,7 +1845,7 @@ static int minmax_nsplit(int64_t C, int64_t inner)
     static const int cap_env = [] {   // FP8Q_K3_BLOCKS: streaming blocks of the two-stage min/max (tuning knob)
         const char *e = getenv("FP8Q_K3_BLOCKS");
         const int v = e ? atoi(e) : 0;
-        return v >= 1 && v <= 65535 ? v : kTargetBlocks;
+        return v >= 1 && v <= kTargetBlocks ? v : kTargetBlocks;   // <= 2048: split rows keep their reducers <= 1024 (progress argument, fp8q_common.h)
     }();
     return (int)balanced_blocks(cdiv(cdiv(inner, 4), kBlock * 8), cap_env / (C > 0 ? C : 1));
 }
@@ -1839,21 +1855,52 @@ size_t fp8q_minmax_workspace_bytes(int64_t C, int64_t inner)
     if (C <= 0 || inner <= 0) return 16;
     if (inner <= direct_max_inner() && C > 1) return 16;  // short-row path needs none
     const int ns = minmax_nsplit(C, inner);
-    return ns > 1 ? (size_t)C * (size_t)ns * 2 * sizeof(unsigned long long) + 16 : 16;   // two tagged granules per part
+    // the 16-byte header {timeout count, reserved} + two tagged granules per part
+    return ns > 1 ? kMinmaxWsHeader + (size_t)C * (size_t)ns * 2 * sizeof(unsigned long long) : kMinmaxWsHeader;
 }
 
-int fp8q_minmax_f32(const float *x, int64_t C, int64_t inner, float *cur_min, float *cur_max,
-                    float *maxval_out, int fold_mode, double momentum, int first, void *ws,
-                    size_t ws_bytes, fp8q_stream_t stream)
+// Synchronising check of a min/max workspace (fp8q_minmax_workspace_check; also run on entry by every min/max call
+// under FP8Q_DEBUG_WS=1): the header's timeout count and the "all granules zero between calls" contract.
+static int minmax_ws_check(void *ws, size_t ws_bytes, int clear, hipStream_t st)
+{
+    if (!ws || ws_bytes < kMinmaxWsHeader || ((uintptr_t)ws & 7)) return FP8Q_EWORKSPACE;
+    if (hipError_t e = hipStreamSynchronize(st)) return (int)e;
+    std::vector<unsigned long long> host(ws_bytes / 8);
+    if (hipError_t e = hipMemcpy(host.data(), ws, host.size() * 8, hipMemcpyDeviceToHost)) return (int)e;
+    const unsigned timeouts = (unsigned)host[0];
+    bool dirty = false;
+    for (size_t i = kMinmaxWsHeader / 8; i < host.size(); ++i) dirty |= host[i] != 0ull;
+    if (clear && (timeouts || dirty)) {
+        if (hipError_t e = hipMemsetAsync(ws, 0, ws_bytes, st)) return (int)e;
+        if (hipError_t e = hipStreamSynchronize(st)) return (int)e;
+    }
+    if (timeouts) return FP8Q_ETIMEDOUT;
+    return dirty ? FP8Q_EWORKSPACE : FP8Q_OK;
+}
+
+static bool minmax_debug_ws()
+{
+    static const bool on = [] {
+        const char *e = getenv("FP8Q_DEBUG_WS");
+        return e && atoi(e) != 0;
+    }();
+    return on;
+}
+
+static int minmax_impl(const float *x, int64_t C, int64_t inner, float *cur_min, float *cur_max, float *maxval_out,
+                       float *packed, int fold_mode, double momentum, int first, void *ws, size_t ws_bytes,
+                       fp8q_stream_t stream)
 {
     if (!x || !cur_min || !cur_max || C <= 0 || inner <= 0 || fold_mode < 0 || fold_mode > 2)
         return FP8Q_EINVAL;
+    if (packed && ((uintptr_t)packed & 15)) return FP8Q_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     FoldArgs fa;
     fa.mode = fold_mode;
     fa.first = first != 0;
     fa.om = (float)(1.0 - momentum);
     fa.mo = (float)momentum;
+    fa.packed = packed;
     if (C > 1) {   // per-channel rows of 128..8192 elements: one launch, the row in registers
         QFmt f = {};
         const int rc = launch_rows_reg(false, x, nullptr, C, inner, cur_min, cur_max, maxval_out, f, fa, st);
@@ -1869,20 +1916,58 @@ int fp8q_minmax_f32(const float *x, int64_t C, int64_t inner, float *cur_min, fl
                                   f, fa, st);
     }
     if (ws_bytes < fp8q_minmax_workspace_bytes(C, inner) || !ws || ((uintptr_t)ws & 7)) return FP8Q_EWORKSPACE;
+    if (minmax_debug_ws())
+        if (int rc = minmax_ws_check(ws, fp8q_minmax_workspace_bytes(C, inner), 0, st)) return rc;
     const int ns = minmax_nsplit(C, inner);
     const unsigned tag = next_minmax_tag();
     const unsigned gx = ns > 1 ? (unsigned)ns + 1u : 1u;   // + the row's reducer block
+    fa.status = (unsigned *)ws;
+    fold_debug_env(fa);
+    unsigned long long *slots = (unsigned long long *)((char *)ws + kMinmaxWsHeader);
     for (int64_t c0 = 0; c0 < C; c0 += 65535) {   // ns > 1 implies C <= kTargetBlocks / 2: a single slab
         const int64_t cn = (C - c0) < 65535 ? (C - c0) : 65535;
+        fa.packed = packed ? packed + 4 * c0 : nullptr;
         if (C * inner * 4 >= kNtBytes)
             hipLaunchKernelGGL(k_minmax_partial<true>, dim3(gx, (unsigned)cn), dim3(kBlock), 0, st, x + c0 * inner, inner,
-                               ns, (unsigned long long *)ws, tag, cur_min + c0, cur_max + c0,
-                               maxval_out ? maxval_out + c0 : nullptr, fa);
+                               ns, slots, tag, cur_min + c0, cur_max + c0, maxval_out ? maxval_out + c0 : nullptr, fa);
         else
             hipLaunchKernelGGL(k_minmax_partial<false>, dim3(gx, (unsigned)cn), dim3(kBlock), 0, st, x + c0 * inner, inner,
-                               ns, (unsigned long long *)ws, tag, cur_min + c0, cur_max + c0,
-                               maxval_out ? maxval_out + c0 : nullptr, fa);
+                               ns, slots, tag, cur_min + c0, cur_max + c0, maxval_out ? maxval_out + c0 : nullptr, fa);
     }
+    return launch_rc();
+}
+
+int fp8q_minmax_f32(const float *x, int64_t C, int64_t inner, float *cur_min, float *cur_max,
+                    float *maxval_out, int fold_mode, double momentum, int first, void *ws,
+                    size_t ws_bytes, fp8q_stream_t stream)
+{
+    return minmax_impl(x, C, inner, cur_min, cur_max, maxval_out, nullptr, fold_mode, momentum, first, ws, ws_bytes, stream);
+}
+
+int fp8q_minmax_packed_f32(const float *x, int64_t C, int64_t inner, float *cur_min, float *cur_max,
+                           float *maxval_out, float *packed, int fold_mode, double momentum, int first, void *ws,
+                           size_t ws_bytes, fp8q_stream_t stream)
+{
+    if (!packed) return FP8Q_EINVAL;
+    return minmax_impl(x, C, inner, cur_min, cur_max, maxval_out, packed, fold_mode, momentum, first, ws, ws_bytes, stream);
+}
+
+int fp8q_minmax_workspace_check(void *ws, size_t ws_bytes, int clear, fp8q_stream_t stream)
+{
+    try {
+        return minmax_ws_check(ws, ws_bytes, clear, (hipStream_t)stream);
+    } catch (...) {
+        return (int)hipErrorOutOfMemory;
+    }
+}
+
+int fp8q_ranges_unpack_f32(const float *packed, int64_t n, float *cur_min, float *cur_max, float *maxval_out,
+                           fp8q_stream_t stream)
+{
+    if (n < 0 || (n > 0 && (!packed || ((uintptr_t)packed & 15)))) return FP8Q_EINVAL;
+    if (n == 0) return FP8Q_OK;
+    hipLaunchKernelGGL(k_ranges_unpack, dim3((unsigned)cdiv(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, packed, n,
+                       cur_min, cur_max, maxval_out);
     return launch_rc();
 }
 

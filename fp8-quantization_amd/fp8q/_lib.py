@@ -27,6 +27,10 @@ SIGNATURES = {
     "fp8q_minmax_workspace_bytes": (ctypes.c_size_t, [_i64, _i64]),
     "fp8q_minmax_f32": (_i, [_vp, _i64, _i64, _vp, _vp, _vp, _i, ctypes.c_double, _i, _vp,
                              ctypes.c_size_t, _vp]),
+    "fp8q_minmax_packed_f32": (_i, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _i, ctypes.c_double, _i, _vp,
+                                    ctypes.c_size_t, _vp]),
+    "fp8q_ranges_unpack_f32": (_i, [_vp, _i64, _vp, _vp, _vp, _vp]),
+    "fp8q_minmax_workspace_check": (_i, [_vp, ctypes.c_size_t, _i, _vp]),
     "fp8q_fused_max_inner": (_i64, []),
     "fp8q_minmax_quantize_f32": (_i, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _f, _i, _i, _vp]),
     "fp8q_mse_workspace_bytes": (ctypes.c_size_t, [_i64, _i64, _i64, _i]),
@@ -37,6 +41,8 @@ SIGNATURES = {
     "fp8q_affine_act_minmax_workspace_bytes": (ctypes.c_size_t, [_i64, _i64, _i64]),
     "fp8q_affine_act_minmax_f32": (_i, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i,
                                         ctypes.c_double, _i, _vp, ctypes.c_size_t, _vp]),
+    "fp8q_affine_act_minmax_packed_f32": (_i, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp,
+                                               _i, ctypes.c_double, _i, _vp, ctypes.c_size_t, _vp]),
     "fp8q_encode_u8": (_i, [_vp, _vp, _i64, _i64, _vp, _i64, _f, _i, _i, _vp]),
     "fp8q_decode_u8": (_i, [_vp, _vp, _i64, _i64, _vp, _i64, _f, _i, _i, _vp]),
     "fp8q_multi_quantize_f32": (_i, [ctypes.POINTER(TensorDesc), _i, _vp]),

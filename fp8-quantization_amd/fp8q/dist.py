@@ -60,7 +60,11 @@ def channel_partition(n_channels, world_size):
 
 
 def allreduce_ranges(mins, maxs, group=None):
-    """In-place global min of `mins` and max of `maxs` with a single all-reduce(MAX)."""
+    """In-place global min of `mins` and max of `maxs` with a single all-reduce(MAX).
+
+    Tensor-op version for ranges that already sit in separate tensors (sync_activation_ranges: once per model).  The
+    per-batch exchange of calibration does not come through here: there the min/max kernel itself writes the packed
+    operand and one kernel unpacks it (ops.minmax(packed=) -> all_reduce -> ops.ranges_unpack)."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return mins, maxs
     n = mins.numel()
@@ -138,12 +142,19 @@ def calibrate_quantize_sharded(x_local, mbits, n_bits=8, sign_bits=1, state=None
     quantization_manager.py:119-122).  Returns (y_local, state); state = (min, max) tensors [1]."""
     ops = ops or _default_ops()
     cur_min, cur_max = state if state is not None else (None, None)
+    multi = dist.is_initialized() and dist.get_world_size(group) > 1
+    packed = ops.new_packed(1, x_local.device) if multi else None
     _mark(timing)
-    cur_min, cur_max = ops.minmax(x_local, False, cur_min, cur_max, mode=1)[:2]
+    # the kernel leaves the folded range, K5's maxval and (multi-rank) the packed all-reduce operand
+    if multi:
+        cur_min, cur_max, maxval = ops.minmax(x_local, False, cur_min, cur_max, mode=1, want_maxval=True, packed=packed)
+    else:
+        cur_min, cur_max, maxval = ops.minmax(x_local, False, cur_min, cur_max, mode=1, want_maxval=True)
     _mark(timing)
-    allreduce_ranges(cur_min, cur_max, group)
+    if multi:
+        dist.all_reduce(packed, op=dist.ReduceOp.MAX, group=group)
+        ops.ranges_unpack(packed, cur_min, cur_max, maxval)         # + fp8_quantizer.py:236 on the global range
     _mark(timing)
-    maxval = torch.abs(torch.max(torch.abs(cur_min), cur_max))      # fp8_quantizer.py:236
     y = ops.quantize(x_local, maxval, mbits, n_bits, sign_bits, out=out)
     _mark(timing)
     return y, (cur_min, cur_max)
@@ -231,7 +242,7 @@ def quantize_weight_sharded(w, mbits, n_bits=8, sign_bits=1, maxval=None, group=
         return q_shard, mv_shard
     if C % world == 0:
         # even split: gather straight into the final tensors (no padding, no re-assembly copies)
-        out, mv_out = torch.empty_like(w), w.new_empty(C)
+        out, mv_out = torch.empty(w.shape, dtype=w.dtype, device=w.device), w.new_empty(C)   # contiguous for any layout of w
         dist.all_gather_into_tensor(out.view(-1), q_shard.reshape(-1), group=group)
         dist.all_gather_into_tensor(mv_out, mv_shard, group=group)
         _mark(timing)

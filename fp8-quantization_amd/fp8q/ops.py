@@ -181,11 +181,58 @@ class MultiPlan:
                 pass
 
 
+def new_packed(C, device):
+    """[C, 4] fp32 buffer for the packed ranges of batch-sharded calibration (16-byte records)."""
+    return torch.empty((C, 4), dtype=torch.float32, device=device)
+
+
+def _check_packed(packed, C):
+    _require(packed, "packed")
+    if packed.numel() != 4 * C or not packed.is_contiguous() or packed.data_ptr() % 16:
+        raise Fp8qError(f"packed must be a contiguous, 16-byte aligned [{C}, 4] tensor")
+
+
+def ranges_unpack(packed, cur_min=None, cur_max=None, maxval=None):
+    """After all-reduce(MAX) of a packed-ranges buffer (minmax(..., packed=) / affine_act_minmax(..., packed=)):
+    cur_min / cur_max / maxval ([C] tensors, written in place; None = allocate).  Returns (cur_min, cur_max, maxval)."""
+    _require(packed, "packed")
+    n = packed.numel() // 4
+    _check_packed(packed, n)
+    if cur_min is None or cur_max is None or maxval is None:
+        st = torch.empty((3, n), dtype=torch.float32, device=packed.device)
+        cur_min = st[0] if cur_min is None else cur_min
+        cur_max = st[1] if cur_max is None else cur_max
+        maxval = st[2] if maxval is None else maxval
+    for t in (cur_min, cur_max, maxval):
+        _require(t, "range vector")
+        if t.numel() != n or not t.is_contiguous():
+            raise Fp8qError("range vectors must be contiguous [C] tensors")
+    with _on_device(packed):
+        rc = lib().fp8q_ranges_unpack_f32(packed.data_ptr(), n, cur_min.data_ptr(), cur_max.data_ptr(),
+                                          maxval.data_ptr(), _stream(packed))
+    check(rc, "fp8q_ranges_unpack_f32")
+    return cur_min, cur_max, maxval
+
+
+def check_workspaces(clear=True):
+    """SYNCHRONISES.  Inspect every min/max workspace this process has used (fp8q_minmax_workspace_check): raises
+    Fp8qError if a reducer block timed out (that call's range is NaN) or a workspace is dirty between calls.
+    Called by QuantizedModel.fix_ranges(), i.e. once after calibration."""
+    for (dev_index, stream, zeroed), ws in list(_ws_cache.items()):
+        if not zeroed:
+            continue
+        with torch.cuda.device(dev_index):
+            rc = lib().fp8q_minmax_workspace_check(ws.data_ptr(), ws.numel(), int(bool(clear)), stream)
+        check(rc, "fp8q_minmax_workspace_check")
+
+
 def minmax(x, per_channel, cur_min=None, cur_max=None, mode=FOLD_CURRENT, momentum=0.9,
-           want_maxval=False):
+           want_maxval=False, packed=None):
     """K2/K3(/K5): batch min/max folded into the running estimate (range_estimators.py:61-125).
 
     cur_min/cur_max: running estimate tensors [C] (updated in place) or None on the first call.
+    packed: optional [C, 4] buffer (new_packed) that receives {-min, max, nan flags} of the folded estimate for the
+    range all-reduce of batch-sharded calibration (see ranges_unpack).
     Returns (cur_min, cur_max[, maxval]) as [C] tensors.
     """
     _require(x, "x")
@@ -216,9 +263,15 @@ def minmax(x, per_channel, cur_min=None, cur_max=None, mode=FOLD_CURRENT, moment
         nbytes = _mm_ws_bytes[(C, inner)] = L.fp8q_minmax_workspace_bytes(C, inner)
     ws = _workspace(x.device, nbytes, zeroed=True)
     with _on_device(x):
-        rc = L.fp8q_minmax_f32(x.data_ptr(), C, inner, cur_min.data_ptr(), cur_max.data_ptr(),
-                               mv.data_ptr() if mv is not None else None, int(mode), float(momentum),
-                               int(first), ws.data_ptr(), ws.numel(), _stream(x))
+        if packed is None:
+            rc = L.fp8q_minmax_f32(x.data_ptr(), C, inner, cur_min.data_ptr(), cur_max.data_ptr(),
+                                   mv.data_ptr() if mv is not None else None, int(mode), float(momentum),
+                                   int(first), ws.data_ptr(), ws.numel(), _stream(x))
+        else:
+            _check_packed(packed, C)
+            rc = L.fp8q_minmax_packed_f32(x.data_ptr(), C, inner, cur_min.data_ptr(), cur_max.data_ptr(),
+                                          mv.data_ptr() if mv is not None else None, packed.data_ptr(), int(mode),
+                                          float(momentum), int(first), ws.data_ptr(), ws.numel(), _stream(x))
     check(rc, "fp8q_minmax_f32")
     return (cur_min, cur_max, mv) if want_maxval else (cur_min, cur_max)
 
@@ -371,8 +424,9 @@ def affine_act_quantize(x, maxval, mbits, n_bits=8, sign_bits=1, bn=None, residu
 
 
 def affine_act_minmax(x, cur_min=None, cur_max=None, mode=FOLD_CURRENT, momentum=0.9, bn=None, residual=None,
-                      act=0):
+                      act=0, packed=None):
     """N2: per-tensor min/max of act(bn(x) + residual), folded into the running estimate.
+    packed: optional [1, 4] buffer for the range all-reduce (see minmax).
     Returns (cur_min, cur_max, maxval) as [1] tensors."""
     _require(x, "x")
     x = x.contiguous()
@@ -389,9 +443,16 @@ def affine_act_minmax(x, cur_min=None, cur_max=None, mode=FOLD_CURRENT, momentum
     L = lib()
     ws = _workspace(x.device, L.fp8q_affine_act_minmax_workspace_bytes(N, C, HW), zeroed=True)
     with _on_device(x):
-        rc = L.fp8q_affine_act_minmax_f32(
-            x.data_ptr(), residual.data_ptr() if residual is not None else None, N, C, HW, ptrs[0], ptrs[1],
-            ptrs[2], ptrs[3], int(act), cur_min.data_ptr(), cur_max.data_ptr(), mv.data_ptr(), int(mode),
-            float(momentum), int(first), ws.data_ptr(), ws.numel(), _stream(x))
+        if packed is None:
+            rc = L.fp8q_affine_act_minmax_f32(
+                x.data_ptr(), residual.data_ptr() if residual is not None else None, N, C, HW, ptrs[0], ptrs[1],
+                ptrs[2], ptrs[3], int(act), cur_min.data_ptr(), cur_max.data_ptr(), mv.data_ptr(), int(mode),
+                float(momentum), int(first), ws.data_ptr(), ws.numel(), _stream(x))
+        else:
+            _check_packed(packed, 1)
+            rc = L.fp8q_affine_act_minmax_packed_f32(
+                x.data_ptr(), residual.data_ptr() if residual is not None else None, N, C, HW, ptrs[0], ptrs[1],
+                ptrs[2], ptrs[3], int(act), cur_min.data_ptr(), cur_max.data_ptr(), mv.data_ptr(), packed.data_ptr(),
+                int(mode), float(momentum), int(first), ws.data_ptr(), ws.numel(), _stream(x))
     check(rc, "fp8q_affine_act_minmax_f32")
     return cur_min, cur_max, mv

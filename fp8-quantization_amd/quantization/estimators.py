@@ -35,19 +35,30 @@ class RangeEstimatorBase(nn.Module):
     def forward(self, x):
         raise NotImplementedError()
 
-    def _sync(self):
-        """Data-parallel calibration (batch sharded over the ranks of `dist_group`): after this rank's update,
-        all-reduce the estimate so that every rank holds what ONE process would have computed on the
-        concatenated batch.  Exact for all three folds: min / max commute with the union, and the EMA
-        (1-m)*new + m*cur is monotone in `new` with the same `cur` on every rank, so max-over-ranks of the folded
-        value equals the fold of the max-over-ranks.  One 16-byte collective per quantizer and batch."""
-        if self.dist_group is None or self.current_xmin is None or self.per_channel:
-            return
-        from fp8q import dist as _fd
-        mn, mx = self.current_xmin.reshape(1).clone(), self.current_xmax.reshape(1).clone()
-        _fd.allreduce_ranges(mn, mx, None if self.dist_group is True else self.dist_group)
-        self.current_xmin, self.current_xmax = mn.reshape(()), mx.reshape(())
-        self.last_maxval = torch.abs(torch.max(torch.abs(mn), mx))      # fp8_quantizer.py:236
+    def _dist_active(self):
+        """Data-parallel calibration is on (fp8q.dist.enable_distributed_calibration) and there is more than one rank."""
+        if self.dist_group is None or self.per_channel:
+            return False
+        import torch.distributed as dist
+        return dist.is_initialized() and dist.get_world_size(self._group()) > 1
+
+    def _group(self):
+        return None if self.dist_group is True else self.dist_group
+
+    def _packed(self, device):
+        """The operand of the range all-reduce, or None.  Data-parallel calibration (batch sharded over the ranks of
+        `dist_group`): the min/max kernel writes {-min, max, nan flags} of the folded estimate next to the estimate
+        itself, the ranks all-reduce(MAX) those 16 bytes, one tiny kernel unpacks them (+ K5) -- every rank then holds
+        what ONE process would have computed on the concatenated batch.  Exact for all three folds: min / max commute
+        with the union, and the EMA (1-m)*new + m*cur is monotone in `new` with the same `cur` on every rank, so the
+        max over ranks of the folded value equals the fold of the max over ranks."""
+        return _ops.new_packed(1, device) if self._dist_active() else None
+
+    def _exchange(self, packed, mn, mx, mv):
+        """all-reduce(MAX) of `packed` and unpack into mn / mx / mv (in place; [1] tensors)."""
+        import torch.distributed as dist
+        dist.all_reduce(packed, op=dist.ReduceOp.MAX, group=self._group())
+        _ops.ranges_unpack(packed, mn, mx, mv)
 
     def reset(self):
         self.current_xmin = None
@@ -71,12 +82,17 @@ class RangeEstimatorBase(nn.Module):
             cur_min, cur_max = cur_min.reshape(-1), cur_max.reshape(-1)
             if self._fold_mode == _ops.FOLD_CURRENT:
                 cur_min = cur_max = None   # overwritten anyway; keeps buffers of old shapes out
-        mn, mx, mv = _ops.minmax(x, self.per_channel, cur_min, cur_max, mode=self._fold_mode,
-                                 momentum=self.momentum, want_maxval=True)
+        packed = self._packed(x.device)
+        if packed is None:
+            mn, mx, mv = _ops.minmax(x, self.per_channel, cur_min, cur_max, mode=self._fold_mode,
+                                     momentum=self.momentum, want_maxval=True)
+        else:
+            mn, mx, mv = _ops.minmax(x, self.per_channel, cur_min, cur_max, mode=self._fold_mode,
+                                     momentum=self.momentum, want_maxval=True, packed=packed)
+            self._exchange(packed, mn, mx, mv)      # global range before the batch is quantized with it
         if not self.per_channel:      # reference returns 0-dim tensors for per-tensor ranges
             mn, mx = mn.reshape(()), mx.reshape(())
         self.current_xmin, self.current_xmax, self.last_maxval = mn, mx, mv
-        self._sync()
         return self.current_xmin, self.current_xmax
 
 
@@ -142,13 +158,7 @@ class FP_MSE_Estimator(RangeEstimatorBase):
         self._mbit_list = None
 
     def _dist_batch(self):
-        if self.dist_group is None or self.per_channel:
-            return False
-        import torch.distributed as dist
-        return dist.is_initialized() and dist.get_world_size(self._group()) > 1
-
-    def _group(self):
-        return None if self.dist_group is True else self.dist_group
+        return self._dist_active()
 
     def _define_search_range(self, x, n_m):
         if self.search_grid is None:

@@ -159,6 +159,10 @@ class FPQuantizer(QuantizerBase):
                  learn_maxval=False, learn_mantissa_bits=False, mse_include_mantissa_bits=True,
                  allow_unsigned=False, **kwargs):
         super().__init__(*args, **kwargs)
+        if learn_mantissa_bits:
+            # fail at construction, not inside a later learn_ranges(): see learn_mantissa_bits()
+            raise NotImplementedError("learn_mantissa_bits=True: learnable mantissa bits are a QAT feature outside this "
+                                      "engine's path (the HIP quantizer takes the mantissa width by value)")
         m = mantissa_bits
         self.ebits = self.n_bits - m - 1
         self.default_bias = 2 ** (self.ebits - 1)

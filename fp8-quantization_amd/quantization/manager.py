@@ -146,10 +146,15 @@ class QuantizationManager(nn.Module):
                 cur_min, cur_max = cur_min.reshape(-1), cur_max.reshape(-1)
             else:
                 cur_min = cur_max = None
-            mn, mx, mv = _ops.affine_act_minmax(x, cur_min, cur_max, mode=est._fold_mode, momentum=est.momentum,
-                                                bn=bn, residual=residual, act=act)
+            packed = est._packed(x.device)
+            if packed is None:
+                mn, mx, mv = _ops.affine_act_minmax(x, cur_min, cur_max, mode=est._fold_mode, momentum=est.momentum,
+                                                    bn=bn, residual=residual, act=act)
+            else:                                    # data-parallel calibration: global range before quantizing
+                mn, mx, mv = _ops.affine_act_minmax(x, cur_min, cur_max, mode=est._fold_mode, momentum=est.momentum,
+                                                    bn=bn, residual=residual, act=act, packed=packed)
+                est._exchange(packed, mn, mx, mv)
             est.current_xmin, est.current_xmax, est.last_maxval = mn.reshape(()), mx.reshape(()), mv
-            est._sync()                              # data-parallel calibration: global range before quantizing
             if q.set_maxval:
                 q._set_maxval_tensor(est.last_maxval)
         if q.maxval.device != x.device:

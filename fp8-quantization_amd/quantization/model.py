@@ -8,6 +8,22 @@ from .layers import QuantizedModule, _for_managers
 
 RANGES_KEY = "__fp8_quantizer_ranges__"
 
+# model -> (plan, [(layer, weight, quantizer)], [signature]) of prequantize_weights().  A side table, not an attribute:
+# the plan wraps a native handle (ctypes), which must neither be pickled / deep-copied with the model
+# (copy.deepcopy(model) and torch.save(model) are everyday operations in the reference's workflows,
+# autoquant_utils.py:375) nor end up owned by two Python objects.  A copy of a model simply has no plan yet.
+import weakref  # noqa: E402
+
+_PLANS = weakref.WeakKeyDictionary()
+
+
+def _plan_signature(m, q):
+    """Everything a prepared plan bakes in BY VALUE for one layer (csrc plan_build: d.f = make_fmt(mbits, n_bits,
+    sign_bits)) plus the conditions under which the layer was eligible: if any of it changes, the plan is stale."""
+    mgr = m.weight_quantizer
+    return (float(q.mantissa_bits), int(q.sign_bits), int(q.n_bits), getattr(q, "_range_epoch", None), mgr.state,
+            bool(getattr(m, "_qw", False)))
+
 
 def quantizer_ranges(model):
     """{manager name: {maxval, mantissa_bits, sign_bits, state}} for every FP8 quantizer of `model`.
@@ -83,7 +99,7 @@ def prequantize_weights(model):
         mods.append((m, w, q))
         items.append((w.detach(), mv, float(q.mantissa_bits), int(q.n_bits), int(q.sign_bits)))
     if not items:
-        model._wq_plan = None
+        _PLANS.pop(model, None)
         return 0
     import fp8q
     # a prepared plan (fp8q_multi_plan_*): descriptors validated and packed once here; requantize_weights() replays
@@ -93,7 +109,7 @@ def prequantize_weights(model):
     for (m, w, q), y in zip(mods, outs):
         m._wq_cache = y
         m._wq_key = m._weight_cache_key(w, q)
-    model._wq_plan = (plan, mods)
+    _PLANS[model] = (plan, mods, [_plan_signature(m, q) for m, w, q in mods])
     return len(outs)
 
 
@@ -102,13 +118,21 @@ def requantize_weights(model):
     call into the prepared plan built by prequantize_weights() = one kernel launch for all layers (the reference
     re-quantizes layer by layer in every forward, hijacker.py:88-98).  Falls back to a fresh prequantize_weights()
     when a tensor was replaced rather than updated.  Returns the number of layers refreshed."""
-    held = getattr(model, "_wq_plan", None)
-    if held is None:
+    import os
+
+    held = _PLANS.get(model)
+    if held is None or os.environ.get("FP8Q_CACHE_WEIGHTS", "1") == "0":
         return prequantize_weights(model)
-    plan, mods = held
-    for (m, w, q), (x, mv) in zip(mods, plan._keep):
+    plan, mods, sigs = held
+    for (m, w, q), (x, mv), sig in zip(mods, plan._keep, sigs):
         cur = m.get_weight_bias()[0]
-        if cur.data_ptr() != x.data_ptr() or tuple(cur.shape) != tuple(x.shape) or q.maxval.data_ptr() != mv.data_ptr():
+        # a tensor replaced rather than updated in place, a format / state change (the plan holds the format by value),
+        # or a weight that became trainable under autograd: rebuild (prequantize_weights re-checks every layer's eligibility)
+        if (cur.data_ptr() != x.data_ptr() or tuple(cur.shape) != tuple(x.shape) or q.maxval.data_ptr() != mv.data_ptr()
+                or m.weight_quantizer.quantizer is not q or (cur.requires_grad and torch.is_grad_enabled())):
+            return prequantize_weights(model)
+        now = _plan_signature(m, q)
+        if now[:3] != sig[:3] or now[4:] != sig[4:]:      # the range epoch (index 3) moves with in-place range updates: fine
             return prequantize_weights(model)
     plan.launch()
     for (m, w, q), y in zip(mods, plan.outs):
@@ -266,6 +290,10 @@ class QuantizedModel(nn.Module):
 
     def fix_ranges(self):
         _for_managers(self, lambda m: m.fix_ranges(), need_init=True)
+        # end of calibration = the one place where a host sync is free: surface what the enqueue-only min/max
+        # launches could not report (a reducer block that timed out -> NaN range; a dirty workspace)
+        import fp8q
+        fp8q.ops.check_workspaces()
         self.prequantize_weights()
 
     def prequantize_weights(self):

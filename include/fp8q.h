@@ -15,7 +15,8 @@
  *   - return 0 on success, a positive hipError_t on a HIP failure, a negative FP8Q_E* on a
  *     bad argument; never throws; stateless and thread-safe
  *   - arithmetic contract: bit-identical to oracle/fp8q_oracle.c (reference op order in
- *     fp32, correctly rounded log2 / 2^x) -- see DESIGN.md "Arithmetic contract"
+ *     fp32, correctly rounded log2 / 2^x) -- see DESIGN.md "Arithmetic contract".  ONE exception:
+ *     fp8q_mse_grid_f32 (K4) -- see its comment
  */
 #ifndef FP8Q_H
 #define FP8Q_H
@@ -27,7 +28,7 @@
 extern "C" {
 #endif
 
-#define FP8Q_VERSION 200 /* 0.2.0: single-launch min/max (zeroed workspaces), multi-tensor plans */
+#define FP8Q_VERSION 300 /* 0.3.0: packed ranges for the calibration all-reduce, workspace status / FP8Q_ETIMEDOUT */
 
 #define FP8Q_OK 0
 #define FP8Q_EINVAL (-1)       /* null pointer, negative size, n_maxval not in {1, C}, ... */
@@ -35,6 +36,7 @@ extern "C" {
 #define FP8Q_EWORKSPACE (-3)   /* workspace too small or misaligned */
 #define FP8Q_ETOOLONG (-4)     /* fused min/max+quantize: rows longer than fp8q_fused_max_inner() */
 #define FP8Q_ETOOMANY (-5)     /* MSE grid search: more than 65535 channels in one call */
+#define FP8Q_ETIMEDOUT (-6)    /* fp8q_minmax_workspace_check: a min/max reducer gave up waiting (that range is NaN) */
 
 /* range-estimator fold modes (how a new batch estimate is merged into the running one) */
 #define FP8Q_FOLD_CURRENT 0 /* overwrite          range_estimators.py:72-73  CurrentMinMaxEstimator */
@@ -48,6 +50,20 @@ extern "C" {
  * allocating it) and every call leaves it zero, so a buffer that is only ever handed to these two entry points, by one
  * stream at a time, never needs clearing again.  Do not share one buffer between launches that may run concurrently,
  * and do not let other kernels scribble over it.
+ * Layout: a 16-byte header {uint32 timeout count, 12 reserved bytes} followed by the 8-byte granules.
+ *
+ * Failure modes and how they surface (the entry points only enqueue, so they cannot report what happens on the device):
+ *   - the reducer block waits a bounded time (~2 s) for its streaming blocks; if one never arrives it writes NaN as
+ *     that row's range AND increments the header's timeout count.  fp8q_minmax_workspace_check() -- which synchronises
+ *     the stream -- then returns FP8Q_ETIMEDOUT; call it wherever a sync is acceptable (the Python layer does at
+ *     fix_ranges(), i.e. once after calibration).
+ *   - a workspace that was not zero on entry, or that two streams used at once, gives wrong ranges silently;
+ *     fp8q_minmax_workspace_check() returns FP8Q_EWORKSPACE when it finds non-zero granules between calls, and with
+ *     FP8Q_DEBUG_WS=1 in the environment every min/max call runs that check (sync + copy) on entry and refuses to
+ *     launch on a dirty workspace.
+ * Progress does not rely on the order in which workgroups are dispatched (streaming blocks never wait; reducers are at
+ * most half of the resident workgroup slots); in-order dispatch -- what the hardware does, not a HIP guarantee -- only
+ * keeps the reducer's wait short.
  */
 
 typedef void *fp8q_stream_t; /* hipStream_t */
@@ -94,6 +110,28 @@ int fp8q_minmax_f32(const float *x, int64_t C, int64_t inner, float *cur_min, fl
  * Requires inner <= fp8q_fused_max_inner(); larger rows: call fp8q_minmax_f32 + fp8q_quantize_f32.
  * HBM traffic: 8 B / element.
  */
+/*
+ * Batch-sharded (data-parallel) calibration: the _packed variants additionally write, per row, the 16-byte record
+ * {-min, max, isnan(min), isnan(max)} of the FOLDED estimate ([C, 4] fp32, 16-byte aligned; a NaN travels as its
+ * flag with -inf as the value).  The ranks then need ONE all-reduce(MAX) over that buffer -- min/max commute with the
+ * union of the shards -- and fp8q_ranges_unpack_f32 turns the reduced records back into cur_min / cur_max (+ K5
+ * maxval_out; each may be NULL).  The reference is single-process (utils/qat_utils.py:27-28); this is north_star's
+ * "activation calibration is batch-sharded with an RCCL all-reduce of the running min/max" with no tensor glue
+ * around the collective.
+ */
+int fp8q_minmax_packed_f32(const float *x, int64_t C, int64_t inner, float *cur_min, float *cur_max,
+                           float *maxval_out, float *packed, int fold_mode, double momentum, int first, void *ws,
+                           size_t ws_bytes, fp8q_stream_t stream);
+int fp8q_ranges_unpack_f32(const float *packed, int64_t n, float *cur_min, float *cur_max, float *maxval_out,
+                           fp8q_stream_t stream);
+
+/*
+ * SYNCHRONISES `stream`, then inspects a min/max workspace: FP8Q_ETIMEDOUT if a reducer timed out since the last
+ * clear, FP8Q_EWORKSPACE if granules are non-zero between calls (contract violated), FP8Q_OK otherwise.
+ * clear != 0: the workspace is zeroed again after a failure was reported (so the buffer stays usable).
+ */
+int fp8q_minmax_workspace_check(void *ws, size_t ws_bytes, int clear, fp8q_stream_t stream);
+
 int64_t fp8q_fused_max_inner(void);
 int fp8q_minmax_quantize_f32(const float *x, float *y, int64_t C, int64_t inner, float *row_min,
                              float *row_max, float *maxval_out, float mbits, int n_bits,
@@ -106,6 +144,12 @@ int fp8q_minmax_quantize_f32(const float *x, float *y, int64_t C, int64_t inner,
  *   x     [C, inner];  grid [n_cand, C] candidate maxvals;  mbits [n_m] (host array)
  *   mses  [n_m, n_cand, C] fp32, accumulated:  += mean over the row of (x - q(x))^2
  *   ws    scratch of at least fp8q_mse_workspace_bytes(C, inner, n_cand, n_m) bytes
+ * NOT bit-exact per element against the oracle (unlike every other entry point): for rows >= 2048 elements the kernel
+ * forms x / s as x * 2^frac(bias) * 2^j and rounds by a magic-number add instead of the reference's IEEE division +
+ * table lookup, and it sums in another order (double partials).  The quantized value of an element is the oracle's
+ * except on exact rounding ties decided by the last bit of the division; table entries agree with the oracle's to
+ * ~1e-6 relative (tests: <= 1e-5 on every entry, the CHOSEN (mantissa bits, maxval) equal to the oracle's choice or
+ * its oracle-MSE within 1e-6 relative of the oracle's minimum -- SURVEY.md 8c).
  */
 size_t fp8q_mse_workspace_bytes(int64_t C, int64_t inner, int64_t n_cand, int n_m);
 int fp8q_mse_grid_f32(const float *x, int64_t C, int64_t inner, const float *grid, int64_t n_cand,
@@ -132,6 +176,12 @@ int fp8q_affine_act_minmax_f32(const float *x, const float *residual, int64_t N,
                                const float *mean, const float *invstd, const float *gamma, const float *beta,
                                int act, float *cur_min, float *cur_max, float *maxval_out, int fold_mode,
                                double momentum, int first, void *ws, size_t ws_bytes, fp8q_stream_t stream);
+
+int fp8q_affine_act_minmax_packed_f32(const float *x, const float *residual, int64_t N, int64_t C, int64_t HW,
+                                      const float *mean, const float *invstd, const float *gamma, const float *beta,
+                                      int act, float *cur_min, float *cur_max, float *maxval_out, float *packed,
+                                      int fold_mode, double momentum, int first, void *ws, size_t ws_bytes,
+                                      fp8q_stream_t stream);
 
 /*
  * N3 -- real FP8 storage codes.  The reference only simulates the format; its

@@ -23,10 +23,37 @@ def quantize(x, maxval, mbits, n_bits=8, sign_bits=1, out=None):
     return y
 
 
-def minmax(x, per_channel, cur_min=None, cur_max=None, mode=0, momentum=0.9, want_maxval=False):
+def new_packed(C, device):
+    return torch.empty((C, 4), dtype=torch.float32, device=device)
+
+
+def pack_ranges(mn, mx, packed):
+    """what fold_store (csrc/fp8q_common.h) writes: {-min, max, isnan(min), isnan(max)}, a NaN travelling as -inf + flag"""
+    nmn, nmx = np.isnan(mn), np.isnan(mx)
+    with np.errstate(invalid="ignore"):
+        p = np.stack([np.where(nmn, -np.inf, -mn), np.where(nmx, -np.inf, mx), nmn.astype(np.float32),
+                      nmx.astype(np.float32)], 1).astype(np.float32)
+    packed.copy_(_t(p))
+
+
+def ranges_unpack(packed, cur_min=None, cur_max=None, maxval=None):
+    p = packed.numpy().reshape(-1, 4)
+    mn = np.where(p[:, 2] > 0, np.float32("nan"), -p[:, 0]).astype(np.float32)
+    mx = np.where(p[:, 3] > 0, np.float32("nan"), p[:, 1]).astype(np.float32)
+    res = [_t(mn), _t(mx), _t(oracle.c_absmax(mn, mx))]
+    for i, dst in enumerate((cur_min, cur_max, maxval)):
+        if dst is not None:
+            dst.copy_(res[i].view_as(dst))
+            res[i] = dst
+    return tuple(res)
+
+
+def minmax(x, per_channel, cur_min=None, cur_max=None, mode=0, momentum=0.9, want_maxval=False, packed=None):
     mn, mx = oracle.c_minmax(x.detach().numpy(), per_channel)
     if cur_min is not None and cur_max is not None:
         mn, mx = oracle.c_fold(cur_min.numpy(), cur_max.numpy(), mn, mx, mode, momentum)
+    if packed is not None:
+        pack_ranges(mn, mx, packed)
     out = (_t(mn), _t(mx))
     return out + (_t(oracle.c_absmax(mn, mx)),) if want_maxval else out
 
@@ -52,7 +79,7 @@ def fused_max_inner():
 def patched():
     """with oracle_ops.patched(): ... -> fp8q.ops.* run on the CPU oracle inside the block."""
     import fp8q
-    names = ("quantize", "minmax", "minmax_quantize", "mse_grid", "fused_max_inner")
+    names = ("quantize", "minmax", "minmax_quantize", "mse_grid", "fused_max_inner", "new_packed", "ranges_unpack")
     saved = {n: getattr(fp8q.ops, n) for n in names}
     try:
         for n in names:

@@ -1,0 +1,93 @@
+"""bench.py as the driver runs it: the JSON-line contract, the bare multi-rank self-launch, configs 3 / 4 in `extras`."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(args, timeout):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):      # a bare invocation: no launcher environment
+        env.pop(k, None)
+    return subprocess.run([sys.executable, BENCH] + args, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env)
+
+
+def _line(stdout):
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert len(lines) == 1, stdout[-3000:]
+    return json.loads(lines[0])
+
+
+def test_bare_multi_gpu_invocation_starts_its_ranks_cpu():
+    """`python bench.py --gpus 2` with no launcher must start 2 ranks itself (it used to sys.exit with a hint).  Without a
+    GPU every rank then refuses -- the engine has no CPU path -- which is visible as one refusal PER RANK and a
+    non-zero exit code."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("CPU-side check of the launcher; the GPU box runs the real thing below")
+    r = _run(["--gpus", "2", "--backend", "gloo", "--steps", "1", "--warmup", "0"], 600)
+    assert r.returncode != 0
+    assert (r.stdout + r.stderr).count("bench.py needs a GPU") >= 2, (r.stdout + r.stderr)[-3000:]
+    assert "launch with: python -m torch.distributed.run" not in r.stdout + r.stderr
+
+
+def test_world_size_mismatch_is_an_error():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "4"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_bare_two_rank_gloo_bench_on_one_gpu():
+    """The multi-process path end to end on the one-GPU box: bare `python bench.py --gpus 2 --backend gloo` re-executes
+    itself through torch.distributed.run, both ranks share cuda:0, every section of the line is produced and the
+    collectives saw 2 ranks.  (gloo carries device tensors through the host: its times say nothing about xGMI.)"""
+    r = _run(["--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "1"], 1500)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
+    line = _line(r.stdout)
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["scaling"] == "weak"
+    nsp = line["north_star_path"]
+    assert nsp["ranks_seen"] == 2
+    assert nsp["weights_allgather"]["fp32"]["collective_us"] > 0
+    assert nsp["c5"]["collective_us"] > 0 and nsp["c5"]["gelem_s"] > 0
+    assert nsp["resnet18_weights_one_allgather"]["tensors"] == 21
+    assert "cpu_baseline" not in line and "extras" not in line          # rank 0 at N = 1 only
+
+
+@pytest.mark.gpu
+def test_single_gpu_line_carries_roofline_cpu_baseline_and_model_configs():
+    """N = 1 as the driver runs it (fewer steps): the contract's keys, `roofline`, `cpu_baseline` (the C port + the
+    reference-equivalent eager chain), and BASELINE configs 3 / 4 under `extras`."""
+    r = _run(["--gpus", "1", "--steps", "20", "--warmup", "5", "--no-north-star-path"], 1500)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
+    line = _line(r.stdout)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["n_gpus"] == 1 and line["steps"] == 20 and line["ranks_seen"] == 1
+    rf = line["roofline"]
+    assert rf["bound"] == "hbm" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["frac"] > 0.5
+    cb = line["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["gpu_output_bit_exact_on_sample"] is True
+    assert cb["reference_equivalent"]["kind"] == "reference-equivalent" and cb["reference_equivalent"]["value"] > 0
+    ex = line["extras"]
+    c3, c4 = ex["c3_resnet18_b64"], ex["c4_mobilenetv2_b64"]
+    v3 = c3["validation_forward"]
+    # the reference's launch pattern: 21 weight + 30 activation quantizer calls, 218.9 M elements
+    assert v3["reference_pattern"]["launches"] == 51
+    assert abs(v3["reference_pattern"]["elements"] - 218.9e6) / 218.9e6 < 0.01
+    assert abs(v3["reference_pattern"]["algorithmic_gb"] - 1.751) < 0.02
+    assert v3["default"]["launches"] < v3["cache0_fused"]["launches"] <= 51
+    assert c3["calibration_batch"]["launches"] >= 51
+    v4 = c4["validation_forward"]
+    assert v4["reference_pattern"]["launches"] == 117
+    assert abs(v4["reference_pattern"]["elements"] - 444.9e6) / 444.9e6 < 0.01
+    for key, n_m in (("calibration_batch_fixed_mantissa", 1), ("calibration_batch_mantissa_search_6", 6)):
+        cal = c4[key]
+        assert cal["by_entry"]["mse_grid"]["calls"] == 117 and cal["k4_t_cand_elem_s"] > 0, key
+    assert c4["calibration_batch_mantissa_search_6"]["library_us"] > c4["calibration_batch_fixed_mantissa"]["library_us"]

@@ -17,12 +17,19 @@ class OracleOps:
     """fp8q.ops look-alike on CPU tensors, for the gloo tests only."""
 
     @staticmethod
-    def minmax(x, per_channel, cur_min=None, cur_max=None, mode=0, momentum=0.9, want_maxval=False):
-        mn, mx = oracle.c_minmax(x.numpy(), per_channel)
-        if cur_min is not None:
-            mn, mx = oracle.c_fold(cur_min.numpy(), cur_max.numpy(), mn, mx, mode, momentum)
-        out = (torch.from_numpy(mn), torch.from_numpy(mx))
-        return out + (torch.from_numpy(oracle.c_absmax(mn, mx)),) if want_maxval else out
+    def minmax(x, per_channel, cur_min=None, cur_max=None, mode=0, momentum=0.9, want_maxval=False, packed=None):
+        import oracle_ops
+        return oracle_ops.minmax(x, per_channel, cur_min, cur_max, mode, momentum, want_maxval, packed)
+
+    @staticmethod
+    def new_packed(C, device):
+        import oracle_ops
+        return oracle_ops.new_packed(C, device)
+
+    @staticmethod
+    def ranges_unpack(packed, cur_min=None, cur_max=None, maxval=None):
+        import oracle_ops
+        return oracle_ops.ranges_unpack(packed, cur_min, cur_max, maxval)
 
     @staticmethod
     def quantize(x, maxval, mbits, n_bits=8, sign_bits=1, out=None):
@@ -403,3 +410,98 @@ def test_data_parallel_mse_calibration():
             np.testing.assert_allclose(ranges[name][2], ref_ranges[name][2], rtol=1e-6, err_msg=name)
         for step, (o, r) in enumerate(zip(outs, ref_outs)):
             np.testing.assert_allclose(o, r[rank::2], rtol=1e-5, atol=1e-6, err_msg=f"step {step}")
+
+
+# ---- world size 4: uneven channel partitions, a rank without channels, 4-way batch shards -------------------------
+
+def _w4_job(rank, world):
+    from fp8q import dist as fd
+    w = torch.from_numpy(_weights())                     # 13 channels over 4 ranks: 4 + 3 + 3 + 3
+    q, mv = fd.quantize_weight_sharded(w, 2, 8, 1, ops=OracleOps)
+    w3 = torch.from_numpy(_weights()[:3].copy())         # 3 channels over 4 ranks: rank 3 owns nothing
+    q3, mv3 = fd.quantize_weight_sharded(w3, 3, 8, 1, ops=OracleOps)
+    qc, mvc, codes = fd.quantize_weight_sharded_codes(w3, 3, 8, 1, ops=OracleOps)
+    buck = fd.quantize_weights_sharded_bucketed([torch.from_numpy(t) for t in _bucket_weights()], 2, 8, 1, ops=OracleOps,
+                                                bucket_bytes=600)
+    return (q.numpy(), mv.numpy(), q3.numpy(), mv3.numpy(), qc.numpy(), mvc.numpy(), codes.numpy(),
+            [(a.numpy(), b.numpy()) for a, b in buck])
+
+
+def _assert_same_quant(got, ref):
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    assert np.array_equal(np.nan_to_num(got).view(np.int32), np.nan_to_num(ref).view(np.int32))
+
+
+def test_four_ranks_uneven_partitions_and_empty_rank():
+    from fp8q.dist import channel_partition
+    assert channel_partition(13, 4) == [(0, 4), (4, 7), (7, 10), (10, 13)]
+    assert channel_partition(3, 4) == [(0, 1), (1, 2), (2, 3), (3, 3)]
+    w = _weights()
+    mn, mx = oracle.c_minmax(w, True)
+    mv = oracle.c_absmax(mn, mx)
+    ref = oracle.c_quantize(w, mv, 2, 8, 1)
+    w3 = w[:3]
+    mv3 = oracle.c_absmax(*oracle.c_minmax(w3, True))
+    ref3 = oracle.c_quantize(w3, mv3, 3, 8, 1)
+    res = run(_w4_job, world=4)
+    assert len(res) == 4
+    for q, m, q3, m3, qc, mc, codes, buck in res:
+        _assert_same_quant(q, ref)
+        np.testing.assert_array_equal(m, mv)
+        _assert_same_quant(q3, ref3)
+        np.testing.assert_array_equal(m3, mv3)
+        _assert_same_quant(qc, ref3)
+        np.testing.assert_array_equal(mc, mv3)
+        np.testing.assert_array_equal(codes, oracle.c_encode(w3, mv3, 3, 8, 1))
+        for wb, (qb, mvb) in zip(_bucket_weights(), buck):
+            rmv = oracle.c_absmax(*oracle.c_minmax(wb, True))
+            np.testing.assert_array_equal(mvb, rmv)
+            _assert_same_quant(qb, oracle.c_quantize(wb, rmv, 2, 8, 1))
+
+
+def _c5_job4(rank, world):
+    from fp8q import dist as fd
+    state, outs = None, []
+    for i, b in enumerate(_batches()):
+        x = torch.from_numpy(b[rank:rank + 1].copy())               # 4 images, one per rank
+        if i == 2 and rank == 3:
+            x = x.clone()
+            x[0, 0, 0, 0] = float("nan")                            # a NaN on ONE rank must reach every rank
+        y, state = fd.calibrate_quantize_sharded(x, 3, 8, 1, state=state, ops=OracleOps)
+        outs.append(y.numpy())
+    return outs, state[0].numpy(), state[1].numpy()
+
+
+def test_four_rank_batch_sharded_calibration_packed_exchange():
+    """Config 5's flow on 4 ranks through the packed exchange (kernel-written {-min, max, nan flags} -> ONE
+    all-reduce(MAX) -> unpack): ranges and quantized shards equal the single-process run; a NaN seen by one rank
+    makes the running range NaN everywhere from that batch on (torch.min / torch.max semantics)."""
+    res = run(_c5_job4, world=4)
+    cur = None
+    for i, b in enumerate(_batches()):
+        b = b.copy()
+        if i == 2:
+            b[3, 0, 0, 0] = np.nan
+        mn, mx = oracle.c_minmax(b, False)
+        cur = (mn, mx) if cur is None else oracle.c_fold(cur[0], cur[1], mn, mx, 1)
+        mv = oracle.c_absmax(*cur)
+        ref = oracle.c_quantize(b, mv, 3, 8, 1)
+        got = np.concatenate([res[r][0][i] for r in range(4)])
+        _assert_same_quant(got, ref)
+    assert np.isnan(cur[0]).all() and np.isnan(cur[1]).all()
+    for r in range(4):
+        assert np.isnan(res[r][1]).all() and np.isnan(res[r][2]).all()
+
+
+def test_pack_unpack_ranges_roundtrip():
+    """the stand-in's packed format (what fold_store writes on the device; the -m gpu tests compare the two)"""
+    import oracle_ops
+    mn = np.array([-1.5, np.nan, 0.0, -0.0, 3.0], np.float32)
+    mx = np.array([2.0, 4.0, np.nan, 0.0, 7.0], np.float32)
+    p = oracle_ops.new_packed(5, "cpu")
+    oracle_ops.pack_ranges(mn, mx, p)
+    assert np.isfinite(p.numpy()[:, :2]).sum() == 8 and not np.isnan(p.numpy()).any()
+    a, b, mv = oracle_ops.ranges_unpack(p)
+    np.testing.assert_array_equal(a.numpy(), mn)
+    np.testing.assert_array_equal(b.numpy(), mx)
+    np.testing.assert_array_equal(mv.numpy(), oracle.c_absmax(mn, mx))

@@ -287,17 +287,42 @@ def test_requantize_weights_uses_the_plan(golden_dir):
         for m in q.modules():
             if isinstance(m, QuantizedModule):
                 m.fix_ranges()
+        import copy
+        from quantization.model import _PLANS
         assert prequantize_weights(q) == 4
-        plan = q._wq_plan[0]
+        plan = _PLANS[q][0]
         layers = [m for m in q.modules() if isinstance(m, QuantizationHijacker)]
         for m in layers:
             m.weight.mul_(0.9)                       # in place: same storage, new contents
-        assert requantize_weights(q) == 4 and q._wq_plan[0] is plan
+        assert requantize_weights(q) == 4 and _PLANS[q][0] is plan
         for m in layers:
             assert m.get_params()[0] is m._wq_cache
             assert torch.equal(m._wq_cache, m.weight_quantizer(m.weight))
         layers[0].weight.data = layers[0].weight.data.clone()     # storage replaced: the plan is rebuilt
-        assert requantize_weights(q) == 4 and q._wq_plan[0] is not plan
+        assert requantize_weights(q) == 4 and _PLANS[q][0] is not plan
+        # the plan bakes the format in by value: a new mantissa width (same maxval storage) must not be served from it
+        plan = _PLANS[q][0]
+        wq = layers[1].weight_quantizer.quantizer
+        wq.mantissa_bits = torch.tensor(3.0)
+        assert requantize_weights(q) == 4 and _PLANS[q][0] is not plan
+        for m in layers:
+            assert torch.equal(m._wq_cache, m.weight_quantizer(m.weight))
+        want = oracle.c_quantize(layers[1].weight.detach().cpu().numpy(), wq.maxval.cpu().numpy().reshape(-1), 3, 8, 1)
+        assert np.array_equal(layers[1]._wq_cache.cpu().numpy().view(np.int32), want.view(np.int32))
+        # a layer that left fix_ranges is no longer eligible: the rebuilt plan covers the remaining three
+        layers[2].weight_quantizer.estimate_ranges()
+        assert requantize_weights(q) == 3
+        layers[2].weight_quantizer.fix_ranges()
+        assert requantize_weights(q) == 4
+        # the plan (a native handle) lives in a side table: models copy and pickle as in the reference's workflows
+        q2 = copy.deepcopy(q)
+        assert q2 not in _PLANS and q in _PLANS
+        import io
+        buf = io.BytesIO()
+        torch.save(q, buf)
+        x = dev(g7["calib"])
+        assert torch.equal(q2(x), q(x))
+        assert requantize_weights(q2) == 4 and q2 in _PLANS and _PLANS[q2][0] is not _PLANS[q][0]
 
 
 def test_kernel_sequence_of_the_model_flow(golden_dir, monkeypatch):
