@@ -418,7 +418,7 @@ def model_configs(ops, dev, only=None):
                     r["forward_ms"] = _wall_ms(lambda: m(x))
                     r["env"] = f"FP8Q_CACHE_WEIGHTS={cache} FP8Q_FUSE_EPILOGUE={fuse}"
                     # the reference's quantizer work for this forward, done in the time this library's launches took
-                    r["reference_work_gb_s"] = round(ref_gb * 1e3 / max(r["library_us"], 1e-3), 1)
+                    r["reference_work_gb_s"] = round(ref_gb * 1e6 / max(r["library_us"], 1e-3), 1)
                     res[name] = r
                 finally:
                     os.environ.pop("FP8Q_CACHE_WEIGHTS", None)

@@ -698,11 +698,7 @@ __device__ __forceinline__ MinMax stage_row_range(const float *wr, bool valid, i
     return m;
 }
 
-// DEFER (experiment, off by default): a chunk's quantized groups stay in registers across the end-of-iteration barrier and
-// are stored AFTER the next chunk has been parked, so that the vmcnt(0) in front of a park never covers stores that were
-// just issued (gfx950 counts loads and stores in one counter; with both kinds pending the compiler can only wait to zero).
-// Measured on [2^21,147]: 513 us against 500 us without -- the store acknowledgements are not what the kernel waits for.
-template <bool NT, bool DEFER>
+template <bool NT>
 __global__ void __launch_bounds__(kBlock, 4)
 k_rows_staged(const float *__restrict__ x, float *__restrict__ y, float *row_min, float *row_max,
               float *maxval_out, QFmt f, FlatArgs a)
@@ -729,20 +725,11 @@ k_rows_staged(const float *__restrict__ x, float *__restrict__ y, float *row_min
     float bh = 0.0f, bt = 0.0f;
     stage_load_body<NT>(x, c, a, v);   // prologue: the first chunk's loads
     stage_load_borders(x, c, cur, bh, bt);
-    vf4 res[U];                 // DEFER: the previous chunk's results
-    int64_t res_elo = -1;
-    int res_ng = 0;
     for (;;) {
         const int64_t elo = c * kChunkElems;
         const int phase = cur.phase, nrows = cur.nrows, len = cur.len;
         const int ng = len >> 2;
         stage_park(win, cur, v, bh, bt);
-        if (DEFER && res_elo >= 0) {
-            vf4 *yp = reinterpret_cast<vf4 *>(y + res_elo);
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (tid + u * kBlock < res_ng) st16<NT>(yp + tid + u * kBlock, res[u]);
-        }
         const int64_t cn = c + G;
         const bool more = cn < a.nchunks;
         ChunkInfo nxt = cur;
@@ -795,16 +782,13 @@ k_rows_staged(const float *__restrict__ x, float *__restrict__ y, float *row_min
         {
             vf4 *yv = reinterpret_cast<vf4 *>(y + elo);
             vf4 w[U];
-            if (!DEFER) {
 #pragma unroll
-                for (int u = 0; u < U; ++u)
-                    if (tid + u * kBlock < ng) w[u] = *reinterpret_cast<const vf4 *>(win + kStagePad + 4 * (tid + u * kBlock));
-            }
+            for (int u = 0; u < U; ++u)
+                if (tid + u * kBlock < ng) w[u] = *reinterpret_cast<const vf4 *>(win + kStagePad + 4 * (tid + u * kBlock));
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int q = tid + u * kBlock;
                 if (q >= ng) break;
-                if (DEFER) w[u] = *reinterpret_cast<const vf4 *>(win + kStagePad + 4 * q);   // just in time: results pile up in res[]
                 const int o = phase + 4 * q;
                 const int lrow = div_small((uint32_t)o, a.magic);
                 const int b = inner - (o - lrow * inner);   // elements left in this row (>= 1)
@@ -816,11 +800,8 @@ k_rows_staged(const float *__restrict__ x, float *__restrict__ y, float *row_min
                     if (b < 3) e[2] = b == 2 ? pt.x : pt.y;
                     if (b < 2) e[1] = pt.x;
                 }
-                if (DEFER && more) res[u] = vf4{e[0], e[1], e[2], e[3]};
-                else st16<NT>(yv + q, vf4{e[0], e[1], e[2], e[3]});
+                st16<NT>(yv + q, vf4{e[0], e[1], e[2], e[3]});
             }
-            res_elo = elo;
-            res_ng = ng;
         }
         if (!more) break;
         __syncthreads();   // the window and the tables are rewritten by the next chunk
@@ -830,69 +811,60 @@ k_rows_staged(const float *__restrict__ x, float *__restrict__ y, float *row_min
 }
 
 // ---------------------------------------------------------------------------------------------
-// Short rows, fused, WAVE-LOCAL: k_rows_wave.  The same single-fetch idea as k_rows_staged, without a single block-level
-// barrier in the data path: every WAVE owns one aligned piece of 1024 elements (4 KiB; a block's four waves = one aligned
-// 16 KiB chunk, neighbouring blocks neighbouring chunks: the access pattern of the copy), keeps its 4 x 16 B per lane in
-// registers, and parks a copy -- plus the head of the first and the tail of the last overlapping row, fetched as one extra
-// 16-byte load per lane on either side (the neighbouring waves' data: L2 hits) -- in a wave-private LDS window.  Row
-// ranges (Gl lanes per row, DPP butterflies), channel constants, tables and head patches are then built by the wave for
-// itself, ordered by wave-level fences only, and the wave quantizes its own registers and stores.  Rows cut by a piece
-// border are evaluated by both neighbours (each has the whole row in its window): same range, same table.
-// k_rows_staged spends 3 block barriers per 16 KiB on the same work; here a wave never waits for another wave.
-// EXPERIMENT, off by default (FP8Q_WAVE=1): bit-exact on every geometry of tools/mb_staged.py, but SLOWER than
-// k_rows_staged on [2^21,147]: 570 us with one piece per wave, 625-635 us persistent with a register prefetch (128 VGPRs,
-// spills), against 482-494 us -- rows cut by the 4 KiB piece borders are evaluated twice (8 rows per piece instead of
-// 7.0), the borders cost two more load instructions per piece, and the block barriers it removes were not what
-// k_rows_staged waits for.  Kept as the A/B partner that shows it.
-// Dynamic LDS per wave: float win[kWavePad | 1024 | kWavePad + 4] | float4 patch[rpc] | float4 chanlite[rpc] | float2 lut[rpc * stride]
+// Short rows, fused, ONE WAVE PER CHUNK: k_rows_solo.  What k_rows_staged's counters said (profiles/r02_staged_valu_lds_pmc.json:
+// 736 VALU wave-instructions per wave and 16 KiB chunk, 75 % of all SIMD cycles busy): the kernel is bound by its
+// instruction count, and 325 of the 736 are the per-row phase -- range, channel constants, table, head patch --
+// which all FOUR waves of a block execute, each for its 8 of the chunk's ~28 rows with 8 lanes per row in lockstep
+// (a wave-instruction costs the same with 8 or with 64 distinct results).  Here a 64-thread block = one wave owns the
+// whole aligned 16 KiB chunk: the ~28 rows sit in ONE wave with 2 lanes per row, so the double-precision channel
+// constants are evaluated once per chunk instead of four times, the row ranges are read from the window as aligned
+// 16-byte groups (ds_read_b128: 2 min3 + 2 max3 + 2 unordered compares per group, no per-element addressing; only a
+// row's first and last group are masked), and there is no block-level barrier at all -- every hand-over is between
+// lanes of the same wave.  The quantize pass is k_rows_staged's: the lane's own 16-byte groups back from the window,
+// per-row {s, 1/s} tables in LDS, head patches for the groups that straddle a row boundary, aligned nontemporal 16-byte
+// stores.  Global traffic: every element fetched once, plus one 16-byte group per lane on either side for the
+// neighbouring chunks' share of the first and the last row (L2 hits: the neighbouring blocks stream them).
+// The next chunk's loads are issued right after the park and fly during the whole body (17 KiB in flight per wave).
+// LDS: float win[kStagePad | 4096 | kStagePad] | float4 patch[rpc] | float4 chanlite[rpc] | float2 lut[rpc * stride]
+// = 27.0 KiB for 147-element rows in E5M2: 5 blocks (waves) per CU.
 // ---------------------------------------------------------------------------------------------
-constexpr int kWavePiece = 1024, kWavePad = 256, kWaveWin = kWavePad + kWavePiece + kWavePad + 4;
-
-struct WaveArgs {
-    int inner, rpc, lut_stride, group;   // rpc: table rows per piece; group: log2(lanes per row)
-    int tail;                            // n - 4 * nvec
-    int wave_bytes;                      // LDS bytes per wave (multiple of 16)
-    uint32_t magic;                      // o / inner
-    int pad0;
-    int64_t nvec, npieces;
-};
-
-struct WaveGeo {
-    int64_t e0, row_lo;
-    int len, tail, phase, nrows, after, ng, nbg, nag;
-};
-
-__device__ __forceinline__ WaveGeo wave_geometry(int64_t piece, const WaveArgs &a)
+__device__ __forceinline__ void wave_sync()
 {
-    WaveGeo g;
-    const int64_t nbody = a.nvec * 4;
-    g.e0 = piece * kWavePiece;
-    g.len = (int)(nbody - g.e0 < kWavePiece ? nbody - g.e0 : kWavePiece);   // multiple of 4 (0 only for a tail-only piece)
-    g.tail = piece == a.npieces - 1 ? a.tail : 0;
-    g.row_lo = div_rows(g.e0, a.inner);
-    g.phase = (int)(g.e0 - g.row_lo * a.inner);
-    g.nrows = div_small((uint32_t)(g.phase + g.len + g.tail - 1), a.magic) + 1;
-    g.after = g.nrows * a.inner - g.phase - g.len;   // elements of the last row behind the body (tail scalars included)
-    g.ng = g.len >> 2;
-    g.nbg = (g.phase + 3) >> 2;                      // groups in front of the piece that hold the first row's head
-    g.nag = (g.after + 3) >> 2;
-    return g;
+    // LDS hand-over between lanes of ONE wave: DS operations of a wave complete in order; the fences keep the
+    // compiler from moving LDS accesses across this point
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// a piece's loads: 4 x 16 B per lane of the body, one 16-B group per lane of either border (the last <= 3 elements of the
-// tensor, which are not a whole group, come as scalars)
-template <bool NT>
-__device__ __forceinline__ void wave_load(const float *x, const WaveGeo &g, const WaveArgs &a, int lane, vf4 (&v)[4], vf4 &vb,
-                                          vf4 &va)
+// hand-over between all lanes of the block: W == 1 (one wave) needs no hardware barrier
+template <int W>
+__device__ __forceinline__ void solo_sync()
 {
+    if (W == 1) wave_sync();
+    else __syncthreads();
+}
+
+// a chunk's loads: 1024 / T x 16 B per lane of the body + border pieces as whole 16-byte groups (head of the first,
+// tail of the last overlapping row: <= 64 groups each, lanes 0..63); the tensor's last <= 3 elements, which are not a
+// whole group, come as scalars
+template <bool NT, int W>
+__device__ __forceinline__ void solo_load(const float *x, int64_t c, const ChunkInfo &ci, const FlatArgs &a, int tid,
+                                          vf4 (&v)[kChunkGroups / (64 * W)], vf4 &vb, vf4 &va)
+{
+    constexpr int T = 64 * W, U = kChunkGroups / T;
+    const int64_t elo = c * kChunkElems;
+    const int ng = ci.len >> 2;
+    const vf4 *xv = reinterpret_cast<const vf4 *>(x + elo);
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
-        if (u * 64 + lane < g.ng) v[u] = ld16<NT>(reinterpret_cast<const vf4 *>(x + g.e0) + u * 64 + lane);
-    if (lane < g.nbg) vb = ld16<false>(reinterpret_cast<const vf4 *>(x + g.e0) - 1 - lane);
-    if (lane < g.nag) {
-        const int64_t nbody = a.nvec * 4, o = g.e0 + g.len + 4 * (int64_t)lane;
+    for (int u = 0; u < U; ++u)
+        if (u * T + tid < ng) v[u] = ld16<NT>(xv + u * T + tid);
+    if (tid < ((ci.phase + 3) >> 2)) vb = ld16<NT>(xv - 1 - tid);
+    const int after = ci.pad[0];
+    if (tid < ((after + 3) >> 2)) {
+        const int64_t nbody = a.nvec * 4, o = elo + ci.len + 4 * (int64_t)tid;
         if (o + 4 <= nbody) {
-            va = ld16<false>(reinterpret_cast<const vf4 *>(x + o));
+            va = ld16<NT>(reinterpret_cast<const vf4 *>(x + o));
         } else {
             const int64_t n = nbody + a.tail;
             va = vf4{o < n ? x[o] : 0.0f, o + 1 < n ? x[o + 1] : 0.0f, o + 2 < n ? x[o + 2] : 0.0f, 0.0f};
@@ -900,58 +872,105 @@ __device__ __forceinline__ void wave_load(const float *x, const WaveGeo &g, cons
     }
 }
 
-template <bool NT>
-__global__ void __launch_bounds__(kBlock, 4)
-k_rows_wave(const float *__restrict__ x, float *__restrict__ y, float *row_min, float *row_max, float *maxval_out,
-            QFmt f, WaveArgs a)
+// min / max / NaN of the row that starts at window index w (inner elements) over Gl = 2^gs (<= 8) adjacent lanes,
+// read as aligned 16-byte groups, four per trip (one LDS round trip per four groups); every lane of the row gets the
+// result.  Elements of a group outside [w, w + inner) (the neighbouring rows' share of the row's first and last group)
+// are replaced by the row's own first element; a lane that runs out of groups re-reads the row's last one.
+__device__ __forceinline__ MinMax solo_row_range(const float *win, int w, int inner, bool valid, int sub, int gs)
 {
+    MinMax m;
+    mm_init(m);
+    if (valid) {
+        const int Gl = 1 << gs, gB = (w + inner - 1) >> 2;
+        const float first = win[w];
+        const vf4 *w4 = reinterpret_cast<const vf4 *>(win);
+        for (int g0 = (w >> 2) + sub; g0 <= gB; g0 += 4 * Gl) {
+            int g[4];
+            vf4 t[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                g[j] = min(g0 + j * Gl, gB);
+                t[j] = w4[g[j]];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int lo = w - 4 * g[j], hi = lo + inner;   // elements k of the group with lo <= k < hi belong to the row
+                if (lo > 0 || hi < 4) {
+                    if (0 < lo || 0 >= hi) t[j].x = first;
+                    if (1 < lo || 1 >= hi) t[j].y = first;
+                    if (2 < lo || 2 >= hi) t[j].z = first;
+                    if (3 < lo || 3 >= hi) t[j].w = first;
+                }
+                mm_acc(m, t[j].x);
+                mm_acc(m, t[j].y);
+                mm_acc(m, t[j].z);
+                mm_acc(m, t[j].w);
+            }
+        }
+    }
+    if (gs >= 1) mm_dpp<0xB1>(m);    // quad_perm [1,0,3,2]
+    if (gs >= 2) mm_dpp<0x4E>(m);    // quad_perm [2,3,0,1]
+    if (gs >= 3) mm_dpp<0x141>(m);   // row_half_mirror
+    if (m.nan) m.mn = m.mx = __builtin_nanf("");
+    return m;
+}
+
+// W = waves per block sharing the chunk (1, 2 or 4); a.group = log2(lanes per row): the launcher takes as many lanes per
+// row as hold all rows of a chunk in one pass of the block's 64 * W lanes (2 / 4 / 8 for 147-element rows).
+template <bool NT, int W>
+__global__ void __launch_bounds__(64 * W, W == 4 ? 4 : (W == 2 ? 3 : 2))   // LDS admits 5 blocks per CU: 168 / 256 VGPRs for W = 2 / 1
+k_rows_solo(const float *__restrict__ x, float *__restrict__ y, float *row_min, float *row_max, float *maxval_out,
+            QFmt f, FlatArgs a)
+{
+    constexpr int T = 64 * W, U = kChunkGroups / T;
+    constexpr bool BATCHQ = W < 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ double ftab[kFastTabSize];
-    for (int i = threadIdx.x; i < kFastTabSize; i += kBlock) ftab[i] = kFastTab[i];
-    __syncthreads();   // the only block-level barrier: the log2 / exp2 tables
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int64_t piece = (int64_t)blockIdx.x * 4 + wave;
-    const int64_t stride = (int64_t)gridDim.x * 4;
-    if (piece >= a.npieces) return;
-    float *win = reinterpret_cast<float *>(smem + (size_t)wave * a.wave_bytes);
-    float4 *patch = reinterpret_cast<float4 *>(win + kWaveWin);
+    __shared__ double ftab[kFastTabSize];   // log2 / exp2 tables of the channel constants: through L1 they cost a global
+                                            // round trip per chunk on every wave's critical path (measured: 2x slower)
+    for (int i = threadIdx.x; i < kFastTabSize; i += T) ftab[i] = kFastTab[i];
+    float *win = reinterpret_cast<float *>(smem);
+    float4 *patch = reinterpret_cast<float4 *>(win + kStageWin);
     float4 *chl = patch + a.rpc;
     float2 *lut = reinterpret_cast<float2 *>(chl + a.rpc);
+    const int tid = threadIdx.x;
     const int inner = a.inner;
+    const int64_t G = gridDim.x;
     const float pmaxf = (float)f.pmax;
-    WaveGeo g = wave_geometry(piece, a);
-    vf4 v[4], vb = {0.0f, 0.0f, 0.0f, 0.0f}, va = {0.0f, 0.0f, 0.0f, 0.0f};
-    wave_load<NT>(x, g, a, lane, v, vb, va);   // prologue: the first piece's loads
+
+    int64_t c = blockIdx.x;   // gridDim.x <= nchunks
+    const uint32_t adv = (uint32_t)G * (uint32_t)kChunkElems;
+    const bool inc_ok = (uint64_t)(G * kChunkElems + 256) * (uint64_t)inner < (1ull << 32);
+    ChunkInfo cur = stage_geometry(c, a);
+    vf4 v[U], vb = {0.0f, 0.0f, 0.0f, 0.0f}, va = {0.0f, 0.0f, 0.0f, 0.0f};
+    solo_load<NT, W>(x, c, cur, a, tid, v, vb, va);   // prologue: the first chunk's loads
     for (;;) {
+        const int64_t elo = c * kChunkElems;
+        const int phase = cur.phase, nrows = cur.nrows, len = cur.len;
+        const int ng = len >> 2;
         // ---- park (waits for the loads issued one iteration ago) ----
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (u * 64 + lane < g.ng) *reinterpret_cast<vf4 *>(win + kWavePad + 4 * (u * 64 + lane)) = v[u];
-        if (lane < g.nbg) *reinterpret_cast<vf4 *>(win + kWavePad - 4 * (lane + 1)) = vb;
-        if (lane < g.nag) *reinterpret_cast<vf4 *>(win + kWavePad + g.len + 4 * lane) = va;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const int64_t next = piece + stride;
-        const bool more = next < a.npieces;
-        WaveGeo gn = g;
-        if (more) {   // the next piece: in flight during everything below
-            gn = wave_geometry(next, a);
-            wave_load<NT>(x, gn, a, lane, v, vb, va);
-        }
-        const int phase = g.phase, nrows = g.nrows, len = g.len;
+        for (int u = 0; u < U; ++u)
+            if (u * T + tid < ng) *reinterpret_cast<vf4 *>(win + kStagePad + 4 * (u * T + tid)) = v[u];
+        if (tid < ((phase + 3) >> 2)) *reinterpret_cast<vf4 *>(win + kStagePad - 4 * (tid + 1)) = vb;
+        if (tid < ((cur.pad[0] + 3) >> 2)) *reinterpret_cast<vf4 *>(win + kStagePad + len + 4 * tid) = va;
+        const int64_t cn = c + G;
+        const bool more = cn < a.nchunks;
+        ChunkInfo nxt = cur;
+        if (more) nxt = inc_ok ? stage_geometry_next(cur, cn, adv, a) : stage_geometry(cn, a);
+        solo_sync<W>();
+        if (more) solo_load<NT, W>(x, cn, nxt, a, tid, v, vb, va);   // the next chunk: in flight during everything below
         // ---- per row, Gl lanes: range from the window -> channel constants -> table -> the row's head patch ----
         {
-            const int gs = a.group, Gl = 1 << gs, rpp = 64 >> gs, sub = lane & (Gl - 1), rs = lane >> gs;
-            const float *w0 = win + (kWavePad - phase);
+            const int gs = a.group, Gl = 1 << gs, rpp = T >> gs, sub = tid & (Gl - 1), rs = tid >> gs;
             for (int rb = 0; rb < nrows; rb += rpp) {
                 const int r = rb + rs;
                 const bool valid = r < nrows;
-                const MinMax m = stage_row_range(w0 + r * inner, valid, inner, sub, gs);   // in every lane of the row
+                if (W > 1 && rb + ((tid & ~63) >> gs) >= nrows) continue;   // no row for this whole wave in this pass
+                const MinMax m = solo_row_range(win, kStagePad - phase + r * inner, inner, valid, sub, gs);
                 if (valid) {
                     const float mv = fabsf(tmax(fabsf(m.mn), m.mx));   // fp8_quantizer.py:236
-                    if (sub == 0 && (r > 0 || phase == 0)) {   // the row starts in this piece: this wave reports it
-                        const int64_t grow = g.row_lo + r;
+                    if (sub == 0 && (r > 0 || phase == 0)) {   // the row starts in this chunk: this block reports it
+                        const int64_t grow = cur.row_lo + r;
                         if (row_min) row_min[grow] = m.mn;
                         if (row_max) row_max[grow] = m.mx;
                         if (maxval_out) maxval_out[grow] = mv;
@@ -960,54 +979,63 @@ k_rows_wave(const float *__restrict__ x, float *__restrict__ y, float *row_min, 
                     if (sub == 0) chl[r] = make_float4(ch.maxv, ch.minv, ch.bias, ch.pthr);
                     lut_part(lut + r * a.lut_stride, ch, f, sub, Gl);
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                wave_sync();   // a row's lanes are in one wave: the table they wrote is theirs to read
                 if (valid) {
-                    const int idx = r * inner - phase;   // piece-local index of the row's first element
+                    const int idx = r * inner - phase;   // chunk-local index of the row's first element
                     if (idx > 0 && idx < len && (idx & 3)) {   // it shares a 16-byte group with the previous row
                         const ChanLite cl = lite_of(chl[r]);
                         for (int k = sub; k < 4 - (idx & 3); k += Gl)
                             reinterpret_cast<float *>(patch)[4 * r + k] =
-                                quant_one(win[kWavePad + idx + k], cl, lut + r * a.lut_stride, pmaxf, f.qthr);
+                                quant_one(win[kStagePad + idx + k], cl, lut + r * a.lut_stride, pmaxf, f.qthr);
                     }
                 }
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (lane < g.tail) {   // the tensor's last <= 3 elements
-            const int e = len + lane;
+        solo_sync<W>();
+        if (tid < cur.tail) {   // the tensor's last <= 3 elements
+            const int e = len + tid;
             const int r = div_small((uint32_t)(phase + e), a.magic);
-            y[g.e0 + e] = quant_one(win[kWavePad + e], lite_of(chl[r]), lut + r * a.lut_stride, pmaxf, f.qthr);
+            y[elo + e] = quant_one(win[kStagePad + e], lite_of(chl[r]), lut + r * a.lut_stride, pmaxf, f.qthr);
         }
-        vf4 *yv = reinterpret_cast<vf4 *>(y + g.e0);
+        {
+            vf4 *yv = reinterpret_cast<vf4 *>(y + elo);
+            constexpr int B = W == 4 ? 2 : 4;   // groups per trip: window groups and channel constants read together
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int q = u * 64 + lane;
-            if (q >= g.ng) break;
-            const vf4 w = *reinterpret_cast<const vf4 *>(win + kWavePad + 4 * q);   // own group back from the window
-            const int o = phase + 4 * q;
-            const int lrow = div_small((uint32_t)o, a.magic);
-            const int b = inner - (o - lrow * inner);   // elements left in this row (>= 1)
-            float e[4] = {w.x, w.y, w.z, w.w};
-            quant_group<4>(e, lite_of(chl[lrow]), lut + lrow * a.lut_stride, pmaxf, f.qthr);
-            if (b < 4) {   // e[b..3] belong to the next row: its head patch
-                const float4 pt = patch[lrow + 1];
-                e[3] = b == 3 ? pt.x : (b == 2 ? pt.y : pt.z);
-                if (b < 3) e[2] = b == 2 ? pt.x : pt.y;
-                if (b < 2) e[1] = pt.x;
+            for (int u0 = 0; u0 < U; u0 += B) {
+                vf4 w[B];
+                float4 cl[B];
+                int lrow[B], left[B];
+#pragma unroll
+                for (int j = 0; j < B; ++j) {
+                    const int q = min((u0 + j) * T + tid, ng - 1);   // (lanes beyond the body re-read its last group)
+                    w[j] = *reinterpret_cast<const vf4 *>(win + kStagePad + 4 * q);   // own group back from the window
+                    const int o = phase + 4 * q;
+                    lrow[j] = div_small((uint32_t)o, a.magic);
+                    left[j] = inner - (o - lrow[j] * inner);   // elements left in this row (>= 1)
+                    cl[j] = chl[lrow[j]];
+                }
+#pragma unroll
+                for (int j = 0; j < B; ++j) {
+                    const int q = (u0 + j) * T + tid;
+                    if (q >= ng) continue;
+                    float e[4] = {w[j].x, w[j].y, w[j].z, w[j].w};
+                    if (BATCHQ) quant_group_batched<4, false>(e, lite_of(cl[j]), lut + lrow[j] * a.lut_stride, pmaxf, f.qthr);
+                    else quant_group<4, false>(e, lite_of(cl[j]), lut + lrow[j] * a.lut_stride, pmaxf, f.qthr);   // fused: NaN rows are all-exact
+                    const int b = left[j];
+                    if (b < 4) {   // e[b..3] belong to the next row: its head patch
+                        const float4 pt = patch[lrow[j] + 1];
+                        e[3] = b == 3 ? pt.x : (b == 2 ? pt.y : pt.z);
+                        if (b < 3) e[2] = b == 2 ? pt.x : pt.y;
+                        if (b < 2) e[1] = pt.x;
+                    }
+                    st16<NT>(yv + q, vf4{e[0], e[1], e[2], e[3]});
+                }
             }
-            st16<NT>(yv + q, vf4{e[0], e[1], e[2], e[3]});
         }
         if (!more) break;
-        // the window and the tables are rewritten by the next piece: every lane is done reading them
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        piece = next;
-        g = gn;
+        solo_sync<W>();   // the window and the tables are rewritten by the next chunk
+        c = cn;
+        cur = nxt;
     }
 }
 
@@ -1466,39 +1494,40 @@ int launch_rows_flat(int mode, const float *x, float *y, int64_t C, int64_t inne
             const int v = e ? atoi(e) : -1;
             return v >= 0 ? v : kStageGrid;
         }();
-        static const int wave_env = [] {   // FP8Q_WAVE=1: the barrier-free k_rows_wave instead of k_rows_staged (A/B: slower)
-            const char *e = getenv("FP8Q_WAVE");
-            return e ? atoi(e) : 0;
-        }();
-        {
-            WaveArgs w = {};
-            w.inner = (int)inner;
-            w.lut_stride = a.lut_stride;
-            w.magic = a.magic;
-            w.tail = a.tail;
-            w.nvec = a.nvec;
-            w.npieces = cdiv(n, kWavePiece);
-            w.rpc = (int)((inner + (kWavePiece + 3) - 2) / inner) + 1;
-            int gs = 0;
-            while (gs < 3 && (2 << gs) * w.rpc <= 64) ++gs;
-            w.group = gs;
-            w.wave_bytes = (int)(((size_t)kWaveWin * sizeof(float) + (size_t)w.rpc * (per_row - 4) + 15) & ~(size_t)15);
-            // 4 waves per block, 4 blocks per CU next to the 3 KiB of statics: <= 9.25 KiB per wave
-            if (wave_env && staged_env && w.wave_bytes <= 9472 && n < (1ll << 52)) {
-                static const int wave_grid = [] {   // FP8Q_WAVE_GRID: persistent-grid cap (blocks); 0 = one piece per wave
-                    const char *e = getenv("FP8Q_WAVE_GRID");
-                    const int v = e ? atoi(e) : -1;
-                    return v >= 0 ? v : 2048;
-                }();
-                const int64_t nblk = cdiv(w.npieces, 4);
-                const dim3 g((unsigned)(wave_grid ? balanced_blocks(nblk, wave_grid) : nblk)), b(kBlock);
-                const size_t wsh = (size_t)w.wave_bytes * 4;
-                if (nt) hipLaunchKernelGGL((k_rows_wave<true>), g, b, wsh, st, x, y, row_min, row_max, maxval_out, f, w);
-                else hipLaunchKernelGGL((k_rows_wave<false>), g, b, wsh, st, x, y, row_min, row_max, maxval_out, f, w);
-                return launch_rc();
-            }
-        }
         const size_t sh = (size_t)kStageWin * sizeof(float) + (size_t)a.rpc * per_row;
+        static const int solo_env = [] {   // FP8Q_SOLO=0: the four-wave k_rows_staged instead of k_rows_solo (A/B)
+            const char *e = getenv("FP8Q_SOLO");
+            return e ? atoi(e) : 1;
+        }();
+        if (staged_env && solo_env && sh <= kStageMaxLds) {
+            static const int solo_w = [] {   // FP8Q_SOLO_W: waves per block sharing a chunk (1, 2 or 4)
+                const char *e = getenv("FP8Q_SOLO_W");
+                const int v = e ? atoi(e) : 0;
+                return v == 1 || v == 2 || v == 4 ? v : 2;
+            }();
+            const int T = 64 * solo_w;
+            int gs = 0;
+            while (gs < 3 && (a.rpc << (gs + 1)) <= T) ++gs;
+            a.group = gs;   // log2(lanes per row); rows beyond T >> gs take further passes
+            a.nch = 1;
+            static const int solo_grid = [] {   // FP8Q_SOLO_GRID: persistent-grid cap (blocks); 0 = one chunk per block
+                const char *e = getenv("FP8Q_SOLO_GRID");
+                const int v = e ? atoi(e) : -1;
+                return v >= 0 ? v : 256 * 8;
+            }();
+            const int64_t blocks = solo_grid ? balanced_blocks(a.nchunks, solo_grid) : a.nchunks;
+            const dim3 g((unsigned)blocks), b((unsigned)T);
+#define FP8Q_LAUNCH_SOLO(WW)                                                                                        \
+    do {                                                                                                            \
+        if (nt) hipLaunchKernelGGL((k_rows_solo<true, WW>), g, b, sh, st, x, y, row_min, row_max, maxval_out, f, a); \
+        else hipLaunchKernelGGL((k_rows_solo<false, WW>), g, b, sh, st, x, y, row_min, row_max, maxval_out, f, a);   \
+    } while (0)
+            if (solo_w == 1) FP8Q_LAUNCH_SOLO(1);
+            else if (solo_w == 2) FP8Q_LAUNCH_SOLO(2);
+            else FP8Q_LAUNCH_SOLO(4);
+#undef FP8Q_LAUNCH_SOLO
+            return launch_rc();
+        }
         if (staged_env && sh <= kStageMaxLds) {
             int gs = 0;
             while (gs < 6 && (2 << gs) * a.rpc <= kBlock) ++gs;
@@ -1506,14 +1535,8 @@ int launch_rows_flat(int mode, const float *x, float *y, int64_t C, int64_t inne
             a.nch = 1;
             const int64_t blocks = staged_grid ? balanced_blocks(a.nchunks, staged_grid) : a.nchunks;
             const dim3 g((unsigned)blocks), b(kBlock);
-            static const int defer_env = [] {   // FP8Q_STAGED_DEFER=1: stores deferred past the next park (A/B: measured 2 % SLOWER)
-                const char *e = getenv("FP8Q_STAGED_DEFER");
-                return e ? atoi(e) : 0;
-            }();
-            if (nt && defer_env) hipLaunchKernelGGL((k_rows_staged<true, true>), g, b, sh, st, x, y, row_min, row_max, maxval_out, f, a);
-            else if (nt) hipLaunchKernelGGL((k_rows_staged<true, false>), g, b, sh, st, x, y, row_min, row_max, maxval_out, f, a);
-            else if (defer_env) hipLaunchKernelGGL((k_rows_staged<false, true>), g, b, sh, st, x, y, row_min, row_max, maxval_out, f, a);
-            else hipLaunchKernelGGL((k_rows_staged<false, false>), g, b, sh, st, x, y, row_min, row_max, maxval_out, f, a);
+            if (nt) hipLaunchKernelGGL((k_rows_staged<true>), g, b, sh, st, x, y, row_min, row_max, maxval_out, f, a);
+            else hipLaunchKernelGGL((k_rows_staged<false>), g, b, sh, st, x, y, row_min, row_max, maxval_out, f, a);
             return launch_rc();
         }
     }

@@ -63,22 +63,17 @@ def load_quantizer_ranges(model, ranges, strict=True):
         m.state = q.state = Qstates[r["state"]]
 
 
-def prequantize_weights(model):
-    """With fixed ranges every layer's weight quantization is independent of the data: instead of one
-    small launch per layer in its first forward (the reference: hijacker.py:88-98, every forward), all FP8
-    weight tensors go through ONE multi-tensor launch (fp8q_multi_quantize_f32) and fill the layers' caches.
-    Bit-identical to the per-layer path; a no-op for anything it does not cover (CPU tensors, INT
-    quantizers, layers that override quantize_weights, FP8Q_CACHE_WEIGHTS=0).  Returns the number of layers."""
+def _plan_layers(model):
+    """[(layer, weight, quantizer, maxval)] of every layer a multi-tensor plan can cover: FP8 weight quantizer with
+    fixed ranges on a contiguous CUDA fp32 weight that autograd is not tracking."""
     import os
-
-    import torch
 
     from .fp8 import FPQuantizer
     from .layers import QuantizationHijacker
     from .manager import Qstates
     if os.environ.get("FP8Q_CACHE_WEIGHTS", "1") == "0":
-        return 0
-    mods, items = [], []
+        return []
+    found = []
     for m in model.modules():
         if not isinstance(m, QuantizationHijacker) or not getattr(m, "_qw", False):
             continue
@@ -96,11 +91,22 @@ def prequantize_weights(model):
         mv = q.maxval.detach()
         if not (mv.is_cuda and mv.dtype == torch.float32) or mv.numel() not in (1, w.shape[0]):
             continue
-        mods.append((m, w, q))
-        items.append((w.detach(), mv, float(q.mantissa_bits), int(q.n_bits), int(q.sign_bits)))
-    if not items:
+        found.append((m, w, q, mv))
+    return found
+
+
+def prequantize_weights(model):
+    """With fixed ranges every layer's weight quantization is independent of the data: instead of one
+    small launch per layer in its first forward (the reference: hijacker.py:88-98, every forward), all FP8
+    weight tensors go through ONE multi-tensor launch (fp8q_multi_quantize_f32) and fill the layers' caches.
+    Bit-identical to the per-layer path; a no-op for anything it does not cover (CPU tensors, INT
+    quantizers, layers that override quantize_weights, FP8Q_CACHE_WEIGHTS=0).  Returns the number of layers."""
+    found = _plan_layers(model)
+    if not found:
         _PLANS.pop(model, None)
         return 0
+    mods = [(m, w, q) for m, w, q, mv in found]
+    items = [(w.detach(), mv, float(q.mantissa_bits), int(q.n_bits), int(q.sign_bits)) for m, w, q, mv in found]
     import fp8q
     # a prepared plan (fp8q_multi_plan_*): descriptors validated and packed once here; requantize_weights() replays
     # it with one launch whenever the weights' or the ranges' CONTENTS change (QAT steps, range updates in place)
@@ -116,23 +122,24 @@ def prequantize_weights(model):
 def requantize_weights(model):
     """Refresh every layer's cached quantized weight after the weights (or the range tensors) changed IN PLACE: one
     call into the prepared plan built by prequantize_weights() = one kernel launch for all layers (the reference
-    re-quantizes layer by layer in every forward, hijacker.py:88-98).  Falls back to a fresh prequantize_weights()
-    when a tensor was replaced rather than updated.  Returns the number of layers refreshed."""
-    import os
-
+    re-quantizes layer by layer in every forward, hijacker.py:88-98).  The plan holds addresses and, BY VALUE, every
+    layer's format: it is replayed only if the set of eligible layers, their tensors' storage and shapes, their
+    format (mantissa / sign / total bits) and their state are what they were when it was built; anything else --
+    a tensor replaced rather than updated, a new mantissa width, a layer that left or entered fix_ranges, a weight that
+    became trainable -- rebuilds it (prequantize_weights).  Returns the number of layers refreshed."""
     held = _PLANS.get(model)
-    if held is None or os.environ.get("FP8Q_CACHE_WEIGHTS", "1") == "0":
+    if held is None:
         return prequantize_weights(model)
     plan, mods, sigs = held
-    for (m, w, q), (x, mv), sig in zip(mods, plan._keep, sigs):
-        cur = m.get_weight_bias()[0]
-        # a tensor replaced rather than updated in place, a format / state change (the plan holds the format by value),
-        # or a weight that became trainable under autograd: rebuild (prequantize_weights re-checks every layer's eligibility)
-        if (cur.data_ptr() != x.data_ptr() or tuple(cur.shape) != tuple(x.shape) or q.maxval.data_ptr() != mv.data_ptr()
-                or m.weight_quantizer.quantizer is not q or (cur.requires_grad and torch.is_grad_enabled())):
+    now = _plan_layers(model)
+    if len(now) != len(mods):
+        return prequantize_weights(model)
+    for (m, w, q), (x, mv), sig, (m2, w2, q2, mv2) in zip(mods, plan._keep, sigs, now):
+        if (m2 is not m or q2 is not q or w2.data_ptr() != x.data_ptr() or tuple(w2.shape) != tuple(x.shape)
+                or mv2.data_ptr() != mv.data_ptr() or mv2.numel() != mv.numel()):
             return prequantize_weights(model)
-        now = _plan_signature(m, q)
-        if now[:3] != sig[:3] or now[4:] != sig[4:]:      # the range epoch (index 3) moves with in-place range updates: fine
+        cur = _plan_signature(m, q)
+        if cur[:3] != sig[:3] or cur[4:] != sig[4:]:      # the range epoch (index 3) moves with in-place range updates: fine
             return prequantize_weights(model)
     plan.launch()
     for (m, w, q), y in zip(mods, plan.outs):
