@@ -227,6 +227,31 @@ def extras(ops, dev):
         host = (time.perf_counter() - t0) / 200
         torch.cuda.synchronize()
         out["resnet18_all_21_weight_tensors_plan_e5m2"]["host_enqueue_us"] = round(host * 1e6, 1)
+        # an event pair around ONE ~20 us launch also measures the stream's start-up gap (an empty kernel reads 6-10 us
+        # this way); 100 launches queued back to back between one pair of events do not
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(100):
+            plan.launch()
+        e1.record()
+        torch.cuda.synchronize()
+        b2b = e0.elapsed_time(e1) * 1e-3 / 100
+        out["resnet18_all_21_weight_tensors_plan_e5m2"].update(
+            back_to_back_us=round(b2b * 1e6, 1), back_to_back_frac_of_8tbs=round(n_w * 8 / b2b / 8e12, 3))
+        # the same launch replayed from a HIP graph (what a captured quantized forward / QAT step would do)
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                plan.launch()
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                plan.launch()
+            rec("resnet18_all_21_weight_tensors_plan_hipgraph_e5m2", n_w, 8, graph.replay, iters=200)
+        except Exception as e:   # noqa: BLE001 -- informational entry only
+            out["resnet18_all_21_weight_tensors_plan_hipgraph_e5m2"] = {"error": repr(e)[:200]}
     # K4: the grid search of FP_MSE_Estimator (range_estimators.py:337-347) on a MobileNetV2 activation, 111 candidate
     # ranges x {1, 6} mantissa widths in one pass (the reference: 111 * |m| full quantizer passes).  ALU-bound: the
     # inner loop issues 7 VALU instructions per candidate-element (k_mse_row: 1 v_med3 + 3 integer + 3 packed fp32
@@ -242,7 +267,8 @@ def extras(ops, dev):
         ce = a4.numel() * 111 * len(mb)
         out[f"k4_mse_111cand_{len(mb)}m_64x32x112x112"] = dict(
             us=round(med * 1e6, 1), t_cand_elem_s=round(ce / med / 1e12, 3), hbm_gb_s=round(a4.numel() * 4 / med / 1e9, 1),
-            valu_issue_frac_of_39_3T=round(ce * 7 / med / 39.3e12, 3), lane_ops_frac_of_78_6T=round(ce * 10 / med / 78.6e12, 3))
+            bound="valu (5-7 issue slots per candidate-element by path: integer rounding with / without clamp, "
+                  "float magic-number rounding with / without clamp; counters under profiles/)")
     del x, y
     return out
 

@@ -280,48 +280,6 @@ __device__ __forceinline__ void quant_group(float (&v)[N], const ChanLite &c, co
     for (int j = 0; j < N; ++j) v[j] = y[j];
 }
 
-// quant_group written in three stages over arrays so that the
-// N table reads (ds_read_b64) are issued back to back and waited for once: as a per-element loop the compiler emitted
-// read -> wait -> use N times, i.e. N LDS round trips on the critical path of every group.
-template <int N, bool CHECK_X = true>
-__device__ __forceinline__ void quant_group_batched(float (&v)[N], const ChanLite &c, const float2 *lut,
-                                            float pmaxf, float qthr)
-{
-    float xc[N], fr[N];
-    int idx[N];
-#pragma unroll
-    for (int j = 0; j < N; ++j) {
-        xc[j] = __builtin_amdgcn_fmed3f(v[j], c.minv, c.maxv);
-        const float w = __builtin_amdgcn_logf(fabsf(xc[j])) + c.bias;
-        const float fl = floorf(w);
-        fr[j] = w - fl;
-        idx[j] = (int)__builtin_amdgcn_fmed3f(fl, 1.0f, pmaxf);
-    }
-    float2 t[N];
-#pragma unroll
-    for (int j = 0; j < N; ++j) t[j] = lut[idx[j]];
-    float y[N];
-    bool rk[N];
-    bool any = c.pthr < 0.0f;
-#pragma unroll
-    for (int j = 0; j < N; ++j) {
-        const float q0 = xc[j] * t[j].y;
-        const float r = rintf(q0);
-        // (x == 0: w = -inf, fr = NaN, the comparison is false and p = 1 is already exact)
-        rk[j] = (CHECK_X && __builtin_amdgcn_classf(v[j], 0x93)) | (fabsf(fr[j] - 0.5f) > c.pthr) | (fabsf(q0 - r) > qthr);
-        any |= rk[j];
-        y[j] = r * t[j].x;
-    }
-    if (__builtin_expect(any, 0)) {
-        const bool all = c.pthr < 0.0f;
-#pragma unroll
-        for (int j = 0; j < N; ++j)
-            if (rk[j] | all) y[j] = quant_exact(v[j], c.maxv, c.minv, c.bias, lut, pmaxf);
-    }
-#pragma unroll
-    for (int j = 0; j < N; ++j) v[j] = y[j];
-}
-
 // one element whose channel varies per element (short-row kernels)
 __device__ __forceinline__ float quant_one(float x, const ChanLite &c, const float2 *lut, float pmaxf,
                                            float qthr)

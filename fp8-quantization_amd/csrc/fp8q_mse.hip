@@ -120,6 +120,7 @@ constexpr int kMseRowTile = 2048;     // elements per wave and tile: 32 per lane
 constexpr int kMseRowEpl = 32;
 constexpr int kMseRowGroup = 128;     // candidates per block (LDS: 48 B each; two double accumulators per lane)
 constexpr int kMseRowMinInner = 2048; // shorter rows: k_mse_grid (lane = candidate)
+constexpr bool kIntRound = true;      // integer round-half-even fast loops (mse_cand_int); false: the float magic-number loops only
 
 typedef float vf2 __attribute__((ext_vector_type(2)));
 
@@ -177,6 +178,79 @@ __device__ __forceinline__ float wave_sum(float v)
     const int b = __builtin_bit_cast(int, v);
     return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16))) +
            (__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48)));
+}
+
+// wave-uniform min / max of a per-lane value (once per tile: the shuffle's LDS-crossbar latency does not matter here)
+__device__ __forceinline__ float wave_min_f(float v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+
+__device__ __forceinline__ float wave_max_f(float v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+
+// Squared error of one candidate over the lane's 32 elements when NO nonzero element of the tile lies below the
+// candidate's first binade (the caller checks it with the tile's smallest nonzero magnitude): rounding t = xc * 2^bf to
+// M fraction bits is then round-half-even on the BITS of t -- lsb = bit (23 - M), r = (bits + half - 1 + lsb) & ~mask
+// (v_bfe_u32, v_add3_u32, v_and_b32) -- with no exponent extraction, no clamp of it to binade 1 and no float add / sub
+// pair: 6 issue slots per element instead of 7, 5 when the candidate's range covers the whole tile (CLAMP = false: the
+// v_med3 goes too).  Zero stays zero; a carry out of the fraction moves the value into the next binade, as rounding
+// up must.  TWO = the candidate has two scale mantissas (m0b below |t| = thr).
+template <bool CLAMP, bool TWO>
+__device__ __forceinline__ vf2 mse_cand_int(const vf2 (&xv)[16], float minv, float maxv, float c1s, float m0s, float m0b, float thr,
+                                            uint32_t sh, uint32_t hm1, uint32_t msk)
+{
+    const vf2 c1 = {c1s, c1s}, m0 = {m0s, m0s};
+    vf2 pa = {0.0f, 0.0f};
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const vf2 xx = xv[u];
+        vf2 xc = xx;
+        if (CLAMP) xc = vf2{__builtin_amdgcn_fmed3f(xx.x, minv, maxv), __builtin_amdgcn_fmed3f(xx.y, minv, maxv)};
+        const vf2 tt = xc * c1;
+        const uint32_t b0 = __float_as_uint(tt.x), b1 = __float_as_uint(tt.y);
+        const uint32_t r0 = (b0 + hm1 + __builtin_amdgcn_ubfe(b0, sh, 1u)) & msk;
+        const uint32_t r1 = (b1 + hm1 + __builtin_amdgcn_ubfe(b1, sh, 1u)) & msk;
+        const vf2 rr = {__uint_as_float(r0), __uint_as_float(r1)};
+        vf2 ms = m0;
+        if (TWO) ms = vf2{fabsf(tt.x) < thr ? m0b : m0s, fabsf(tt.y) < thr ? m0b : m0s};
+        const vf2 d = xx - rr * ms;
+        pa = __builtin_elementwise_fma(d, d, pa);
+    }
+    return pa;
+}
+
+// The general fast loop: the float magic-number rounding (t + C) - C, C = 1.5 * 2^(max(exponent(t), exponent of binade 1)
+// + 23 - M) -- the max is the subnormal range's fixed step, which the integer loop above cannot do.  7 issue slots per
+// element, 6 without the clamp.
+template <bool CLAMP, bool TWO>
+__device__ __forceinline__ vf2 mse_cand_magic(const vf2 (&xv)[16], float minv, float maxv, float c1s, float m0s, float m0b, float thr,
+                                              uint32_t lo, uint32_t kadd)
+{
+    const vf2 c1 = {c1s, c1s}, m0 = {m0s, m0s};
+    vf2 pa = {0.0f, 0.0f};
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const vf2 xx = xv[u];
+        vf2 xc = xx;
+        if (CLAMP) xc = vf2{__builtin_amdgcn_fmed3f(xx.x, minv, maxv), __builtin_amdgcn_fmed3f(xx.y, minv, maxv)};
+        const vf2 tt = xc * c1;
+        const uint32_t b0 = max(__float_as_uint(tt.x) & 0x7f800000u, lo) + kadd;
+        const uint32_t b1 = max(__float_as_uint(tt.y) & 0x7f800000u, lo) + kadd;
+        const vf2 cc = {__uint_as_float(b0), __uint_as_float(b1)};
+        const vf2 rr = (tt + cc) - cc;          // t rounded to M fraction bits, half to even
+        vf2 ms = m0;
+        if (TWO) ms = vf2{fabsf(tt.x) < thr ? m0b : m0s, fabsf(tt.y) < thr ? m0b : m0s};
+        const vf2 d = xx - rr * ms;
+        pa = __builtin_elementwise_fma(d, d, pa);
+    }
+    return pa;
 }
 
 __global__ void __launch_bounds__(64)
@@ -254,6 +328,20 @@ k_mse_row(const float *__restrict__ x, const float *__restrict__ grid, double *_
                 xv[2 * u + 1] = vf2{e[2], e[3]};
             }
         }
+        // tile statistics (wave-uniform), amortised over the >= 111 candidates: does a candidate's range cover the tile
+        // (no clamp needed), and does any nonzero element fall below a candidate's first binade (integer rounding needs
+        // none to)?  NaN elements are ignored here: their squared error is NaN on every path.
+        float tmn = __builtin_inff(), tmx = -__builtin_inff(), anz = __builtin_inff();
+#pragma unroll
+        for (int u = 0; u < kMseRowEpl / 2; ++u) {
+            tmn = fminf(tmn, fminf(xv[u].x, xv[u].y));
+            tmx = fmaxf(tmx, fmaxf(xv[u].x, xv[u].y));
+            const float a0 = fabsf(xv[u].x), a1 = fabsf(xv[u].y);
+            anz = fminf(anz, fminf(a0 > 0.0f ? a0 : __builtin_inff(), a1 > 0.0f ? a1 : __builtin_inff()));
+        }
+        tmn = wave_min_f(tmn);
+        tmx = wave_max_f(tmx);
+        anz = wave_min_f(anz);
 #pragma unroll
         for (int jq = 0; jq < kMseRowGroup / 64; ++jq) {
             const int jb = jq * 64;
@@ -264,33 +352,29 @@ k_mse_row(const float *__restrict__ x, const float *__restrict__ grid, double *_
             for (int jl = 0; jl < jn; ++jl) {
                 const CandK kn = cst[jb + min(jl + 1, jn - 1)];   // next candidate's constants: in flight during this one
                 vf2 pa = {0.0f, 0.0f};
-                if (__builtin_expect(k.fast == 1, 1)) {
-                    const vf2 c1 = {k.c1, k.c1}, m0 = {k.m0, k.m0};
-#pragma unroll
-                    for (int u = 0; u < kMseRowEpl / 2; ++u) {
-                        const vf2 xx = xv[u];
-                        const vf2 xc = {__builtin_amdgcn_fmed3f(xx.x, k.minv, k.maxv), __builtin_amdgcn_fmed3f(xx.y, k.minv, k.maxv)};
-                        const vf2 tt = xc * c1;
-                        const uint32_t b0 = max(__float_as_uint(tt.x) & 0x7f800000u, k.lo) + k.kadd;
-                        const uint32_t b1 = max(__float_as_uint(tt.y) & 0x7f800000u, k.lo) + k.kadd;
-                        const vf2 cc = {__uint_as_float(b0), __uint_as_float(b1)};
-                        const vf2 rr = (tt + cc) - cc;          // t rounded to M fraction bits, half to even
-                        const vf2 d = xx - rr * m0;
-                        pa = __builtin_elementwise_fma(d, d, pa);
+                // integer rounding: no nonzero |t| below binade 1 (|xc| >= min(anz, maxv), and maxv sits in the top binade)
+                const bool int_ok = kIntRound && k.fast != 0 && anz * k.c1 >= __uint_as_float(k.lo) && k.maxv >= anz;
+                if (int_ok) {
+                    const uint32_t sh = k.kadd >> 23;                       // 23 - M: position of the last kept fraction bit
+                    const uint32_t hm1 = (1u << (sh - 1u)) - 1u, msk = ~((1u << sh) - 1u);
+                    const bool cover = tmn >= k.minv && tmx <= k.maxv;   // the candidate's range covers the tile: nothing to clamp
+                    const float thr = __uint_as_float(k.thr);
+                    if (k.fast == 1) {
+                        pa = cover ? mse_cand_int<false, false>(xv, k.minv, k.maxv, k.c1, k.m0, k.m0b, thr, sh, hm1, msk)
+                                   : mse_cand_int<true, false>(xv, k.minv, k.maxv, k.c1, k.m0, k.m0b, thr, sh, hm1, msk);
+                    } else {
+                        pa = cover ? mse_cand_int<false, true>(xv, k.minv, k.maxv, k.c1, k.m0, k.m0b, thr, sh, hm1, msk)
+                                   : mse_cand_int<true, true>(xv, k.minv, k.maxv, k.c1, k.m0, k.m0b, thr, sh, hm1, msk);
                     }
-                } else if (k.fast == 2) {   // two scale mantissas: the low binades (exponent field below thr) use m0b
-#pragma unroll
-                    for (int u = 0; u < kMseRowEpl / 2; ++u) {
-                        const vf2 xx = xv[u];
-                        const vf2 xc = {__builtin_amdgcn_fmed3f(xx.x, k.minv, k.maxv), __builtin_amdgcn_fmed3f(xx.y, k.minv, k.maxv)};
-                        const vf2 tt = xc * vf2{k.c1, k.c1};
-                        const uint32_t e0 = max(__float_as_uint(tt.x) & 0x7f800000u, k.lo);
-                        const uint32_t e1 = max(__float_as_uint(tt.y) & 0x7f800000u, k.lo);
-                        const vf2 cc = {__uint_as_float(e0 + k.kadd), __uint_as_float(e1 + k.kadd)};
-                        const vf2 rr = (tt + cc) - cc;
-                        const vf2 ms = {e0 < k.thr ? k.m0b : k.m0, e1 < k.thr ? k.m0b : k.m0};
-                        const vf2 d = xx - rr * ms;
-                        pa = __builtin_elementwise_fma(d, d, pa);
+                } else if (k.fast != 0) {
+                    const bool cover = tmn >= k.minv && tmx <= k.maxv;   // nothing to clamp for this candidate on this tile
+                    const float thr = __uint_as_float(k.thr);
+                    if (k.fast == 1) {
+                        pa = cover ? mse_cand_magic<false, false>(xv, k.minv, k.maxv, k.c1, k.m0, k.m0b, thr, k.lo, k.kadd)
+                                   : mse_cand_magic<true, false>(xv, k.minv, k.maxv, k.c1, k.m0, k.m0b, thr, k.lo, k.kadd);
+                    } else {   // two scale mantissas: the low binades (|t| below thr) use m0b
+                        pa = cover ? mse_cand_magic<false, true>(xv, k.minv, k.maxv, k.c1, k.m0, k.m0b, thr, k.lo, k.kadd)
+                                   : mse_cand_magic<true, true>(xv, k.minv, k.maxv, k.c1, k.m0, k.m0b, thr, k.lo, k.kadd);
                     }
                 } else {
                     // exact per-element path (scales not exactly geometric in fp32, tiny / huge / degenerate ranges)

@@ -810,235 +810,6 @@ k_rows_staged(const float *__restrict__ x, float *__restrict__ y, float *row_min
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Short rows, fused, ONE WAVE PER CHUNK: k_rows_solo.  What k_rows_staged's counters said (profiles/r02_staged_valu_lds_pmc.json:
-// 736 VALU wave-instructions per wave and 16 KiB chunk, 75 % of all SIMD cycles busy): the kernel is bound by its
-// instruction count, and 325 of the 736 are the per-row phase -- range, channel constants, table, head patch --
-// which all FOUR waves of a block execute, each for its 8 of the chunk's ~28 rows with 8 lanes per row in lockstep
-// (a wave-instruction costs the same with 8 or with 64 distinct results).  Here a 64-thread block = one wave owns the
-// whole aligned 16 KiB chunk: the ~28 rows sit in ONE wave with 2 lanes per row, so the double-precision channel
-// constants are evaluated once per chunk instead of four times, the row ranges are read from the window as aligned
-// 16-byte groups (ds_read_b128: 2 min3 + 2 max3 + 2 unordered compares per group, no per-element addressing; only a
-// row's first and last group are masked), and there is no block-level barrier at all -- every hand-over is between
-// lanes of the same wave.  The quantize pass is k_rows_staged's: the lane's own 16-byte groups back from the window,
-// per-row {s, 1/s} tables in LDS, head patches for the groups that straddle a row boundary, aligned nontemporal 16-byte
-// stores.  Global traffic: every element fetched once, plus one 16-byte group per lane on either side for the
-// neighbouring chunks' share of the first and the last row (L2 hits: the neighbouring blocks stream them).
-// The next chunk's loads are issued right after the park and fly during the whole body (17 KiB in flight per wave).
-// LDS: float win[kStagePad | 4096 | kStagePad] | float4 patch[rpc] | float4 chanlite[rpc] | float2 lut[rpc * stride]
-// = 27.0 KiB for 147-element rows in E5M2: 5 blocks (waves) per CU.
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void wave_sync()
-{
-    // LDS hand-over between lanes of ONE wave: DS operations of a wave complete in order; the fences keep the
-    // compiler from moving LDS accesses across this point
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// hand-over between all lanes of the block: W == 1 (one wave) needs no hardware barrier
-template <int W>
-__device__ __forceinline__ void solo_sync()
-{
-    if (W == 1) wave_sync();
-    else __syncthreads();
-}
-
-// a chunk's loads: 1024 / T x 16 B per lane of the body + border pieces as whole 16-byte groups (head of the first,
-// tail of the last overlapping row: <= 64 groups each, lanes 0..63); the tensor's last <= 3 elements, which are not a
-// whole group, come as scalars
-template <bool NT, int W>
-__device__ __forceinline__ void solo_load(const float *x, int64_t c, const ChunkInfo &ci, const FlatArgs &a, int tid,
-                                          vf4 (&v)[kChunkGroups / (64 * W)], vf4 &vb, vf4 &va)
-{
-    constexpr int T = 64 * W, U = kChunkGroups / T;
-    const int64_t elo = c * kChunkElems;
-    const int ng = ci.len >> 2;
-    const vf4 *xv = reinterpret_cast<const vf4 *>(x + elo);
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-        if (u * T + tid < ng) v[u] = ld16<NT>(xv + u * T + tid);
-    if (tid < ((ci.phase + 3) >> 2)) vb = ld16<NT>(xv - 1 - tid);
-    const int after = ci.pad[0];
-    if (tid < ((after + 3) >> 2)) {
-        const int64_t nbody = a.nvec * 4, o = elo + ci.len + 4 * (int64_t)tid;
-        if (o + 4 <= nbody) {
-            va = ld16<NT>(reinterpret_cast<const vf4 *>(x + o));
-        } else {
-            const int64_t n = nbody + a.tail;
-            va = vf4{o < n ? x[o] : 0.0f, o + 1 < n ? x[o + 1] : 0.0f, o + 2 < n ? x[o + 2] : 0.0f, 0.0f};
-        }
-    }
-}
-
-// min / max / NaN of the row that starts at window index w (inner elements) over Gl = 2^gs (<= 8) adjacent lanes,
-// read as aligned 16-byte groups, four per trip (one LDS round trip per four groups); every lane of the row gets the
-// result.  Elements of a group outside [w, w + inner) (the neighbouring rows' share of the row's first and last group)
-// are replaced by the row's own first element; a lane that runs out of groups re-reads the row's last one.
-__device__ __forceinline__ MinMax solo_row_range(const float *win, int w, int inner, bool valid, int sub, int gs)
-{
-    MinMax m;
-    mm_init(m);
-    if (valid) {
-        const int Gl = 1 << gs, gB = (w + inner - 1) >> 2;
-        const float first = win[w];
-        const vf4 *w4 = reinterpret_cast<const vf4 *>(win);
-        for (int g0 = (w >> 2) + sub; g0 <= gB; g0 += 4 * Gl) {
-            int g[4];
-            vf4 t[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                g[j] = min(g0 + j * Gl, gB);
-                t[j] = w4[g[j]];
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int lo = w - 4 * g[j], hi = lo + inner;   // elements k of the group with lo <= k < hi belong to the row
-                if (lo > 0 || hi < 4) {
-                    if (0 < lo || 0 >= hi) t[j].x = first;
-                    if (1 < lo || 1 >= hi) t[j].y = first;
-                    if (2 < lo || 2 >= hi) t[j].z = first;
-                    if (3 < lo || 3 >= hi) t[j].w = first;
-                }
-                mm_acc(m, t[j].x);
-                mm_acc(m, t[j].y);
-                mm_acc(m, t[j].z);
-                mm_acc(m, t[j].w);
-            }
-        }
-    }
-    if (gs >= 1) mm_dpp<0xB1>(m);    // quad_perm [1,0,3,2]
-    if (gs >= 2) mm_dpp<0x4E>(m);    // quad_perm [2,3,0,1]
-    if (gs >= 3) mm_dpp<0x141>(m);   // row_half_mirror
-    if (m.nan) m.mn = m.mx = __builtin_nanf("");
-    return m;
-}
-
-// W = waves per block sharing the chunk (1, 2 or 4); a.group = log2(lanes per row): the launcher takes as many lanes per
-// row as hold all rows of a chunk in one pass of the block's 64 * W lanes (2 / 4 / 8 for 147-element rows).
-template <bool NT, int W>
-__global__ void __launch_bounds__(64 * W, W == 4 ? 4 : (W == 2 ? 3 : 2))   // LDS admits 5 blocks per CU: 168 / 256 VGPRs for W = 2 / 1
-k_rows_solo(const float *__restrict__ x, float *__restrict__ y, float *row_min, float *row_max, float *maxval_out,
-            QFmt f, FlatArgs a)
-{
-    constexpr int T = 64 * W, U = kChunkGroups / T;
-    constexpr bool BATCHQ = W < 4;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ double ftab[kFastTabSize];   // log2 / exp2 tables of the channel constants: through L1 they cost a global
-                                            // round trip per chunk on every wave's critical path (measured: 2x slower)
-    for (int i = threadIdx.x; i < kFastTabSize; i += T) ftab[i] = kFastTab[i];
-    float *win = reinterpret_cast<float *>(smem);
-    float4 *patch = reinterpret_cast<float4 *>(win + kStageWin);
-    float4 *chl = patch + a.rpc;
-    float2 *lut = reinterpret_cast<float2 *>(chl + a.rpc);
-    const int tid = threadIdx.x;
-    const int inner = a.inner;
-    const int64_t G = gridDim.x;
-    const float pmaxf = (float)f.pmax;
-
-    int64_t c = blockIdx.x;   // gridDim.x <= nchunks
-    const uint32_t adv = (uint32_t)G * (uint32_t)kChunkElems;
-    const bool inc_ok = (uint64_t)(G * kChunkElems + 256) * (uint64_t)inner < (1ull << 32);
-    ChunkInfo cur = stage_geometry(c, a);
-    vf4 v[U], vb = {0.0f, 0.0f, 0.0f, 0.0f}, va = {0.0f, 0.0f, 0.0f, 0.0f};
-    solo_load<NT, W>(x, c, cur, a, tid, v, vb, va);   // prologue: the first chunk's loads
-    for (;;) {
-        const int64_t elo = c * kChunkElems;
-        const int phase = cur.phase, nrows = cur.nrows, len = cur.len;
-        const int ng = len >> 2;
-        // ---- park (waits for the loads issued one iteration ago) ----
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-            if (u * T + tid < ng) *reinterpret_cast<vf4 *>(win + kStagePad + 4 * (u * T + tid)) = v[u];
-        if (tid < ((phase + 3) >> 2)) *reinterpret_cast<vf4 *>(win + kStagePad - 4 * (tid + 1)) = vb;
-        if (tid < ((cur.pad[0] + 3) >> 2)) *reinterpret_cast<vf4 *>(win + kStagePad + len + 4 * tid) = va;
-        const int64_t cn = c + G;
-        const bool more = cn < a.nchunks;
-        ChunkInfo nxt = cur;
-        if (more) nxt = inc_ok ? stage_geometry_next(cur, cn, adv, a) : stage_geometry(cn, a);
-        solo_sync<W>();
-        if (more) solo_load<NT, W>(x, cn, nxt, a, tid, v, vb, va);   // the next chunk: in flight during everything below
-        // ---- per row, Gl lanes: range from the window -> channel constants -> table -> the row's head patch ----
-        {
-            const int gs = a.group, Gl = 1 << gs, rpp = T >> gs, sub = tid & (Gl - 1), rs = tid >> gs;
-            for (int rb = 0; rb < nrows; rb += rpp) {
-                const int r = rb + rs;
-                const bool valid = r < nrows;
-                if (W > 1 && rb + ((tid & ~63) >> gs) >= nrows) continue;   // no row for this whole wave in this pass
-                const MinMax m = solo_row_range(win, kStagePad - phase + r * inner, inner, valid, sub, gs);
-                if (valid) {
-                    const float mv = fabsf(tmax(fabsf(m.mn), m.mx));   // fp8_quantizer.py:236
-                    if (sub == 0 && (r > 0 || phase == 0)) {   // the row starts in this chunk: this block reports it
-                        const int64_t grow = cur.row_lo + r;
-                        if (row_min) row_min[grow] = m.mn;
-                        if (row_max) row_max[grow] = m.mx;
-                        if (maxval_out) maxval_out[grow] = mv;
-                    }
-                    const Chan ch = make_chan_fast(mv, f, ftab);
-                    if (sub == 0) chl[r] = make_float4(ch.maxv, ch.minv, ch.bias, ch.pthr);
-                    lut_part(lut + r * a.lut_stride, ch, f, sub, Gl);
-                }
-                wave_sync();   // a row's lanes are in one wave: the table they wrote is theirs to read
-                if (valid) {
-                    const int idx = r * inner - phase;   // chunk-local index of the row's first element
-                    if (idx > 0 && idx < len && (idx & 3)) {   // it shares a 16-byte group with the previous row
-                        const ChanLite cl = lite_of(chl[r]);
-                        for (int k = sub; k < 4 - (idx & 3); k += Gl)
-                            reinterpret_cast<float *>(patch)[4 * r + k] =
-                                quant_one(win[kStagePad + idx + k], cl, lut + r * a.lut_stride, pmaxf, f.qthr);
-                    }
-                }
-            }
-        }
-        solo_sync<W>();
-        if (tid < cur.tail) {   // the tensor's last <= 3 elements
-            const int e = len + tid;
-            const int r = div_small((uint32_t)(phase + e), a.magic);
-            y[elo + e] = quant_one(win[kStagePad + e], lite_of(chl[r]), lut + r * a.lut_stride, pmaxf, f.qthr);
-        }
-        {
-            vf4 *yv = reinterpret_cast<vf4 *>(y + elo);
-            constexpr int B = W == 4 ? 2 : 4;   // groups per trip: window groups and channel constants read together
-#pragma unroll
-            for (int u0 = 0; u0 < U; u0 += B) {
-                vf4 w[B];
-                float4 cl[B];
-                int lrow[B], left[B];
-#pragma unroll
-                for (int j = 0; j < B; ++j) {
-                    const int q = min((u0 + j) * T + tid, ng - 1);   // (lanes beyond the body re-read its last group)
-                    w[j] = *reinterpret_cast<const vf4 *>(win + kStagePad + 4 * q);   // own group back from the window
-                    const int o = phase + 4 * q;
-                    lrow[j] = div_small((uint32_t)o, a.magic);
-                    left[j] = inner - (o - lrow[j] * inner);   // elements left in this row (>= 1)
-                    cl[j] = chl[lrow[j]];
-                }
-#pragma unroll
-                for (int j = 0; j < B; ++j) {
-                    const int q = (u0 + j) * T + tid;
-                    if (q >= ng) continue;
-                    float e[4] = {w[j].x, w[j].y, w[j].z, w[j].w};
-                    if (BATCHQ) quant_group_batched<4, false>(e, lite_of(cl[j]), lut + lrow[j] * a.lut_stride, pmaxf, f.qthr);
-                    else quant_group<4, false>(e, lite_of(cl[j]), lut + lrow[j] * a.lut_stride, pmaxf, f.qthr);   // fused: NaN rows are all-exact
-                    const int b = left[j];
-                    if (b < 4) {   // e[b..3] belong to the next row: its head patch
-                        const float4 pt = patch[lrow[j] + 1];
-                        e[3] = b == 3 ? pt.x : (b == 2 ? pt.y : pt.z);
-                        if (b < 3) e[2] = b == 2 ? pt.x : pt.y;
-                        if (b < 2) e[1] = pt.x;
-                    }
-                    st16<NT>(yv + q, vf4{e[0], e[1], e[2], e[3]});
-                }
-            }
-        }
-        if (!more) break;
-        solo_sync<W>();   // the window and the tables are rewritten by the next chunk
-        c = cn;
-        cur = nxt;
-    }
-}
-
 // K2 twin of k_rows_staged: per-row min/max (+ fold into the running estimate) of rows <= 256 elements at any row
 // length and phase.  Loads are the aligned, coalesced 16 KiB chunks of a plain copy (the row-tiled kernel reads
 // row-aligned tiles: 5.2-5.4 TB/s); LDS only transposes them for the G-lanes-per-row reduction.  No tables: 18.4 KiB of
@@ -1115,92 +886,103 @@ struct MultiDesc {
 
 struct MultiArgs {
     int n;
+    int rpc_max;         // most table rows any chunk of any tensor needs
     uint32_t total_chunks;
     MultiDesc d[kMultiMax];
 };
 
+// One launch, every block resident at once (<= 1024 blocks: 4 per CU), chunks handed out grid-stride (neighbouring
+// blocks on neighbouring chunks, a block's few chunks software-ordered: loads first, tables while they fly).  Round 2's
+// version -- one chunk per block, 2850 blocks for ResNet-18 = 2.8 rounds -- spent most of its 24 us in per-block serial
+// latency: a single thread's 64-bit software division, one thread per row building a whole table, a head-patch phase
+// with dependent global loads, and only then the chunk's own loads.  Here: the chunk's loads are issued before anything
+// else; the geometry is computed by every thread (double-precision quotient + fix-up: no LDS hand-off); a row's table
+// is built by up to 32 lanes; the <= 3 elements of a 16-byte group that belong to the NEXT row are quantized in place
+// with that row's table (a rare divergent branch) instead of a patch phase; the 3 KiB of log2 / exp2 tables are staged
+// once per block, not once per chunk.
 __global__ void __launch_bounds__(kBlock, 4)
 k_multi_flat(MultiArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ double ftab[kFastTabSize];
-    __shared__ ChunkInfo cinfo;
     const int tid = threadIdx.x;
-    int t = 0;
-    while (t + 1 < a.n && a.d[t + 1].chunk0 <= blockIdx.x) ++t;   // uniform
-    const MultiDesc &d = a.d[t];
-    const QFmt f = d.f;
-    const int inner = d.inner, lut_stride = f.pmax + 1;
-    const int64_t c = (int64_t)blockIdx.x - d.chunk0;
-    const int64_t elo = c * kChunkElems;
-    const float *x = d.x + elo;
-    float *y = d.y + elo;
-    float4 *patch = reinterpret_cast<float4 *>(smem);
-    float4 *chl = patch + d.rpc;
-    float2 *lut = reinterpret_cast<float2 *>(chl + d.rpc);
-    const float pmaxf = (float)f.pmax;
+    float4 *chl = reinterpret_cast<float4 *>(smem);
+    float2 *lut = reinterpret_cast<float2 *>(chl + a.rpc_max);
     for (int i = tid; i < kFastTabSize; i += kBlock) ftab[i] = kFastTab[i];
-    if (tid == 0) {
+    constexpr int U = 4;
+    // which tensor chunk g belongs to: lane l looks at descriptor l's first chunk, one ballot -- a scan over the
+    // descriptors is up to 31 DEPENDENT scalar loads from the kernel-argument segment (~2 us for a model's last tensors)
+    auto tensor_of = [&](uint32_t g) -> int {
+        const int l = tid & 63;
+        const uint32_t c0 = l < a.n ? a.d[l].chunk0 : 0xffffffffu;
+        return __popcll(__ballot(c0 <= g)) - 1;   // chunk0 ascends from 0: uniform, >= 0
+    };
+    auto issue = [&](uint32_t g, int t, vf4 (&w)[U]) {   // the chunk's 16-byte groups: 4 per lane
+        const MultiDesc &d = a.d[t];
+        const int64_t elo = (int64_t)(g - d.chunk0) * kChunkElems;
         const int64_t rem = d.nvec * 4 - elo;
-        ChunkInfo ci;
-        ci.len = rem < kChunkElems ? (int)rem : kChunkElems;
-        ci.tail = (rem <= kChunkElems) ? d.tail : 0;
-        ci.row_lo = d.single_row ? 0 : elo / inner;
-        ci.phase = d.single_row ? 0 : (int)(elo - ci.row_lo * inner);
-        ci.nrows = d.single_row ? 1 : (ci.phase + ci.len + ci.tail - 1) / inner + 1;
-        ci.pad[0] = ci.pad[1] = 0;
-        cinfo = ci;
-    }
-    __syncthreads();
-    const ChunkInfo ci = cinfo;
-    for (int r = tid; r < ci.nrows; r += kBlock) {
-        const Chan ch = make_chan_fast(d.maxval[d.single_row ? 0 : ci.row_lo + r], f, ftab);
-        chl[r] = make_float4(ch.maxv, ch.minv, ch.bias, ch.pthr);
-        lut_row(lut + r * lut_stride, ch, f);
-    }
-    __syncthreads();
-    for (int r = tid; r < ci.nrows; r += kBlock) {
-        float pv[3] = {0.0f, 0.0f, 0.0f};
-        if (r + 1 < ci.nrows) {
-            const int idx = (r + 1) * inner - ci.phase;   // chunk-local index of row r+1's first element
-            if (idx < ci.len && (idx & 3)) {
-                const ChanLite cl = lite_of(chl[r + 1]);
-                const float2 *lt = lut + (r + 1) * lut_stride;
-                for (int k = 0; k < 4 - (idx & 3); ++k) pv[k] = quant_one(x[idx + k], cl, lt, pmaxf, f.qthr);
+        const int ng = (rem < kChunkElems ? (int)rem : kChunkElems) >> 2;
+        const vf4 *xv = reinterpret_cast<const vf4 *>(d.x + elo);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (tid + u * kBlock < ng) w[u] = ld16<false>(xv + tid + u * kBlock);
+    };
+    for (uint32_t g = blockIdx.x; g < a.total_chunks; g += gridDim.x) {
+        const int t = tensor_of(g);
+        vf4 v[U];
+        issue(g, t, v);   // in flight during the table phase (requesting the block's NEXT chunk here as well measured slower:
+                          // 21.1 vs 19.1 us for ResNet-18's 21 tensors)
+        const MultiDesc &d = a.d[t];
+        const QFmt f = d.f;
+        const int inner = d.inner, lut_stride = f.pmax + 1;
+        const float pmaxf = (float)f.pmax;
+        const int64_t elo = (int64_t)(g - d.chunk0) * kChunkElems;
+        const float *x = d.x + elo;
+        float *y = d.y + elo;
+        const int64_t rem = d.nvec * 4 - elo;
+        const int len = rem < kChunkElems ? (int)rem : kChunkElems;
+        const int ng = len >> 2;
+        const int tail = (rem <= kChunkElems) ? d.tail : 0;
+        const int64_t row_lo = d.single_row ? 0 : div_rows(elo, inner);
+        const int phase = d.single_row ? 0 : (int)(elo - row_lo * inner);
+        const int nrows = d.single_row ? 1 : div_small((uint32_t)(phase + len + tail - 1), d.magic) + 1;
+        __syncthreads();   // the previous chunk's tables are no longer read (first chunk: ftab is staged)
+        {
+            int gs = 0;   // log2(lanes per row): as many as hold all rows in one pass, at most 32
+            while (gs < 5 && (nrows << (gs + 1)) <= kBlock) ++gs;
+            const int L = 1 << gs, sub = tid & (L - 1);
+            for (int r = tid >> gs; r < nrows; r += kBlock >> gs) {
+                const Chan ch = make_chan_fast(d.maxval[d.single_row ? 0 : row_lo + r], f, ftab);
+                if (sub == 0) chl[r] = make_float4(ch.maxv, ch.minv, ch.bias, ch.pthr);
+                lut_part(lut + r * lut_stride, ch, f, sub, L);
             }
         }
-        patch[r] = make_float4(pv[0], pv[1], pv[2], 0.0f);
-    }
-    if (tid < ci.tail) {   // the tensor's last <= 3 elements
-        const int e = ci.len + tid;
-        const int r = d.single_row ? 0 : div_small((uint32_t)(ci.phase + e), d.magic);
-        y[e] = quant_one(x[e], lite_of(chl[r]), lut + r * lut_stride, pmaxf, f.qthr);
-    }
-    __syncthreads();
-    constexpr int U = 4;
-    const vf4 *xv = reinterpret_cast<const vf4 *>(x);
-    vf4 *yv = reinterpret_cast<vf4 *>(y);
-    const int ng = ci.len >> 2;
-    vf4 v[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-        if (tid + u * kBlock < ng) v[u] = ld16<false>(xv + tid + u * kBlock);
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int q = tid + u * kBlock;
-        if (q >= ng) break;
-        const int o = ci.phase + 4 * q;
-        const int lrow = d.single_row ? 0 : div_small((uint32_t)o, d.magic);
-        const int b = d.single_row ? 4 : inner - (o - lrow * inner);   // elements left in this row (>= 1)
-        float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
-        quant_group<4>(e, lite_of(chl[lrow]), lut + lrow * lut_stride, pmaxf, f.qthr);
-        if (b < 4) {   // e[b..3] belong to the next row: take them from its patch
-            const float4 pt = patch[lrow];
-            e[3] = b == 3 ? pt.x : (b == 2 ? pt.y : pt.z);
-            if (b < 3) e[2] = b == 2 ? pt.x : pt.y;
-            if (b < 2) e[1] = pt.x;
+        __syncthreads();
+        if (tid < tail) {   // the tensor's last <= 3 elements
+            const int e = len + tid;
+            const int r = d.single_row ? 0 : div_small((uint32_t)(phase + e), d.magic);
+            y[e] = quant_one(x[e], lite_of(chl[r]), lut + r * lut_stride, pmaxf, f.qthr);
         }
-        st16<false>(yv + q, vf4{e[0], e[1], e[2], e[3]});
+        vf4 *yv = reinterpret_cast<vf4 *>(y);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int q = tid + u * kBlock;
+            if (q >= ng) break;
+            const int o = phase + 4 * q;
+            const int lrow = d.single_row ? 0 : div_small((uint32_t)o, d.magic);
+            const int b = d.single_row ? 4 : inner - (o - lrow * inner);   // elements left in this row (>= 1)
+            const float in[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+            float e[4] = {in[0], in[1], in[2], in[3]};
+            quant_group<4>(e, lite_of(chl[lrow]), lut + lrow * lut_stride, pmaxf, f.qthr);
+            if (b < 4) {   // e[b..3] belong to the next row (rows are >= 4 long: one boundary per group at most)
+                const ChanLite cl = lite_of(chl[lrow + 1]);
+                const float2 *lt = lut + (lrow + 1) * lut_stride;
+#pragma unroll
+                for (int k = 1; k < 4; ++k)
+                    if (k >= b) e[k] = quant_one(in[k], cl, lt, pmaxf, f.qthr);
+            }
+            st16<false>(yv + q, vf4{e[0], e[1], e[2], e[3]});
+        }
     }
 }
 
@@ -1495,39 +1277,6 @@ int launch_rows_flat(int mode, const float *x, float *y, int64_t C, int64_t inne
             return v >= 0 ? v : kStageGrid;
         }();
         const size_t sh = (size_t)kStageWin * sizeof(float) + (size_t)a.rpc * per_row;
-        static const int solo_env = [] {   // FP8Q_SOLO=0: the four-wave k_rows_staged instead of k_rows_solo (A/B)
-            const char *e = getenv("FP8Q_SOLO");
-            return e ? atoi(e) : 1;
-        }();
-        if (staged_env && solo_env && sh <= kStageMaxLds) {
-            static const int solo_w = [] {   // FP8Q_SOLO_W: waves per block sharing a chunk (1, 2 or 4)
-                const char *e = getenv("FP8Q_SOLO_W");
-                const int v = e ? atoi(e) : 0;
-                return v == 1 || v == 2 || v == 4 ? v : 2;
-            }();
-            const int T = 64 * solo_w;
-            int gs = 0;
-            while (gs < 3 && (a.rpc << (gs + 1)) <= T) ++gs;
-            a.group = gs;   // log2(lanes per row); rows beyond T >> gs take further passes
-            a.nch = 1;
-            static const int solo_grid = [] {   // FP8Q_SOLO_GRID: persistent-grid cap (blocks); 0 = one chunk per block
-                const char *e = getenv("FP8Q_SOLO_GRID");
-                const int v = e ? atoi(e) : -1;
-                return v >= 0 ? v : 256 * 8;
-            }();
-            const int64_t blocks = solo_grid ? balanced_blocks(a.nchunks, solo_grid) : a.nchunks;
-            const dim3 g((unsigned)blocks), b((unsigned)T);
-#define FP8Q_LAUNCH_SOLO(WW)                                                                                        \
-    do {                                                                                                            \
-        if (nt) hipLaunchKernelGGL((k_rows_solo<true, WW>), g, b, sh, st, x, y, row_min, row_max, maxval_out, f, a); \
-        else hipLaunchKernelGGL((k_rows_solo<false, WW>), g, b, sh, st, x, y, row_min, row_max, maxval_out, f, a);   \
-    } while (0)
-            if (solo_w == 1) FP8Q_LAUNCH_SOLO(1);
-            else if (solo_w == 2) FP8Q_LAUNCH_SOLO(2);
-            else FP8Q_LAUNCH_SOLO(4);
-#undef FP8Q_LAUNCH_SOLO
-            return launch_rc();
-        }
         if (staged_env && sh <= kStageMaxLds) {
             int gs = 0;
             while (gs < 6 && (2 << gs) * a.rpc <= kBlock) ++gs;
@@ -2045,14 +1794,19 @@ static int plan_build(const fp8q_tensor_desc *descs, int n, fp8q_multi_plan &pla
     PlanStep cur;
     cur.batched = true;
     cur.args.n = 0;
+    cur.args.rpc_max = 0;
     cur.args.total_chunks = 0;
     cur.shmem = 0;
+    size_t lut_max = 0;   // largest table area (rows x entries) any tensor of the current launch needs
     auto flush = [&]() {
         if (cur.args.n == 0) return;
+        cur.shmem = (size_t)cur.args.rpc_max * 16 + lut_max;   // [chanlite[rpc_max] | tables]
         plan.steps.push_back(cur);
         cur.args.n = 0;
+        cur.args.rpc_max = 0;
         cur.args.total_chunks = 0;
         cur.shmem = 0;
+        lut_max = 0;
     };
     for (int i = 0; i < n; ++i) {
         const fp8q_tensor_desc &t = descs[i];
@@ -2072,6 +1826,7 @@ static int plan_build(const fp8q_tensor_desc *descs, int n, fp8q_multi_plan &pla
             PlanStep one;
             one.batched = false;
             one.args.n = 0;
+            one.args.rpc_max = 0;
             one.args.total_chunks = 0;
             one.shmem = 0;
             one.single = t;
@@ -2092,8 +1847,11 @@ static int plan_build(const fp8q_tensor_desc *descs, int n, fp8q_multi_plan &pla
         d.chunk0 = cur.args.total_chunks;
         d.f = f;
         cur.args.total_chunks += (uint32_t)cdiv(d.nvec, kChunkGroups);
-        const size_t need = (size_t)(rpc * per_row);
-        if (need > cur.shmem) cur.shmem = need;
+        // per table row: the channel constants (16 B) + pmax + 1 entries {s, 1/s}; every tensor of the launch uses the
+        // same layout [chanlite[rpc_max] | tables], so size it for the largest of each
+        if ((int)rpc > cur.args.rpc_max) cur.args.rpc_max = (int)rpc;
+        const size_t need = (size_t)rpc * (size_t)(f.pmax + 1) * 8;
+        if (need > lut_max) lut_max = need;
     }
     flush();
     return FP8Q_OK;
@@ -2103,7 +1861,14 @@ static int plan_launch(const fp8q_multi_plan &plan, hipStream_t st)
 {
     for (const PlanStep &s : plan.steps) {
         if (s.batched) {
-            hipLaunchKernelGGL(k_multi_flat, dim3(s.args.total_chunks), dim3(kBlock), s.shmem, st, s.args);
+            // every block resident at once (4 per CU at 128 VGPRs): chunks grid-stride, a few per block
+            static const int grid_env = [] {   // FP8Q_MULTI_GRID: block cap of the multi-tensor launch (tuning knob)
+                const char *e = getenv("FP8Q_MULTI_GRID");
+                const int v = e ? atoi(e) : 0;
+                return v >= 1 ? v : 1024;
+            }();
+            hipLaunchKernelGGL(k_multi_flat, dim3((unsigned)balanced_blocks(s.args.total_chunks, grid_env)), dim3(kBlock),
+                               s.shmem, st, s.args);
             if (int rc = launch_rc()) return rc;
         } else {
             const fp8q_tensor_desc &t = s.single;

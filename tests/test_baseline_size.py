@@ -134,6 +134,7 @@ class LaunchChecker:
         self.ops = ops
         self.count = {n: 0 for n in self.NAMES}
         self.elements = 0
+        self.choice = dict(quantizers=0, channels=0, channels_with_another_candidate=0, oracle_candidates_evaluated=0)
         self.real = {n: getattr(ops, n) for n in self.NAMES}
         for n in self.NAMES:
             monkeypatch.setattr(ops, n, self._wrap(n))
@@ -233,6 +234,48 @@ class LaunchChecker:
                         f"multi_quantize {tuple(x.shape)}")
             self.elements += x.numel()
 
+    @staticmethod
+    def _choice(table):
+        """FP_MSE_Estimator's decision from a [n_m, n_cand, C] table (range_estimators.py:350-369): plurality vote of
+        the per-channel best mantissa width (torch.mode: the smallest of the most frequent), then the per-channel
+        argmin over the candidates of that width."""
+        best_m_per_ch = table.min(1).argmin(0)
+        m = int(np.bincount(best_m_per_ch, minlength=table.shape[0]).argmax())
+        return m, table[m].argmin(0)
+
+    def _check_choice(self, a, got, ref, what):
+        """SURVEY.md 8c for K4: the CHOSEN (mantissa bits, maxval[C]) equals the choice from the oracle's table, or the
+        oracle's MSE at the chosen candidate is within 1e-6 relative of the oracle's minimum.  `ref` = the oracle's
+        full table (per-channel weights, small activations) or None (long per-tensor rows): then the oracle is
+        evaluated, on the whole tensor, at every candidate whose device MSE is within 1e-4 of the device minimum --
+        the device table agrees with the oracle's to 1e-5 everywhere, so the oracle's argmin is one of those."""
+        st = self.choice
+        m_got, arg_got = self._choice(got)
+        if ref is not None:
+            m_ref, arg_ref = self._choice(ref)
+            assert m_got == m_ref, (what, "mantissa vote", m_got, m_ref)
+            cols = np.arange(got.shape[2])
+            chosen, best = ref[m_ref][arg_got, cols], ref[m_ref][arg_ref, cols]
+        else:
+            x, grid, mb = a["x"].contiguous(), _np(a["grid"]), list(a["mbits_list"])
+            near = np.argwhere(got[:, :, 0] <= got.min() * (1 + 1e-4))       # (m, candidate) pairs, C == 1
+            ms, cs = sorted(set(int(v) for v in near[:, 0])), sorted(set(int(v) for v in near[:, 1]))
+            sub = oracle.c_mse_grid(_np(x), False, np.ascontiguousarray(grid[cs]), [mb[m] for m in ms],
+                                    n_bits=a["n_bits"], sign_bits=a["sign_bits"])
+            pairs = {(m, c): sub[ms.index(m), cs.index(c), 0] for m, c in near.tolist()}
+            (m_ref, c_ref), best = min(pairs.items(), key=lambda kv: (kv[1], kv[0]))
+            assert m_got == m_ref or pairs[(m_got, int(arg_got[0]))] <= best * (1 + 1e-6), (what, pairs, m_got, arg_got)
+            chosen, best = np.array([pairs[(m_got, int(arg_got[0]))]]), np.array([best])
+            arg_ref = np.array([c_ref if m_ref == m_got else -1])
+            st["oracle_candidates_evaluated"] += len(pairs)
+        differ = arg_got != arg_ref
+        ok = chosen <= best * (1 + 1e-6)
+        assert ok.all(), (what, "chosen candidate's oracle MSE not within 1e-6 of the oracle's minimum",
+                          np.argwhere(~ok)[:4].tolist(), chosen[~ok][:4], best[~ok][:4])
+        st["quantizers"] += 1
+        st["channels"] += int(differ.size)
+        st["channels_with_another_candidate"] += int(differ.sum())
+
     def _check_mse_grid(self, a, out, pre):
         x, grid = a["x"].contiguous(), a["grid"]
         assert not pre.any(), "one calibration batch: the table starts at zero, so the increment is the table"
@@ -242,6 +285,7 @@ class LaunchChecker:
         what = f"mse_grid {tuple(x.shape)} per_channel={a['per_channel']}"
         if a["per_channel"] or x.numel() <= MSE_FULL_ORACLE_MAX:
             ref = oracle.c_mse_grid(_np(x), a["per_channel"], _np(grid), mb, **kw)
+            self._check_choice(a, got, ref, what)
             # K4 forms x / s_p as x * 2^frac(bias) * 2^j (fp8q_mse.hip): the quotient can differ from the IEEE division
             # by ~2.4e-7 relative, which moves rint() only for an element that close to the midpoint of two grid
             # points -- where both are (almost) equally far, so that element's squared error changes by <= 2^(M+3) *
@@ -274,6 +318,7 @@ class LaunchChecker:
                     ref = oracle.c_mse_grid(_np(sl), False, _np(grid), mb, **kw)
                     np.testing.assert_allclose(p, ref, rtol=1e-5, atol=1e-30, err_msg=what + f" slice {s}")
             np.testing.assert_allclose(got, acc / n, rtol=2e-6, atol=1e-30, err_msg=what + " vs its slices")
+            self._check_choice(a, got, None, what)
         self.elements += x.numel()
 
 
@@ -337,6 +382,14 @@ def test_every_launch_of_a_full_size_model_pass(tag, n_weight, n_act_min, monkey
     assert torch.isfinite(out).all() and out.shape == (64, 1000)
     c = chk.count
     print(f"\n{tag} @ 64x3x224x224: launches checked {c}; {chk.elements / 1e6:.0f} M elements through the oracle")
+    if tag != "r18":
+        # K4's decision at full size: every quantizer's chosen (mantissa bits, maxval) against the oracle
+        ch = chk.choice
+        print(f"{tag}: MSE decisions checked for {ch['quantizers']} quantizers / {ch['channels']} channels; "
+              f"{ch['channels_with_another_candidate']} channels chose another candidate than the oracle's table "
+              f"(each within 1e-6 relative of the oracle's minimum); {ch['oracle_candidates_evaluated']} near-minimum "
+              f"candidates of long per-tensor rows evaluated by the oracle on the whole tensor")
+        assert ch["quantizers"] == c["mse_grid"] >= n_weight + n_act_min
     if tag == "r18":
         # calibration: one fused min/max+quantize launch per weight tensor, range + quantize per activation
         assert cal["minmax_quantize"] == n_weight, cal
