@@ -462,11 +462,13 @@ def model_configs(ops, dev, only=None):
                 cal = calibrate(m)
                 if only == "c3":
                     with torch.no_grad():
+                        one = timer.measure(lambda: m(x))
                         for _ in range(20):
                             m(x)
                     torch.cuda.synchronize()
-                    return {"c3_resnet18_b64": {"profiled": "1 calibration batch + fix_ranges + 20 default validation forwards",
-                                                "calibration_batch": cal}}
+                    return {"c3_resnet18_b64": {"profiled": "1 calibration batch + fix_ranges + 1 event-timed + 20 plain default "
+                                                            "validation forwards", "calibration_batch": cal,
+                                                "validation_forward_default": one}}
                 out["c3_resnet18_b64"] = dict(
                     workload="ResNet-18, batch 64 x 3 x 224 x 224 synthetic, fp_quantizer E5M2 (8 bit, 2 mantissa bits), "
                              "per-channel current_minmax weights, per-tensor allminmax activations",
@@ -494,10 +496,11 @@ def model_configs(ops, dev, only=None):
                     entry[key] = cal
                     if only is not None:
                         with torch.no_grad():
+                            entry["validation_forward_default"] = timer.measure(lambda: m(x))
                             for _ in range(20):
                                 m(x)
                         torch.cuda.synchronize()
-                        entry["profiled"] = "1 calibration batch + fix_ranges + 20 default validation forwards"
+                        entry["profiled"] = "1 calibration batch + fix_ranges + 1 event-timed + 20 plain default validation forwards"
                         return {"c4_mobilenetv2_b64": entry}
                     if not search:
                         entry["validation_forward"] = validation(m, 3.559)

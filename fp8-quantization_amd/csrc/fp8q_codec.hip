@@ -43,11 +43,10 @@ k_codec_rows(const float *__restrict__ x, uint8_t *__restrict__ codes, float *__
             for (int k = 0; k < 4; ++k) v[k] = xv[g * 4 + k];   // not nontemporal: the line's other quarters hit L1
             uint32_t w[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                w[k] = encode_one(v[k].x, c, lut, pmaxf, f.qthr, M, sign_shift) |
-                       (encode_one(v[k].y, c, lut, pmaxf, f.qthr, M, sign_shift) << 8) |
-                       (encode_one(v[k].z, c, lut, pmaxf, f.qthr, M, sign_shift) << 16) |
-                       (encode_one(v[k].w, c, lut, pmaxf, f.qthr, M, sign_shift) << 24);
+            for (int k = 0; k < 4; ++k) {
+                const float in[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+                w[k] = encode_group4(in, c, lut, pmaxf, f.qthr, M, sign_shift);
+            }
             *reinterpret_cast<uint4 *>(cr + g * 16) = make_uint4(w[0], w[1], w[2], w[3]);
         }
         for (int64_t i = (ng16 << 4) + (int64_t)blockIdx.x * kBlock + tid; i < inner; i += (int64_t)gridDim.x * kBlock)

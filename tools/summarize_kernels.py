@@ -6,6 +6,89 @@ import json
 import os
 import sys
 
+
+
+def model_trace(tag, name, trace_csv, log, title, n_fwd=20):
+    """profiles/<tag>_<name>_kernels.txt from `rocprofv3 --kernel-trace -- python bench.py --only-model-config ...`:
+    the run ends with n_fwd identical validation forwards, i.e. the tail of the dispatch sequence is periodic -- find
+    the period, average the kernels of one forward over the n_fwd repeats, and put this library's share next to the
+    algorithmic bytes the same run counted (bench.py LaunchTimer, the JSON line in `log`)."""
+    rows = sorted(csv.DictReader(open(trace_csv)), key=lambda r: int(r["Start_Timestamp"]))
+    names = [r["Kernel_Name"] for r in rows]
+    dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
+    period = None
+    for k in range(8, len(names) // n_fwd + 1):
+        if all(names[len(names) - (j + 1) * k: len(names) - j * k] == names[len(names) - k:] for j in range(1, n_fwd)):
+            period = k
+            break
+    assert period, "no periodic tail found"
+    info = {}
+    for ln in open(log):
+        if ln.startswith("{"):
+            info = json.loads(ln)
+    entry = next(iter(info.values())) if info else {}
+    mine = lambda n: "anonymous namespace" in n and ("k_" in n)
+    lib = lambda k: short(k) or k
+    per = collections.OrderedDict()
+    tail0 = len(names) - n_fwd * period
+    for i in range(tail0, len(names)):
+        d = per.setdefault(names[i], [0, 0])
+        d[0] += 1
+        d[1] += dur[i]
+    tot_ns = sum(v[1] for v in per.values()) / n_fwd
+    lib_ns = sum(v[1] for k, v in per.items() if mine(k)) / n_fwd
+    lib_n = sum(v[0] for k, v in per.items() if mine(k)) / n_fwd
+    vf = entry.get("validation_forward_default", {})
+    gb = vf.get("algorithmic_gb")
+    out = [f"# rocprofv3 --kernel-trace -- python bench.py --only-model-config {name}   ({tag}, MI355X)",
+           f"# {title}",
+           f"# run = 1 calibration batch + fix_ranges() + 1 event-timed + {n_fwd} plain validation forwards (weights cached, "
+           "BN+ReLU(+residual)+quantizer fused); the kernel sequence of one forward was found as the period of the trace's tail",
+           f"# PER VALIDATION FORWARD (mean of {n_fwd}): {period} kernel dispatches, {tot_ns / 1e6:.3f} ms of kernel time; "
+           f"THIS LIBRARY: {lib_n:.0f} launches, {lib_ns / 1e3:.1f} us = {100 * lib_ns / tot_ns:.1f} % of it"]
+    if gb:
+        out.append(f"# algorithmic bytes of those launches (SURVEY 8d accounting, bench.py LaunchTimer): {gb} GB -> "
+                   f"{gb * 1e6 / (lib_ns / 1e3):.0f} GB/s = {gb * 1e6 / (lib_ns / 1e3) / 8000:.3f} of 8 TB/s "
+                   f"(by HIP events around the same launches in the same run: {vf.get('library_us')} us, {vf.get('gb_s')} GB/s)")
+    out.append("Name,CallsPerForward,UsPerForward,AvgUs")
+    for k, v in sorted(per.items(), key=lambda kv: -kv[1][1]):
+        if mine(k):
+            out.append(f"{lib(k)},{v[0] / n_fwd:g},{v[1] / n_fwd / 1e3:.1f},{v[1] / v[0] / 1e3:.2f}")
+    others = sum(v[1] for k, v in per.items() if not mine(k)) / n_fwd
+    out.append(f"(everything else: MIOpen / rocBLAS / torch),{sum(v[0] for k, v in per.items() if not mine(k)) / n_fwd:g},"
+               f"{others / 1e3:.1f},")
+    # the calibration phase: this library's kernels before the validation forwards (first MIOpen calls excluded by name)
+    cal = collections.OrderedDict()
+    for i in range(0, tail0 - period):
+        if mine(names[i]):
+            d = cal.setdefault(names[i], [0, 0])
+            d[0] += 1
+            d[1] += dur[i]
+    cb = entry.get("calibration_batch") or entry.get("calibration_batch_fixed_mantissa") or entry.get("calibration_batch_mantissa_search_6") or {}
+    out.append(f"# CALIBRATION BATCH + fix_ranges (this library's kernels before the validation forwards): "
+               f"{sum(v[0] for v in cal.values())} launches, {sum(v[1] for v in cal.values()) / 1e3:.1f} us"
+               + (f"; by HIP events: {cb.get('library_us')} us in {cb.get('launches')} calls, wall {cb.get('wall_ms')} ms"
+                  f" (host-side estimator logic included)" if cb else ""))
+    out.append("Name,Calls,TotalUs,AvgUs")
+    for k, v in sorted(cal.items(), key=lambda kv: -kv[1][1]):
+        out.append(f"{lib(k)},{v[0]},{v[1] / 1e3:.1f},{v[1] / v[0] / 1e3:.2f}")
+    path = f"profiles/{tag}_{name}_kernels.txt"
+    open(path, "w").write("\n".join(out) + "\n")
+    print(open(path).read())
+
+
+def short(k):   # (defined again below for the stats summaries; needed here first)
+    if "at::native" in k or "at::cuda" in k:
+        return None
+    return k.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0].replace(", ", ";")
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "model":
+    # python tools/summarize_kernels.py model <tag> <c3|c4|c4_search> <kernel_trace.csv> <stdout log> "<title>"
+    os.makedirs("profiles", exist_ok=True)
+    model_trace(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5], sys.argv[6])
+    sys.exit(0)
+
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 os.makedirs("profiles", exist_ok=True)
 
