@@ -16,8 +16,19 @@ The path has exactly two exchange steps; everything else is embar
 oracle-backed object with the same three functions so that the sharding / collective logic runs
 under gloo without a GPU; the product default never touches the oracle.
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+
+def _multi(group=None):
+    """True when the collective code path has to run: more than one rank -- or FP8Q_DIST_FORCE=1, which runs it on a
+    single rank too (hardware smoke test of the RCCL call sequence on a one-GPU box: every collective of this module
+    executes on the "nccl" backend, with itself as the only peer)."""
+    if not dist.is_initialized():
+        return False
+    return dist.get_world_size(group) > 1 or os.environ.get("FP8Q_DIST_FORCE") == "1"
 
 
 def _default_ops():
@@ -65,7 +76,7 @@ def allreduce_ranges(mins, maxs, group=None):
     Tensor-op version for ranges that already sit in separate tensors (sync_activation_ranges: once per model).  The
     per-batch exchange of calibration does not come through here: there the min/max kernel itself writes the packed
     operand and one kernel unpacks it (ops.minmax(packed=) -> all_reduce -> ops.ranges_unpack)."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not _multi(group):
         return mins, maxs
     n = mins.numel()
     buf = torch.cat([-mins.reshape(-1), maxs.reshape(-1)])
@@ -142,7 +153,7 @@ def calibrate_quantize_sharded(x_local, mbits, n_bits=8, sign_bits=1, state=None
     quantization_manager.py:119-122).  Returns (y_local, state); state = (min, max) tensors [1]."""
     ops = ops or _default_ops()
     cur_min, cur_max = state if state is not None else (None, None)
-    multi = dist.is_initialized() and dist.get_world_size(group) > 1
+    multi = _multi(group)
     packed = ops.new_packed(1, x_local.device) if multi else None
     _mark(timing)
     # the kernel leaves the folded range, K5's maxval and (multi-rank) the packed all-reduce operand
@@ -182,7 +193,7 @@ def quantize_weight_sharded_codes(w, mbits, n_bits=8, sign_bits=1, group=None, o
         mv_shard = w.new_empty(0)
         c_shard = torch.empty(0, dtype=torch.uint8, device=w.device)
     _mark(timing)
-    if world > 1 and C % world == 0:
+    if _multi(group) and C % world == 0:
         # even split: gather straight into the final tensors (no padding, no re-assembly copies)
         codes = torch.empty(w.shape, dtype=torch.uint8, device=w.device)
         maxval = w.new_empty(C)
@@ -237,7 +248,7 @@ def quantize_weight_sharded(w, mbits, n_bits=8, sign_bits=1, maxval=None, group=
         q_shard = shard
         mv_shard = w.new_empty(0)
     _mark(timing)
-    if not gather or world == 1:
+    if not gather or not _multi(group):
         _mark(timing)
         return q_shard, mv_shard
     if C % world == 0:
@@ -296,7 +307,7 @@ def quantize_weights_sharded_bucketed(weights, mbits, n_bits=8, sign_bits=1, gro
     recvs, handles = [None] * len(totals), []
 
     def exchange(bi):
-        if world > 1:
+        if _multi(group):
             recvs[bi] = torch.empty(world * totals[bi], dtype=dt, device=dev0)
             h = dist.all_gather_into_tensor(recvs[bi], sends[bi], group=group, async_op=len(totals) > 1)
             if h is not None:
@@ -320,7 +331,7 @@ def quantize_weights_sharded_bucketed(weights, mbits, n_bits=8, sign_bits=1, gro
         h.wait()
     out = []
     for w, (bi, C, inner, per, off_v, off_m) in zip(weights, geo):
-        if world == 1:      # nothing to re-assemble: views of the packed buffer
+        if world == 1 and not _multi(group):      # nothing to re-assemble: views of the packed buffer
             out.append((recvs[bi][0, off_v: off_v + C * inner].view_as(w), recvs[bi][0, off_m: off_m + C]))
             continue
         parts, mvs = [], []
@@ -356,7 +367,7 @@ def mse_search_sharded(x_local, per_channel, mbit_list, n_bits=8, sign_bits=1, s
         mses = x_local.new_zeros(n_m, N_MSE_GRID, 0)
     elif state is None:
         mx = ops.minmax(x_local, per_channel, want_maxval=True)[2]
-        if shard == "batch" and world > 1:
+        if shard == "batch" and _multi(group):
             dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
         cols = [torch.linspace(0.1 * m, 1.2 * m, N_MSE_GRID) for m in mx.detach().cpu().tolist()]
         grid = torch.stack(cols).to(x_local.device).transpose(0, 1).contiguous()       # [111, C]
@@ -366,7 +377,7 @@ def mse_search_sharded(x_local, per_channel, mbit_list, n_bits=8, sign_bits=1, s
     inc = torch.zeros_like(mses)
     if not empty:
         ops.mse_grid(x_local, per_channel, grid, list(mbit_list), n_bits, sign_bits, inc)
-    if shard == "batch" and world > 1:
+    if shard == "batch" and _multi(group):
         n_local = float(x_local.numel() // grid.shape[1])
         packed = torch.cat([inc.double().reshape(-1) * n_local, torch.tensor([n_local], dtype=torch.float64,
                                                                                device=inc.device)])
@@ -375,7 +386,7 @@ def mse_search_sharded(x_local, per_channel, mbit_list, n_bits=8, sign_bits=1, s
     mses += inc
     best_m_per_ch = mses.min(1)[0].argmin(0)                                           # [C_local]
     votes = best_m_per_ch
-    if shard == "channel" and world > 1:
+    if shard == "channel" and _multi(group):
         sizes = [torch.zeros(1, dtype=torch.int64, device=votes.device) for _ in range(world)]
         dist.all_gather(sizes, torch.tensor([votes.numel()], dtype=torch.int64, device=votes.device), group=group)
         per = int(max(int(s.item()) for s in sizes))

@@ -39,8 +39,8 @@ class RangeEstimatorBase(nn.Module):
         """Data-parallel calibration is on (fp8q.dist.enable_distributed_calibration) and there is more than one rank."""
         if self.dist_group is None or self.per_channel:
             return False
-        import torch.distributed as dist
-        return dist.is_initialized() and dist.get_world_size(self._group()) > 1
+        from fp8q import dist as _fd
+        return _fd._multi(self._group())
 
     def _group(self):
         return None if self.dist_group is True else self.dist_group

@@ -163,3 +163,64 @@ def test_debug_ws_refuses_a_dirty_workspace():
         print("OK_AFTER_CLEAR")
     """, FP8Q_DEBUG_WS="1")
     assert r.returncode == 0 and "REFUSED" in r.stdout and "OK_AFTER_CLEAR" in r.stdout, r.stdout + r.stderr
+
+
+def test_rccl_runs_every_collective_of_the_path_single_rank():
+    """The one-GPU box cannot host two RCCL ranks, but it can run every collective this repo issues on the "nccl"
+    backend with one rank (FP8Q_DIST_FORCE=1 takes the multi-rank code path): the packed range all-reduce of config 5
+    and of the estimators, the fp32 / code all-gathers of the channel-sharded weights, the bucketed exchange with
+    asynchronous handles, both MSE exchanges.  Results must equal the plain single-process ones bit for bit."""
+    r = _sub("""
+        import os, torch, torch.distributed as dist
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 300))
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        assert dist.get_backend() == "nccl"
+        import fp8q
+        from fp8q import dist as fd, ops
+        g = torch.Generator(device=dev).manual_seed(3)
+        x1 = torch.randn(32, 512, 512, device=dev, generator=g)
+        x2 = torch.randn(32, 512, 512, device=dev, generator=g) * 1.5
+        os.environ["FP8Q_DIST_FORCE"] = "0"
+        ref, st = [], None
+        for x in (x1, x2):
+            y, st = fd.calibrate_quantize_sharded(x, 3, 8, 1, state=st)
+            ref.append(y.clone())
+        ref_state = (st[0].clone(), st[1].clone())
+        w = torch.randn(130, 3, 7, 7, device=dev, generator=g) * 0.1
+        rq, rmv = fd.quantize_weight_sharded(w, 2, 8, 1)
+        ws = [torch.randn(*s, device=dev, generator=g) * 0.05 for s in ((64, 3, 7, 7), (128, 64, 3, 3), (10, 128))]
+        rb = fd.quantize_weights_sharded_bucketed(ws, 2, 8, 1)
+        rm = fd.mse_search_sharded(x1[:2], False, [2.0, 3.0], 8, 1, "batch", None)
+        rmc = fd.mse_search_sharded(w, True, [2.0, 3.0], 8, 1, "channel", None)
+        os.environ["FP8Q_DIST_FORCE"] = "1"            # same calls, every collective now runs on RCCL
+        st = None
+        for x, want in zip((x1, x2), ref):
+            y, st = fd.calibrate_quantize_sharded(x, 3, 8, 1, state=st)
+            assert torch.equal(y.view(torch.int32), want.view(torch.int32))
+        assert torch.equal(st[0], ref_state[0]) and torch.equal(st[1], ref_state[1])
+        q, mv = fd.quantize_weight_sharded(w, 2, 8, 1)
+        assert torch.equal(q.view(torch.int32), rq.view(torch.int32)) and torch.equal(mv, rmv)
+        qc, mvc, codes = fd.quantize_weight_sharded_codes(w, 2, 8, 1)
+        assert torch.equal(qc.view(torch.int32), rq.view(torch.int32)) and torch.equal(mvc, rmv) and codes.dtype == torch.uint8
+        for bb in (None, 1 << 16):
+            for (a, b), (c, d) in zip(fd.quantize_weights_sharded_bucketed(ws, 2, 8, 1, bucket_bytes=bb), rb):
+                assert torch.equal(a.view(torch.int32), c.view(torch.int32)) and torch.equal(b, d)
+        m = fd.mse_search_sharded(x1[:2], False, [2.0, 3.0], 8, 1, "batch", None)
+        assert m[1] == rm[1] and torch.allclose(m[0], rm[0], rtol=1e-6)
+        mc = fd.mse_search_sharded(w, True, [2.0, 3.0], 8, 1, "channel", None)
+        assert mc[1] == rmc[1] and torch.equal(mc[0], rmc[0])
+        # the estimators' per-batch exchange (enable_distributed_calibration) on RCCL
+        from quantization.range_estimators import RangeEstimators
+        e1 = RangeEstimators.allminmax.cls(per_channel=False)
+        e2 = RangeEstimators.allminmax.cls(per_channel=False)
+        e2.dist_group = True
+        for x in (x1, x2):
+            a = e1(x); b = e2(x)
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(e1.last_maxval, e2.last_maxval)
+        torch.cuda.synchronize()
+        dist.destroy_process_group()
+        print("RCCL_PATH_OK")
+    """, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    assert r.returncode == 0 and "RCCL_PATH_OK" in r.stdout, (r.stdout + r.stderr)[-3000:]
