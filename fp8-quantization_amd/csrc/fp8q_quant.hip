@@ -998,6 +998,60 @@ k_multi_flat(MultiArgs a)
     }
 }
 
+// Per-channel ranges of MANY tensors in one launch: the estimate-state twin of k_multi_flat.  A model's weight tensors in
+// estimate_ranges state (current_minmax, set_maxval: quantization_manager.py:114-122 per layer, i.e. one fused launch per
+// layer = 21 launches of ~4 us for ResNet-18, or ~23 us each when driven from Python -- launch-bound either way) need
+// every row's min / max before anything can be quantized.  Here one wave owns one row (rows of these tensors are
+// 4 ... 16384 elements: 64 B ... 64 KiB), rows of all tensors are numbered consecutively, and the result
+// maxval[c] = |max(|min_c|, max_c)| (fp8_quantizer.py:236) goes where k_multi_flat will read it: the two launches
+// together are fp8q_multi_minmax_quantize_f32.  Dword loads (rows start at any 4-byte phase), coalesced per wave.
+struct RowsDesc {
+    const float *x;
+    float *maxval;     // [C] output
+    float *row_min;    // [C] output or nullptr
+    float *row_max;
+    int inner;
+    uint32_t row0;     // first global row id of this tensor
+};
+
+struct RowsArgs {
+    int n;
+    uint32_t total_rows;
+    RowsDesc d[kMultiMax];
+};
+
+__global__ void __launch_bounds__(kBlock)
+k_multi_rowmax(RowsArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t row = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (row >= a.total_rows) return;   // whole wave
+    const uint32_t r0 = lane < a.n ? a.d[lane].row0 : 0xffffffffu;
+    const int t = __popcll(__ballot(r0 <= row)) - 1;   // row0 ascends from 0
+    const RowsDesc &d = a.d[t];
+    const int64_t c = row - d.row0;
+    const float *xr = d.x + c * d.inner;
+    MinMax m;
+    mm_init(m);
+    int i = lane;
+    for (; i + 192 < d.inner; i += 256) {   // four loads in flight per lane
+        const float v0 = xr[i], v1 = xr[i + 64], v2 = xr[i + 128], v3 = xr[i + 192];
+        mm_acc(m, v0);
+        mm_acc(m, v1);
+        mm_acc(m, v2);
+        mm_acc(m, v3);
+    }
+    for (; i < d.inner; i += 64) mm_acc(m, xr[i]);
+    mm_wave_reduce(m);
+    if (lane == 0) {
+        float mn = m.mn, mx = m.mx;
+        if (m.nan) mn = mx = __builtin_nanf("");
+        if (d.row_min) d.row_min[c] = mn;
+        if (d.row_max) d.row_max[c] = mx;
+        d.maxval[c] = fabsf(tmax(fabsf(mn), mx));
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Fused K2+K5+K1 for rows of 257..8192 elements (a multiple of 4, 16-byte aligned): the row stays in
 // REGISTERS between the min/max pass and the quantize pass, so the tensor is read once (8 B/element of
@@ -1903,6 +1957,44 @@ int fp8q_multi_quantize_f32(const fp8q_tensor_desc *descs, int n, fp8q_stream_t 
     } catch (...) {
         return (int)hipErrorOutOfMemory;
     }
+}
+
+int fp8q_multi_minmax_quantize_f32(const fp8q_tensor_desc *descs, int n, fp8q_stream_t stream)
+{
+    if (n < 0 || (n > 0 && !descs)) return FP8Q_EINVAL;
+    for (int i = 0; i < n; ++i) {   // per-channel ranges only; nothing is enqueued if a descriptor is bad
+        const fp8q_tensor_desc &t = descs[i];
+        if (t.C < 0 || t.inner < 0 || t.n_maxval != t.C || t.C >= (1ll << 31) || t.inner >= (1ll << 31)) return FP8Q_EINVAL;
+        QFmt f;
+        if (int rc = make_fmt(t.mbits, t.n_bits, t.sign_bits, &f)) return rc;
+        if (t.C > 0 && t.inner > 0 && (!t.x || !t.y || !t.maxval || ((uintptr_t)t.x & 3))) return FP8Q_EINVAL;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    RowsArgs ra;
+    ra.n = 0;
+    ra.total_rows = 0;
+    auto flush = [&]() -> int {
+        if (ra.n == 0) return FP8Q_OK;
+        hipLaunchKernelGGL(k_multi_rowmax, dim3((unsigned)cdiv(ra.total_rows, kBlock / 64)), dim3(kBlock), 0, st, ra);
+        ra.n = 0;
+        ra.total_rows = 0;
+        return launch_rc();
+    };
+    for (int i = 0; i < n; ++i) {
+        const fp8q_tensor_desc &t = descs[i];
+        if (t.C == 0 || t.inner == 0) continue;
+        if (ra.n == kMultiMax || (uint64_t)ra.total_rows + (uint64_t)t.C >= (1ull << 31))
+            if (int rc = flush()) return rc;
+        RowsDesc &d = ra.d[ra.n++];
+        d.x = t.x;
+        d.maxval = const_cast<float *>(t.maxval);   // OUTPUT of this entry point (see include/fp8q.h)
+        d.row_min = d.row_max = nullptr;
+        d.inner = (int)t.inner;
+        d.row0 = ra.total_rows;
+        ra.total_rows += (uint32_t)t.C;
+    }
+    if (int rc = flush()) return rc;
+    return fp8q_multi_quantize_f32(descs, n, stream);   // same stream: reads the ranges just written
 }
 
 int fp8q_multi_plan_create(const fp8q_tensor_desc *descs, int n, fp8q_multi_plan **plan_out)

@@ -316,16 +316,24 @@ def quantize_weights_sharded_bucketed(weights, mbits, n_bits=8, sign_bits=1, gro
         else:
             recvs[bi] = sends[bi].view(1, totals[bi])
 
+    multi = getattr(ops, "multi_minmax_quantize", None)   # ranges + quantize of a whole bucket in two launches
+    pending = []
     for i, (w, (bi, C, inner, per, off_v, off_m)) in enumerate(zip(weights, geo)):
         lo, hi = channel_partition(C, world)[rank]
         if hi > lo:
             shard = w[lo:hi].contiguous()
             dst = sends[bi][off_v: off_v + (hi - lo) * inner].view(shard.shape)    # quantize straight into the send buffer
-            q, mv = _local_minmax_quantize(ops, shard, mbits, n_bits, sign_bits, out=dst)
-            if q.data_ptr() != dst.data_ptr():
-                dst.copy_(q)
-            sends[bi][off_m: off_m + (hi - lo)] = mv
+            if multi is not None:
+                pending.append((shard, sends[bi][off_m: off_m + (hi - lo)], mbits, n_bits, sign_bits, dst))
+            else:
+                q, mv = _local_minmax_quantize(ops, shard, mbits, n_bits, sign_bits, out=dst)
+                if q.data_ptr() != dst.data_ptr():
+                    dst.copy_(q)
+                sends[bi][off_m: off_m + (hi - lo)] = mv
         if i + 1 == len(weights) or geo[i + 1][0] != bi:   # bucket complete: ship it, go on quantizing the next
+            if pending:
+                multi(pending)      # every shard of the bucket: one range launch + one quantize launch, ranges land in place
+                pending = []
             exchange(bi)
     for h in handles:
         h.wait()

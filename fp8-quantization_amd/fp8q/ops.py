@@ -137,6 +137,27 @@ def multi_quantize(items):
     return outs
 
 
+def multi_minmax_quantize(items):
+    """Multi-tensor K2+K5+K1: per-channel current_minmax ranges + quantize of many tensors in TWO launches
+    (fp8q_multi_minmax_quantize_f32).  items: iterable of (x, maxval_out, mbits[, n_bits[, sign_bits[, out]]]);
+    maxval_out is a [C] CUDA fp32 tensor that RECEIVES the ranges.  Returns the list of outputs (bit-identical to
+    minmax_quantize() on each item)."""
+    items = [tuple(it) for it in items]
+    if not items:
+        return []
+    for it in items:
+        if it[1].numel() != (it[0].shape[0] if it[0].dim() > 0 else 1) or not it[1].is_contiguous():
+            raise Fp8qError("multi_minmax_quantize: maxval_out must be a contiguous [C] tensor")
+    descs, outs, keep = _pack_descs(items)
+    for (x, mv), it in zip(keep, items):
+        if mv.data_ptr() != it[1].data_ptr():
+            raise Fp8qError("multi_minmax_quantize: maxval_out must be contiguous (a copy would receive the ranges)")
+    with _on_device(keep[0][0]):
+        rc = lib().fp8q_multi_minmax_quantize_f32(descs, len(items), _stream(keep[0][0]))
+    check(rc, "fp8q_multi_minmax_quantize_f32")
+    return outs
+
+
 class MultiPlan:
     """Prepared multi-tensor K1 (fp8q_multi_plan_*): the descriptors of `items` are validated and packed once;
     launch() re-quantizes every tensor into its output with one ctypes call and one kernel launch per 32 tensors.

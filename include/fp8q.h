@@ -222,6 +222,17 @@ typedef struct fp8q_tensor_desc {
 int fp8q_multi_quantize_f32(const fp8q_tensor_desc *descs, int n, fp8q_stream_t stream);
 
 /*
+ * Multi-tensor K2+K5+K1 -- all weight tensors of a model in ESTIMATE state (per-channel current_minmax with
+ * set_maxval: QuantizationManager.forward, quantization_manager.py:114-122, once per layer in the reference): one launch
+ * finds every row's range and WRITES maxval[c] = |max(|min_c|, max_c)| into each descriptor's `maxval` buffer ([C];
+ * n_maxval must equal C -- the pointer is an output here despite its const type), a second one is
+ * fp8q_multi_quantize_f32 on the same descriptors.  Two launches for a whole model instead of one per layer; results
+ * bit-identical to fp8q_minmax_quantize_f32 per tensor.  This is what a rank of the channel-sharded multi-GPU weight
+ * path runs on its shards before the all-gather (fp8q.dist.quantize_weights_sharded_bucketed).
+ */
+int fp8q_multi_minmax_quantize_f32(const fp8q_tensor_desc *descs, int n, fp8q_stream_t stream);
+
+/*
  * Prepared multi-tensor launch.  fp8q_multi_quantize_f32 validates, classifies and packs its descriptors on every
  * call; for a fixed set of tensors (a model's weights after fix_ranges(), re-quantized whenever the weights change)
  * that work is done ONCE here and a call costs one kernel launch per 32 tensors.  The plan is a small HOST object

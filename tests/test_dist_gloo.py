@@ -302,6 +302,30 @@ def _bucket_job(rank, world, bucket_bytes=None):
     return [(q.numpy(), mv.numpy()) for q, mv in out]
 
 
+class MultiOracleOps(OracleOps):
+    """+ the multi-tensor range+quantize entry point (what fp8q.ops has): the bucketed path takes its two-launch branch"""
+    calls = [0]
+
+    @classmethod
+    def multi_minmax_quantize(cls, items):
+        cls.calls[0] += 1
+        outs = []
+        for x, mv_out, mbits, n_bits, sign_bits, out in items:
+            q, _, _, mv = OracleOps.minmax_quantize(x, mbits, n_bits, sign_bits)
+            mv_out.copy_(mv)
+            out.copy_(q)
+            outs.append(out)
+        return outs
+
+
+def _bucket_job_multi(rank, world):
+    from fp8q import dist as fd
+    out = fd.quantize_weights_sharded_bucketed([torch.from_numpy(w) for w in _bucket_weights()], 2, 8, 1, ops=MultiOracleOps,
+                                               bucket_bytes=600)
+    assert MultiOracleOps.calls[0] == 3, MultiOracleOps.calls      # one call per bucket, not one per tensor
+    return [(q.numpy(), mv.numpy()) for q, mv in out]
+
+
 def _bucket_job_small(rank, world):
     return _bucket_job(rank, world, bucket_bytes=600)      # 5 tensors -> 3 buckets, async all-gathers
 
@@ -315,7 +339,7 @@ def test_bucketed_weight_quantization_one_all_gather():
     only rank 0 owns), or packed into several buckets whose all-gathers are launched asynchronously while the next
     bucket is quantized: every rank ends up with exactly the single-process quantized tensors and ranges."""
     ws = _bucket_weights()
-    for job in (_bucket_job, _bucket_job_small, _bucket_job_tiny):
+    for job in (_bucket_job, _bucket_job_small, _bucket_job_tiny, _bucket_job_multi):
         for res in run(job):
             for w, (q, mv) in zip(ws, res):
                 mn, mx = oracle.c_minmax(w, True)

@@ -522,6 +522,44 @@ def test_multi_tensor_quantize(ops):
         ops.multi_quantize([(items[0][0], items[0][1][:3], 2, 8, 1)])   # wrong maxval length
 
 
+def test_multi_tensor_minmax_quantize(ops):
+    """fp8q_multi_minmax_quantize_f32: per-channel current_minmax ranges + quantize of a whole model's weight tensors in
+    two launches -- ranges and values bit-identical to the oracle and to one fused fp8q_minmax_quantize_f32 per tensor;
+    short / odd / long rows, a zero channel (NaN quirk), a NaN element, an unaligned view, an empty tensor, > 32 tensors."""
+    rng = np.random.RandomState(6)
+    shapes = [(64, 3, 7, 7), (64, 64, 3, 3), (128, 64, 1, 1), (512, 512, 3, 3), (1000, 512), (32, 1, 3, 3), (7, 5), (3, 4099),
+              (1, 4), (0, 9), (5, 20000), (24, 144, 1, 1)] + [(16, 10 + i) for i in range(24)]
+    items, xs = [], []
+    for i, shp in enumerate(shapes):
+        x = (rng.randn(*shp) * 0.1).astype(np.float32)
+        if i == 1:
+            x[3] = 0.0                      # all-zero channel: maxval 0 -> NaN channel, as in the reference
+        if i == 3:
+            x[7, 5, 1, 1] = np.nan          # NaN anywhere in a row: the row's range is NaN
+        xs.append(x)
+        items.append((dev(x) if x.size else torch.empty(shp, device="cuda"),
+                      torch.full((shp[0],), -7.0, device="cuda"), (2, 3, 4)[i % 3], 8, 1))
+    base = dev((rng.randn(64 * 147 + 1) * 0.1).astype(np.float32))
+    items.append((base[1:].view(64, 147), torch.empty(64, device="cuda"), 2, 8, 1))
+    xs.append(base[1:].view(64, 147).cpu().numpy())
+    outs = ops.multi_minmax_quantize(items)
+    assert len(outs) == len(items)
+    for i, (it, y, x) in enumerate(zip(items, outs, xs)):
+        if x.size == 0:
+            assert y.numel() == 0
+            continue
+        mn, mx = oracle.c_minmax(x, True)
+        mv = oracle.c_absmax(mn, mx)
+        got_mv = it[1].cpu().numpy()
+        assert np.array_equal(np.isnan(got_mv), np.isnan(mv)) and np.array_equal(got_mv[~np.isnan(mv)], mv[~np.isnan(mv)]), i
+        assert_bit_exact(y.cpu().numpy(), oracle.c_quantize(x, mv, it[2], 8, 1), f"multi minmax item {i} {x.shape}")
+        if x.shape[1:] and int(np.prod(x.shape[1:])) <= ops.fused_max_inner():
+            y1, _, _, mv1 = ops.minmax_quantize(it[0], it[2], 8, 1)
+            assert_bit_exact(y.cpu().numpy(), y1.cpu().numpy(), f"multi vs fused {i}")
+    with pytest.raises(Exception):
+        ops.multi_minmax_quantize([(items[0][0], torch.empty(3, device="cuda"), 2, 8, 1)])   # wrong range length
+
+
 def test_more_than_2_31_elements(ops):
     """Maximum sizes: a per-tensor tensor with > 2^31 elements (8.6 GB in, 8.6 GB out) exercises the
     64-bit indexing; chunks quantized separately must give the same bits, min/max must see the planted
