@@ -377,9 +377,10 @@ def mse_search_sharded(x_local, per_channel, mbit_list, n_bits=8, sign_bits=1, s
         mx = ops.minmax(x_local, per_channel, want_maxval=True)[2]
         if shard == "batch" and _multi(group):
             dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
-        cols = [torch.linspace(0.1 * m, 1.2 * m, N_MSE_GRID) for m in mx.detach().cpu().tolist()]
-        grid = torch.stack(cols).to(x_local.device).transpose(0, 1).contiguous()       # [111, C]
-        mses = torch.zeros(n_m, N_MSE_GRID, len(cols), device=x_local.device)
+        from quantization.estimators import linspace_columns
+        cols = linspace_columns(mx.detach().cpu().tolist(), N_MSE_GRID)                # [C, 111], == torch.linspace per channel
+        grid = cols.to(x_local.device).transpose(0, 1).contiguous()                    # [111, C]
+        mses = torch.zeros(n_m, N_MSE_GRID, cols.shape[0], device=x_local.device)
     else:
         grid, mses = state
     inc = torch.zeros_like(mses)

@@ -135,6 +135,53 @@ class RunningMinMaxEstimator(RangeEstimatorBase):
         return self._update(x)
 
 
+def _fma_f32(a, b, c):
+    """fl32(a * b + c) with ONE rounding, for float32 arrays.  The product of two floats is exact in double; the double
+    sum t is rounded once more when it is narrowed to float32, which goes wrong only if t sits exactly on a float32
+    rounding midpoint (low 29 fraction bits == 0x10000000) while the exact sum does not -- those (rare) elements are
+    redone with the sum rounded to ODD (exact residual by TwoSum), after which the narrowing rounds correctly."""
+    p = a.astype(np.float64) * b.astype(np.float64)
+    c = np.broadcast_to(c.astype(np.float64), p.shape)
+    t = p + c
+    risky = (t.view(np.int64) & 0x1FFFFFFF) == 0x10000000
+    if risky.any():
+        pr, cr, tr = p[risky], c[risky], t[risky]
+        bb = tr - pr
+        err = (pr - (tr - bb)) + (cr - bb)                  # exact: p + c == t + err
+        other = np.nextafter(tr, np.where(err > 0, np.inf, -np.inf))
+        t = t.copy()
+        t[risky] = np.where(err == 0, tr, other)            # t is even here (midpoint pattern): the odd neighbour on err's side
+    return t.astype(np.float32)
+
+
+def linspace_columns(mx_host, steps):
+    """[C, steps] float32: row c == torch.linspace(0.1 * m_c, 1.2 * m_c, steps) (python-float products, as the reference
+    computes its MSE search grid per channel, range_estimators.py:296-305) WITHOUT one torch call per channel (15 us
+    each: 0.3 s of host time for MobileNetV2's 18 119 channels).  ATen's CPU kernel for fewer steps than its parallel
+    grain evaluates element i as fl32(start + step * i) for i < steps // 2 and fl32(end - step * (steps - 1 - i)) after,
+    each with a fused multiply-add; that formula is reproduced here and CHECKED against torch.linspace itself on a few
+    channels of every call -- on any difference (another ATen build, a CPU without FMA) the per-channel loop is used."""
+    m = np.asarray(mx_host, np.float64)
+    with np.errstate(all="ignore"):
+        start, end = (0.1 * m).astype(np.float32), (1.2 * m).astype(np.float32)
+        step = ((end - start) / np.float32(steps - 1)).astype(np.float32)
+        i = np.arange(steps, dtype=np.float32)
+        half = steps // 2
+        lo = _fma_f32(step[:, None], i[None, :half], start[:, None])
+        hi = _fma_f32(-step[:, None], (np.float32(steps - 1) - i[None, half:]), end[:, None])
+    cols = np.concatenate([lo, hi], 1)
+    probe = sorted({0, len(m) // 2, len(m) - 1, int(np.argmax(m)), int(np.argmin(m))})
+    try:
+        ok = np.isfinite(m).all() and np.isfinite(cols).all() and steps >= 2 and all(
+            np.array_equal(torch.linspace(0.1 * float(m[c]), 1.2 * float(m[c]), steps).numpy().view(np.int32),
+                           cols[c].view(np.int32)) for c in probe)
+    except Exception:       # e.g. a range that overflows float32: let the per-channel loop raise what the reference raises
+        ok = False
+    if not ok:
+        return torch.stack([torch.linspace(0.1 * v, 1.2 * v, steps) for v in m.tolist()])
+    return torch.from_numpy(cols)
+
+
 class FP_MSE_Estimator(RangeEstimatorBase):
     """Grid search over 111 clipping values (x 1..n mantissa widths) minimising the MSE.
 
@@ -168,9 +215,9 @@ class FP_MSE_Estimator(RangeEstimatorBase):
                 import torch.distributed as dist
                 dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=self._group())
             mx_host = mx.detach().cpu().tolist()            # one sync, first batch only
-            cols = [torch.linspace(0.1 * m, 1.2 * m, self.N_GRID) for m in mx_host]
-            self.search_grid = torch.stack(cols).to(x.device).transpose(0, 1).contiguous()  # [111, C]
-            self.mses = torch.zeros(n_m, self.N_GRID, len(cols), device=x.device)
+            cols = linspace_columns(mx_host, self.N_GRID)                                   # [C, 111], == torch.linspace per channel
+            self.search_grid = cols.to(x.device).transpose(0, 1).contiguous()               # [111, C]
+            self.mses = torch.zeros(n_m, self.N_GRID, cols.shape[0], device=x.device)
         return self.search_grid, self.mses
 
     def forward(self, x):

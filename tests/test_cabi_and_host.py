@@ -206,3 +206,22 @@ def test_torch_free_cabi_program_runs():
     exe = build_smoke()
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "CABI SMOKE PASSED" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_mse_search_grid_columns_equal_torch_linspace():
+    """FP_MSE_Estimator builds its [111, C] search grid with one numpy pass instead of one torch.linspace call per
+    channel (range_estimators.py:296-305 loops in Python): every row must be torch.linspace's, bit for bit -- across
+    magnitudes, step counts, zero / denormal maxima; non-finite input falls back to the per-channel loop."""
+    import numpy as np
+    import torch
+    from quantization.estimators import linspace_columns
+    rng = np.random.RandomState(7)
+    m = np.concatenate([np.exp(rng.uniform(-30, 30, 3000)), rng.rand(2000), [0.0, 1e-45, 1.0, 2.0 ** -126, 1e-40]])
+    for steps in (2, 7, 111, 1000):
+        got = linspace_columns(m.tolist(), steps).numpy()
+        pick = range(len(m)) if steps == 111 else range(0, len(m), 37)
+        for c in pick:
+            ref = torch.linspace(0.1 * float(m[c]), 1.2 * float(m[c]), steps).numpy()
+            assert np.array_equal(ref.view(np.int32), got[c].view(np.int32)), (steps, c, m[c])
+    got = linspace_columns([1.0, float("inf")], 111)
+    assert torch.equal(got[0], torch.linspace(0.1, 1.2, 111)) and not torch.isfinite(got[1]).any()
