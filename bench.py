@@ -71,6 +71,46 @@ def ev_time(fn, iters, warm=2):
     return ts[len(ts) // 2], sum(ts) / len(ts)
 
 
+def measure_traffic(timeout_s=240):
+    """HBM bytes per launch of the headline kernel from the PMC counters, measured NOW: two rocprofv3 passes (FETCH_SIZE
+    and WRITE_SIZE cannot share a pass: 3 + 2 of the 4 TCC slots) over a 3-step, headline-only run of this same script,
+    corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE counts 64 B per 128-B request
+    of a wide coalesced stream: x2; KB -> x1024).  Returns (bytes, detail) or (None, why)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if prof is None:
+        return None, "rocprofv3 not found"
+    vals = {}
+    env = dict(os.environ, TMPDIR="/tmp", FP8Q_BENCH_PREWARM_S="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = tempfile.mkdtemp(prefix="fp8q_pmc_", dir="/tmp")
+        cmd = [prof, "--pmc", ctr, "--output-format", "csv", "-d", out, "-o", "b", "--", sys.executable,
+               os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--no-extras", "--no-cpu-baseline",
+               "--no-north-star-path", "--no-traffic"]
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+            got = []
+            for path in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(path)):
+                    if "k_rows_flat<0" in r["Kernel_Name"] and r["Counter_Name"] == ctr:
+                        got.append(float(r["Counter_Value"]))
+            if not got:
+                return None, f"no {ctr} samples of the headline kernel"
+            vals[ctr] = (sum(got) / len(got), len(got))
+        except Exception as e:   # noqa: BLE001 -- a profiler problem must not cost the bench line
+            return None, f"{ctr} pass failed: {e!r}"[:200]
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    fetch, write = vals["FETCH_SIZE"][0] * 1024 * 2, vals["WRITE_SIZE"][0] * 1024
+    return fetch + write, dict(fetch_bytes=round(fetch), write_bytes=round(write), launches_sampled=vals["FETCH_SIZE"][1])
+
+
 def cpu_baseline(x_cpu, maxval_cpu):
     """CPU oracle on a bounded sample of the same workload (whole channels), all host cores.
 
@@ -639,6 +679,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="do not measure roofline.traffic live (two short rocprofv3 --pmc passes of this script, N = 1 only); "
+                         "the figure recorded under profiles/ is reported instead")
     ap.add_argument("--no-model-configs", action="store_true",
                     help="skip extras.c3_resnet18_b64 / extras.c4_mobilenetv2_b64 (BASELINE configs 3 and 4)")
     ap.add_argument("--only-model-config", choices=["c3", "c4", "c4_search"], default=None,
@@ -742,11 +785,20 @@ def main():
     if rank == 0:
         traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
+        if world == 1 and not args.no_traffic:
+            traffic, detail = measure_traffic()
+            if traffic is not None:
+                traffic_source = ("measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over "
+                                  "`bench.py --steps 3 --warmup 1` of the same kernel; FETCH x 1024 x 2 (gfx950 correction) + "
+                                  f"WRITE x 1024; {detail}")
+            else:
+                traffic_source = f"live PMC passes unavailable ({detail}); "
+        if traffic is None and os.path.exists(tpath):
             try:
                 traffic = json.load(open(tpath)).get("k1_bytes_per_launch")
-                traffic_source = ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of "
-                                  "this command, recorded when the profile was taken -- NOT measured in this run")
+                traffic_source = (traffic_source or "") + (
+                    "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of "
+                    "this command, recorded when the profile was taken -- NOT measured in this run")
             except Exception:
                 traffic = None
         line = {

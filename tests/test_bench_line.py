@@ -72,6 +72,9 @@ def test_single_gpu_line_carries_roofline_cpu_baseline_and_model_configs():
     assert line["n_gpus"] == 1 and line["steps"] == 20 and line["ranks_seen"] == 1
     rf = line["roofline"]
     assert rf["bound"] == "hbm" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["frac"] > 0.5
+    # HBM traffic from the PMC counters, measured by the run itself (two rocprofv3 --pmc passes): no wasted re-reads
+    assert rf["traffic_source"].startswith("measured in this run"), rf["traffic_source"]
+    assert 0.98 < rf["traffic"] / rf["algorithmic_bytes_per_launch"] < 1.05
     cb = line["cpu_baseline"]
     assert cb["kind"] == "port" and cb["gpu_output_bit_exact_on_sample"] is True
     assert cb["reference_equivalent"]["kind"] == "reference-equivalent" and cb["reference_equivalent"]["value"] > 0

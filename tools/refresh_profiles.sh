@@ -8,7 +8,7 @@ R=$PWD
 export TMPDIR=/tmp
 mkdir -p $R/gpurun_out
 python bench.py 2> $R/gpurun_out/${TAG}_bench.err | tail -1 > $R/gpurun_out/${TAG}_bench_n1.json
-HEAD="--no-extras --no-cpu-baseline --no-north-star-path"     # the headline kernel alone
+HEAD="--no-extras --no-cpu-baseline --no-north-star-path --no-traffic"     # the headline kernel alone
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_kt -o bench -- python $R/bench.py $HEAD > $R/gpurun_out/${TAG}_kt.log 2>&1
 export FP8Q_BENCH_PREWARM_S=0
