@@ -40,7 +40,7 @@ __device__ __forceinline__ float res_act(float t, float r, const AffineArgs &a)
 // bit-identical on 100 % of elements): alpha = invstd * gamma, beta' = fma(-mean, alpha, beta),
 // out = fma(x, alpha, beta'); {alpha, beta'} of the planes a piece overlaps are staged in LDS per
 // step, the plane of a 16-byte group comes from one 32-bit magic division of its piece-local offset.
-template <bool NT>
+template <bool NT, int U>
 __global__ void __launch_bounds__(kBlock)
 k_affine_act(const float *__restrict__ x, const float *__restrict__ res, float *__restrict__ y,
              const float *__restrict__ mean, const float *__restrict__ invstd,
@@ -51,7 +51,6 @@ k_affine_act(const float *__restrict__ x, const float *__restrict__ res, float *
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float2 *cst = reinterpret_cast<float2 *>(smem);   // [cpp] {alpha, beta'} (has_bn only)
     const int tid = threadIdx.x;
-    constexpr int U = 4;
     const Chan cfull = make_chan(maxval[0], f);
     for (int i = tid; i <= f.pmax; i += kBlock) lut[i] = lut_entry(cfull, i, f.M);
     const ChanLite c = lite(cfull);
@@ -247,7 +246,7 @@ static int affine_args(int64_t N, int64_t C, int64_t HW, int act, bool has_bn, b
     return FP8Q_OK;
 }
 
-static void affine_grid(int64_t N, const AffineArgs &a, bool quant, int64_t *bx, int64_t *by)
+static void affine_grid(int64_t N, const AffineArgs &a, bool quant, int64_t *bx, int64_t *by, int U = 4)
 {
     const int64_t ymax = quant ? 65535 : 65534;   // the calibration twin adds one block row for its reducer
     *by = N < ymax ? N : ymax;
@@ -255,7 +254,7 @@ static void affine_grid(int64_t N, const AffineArgs &a, bool quant, int64_t *bx,
     if (quant) {
         // one 16 KiB piece per block while the grid stays below 64 K blocks; a partial last piece of the
         // image gets no block of its own
-        const int64_t pieces = nvec / (kBlock * 4) > 0 ? nvec / (kBlock * 4) : 1;
+        const int64_t pieces = nvec / (kBlock * U) > 0 ? nvec / (kBlock * U) : 1;
         *bx = balanced_blocks(pieces, (pieces * *by > 4096 ? 65536 : kTargetBlocks) / *by);   // K1's grid rule
     } else {
         // read-only twin: a persistent grid of <= 2048 blocks with 4 KiB steps measured best (36 us against
@@ -280,18 +279,28 @@ int fp8q_affine_act_quantize_f32(const float *x, const float *residual, float *y
     if (N == 0) return FP8Q_OK;
     if (!x || !y || !maxval) return FP8Q_EINVAL;
     if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual) & 15) return FP8Q_EINVAL;
+    static const int64_t small_elems = [] {   // FP8Q_EPI_SMALL_M: tensors below this many M elements run 4 KiB pieces per block
+        const char *e = getenv("FP8Q_EPI_SMALL_M");
+        const long v = e ? atol(e) : -1;
+        return (int64_t)(v >= 0 ? v : 8) << 20;
+    }();
+    // cache-sized tensors are latency-bound: four times as many blocks with a quarter of the piece each
+    const bool small = N * a.image < small_elems;
     for (int64_t n0 = 0; n0 < N; n0 += 65535) {
         int64_t bx, by;
-        affine_grid(N - n0, a, true, &bx, &by);
+        affine_grid(N - n0, a, true, &bx, &by, small ? 1 : 4);
         const size_t shm = has_bn ? (size_t)a.cpp * sizeof(float2) : 0;
+        const dim3 g((unsigned)bx, (unsigned)by), b(kBlock);
+        const float *rp = residual ? residual + n0 * a.image : nullptr;
         if (N * a.image * 4 >= kNtBytes)
-            hipLaunchKernelGGL((k_affine_act<true>), dim3((unsigned)bx, (unsigned)by), dim3(kBlock), shm,
-                               (hipStream_t)stream, x + n0 * a.image, residual ? residual + n0 * a.image : nullptr,
-                               y + n0 * a.image, mean, invstd, gamma, beta, maxval, f, a);
+            hipLaunchKernelGGL((k_affine_act<true, 4>), g, b, shm, (hipStream_t)stream, x + n0 * a.image, rp, y + n0 * a.image,
+                               mean, invstd, gamma, beta, maxval, f, a);
+        else if (small)
+            hipLaunchKernelGGL((k_affine_act<false, 1>), g, b, shm, (hipStream_t)stream, x + n0 * a.image, rp, y + n0 * a.image,
+                               mean, invstd, gamma, beta, maxval, f, a);
         else
-            hipLaunchKernelGGL((k_affine_act<false>), dim3((unsigned)bx, (unsigned)by), dim3(kBlock), shm,
-                               (hipStream_t)stream, x + n0 * a.image, residual ? residual + n0 * a.image : nullptr,
-                               y + n0 * a.image, mean, invstd, gamma, beta, maxval, f, a);
+            hipLaunchKernelGGL((k_affine_act<false, 4>), g, b, shm, (hipStream_t)stream, x + n0 * a.image, rp, y + n0 * a.image,
+                               mean, invstd, gamma, beta, maxval, f, a);
     }
     return launch_rc();
 }
