@@ -30,7 +30,9 @@ namespace {
 // ---------------------------------------------------------------------------------------------
 // K1 rows: blockIdx.y = row (channel), blockIdx.x strides over the row.  {s, 1/s} table in LDS.
 // ---------------------------------------------------------------------------------------------
-template <bool NT>
+// U = 16-byte groups per lane and step: 4 (16 KiB pieces per block), or 1 for cache-sized tensors, whose launches are
+// latency-bound and want four times the blocks (as k_affine_act: fp8q_epilogue.hip)
+template <bool NT, int U>
 __global__ void __launch_bounds__(kBlock)
 k_quant_rows(const float *__restrict__ x, float *__restrict__ y, int64_t inner,
              const float *__restrict__ maxval, int per_channel, QFmt f)
@@ -60,28 +62,28 @@ k_quant_rows(const float *__restrict__ x, float *__restrict__ y, int64_t inner,
     const vf4 *xv = reinterpret_cast<const vf4 *>(xr + head);
     vf4 *yv = reinterpret_cast<vf4 *>(yr + head);
 
-    const int64_t step = (int64_t)gridDim.x * (kBlock * kUnroll);
-    for (int64_t base = (int64_t)blockIdx.x * (kBlock * kUnroll); base < nvec; base += step) {
-        if (base + kBlock * kUnroll <= nvec) {
-            vf4 v[kUnroll];
+    const int64_t step = (int64_t)gridDim.x * (kBlock * U);
+    for (int64_t base = (int64_t)blockIdx.x * (kBlock * U); base < nvec; base += step) {
+        if (base + kBlock * U <= nvec) {
+            vf4 v[U];
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u) v[u] = ld16<NT>(xv + base + u * kBlock + tid);
-            float e[kUnroll * 4];
+            for (int u = 0; u < U; ++u) v[u] = ld16<NT>(xv + base + u * kBlock + tid);
+            float e[U * 4];
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u) {
+            for (int u = 0; u < U; ++u) {
                 e[4 * u + 0] = v[u].x;
                 e[4 * u + 1] = v[u].y;
                 e[4 * u + 2] = v[u].z;
                 e[4 * u + 3] = v[u].w;
             }
-            quant_group<kUnroll * 4>(e, c, lut, pmaxf, qthr);
+            quant_group<U * 4>(e, c, lut, pmaxf, qthr);
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u) {
+            for (int u = 0; u < U; ++u) {
                 vf4 w = {e[4 * u + 0], e[4 * u + 1], e[4 * u + 2], e[4 * u + 3]};
                 st16<NT>(yv + base + u * kBlock + tid, w);
             }
         } else {
-            for (int u = 0; u < kUnroll; ++u) {
+            for (int u = 0; u < U; ++u) {
                 const int64_t i = base + u * kBlock + tid;
                 if (i < nvec) {
                     const vf4 w = ld16<NT>(xv + i);
@@ -1659,16 +1661,25 @@ int fp8q_quantize_f32(const float *x, float *y, int64_t C, int64_t inner, const 
     }();
     // One 16 KiB piece per block for big tensors (measured: 6.3 TB/s against 5.8 with a persistent grid of 2048
     // blocks at 1 GiB; small tensors prefer the smaller grid); a partial last piece of a row gets no block of its own.
-    const int64_t pieces = inner / (4 * kBlock * kUnroll) > 0 ? inner / (4 * kBlock * kUnroll) : 1;
-    const int64_t total_cap = k1_blocks_env > 0 ? k1_blocks_env : (pieces * C > 4096 ? 65536 : kTargetBlocks);
+    static const int64_t small_elems = [] {   // FP8Q_K1_SMALL_M: tensors below this many Mi elements run 4 KiB pieces per block
+        const char *e = getenv("FP8Q_K1_SMALL_M");
+        const long v = e ? atol(e) : -1;
+        return (int64_t)(v >= 0 ? v : 8) << 20;
+    }();
+    const bool small = C == 1 && inner < small_elems;   // per tensor only: a per-channel block also builds its row's table
+    const int U = small ? 1 : kUnroll;
+    const int64_t pieces = inner / (4 * kBlock * U) > 0 ? inner / (4 * kBlock * U) : 1;
+    const int64_t total_cap = k1_blocks_env > 0 ? k1_blocks_env : (pieces * C > 4096 ? 65536 : (small ? 4 : 1) * kTargetBlocks);
     const int64_t cap = total_cap / C > 0 ? total_cap / C : 1;
     const int64_t bx = balanced_blocks(pieces, cap);
     if (aligned) {
         const dim3 g((unsigned)bx, (unsigned)C), b(kBlock);
         if (nt)
-            hipLaunchKernelGGL(k_quant_rows<true>, g, b, 0, st, x, y, inner, maxval, per_channel, f);
+            hipLaunchKernelGGL((k_quant_rows<true, kUnroll>), g, b, 0, st, x, y, inner, maxval, per_channel, f);
+        else if (small)
+            hipLaunchKernelGGL((k_quant_rows<false, 1>), g, b, 0, st, x, y, inner, maxval, per_channel, f);
         else
-            hipLaunchKernelGGL(k_quant_rows<false>, g, b, 0, st, x, y, inner, maxval, per_channel, f);
+            hipLaunchKernelGGL((k_quant_rows<false, kUnroll>), g, b, 0, st, x, y, inner, maxval, per_channel, f);
     } else {
         int64_t bs = cdiv(inner, kBlock);
         if (bs > cap * 4) bs = cap * 4;
