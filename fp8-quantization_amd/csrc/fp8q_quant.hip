@@ -1365,10 +1365,17 @@ int launch_rows_flat(int mode, const float *x, float *y, int64_t C, int64_t inne
     static const int grid_env = [] {
         const char *e = getenv("FP8Q_FLAT_GRID");
         const int v = e ? atoi(e) : 0;
-        return v >= 1 ? v : 32768;
+        return v >= 1 ? v : 0;
     }();
+    // Tensors beyond the caches: one tile per block (a grid of tens of thousands of short blocks streams 5-10 % faster
+    // than a persistent one).  Cache-sized tensors (K1, <= 16384 chunks = 64 MiB): one tile per block means 1..16 ROUNDS of
+    // the 1024 resident blocks, and a fractional last round is lost time (2352 tiles = 2.3 rounds pay for 3) -- a
+    // resident grid striding over the chunks hands every block the same number +- 1 instead: [2^17,147] 40.2 -> 35.1 us,
+    // [2^18,147] 66.2 -> 61.2, [30000,1152] 58.7 -> 51.4, [100000,576] 87.0 -> 83.1; at 36864 chunks it already loses
+    // on 576 / 1152-element rows (207 -> 216..241 us), on the headline (75264 chunks) 408 -> 437..477.
     int64_t blocks = cdiv(a.nchunks, nch);
-    if (blocks > grid_env) blocks = grid_env;
+    const int64_t grid_cap = grid_env ? grid_env : ((mode == kModeQuant && a.nchunks <= 16384) ? 1024 : 32768);
+    if (blocks > grid_cap) blocks = grid_cap;
     const size_t shmem = (size_t)kFlatMaxCh * sizeof(ChunkInfo) + (size_t)a.rpc * nch * per_row;
     const dim3 g((unsigned)blocks), b(kBlock);
     if (mode == kModeQuant) {
