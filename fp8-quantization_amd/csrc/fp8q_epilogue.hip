@@ -255,7 +255,18 @@ static void affine_grid(int64_t N, const AffineArgs &a, bool quant, int64_t *bx,
         // one 16 KiB piece per block while the grid stays below 64 K blocks; a partial last piece of the
         // image gets no block of its own
         const int64_t pieces = nvec / (kBlock * U) > 0 ? nvec / (kBlock * U) : 1;
-        *bx = balanced_blocks(pieces, (pieces * *by > 4096 ? 65536 : kTargetBlocks) / *by);   // K1's grid rule
+        static const int64_t cap_env = [] {   // FP8Q_EPI_GRID: total block cap of the quantizing epilogue kernel (experiments)
+            const char *e = getenv("FP8Q_EPI_GRID");
+            const long v = e ? atol(e) : 0;
+            return (int64_t)(v > 0 ? v : 0);
+        }();
+        // tensors beyond the caches: one piece per block; cache-sized ones (< 64 MiB): a resident grid of 2048 blocks with
+        // the same number of pieces each -- one piece per block is then a handful of ROUNDS of the resident blocks, and a
+        // fractional last round is lost time ([64,144,28,28] 20.2 -> 17.0 us, [64,24,56,56] 15.8 -> 13.8, [64,64,56,56]
+        // 25.2 -> 23.7, [64,128,28,28] 18.5 -> 16.9 by rocprofv3)
+        const bool cache_sized = N * a.image * 4 < kNtBytes;
+        const int64_t total = cap_env ? cap_env : ((cache_sized || pieces * *by <= 4096) ? kTargetBlocks : 65536);
+        *bx = balanced_blocks(pieces, total / *by > 0 ? total / *by : 1);   // K1's grid rule
     } else {
         // read-only twin: a persistent grid of <= 2048 blocks with 4 KiB steps measured best (36 us against
         // 43-55 us for 16 KiB steps or one piece per block at [64,64,112,112])
