@@ -267,6 +267,48 @@ def test_mse_row_kernel_all_paths(ops):
     np.testing.assert_allclose(mses2.cpu().numpy()[ok], 2 * ref[ok], rtol=1e-5, atol=1e-37)
 
 
+def test_mse_row_kernel_tile_dependent_paths(ops):
+    """Round 3: k_mse_row picks, per (tile, candidate), between integer rounding on the bits of t (no nonzero element below
+    the candidate's first binade), the float magic-number rounding (fixed-step subnormal range present) and their
+    clamp-free twins (candidate range covers the tile).  Tensors built so that neighbouring 2048-element tiles take
+    different paths: sparse tiles (exact zeros, -0), tiles with a few tiny / denormal nonzeros, tiles beyond every
+    candidate, exact rounding ties, one-sided data on an unsigned format, +-inf (clamps) and NaN (NaN table)."""
+    rng = np.random.RandomState(23)
+    n = 2048 * 24
+    for sign, special in ((1, False), (0, False), (1, True)):
+        x = rng.randn(n).astype(np.float32)
+        t = x.reshape(24, 2048)
+        t[1] *= (rng.rand(2048) < 0.5)                       # ReLU-like: half exact zeros
+        t[2, ::7] = -0.0
+        t[3, :5] = np.float32([1e-6, -3e-7, 1e-20, 1e-38, 1e-45])      # tiny and denormal nonzeros: float path for every candidate
+        t[4] *= 8.0                                          # far beyond most candidates: everything clamps
+        t[5] *= 0.01                                         # every candidate covers the tile: clamp-free
+        t[6] = np.round(t[6] * 8) / 8 + 1 / 16               # exact ties of coarse grids
+        t[7] = 1.25                                          # constant tile
+        t[8, 100] = 1e-3
+        t[8, 101:] = 0.0
+        if sign == 0:
+            x = np.abs(x)
+        if special:
+            x[9 * 2048 + 3] = np.inf
+            x[10 * 2048 + 5] = -np.inf
+        grid = np.linspace(0.1 * 5.5, 1.2 * 5.5, 111).astype(np.float32)[:, None]
+        mb = [1.0, 2.0, 3.0, 4.0, 5.0, 6.0]
+        mses = torch.zeros(len(mb), 111, 1, device="cuda")
+        ops.mse_grid(dev(x), False, dev(grid), mb, 8, sign, mses)
+        ref = oracle.c_mse_grid(x, False, grid, mb, 8, sign)
+        np.testing.assert_allclose(mses.cpu().numpy(), ref, rtol=1e-5, atol=1e-37, err_msg=f"sign {sign} special {special}")
+        # the decision the estimator takes from the table (SURVEY 8c): equal, or within 1e-6 of the oracle's minimum
+        got = mses.cpu().numpy()[:, :, 0]
+        gi, ri = np.unravel_index(got.argmin(), got.shape), np.unravel_index(ref[:, :, 0].argmin(), got.shape)
+        assert gi == ri or ref[:, :, 0][gi] <= ref[:, :, 0][ri] * (1 + 1e-6), (gi, ri)
+    xn = rng.randn(n).astype(np.float32)
+    xn[12345] = np.nan
+    mses = torch.zeros(2, 111, 1, device="cuda")
+    ops.mse_grid(dev(xn), False, dev(grid), [2.0, 3.0], 8, 1, mses)
+    assert torch.isnan(mses).all()
+
+
 def test_full_size_properties(ops):
     """Size-independent properties at a BASELINE-scale tensor ([2^20,3,7,7], 154 M elements)."""
     n_ch = 1 << 20
