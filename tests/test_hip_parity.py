@@ -525,6 +525,25 @@ def test_fuzz_geometries_against_oracle(ops):
                          "per-tensor " + what)
 
 
+@pytest.mark.parametrize("C,inner,M", [(1 << 17, 147, 2), (1 << 18, 147, 3), (30000, 1152, 2), (100000, 576, 2), (70001, 99, 3)])
+def test_flat_kernel_resident_grid_mid_size(ops, C, inner, M):
+    """Cache-sized per-channel tensors (1024 < tiles, <= 16384 chunks) run k_rows_flat on a RESIDENT grid of 1024 blocks
+    that stride over the chunks (several tiles per block): every row band of the result against the oracle."""
+    g = torch.Generator(device="cuda").manual_seed(C + inner)
+    x = torch.randn(C, inner, device="cuda", generator=g) * (torch.rand(C, 1, device="cuda", generator=g) * 2 + 0.05)
+    mv = ops.minmax(x, True, want_maxval=True)[2]
+    y = ops.quantize(x, mv, M, 8, 1)
+    mvh = mv.cpu().numpy()
+    for lo in (0, C // 3, C // 2 + 17, C - 2048):
+        sl = slice(lo, lo + 2048)
+        ref = oracle.c_quantize(x[sl].cpu().numpy(), mvh[sl], M, 8, 1)
+        assert_bit_exact(y[sl].cpu().numpy(), ref, f"rows {lo}..{lo + 2048} of [{C},{inner}]")
+    # and the whole tensor against the fused kernel's output (another kernel, same arithmetic)
+    if inner <= ops.fused_max_inner():
+        y2 = ops.minmax_quantize(x, M, 8, 1)[0]
+        assert torch.equal(y.view(torch.int32), y2.view(torch.int32))
+
+
 def test_multi_tensor_quantize(ops):
     """fp8q_multi_quantize_f32: every weight tensor of a model in one launch, bit-identical to one
     fp8q_quantize_f32 per tensor (and to the oracle); mixed formats, per-tensor entries, tensors that fall back
