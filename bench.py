@@ -307,7 +307,7 @@ def extras(ops, dev):
         ce = a4.numel() * 111 * len(mb)
         out[f"k4_mse_111cand_{len(mb)}m_64x32x112x112"] = dict(
             us=round(med * 1e6, 1), t_cand_elem_s=round(ce / med / 1e12, 3), hbm_gb_s=round(a4.numel() * 4 / med / 1e9, 1),
-            bound="valu (5-7 issue slots per candidate-element by path: integer rounding with / without clamp, "
+            bound="valu (4-7 issue slots per candidate-element by path: bit-level rounding with / without clamp, "
                   "float magic-number rounding with / without clamp; counters under profiles/)")
     del x, y
     return out

@@ -197,14 +197,13 @@ __device__ __forceinline__ float wave_max_f(float v)
 
 // Squared error of one candidate over the lane's 32 elements when NO nonzero element of the tile lies below the
 // candidate's first binade (the caller checks it with the tile's smallest nonzero magnitude): rounding t = xc * 2^bf to
-// M fraction bits is then round-half-even on the BITS of t -- lsb = bit (23 - M), r = (bits + half - 1 + lsb) & ~mask
-// (v_bfe_u32, v_add3_u32, v_and_b32) -- with no exponent extraction, no clamp of it to binade 1 and no float add / sub
-// pair: 6 issue slots per element instead of 7, 5 when the candidate's range covers the whole tile (CLAMP = false: the
-// v_med3 goes too).  Zero stays zero; a carry out of the fraction moves the value into the next binade, as rounding
+// M fraction bits is then rounding on the BITS of t -- r = (bits + half) & ~mask (v_add_u32, v_and_b32) -- with no
+// exponent extraction, no clamp of it to binade 1 and no float add / sub pair: 5 issue slots per element instead of 7, 4
+// when the candidate's range covers the whole tile (CLAMP = false: the v_med3 goes too).  Zero stays zero; a carry out of the fraction moves the value into the next binade, as rounding
 // up must.  TWO = the candidate has two scale mantissas (m0b below |t| = thr).
 template <bool CLAMP, bool TWO>
 __device__ __forceinline__ vf2 mse_cand_int(const vf2 (&xv)[16], float minv, float maxv, float c1s, float m0s, float m0b, float thr,
-                                            uint32_t sh, uint32_t hm1, uint32_t msk)
+                                            uint32_t half, uint32_t msk)
 {
     const vf2 c1 = {c1s, c1s}, m0 = {m0s, m0s};
     vf2 pa = {0.0f, 0.0f};
@@ -215,8 +214,10 @@ __device__ __forceinline__ vf2 mse_cand_int(const vf2 (&xv)[16], float minv, flo
         if (CLAMP) xc = vf2{__builtin_amdgcn_fmed3f(xx.x, minv, maxv), __builtin_amdgcn_fmed3f(xx.y, minv, maxv)};
         const vf2 tt = xc * c1;
         const uint32_t b0 = __float_as_uint(tt.x), b1 = __float_as_uint(tt.y);
-        const uint32_t r0 = (b0 + hm1 + __builtin_amdgcn_ubfe(b0, sh, 1u)) & msk;
-        const uint32_t r1 = (b1 + hm1 + __builtin_amdgcn_ubfe(b1, sh, 1u)) & msk;
+        // round half UP on the magnitude bits (2 ops) instead of half to even (3): the two differ only on an exact tie,
+        // where both neighbours are equally far from x -- the squared error is the same (to the last bits of r * m0)
+        const uint32_t r0 = (b0 + half) & msk;
+        const uint32_t r1 = (b1 + half) & msk;
         const vf2 rr = {__uint_as_float(r0), __uint_as_float(r1)};
         vf2 ms = m0;
         if (TWO) ms = vf2{fabsf(tt.x) < thr ? m0b : m0s, fabsf(tt.y) < thr ? m0b : m0s};
@@ -356,15 +357,15 @@ k_mse_row(const float *__restrict__ x, const float *__restrict__ grid, double *_
                 const bool int_ok = kIntRound && k.fast != 0 && anz * k.c1 >= __uint_as_float(k.lo) && k.maxv >= anz;
                 if (int_ok) {
                     const uint32_t sh = k.kadd >> 23;                       // 23 - M: position of the last kept fraction bit
-                    const uint32_t hm1 = (1u << (sh - 1u)) - 1u, msk = ~((1u << sh) - 1u);
+                    const uint32_t half = 1u << (sh - 1u), msk = ~((1u << sh) - 1u);
                     const bool cover = tmn >= k.minv && tmx <= k.maxv;   // the candidate's range covers the tile: nothing to clamp
                     const float thr = __uint_as_float(k.thr);
                     if (k.fast == 1) {
-                        pa = cover ? mse_cand_int<false, false>(xv, k.minv, k.maxv, k.c1, k.m0, k.m0b, thr, sh, hm1, msk)
-                                   : mse_cand_int<true, false>(xv, k.minv, k.maxv, k.c1, k.m0, k.m0b, thr, sh, hm1, msk);
+                        pa = cover ? mse_cand_int<false, false>(xv, k.minv, k.maxv, k.c1, k.m0, k.m0b, thr, half, msk)
+                                   : mse_cand_int<true, false>(xv, k.minv, k.maxv, k.c1, k.m0, k.m0b, thr, half, msk);
                     } else {
-                        pa = cover ? mse_cand_int<false, true>(xv, k.minv, k.maxv, k.c1, k.m0, k.m0b, thr, sh, hm1, msk)
-                                   : mse_cand_int<true, true>(xv, k.minv, k.maxv, k.c1, k.m0, k.m0b, thr, sh, hm1, msk);
+                        pa = cover ? mse_cand_int<false, true>(xv, k.minv, k.maxv, k.c1, k.m0, k.m0b, thr, half, msk)
+                                   : mse_cand_int<true, true>(xv, k.minv, k.maxv, k.c1, k.m0, k.m0b, thr, half, msk);
                     }
                 } else if (k.fast != 0) {
                     const bool cover = tmn >= k.minv && tmx <= k.maxv;   // nothing to clamp for this candidate on this tile
