@@ -145,9 +145,10 @@ int fp8q_minmax_quantize_f32(const float *x, float *y, int64_t C, int64_t inner,
  *   mses  [n_m, n_cand, C] fp32, accumulated:  += mean over the row of (x - q(x))^2
  *   ws    scratch of at least fp8q_mse_workspace_bytes(C, inner, n_cand, n_m) bytes
  * NOT bit-exact per element against the oracle (unlike every other entry point): for rows >= 2048 elements the kernel
- * forms x / s as x * 2^frac(bias) * 2^j and rounds by a magic-number add instead of the reference's IEEE division +
- * table lookup, and it sums in another order (double partials).  The quantized value of an element is the oracle's
- * except on exact rounding ties decided by the last bit of the division; table entries agree with the oracle's to
+ * forms x / s as x * 2^frac(bias) * 2^j and rounds that by a magic-number add or directly on its bits (round half up
+ * on the magnitude) instead of the reference's IEEE division + table lookup, and it sums in another order (double
+ * partials).  The quantized value of an element is the oracle's except on (near-)exact rounding ties -- where both
+ * neighbouring grid points are equally far from x, so the squared error is the same; table entries agree with the oracle's to
  * ~1e-6 relative (tests: <= 1e-5 on every entry, the CHOSEN (mantissa bits, maxval) equal to the oracle's choice or
  * its oracle-MSE within 1e-6 relative of the oracle's minimum -- SURVEY.md 8c).
  */
