@@ -103,7 +103,8 @@ k_mse_grid(const float *__restrict__ x, const float *__restrict__ grid, double *
 
 // ---------------------------------------------------------------------------------------------
 // K4 for LONG rows (per-tensor activations: 99 % of config 4's grid-search work): lane = ELEMENT.
-// One wave = one block owns tiles of 2048 consecutive elements of one row (32 per lane, in registers) and walks the
+// One wave = one block owns tiles of 4096 consecutive elements of one row (64 per lane, in registers: with the 4-7-slot
+// loops the per-candidate reduction and constant hand-over were a fifth of the work at 32 per lane) and walks the
 // candidates of its group one after the other; a candidate's constants are wave-uniform (broadcast LDS reads), its
 // squared error is summed over the lane's 32 elements in two fp32 accumulators, reduced across the wave with DPP adds
 // and added to the candidate's double accumulator in LDS.  No per-candidate table and no logarithm: with
@@ -116,8 +117,8 @@ k_mse_grid(const float *__restrict__ x, const float *__restrict__ grid, double *
 // (or out of the fast range) take an exact per-element path -- same results as the table kernel either way.
 // Rounding differs from IEEE x / s_p only where the quotient is within ~2.4e-7 relative of a tie (see k_mse_grid).
 // ---------------------------------------------------------------------------------------------
-constexpr int kMseRowTile = 2048;     // elements per wave and tile: 32 per lane
-constexpr int kMseRowEpl = 32;
+constexpr int kMseRowTile = 4096;     // elements per wave and tile: 64 per lane
+constexpr int kMseRowEpl = 64;
 constexpr int kMseRowGroup = 128;     // candidates per block (LDS: 48 B each; two double accumulators per lane)
 constexpr int kMseRowMinInner = 2048; // shorter rows: k_mse_grid (lane = candidate)
 constexpr bool kIntRound = true;      // integer round-half-even fast loops (mse_cand_int); false: the float magic-number loops only
@@ -202,13 +203,13 @@ __device__ __forceinline__ float wave_max_f(float v)
 // when the candidate's range covers the whole tile (CLAMP = false: the v_med3 goes too).  Zero stays zero; a carry out of the fraction moves the value into the next binade, as rounding
 // up must.  TWO = the candidate has two scale mantissas (m0b below |t| = thr).
 template <bool CLAMP, bool TWO>
-__device__ __forceinline__ vf2 mse_cand_int(const vf2 (&xv)[16], float minv, float maxv, float c1s, float m0s, float m0b, float thr,
+__device__ __forceinline__ vf2 mse_cand_int(const vf2 (&xv)[kMseRowEpl / 2], float minv, float maxv, float c1s, float m0s, float m0b, float thr,
                                             uint32_t half, uint32_t msk)
 {
     const vf2 c1 = {c1s, c1s}, m0 = {m0s, m0s};
     vf2 pa = {0.0f, 0.0f};
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
+    for (int u = 0; u < kMseRowEpl / 2; ++u) {
         const vf2 xx = xv[u];
         vf2 xc = xx;
         if (CLAMP) xc = vf2{__builtin_amdgcn_fmed3f(xx.x, minv, maxv), __builtin_amdgcn_fmed3f(xx.y, minv, maxv)};
@@ -231,13 +232,13 @@ __device__ __forceinline__ vf2 mse_cand_int(const vf2 (&xv)[16], float minv, flo
 // + 23 - M) -- the max is the subnormal range's fixed step, which the integer loop above cannot do.  7 issue slots per
 // element, 6 without the clamp.
 template <bool CLAMP, bool TWO>
-__device__ __forceinline__ vf2 mse_cand_magic(const vf2 (&xv)[16], float minv, float maxv, float c1s, float m0s, float m0b, float thr,
+__device__ __forceinline__ vf2 mse_cand_magic(const vf2 (&xv)[kMseRowEpl / 2], float minv, float maxv, float c1s, float m0s, float m0b, float thr,
                                               uint32_t lo, uint32_t kadd)
 {
     const vf2 c1 = {c1s, c1s}, m0 = {m0s, m0s};
     vf2 pa = {0.0f, 0.0f};
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
+    for (int u = 0; u < kMseRowEpl / 2; ++u) {
         const vf2 xx = xv[u];
         vf2 xc = xx;
         if (CLAMP) xc = vf2{__builtin_amdgcn_fmed3f(xx.x, minv, maxv), __builtin_amdgcn_fmed3f(xx.y, minv, maxv)};
@@ -477,14 +478,14 @@ static RowGeo mse_row_geo(int64_t C, int64_t inner, int64_t n_cand, int n_m)
     // and a nearly empty last round is pure loss (111 candidates on [64,32,112,112]: 12 544 blocks on 4 096 resident
     // waves = 3.06 -> 4 rounds, 77 %).  Cutting the candidates into more, smaller groups gives finer rounds at the
     // price of one more constant-setup pass per block: pick the split with the best product of the two.
-    const int64_t resident = 256 * 16;   // CUs x waves (112 VGPRs: 4 per SIMD)
+    const int64_t resident = 256 * 12;   // CUs x waves (144 VGPRs: 3 per SIMD)
     const int64_t g0 = cdiv(total, kMseRowGroup);
     double best = -1.0;
     for (int64_t ng = g0; ng <= g0 * 4 && ng <= total; ++ng) {
         const int64_t gs = cdiv(total, ng), waves = g.nblk * ng * (C > 0 ? C : 1);
         const double rounds = (double)cdiv(waves, resident);
         const double fill = (double)waves / (rounds * (double)resident);
-        const double work = (double)gs * 240.0 * g.tpb, setup = 250.0 * (double)cdiv(gs, 64);
+        const double work = (double)gs * (6.0 * kMseRowEpl) * g.tpb, setup = 250.0 * (double)cdiv(gs, 64);
         const double score = fill * work / (work + setup);
         if (score > best * 1.005) {   // prefer fewer groups on ties
             best = score;
