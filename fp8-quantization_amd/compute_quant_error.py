@@ -54,10 +54,11 @@ def format_row(row):
 
 def compute_quant_error(distr, n_bits=8, n_samples=5000000, seed=10, device="cuda", verbose=True):
     """One row per format: (exp_bits, mantissa_bits, range_max, quant_mse, quant_sqnr, dot_mse, dot_sqnr).
-    The samples live on the GPU; each format's clipping range comes from ONE pass of the MSE-grid kernel over them
-    (1000 candidates), the expected errors are the analytic integrals over the format's grid."""
+    The float64 samples live on the GPU; each format's clipping range comes from ONE pass of the float64 MSE-grid
+    kernel over them (1000 candidates, the reference's float64 arithmetic: fp8q_mse_grid_f64), the expected errors
+    are the analytic integrals over the format's grid."""
     seed_all(seed)
-    samples = torch.as_tensor(distr.sample((n_samples,))).to(device=device, dtype=torch.float32)
+    samples = torch.as_tensor(distr.sample((n_samples,))).to(device=device)    # float64, as the reference (:19-20)
     table = []
     for exp_bits, _name in FORMATS:
         q = _make_quantizer(exp_bits, n_bits)

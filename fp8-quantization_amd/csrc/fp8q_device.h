@@ -104,6 +104,32 @@ __device__ __forceinline__ float log2_tab(float a, const double *tab)
     return (float)l2;
 }
 
+// The f64 lane's log2 (x float64: BASELINE config 1): the same table-driven evaluation returned in DOUBLE -- absolute error
+// <= ~2^-52 (1 + |log2 a|), the accuracy class of the 1-ulp double log2 the reference calls -- and the very op sequence of
+// oracle/fp8q_oracle.c:orc_log2_d, so the f64 kernels' rare exact path decides binade borders as the oracle does.
+__device__ __forceinline__ double log2_tab_d(double a, const double *tab)
+{
+    if (__builtin_expect(!(a > 0.0) || a == (double)__builtin_inff(), 0))
+        return a == 0.0 ? -(double)__builtin_inff() : (a > 0.0 ? a : (double)__builtin_nanf(""));
+    int adj = 0;
+    if (a < 0x1p-1022) {   // denormal double: renormalise
+        a *= 0x1p64;
+        adj = -64;
+    }
+    const uint64_t b = (uint64_t)__double_as_longlong(a);
+    const int i = (int)(b >> 45) & 0x7f;
+    const double m = __longlong_as_double((long long)((b & 0x000fffffffffffffull) | 0x3ff0000000000000ull));
+    const double r = fma(m, tab[i], -1.0);
+    double p = fma(r, 1.0 / 7.0, -1.0 / 6.0);
+    p = fma(r, p, 1.0 / 5.0);
+    p = fma(r, p, -1.0 / 4.0);
+    p = fma(r, p, 1.0 / 3.0);
+    p = fma(r, p, -1.0 / 2.0);
+    p = fma(r, p, 1.0);
+    p = p * r;                                      // ln(1 + r)
+    return (double)((int)(b >> 52) - 1023 + adj) + fma(p, 1.4426950408889634074, tab[128 + i]);
+}
+
 // Channel constants from maxval.  g = 2^-bf, bf in [0,1): j = floor(128 bf),
 // 2^-bf = 2^(-j/128) * exp(-(bf - j/128) ln2), degree 6; a non-finite bias has bf = NaN -> g = NaN.
 __device__ __forceinline__ Chan make_chan_fast(float maxv, const QFmt &f, const double *tab)

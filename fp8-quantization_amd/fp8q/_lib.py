@@ -36,6 +36,12 @@ SIGNATURES = {
     "fp8q_mse_workspace_bytes": (ctypes.c_size_t, [_i64, _i64, _i64, _i]),
     "fp8q_mse_grid_f32": (_i, [_vp, _i64, _i64, _vp, _i64, ctypes.POINTER(_f), _i, _i, _i, _vp, _vp,
                                ctypes.c_size_t, _vp]),
+    "fp8q_quantize_f64": (_i, [_vp, _vp, _i64, _i64, _vp, _i64, _f, _i, _i, _vp]),
+    "fp8q_minmax_f64_workspace_bytes": (ctypes.c_size_t, [_i64, _i64]),
+    "fp8q_minmax_f64": (_i, [_vp, _i64, _i64, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
+    "fp8q_mse_f64_workspace_bytes": (ctypes.c_size_t, [_i64, _i64, _i64, _i]),
+    "fp8q_mse_grid_f64": (_i, [_vp, _i64, _i64, _vp, _i64, ctypes.POINTER(_f), _i, _i, _i, _vp, _i, _vp,
+                               ctypes.c_size_t, _vp]),
     "fp8q_affine_act_quantize_f32": (_i, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i, _vp, _f, _i, _i,
                                           _vp]),
     "fp8q_affine_act_minmax_workspace_bytes": (ctypes.c_size_t, [_i64, _i64, _i64]),

@@ -43,11 +43,28 @@ class _on_device:
         return False
 
 
-def _require(t, name):
+def _require(t, name, dtype=torch.float32, like=None):
+    """t is a CUDA(HIP) tensor of `dtype` (a dtype or a tuple of them), on `like`'s device when given."""
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise Fp8qError(f"{name} must be a CUDA(HIP) tensor: the FP8 engine has no CPU path")
-    if t.dtype != torch.float32:
-        raise Fp8qError(f"{name} must be float32, got {t.dtype}")
+    if t.dtype != dtype and not (isinstance(dtype, tuple) and t.dtype in dtype):
+        want = " or ".join(str(d).replace("torch.", "") for d in (dtype if isinstance(dtype, tuple) else (dtype,)))
+        raise Fp8qError(f"{name} must be {want}, got {t.dtype}")
+    if like is not None and t.device != like.device:
+        raise Fp8qError(f"{name} is on {t.device}, expected {like.device} (all tensors of a call live on one device)")
+
+
+def _out(out, like, dtype=None, name="out"):
+    """The output tensor of a launch: a fresh one, or the caller's `out=` after checking that the kernel may write
+    like.numel() elements of `dtype` through its raw pointer (same device, dtype, element count, contiguous)."""
+    dtype = like.dtype if dtype is None else dtype
+    if out is None:
+        return torch.empty(like.shape, dtype=dtype, device=like.device)
+    _require(out, name, dtype, like)
+    if out.numel() != like.numel() or not out.is_contiguous():
+        raise Fp8qError(f"{name} must be a contiguous tensor of {like.numel()} elements "
+                        f"(got {tuple(out.shape)}, contiguous={out.is_contiguous()})")
+    return out
 
 
 def _rows(x, per_channel):
@@ -74,19 +91,22 @@ def _workspace(dev, nbytes, zeroed=False):
 
 def quantize(x, maxval, mbits, n_bits=8, sign_bits=1, out=None):
     """K1: FP8 quantize+dequantize (fp8_quantizer.py:91-133).  maxval: CUDA fp32 tensor [1] or [C]."""
-    _require(x, "x")
-    _require(maxval, "maxval")
+    _require(x, "x", (torch.float32, torch.float64))
+    _require(maxval, "maxval", like=x)
     x = x.contiguous()
     maxval = maxval.contiguous().view(-1)
     n_mv = maxval.numel()
     C, inner = _rows(x, n_mv != 1)
     if n_mv != 1 and n_mv != C:
         raise Fp8qError(f"maxval has {n_mv} elements, expected 1 or {C}")
-    y = torch.empty_like(x) if out is None else out
+    y = _out(out, x)
+    # float64 input (BASELINE config 1): the reference's chain under ATen's type promotion -- bias in float32,
+    # everything downstream of x in float64 (fp8q_quantize_f64)
+    fn = lib().fp8q_quantize_f64 if x.dtype == torch.float64 else lib().fp8q_quantize_f32
     with _on_device(x):
-        rc = lib().fp8q_quantize_f32(x.data_ptr(), y.data_ptr(), C, inner, maxval.data_ptr(), n_mv,
-                                     float(mbits), int(n_bits), int(sign_bits), _stream(x))
-    check(rc, "fp8q_quantize_f32")
+        rc = fn(x.data_ptr(), y.data_ptr(), C, inner, maxval.data_ptr(), n_mv, float(mbits), int(n_bits),
+                int(sign_bits), _stream(x))
+    check(rc, "fp8q_quantize_f64" if x.dtype == torch.float64 else "fp8q_quantize_f32")
     return y
 
 
@@ -102,7 +122,7 @@ def _pack_descs(items):
         sign_bits = it[4] if len(it) > 4 else 1
         out = it[5] if len(it) > 5 else None
         _require(x, "x")
-        _require(maxval, "maxval")
+        _require(maxval, "maxval", like=x)
         if dev0 is None:
             dev0 = x.device
         elif x.device != dev0:
@@ -113,7 +133,7 @@ def _pack_descs(items):
         C, inner = _rows(x, n_mv != 1)
         if n_mv != 1 and n_mv != C:
             raise Fp8qError(f"maxval has {n_mv} elements, expected 1 or {C}")
-        y = torch.empty_like(x) if out is None else out
+        y = _out(out, x)
         d.x, d.y, d.maxval = x.data_ptr(), y.data_ptr(), maxval.data_ptr()
         d.C, d.inner, d.n_maxval = C, inner, n_mv
         d.mbits, d.n_bits, d.sign_bits = float(mbits), int(n_bits), int(sign_bits)
@@ -225,7 +245,7 @@ def ranges_unpack(packed, cur_min=None, cur_max=None, maxval=None):
         cur_max = st[1] if cur_max is None else cur_max
         maxval = st[2] if maxval is None else maxval
     for t in (cur_min, cur_max, maxval):
-        _require(t, "range vector")
+        _require(t, "range vector", like=packed)
         if t.numel() != n or not t.is_contiguous():
             raise Fp8qError("range vectors must be contiguous [C] tensors")
     with _on_device(packed):
@@ -271,8 +291,8 @@ def minmax(x, per_channel, cur_min=None, cur_max=None, mode=FOLD_CURRENT, moment
         else:
             cur_min, cur_max = stats.unbind(0)
     else:
-        _require(cur_min, "cur_min")
-        _require(cur_max, "cur_max")
+        _require(cur_min, "cur_min", like=x)
+        _require(cur_max, "cur_max", like=x)
         if cur_min.numel() != C or cur_max.numel() != C or not cur_min.is_contiguous() \
                 or not cur_max.is_contiguous():
             raise Fp8qError("running estimate has the wrong shape")
@@ -290,6 +310,7 @@ def minmax(x, per_channel, cur_min=None, cur_max=None, mode=FOLD_CURRENT, moment
                                    int(first), ws.data_ptr(), ws.numel(), _stream(x))
         else:
             _check_packed(packed, C)
+            _require(packed, "packed", like=x)
             rc = L.fp8q_minmax_packed_f32(x.data_ptr(), C, inner, cur_min.data_ptr(), cur_max.data_ptr(),
                                           mv.data_ptr() if mv is not None else None, packed.data_ptr(), int(mode),
                                           float(momentum), int(first), ws.data_ptr(), ws.numel(), _stream(x))
@@ -308,7 +329,7 @@ def minmax_quantize(x, mbits, n_bits=8, sign_bits=1, out=None):
     _require(x, "x")
     x = x.contiguous()
     C, inner = _rows(x, True)
-    y = torch.empty_like(x) if out is None else out
+    y = _out(out, x)
     mn, mx, mv = torch.empty((3, C), dtype=torch.float32, device=x.device).unbind(0)   # one allocation (host-bound sizes)
     with _on_device(x):
         rc = lib().fp8q_minmax_quantize_f32(x.data_ptr(), y.data_ptr(), C, inner, mn.data_ptr(),
@@ -321,7 +342,8 @@ def minmax_quantize(x, mbits, n_bits=8, sign_bits=1, out=None):
 def copy(x, out=None):
     """float4 copy kernel with K1's launch shape (HBM ceiling yardstick)."""
     _require(x, "x")
-    y = torch.empty_like(x) if out is None else out
+    x = x.contiguous()
+    y = _out(out, x)
     with _on_device(x):
         rc = lib().fp8q_copy_f32(x.data_ptr(), y.data_ptr(), x.numel(), _stream(x))
     check(rc, "fp8q_copy_f32")
@@ -335,8 +357,8 @@ def mse_grid(x, per_channel, grid, mbits_list, n_bits, sign_bits, mses):
     """
     import ctypes
     _require(x, "x")
-    _require(grid, "grid")
-    _require(mses, "mses")
+    _require(grid, "grid", like=x)
+    _require(mses, "mses", like=x)
     x = x.contiguous()
     C, inner = _rows(x, per_channel)
     n_m = len(mbits_list)
@@ -355,17 +377,62 @@ def mse_grid(x, per_channel, grid, mbits_list, n_bits, sign_bits, mses):
     return mses
 
 
+def minmax_f64(x, per_channel):
+    """Row min / max of a float64 tensor as [C] float64 tensors (fp8q_minmax_f64): what LineSearchEstimator needs of
+    its float64 sample (range_estimators.py:205-222: data.min(), data.max()).  NaN anywhere in a row -> NaN."""
+    _require(x, "x", torch.float64)
+    x = x.contiguous()
+    C, inner = _rows(x, per_channel)
+    if C == 0 or inner == 0:
+        raise Fp8qError("min/max of an empty tensor")
+    mn, mx = torch.empty((2, C), dtype=torch.float64, device=x.device).unbind(0)
+    L = lib()
+    ws = _workspace(x.device, L.fp8q_minmax_f64_workspace_bytes(C, inner))
+    with _on_device(x):
+        rc = L.fp8q_minmax_f64(x.data_ptr(), C, inner, mn.data_ptr(), mx.data_ptr(), ws.data_ptr(), ws.numel(), _stream(x))
+    check(rc, "fp8q_minmax_f64")
+    return mn, mx
+
+
+def mse_grid_f64(x, per_channel, grid, mbits_list, n_bits, sign_bits, out, reduce="sum"):
+    """K4 on float64: out[n_m, n_cand, C] (float64, updated in place) += row-sum (reduce="sum": LineSearchEstimator.loss_fx,
+    range_estimators.py:161-169) or row-mean (reduce="mean": FP_MSE_Estimator, :337-347) of (x - q(x; m, grid[i, c]))^2.
+    grid: CUDA fp32 [n_cand, C] candidate maxvals (what torch.Tensor([x_max]) holds in the reference)."""
+    import ctypes
+    if reduce not in ("sum", "mean"):
+        raise Fp8qError("reduce must be 'sum' or 'mean'")
+    _require(x, "x", torch.float64)
+    _require(grid, "grid", like=x)
+    _require(out, "out", torch.float64, like=x)
+    x = x.contiguous()
+    C, inner = _rows(x, per_channel)
+    n_m = len(mbits_list)
+    n_cand = grid.shape[0]
+    if grid.dim() != 2 or grid.shape[1] != C or not grid.is_contiguous():
+        raise Fp8qError(f"grid must be contiguous [n_cand, {C}]")
+    if tuple(out.shape) != (n_m, n_cand, C) or not out.is_contiguous():
+        raise Fp8qError(f"out must be contiguous [{n_m}, {n_cand}, {C}]")
+    L = lib()
+    ws = _workspace(x.device, L.fp8q_mse_f64_workspace_bytes(C, inner, n_cand, n_m))
+    mb = (ctypes.c_float * n_m)(*[float(v) for v in mbits_list])
+    with _on_device(x):
+        rc = L.fp8q_mse_grid_f64(x.data_ptr(), C, inner, grid.data_ptr(), n_cand, mb, n_m, int(n_bits), int(sign_bits),
+                                 out.data_ptr(), int(reduce == "sum"), ws.data_ptr(), ws.numel(), _stream(x))
+    check(rc, "fp8q_mse_grid_f64")
+    return out
+
+
 def encode(x, maxval, mbits, n_bits=8, sign_bits=1, out=None):
     """N3: uint8 storage codes of quantize(x) ([sign | exponent | fraction], fp8_quantizer.py:13-41)."""
     _require(x, "x")
-    _require(maxval, "maxval")
+    _require(maxval, "maxval", like=x)
     x = x.contiguous()
     maxval = maxval.contiguous().view(-1)
     n_mv = maxval.numel()
     C, inner = _rows(x, n_mv != 1)
     if n_mv != 1 and n_mv != C:
         raise Fp8qError(f"maxval has {n_mv} elements, expected 1 or {C}")
-    codes = torch.empty(x.shape, dtype=torch.uint8, device=x.device) if out is None else out
+    codes = _out(out, x, torch.uint8)
     with _on_device(x):
         rc = lib().fp8q_encode_u8(x.data_ptr(), codes.data_ptr(), C, inner, maxval.data_ptr(), n_mv, float(mbits),
                                   int(n_bits), int(sign_bits), _stream(x))
@@ -379,14 +446,14 @@ def decode(codes, maxval, mbits, n_bits=8, sign_bits=1, out=None):
     into the next binade (see include/fp8q.h)."""
     if not isinstance(codes, torch.Tensor) or not codes.is_cuda or codes.dtype != torch.uint8:
         raise Fp8qError("codes must be a CUDA(HIP) uint8 tensor")
-    _require(maxval, "maxval")
+    _require(maxval, "maxval", like=codes)
     codes = codes.contiguous()
     maxval = maxval.contiguous().view(-1)
     n_mv = maxval.numel()
     C, inner = _rows(codes, n_mv != 1)
     if n_mv != 1 and n_mv != C:
         raise Fp8qError(f"maxval has {n_mv} elements, expected 1 or {C}")
-    y = torch.empty(codes.shape, dtype=torch.float32, device=codes.device) if out is None else out
+    y = _out(out, codes, torch.float32)
     with _on_device(codes):
         rc = lib().fp8q_decode_u8(codes.data_ptr(), y.data_ptr(), C, inner, maxval.data_ptr(), n_mv, float(mbits),
                                   int(n_bits), int(sign_bits), _stream(codes))
@@ -425,16 +492,18 @@ def affine_act_quantize(x, maxval, mbits, n_bits=8, sign_bits=1, bn=None, residu
     """N2: quantize(act(bn(x) + residual)) in one pass.  bn = (mean, invstd, gamma, beta), each [C];
     act: 0 none, 1 ReLU, 2 ReLU6; per-tensor maxval [1]."""
     _require(x, "x")
-    _require(maxval, "maxval")
+    _require(maxval, "maxval", like=x)
     x = x.contiguous()
     N, C, HW = _nchw(x)
     if residual is not None:
-        _require(residual, "residual")
+        _require(residual, "residual", like=x)
         residual = residual.contiguous()
         if residual.shape != x.shape:
             raise Fp8qError("residual must have x's shape")
+    if maxval.numel() != 1:
+        raise Fp8qError("the fused epilogue quantizes per tensor: maxval must have one element")
     ptrs, keep = _bn_ptrs(bn, C, x.device)
-    y = torch.empty_like(x) if out is None else out
+    y = _out(out, x)
     with _on_device(x):
         rc = lib().fp8q_affine_act_quantize_f32(
             x.data_ptr(), residual.data_ptr() if residual is not None else None, y.data_ptr(), N, C, HW,
@@ -453,13 +522,20 @@ def affine_act_minmax(x, cur_min=None, cur_max=None, mode=FOLD_CURRENT, momentum
     x = x.contiguous()
     N, C, HW = _nchw(x)
     if residual is not None:
-        _require(residual, "residual")
+        _require(residual, "residual", like=x)
         residual = residual.contiguous()
+        if residual.shape != x.shape:
+            raise Fp8qError("residual must have x's shape")
     ptrs, keep = _bn_ptrs(bn, C, x.device)
     first = cur_min is None or cur_max is None
     if first:
         cur_min = torch.empty(1, dtype=torch.float32, device=x.device)
         cur_max = torch.empty(1, dtype=torch.float32, device=x.device)
+    else:
+        for t in (cur_min, cur_max):
+            _require(t, "running estimate", like=x)
+            if t.numel() != 1 or not t.is_contiguous():
+                raise Fp8qError("running estimate has the wrong shape")
     mv = torch.empty(1, dtype=torch.float32, device=x.device)
     L = lib()
     ws = _workspace(x.device, L.fp8q_affine_act_minmax_workspace_bytes(N, C, HW), zeroed=True)
@@ -471,6 +547,7 @@ def affine_act_minmax(x, cur_min=None, cur_max=None, mode=FOLD_CURRENT, momentum
                 float(momentum), int(first), ws.data_ptr(), ws.numel(), _stream(x))
         else:
             _check_packed(packed, 1)
+            _require(packed, "packed", like=x)
             rc = L.fp8q_affine_act_minmax_packed_f32(
                 x.data_ptr(), residual.data_ptr() if residual is not None else None, N, C, HW, ptrs[0], ptrs[1],
                 ptrs[2], ptrs[3], int(act), cur_min.data_ptr(), cur_max.data_ptr(), mv.data_ptr(), packed.data_ptr(),

@@ -161,7 +161,9 @@ def linspace_columns(mx_host, steps):
     grain evaluates element i as fl32(start + step * i) for i < steps // 2 and fl32(end - step * (steps - 1 - i)) after,
     each with a fused multiply-add; that formula is reproduced here and CHECKED against torch.linspace itself on a few
     channels of every call -- on any difference (another ATen build, a CPU without FMA) the per-channel loop is used."""
-    m = np.asarray(mx_host, np.float64)
+    m = np.asarray(mx_host, np.float64).reshape(-1)
+    if m.size == 0:
+        return torch.empty((0, steps), dtype=torch.float32)
     with np.errstate(all="ignore"):
         start, end = (0.1 * m).astype(np.float32), (1.2 * m).astype(np.float32)
         step = ((end - start) / np.float32(steps - 1)).astype(np.float32)
@@ -292,8 +294,10 @@ class LineSearchEstimator(RangeEstimatorBase):
     loop over candidates with elementwise torch ops.  Only the symmetric 1-D search exists: the
     reference takes it for every quantizer that can reach this estimator (`quantizer.symmetric`
     is used without being called there, so it is truthy for FPQuantizer too -- SURVEY.md 3.4).
-    The reference evaluates in float64 on the CPU; here x is cast to fp32 on the device, and the
-    per-candidate sums are accumulated in double inside the kernel.
+    Precision follows the data, as in the reference: a float64 sample (compute_quant_error.py:19-20) is searched in
+    float64 -- fp8q_minmax_f64 for the search range, fp8q_mse_grid_f64 for the candidates: the reference's arithmetic
+    under ATen's type promotion (bias in float32, everything downstream of x in float64), per-candidate sums of squares
+    in float64 -- so the chosen candidate is the reference's; float32 data runs the float32 kernels.
     """
 
     def __init__(self, num_candidates=1000, opt_method=OptMethod.grid, range_margin=0.5, expand_range=10.0,
@@ -326,8 +330,8 @@ class LineSearchEstimator(RangeEstimatorBase):
         self.channel_groups = len(data) if self.per_channel else 1
         self.loss_array = np.zeros((self.channel_groups, self.num_candidates + 1))
         self.loss_array[:, 0] = np.inf            # candidate 0 would be an empty range
-        mn, mx = _ops.minmax(data, False)
-        lo, hi = float(mn), float(mx)
+        mn, mx = _ops.minmax_f64(data, False) if data.dtype == torch.float64 else _ops.minmax(data, False)
+        lo, hi = float(mn), float(mx)              # (the reference synchronises here too: float(data.min()))
         if self.one_sided_dist is None:
             self.one_sided_dist = lo >= 0
         self.max_pos_thr = max(abs(lo), hi) + self.range_margin
@@ -346,8 +350,13 @@ class LineSearchEstimator(RangeEstimatorBase):
             if not q.set_maxval:
                 raise NotImplementedError("line search needs set_maxval=True to change the range")
             grid = torch.from_numpy(thr).to(data.device).view(n, 1).expand(n, C).contiguous()
-            mses = torch.zeros(1, n, C, device=data.device)
             sign_bits = 0 if (q.allow_unsigned and self.one_sided_dist) else q.sign_bits
+            if data.dtype == torch.float64:      # loss_fx: torch.sum((data - y) ** 2) in float64, per candidate
+                sse = torch.zeros(1, n, C, dtype=torch.float64, device=data.device)
+                _ops.mse_grid_f64(data, self.per_channel, grid, [float(q.mantissa_bits)], q.n_bits, sign_bits, sse,
+                                  reduce="sum")
+                return sse[0].transpose(0, 1).cpu().numpy()
+            mses = torch.zeros(1, n, C, device=data.device)
             _ops.mse_grid(data, self.per_channel, grid, [float(q.mantissa_bits)], q.n_bits, sign_bits, mses)
             return (mses[0].double() * inner).transpose(0, 1).cpu().numpy()
         import copy
@@ -362,7 +371,7 @@ class LineSearchEstimator(RangeEstimatorBase):
 
     def forward(self, data):
         data = data.detach()
-        if data.dtype != torch.float32:
+        if data.dtype not in (torch.float32, torch.float64):
             data = data.float()
         if self.loss_array is None:
             self._define_search_range(data)

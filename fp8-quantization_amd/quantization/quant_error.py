@@ -3,7 +3,7 @@
 Restates /root/reference/utils/grid.py:46-93 and quantization/quant_error_estimator.py:40-161:
 every real number rounds to the nearest grid point, so the expected squared error is a sum over
 half-cells of int p(x) (x - g)^2 dx, plus the point masses that clipping puts on the range ends.
-CPU / float64; the quantizer itself is only used for the empirical cross-check (on the GPU).
+CPU / float64; the quantizer itself is only used for the empirical cross-check (on the GPU, float64 lane).
 """
 import numpy as np
 import torch
@@ -71,7 +71,7 @@ def estimate_rounding_error_empirical(W, quantizer, range_min, range_max):
 
 def _device_sample(distr, n):
     dev = "cuda" if torch.cuda.is_available() else "cpu"
-    return torch.tensor(distr.sample((n,))).to(dev, torch.float32)
+    return torch.tensor(distr.sample((n,))).to(dev)     # float64, as the reference's empirical check (:146-151)
 
 
 def compute_expected_quant_mse(distr, quant, quant_range_min, quant_range_max, num_samples):

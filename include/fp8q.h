@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define FP8Q_VERSION 300 /* 0.3.0: packed ranges for the calibration all-reduce, workspace status / FP8Q_ETIMEDOUT */
+#define FP8Q_VERSION 400 /* 0.4.0: float64 lane (fp8q_quantize_f64, fp8q_minmax_f64, fp8q_mse_grid_f64) */
 
 #define FP8Q_OK 0
 #define FP8Q_EINVAL (-1)       /* null pointer, negative size, n_maxval not in {1, C}, ... */
@@ -156,6 +156,32 @@ size_t fp8q_mse_workspace_bytes(int64_t C, int64_t inner, int64_t n_cand, int n_
 int fp8q_mse_grid_f32(const float *x, int64_t C, int64_t inner, const float *grid, int64_t n_cand,
                       const float *mbits_host, int n_m, int n_bits, int sign_bits, float *mses,
                       void *ws, size_t ws_bytes, fp8q_stream_t stream);
+
+/*
+ * The float64 lane -- BASELINE config 1.  compute_quant_error.py:19-20 draws float64 samples; LineSearchEstimator
+ * (quantization/range_estimators.py:161-169, 205-222, 236-256) takes their min / max and scores 1000 clipping candidates
+ * on them, and quant_error_estimator.py:67-73 runs the quantizer's forward on a float64 sample.  Under ATen's type
+ * promotion quantize_to_fp8_ste_MM (fp8_quantizer.py:105-133) then keeps M, E and bias in float32 (maxval and the mantissa
+ * bits are float32 tensors) and evaluates everything downstream of x in float64.  Arithmetic contract: bit-identical to
+ * oracle/fp8q_oracle.c:orc_quant1_f64 (double log2 / 2^x = the table-driven 1-ulp evaluations defined there; against the
+ * reference's own 1-ulp Sleef routines: <= 2 ulp(double) per element, the same grid point -- tests/golden/g1c_*.npz).
+ *   fp8q_quantize_f64   K1: x, y [C, inner] float64 (y may alias x), 8-byte aligned; maxval fp32 [1] or [C].  16 B / element.
+ *   fp8q_minmax_f64     row_min / row_max [C] float64 of x [C, inner] (NaN anywhere in a row -> NaN); two launches.
+ *   fp8q_mse_grid_f64   K4: out[n_m, n_cand, C] (float64) += sum over the row of (x - q(x; mbits[m], grid[i, c]))^2
+ *                       (reduce_sum != 0: LineSearchEstimator.loss_fx, torch.sum) or its mean (reduce_sum == 0:
+ *                       FP_MSE_Estimator.forward :337-347).  Per element the K1-f64 arithmetic, bit for bit; the sums
+ *                       are formed in another order than ATen's (or the oracle's compensated one): ~1e-15 relative.
+ *                       ws: at least fp8q_mse_f64_workspace_bytes() bytes, 8-byte aligned, need not be initialised.
+ */
+int fp8q_quantize_f64(const double *x, double *y, int64_t C, int64_t inner, const float *maxval, int64_t n_maxval,
+                      float mbits, int n_bits, int sign_bits, fp8q_stream_t stream);
+size_t fp8q_minmax_f64_workspace_bytes(int64_t C, int64_t inner);
+int fp8q_minmax_f64(const double *x, int64_t C, int64_t inner, double *row_min, double *row_max, void *ws,
+                    size_t ws_bytes, fp8q_stream_t stream);
+size_t fp8q_mse_f64_workspace_bytes(int64_t C, int64_t inner, int64_t n_cand, int n_m);
+int fp8q_mse_grid_f64(const double *x, int64_t C, int64_t inner, const float *grid, int64_t n_cand,
+                      const float *mbits_host, int n_m, int n_bits, int sign_bits, double *out, int reduce_sum, void *ws,
+                      size_t ws_bytes, fp8q_stream_t stream);
 
 /*
  * N2 -- producer epilogue fused with the activation quantizer: eval-mode batch norm

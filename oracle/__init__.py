@@ -27,8 +27,8 @@ _lib = None
 
 def build(force=False):
     """Compile oracle/fp8q_oracle.c -> oracle/_ref/libfp8q_oracle.so (gcc, seconds)."""
-    src = os.path.join(_HERE, "fp8q_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("fp8q_oracle.c", "fp8q_oracle_tables.h")]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
     return _SO
 
@@ -56,6 +56,15 @@ def lib():
         L.orc_decode_u8.argtypes = [u8p, f32p, i64, i64, f32p, i64, ctypes.c_float, ctypes.c_int, ctypes.c_int]
         L.orc_fp_grid.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                   ctypes.POINTER(ctypes.c_double)]
+        f64p = ctypes.POINTER(ctypes.c_double)
+        L.orc_quantize_f64.argtypes = [f64p, f64p, i64, i64, f32p, i64, ctypes.c_float, ctypes.c_int, ctypes.c_int]
+        L.orc_minmax_f64.argtypes = [f64p, i64, i64, f64p, f64p]
+        L.orc_sse_grid_f64.argtypes = [f64p, i64, i64, f32p, i64, f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, f64p,
+                                       ctypes.c_int]
+        L.orc_log2_f64.argtypes = [ctypes.c_double]
+        L.orc_log2_f64.restype = ctypes.c_double
+        L.orc_exp2_f64.argtypes = [ctypes.c_double]
+        L.orc_exp2_f64.restype = ctypes.c_double
         L.orc_num_threads.restype = ctypes.c_int
         L.orc_set_num_threads.argtypes = [ctypes.c_int]
         _lib = L
@@ -153,6 +162,64 @@ def c_mse_grid(x, per_channel, grid, mbits_list, n_bits=8, sign_bits=1, mses=Non
     lib().orc_mse_grid_f32(_p(x2), C, x2.shape[1], _p(grid), grid.shape[0], _p(mb), mb.size,
                            int(n_bits), int(sign_bits), _p(mses))
     return mses
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _pd(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+
+def _as_2d_f64(x, per_channel):
+    x = _f64(x)
+    if per_channel:
+        return x.reshape(x.shape[0], -1) if x.ndim > 0 else x.reshape(1, 1)
+    return x.reshape(1, -1)
+
+
+def c_quantize_f64(x, maxval, mbits, n_bits=8, sign_bits=1):
+    """quantize_to_fp8_ste_MM on a float64 tensor (fp8_quantizer.py:91-133 under ATen's type promotion: bias in
+    float32, everything downstream of x in float64).  maxval: float32 scalar/[1] or [C]."""
+    x = _f64(x)
+    mv = _f32(np.atleast_1d(maxval)).reshape(-1)
+    x2 = _as_2d_f64(x, mv.size != 1)
+    assert mv.size in (1, x2.shape[0])
+    y = np.empty_like(x2)
+    rc = lib().orc_quantize_f64(_pd(x2), _pd(y), x2.shape[0], x2.shape[1], _p(mv), mv.size, float(mbits), int(n_bits),
+                                int(sign_bits))
+    assert rc == 0
+    return y.reshape(x.shape)
+
+
+def c_minmax_f64(x, per_channel):
+    x2 = _as_2d_f64(x, per_channel)
+    mn, mx = np.empty(x2.shape[0], np.float64), np.empty(x2.shape[0], np.float64)
+    lib().orc_minmax_f64(_pd(x2), x2.shape[0], x2.shape[1], _pd(mn), _pd(mx))
+    return mn, mx
+
+
+def c_sse_grid_f64(x, per_channel, grid, mbits_list, n_bits=8, sign_bits=1, out=None, reduce="sum"):
+    """out[n_m, n_cand, C] (float64) += sum (LineSearchEstimator.loss_fx, range_estimators.py:161-169) or mean
+    (FP_MSE_Estimator, :337-347) over each row of (x - q(x; m, grid[i, c]))^2, x float64."""
+    x2 = _as_2d_f64(x, per_channel)
+    grid = _f32(grid)
+    mb = _f32(np.atleast_1d(mbits_list))
+    C = x2.shape[0]
+    assert grid.ndim == 2 and grid.shape[1] == C
+    out = np.zeros((mb.size, grid.shape[0], C), np.float64) if out is None else _f64(out)
+    lib().orc_sse_grid_f64(_pd(x2), C, x2.shape[1], _p(grid), grid.shape[0], _p(mb), mb.size, int(n_bits),
+                           int(sign_bits), _pd(out), int(reduce == "sum"))
+    return out
+
+
+def c_log2_f64(a):
+    return lib().orc_log2_f64(float(a))
+
+
+def c_exp2_f64(e):
+    return lib().orc_exp2_f64(float(e))
 
 
 def c_encode(x, maxval, mbits, n_bits=8, sign_bits=1):

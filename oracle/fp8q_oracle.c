@@ -25,6 +25,7 @@
  *   quantization/quantizers/fp8_quantizer.py:13-50    generate_all_values_fp(_scaled)
  *   quantization/range_estimators.py:56-125           current/all/running min-max
  *   quantization/range_estimators.py:285-369          FP_MSE_Estimator
+ *   quantization/range_estimators.py:133-282          LineSearchEstimator (fp64 lane, see below)
  */
 #include <math.h>
 #include <stdint.h>
@@ -195,6 +196,149 @@ int orc_mse_grid_f32(const float *x, int64_t C, int64_t inner, const float *grid
             acc += (double)(d * d);
         }
         mses[j] += (float)(acc / (double)inner);
+    }
+    return 0;
+}
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * fp64 lane -- the reference's chain on a float64 tensor (BASELINE config 1: compute_quant_error.py:19-20 samples in
+ * float64, range_estimators.py:161-169 / 236-256 evaluate 1000 candidates on them, quant_error_estimator.py:67-73 calls
+ * quant.forward on float64).  Type promotion in quantize_to_fp8_ste_MM (fp8_quantizer.py:105-133) with x float64 and
+ * maxval / mantissa bits float32 TENSORS: M, E and bias stay float32 (:105-110, every operand is float32); xc, log2|xc|,
+ * the sum with bias, floor / clamp, the scale exponent, 2^e, the division, round and the product are float64.
+ *
+ * log2 and 2^x in double are 1-ulp library routines in the reference (Sleef, through ATen's Vectorized<double>) whose
+ * last bit no independent implementation reproduces; here they are the table-driven evaluations below, the SAME IEEE op
+ * sequence the HIP kernels run (csrc/fp8q_device.h: log2_tab_d, make_chan_fast), so HIP and oracle agree bit for bit.
+ * tests/test_oracle_f64.py pins both against libm (log2: <= 2^-45 (1 + |v|) absolute; 2^x: <= 2 ulp) and the f64 chain
+ * against reference-generated goldens (g1c_quantize_f64.npz: <= 2 ulp(double) per element, no grid-step flips).
+ * --------------------------------------------------------------------------------------------------------------- */
+#include "fp8q_oracle_tables.h"
+
+static double orc_log2_d(double a)
+{
+    if (!(a > 0.0) || a == INFINITY) return a == 0.0 ? -INFINITY : (a > 0.0 ? a : NAN);
+    int adj = 0;
+    if (a < 0x1p-1022) { /* denormal double: renormalise */
+        a *= 0x1p64;
+        adj = -64;
+    }
+    uint64_t b;
+    memcpy(&b, &a, 8);
+    const int i = (int)(b >> 45) & 0x7f;
+    const uint64_t mb = (b & 0x000fffffffffffffull) | 0x3ff0000000000000ull;
+    double m;
+    memcpy(&m, &mb, 8);
+    const double r = fma(m, orc_tab[i], -1.0);
+    double p = fma(r, 1.0 / 7.0, -1.0 / 6.0);
+    p = fma(r, p, 1.0 / 5.0);
+    p = fma(r, p, -1.0 / 4.0);
+    p = fma(r, p, 1.0 / 3.0);
+    p = fma(r, p, -1.0 / 2.0);
+    p = fma(r, p, 1.0);
+    p = p * r; /* ln(1 + r) */
+    return (double)((int)(b >> 52) - 1023 + adj) + fma(p, 1.4426950408889634074, orc_tab[128 + i]);
+}
+
+/* 2^e = ldexp(2^-bf, n) with n = ceil(e), bf = n - e in [0, 1) (exact); 2^-bf = 2^(-j/128) exp(-(bf - j/128) ln 2) */
+static double orc_exp2_d(double e)
+{
+    if (!(fabs(e) < INFINITY)) return e != e ? e : (e > 0.0 ? INFINITY : 0.0);
+    const double n = ceil(e);
+    const double bf = n - e;
+    const int j = (int)(bf * 128.0);
+    const double t = -(bf - (double)j * (1.0 / 128.0)) * 0.69314718055994530942;
+    double q = fma(t, 1.0 / 720.0, 1.0 / 120.0);
+    q = fma(t, q, 1.0 / 24.0);
+    q = fma(t, q, 1.0 / 6.0);
+    q = fma(t, q, 0.5);
+    q = fma(t, q, 1.0);
+    q = q * t; /* exp(t) - 1 */
+    const double ej = orc_tab[256 + j];
+    const double g = fma(ej, q, ej);
+    if (n > 4000.0) return INFINITY;
+    if (n < -4000.0) return 0.0;
+    return ldexp(g, (int)n);
+}
+
+/* exported for tests/test_oracle_f64.py (checked against libm there) */
+double orc_log2_f64(double a) { return orc_log2_d(a); }
+double orc_exp2_f64(double e) { return orc_exp2_d(e); }
+
+static inline double t_max_d(double a, double b) { return (a != a) ? a : ((b != b) ? b : (a > b ? a : b)); }
+static inline double t_min_d(double a, double b) { return (a != a) ? a : ((b != b) ? b : (a < b ? a : b)); }
+
+/* fp8_quantizer.py:112-133 for one float64 element; the channel constants are the float32 ones (orc_chan) */
+static inline double orc_quant1_f64(double x, const orc_chan_t *p)
+{
+    double xc = t_min_d(t_max_d(x, (double)p->minval), (double)p->maxval);
+    double v = orc_log2_d(fabs(xc)) + (double)p->bias;
+    double ls = floor(v);
+    if (ls < 1.0) ls = 1.0;
+    double e = (ls - (double)p->M) - (double)p->bias;
+    double s = orc_exp2_d(e);
+    return rint(xc / s) * s;
+}
+
+/* K1 on float64.  x, y: [C, inner] doubles; maxval: fp32, n_maxval == 1 or C. */
+int orc_quantize_f64(const double *x, double *y, int64_t C, int64_t inner, const float *maxval, int64_t n_maxval,
+                     float mbits, int n_bits, int sign_bits)
+{
+    if (n_maxval != 1 && n_maxval != C) return -1;
+    for (int64_t c = 0; c < C; ++c) {
+        const orc_chan_t p = orc_chan(maxval[n_maxval == 1 ? 0 : c], mbits, n_bits, sign_bits);
+#pragma omp parallel for schedule(static) if (inner >= 4096)
+        for (int64_t i = 0; i < inner; ++i) y[c * inner + i] = orc_quant1_f64(x[c * inner + i], &p);
+    }
+    return 0;
+}
+
+/* min / max of float64 rows (LineSearchEstimator._define_search_range, range_estimators.py:205-222: data.min(), data.max()) */
+int orc_minmax_f64(const double *x, int64_t C, int64_t inner, double *mn, double *mx)
+{
+#pragma omp parallel for schedule(static)
+    for (int64_t c = 0; c < C; ++c) {
+        double lo = INFINITY, hi = -INFINITY;
+        int nan = 0;
+        for (int64_t i = 0; i < inner; ++i) {
+            double v = x[c * inner + i];
+            nan |= (v != v);
+            lo = v < lo ? v : lo;
+            hi = v > hi ? v : hi;
+        }
+        mn[c] = nan ? NAN : lo;
+        mx[c] = nan ? NAN : hi;
+    }
+    return 0;
+}
+
+/* K4 on float64: the candidate loop of LineSearchEstimator._perform_1D_search (range_estimators.py:236-256) with
+ * loss_fx (:161-169: torch.sum((data - y) ** 2), per row when per_channel_loss) -- reduce_sum != 0 -- or the mean of
+ * FP_MSE_Estimator.forward (:337-347) -- reduce_sum == 0.  out: [n_m, n_cand, C] doubles, accumulated (+=).
+ * The sum is compensated (Neumaier): the checker's value is the correctly rounded sum to ~1 ulp, whatever the order
+ * the reference's ATen cascade or the HIP kernel's tree use (both within ~1e-15 relative of it). */
+int orc_sse_grid_f64(const double *x, int64_t C, int64_t inner, const float *grid, int64_t n_cand, const float *mbits,
+                     int n_m, int n_bits, int sign_bits, double *out, int reduce_sum)
+{
+    int64_t jobs = (int64_t)n_m * n_cand * C;
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int64_t j = 0; j < jobs; ++j) {
+        int64_t c = j % C;
+        int64_t i = (j / C) % n_cand;
+        int m = (int)(j / (C * n_cand));
+        float g = grid[i * C + c];
+        orc_chan_t p = orc_chan(fabsf(t_max(fabsf(-g), g)), mbits[m], n_bits, sign_bits); /* set_quant_range(-g, g) */
+        const double *xr = x + c * inner;
+        double sum = 0.0, comp = 0.0;
+        for (int64_t k = 0; k < inner; ++k) {
+            double d = xr[k] - orc_quant1_f64(xr[k], &p);
+            double v = d * d;
+            double t = sum + v;
+            comp += fabs(sum) >= fabs(v) ? (sum - t) + v : (v - t) + sum;
+            sum = t;
+        }
+        sum += comp;
+        out[j] += reduce_sum ? sum : sum / (double)inner;
     }
     return 0;
 }

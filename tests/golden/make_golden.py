@@ -23,6 +23,8 @@ Fixture files:
   g9_mobilenetv2.npz QuantizedMobileNetV2 (models/mobilenet_v2_quantized.py:29-92) + MSE, config 4 at 64x64
   g1b_bulk.npz       quantize_to_fp8_ste_MM on 4 x 4 M seeded normals: output hash + sparse difference to the C oracle
   g10_autograd.npz   backward of quantize_to_fp8_ste_MM (d/dx, d/dmaxval)
+  g1c_quantize_f64.npz quantize_to_fp8_ste_MM on FLOAT64 inputs (ATen type promotion: bias float32, the rest float64)
+  (g5 also holds LineSearchEstimator.loss_array -- 1001 float64 sums per distribution and format -- and the chosen index)
 """
 import os
 import sys
@@ -332,6 +334,69 @@ def make_g7():
     print("g7 ok")
 
 
+def edge_inputs_f64(M, maxval, sign_bits, n_bits=8):
+    """float64 twin of edge_inputs: ties and binade borders placed with double precision."""
+    E = n_bits - sign_bits - M
+    mv = float(np.float32(maxval))
+    bias = float(np.float32(np.float32(np.float32(2.0 ** E - np.float32(np.log2(np.float32(mv)))) +
+                                       np.float32(np.log2(2 - 2.0 ** (-M)))) - np.float32(1)))
+    vals = [0.0, -0.0, 1e-30, -1e-30, 1e-310, -4e-320, 1e-42, mv, -mv, mv * 1.5, -mv * 1.5, float("inf"), float("-inf"),
+            float("nan"), float(np.nextafter(mv, 0.0)), float(np.nextafter(mv, np.inf)), 1.0, 0.5, 2.0, -0.25]
+    pmax = int(2 ** E)
+    for p in sorted(set([1, 2, 3, max(pmax // 2, 1), max(pmax - 2, 1), max(pmax - 1, 1), pmax])):
+        s = 2.0 ** (p - M - bias)
+        lo = 2.0 ** (p - bias)
+        for k in (0, 1, 2, 2 ** M - 1, 2 ** M, 2 ** M + 1, 2 ** (M + 1) - 2, 2 ** (M + 1) - 1):
+            t = (k + 0.5) * s
+            vals += [t, float(np.nextafter(t, 0.0)), float(np.nextafter(t, np.inf)), -t]
+        vals += [lo, float(np.nextafter(lo, 0.0)), float(np.nextafter(lo, np.inf)), -lo, lo * (1 + 2.0 ** -30),
+                 lo * (1 - 2.0 ** -30)]
+    return np.array(vals, dtype=np.float64)
+
+
+def make_g1c():
+    """quantize_to_fp8_ste_MM on float64 tensors (BASELINE config 1's dtype): maxval / mantissa bits float32 tensors,
+    so bias is float32 and everything downstream of x is float64 (fp8_quantizer.py:105-133 under type promotion)."""
+    out = {}
+    rng = np.random.RandomState(4321)
+    base = rng.randn(1024)
+    cases = []
+    cid = 0
+    for M in (1, 2, 3, 4, 5, 6):
+        for mv in (default_maxval(M), 2.5, 0.7361, 18.583):
+            for sb in (1, 0):
+                if sb == 0 and mv != 0.7361:
+                    continue
+                x = np.concatenate([base * (mv / 2.3), edge_inputs_f64(M, mv, sb)])
+                y = quantize_to_fp8_ste_MM(torch.from_numpy(x.copy()), 8, torch.Tensor([mv]), torch.Tensor([float(M)]), sb)
+                assert y.dtype == torch.float64
+                out[f"c{cid}_x"] = x
+                out[f"c{cid}_y"] = y.numpy()
+                cases.append((cid, M, float(np.float32(mv)), sb, 1))
+                cid += 1
+    for M in (2, 3, 5):     # per-channel maxval [8], x [8, 300]
+        mvs = (np.abs(rng.randn(8)) * 2 + 0.05).astype(np.float32)
+        x = rng.randn(8, 300) * (mvs[:, None].astype(np.float64) / 2.0)
+        y = quantize_to_fp8_ste_MM(torch.from_numpy(x.copy()), 8, torch.from_numpy(mvs.copy()), torch.Tensor([float(M)]), 1)
+        out[f"c{cid}_x"] = x
+        out[f"c{cid}_y"] = y.numpy()
+        out[f"c{cid}_maxval"] = mvs
+        cases.append((cid, M, -1.0, 1, 8))
+        cid += 1
+    mvs = np.array([1.0, 0.0, 2.5, np.inf, np.nan, 1e-40], dtype=np.float32)    # degenerate channels
+    x = rng.randn(6, 64)
+    x[1] = 0
+    y = quantize_to_fp8_ste_MM(torch.from_numpy(x.copy()), 8, torch.from_numpy(mvs.copy()), torch.Tensor([3.0]), 1)
+    out[f"c{cid}_x"] = x
+    out[f"c{cid}_y"] = y.numpy()
+    out[f"c{cid}_maxval"] = mvs
+    cases.append((cid, 3, -1.0, 1, 6))
+    cid += 1
+    out["cases"] = np.array(cases, dtype=np.float64)  # id, mbits, maxval(-1: per-channel), sign, n_maxval
+    np.savez_compressed(os.path.join(OUT, "g1c_quantize_f64.npz"), **out)
+    print("g1c:", cid, "cases")
+
+
 def copy_net(net):
     import copy
     return copy.deepcopy(net)
@@ -343,7 +408,7 @@ def make_g5():
     MSE -- plus a few raw values of the closed-form interval integrals (utils/distributions.py)."""
     from utils.distributions import ClippedGaussDistr, UniformDistr, ClippedStudentTDistr
     from quantization.quant_error_estimator import compute_expected_quant_mse, compute_expected_dot_prod_mse
-    from quantization.range_estimators import estimate_range_line_search
+    from quantization.range_estimators import LineSearchEstimator
     from quantization.quantizers.uniform_quantizers import SymmetricUniformQuantizer
     from utils import seed_all
     distrs = {"uniform": UniformDistr(range_min=-1.0, range_max=1.0, params_dict={}),
@@ -361,7 +426,11 @@ def make_g5():
             M = 7 - exp_bits
             q = FPQuantizer(n_bits=8, mantissa_bits=M, set_maxval=True) if exp_bits > 0 \
                 else SymmetricUniformQuantizer(n_bits=8)
-            rmin, rmax = estimate_range_line_search(sample, q)
+            est = LineSearchEstimator(quantizer=q)          # what estimate_range_line_search builds (:372-379)
+            rmin, rmax = est.forward(sample)
+            out[f"{name}_loss_{exp_bits}"] = np.asarray(est.loss_array, np.float64).copy()     # [1, 1001], [:, 0] = inf
+            out[f"{name}_search_{exp_bits}"] = np.array([est.max_pos_thr, est.max_search_range, est.step_size,
+                                                         float(est.one_sided_dist)])
             mse = compute_expected_quant_mse(d, q, rmin, rmax, n)
             dp = compute_expected_dot_prod_mse(d, d, q, q, rmin, rmax, rmin, rmax)
             rows.append((exp_bits, float(rmin), float(rmax), float(mse), float(dp)))
@@ -574,6 +643,7 @@ if __name__ == "__main__":
     make_g1b()
     make_g10()
     make_g1()
+    make_g1c()
     make_g2()
     make_g3()
     make_g4()

@@ -75,19 +75,34 @@ def test_uniform_quantizer_host_semantics():
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["uniform", "gauss", "student"])
 def test_compute_quant_error_vs_reference(g5, name):
-    """Whole config-1 procedure on the GPU: line-search range within one candidate step of the
-    reference's float64 search, analytic MSE within 1 %, SQNR within 0.05 dB."""
+    """Whole config-1 procedure on the GPU in the reference's own precision (float64 samples, float64 line search):
+    every format picks the reference's candidate -- the SAME index, hence the same float32 range -- and the analytic
+    MSEs follow to 1e-6 (FP formats; the reference scales their grid through a float32 tensor).  The INT8 row (a few
+    elementwise torch ops, not part of the FP8 path) picks the same candidate too; its ANALYTIC error keeps the note
+    below: the reference integrates a float32 grid."""
     import compute_quant_error as cqe
+    from quantization.range_estimators import LineSearchEstimator
     d = _distrs()[name]
+    cqe.seed_all(10)
+    samples = torch.as_tensor(d.sample((200000,))).cuda()
+    assert samples.dtype == torch.float64
+    for exp_bits, _ in cqe.FORMATS:
+        est = LineSearchEstimator(quantizer=cqe._make_quantizer(exp_bits, 8))
+        lo, hi = est.forward(samples)
+        ref_loss = g5[f"{name}_loss_{exp_bits}"]
+        assert int(est.loss_array.argmin(axis=1)[0]) == int(ref_loss.argmin(axis=1)[0]), (name, exp_bits)
+        np.testing.assert_allclose(est.loss_array[:, 1:], ref_loss[:, 1:], rtol=1e-12 if exp_bits else 1e-9)
+        np.testing.assert_array_equal([est.max_pos_thr, est.max_search_range, est.step_size, float(est.one_sided_dist)],
+                                      g5[f"{name}_search_{exp_bits}"])
     rows = cqe.compute_quant_error(d, n_samples=200000, seed=10, verbose=False)
     for (eb, M, rmax, mse, sqnr, dp, dps), (reb, rrmin, rrmax, rmse, rdp) in zip(rows, g5[f"{name}_rows"]):
         assert eb == reb
-        # the optimum is flat: a neighbouring candidate (fp32 vs the reference's float64 sums) moves the
-        # range by one step = (max|x| + 0.5) / 100, i.e. up to ~1.5 % of small ranges
-        assert abs(rmax - rrmax) <= 0.02 * rrmax + 1e-6, (name, eb, rmax, rrmax)
-        int_tol = {"uniform": 0.09, "gauss": 0.01, "student": 0.03}[name] if eb == 0 else 0.01
-        assert abs(mse - rmse) <= int_tol * rmse, (name, eb, mse, rmse)
-        assert abs(dp - rdp) <= (int_tol + 0.002) * rdp
+        assert rmax == rrmax, (name, eb, rmax, rrmax)                      # the same candidate -> the same float32 range
+        # INT8: the reference hands its integrator a float32 grid (catastrophic cancellation in the closed forms): its
+        # own numbers carry noise of +7.5 % / -0.14 % / +1.2 % against the float64 evaluation done here
+        tol = {"uniform": 0.09, "gauss": 0.003, "student": 0.02}[name] if eb == 0 else 2e-6
+        assert abs(mse - rmse) <= tol * rmse, (name, eb, mse, rmse)
+        assert abs(dp - rdp) <= tol * rdp, (name, eb, dp, rdp)
     if name == "gauss":   # BASELINE config 1 headline pair: E4M3 31.6 dB vs INT8 40.6 dB
         by = {r[0]: r for r in rows}
-        assert abs(by[4][4] - 31.55) < 0.05 and abs(by[0][4] - 40.56) < 0.05, (by[4][4], by[0][4])
+        assert abs(by[4][4] - 31.55) < 0.01 and abs(by[0][4] - 40.56) < 0.01, (by[4][4], by[0][4])
