@@ -435,9 +435,140 @@ k_mse_final(const double *__restrict__ ws, float *__restrict__ mses, int64_t C, 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Device-side search grid and winner selection of FP_MSE_Estimator: with these two, a calibration batch needs no host
+// round trip (the reference synchronises at range_estimators.py:305, :353 and :360).
+// ---------------------------------------------------------------------------------------------
+// grid[i, c] = torch.linspace(0.1 * mx_c, 1.2 * mx_c, steps)[i] bit for bit (range_estimators.py:296-305: the products
+// are python-float (double) multiplications of mx.item(), narrowed to float32 by linspace).  ATen's CPU kernel, for
+// fewer steps than its parallel grain, evaluates element i as fl32(start + step * i) for i < steps / 2 and
+// fl32(end - step * (steps - 1 - i)) after, each with one fused multiply-add, step = fl32(fl32(end - start) / (steps - 1)).
+// (fp8q.ops checks this kernel against torch.linspace itself once per process.)
+__global__ void __launch_bounds__(kBlock)
+k_mse_linspace(const float *__restrict__ mx, int64_t C, int steps, double lo_frac, double hi_frac, float *__restrict__ grid)
+{
+    const int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= C * steps) return;
+    const int i = (int)(idx / C);
+    const int64_t c = idx - (int64_t)i * C;
+    const double m = (double)mx[c];
+    const float start = (float)(lo_frac * m), end = (float)(hi_frac * m);
+    const float step = (end - start) / (float)(steps - 1);
+    grid[idx] = i < steps / 2 ? fmaf(step, (float)i, start) : fmaf(-step, (float)(steps - 1 - i), end);
+}
+
+// torch.min / torch.argmin over one dimension: the first index of the smallest value, a NaN counting as smaller than
+// everything (the first NaN wins).  Key = (isnan desc, value asc, index asc).
+struct ArgMin {
+    float v;
+    int idx;
+};
+
+__device__ __forceinline__ bool argmin_less(const ArgMin &a, const ArgMin &b)
+{
+    const bool an = a.v != a.v, bn = b.v != b.v;
+    if (an != bn) return an;
+    if (!an && a.v != b.v) return a.v < b.v;
+    return a.idx < b.idx;
+}
+
+__device__ __forceinline__ ArgMin wave_argmin(ArgMin a)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        ArgMin o;
+        o.v = __shfl_xor(a.v, off, 64);
+        o.idx = __shfl_xor(a.idx, off, 64);
+        if (argmin_less(o, a)) a = o;
+    }
+    return a;
+}
+
+// stage 1: one wave per channel.  For every mantissa width m: the minimum over the candidates and its first index;
+// then the channel's best width (range_estimators.py:350-351: mses.min(1)[0].argmin(0)).
+// sel: int32 [C, 1 + n_m] = {best width index, argmin_i for width 0, ..., argmin_i for width n_m - 1}
+__global__ void __launch_bounds__(kBlock)
+k_mse_select_rows(const float *__restrict__ mses, int64_t C, int n_m, int n_cand, int *__restrict__ sel)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= C) return;
+    ArgMin best_m = {__builtin_inff(), 0x7fffffff};
+    for (int m = 0; m < n_m; ++m) {
+        ArgMin a = {__builtin_inff(), 0x7fffffff};
+        for (int i = lane; i < n_cand; i += 64) {
+            const ArgMin o = {mses[((int64_t)m * n_cand + i) * C + c], i};
+            if (argmin_less(o, a)) a = o;
+        }
+        a = wave_argmin(a);
+        if (lane == 0) sel[c * (1 + n_m) + 1 + m] = a.idx;
+        const ArgMin o = {a.v, m};
+        if (argmin_less(o, best_m)) best_m = o;
+    }
+    if (lane == 0) sel[c * (1 + n_m)] = best_m.idx;
+}
+
+// stage 2 (one block): plurality vote over the channels' best widths (torch.mode: the most frequent value, the
+// smallest one on a tie -- :352-354), then per channel the winning width's argmin candidate and its maxval (:356-362).
+__global__ void __launch_bounds__(kBlock)
+k_mse_select_vote(const int *__restrict__ sel, const float *__restrict__ grid, int64_t C, int n_m, MseArgs a /* fmt[m].M = width m */,
+                  float *__restrict__ mbits_out, int *__restrict__ vote_out, float *__restrict__ maxval_out, float *__restrict__ xmin_out, float sign)
+{
+    __shared__ int hist[kMseMaxM];
+    __shared__ int s_vote;
+    if (threadIdx.x < kMseMaxM) hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (int64_t c = threadIdx.x; c < C; c += kBlock) atomicAdd(&hist[sel[c * (1 + n_m)]], 1);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int v = 0;
+        for (int m = 1; m < n_m; ++m)
+            if (hist[m] > hist[v]) v = m;
+        s_vote = v;
+        mbits_out[0] = a.fmt[v].M;
+        if (vote_out) vote_out[0] = v;
+    }
+    __syncthreads();
+    const int v = s_vote;
+    for (int64_t c = threadIdx.x; c < C; c += kBlock) {
+        const float mv = grid[(int64_t)sel[c * (1 + n_m) + 1 + v] * C + c];
+        maxval_out[c] = mv;
+        if (xmin_out) xmin_out[c] = sign * mv;       // sign_bits * -1.0 * maxval (:369)
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int fp8q_mse_linspace_f32(const float *mx, int64_t C, int n_cand, double lo_frac, double hi_frac, float *grid,
+                          fp8q_stream_t stream)
+{
+    if (!mx || !grid || C <= 0 || n_cand < 2 || n_cand > (1 << 20)) return FP8Q_EINVAL;
+    hipLaunchKernelGGL(k_mse_linspace, dim3((unsigned)cdiv(C * n_cand, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, mx, C,
+                       n_cand, lo_frac, hi_frac, grid);
+    return launch_rc();
+}
+
+size_t fp8q_mse_select_workspace_bytes(int64_t C, int n_m) { return C > 0 && n_m > 0 ? (size_t)C * (1 + n_m) * sizeof(int) + 16 : 16; }
+
+int fp8q_mse_select_f32(const float *mses, const float *grid, int64_t C, int64_t n_cand, const float *mbits_host, int n_m,
+                        int sign_bits, float *mbits_out, int *vote_out, float *maxval_out, float *xmin_out, void *ws,
+                        size_t ws_bytes, fp8q_stream_t stream)
+{
+    if (!mses || !grid || !mbits_host || !mbits_out || !maxval_out || C <= 0 || n_cand <= 0 || n_cand > (1 << 20) ||
+        n_m <= 0 || n_m > kMseMaxM || (sign_bits != 0 && sign_bits != 1))
+        return FP8Q_EINVAL;
+    if (!ws || ws_bytes < fp8q_mse_select_workspace_bytes(C, n_m) || ((uintptr_t)ws & 3)) return FP8Q_EWORKSPACE;
+    MseArgs a;
+    memset(&a, 0, sizeof(a));
+    for (int m = 0; m < n_m; ++m) a.fmt[m].M = mbits_host[m];   // the candidate widths as given (the vote returns one of them)
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_mse_select_rows, dim3((unsigned)cdiv(C, 4)), dim3(kBlock), 0, st, mses, C, n_m, (int)n_cand, (int *)ws);
+    if (int rc = launch_rc()) return rc;
+    hipLaunchKernelGGL(k_mse_select_vote, dim3(1), dim3(kBlock), 0, st, (const int *)ws, grid, C, n_m, a, mbits_out, vote_out, maxval_out, xmin_out, -(float)sign_bits);
+    return launch_rc();
+}
 
 static int mse_nsplit(int64_t C, int64_t inner, int64_t n_cand, int n_m)
 {

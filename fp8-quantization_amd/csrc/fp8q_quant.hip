@@ -33,9 +33,8 @@ namespace {
 // U = 16-byte groups per lane and step: 4 (16 KiB pieces per block), or 1 for cache-sized tensors, whose launches are
 // latency-bound and want four times the blocks (as k_affine_act: fp8q_epilogue.hip)
 template <bool NT, int U>
-__global__ void __launch_bounds__(kBlock)
-k_quant_rows(const float *__restrict__ x, float *__restrict__ y, int64_t inner,
-             const float *__restrict__ maxval, int per_channel, QFmt f)
+__device__ __forceinline__ void quant_rows_body(const float *__restrict__ x, float *__restrict__ y, int64_t inner,
+                                                const float *__restrict__ maxval, int per_channel, const QFmt &f)
 {
     __shared__ float2 lut[kLutMax];
     const int row = blockIdx.y;
@@ -95,6 +94,14 @@ k_quant_rows(const float *__restrict__ x, float *__restrict__ y, int64_t inner,
             }
         }
     }
+}
+
+template <bool NT, int U>
+__global__ void __launch_bounds__(kBlock)
+k_quant_rows(const float *__restrict__ x, float *__restrict__ y, int64_t inner,
+             const float *__restrict__ maxval, int per_channel, QFmt f)
+{
+    quant_rows_body<NT, U>(x, y, inner, maxval, per_channel, f);
 }
 
 // arguments of k_rows_direct
@@ -1167,9 +1174,8 @@ k_rows_reg(const float *__restrict__ x, float *__restrict__ y, int64_t C, int in
 }
 
 // K1 scalar fallback (x / y not 16-byte co-aligned): one row per blockIdx.y, dword accesses
-__global__ void __launch_bounds__(kBlock)
-k_quant_scalar(const float *__restrict__ x, float *__restrict__ y, int64_t inner,
-               const float *__restrict__ maxval, int per_channel, QFmt f)
+__device__ __forceinline__ void quant_scalar_body(const float *__restrict__ x, float *__restrict__ y, int64_t inner,
+                                                  const float *__restrict__ maxval, int per_channel, const QFmt &f)
 {
     __shared__ float2 lut[kLutMax];
     const int row = blockIdx.y;
@@ -1182,6 +1188,47 @@ k_quant_scalar(const float *__restrict__ x, float *__restrict__ y, int64_t inner
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < inner;
          i += (int64_t)gridDim.x * kBlock)
         yr[i] = quant_one(xr[i], c, lut, (float)f.pmax, f.qthr);
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_quant_scalar(const float *__restrict__ x, float *__restrict__ y, int64_t inner,
+               const float *__restrict__ maxval, int per_channel, QFmt f)
+{
+    quant_scalar_body(x, y, inner, maxval, per_channel, f);
+}
+
+// K1 with the mantissa width read from DEVICE memory (fp8q_quantize_dm_f32): the MSE estimator's plurality vote on the
+// mantissa bits (range_estimators.py:350-354) stays on the GPU, and the batch that follows it in the same calibration
+// forward is quantized with the winner without a host round trip.  The host cannot know the format, so it passes the
+// constants of every width the call admits (M = 1 .. n_bits - sign_bits); calibration-only path: one row per
+// blockIdx.y whatever the row length (the by-value kernels keep their tuned routes).
+struct FmtSel {
+    const float *mbits_dev;
+    int hi;           // n_bits - sign_bits
+    QFmt tab[8];      // tab[M - 1]
+};
+
+__device__ __forceinline__ QFmt pick_fmt(const FmtSel &s)
+{
+    float M = rintf(*s.mbits_dev);                       // torch.round: half to even (fp8_quantizer.py:105)
+    M = fminf(fmaxf(M, 1.0f), (float)s.hi);              // NaN -> 1 (the by-value entry point refuses NaN on the host)
+    return s.tab[(int)M - 1];
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_quant_rows_dm(const float *__restrict__ x, float *__restrict__ y, int64_t inner, const float *__restrict__ maxval,
+                int per_channel, FmtSel sel)
+{
+    const QFmt f = pick_fmt(sel);
+    quant_rows_body<false, kUnroll>(x, y, inner, maxval, per_channel, f);
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_quant_scalar_dm(const float *__restrict__ x, float *__restrict__ y, int64_t inner, const float *__restrict__ maxval,
+                  int per_channel, FmtSel sel)
+{
+    const QFmt f = pick_fmt(sel);
+    quant_scalar_body(x, y, inner, maxval, per_channel, f);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1697,6 +1744,47 @@ int fp8q_quantize_f32(const float *x, float *y, int64_t C, int64_t inner, const 
                            inner, maxval, per_channel, f);
     }
     return launch_rc();
+}
+
+int fp8q_quantize_dm_f32(const float *x, float *y, int64_t C, int64_t inner, const float *maxval, int64_t n_maxval,
+                         const float *mbits_dev, int n_bits, int sign_bits, fp8q_stream_t stream)
+{
+    if (C < 0 || inner < 0 || (n_maxval != 1 && n_maxval != C) || !mbits_dev) return FP8Q_EINVAL;
+    FmtSel sel;
+    sel.mbits_dev = mbits_dev;
+    sel.hi = n_bits - sign_bits;
+    if (sel.hi < 1 || sel.hi > 8) return FP8Q_EINVAL;
+    for (int M = 1; M <= 8; ++M)
+        if (int rc = make_fmt((float)(M <= sel.hi ? M : sel.hi), n_bits, sign_bits, &sel.tab[M - 1])) return rc;
+    if (C == 0 || inner == 0) return FP8Q_OK;
+    if (!x || !y || !maxval) return FP8Q_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int per_channel = n_maxval != 1;
+    if (!per_channel) {
+        inner *= C;
+        C = 1;
+    }
+    for (int64_t c0 = 0; c0 < C; c0 += 65535) {   // gridDim.y limit
+        const int64_t cn = (C - c0) < 65535 ? (C - c0) : 65535;
+        const float *xs = x + c0 * inner;
+        float *ys = y + c0 * inner;
+        // k_quant_rows peels every row to 16-byte alignment assuming x and y rows are co-aligned
+        const bool aligned = (((uintptr_t)xs ^ (uintptr_t)ys) & 15) == 0 && ((uintptr_t)xs & 3) == 0;
+        const int64_t pieces = inner / (4 * kBlock * kUnroll) > 0 ? inner / (4 * kBlock * kUnroll) : 1;
+        const int64_t cap = (4 * kTargetBlocks) / cn > 0 ? (4 * kTargetBlocks) / cn : 1;
+        const int64_t bx = balanced_blocks(pieces, cap);
+        if (aligned) {
+            hipLaunchKernelGGL(k_quant_rows_dm, dim3((unsigned)bx, (unsigned)cn), dim3(kBlock), 0, st, xs, ys, inner,
+                               maxval + (per_channel ? c0 : 0), per_channel, sel);
+        } else {
+            int64_t bs = cdiv(inner, kBlock);
+            if (bs > cap) bs = cap;
+            hipLaunchKernelGGL(k_quant_scalar_dm, dim3((unsigned)bs, (unsigned)cn), dim3(kBlock), 0, st, xs, ys, inner,
+                               maxval + (per_channel ? c0 : 0), per_channel, sel);
+        }
+        if (int rc = launch_rc()) return rc;
+    }
+    return FP8Q_OK;
 }
 
 static int minmax_nsplit(int64_t C, int64_t inner)

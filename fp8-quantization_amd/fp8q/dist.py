@@ -377,10 +377,8 @@ def mse_search_sharded(x_local, per_channel, mbit_list, n_bits=8, sign_bits=1, s
         mx = ops.minmax(x_local, per_channel, want_maxval=True)[2]
         if shard == "batch" and _multi(group):
             dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
-        from quantization.estimators import linspace_columns
-        cols = linspace_columns(mx.detach().cpu().tolist(), N_MSE_GRID)                # [C, 111], == torch.linspace per channel
-        grid = cols.to(x_local.device).transpose(0, 1).contiguous()                    # [111, C]
-        mses = torch.zeros(n_m, N_MSE_GRID, cols.shape[0], device=x_local.device)
+        grid = ops.mse_linspace(mx, N_MSE_GRID)                # [111, C] on the device, == torch.linspace per channel
+        mses = torch.zeros(n_m, N_MSE_GRID, grid.shape[1], device=x_local.device)
     else:
         grid, mses = state
     inc = torch.zeros_like(mses)

@@ -90,7 +90,8 @@ def _workspace(dev, nbytes, zeroed=False):
 
 
 def quantize(x, maxval, mbits, n_bits=8, sign_bits=1, out=None):
-    """K1: FP8 quantize+dequantize (fp8_quantizer.py:91-133).  maxval: CUDA fp32 tensor [1] or [C]."""
+    """K1: FP8 quantize+dequantize (fp8_quantizer.py:91-133).  maxval: CUDA fp32 tensor [1] or [C]; x float32 or
+    float64; mbits: a number, or a 1-element CUDA float32 tensor (read by the kernel: no host round trip)."""
     _require(x, "x", (torch.float32, torch.float64))
     _require(maxval, "maxval", like=x)
     x = x.contiguous()
@@ -100,6 +101,16 @@ def quantize(x, maxval, mbits, n_bits=8, sign_bits=1, out=None):
     if n_mv != 1 and n_mv != C:
         raise Fp8qError(f"maxval has {n_mv} elements, expected 1 or {C}")
     y = _out(out, x)
+    if isinstance(mbits, torch.Tensor) and mbits.is_cuda:
+        # mantissa width in DEVICE memory (the MSE estimator's vote, not yet brought to the host): fp8q_quantize_dm_f32
+        _require(mbits, "mbits", like=x)
+        if mbits.numel() != 1 or x.dtype != torch.float32:
+            raise Fp8qError("a device-resident mantissa width must be a 1-element float32 tensor, x float32")
+        with _on_device(x):
+            rc = lib().fp8q_quantize_dm_f32(x.data_ptr(), y.data_ptr(), C, inner, maxval.data_ptr(), n_mv,
+                                            mbits.data_ptr(), int(n_bits), int(sign_bits), _stream(x))
+        check(rc, "fp8q_quantize_dm_f32")
+        return y
     # float64 input (BASELINE config 1): the reference's chain under ATen's type promotion -- bias in float32,
     # everything downstream of x in float64 (fp8q_quantize_f64)
     fn = lib().fp8q_quantize_f64 if x.dtype == torch.float64 else lib().fp8q_quantize_f32
@@ -375,6 +386,71 @@ def mse_grid(x, per_channel, grid, mbits_list, n_bits, sign_bits, mses):
                                  int(sign_bits), mses.data_ptr(), ws.data_ptr(), ws.numel(), _stream(x))
     check(rc, "fp8q_mse_grid_f32")
     return mses
+
+
+_linspace_checked = {}
+
+
+def _linspace_self_check(steps, lo_frac, hi_frac, device):
+    """Once per process and (steps, fractions): the device search-grid kernel against torch.linspace itself on a few
+    ranges (another ATen build could evaluate linspace differently).  Synchronises; raises on a mismatch."""
+    key = (steps, lo_frac, hi_frac)
+    if _linspace_checked.get(key):
+        return
+    probe = torch.tensor([1.0, 0.7361, 3.3e-5, 123.456, 6.0e4, 0.0131, 2.5], dtype=torch.float32)
+    got = torch.empty((steps, probe.numel()), dtype=torch.float32, device=device)
+    dev_probe = probe.to(device)
+    check(lib().fp8q_mse_linspace_f32(dev_probe.data_ptr(), probe.numel(), steps, lo_frac, hi_frac, got.data_ptr(),
+                                      _stream(got)), "fp8q_mse_linspace_f32")
+    want = torch.stack([torch.linspace(lo_frac * float(v), hi_frac * float(v), steps) for v in probe.tolist()], 1)
+    if not torch.equal(got.cpu().view(torch.int32), want.view(torch.int32)):
+        raise Fp8qError("fp8q_mse_linspace_f32 does not reproduce torch.linspace on this PyTorch build")
+    _linspace_checked[key] = True
+
+
+def mse_linspace(mx, steps=111, lo_frac=0.1, hi_frac=1.2):
+    """[steps, C] float32 search grid of FP_MSE_Estimator on the device: column c == torch.linspace(lo_frac * mx[c],
+    hi_frac * mx[c], steps), bit for bit (range_estimators.py:296-305) -- no host round trip."""
+    _require(mx, "mx")
+    mx = mx.contiguous().view(-1)
+    C = mx.numel()
+    if C == 0:
+        return torch.empty((steps, 0), dtype=torch.float32, device=mx.device)
+    with _on_device(mx):
+        _linspace_self_check(int(steps), float(lo_frac), float(hi_frac), mx.device)
+        grid = torch.empty((steps, C), dtype=torch.float32, device=mx.device)
+        rc = lib().fp8q_mse_linspace_f32(mx.data_ptr(), C, int(steps), float(lo_frac), float(hi_frac), grid.data_ptr(),
+                                         _stream(mx))
+    check(rc, "fp8q_mse_linspace_f32")
+    return grid
+
+
+def mse_select(mses, grid, mbits_list, sign_bits=1):
+    """Winner of the MSE grid search on the device (range_estimators.py:350-369): per channel the mantissa width with the
+    smallest minimum, the plurality vote over the channels (torch.mode: smallest value on a tie), per channel the
+    winning width's argmin candidate.  Returns (mbits [1] CUDA float32, vote index [1] CUDA int32, maxval [C],
+    xmin [C] = -sign_bits * maxval) -- nothing comes back to the host."""
+    import ctypes
+    _require(mses, "mses")
+    _require(grid, "grid", like=mses)
+    n_m = len(mbits_list)
+    if mses.dim() != 3 or mses.shape[0] != n_m or tuple(mses.shape[1:]) != tuple(grid.shape) or not mses.is_contiguous() \
+            or not grid.is_contiguous():
+        raise Fp8qError(f"mses must be contiguous [{n_m}, n_cand, C] and grid contiguous [n_cand, C]")
+    n_cand, C = grid.shape
+    dev = mses.device
+    out = torch.empty((2, C), dtype=torch.float32, device=dev)
+    mb = torch.empty(1, dtype=torch.float32, device=dev)
+    vote = torch.empty(1, dtype=torch.int32, device=dev)
+    L = lib()
+    ws = _workspace(dev, L.fp8q_mse_select_workspace_bytes(C, n_m))
+    mbh = (ctypes.c_float * n_m)(*[float(v) for v in mbits_list])
+    with _on_device(mses):
+        rc = L.fp8q_mse_select_f32(mses.data_ptr(), grid.data_ptr(), C, n_cand, mbh, n_m, int(sign_bits), mb.data_ptr(),
+                                   vote.data_ptr(), out[0].data_ptr(), out[1].data_ptr(), ws.data_ptr(), ws.numel(),
+                                   _stream(mses))
+    check(rc, "fp8q_mse_select_f32")
+    return mb, vote, out[0], out[1]
 
 
 def minmax_f64(x, per_channel):

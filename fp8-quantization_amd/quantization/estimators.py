@@ -188,10 +188,13 @@ class FP_MSE_Estimator(RangeEstimatorBase):
     """Grid search over 111 clipping values (x 1..n mantissa widths) minimising the MSE.
 
     The double Python loop of the reference (range_estimators.py:337-347: 111*|m| full quantizer
-    passes, each ~16 kernel launches) is ONE pass over x (fp8q_mse_grid_f32).  Host round trips:
-    one on the first batch to lay out the search grid exactly as the reference does (python
-    floats -> torch.linspace), one per call for the plurality vote on mantissa bits (the reference
-    synchronises there too, :353).
+    passes, each ~16 kernel launches) is ONE pass over x (fp8q_mse_grid_f32), and the three host round trips of the
+    reference (:305 mx.item() for the search grid, :353 the mantissa vote's .item(), :360 one gather per channel)
+    are device kernels (fp8q_mse_linspace_f32, fp8q_mse_select_f32): a call enqueues work and returns.  The voted
+    mantissa width reaches the quantizer as a device scalar (FPQuantizer.mantissa_bits keeps it pending; the batch
+    that follows in the same forward is quantized by fp8q_quantize_dm_f32) and comes to the host when somebody reads
+    it -- QuantizedModel.fix_ranges() collects all of a model's in one copy.
+    Still synchronising: allow_unsigned=True (the reference's any(x < 0) decides sign_bits, a host-side int).
     """
     N_GRID = 111   # hard-coded in the reference (:305); `num_candidates` is accepted and ignored
 
@@ -212,21 +215,33 @@ class FP_MSE_Estimator(RangeEstimatorBase):
     def _define_search_range(self, x, n_m):
         if self.search_grid is None:
             assert self.mses is None
-            _, _, mx = _ops.minmax(x, self.per_channel, want_maxval=True)
+            if x.dtype == torch.float64:
+                mn, hi = _ops.minmax_f64(x, self.per_channel)
+                mx = torch.max(mn.abs(), hi.abs()).float()      # == float32 of the python float the reference multiplies
+            else:
+                _, _, mx = _ops.minmax(x, self.per_channel, want_maxval=True)
             if self._dist_batch():                          # batch-sharded: the grid comes from the global max
                 import torch.distributed as dist
                 dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=self._group())
-            mx_host = mx.detach().cpu().tolist()            # one sync, first batch only
-            cols = linspace_columns(mx_host, self.N_GRID)                                   # [C, 111], == torch.linspace per channel
-            self.search_grid = cols.to(x.device).transpose(0, 1).contiguous()               # [111, C]
-            self.mses = torch.zeros(n_m, self.N_GRID, cols.shape[0], device=x.device)
+            self.search_grid = _ops.mse_linspace(mx, self.N_GRID)          # [111, C], == torch.linspace per channel
+            self.mses = torch.zeros(n_m, self.N_GRID, self.search_grid.shape[1], device=x.device)
         return self.search_grid, self.mses
+
+    def _accumulate(self, x, grid, mbit_list, q, mses):
+        """mses += this batch's per-channel mean squared error of every (width, candidate)"""
+        if x.dtype == torch.float64:        # the reference adds a float64 mean into its float32 table (:346-347)
+            inc = torch.zeros(mses.shape, dtype=torch.float64, device=mses.device)
+            _ops.mse_grid_f64(x, self.per_channel, grid, mbit_list, q.n_bits, q.sign_bits, inc, reduce="mean")
+            mses += inc.float()
+        else:
+            _ops.mse_grid(x, self.per_channel, grid, mbit_list, q.n_bits, q.sign_bits, mses)
 
     def forward(self, x):
         q = self.quantizer
-        mbit_list = [float(q.mantissa_bits)]
         if q.mse_include_mantissa_bits:
             mbit_list = [float(m) for m in range(1, q.n_bits - q.sign_bits)]
+        else:
+            mbit_list = [float(q.mantissa_bits)]
         if self.mses is not None and len(mbit_list) != self.mses.shape[0]:
             # allow_unsigned flipped sign_bits after the first batch (one-sided data), which changes the number of
             # candidate mantissa widths; the reference indexes past its accumulated [|m|, 111, C] table here
@@ -251,31 +266,28 @@ class FP_MSE_Estimator(RangeEstimatorBase):
             # over the ranks in float64 (<= 2.7 KB) -> the mean over the concatenated batch
             import torch.distributed as dist
             inc = torch.zeros_like(mses)
-            _ops.mse_grid(x, self.per_channel, grid, mbit_list, q.n_bits, q.sign_bits, inc)
+            self._accumulate(x, grid, mbit_list, q, inc)
             n_local = float(x.numel())
             packed = torch.cat([inc.double().reshape(-1) * n_local,
                                 torch.tensor([n_local], dtype=torch.float64, device=inc.device)])
             dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=self._group())
             mses += (packed[:-1] / packed[-1]).to(mses.dtype).view_as(mses)
         elif q.set_maxval:
-            _ops.mse_grid(x, self.per_channel, grid, mbit_list, q.n_bits, q.sign_bits, mses)
+            self._accumulate(x, grid, mbit_list, q, mses)
         else:
             # set_maxval=False: set_quant_range is a no-op, every candidate scores the same
             cur = q.maxval.to(x.device).reshape(1, -1).expand(1, grid.shape[1]).contiguous()
             one = torch.zeros(len(mbit_list), 1, grid.shape[1], device=x.device)
-            _ops.mse_grid(x, self.per_channel, cur, mbit_list, q.n_bits, q.sign_bits, one)
+            self._accumulate(x, cur, mbit_list, q, one)
             mses += one
 
-        best_m_per_ch = mses.min(1)[0].argmin(0)
-        best_idx = int(torch.mode(best_m_per_ch).values.item())
-        best_mbits = float(mbit_list[best_idx])
-        arg = mses[best_idx].argmin(0)                                  # [C]
-        maxval = grid.gather(0, arg.unsqueeze(0)).squeeze(0)            # grid[arg[c], c]
-        q.mantissa_bits = torch.tensor(best_mbits)
+        mbits_dev, _vote, maxval, xmin = _ops.mse_select(mses, grid, mbit_list, sign_bits)
+        # a single candidate width needs no vote: keep the host value (no pending device scalar, the tuned K1 routes)
+        q.mantissa_bits = mbits_dev if len(mbit_list) > 1 else torch.tensor([float(mbit_list[0])])
         if q.set_maxval:
             q.maxval = grid[-1].clone()      # the reference leaves the last candidate in place
-        self.last_maxval = None
-        return sign_bits * -1.0 * maxval, maxval
+        self.last_maxval = maxval            # == |max(|xmin|, maxval)|: what set_quant_range(xmin, maxval) will store
+        return xmin, maxval
 
 
 class OptMethod(BaseEnumOptions):

@@ -83,8 +83,11 @@ def _host_float(t):
 
 
 def quantize_to_fp8_ste_MM(x_float, n_bits, maxval, num_mantissa_bits, sign_bits):
-    """Same call signature as fp8_quantizer.py:91-97.  maxval: tensor [1] or [C] on x's device."""
-    mbits = _host_float(num_mantissa_bits)
+    """Same call signature as fp8_quantizer.py:91-97.  maxval: tensor [1] or [C] on x's device.  num_mantissa_bits: a
+    number / host tensor (passed to the kernel by value) or a 1-element tensor on x's GPU (read by the kernel)."""
+    on_device = (isinstance(num_mantissa_bits, torch.Tensor) and num_mantissa_bits.is_cuda and num_mantissa_bits.numel() == 1
+                 and x_float.dtype == torch.float32 and not (torch.is_grad_enabled() and x_float.requires_grad))
+    mbits = num_mantissa_bits.detach().reshape(1).float() if on_device else _host_float(num_mantissa_bits)
     if not isinstance(maxval, torch.Tensor):
         maxval = torch.tensor([float(maxval)], dtype=torch.float32)
     maxval = maxval.to(device=x_float.device, dtype=torch.float32).reshape(-1)
@@ -179,6 +182,35 @@ class FPQuantizer(QuantizerBase):
 
     _RANGE_ATTRS = ("maxval", "mantissa_bits", "sign_bits")
 
+    # `mantissa_bits` is a [1] HOST tensor, as everywhere in the reference's host logic (float(q.mantissa_bits), state
+    # dicts, printouts).  One producer writes it on the DEVICE: the MSE estimator's plurality vote
+    # (fp8q_mse_select_f32).  Such a value stays pending on the GPU -- forward() hands it to the kernel as a device
+    # scalar -- until somebody reads the attribute (one .cpu(), then cached) or QuantizedModel.fix_ranges() brings all
+    # pending widths of a model over in one copy.
+    @property
+    def mantissa_bits(self):
+        host = self.__dict__.get("_mbits_host")
+        if host is None:
+            host = self.__dict__["_mbits_dev"].detach().reshape(1).float().cpu()     # synchronises
+            self.__dict__["_mbits_host"] = host
+        return host
+
+    @mantissa_bits.setter
+    def mantissa_bits(self, value):
+        if isinstance(value, torch.Tensor) and value.is_cuda:
+            self.__dict__["_mbits_dev"], self.__dict__["_mbits_host"] = value, None
+        else:
+            self.__dict__["_mbits_dev"], self.__dict__["_mbits_host"] = None, value
+
+    def _mantissa_bits_arg(self):
+        """what forward() passes to the kernel: the host value when it is known, else the pending device scalar"""
+        host = self.__dict__.get("_mbits_host")
+        return host if host is not None else self.__dict__["_mbits_dev"]
+
+    def _pending_mantissa_bits(self):
+        """the device scalar not yet seen by the host, or None"""
+        return self.__dict__.get("_mbits_dev") if self.__dict__.get("_mbits_host") is None else None
+
     def __setattr__(self, name, value):
         # every assignment of a range attribute starts a new range epoch: consumers that cache results computed with
         # these ranges (the layers' quantized-weight cache) key on it instead of on tensor addresses
@@ -190,7 +222,7 @@ class FPQuantizer(QuantizerBase):
     def forward(self, x_float):
         if self.maxval.device != x_float.device:
             self.maxval = self.maxval.to(x_float.device)
-        return quantize_to_fp8_ste_MM(x_float, self.n_bits, self.maxval, self.mantissa_bits,
+        return quantize_to_fp8_ste_MM(x_float, self.n_bits, self.maxval, self._mantissa_bits_arg(),
                                       self.sign_bits)
 
     # NB: plain methods, as in the reference (:207-211): truthy when used without a call

@@ -20,7 +20,7 @@ from .registry import BaseEnumOptions, ClassEnumOptions, MethodMap
 from .fp8 import FPQuantizer, QuantizerBase, QuantizerNotInitializedError
 from .uniform import SymmetricUniformQuantizer, AsymmetricUniformQuantizer
 from .estimators import (RangeEstimators, RangeEstimatorBase, CurrentMinMaxEstimator,
-                         AllMinMaxEstimator, RunningMinMaxEstimator)
+                         AllMinMaxEstimator, RunningMinMaxEstimator, FP_MSE_Estimator)
 
 
 class QMethods(ClassEnumOptions):
@@ -104,7 +104,13 @@ class QuantizationManager(nn.Module):
                 and not (x.requires_grad and torch.is_grad_enabled()))   # weights are Parameters: fine under no_grad
         if not fast:
             xmin, xmax = est(x)                      # generic protocol, reference order
-            self.set_quant_range(xmin, xmax)
+            if (type(q) is FPQuantizer and type(est) is FP_MSE_Estimator and q.set_maxval and not q.allow_unsigned
+                    and est.last_maxval is not None):
+                # set_quant_range(xmin, xmax) would store |max(|xmin|, xmax)| == xmax (three tiny launches): the
+                # estimator's select kernel already wrote it
+                q._set_maxval_tensor(est.last_maxval)
+            else:
+                self.set_quant_range(xmin, xmax)
             return q(x)
         if not q.set_maxval:
             est(x)                                   # estimate is tracked, the format's maxval stays

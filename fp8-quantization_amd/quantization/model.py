@@ -25,6 +25,19 @@ def _plan_signature(m, q):
             bool(getattr(m, "_qw", False)))
 
 
+def materialize_mantissa_bits(model):
+    """Bring every mantissa width that is still pending on the GPU (the MSE estimators' votes) to the host in ONE
+    device-to-host copy; afterwards every quantizer passes its width by value again (the tuned K1 routes)."""
+    pending = [(q, q._pending_mantissa_bits()) for q in model.modules() if hasattr(q, "_pending_mantissa_bits")]
+    pending = [(q, t) for q, t in pending if t is not None]
+    if not pending:
+        return 0
+    host = torch.cat([t.detach().reshape(1).float() for _, t in pending]).cpu()
+    for (q, _), v in zip(pending, host):
+        q.__dict__["_mbits_host"] = v.reshape(1).clone()       # (not an assignment: the range epoch stays)
+    return len(pending)
+
+
 def quantizer_ranges(model):
     """{manager name: {maxval, mantissa_bits, sign_bits, state}} for every FP8 quantizer of `model`.
 
@@ -297,6 +310,7 @@ class QuantizedModel(nn.Module):
 
     def fix_ranges(self):
         _for_managers(self, lambda m: m.fix_ranges(), need_init=True)
+        materialize_mantissa_bits(self)
         # end of calibration = the one place where a host sync is free: surface what the enqueue-only min/max
         # launches could not report (a reducer block that timed out -> NaN range; a dirty workspace)
         import fp8q

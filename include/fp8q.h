@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define FP8Q_VERSION 400 /* 0.4.0: float64 lane (fp8q_quantize_f64, fp8q_minmax_f64, fp8q_mse_grid_f64) */
+#define FP8Q_VERSION 400 /* 0.4.0: float64 lane (fp8q_quantize_f64, fp8q_minmax_f64, fp8q_mse_grid_f64); sync-free MSE calibration */
 
 #define FP8Q_OK 0
 #define FP8Q_EINVAL (-1)       /* null pointer, negative size, n_maxval not in {1, C}, ... */
@@ -156,6 +156,31 @@ size_t fp8q_mse_workspace_bytes(int64_t C, int64_t inner, int64_t n_cand, int n_
 int fp8q_mse_grid_f32(const float *x, int64_t C, int64_t inner, const float *grid, int64_t n_cand,
                       const float *mbits_host, int n_m, int n_bits, int sign_bits, float *mses,
                       void *ws, size_t ws_bytes, fp8q_stream_t stream);
+
+/*
+ * Sync-free MSE calibration.  The reference's FP_MSE_Estimator goes back to the host three times per call
+ * (range_estimators.py:305 mx.item() for the search grid, :353 torch.mode(...).item() for the mantissa vote, :360 one
+ * gather per channel); these entry points keep all of it on the device:
+ *   fp8q_mse_linspace_f32  grid[i, c] = torch.linspace(lo_frac * mx[c], hi_frac * mx[c], n_cand)[i], bit for bit
+ *                          ([n_cand, C]; the reference uses 0.1, 1.2 and 111: :296-305)
+ *   fp8q_mse_select_f32    :350-369 on mses [n_m, n_cand, C] / grid [n_cand, C]: per channel the width with the smallest
+ *                          minimum, the plurality vote over the channels (torch.mode: smallest value on a tie) ->
+ *                          mbits_out[0] = mbits_host[vote] (DEVICE scalar), vote_out[0] = its index (may be NULL), per
+ *                          channel maxval_out[c] = grid[argmin_i mses[vote, i, c], c] and xmin_out[c] = -sign_bits *
+ *                          maxval (may be NULL).  torch.min / argmin semantics: first index of the minimum, NaN first.
+ *                          ws: at least fp8q_mse_select_workspace_bytes(C, n_m) bytes, 4-byte aligned.
+ *   fp8q_quantize_dm_f32   K1 (fp8q_quantize_f32) with the mantissa width read from a DEVICE scalar, so that the batch
+ *                          that follows the vote in the same calibration forward needs no host round trip.  One row
+ *                          per workgroup column whatever the row length: a calibration path, not the tuned K1 routes.
+ */
+int fp8q_mse_linspace_f32(const float *mx, int64_t C, int n_cand, double lo_frac, double hi_frac, float *grid,
+                          fp8q_stream_t stream);
+size_t fp8q_mse_select_workspace_bytes(int64_t C, int n_m);
+int fp8q_mse_select_f32(const float *mses, const float *grid, int64_t C, int64_t n_cand, const float *mbits_host, int n_m,
+                        int sign_bits, float *mbits_out, int *vote_out, float *maxval_out, float *xmin_out, void *ws,
+                        size_t ws_bytes, fp8q_stream_t stream);
+int fp8q_quantize_dm_f32(const float *x, float *y, int64_t C, int64_t inner, const float *maxval, int64_t n_maxval,
+                         const float *mbits_dev, int n_bits, int sign_bits, fp8q_stream_t stream);
 
 /*
  * The float64 lane -- BASELINE config 1.  compute_quant_error.py:19-20 draws float64 samples; LineSearchEstimator

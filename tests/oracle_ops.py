@@ -16,7 +16,11 @@ def _t(a):
 
 
 def quantize(x, maxval, mbits, n_bits=8, sign_bits=1, out=None):
-    y = _t(oracle.c_quantize(x.detach().numpy(), maxval.detach().numpy(), mbits, n_bits, sign_bits))
+    mbits = float(mbits)        # (a 1-element tensor on the GPU path: the device-resident vote)
+    if x.dtype == torch.float64:
+        y = _t(oracle.c_quantize_f64(x.detach().numpy(), maxval.detach().numpy(), mbits, n_bits, sign_bits))
+    else:
+        y = _t(oracle.c_quantize(x.detach().numpy(), maxval.detach().numpy(), mbits, n_bits, sign_bits))
     if out is not None:
         out.copy_(y)
         return out
@@ -71,6 +75,33 @@ def mse_grid(x, per_channel, grid, mbits_list, n_bits, sign_bits, mses):
     return mses
 
 
+def mse_linspace(mx, steps=111, lo_frac=0.1, hi_frac=1.2):
+    """range_estimators.py:296-305: torch.linspace per channel, python-float products"""
+    return torch.stack([torch.linspace(lo_frac * v, hi_frac * v, steps) for v in mx.reshape(-1).tolist()], 1)
+
+
+def mse_select(mses, grid, mbits_list, sign_bits=1):
+    """range_estimators.py:350-369 with the reference's own torch calls"""
+    best_m_per_ch = mses.min(1)[0].argmin(0)
+    vote = int(torch.mode(best_m_per_ch).values.item())
+    arg = mses[vote].argmin(0)
+    maxval = grid.gather(0, arg.unsqueeze(0)).squeeze(0)
+    return (torch.tensor([float(mbits_list[vote])]), torch.tensor([vote], dtype=torch.int32), maxval,
+            sign_bits * -1.0 * maxval)
+
+
+def minmax_f64(x, per_channel):
+    mn, mx = oracle.c_minmax_f64(x.detach().numpy(), per_channel)
+    return _t(mn), _t(mx)
+
+
+def mse_grid_f64(x, per_channel, grid, mbits_list, n_bits, sign_bits, out, reduce="sum"):
+    res = oracle.c_sse_grid_f64(x.detach().numpy(), per_channel, grid.numpy(), list(mbits_list), n_bits, sign_bits,
+                                out.numpy().copy(), reduce=reduce)
+    out.copy_(_t(res))
+    return out
+
+
 def fused_max_inner():
     return 16384
 
@@ -79,7 +110,8 @@ def fused_max_inner():
 def patched():
     """with oracle_ops.patched(): ... -> fp8q.ops.* run on the CPU oracle inside the block."""
     import fp8q
-    names = ("quantize", "minmax", "minmax_quantize", "mse_grid", "fused_max_inner", "new_packed", "ranges_unpack")
+    names = ("quantize", "minmax", "minmax_quantize", "mse_grid", "fused_max_inner", "new_packed", "ranges_unpack",
+             "mse_linspace", "mse_select", "minmax_f64", "mse_grid_f64")
     saved = {n: getattr(fp8q.ops, n) for n in names}
     try:
         for n in names:
