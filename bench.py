@@ -12,10 +12,15 @@ One step = one pass of the hot path quantize_to_fp8_ste_MM (fp8_quantizer.py:91-
 the tensor = one launch of the HIP kernel k_rows_flat<0> (short rows cut into aligned 16 KiB chunks) through the C ABI (fp8q_quantize_f32).
 Inputs are resident in HBM before the timed region.
 
-N > 1 (one process per GPU, torch.distributed/RCCL).  `value` is the channel-sharded K1 rate: every rank owns 2^21
-channels, channels are independent, no data-path collective (weak scaling) -- channels*147 of ALL ranks / max-over-ranks
-time.  Next to it, in the same JSON line, `north_star_path` times the two exchange steps north_star names, at any N
-(N = 1: the collectives are no-ops and the figures are the kernels' own):
+N > 1 (one process per GPU, torch.distributed/RCCL).  `value` is north_star's own weight flow END TO END: one
+[N * 2^21, 3, 7, 7] tensor held by every rank, rank r quantizes channels channel_partition(C, N)[r] (the N = 1 kernel on
+the N = 1 shard: weak scaling) and the shards are re-assembled on every rank with one RCCL all-gather over xGMI
+(fp8q.dist.quantize_weight_sharded) -- all elements / max-over-ranks wall time, collective included.  Top-level keys next
+to it: `value_kernel_only` (the same elements / the kernel phase alone: what `value` was before round 4), `kernel_us`,
+`collective_us`, `xgmi_gb_s` (bytes each rank receives / collective time), and from `north_star_path`, which times the
+two exchange steps north_star names at any N (N = 1: the collectives are no-ops and the figures are the kernels' own):
+`value_codes_wire` (same flow with 1-byte storage codes on the wire), `value_resnet18_strong` (ResNet-18's 21 weight
+tensors, one bucketed all-gather; strong scaling), `value_c5` (BASELINE config 5 including its all-reduce).
   weights_allgather  one [N * 2^18, 3, 7, 7] weight tensor held by every rank; rank r finds the ranges of and quantizes
                      channels channel_partition(C, N)[r] (fused min/max+quantize), then the shards and their per-channel
                      ranges are re-assembled with RCCL all-gathers -- fp32 on the wire, and 1-byte storage codes
@@ -23,6 +28,8 @@ time.  Next to it, in the same JSON line, `north_star_path` times the two exchan
   c5                 BASELINE config 5: per-rank slab [512, 4096, 512], allminmax fold -> all-reduce of the 2-float
                      range -> E4M3 quantize with the global range
   ranks_seen         sum over ranks of 1 through an RCCL all-reduce: proves the collective spanned N processes
+`python bench.py --dry-run-ranks 8` (no GPU needed) runs the same call sequence on 8 gloo ranks with CPU tensors, a
+compute stub and scaled-down tensors, and prints every collective with its byte count next to the full-size counts.
 
 The JSON line also carries:
   roofline      the dominant kernel's algorithmic bytes (8 B/element) / its HIP-event launch time
@@ -71,7 +78,7 @@ def ev_time(fn, iters, warm=2):
     return ts[len(ts) // 2], sum(ts) / len(ts)
 
 
-def measure_traffic(timeout_s=240):
+def measure_traffic(timeout_s=60):
     """HBM bytes per launch of the headline kernel from the PMC counters, measured NOW: two rocprofv3 passes (FETCH_SIZE
     and WRITE_SIZE cannot share a pass: 3 + 2 of the 4 TCC slots) over a 3-step, headline-only run of this same script,
     corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE counts 64 B per 128-B request
@@ -108,7 +115,11 @@ def measure_traffic(timeout_s=240):
         finally:
             shutil.rmtree(out, ignore_errors=True)
     fetch, write = vals["FETCH_SIZE"][0] * 1024 * 2, vals["WRITE_SIZE"][0] * 1024
-    return fetch + write, dict(fetch_bytes=round(fetch), write_bytes=round(write), launches_sampled=vals["FETCH_SIZE"][1])
+    return fetch + write, dict(fetch_bytes=round(fetch), write_bytes=round(write), launches_sampled=vals["FETCH_SIZE"][1],
+                               raw_counters=dict(FETCH_SIZE_KB_avg=round(vals["FETCH_SIZE"][0], 1),
+                                                 WRITE_SIZE_KB_avg=round(vals["WRITE_SIZE"][0], 1),
+                                                 correction="FETCH_SIZE x 1024 x 2 (gfx950: 64 B counted per 128-B request), "
+                                                            "WRITE_SIZE x 1024"))
 
 
 def cpu_baseline(x_cpu, maxval_cpu):
@@ -684,6 +695,133 @@ def north_star_path(args, ops, dev, rank, world, backend):
     return res
 
 
+class _DryOps:
+    """Compute stub of `--dry-run-ranks`: the shapes, dtypes and buffers of fp8q.ops with torch CPU ops and NO FP8
+    arithmetic (quantize = copy).  It exists so that the collective call sequence of fp8q.dist can run without a GPU."""
+
+    @staticmethod
+    def quantize(x, maxval, mbits, n_bits=8, sign_bits=1, out=None):
+        if out is None:
+            return x.clone()
+        out.copy_(x.reshape(out.shape))
+        return out
+
+    @staticmethod
+    def new_packed(C, device):
+        return torch.empty((C, 4), dtype=torch.float32, device=device)
+
+    @staticmethod
+    def minmax(x, per_channel, cur_min=None, cur_max=None, mode=0, momentum=0.9, want_maxval=False, packed=None):
+        f = x.reshape(x.shape[0], -1) if per_channel else x.reshape(1, -1)
+        mn, mx = f.min(1)[0], f.max(1)[0]
+        if cur_min is not None and mode == 1:
+            mn, mx = torch.min(cur_min, mn), torch.max(cur_max, mx)
+        if packed is not None:
+            packed.copy_(torch.stack([-mn, mx, torch.zeros_like(mn), torch.zeros_like(mn)], 1))
+        mv = torch.max(mn.abs(), mx).abs()
+        return (mn, mx, mv) if want_maxval else (mn, mx)
+
+    @staticmethod
+    def ranges_unpack(packed, cur_min=None, cur_max=None, maxval=None):
+        p = packed.reshape(-1, 4)
+        for dst, v in ((cur_min, -p[:, 0]), (cur_max, p[:, 1]), (maxval, torch.max(p[:, 0].abs(), p[:, 1]).abs())):
+            if dst is not None:
+                dst.copy_(v)
+        return cur_min, cur_max, maxval
+
+    @staticmethod
+    def minmax_quantize(x, mbits, n_bits=8, sign_bits=1, out=None):
+        mn, mx, mv = _DryOps.minmax(x, True, want_maxval=True)
+        return _DryOps.quantize(x, mv, mbits, out=out), mn, mx, mv
+
+    @staticmethod
+    def encode(x, maxval, mbits, n_bits=8, sign_bits=1, out=None):
+        return torch.zeros(x.shape, dtype=torch.uint8)
+
+    @staticmethod
+    def decode(codes, maxval, mbits, n_bits=8, sign_bits=1, out=None):
+        return torch.zeros(codes.shape, dtype=torch.float32)
+
+
+def dry_run(args, world, rank):
+    """`--dry-run-ranks R`: the N-rank call sequence of this script without a GPU.  R gloo ranks, CPU tensors, _DryOps:
+    the headline flow (quantize_weight_sharded), the 1-byte-codes variant, ResNet-18's 21 tensors through ONE bucketed
+    all-gather (real shapes) and config 5's fold -> all-reduce -> quantize, tensors scaled down to `scale` channels /
+    slab rows per rank.  Every collective is logged with its operand bytes; rank 0 prints the sequence next to the
+    byte counts of the full-size run, so the first real multi-GPU run cannot fail on plumbing or be surprised by sizes."""
+    R = args.dry_run_ranks
+    if "WORLD_SIZE" not in os.environ:
+        import subprocess
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+               f"--nproc-per-node={R}", os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+    if world != R:
+        sys.exit(f"bench.py: --dry-run-ranks {R} but the launcher started WORLD_SIZE={world} ranks")
+    dist.init_process_group("gloo")
+    from fp8q import dist as fd
+    log = []
+    real = {n: getattr(dist, n) for n in ("all_gather_into_tensor", "all_reduce", "all_gather", "barrier")}
+
+    def spy(name):
+        def f(*a, **k):
+            ts = [t for t in a if isinstance(t, torch.Tensor)] + [t for arg in a if isinstance(arg, (list, tuple)) for t in arg
+                                                                   if isinstance(t, torch.Tensor)]
+            send = ts[-1] if name == "all_gather_into_tensor" else (ts[0] if ts else None)
+            log.append(dict(op=name, dtype=str(send.dtype).replace("torch.", "") if send is not None else None,
+                            send_bytes=int(send.numel() * send.element_size()) if send is not None else 0,
+                            reduce=str(k.get("op", "")).split(".")[-1] or None))
+            return real[name](*a, **k)
+        return f
+    for n in real:
+        setattr(dist, n, spy(n))
+    try:
+        scale = 1 << 10
+        ops = _DryOps()
+        seq = {}
+
+        def section(name, fn):
+            start = len(log)
+            fn()
+            seq[name] = log[start:]
+        g = torch.Generator().manual_seed(1234)
+        w = torch.randn(world * scale, 3, 7, 7, generator=g) * 0.1
+        mv = ops.minmax(w, True, want_maxval=True)[2]
+        section("headline: quantize_weight_sharded(fixed ranges)", lambda: fd.quantize_weight_sharded(w, MBITS, NBITS, SIGN, maxval=mv, ops=ops))
+        section("weights_allgather.fp32: quantize_weight_sharded(current_minmax)", lambda: fd.quantize_weight_sharded(w, MBITS, NBITS, SIGN, ops=ops))
+        section("weights_allgather.codes_u8: quantize_weight_sharded_codes", lambda: fd.quantize_weight_sharded_codes(w, MBITS, NBITS, SIGN, ops=ops))
+        shapes = [(64, 3, 7, 7)] + [(64, 64, 3, 3)] * 4 + [(128, 64, 3, 3), (128, 128, 3, 3), (128, 64, 1, 1)] + \
+            [(128, 128, 3, 3)] * 2 + [(256, 128, 3, 3), (256, 256, 3, 3), (256, 128, 1, 1)] + [(256, 256, 3, 3)] * 2 + \
+            [(512, 256, 3, 3), (512, 512, 3, 3), (512, 256, 1, 1)] + [(512, 512, 3, 3)] * 2 + [(1000, 512)]
+        ws = [torch.randn(*sh, generator=g) * 0.05 for sh in shapes]
+        section("resnet18_weights_one_allgather: quantize_weights_sharded_bucketed (REAL shapes)",
+                lambda: fd.quantize_weights_sharded_bucketed(ws, MBITS, NBITS, SIGN, ops=ops))
+        xs = torch.randn(8, 64, 64, generator=torch.Generator().manual_seed(1234 + rank))
+        section("c5: calibrate_quantize_sharded", lambda: fd.calibrate_quantize_sharded(xs, 3, 8, 1, ops=ops))
+        one = torch.ones(1)
+        dist.all_reduce(one)
+    finally:
+        for n, f in real.items():
+            setattr(dist, n, f)
+    if rank == 0:
+        ne, nc = N_CH * ROW, N_CH
+        full = {
+            "headline (value at --gpus N)": {"all_gather_into_tensor values": {"send_bytes_per_rank": ne * 4, "received_per_rank": (R - 1) * ne * 4},
+                                             "all_gather_into_tensor ranges": {"send_bytes_per_rank": nc * 4, "received_per_rank": (R - 1) * nc * 4}},
+            "weights_allgather [N*2^18,3,7,7] codes_u8": {"all_gather_into_tensor codes": {"send_bytes_per_rank": (1 << 18) * ROW},
+                                                          "all_gather_into_tensor ranges": {"send_bytes_per_rank": (1 << 18) * 4}},
+            "resnet18_weights_one_allgather": {"all_gather_into_tensor bucket": {
+                "send_bytes_per_rank": seq["resnet18_weights_one_allgather: quantize_weights_sharded_bucketed (REAL shapes)"][0]["send_bytes"],
+                "note": "real shapes: this IS the full-size count (values + ranges of every tensor's shard, padded to 16 B)"}},
+            "c5 [512,4096,512] per rank": {"all_reduce MAX": {"send_bytes_per_rank": 16, "note": "{-min, max, nan flags}: 4 floats"}},
+        }
+        print(json.dumps({"dry_run": True, "ranks": R, "ranks_seen": int(one.item()), "backend": "gloo (CPU tensors, compute stub)",
+                          "scaled_down_to": {"channels_per_rank": scale, "c5_slab": [8, 64, 64]},
+                          "call_sequence_as_executed": seq, "full_size_bytes": full}), flush=True)
+    dist.destroy_process_group()
+    if int(one.item()) != R:
+        sys.exit(f"bench.py: dry run spanned {int(one.item())} ranks, expected {R}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -701,6 +839,12 @@ def main():
                          "and print its entry")
     ap.add_argument("--no-north-star-path", action="store_true",
                     help="skip the sharded-weights / config-5 section (profiling runs of the headline kernel)")
+    ap.add_argument("--channels-per-gpu", type=int, default=N_CH,
+                    help="rows of the headline tensor per GPU (default 2^21 = the judged workload; smaller only for smoke "
+                         "tests of the multi-process path over gloo, disclosed in config.workload)")
+    ap.add_argument("--dry-run-ranks", type=int, default=0,
+                    help="no GPU: run the N-rank call sequence (headline flow + north_star_path) on that many gloo ranks "
+                         "with CPU tensors and a compute stub, print every collective and its byte count")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for --gpus N > 1 (nccl = RCCL; gloo only for smoke-testing the "
                          "multi-process path on a box with fewer GPUs than ranks)")
@@ -709,16 +853,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.dry_run_ranks:
+        return dry_run(args, world, rank)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # bare `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU) through the same launcher
         # the driver uses; its rank 0 prints the JSON line, this process only relays the exit code
-        import socket
         import subprocess
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            port = sk.getsockname()[1]
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        # --standalone: the launcher picks its own free rendezvous port (no bind-then-close race between benches)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+               f"--nproc-per-node={args.gpus}", os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd))
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
@@ -743,15 +886,33 @@ def main():
         print(json.dumps(model_configs(ops, dev, only=args.only_model_config)), flush=True)
         return
 
-    # synthetic weights: this rank's shard of output channels (seed differs per rank)
-    g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    x = torch.randn(N_CH, 3, 7, 7, device=dev, generator=g) * 0.1
-    y = torch.empty_like(x)
-    _, _, maxval = ops.minmax(x, True, want_maxval=True)   # current_minmax + set_quant_range, once
-    torch.cuda.synchronize()
+    n_ch = int(args.channels_per_gpu)
+    from fp8q import dist as fd
+    if world == 1:
+        # synthetic weights: this GPU's output channels
+        g = torch.Generator(device=dev).manual_seed(1234 + rank)
+        x = torch.randn(n_ch, 3, 7, 7, device=dev, generator=g) * 0.1
+        y = torch.empty_like(x)
+        _, _, maxval = ops.minmax(x, True, want_maxval=True)   # current_minmax + set_quant_range, once
+        shard = x
 
-    def step():
-        ops.quantize(x, maxval, MBITS, NBITS, SIGN, out=y)
+        def step(t=None):
+            ops.quantize(x, maxval, MBITS, NBITS, SIGN, out=y)
+    else:
+        # north_star's weight flow: the SAME full tensor on every rank (same seed), rank r owns n_ch of its channels
+        g = torch.Generator(device=dev).manual_seed(1234)
+        x = torch.empty(world * n_ch, 3, 7, 7, device=dev)
+        for i in range(0, world * n_ch, 1 << 18):
+            x[i:i + (1 << 18)].normal_(generator=g)
+        x *= 0.1
+        _, _, maxval = ops.minmax(x, True, want_maxval=True)
+        lo, hi = fd.channel_partition(world * n_ch, world)[rank]
+        shard, y = x[lo:hi], torch.empty(hi - lo, 3, 7, 7, device=dev)
+        full = [None]
+
+        def step(t=None):     # quantize this rank's channels (fixed ranges, as at N = 1) + all-gather of the shards
+            full[0] = fd.quantize_weight_sharded(x, MBITS, NBITS, SIGN, maxval=maxval, timing=t)
+    torch.cuda.synchronize()
 
     # Setup, before the W warm-up steps of the contract: the GPU's clocks need tens of milliseconds of
     # sustained work to settle (the first ~40 launches after an idle period run 8-10 % slower), so the
@@ -759,7 +920,7 @@ def main():
     t_pre = time.perf_counter()
     while time.perf_counter() - t_pre < PREWARM_S:
         for _ in range(10):
-            step()
+            ops.quantize(shard, maxval[:shard.shape[0]] if world == 1 else maxval[lo:hi], MBITS, NBITS, SIGN, out=y)
         torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
@@ -768,30 +929,39 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    evs = []
+    evs, timing = [], {}
     for _ in range(args.steps):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        step()
-        b.record()
-        evs.append((a, b))
+        if world == 1:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            step()
+            b.record()
+            evs.append((a, b))
+        else:
+            step(timing)        # fp8q.dist records an event before the kernel, after it and after the collective
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    collective_s = 0.0
     if world > 1:
         t = torch.tensor([elapsed], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    step_s = sorted(a.elapsed_time(b) * 1e-3 for a, b in evs)
+        e = timing["events"]
+        step_s = sorted(e[3 * i].elapsed_time(e[3 * i + 1]) * 1e-3 for i in range(args.steps))
+        collective_s = sum(e[3 * i + 1].elapsed_time(e[3 * i + 2]) * 1e-3 for i in range(args.steps)) / max(args.steps, 1)
+    else:
+        step_s = sorted(a.elapsed_time(b) * 1e-3 for a, b in evs)
     kern_s = sum(step_s) / max(len(step_s), 1)
 
-    n_elem = x.numel()
+    n_elem = shard.numel()
     total_elem = n_elem * world
     value = total_elem * args.steps / elapsed / 1e9
     achieved = n_elem * BYTES_PER_ELEM / kern_s / 1e9
     wall_gbs = n_elem * BYTES_PER_ELEM / (elapsed / args.steps) / 1e9
+    rx_bytes = (world - 1) * (n_elem + shard.shape[0]) * 4       # what the all-gathers (values + ranges) bring to a rank
 
     line = None
     if rank == 0:
@@ -818,11 +988,15 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"conv1-shaped weights [{N_CH},3,7,7] fp32 per GPU, per-channel E5M2 "
+            "value_kernel_only": round(total_elem / kern_s / 1e9, 2),
+            "config": {"workload": f"conv1-shaped weights [{n_ch},3,7,7] fp32 per GPU, per-channel E5M2 "
                                    "quantize+dequantize, fixed ranges from current_minmax (BASELINE config 2, "
-                                   "synthetic NxCxKxK scale-up)",
-                       "elements_per_gpu": n_elem, "parallelism": f"channel-sharded x{world}, no data-path collective "
-                       "in `value`; the all-gather / all-reduce steps are timed in north_star_path",
+                                   "synthetic NxCxKxK scale-up)" + ("" if n_ch == N_CH else " -- REDUCED by --channels-per-gpu: smoke test, not the judged workload"),
+                       "elements_per_gpu": n_elem,
+                       "parallelism": "1 GPU" if world == 1 else (
+                           f"one [{world * n_ch},3,7,7] tensor on every rank, channel-sharded x{world}: each rank quantizes its "
+                           f"{n_ch} channels, one all-gather re-assembles values + ranges on every rank; `value` INCLUDES the "
+                           "collective, `value_kernel_only` does not"),
                        "prewarm_ms": int(PREWARM_S * 1e3)},
             "roofline": {"bound": "hbm", "kernel": "k_rows_flat<0,NT>", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
@@ -833,6 +1007,10 @@ def main():
                          "median_launch_us": round(step_s[len(step_s) // 2] * 1e6, 1),
                          "min_launch_us": round(step_s[0] * 1e6, 1), "max_launch_us": round(step_s[-1] * 1e6, 1)},
         }
+        if world > 1:
+            line.update(kernel_us=round(kern_s * 1e6, 1), collective_us=round(collective_s * 1e6, 1),
+                        xgmi_bytes_received_per_rank=int(rx_bytes),
+                        xgmi_gb_s=round(rx_bytes / max(collective_s, 1e-9) / 1e9, 2) if args.backend == "nccl" else None)
         if world == 1 and not args.no_cpu_baseline:
             # bounded sample: generate only what the CPU leg needs
             sample_ch = 1 << 18
@@ -847,12 +1025,18 @@ def main():
                 np.array_equal(got.view(np.int32), ref.view(np.int32)))
             # same object, next to the port: the reference's own op chain on the host cores (reported, not a target)
             line["cpu_baseline"]["reference_equivalent"] = torch_eager_cpu(xc, mvc, min(n_ch, 1 << 16))
-    del x, y
+    del x, y, shard
+    if world > 1:
+        del full
     torch.cuda.empty_cache()
     if not args.no_north_star_path:
         nsp = north_star_path(args, ops, dev, rank, world, args.backend)     # every rank takes part
         if rank == 0:
             line["north_star_path"] = nsp
+            # the other end-to-end rates of the path, as top-level keys (collectives included at N > 1)
+            line["value_codes_wire"] = nsp["weights_allgather"]["codes_u8"]["gelem_s"]
+            line["value_resnet18_strong"] = nsp["resnet18_weights_one_allgather"]["gelem_s"]
+            line["value_c5"] = nsp["c5"]["gelem_s"]
     # every rank must have been seen by a collective: an all-reduce of ones before anything is reported
     seen = world
     if world > 1:

@@ -36,6 +36,30 @@ def test_bare_multi_gpu_invocation_starts_its_ranks_cpu():
     assert "launch with: python -m torch.distributed.run" not in r.stdout + r.stderr
 
 
+def test_dry_run_ranks_prints_the_call_sequence_cpu():
+    """`python bench.py --dry-run-ranks 4`: no GPU, 4 gloo ranks, the N-rank call sequence of the bench (headline flow,
+    codes variant, ResNet-18 bucketed all-gather at its real shapes, config 5) with every collective's byte count."""
+    r = _run(["--dry-run-ranks", "4"], 900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"dry_run"' in ln]
+    assert len(lines) == 1, r.stdout[-3000:]
+    d = json.loads(lines[0])
+    assert d["ranks"] == 4 and d["ranks_seen"] == 4
+    seq = d["call_sequence_as_executed"]
+    head = seq["headline: quantize_weight_sharded(fixed ranges)"]
+    assert [c["op"] for c in head] == ["all_gather_into_tensor", "all_gather_into_tensor"]
+    assert head[0]["send_bytes"] == 1024 * 147 * 4 and head[1]["send_bytes"] == 1024 * 4
+    codes = seq["weights_allgather.codes_u8: quantize_weight_sharded_codes"]
+    assert codes[0]["dtype"] == "uint8" and codes[0]["send_bytes"] == 1024 * 147
+    r18 = seq["resnet18_weights_one_allgather: quantize_weights_sharded_bucketed (REAL shapes)"]
+    assert len(r18) == 1 and abs(r18[0]["send_bytes"] - (11678912 + 4800) * 4 / 4) < 0.01 * 11678912     # 1/4 of the model per rank
+    c5 = seq["c5: calibrate_quantize_sharded"]
+    assert c5 == [dict(op="all_reduce", dtype="float32", send_bytes=16, reduce="MAX")]
+    full = d["full_size_bytes"]["headline (value at --gpus N)"]
+    assert full["all_gather_into_tensor values"]["send_bytes_per_rank"] == (1 << 21) * 147 * 4
+    assert full["all_gather_into_tensor values"]["received_per_rank"] == 3 * (1 << 21) * 147 * 4
+
+
 def test_world_size_mismatch_is_an_error():
     env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, BENCH, "--gpus", "4"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
@@ -47,10 +71,21 @@ def test_bare_two_rank_gloo_bench_on_one_gpu():
     """The multi-process path end to end on the one-GPU box: bare `python bench.py --gpus 2 --backend gloo` re-executes
     itself through torch.distributed.run, both ranks share cuda:0, every section of the line is produced and the
     collectives saw 2 ranks.  (gloo carries device tensors through the host: its times say nothing about xGMI.)"""
-    r = _run(["--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "1"], 1500)
+    r = _run(["--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "1", "--channels-per-gpu", "65536"], 1500)
     assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
     line = _line(r.stdout)
     assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["scaling"] == "weak"
+    # `value` is north_star's weight flow END TO END (shard -> quantize -> all-gather): it contains the collective
+    for k in ("value_kernel_only", "kernel_us", "collective_us", "xgmi_bytes_received_per_rank", "xgmi_gb_s",
+              "value_codes_wire", "value_resnet18_strong", "value_c5"):
+        assert k in line, k
+    assert line["collective_us"] > 0 and line["kernel_us"] > 0
+    assert line["ms_per_step"] * 1e3 >= line["kernel_us"] + 0.9 * line["collective_us"]      # the step time holds both phases
+    assert line["value"] < line["value_kernel_only"]
+    n_total = 2 * 65536 * 147
+    assert abs(line["value"] - n_total / (line["ms_per_step"] * 1e-3) / 1e9) <= 0.02 * line["value"]
+    assert line["xgmi_bytes_received_per_rank"] == (65536 * 147 + 65536) * 4 and line["xgmi_gb_s"] is None   # gloo: no xGMI figure
+    assert "REDUCED" in line["config"]["workload"] and "INCLUDES the collective" in line["config"]["parallelism"]
     nsp = line["north_star_path"]
     assert nsp["ranks_seen"] == 2
     assert nsp["weights_allgather"]["fp32"]["collective_us"] > 0
