@@ -7,6 +7,7 @@
 
 #include <atomic>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -81,6 +82,14 @@ inline void fold_debug_env(FoldArgs &fa)
         const char *e = getenv("FP8Q_TEST_FAULT");
         return e && !strcmp(e, "drop_publish") ? 1 : 0;
     }();
+    static const bool warned = [] {   // test hooks in a production library: never honoured silently
+        if (fault || limit != (1 << 23))
+            fprintf(stderr, "fp8q: WARNING: test hooks active (FP8Q_TEST_FAULT=%s, FP8Q_K3_SPIN_LIMIT=%d): split-row min/max "
+                            "ranges may time out to NaN (reported by fp8q_minmax_workspace_check); unset them outside the test suite\n",
+                    fault ? "drop_publish" : "off", limit);
+        return true;
+    }();
+    (void)warned;
     fa.spin_limit = limit;
     fa.fault = fault;
 }

@@ -106,7 +106,7 @@ k_mse_grid(const float *__restrict__ x, const float *__restrict__ grid, double *
 // One wave = one block owns tiles of 4096 consecutive elements of one row (64 per lane, in registers: with the 4-7-slot
 // loops the per-candidate reduction and constant hand-over were a fifth of the work at 32 per lane) and walks the
 // candidates of its group one after the other; a candidate's constants are wave-uniform (broadcast LDS reads), its
-// squared error is summed over the lane's 32 elements in two fp32 accumulators, reduced across the wave with DPP adds
+// squared error is summed over the lane's 64 elements in two fp32 accumulators, reduced across the wave with DPP adds
 // and added to the candidate's double accumulator in LDS.  No per-candidate table and no logarithm: with
 // bias = bi + bf, t = xc * 2^bf has the element's binade p - bi in its exponent field, so rounding xc to the format's
 // grid is rounding t to M fraction bits -- the float magic-number trick (t + C) - C with C = 1.5 * 2^(e' + 23 - M),
@@ -121,7 +121,7 @@ constexpr int kMseRowTile = 4096;     // elements per wave and tile: 64 per lane
 constexpr int kMseRowEpl = 64;
 constexpr int kMseRowGroup = 128;     // candidates per block (LDS: 48 B each; two double accumulators per lane)
 constexpr int kMseRowMinInner = 2048; // shorter rows: k_mse_grid (lane = candidate)
-constexpr bool kIntRound = true;      // integer round-half-even fast loops (mse_cand_int); false: the float magic-number loops only
+constexpr bool kIntRound = true;      // bit-level round-half-UP-on-the-magnitude fast loops (mse_cand_int: differs from half-to-even only on exact ties, same squared error); false: the float magic-number loops only
 
 typedef float vf2 __attribute__((ext_vector_type(2)));
 
@@ -196,7 +196,7 @@ __device__ __forceinline__ float wave_max_f(float v)
     return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
 }
 
-// Squared error of one candidate over the lane's 32 elements when NO nonzero element of the tile lies below the
+// Squared error of one candidate over the lane's 64 elements (kMseRowEpl) when NO nonzero element of the tile lies below the
 // candidate's first binade (the caller checks it with the tile's smallest nonzero magnitude): rounding t = xc * 2^bf to
 // M fraction bits is then rounding on the BITS of t -- r = (bits + half) & ~mask (v_add_u32, v_and_b32) -- with no
 // exponent extraction, no clamp of it to binade 1 and no float add / sub pair: 5 issue slots per element instead of 7, 4

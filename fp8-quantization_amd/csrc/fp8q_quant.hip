@@ -2068,15 +2068,18 @@ int fp8q_multi_quantize_f32(const fp8q_tensor_desc *descs, int n, fp8q_stream_t 
     }
 }
 
-int fp8q_multi_minmax_quantize_f32(const fp8q_tensor_desc *descs, int n, fp8q_stream_t stream)
+int fp8q_multi_minmax_quantize_f32(const fp8q_tensor_desc *descs, float *const *maxval_out, int n, fp8q_stream_t stream)
 {
-    if (n < 0 || (n > 0 && !descs)) return FP8Q_EINVAL;
+    if (n < 0 || (n > 0 && (!descs || !maxval_out))) return FP8Q_EINVAL;
     for (int i = 0; i < n; ++i) {   // per-channel ranges only; nothing is enqueued if a descriptor is bad
         const fp8q_tensor_desc &t = descs[i];
         if (t.C < 0 || t.inner < 0 || t.n_maxval != t.C || t.C >= (1ll << 31) || t.inner >= (1ll << 31)) return FP8Q_EINVAL;
         QFmt f;
         if (int rc = make_fmt(t.mbits, t.n_bits, t.sign_bits, &f)) return rc;
-        if (t.C > 0 && t.inner > 0 && (!t.x || !t.y || !t.maxval || ((uintptr_t)t.x & 3))) return FP8Q_EINVAL;
+        if (t.C > 0 && t.inner > 0 && (!t.x || !t.y || !maxval_out[i] || ((uintptr_t)t.x & 3))) return FP8Q_EINVAL;
+        // the quantize launch reads the ranges where the range launch wrote them: descs[i].maxval names that buffer too
+        // (or is NULL); an input range buffer elsewhere would be silently ignored -- refuse it
+        if (t.maxval && t.maxval != maxval_out[i]) return FP8Q_EINVAL;
     }
     hipStream_t st = (hipStream_t)stream;
     RowsArgs ra;
@@ -2096,14 +2099,16 @@ int fp8q_multi_minmax_quantize_f32(const fp8q_tensor_desc *descs, int n, fp8q_st
             if (int rc = flush()) return rc;
         RowsDesc &d = ra.d[ra.n++];
         d.x = t.x;
-        d.maxval = const_cast<float *>(t.maxval);   // OUTPUT of this entry point (see include/fp8q.h)
+        d.maxval = maxval_out[i];
         d.row_min = d.row_max = nullptr;
         d.inner = (int)t.inner;
         d.row0 = ra.total_rows;
         ra.total_rows += (uint32_t)t.C;
     }
     if (int rc = flush()) return rc;
-    return fp8q_multi_quantize_f32(descs, n, stream);   // same stream: reads the ranges just written
+    std::vector<fp8q_tensor_desc> q(descs, descs + n);
+    for (int i = 0; i < n; ++i) q[i].maxval = maxval_out[i];
+    return fp8q_multi_quantize_f32(q.data(), n, stream);   // same stream: reads the ranges just written
 }
 
 int fp8q_multi_plan_create(const fp8q_tensor_desc *descs, int n, fp8q_multi_plan **plan_out)

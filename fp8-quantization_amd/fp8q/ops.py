@@ -9,6 +9,7 @@ from ._lib import Fp8qError, check, lib
 FOLD_CURRENT, FOLD_ALL, FOLD_RUNNING = 0, 1, 2
 
 _ws_cache = {}
+_ws_retired = []     # outgrown min/max workspaces, not yet inspected by check_workspaces()
 _mm_ws_bytes = {}
 
 
@@ -83,6 +84,10 @@ def _workspace(dev, nbytes, zeroed=False):
            zeroed)
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
+        if ws is not None and zeroed:
+            # a min/max workspace outgrown: its header may hold a time-out count that nobody has looked at yet --
+            # keep it until the next check_workspaces() instead of dropping the report with the buffer
+            _ws_retired.append((key, ws))
         alloc = torch.zeros if zeroed else torch.empty
         ws = alloc(max(int(nbytes), 1 << 16), dtype=torch.uint8, device=dev)
         _ws_cache[key] = ws
@@ -183,8 +188,10 @@ def multi_minmax_quantize(items):
     for (x, mv), it in zip(keep, items):
         if mv.data_ptr() != it[1].data_ptr():
             raise Fp8qError("multi_minmax_quantize: maxval_out must be contiguous (a copy would receive the ranges)")
+    import ctypes
+    mv_out = (ctypes.c_void_p * len(items))(*[mv.data_ptr() for _, mv in keep])      # where the ranges are WRITTEN
     with _on_device(keep[0][0]):
-        rc = lib().fp8q_multi_minmax_quantize_f32(descs, len(items), _stream(keep[0][0]))
+        rc = lib().fp8q_multi_minmax_quantize_f32(descs, mv_out, len(items), _stream(keep[0][0]))
     check(rc, "fp8q_multi_minmax_quantize_f32")
     return outs
 
@@ -267,15 +274,21 @@ def ranges_unpack(packed, cur_min=None, cur_max=None, maxval=None):
 
 
 def check_workspaces(clear=True):
-    """SYNCHRONISES.  Inspect every min/max workspace this process has used (fp8q_minmax_workspace_check): raises
-    Fp8qError if a reducer block timed out (that call's range is NaN) or a workspace is dirty between calls.
-    Called by QuantizedModel.fix_ranges(), i.e. once after calibration."""
-    for (dev_index, stream, zeroed), ws in list(_ws_cache.items()):
-        if not zeroed:
-            continue
+    """SYNCHRONISES.  Inspect every min/max workspace this process has used since the last check -- the live ones and
+    those a larger request has replaced in the meantime (fp8q_minmax_workspace_check): raises Fp8qError if a reducer
+    block timed out (that call's range is NaN) or a workspace is dirty between calls.  Every workspace is inspected
+    (and cleared) before the first failure is raised.  Called by QuantizedModel.fix_ranges(), i.e. once after
+    calibration."""
+    todo = [(k, w) for k, w in list(_ws_cache.items()) if k[2]] + list(_ws_retired)
+    del _ws_retired[:]
+    failures = []
+    for (dev_index, stream, _zeroed), ws in todo:
         with torch.cuda.device(dev_index):
             rc = lib().fp8q_minmax_workspace_check(ws.data_ptr(), ws.numel(), int(bool(clear)), stream)
-        check(rc, "fp8q_minmax_workspace_check")
+        if rc:
+            failures.append(rc)
+    if failures:
+        check(failures[0], f"fp8q_minmax_workspace_check ({len(failures)} of {len(todo)} workspaces failed)")
 
 
 def minmax(x, per_channel, cur_min=None, cur_max=None, mode=FOLD_CURRENT, momentum=0.9,

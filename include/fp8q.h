@@ -276,13 +276,14 @@ int fp8q_multi_quantize_f32(const fp8q_tensor_desc *descs, int n, fp8q_stream_t 
 /*
  * Multi-tensor K2+K5+K1 -- all weight tensors of a model in ESTIMATE state (per-channel current_minmax with
  * set_maxval: QuantizationManager.forward, quantization_manager.py:114-122, once per layer in the reference): one launch
- * finds every row's range and WRITES maxval[c] = |max(|min_c|, max_c)| into each descriptor's `maxval` buffer ([C];
- * n_maxval must equal C -- the pointer is an output here despite its const type), a second one is
- * fp8q_multi_quantize_f32 on the same descriptors.  Two launches for a whole model instead of one per layer; results
- * bit-identical to fp8q_minmax_quantize_f32 per tensor.  This is what a rank of the channel-sharded multi-GPU weight
- * path runs on its shards before the all-gather (fp8q.dist.quantize_weights_sharded_bucketed).
+ * finds every row's range and writes maxval_out[i][c] = |max(|min_c|, max_c)| ([C] floats per tensor, a HOST array of n
+ * device pointers), a second one is fp8q_multi_quantize_f32 reading those ranges.  descs[i].n_maxval must equal C;
+ * descs[i].maxval is an INPUT field and is not written: it must be NULL or name the same buffer as maxval_out[i]
+ * (FP8Q_EINVAL otherwise -- a range buffer elsewhere would be ignored).  Two launches for a whole model instead of one
+ * per layer; results bit-identical to fp8q_minmax_quantize_f32 per tensor.  This is what a rank of the channel-sharded
+ * multi-GPU weight path runs on its shards before the all-gather (fp8q.dist.quantize_weights_sharded_bucketed).
  */
-int fp8q_multi_minmax_quantize_f32(const fp8q_tensor_desc *descs, int n, fp8q_stream_t stream);
+int fp8q_multi_minmax_quantize_f32(const fp8q_tensor_desc *descs, float *const *maxval_out, int n, fp8q_stream_t stream);
 
 /*
  * Prepared multi-tensor launch.  fp8q_multi_quantize_f32 validates, classifies and packs its descriptors on every

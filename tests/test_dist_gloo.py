@@ -49,6 +49,16 @@ class OracleOps:
         return mses
 
     @staticmethod
+    def mse_linspace(mx, steps=111, lo_frac=0.1, hi_frac=1.2):
+        import oracle_ops
+        return oracle_ops.mse_linspace(mx, steps, lo_frac, hi_frac)
+
+    @staticmethod
+    def mse_select(mses, grid, mbits_list, sign_bits=1):
+        import oracle_ops
+        return oracle_ops.mse_select(mses, grid, mbits_list, sign_bits)
+
+    @staticmethod
     def encode(x, maxval, mbits, n_bits=8, sign_bits=1, out=None):
         return torch.from_numpy(oracle.c_encode(x.numpy(), maxval.numpy(), mbits, n_bits, sign_bits))
 

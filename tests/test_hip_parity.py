@@ -147,6 +147,65 @@ def test_quantize_empty_and_errors(ops):
         ops.quantize(dev(np.zeros(4)), dev([1.0]), 3, n_bits=16, sign_bits=1)  # E > 7
 
 
+def test_out_and_device_arguments_are_validated(ops):
+    """A raw pointer goes to the kernel: an `out=` of the wrong dtype / size / layout / device, or a range vector on another
+    device, must be refused before the launch (Fp8qError), never written through."""
+    import fp8q
+    x = torch.randn(8, 3, 7, 7, device="cuda")
+    mv1, mvc = dev([1.5]), dev(np.full(8, 1.5))
+    bad_outs = [torch.empty(8, 3, 7, 7, dtype=torch.float64, device="cuda"),      # dtype
+                torch.empty(8, 3, 7, 6, device="cuda"),                             # too small
+                torch.empty(8, 3, 7, 14, device="cuda")[..., ::2],                  # not contiguous
+                torch.empty(8, 3, 7, 7)]                                            # CPU
+    calls = [lambda o: ops.quantize(x, mv1, 3, out=o), lambda o: ops.quantize(x, mvc, 3, out=o),
+             lambda o: ops.minmax_quantize(x, 2, out=o), lambda o: ops.copy(x, out=o),
+             lambda o: ops.affine_act_quantize(x, mv1, 3, act=1, out=o),
+             lambda o: ops.multi_quantize([(x, mvc, 2, 8, 1, o)]),
+             lambda o: ops.decode(ops.encode(x, mvc, 3), mvc, 3, out=o)]
+    for call in calls:
+        for o in bad_outs:
+            with pytest.raises(fp8q.Fp8qError):
+                call(o)
+    with pytest.raises(fp8q.Fp8qError):
+        ops.encode(x, mvc, 3, out=torch.empty(8, 3, 7, 7, device="cuda"))           # codes must be uint8
+    with pytest.raises(fp8q.Fp8qError):
+        ops.encode(x, mvc, 3, out=torch.empty(8 * 147 - 1, dtype=torch.uint8, device="cuda"))
+    with pytest.raises(fp8q.Fp8qError):
+        ops.quantize(x, torch.tensor([1.5]), 3)                                     # maxval on the CPU
+    with pytest.raises(fp8q.Fp8qError):
+        ops.affine_act_quantize(x, mvc, 3)                                          # per-channel maxval into the per-tensor epilogue
+    with pytest.raises(fp8q.Fp8qError):
+        ops.affine_act_quantize(x, mv1, 3, residual=torch.zeros(8, 3, 7, 6, device="cuda"))
+    with pytest.raises(fp8q.Fp8qError):
+        ops.minmax(x, True, torch.zeros(8), torch.zeros(8))                         # running estimate on the CPU
+    with pytest.raises(fp8q.Fp8qError):
+        ops.mse_grid(x, True, torch.ones(4, 8, device="cuda"), [3.0], 8, 1, torch.zeros(1, 4, 8))   # table on the CPU
+    if torch.cuda.device_count() > 1:
+        with pytest.raises(fp8q.Fp8qError):
+            ops.quantize(x, mv1.to("cuda:1"), 3)
+    # a good `out=` of another SHAPE with the same element count is fine (the kernel sees [C, inner] either way)
+    o = torch.empty(8 * 147, device="cuda")
+    assert torch.equal(ops.quantize(x, mv1, 3, out=o).view_as(x), ops.quantize(x, mv1, 3))
+
+
+def test_retired_workspace_is_still_checked(ops):
+    """check_workspaces() also inspects min/max workspaces that a larger request has replaced since the last check."""
+    import fp8q
+    ops.check_workspaces()
+    small = torch.randn(1 << 16, device="cuda")
+    ops.minmax(small, False)
+    key = [k for k in ops._ws_cache if k[2]][0]
+    old = ops._ws_cache[key]
+    old.view(torch.int32)[0] = 3                    # pretend three reducers timed out on it
+    ops._ws_cache[key] = torch.zeros(16, dtype=torch.uint8, device="cuda")     # force the next call to outgrow the buffer
+    ops._ws_retired.append((key, old))
+    ops._ws_cache[key] = torch.zeros(1 << 16, dtype=torch.uint8, device="cuda")
+    with pytest.raises(fp8q.Fp8qError, match="timed out"):
+        ops.check_workspaces()
+    ops.check_workspaces()                          # reported once, cleared, forgotten
+    assert not ops._ws_retired
+
+
 @pytest.mark.parametrize("shape,pc", [((64, 3, 7, 7), True), ((64, 3, 7, 7), False), ((4, 8, 6, 6), False),
                                       ((1000, 512), True), ((8, 300000), True), ((3, 5), True),
                                       ((64, 64, 56, 56), False), ((2, 2049), True)])
