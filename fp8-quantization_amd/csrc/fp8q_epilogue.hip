@@ -162,6 +162,101 @@ k_affine_act(const float *__restrict__ x, const float *__restrict__ res, float *
     }
 }
 
+// Small (cache-sized) activations: the launch is latency-bound -- what counts is the length of the dependent chain from
+// block start to the first store, not bandwidth.  k_affine_act's chain is {maxval -> channel constants -> table} ->
+// barrier -> {BN vectors -> LDS} -> barrier -> {x} -> arithmetic -> store: three memory round trips behind each other
+// where the plain K1 has two.  Here a lane handles ONE 16-byte group per step and fetches the BN vectors of its own
+// plane(s) straight from global memory (L2 hits: <= 20 KB per model layer) next to x itself, so x, residual and the BN
+// vectors are one round trip, issued BEFORE the table is built (EARLY) so that the table's arithmetic hides it.
+// rocprofv3 kernel durations at batch 64 (round 3's staged kernel -> this one): [64,160,7,7] 5.4 -> 4.4 us, [64,96,14,14]
+// 6.7 -> 5.3, [64,576,7,7] 6.7 -> 5.5, [64,384,14,14] 12.2 -> 9.5, [64,144,28,28] 16.0 -> 13.1 (plain K1 on the same
+// tensors: 3.9 / 5.1 / 5.1 / 7.3 / 10.4); it wins up to the nontemporal threshold ([64,192,28,28] 19.7 -> 14.8 us,
+// [64,64,56,56] 21.2 -> 18.5) and loses beyond it, where the staged kernel's LDS constants cost less than eight extra
+// dword loads per group ([64,96,56,56] 31.3 vs 35.6 us with NT = true, U = 4) -- so it serves every tensor below 64 MiB.
+template <bool EARLY, bool NT, int U>
+__global__ void __launch_bounds__(kBlock)
+k_affine_act_small(const float *__restrict__ x, const float *__restrict__ res, float *__restrict__ y,
+                   const float *__restrict__ mean, const float *__restrict__ invstd, const float *__restrict__ gamma,
+                   const float *__restrict__ beta, const float *__restrict__ maxval, QFmt f, AffineArgs a)
+{
+    __shared__ float2 lut[kLutMax];
+    const int tid = threadIdx.x;
+    const int64_t base0 = (int64_t)blockIdx.y * a.image;
+    const int nvec = (int)(a.image >> 2);
+    const vf4 *xv = reinterpret_cast<const vf4 *>(x + base0);
+    const vf4 *rv = reinterpret_cast<const vf4 *>(res + (a.has_res ? base0 : 0));
+    vf4 *yv = reinterpret_cast<vf4 *>(y + base0);
+    const uint32_t HW = (uint32_t)a.HW;
+    const int step = gridDim.x * (kBlock * U);
+    int base = blockIdx.x * (kBlock * U);
+
+    struct Grp {
+        vf4 v, r;
+        float al0, bp0, al1, bp1;   // {alpha, beta'} of the group's plane and of the next one (HW >= 4: a group spans <= 2)
+        uint32_t off;               // offset of the group's first element inside its plane
+    };
+    auto fetch = [&](int jj, Grp &g) {
+        g.v = ld16<NT>(xv + jj);
+        g.r = a.has_res ? ld16<NT>(rv + jj) : vf4{0.0f, 0.0f, 0.0f, 0.0f};
+        g.off = 0;
+        g.al0 = g.al1 = 1.0f;
+        g.bp0 = g.bp1 = 0.0f;
+        if (a.has_bn) {
+            const uint32_t i0 = (uint32_t)jj * 4u;
+            const uint32_t ch = (uint32_t)(((uint64_t)i0 * a.magic48) >> 48);      // plane == channel
+            g.off = i0 - ch * HW;
+            const uint32_t ch1 = ch + 1u < (uint32_t)a.C ? ch + 1u : ch;
+            const float m0 = mean[ch], s0 = invstd[ch], g0 = gamma[ch], b0 = beta[ch];
+            const float m1 = mean[ch1], s1 = invstd[ch1], g1 = gamma[ch1], b1 = beta[ch1];
+            g.al0 = s0 * g0;
+            g.bp0 = fmaf(-m0, g.al0, b0);
+            g.al1 = s1 * g1;
+            g.bp1 = fmaf(-m1, g.al1, b1);
+        }
+    };
+    Grp g[U];
+    if (EARLY) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (base + u * kBlock + tid < nvec) fetch(base + u * kBlock + tid, g[u]);
+    }
+    const Chan cfull = make_chan(maxval[0], f);
+    for (int i = tid; i <= f.pmax; i += kBlock) lut[i] = lut_entry(cfull, i, f.M);
+    const ChanLite c = lite(cfull);
+    const float pmaxf = (float)f.pmax;
+    __syncthreads();
+    bool first = true;
+    for (; base < nvec; base += step) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = base + u * kBlock + tid;
+            if (j < nvec && !(EARLY && first)) fetch(j, g[u]);
+        }
+        first = false;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = base + u * kBlock + tid;
+            if (j >= nvec) break;
+            float e[4] = {g[u].v.x, g[u].v.y, g[u].v.z, g[u].v.w};
+            const float rr[4] = {g[u].r.x, g[u].r.y, g[u].r.z, g[u].r.w};
+            if (a.has_bn) {
+                // elements at group-local index >= cross belong to the next plane (HW >= 4: at most one crossing)
+                const uint32_t cross = HW - g[u].off;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const bool nxt = (uint32_t)k >= cross;
+                    e[k] = res_act(fmaf(e[k], nxt ? g[u].al1 : g[u].al0, nxt ? g[u].bp1 : g[u].bp0), rr[k], a);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) e[k] = res_act(e[k], rr[k], a);
+            }
+            quant_group<4>(e, c, lut, pmaxf, f.qthr);
+            st16<NT>(yv + j, vf4{e[0], e[1], e[2], e[3]});
+        }
+    }
+}
+
 // Calibration twin of k_affine_act: min / max of act(bn(x) + residual); the block that finishes last folds all blocks'
 // partials into the running estimate (block_minmax_fold: one launch).  Read-only, so the
 // trade-offs differ from the quantizing kernel: a persistent grid of <= 2048 blocks with 4 KiB steps, plain
@@ -276,6 +371,16 @@ static void affine_grid(int64_t N, const AffineArgs &a, bool quant, int64_t *bx,
     }
 }
 
+// FP8Q_EPI_SMALL_KIND: 0 = the staged kernel for small tensors too (round 3), 1 = k_affine_act_small, 2 = with early loads
+static int small_kind()
+{
+    static const int v = [] {
+        const char *e = getenv("FP8Q_EPI_SMALL_KIND");
+        return e ? atoi(e) : 2;
+    }();
+    return v;
+}
+
 int fp8q_affine_act_quantize_f32(const float *x, const float *residual, float *y, int64_t N, int64_t C,
                                  int64_t HW, const float *mean, const float *invstd, const float *gamma,
                                  const float *beta, int act, const float *maxval, float mbits, int n_bits,
@@ -293,7 +398,7 @@ int fp8q_affine_act_quantize_f32(const float *x, const float *residual, float *y
     static const int64_t small_elems = [] {   // FP8Q_EPI_SMALL_M: tensors below this many M elements run 4 KiB pieces per block
         const char *e = getenv("FP8Q_EPI_SMALL_M");
         const long v = e ? atol(e) : -1;
-        return (int64_t)(v >= 0 ? v : 8) << 20;
+        return (int64_t)(v >= 0 ? v : 16) << 20;
     }();
     // cache-sized tensors are latency-bound: four times as many blocks with a quarter of the piece each
     const bool small = N * a.image < small_elems;
@@ -306,7 +411,14 @@ int fp8q_affine_act_quantize_f32(const float *x, const float *residual, float *y
         if (N * a.image * 4 >= kNtBytes)
             hipLaunchKernelGGL((k_affine_act<true, 4>), g, b, shm, (hipStream_t)stream, x + n0 * a.image, rp, y + n0 * a.image,
                                mean, invstd, gamma, beta, maxval, f, a);
-        else if (small)
+        else if (small && (a.HW >= 4 || !has_bn) && small_kind() != 0) {
+            if (small_kind() == 2)
+                hipLaunchKernelGGL((k_affine_act_small<true, false, 1>), g, b, 0, (hipStream_t)stream, x + n0 * a.image, rp, y + n0 * a.image,
+                                   mean, invstd, gamma, beta, maxval, f, a);
+            else
+                hipLaunchKernelGGL((k_affine_act_small<false, false, 1>), g, b, 0, (hipStream_t)stream, x + n0 * a.image, rp, y + n0 * a.image,
+                                   mean, invstd, gamma, beta, maxval, f, a);
+        } else if (small)
             hipLaunchKernelGGL((k_affine_act<false, 1>), g, b, shm, (hipStream_t)stream, x + n0 * a.image, rp, y + n0 * a.image,
                                mean, invstd, gamma, beta, maxval, f, a);
         else
