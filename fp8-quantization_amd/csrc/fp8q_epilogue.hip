@@ -25,6 +25,25 @@ struct AffineArgs {
 constexpr int kAffinePiece = kBlock * 4 * 4;   // elements per block and step (16 KiB)
 constexpr int kAffineMagicMaxHW = kMagicMaxDivisor;   // above: a piece spans <= 2 planes (compare instead of divide)
 
+// {alpha, beta'} of one channel: alpha = invstd * gamma, beta' = fma(-mean, alpha, beta) (ATen's eval-mode batch norm) --
+// or, with has_bn == 2, read from the folded [C, 2] vector that fp8q_bn_fold_f32 wrote (`mean` then points to it): one
+// 8-byte load instead of four 4-byte ones per plane, the same two numbers.
+__device__ __forceinline__ float2 bn_ab(const float *__restrict__ mean, const float *__restrict__ invstd,
+                                        const float *__restrict__ gamma, const float *__restrict__ beta, uint32_t ch, int has_bn)
+{
+    if (has_bn == 2) return reinterpret_cast<const float2 *>(mean)[ch];
+    const float alpha = invstd[ch] * gamma[ch];
+    return make_float2(alpha, fmaf(-mean[ch], alpha, beta[ch]));
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_bn_fold(const float *__restrict__ mean, const float *__restrict__ invstd, const float *__restrict__ gamma,
+          const float *__restrict__ beta, int64_t C, float2 *__restrict__ ab)
+{
+    const int64_t c = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (c < C) ab[c] = bn_ab(mean, invstd, gamma, beta, (uint32_t)c, 1);
+}
+
 // act(t + r) -- the non-affine part of the epilogue
 __device__ __forceinline__ float res_act(float t, float r, const AffineArgs &a)
 {
@@ -75,9 +94,8 @@ k_affine_act(const float *__restrict__ x, const float *__restrict__ res, float *
             const uint32_t ch_lo = e0 / HW;
             phase = e0 - ch_lo * HW;
             const uint32_t ch_hi = ch_lo + 1u < (uint32_t)a.C ? ch_lo + 1u : ch_lo;
-            const float al0 = invstd[ch_lo] * gamma[ch_lo], al1 = invstd[ch_hi] * gamma[ch_hi];
-            p0 = make_float2(al0, fmaf(-mean[ch_lo], al0, beta[ch_lo]));
-            p1 = make_float2(al1, fmaf(-mean[ch_hi], al1, beta[ch_hi]));
+            p0 = bn_ab(mean, invstd, gamma, beta, ch_lo, a.has_bn);
+            p1 = bn_ab(mean, invstd, gamma, beta, ch_hi, a.has_bn);
         }
         if (a.has_bn && !direct) {
             __syncthreads();   // the previous step's constants are no longer read
@@ -86,10 +104,7 @@ k_affine_act(const float *__restrict__ x, const float *__restrict__ res, float *
             phase = e0 - ch_lo * HW;
             for (int k = tid; k < a.cpp; k += kBlock) {
                 const uint32_t ch = ch_lo + (uint32_t)k;
-                if (ch < (uint32_t)a.C) {
-                    const float alpha = invstd[ch] * gamma[ch];
-                    cst[k] = make_float2(alpha, fmaf(-mean[ch], alpha, beta[ch]));
-                }
+                if (ch < (uint32_t)a.C) cst[k] = bn_ab(mean, invstd, gamma, beta, ch, a.has_bn);
             }
             __syncthreads();
         }
@@ -173,6 +188,10 @@ k_affine_act(const float *__restrict__ x, const float *__restrict__ res, float *
 // tensors: 3.9 / 5.1 / 5.1 / 7.3 / 10.4); it wins up to the nontemporal threshold ([64,192,28,28] 19.7 -> 14.8 us,
 // [64,64,56,56] 21.2 -> 18.5) and loses beyond it, where the staged kernel's LDS constants cost less than eight extra
 // dword loads per group ([64,96,56,56] 31.3 vs 35.6 us with NT = true, U = 4) -- so it serves every tensor below 64 MiB.
+// Measured and rejected on top of it: 2 or 4 groups per lane and step (U = 2: +8...12 %, U = 4: +15...35 % time),
+// nontemporal accesses below 64 MiB (+10 %), grids of 1024...16384 blocks (2048...4096 equal, the rest worse), requesting
+// the next step's group before the arithmetic of the current one (no change).  With the folded BN vector (has_bn == 2:
+// two 8-byte loads per group instead of eight 4-byte ones) another 5-8 %: [64,64,56,56] 19.9 -> 18.5 us (K1: 17.9).
 template <bool EARLY, bool NT, int U>
 __global__ void __launch_bounds__(kBlock)
 k_affine_act_small(const float *__restrict__ x, const float *__restrict__ res, float *__restrict__ y,
@@ -206,12 +225,12 @@ k_affine_act_small(const float *__restrict__ x, const float *__restrict__ res, f
             const uint32_t ch = (uint32_t)(((uint64_t)i0 * a.magic48) >> 48);      // plane == channel
             g.off = i0 - ch * HW;
             const uint32_t ch1 = ch + 1u < (uint32_t)a.C ? ch + 1u : ch;
-            const float m0 = mean[ch], s0 = invstd[ch], g0 = gamma[ch], b0 = beta[ch];
-            const float m1 = mean[ch1], s1 = invstd[ch1], g1 = gamma[ch1], b1 = beta[ch1];
-            g.al0 = s0 * g0;
-            g.bp0 = fmaf(-m0, g.al0, b0);
-            g.al1 = s1 * g1;
-            g.bp1 = fmaf(-m1, g.al1, b1);
+            const float2 q0 = bn_ab(mean, invstd, gamma, beta, ch, a.has_bn);
+            const float2 q1 = bn_ab(mean, invstd, gamma, beta, ch1, a.has_bn);
+            g.al0 = q0.x;
+            g.bp0 = q0.y;
+            g.al1 = q1.x;
+            g.bp1 = q1.y;
         }
     };
     Grp g[U];
@@ -292,16 +311,14 @@ k_affine_minmax(const float *__restrict__ x, const float *__restrict__ res, cons
             const uint32_t i0 = (uint32_t)j * 4u;
             uint32_t ch = (uint32_t)(((uint64_t)i0 * a.magic48) >> 48);      // plane == channel
             uint32_t off = i0 - ch * HW;
-            float alpha = invstd[ch] * gamma[ch];
-            float bp = fmaf(-mean[ch], alpha, beta[ch]);
+            float2 p = bn_ab(mean, invstd, gamma, beta, ch, a.has_bn);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                e[q] = res_act(fmaf(e[q], alpha, bp), rr[q], a);
+                e[q] = res_act(fmaf(e[q], p.x, p.y), rr[q], a);
                 if (++off == HW && q < 3) {      // the group crosses into the next plane
                     off = 0;
                     ++ch;                         // still < C: the group ends inside the image
-                    alpha = invstd[ch] * gamma[ch];
-                    bp = fmaf(-mean[ch], alpha, beta[ch]);
+                    p = bn_ab(mean, invstd, gamma, beta, ch, a.has_bn);
                 }
             }
         } else {
@@ -320,7 +337,7 @@ k_affine_minmax(const float *__restrict__ x, const float *__restrict__ res, cons
 
 extern "C" {
 
-static int affine_args(int64_t N, int64_t C, int64_t HW, int act, bool has_bn, bool has_res, AffineArgs *a)
+static int affine_args(int64_t N, int64_t C, int64_t HW, int act, int has_bn, bool has_res, AffineArgs *a)
 {
     if (N < 0 || C <= 0 || HW <= 0 || act < 0 || act > 2) return FP8Q_EINVAL;
     // 16-byte groups must not straddle images; 32-bit element indices within an image; the 48-bit magic
@@ -381,13 +398,44 @@ static int small_kind()
     return v;
 }
 
+int fp8q_bn_fold_f32(const float *mean, const float *invstd, const float *gamma, const float *beta, int64_t C,
+                     float *alpha_beta, fp8q_stream_t stream)
+{
+    if (C < 0 || (C > 0 && (!mean || !invstd || !gamma || !beta || !alpha_beta || ((uintptr_t)alpha_beta & 7)))) return FP8Q_EINVAL;
+    if (C == 0) return FP8Q_OK;
+    hipLaunchKernelGGL(k_bn_fold, dim3((unsigned)cdiv(C, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, mean, invstd, gamma,
+                       beta, C, reinterpret_cast<float2 *>(alpha_beta));
+    return launch_rc();
+}
+
+static int affine_quantize_impl(const float *x, const float *residual, float *y, int64_t N, int64_t C, int64_t HW,
+                                const float *mean, const float *invstd, const float *gamma, const float *beta, int has_bn,
+                                int act, const float *maxval, float mbits, int n_bits, int sign_bits, fp8q_stream_t stream);
+
 int fp8q_affine_act_quantize_f32(const float *x, const float *residual, float *y, int64_t N, int64_t C,
                                  int64_t HW, const float *mean, const float *invstd, const float *gamma,
                                  const float *beta, int act, const float *maxval, float mbits, int n_bits,
                                  int sign_bits, fp8q_stream_t stream)
 {
-    const bool has_bn = mean != nullptr;
+    const int has_bn = mean != nullptr;
     if (has_bn && (!invstd || !gamma || !beta)) return FP8Q_EINVAL;
+    return affine_quantize_impl(x, residual, y, N, C, HW, mean, invstd, gamma, beta, has_bn, act, maxval, mbits, n_bits,
+                                sign_bits, stream);
+}
+
+int fp8q_affine_act_quantize_ab_f32(const float *x, const float *residual, float *y, int64_t N, int64_t C, int64_t HW,
+                                    const float *alpha_beta, int act, const float *maxval, float mbits, int n_bits,
+                                    int sign_bits, fp8q_stream_t stream)
+{
+    if (!alpha_beta || ((uintptr_t)alpha_beta & 7)) return FP8Q_EINVAL;
+    return affine_quantize_impl(x, residual, y, N, C, HW, alpha_beta, nullptr, nullptr, nullptr, 2, act, maxval, mbits,
+                                n_bits, sign_bits, stream);
+}
+
+static int affine_quantize_impl(const float *x, const float *residual, float *y, int64_t N, int64_t C, int64_t HW,
+                                const float *mean, const float *invstd, const float *gamma, const float *beta, int has_bn,
+                                int act, const float *maxval, float mbits, int n_bits, int sign_bits, fp8q_stream_t stream)
+{
     AffineArgs a;
     if (int rc = affine_args(N, C, HW, act, has_bn, residual != nullptr, &a)) return rc;
     QFmt f;
@@ -442,7 +490,7 @@ static int affine_minmax_impl(const float *x, const float *residual, int64_t N, 
                               int act, float *cur_min, float *cur_max, float *maxval_out, float *packed, int fold_mode,
                               double momentum, int first, void *ws, size_t ws_bytes, fp8q_stream_t stream)
 {
-    const bool has_bn = mean != nullptr;
+    const int has_bn = mean != nullptr;
     if (has_bn && (!invstd || !gamma || !beta)) return FP8Q_EINVAL;
     AffineArgs a;
     if (int rc = affine_args(N, C, HW, act, has_bn, residual != nullptr, &a)) return rc;

@@ -577,9 +577,23 @@ def affine_act_supported(x):
     return N > 0 and (C * HW) % 4 == 0 and x.data_ptr() % 16 == 0
 
 
-def affine_act_quantize(x, maxval, mbits, n_bits=8, sign_bits=1, bn=None, residual=None, act=0, out=None):
-    """N2: quantize(act(bn(x) + residual)) in one pass.  bn = (mean, invstd, gamma, beta), each [C];
-    act: 0 none, 1 ReLU, 2 ReLU6; per-tensor maxval [1]."""
+def bn_fold(bn):
+    """[C, 2] fp32 {alpha, beta'} = {invstd * gamma, fma(-mean, alpha, beta)} of an eval-mode batch norm
+    (fp8q_bn_fold_f32): the per-channel constants of the fused epilogue, folded once per parameter set."""
+    mean = bn[0]
+    _require(mean, "bn parameter")
+    C = mean.numel()
+    ptrs, keep = _bn_ptrs(bn, C, mean.device)
+    ab = torch.empty((C, 2), dtype=torch.float32, device=mean.device)
+    with _on_device(mean):
+        rc = lib().fp8q_bn_fold_f32(ptrs[0], ptrs[1], ptrs[2], ptrs[3], C, ab.data_ptr(), _stream(mean))
+    check(rc, "fp8q_bn_fold_f32")
+    return ab
+
+
+def affine_act_quantize(x, maxval, mbits, n_bits=8, sign_bits=1, bn=None, residual=None, act=0, out=None, bn_ab=None):
+    """N2: quantize(act(bn(x) + residual)) in one pass.  bn = (mean, invstd, gamma, beta), each [C] -- or bn_ab = the
+    folded [C, 2] vector of bn_fold(bn) (same result, fewer loads); act: 0 none, 1 ReLU, 2 ReLU6; per-tensor maxval [1]."""
     _require(x, "x")
     _require(maxval, "maxval", like=x)
     x = x.contiguous()
@@ -591,8 +605,19 @@ def affine_act_quantize(x, maxval, mbits, n_bits=8, sign_bits=1, bn=None, residu
             raise Fp8qError("residual must have x's shape")
     if maxval.numel() != 1:
         raise Fp8qError("the fused epilogue quantizes per tensor: maxval must have one element")
-    ptrs, keep = _bn_ptrs(bn, C, x.device)
     y = _out(out, x)
+    if bn_ab is not None:
+        _require(bn_ab, "bn_ab", like=x)
+        if bn_ab.numel() != 2 * C or not bn_ab.is_contiguous():
+            raise Fp8qError("bn_ab must be a contiguous [C, 2] tensor (fp8q.ops.bn_fold)")
+        with _on_device(x):
+            rc = lib().fp8q_affine_act_quantize_ab_f32(
+                x.data_ptr(), residual.data_ptr() if residual is not None else None, y.data_ptr(), N, C, HW,
+                bn_ab.data_ptr(), int(act), maxval.contiguous().data_ptr(), float(mbits), int(n_bits), int(sign_bits),
+                _stream(x))
+        check(rc, "fp8q_affine_act_quantize_ab_f32")
+        return y
+    ptrs, keep = _bn_ptrs(bn, C, x.device)
     with _on_device(x):
         rc = lib().fp8q_affine_act_quantize_f32(
             x.data_ptr(), residual.data_ptr() if residual is not None else None, y.data_ptr(), N, C, HW,

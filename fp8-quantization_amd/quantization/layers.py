@@ -192,14 +192,14 @@ class QuantizationHijacker(QuantizedModule):
             return 0
         return {nn.ReLU: 1, nn.ReLU6: 2}.get(type(a))
 
-    def _finish(self, out, bn=None):
+    def _finish(self, out, bn=None, bn_ab=None):
         """activation (+ the batch norm handed over by BNFusedHijacker) and output quantization; one
         fused kernel when possible, else the reference's op-by-op chain."""
         act = self._act_code()
         aq = self.activation_quantizer
         if (not self.quantize_input and self._qa and act is not None and isinstance(aq, QuantizationManager)
                 and aq.can_fuse(out)):
-            return aq.forward_fused(out, bn=bn, act=act)
+            return aq.forward_fused(out, bn=bn, act=act, bn_ab=bn_ab() if bn_ab is not None else None)
         if bn is not None:
             out = self._batch_norm(out)
         if self.activation_function is not None:
@@ -248,6 +248,7 @@ class QuantizationHijacker(QuantizedModule):
         self._wq_key = None
         self._wq_cache = None
         self._invstd_key = None
+        self._ab_key = None
 
     def quantize_weights(self, weights):
         return self.weight_quantizer(weights)
@@ -286,7 +287,7 @@ class BNFusedHijacker(QuantizationHijacker):
         out = self.run_forward(x, weight, bias)
         if self.training:                     # batch statistics: never fused
             return self._finish(self._batch_norm(out))
-        return self._finish(out, bn=self._bn_vectors())
+        return self._finish(out, bn=self._bn_vectors(), bn_ab=self._bn_folded if out.is_cuda else None)
 
     def _batch_norm(self, out):
         return F.batch_norm(out, self.running_mean, self.running_var, self.gamma, self.beta,
@@ -300,6 +301,17 @@ class BNFusedHijacker(QuantizationHijacker):
             self._invstd = 1 / torch.sqrt(self.running_var + self.epsilon)
             self._invstd_key = key
         return self.running_mean, self._invstd, self.gamma.detach(), self.beta.detach()
+
+    def _bn_folded(self):
+        """[C, 2] {alpha, beta'} of the eval-mode batch norm for the fused epilogue (fp8q.ops.bn_fold), cached until any
+        of the four parameter tensors changes (in-place version counters + addresses; `.data` edits: invalidate_weight_cache())."""
+        bn = self._bn_vectors()
+        key = tuple((t.data_ptr(), t._version) for t in (self.running_mean, self.running_var, self.gamma, self.beta)) + (self.epsilon,)
+        if getattr(self, "_ab_key", None) != key:
+            from fp8q import ops as _fops
+            self._ab = _fops.bn_fold(bn)
+            self._ab_key = key
+        return self._ab
 
     def get_bn_dim(self):
         if isinstance(self, nn.Linear):

@@ -143,7 +143,7 @@ class QuantizationManager(nn.Module):
             return (type(est) in _MINMAX and not q.allow_unsigned and not getattr(est, "percentile", None))
         return True
 
-    def forward_fused(self, x, bn=None, residual=None, act=0):
+    def forward_fused(self, x, bn=None, residual=None, act=0, bn_ab=None):
         """quantize(act(bn(x) + residual)); range update first when estimating (reference order)."""
         q, est = self.quantizer, self.range_estimator
         if self._estimating():
@@ -166,7 +166,7 @@ class QuantizationManager(nn.Module):
         if q.maxval.device != x.device:
             q.maxval = q.maxval.to(x.device)
         return _ops.affine_act_quantize(x, q.maxval, float(q.mantissa_bits), q.n_bits, q.sign_bits, bn=bn,
-                                        residual=residual, act=act)
+                                        residual=residual, act=act, bn_ab=bn_ab if bn is not None else None)
 
     def extra_repr(self):
         return f"state={self.state.name}"

@@ -223,6 +223,18 @@ int fp8q_affine_act_quantize_f32(const float *x, const float *residual, float *y
                                  int64_t HW, const float *mean, const float *invstd, const float *gamma,
                                  const float *beta, int act, const float *maxval, float mbits, int n_bits,
                                  int sign_bits, fp8q_stream_t stream);
+/*
+ * The same epilogue with the batch norm's per-channel constants folded once: fp8q_bn_fold_f32 writes
+ * alpha_beta[c] = {alpha_c, beta'_c} = {invstd_c * gamma_c, fma(-mean_c, alpha_c, beta_c)} ([C, 2] fp32, 8-byte aligned) --
+ * the two numbers the kernels above form per plane -- and fp8q_affine_act_quantize_ab_f32 reads them (one 8-byte load
+ * per plane instead of four 4-byte ones).  Bit-identical results; in eval mode the vector changes only when the BN
+ * parameters do, so a caller folds once and reuses it for every forward.
+ */
+int fp8q_bn_fold_f32(const float *mean, const float *invstd, const float *gamma, const float *beta, int64_t C,
+                     float *alpha_beta, fp8q_stream_t stream);
+int fp8q_affine_act_quantize_ab_f32(const float *x, const float *residual, float *y, int64_t N, int64_t C, int64_t HW,
+                                    const float *alpha_beta, int act, const float *maxval, float mbits, int n_bits,
+                                    int sign_bits, fp8q_stream_t stream);
 size_t fp8q_affine_act_minmax_workspace_bytes(int64_t N, int64_t C, int64_t HW);
 int fp8q_affine_act_minmax_f32(const float *x, const float *residual, int64_t N, int64_t C, int64_t HW,
                                const float *mean, const float *invstd, const float *gamma, const float *beta,

@@ -65,6 +65,14 @@ def test_fused_epilogue_bit_exact(shape, use_bn, use_res, act):
     assert np.array_equal(np.isnan(y), np.isnan(ref))
     ok = ~np.isnan(ref)
     assert np.array_equal(y[ok].view(np.int32), ref[ok].view(np.int32))
+    if use_bn:      # the folded-constants entry point (fp8q_bn_fold_f32 + fp8q_affine_act_quantize_ab_f32): the same bits
+        bnd = tuple(dev(b) for b in bn)
+        ab = ops.bn_fold(bnd)
+        alpha = bn[1] * bn[2]
+        np.testing.assert_array_equal(ab.cpu().numpy()[:, 0], alpha)
+        y2 = ops.affine_act_quantize(xd, dev(mv), 3, 8, 1, bn=bnd, bn_ab=ab, residual=dev(res) if use_res else None,
+                                     act=act).cpu().numpy()
+        assert np.array_equal(np.isnan(y2), np.isnan(y)) and np.array_equal(y2[ok].view(np.int32), y[ok].view(np.int32))
     # range of the same pre-quantization tensor, folded like allminmax
     t2 = t.copy()
     t2.reshape(-1)[:2] = 0            # drop the NaN / inf probes for the range check

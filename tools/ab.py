@@ -54,10 +54,11 @@ def cases_epi():
         x = torch.randn(64, C, hw, hw, device=dev)
         y = torch.empty_like(x)
         bn = tuple(torch.rand(C, device=dev) + 0.5 for _ in range(4))
-        out.append((f"bn+relu6+q [64,{C},{hw},{hw}]", x.numel() * 8, lambda x=x, y=y, bn=bn: ops.affine_act_quantize(x, mv, 3, 8, 1, bn=bn, act=2, out=y)))
+        kw = dict(bn=bn, bn_ab=ops.bn_fold(bn)) if os.environ.get("FOLD") == "1" else dict(bn=bn)     # FOLD=1: folded BN constants
+        out.append((f"bn+relu6+q [64,{C},{hw},{hw}]", x.numel() * 8, lambda x=x, y=y, kw=kw: ops.affine_act_quantize(x, mv, 3, 8, 1, act=2, out=y, **kw)))
         if (C, hw) in ((64, 56), (128, 28), (256, 14), (512, 7), (24, 56), (32, 28), (64, 14), (96, 14), (160, 7)):
             r = torch.randn_like(x)
-            out.append((f"bn+res+relu+q [64,{C},{hw},{hw}]", x.numel() * 12, lambda x=x, y=y, bn=bn, r=r: ops.affine_act_quantize(x, mv, 3, 8, 1, bn=bn, residual=r, act=1, out=y)))
+            out.append((f"bn+res+relu+q [64,{C},{hw},{hw}]", x.numel() * 12, lambda x=x, y=y, kw=kw, r=r: ops.affine_act_quantize(x, mv, 3, 8, 1, residual=r, act=1, out=y, **kw)))
         out.append((f"   plain K1 [64,{C},{hw},{hw}]", x.numel() * 8, lambda x=x, y=y: ops.quantize(x, mv, 3, 8, 1, out=y)))
     return out
 
