@@ -921,6 +921,16 @@ struct MultiArgs {
 // is built by up to 32 lanes; the <= 3 elements of a 16-byte group that belong to the NEXT row are quantized in place
 // with that row's table (a rare divergent branch) instead of a patch phase; the 3 KiB of log2 / exp2 tables are staged
 // once per block, not once per chunk.
+// Round 4 ablations on ResNet-18's 21 tensors (tools/ab.py multi, 93 MB of traffic; the plain copy of the same bytes:
+// 14.2 us): this kernel 20.4 us; with the arithmetic removed (loads, tables, stores only) 16.2; with the tables of a
+// block's first chunk reused for its other chunks 19.6 -- i.e. the per-chunk table phase costs ~1 us and the
+// quantizer arithmetic ~4.5 us, which adds to the memory time instead of hiding under it: all ~1000 resident blocks
+// start together and stay in phase (everybody loads, then everybody computes; 11.7 M elements x ~22 issue slots are
+// ~6.5 us of a busy VALU), and at 3 chunks per block the kernel ends before the phases drift apart.  Requesting a
+// block's next chunk right before the current chunk's arithmetic (16 more VGPRs: 100) did not change that (20.4 vs
+// 20.1 us), nor did 950 / 1280 / 1425 / 2850 blocks (21.8 / 20.4 / 19.7 / 21.5 us).  One table phase for all of a
+// block's chunks would remove at most the ~1 us the tables cost.  Not pursued further: the launch replaces 21 launches
+// (130 us from Python), and the remaining 5 us are the arithmetic of a cache-resident stream.
 __global__ void __launch_bounds__(kBlock, 4)
 k_multi_flat(MultiArgs a)
 {
