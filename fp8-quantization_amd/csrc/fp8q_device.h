@@ -386,8 +386,12 @@ __device__ __forceinline__ uint32_t encode_one(float x, const ChanLite &c, const
 __device__ __forceinline__ uint32_t encode_group4(const float (&v)[4], const ChanLite &c, const float2 *lut, float pmaxf,
                                                   float qthr, int M, int sign_shift)
 {
-    float r[4];
-    int p[4];
+    // The field (p << M) + |r| - 2^M is formed in FLOAT -- the binade index is there as a float (ls), r is a finite
+    // integer in [0, 2^(M+1)] unless `any` ends up set -- and v_cvt_pk_u8_f32 converts it and places it in its byte in one
+    // instruction (3 slots per element instead of 7 integer ones); the sign of r is the sign of x (the quantizer is odd,
+    // -0 keeps its sign: encode_one), so the four sign bits come from the top bytes of the inputs with two v_perm_b32.
+    const float m2f = (float)(1u << M);
+    float cf[4];
     bool any = c.pthr < 0.0f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -395,25 +399,23 @@ __device__ __forceinline__ uint32_t encode_group4(const float (&v)[4], const Cha
         const float w = __builtin_amdgcn_logf(fabsf(xc)) + c.bias;
         const float fl = floorf(w);
         const float fr = w - fl;
-        p[j] = (int)__builtin_amdgcn_fmed3f(fl, 1.0f, pmaxf);
-        const float2 t = lut[p[j]];
+        const float ls = __builtin_amdgcn_fmed3f(fl, 1.0f, pmaxf);
+        const float2 t = lut[(int)ls];
         const float q0 = xc * t.y;
-        r[j] = rintf(q0);
-        any |= __builtin_amdgcn_classf(v[j], 0x93) | (fabsf(fr - 0.5f) > c.pthr) | (fabsf(q0 - r[j]) > qthr);
+        const float r = rintf(q0);
+        cf[j] = fmaf(ls, m2f, fabsf(r)) - m2f;
+        any |= __builtin_amdgcn_classf(v[j], 0x93) | (fabsf(fr - 0.5f) > c.pthr) | (fabsf(q0 - r) > qthr);
     }
-    if (__builtin_expect(any, 0))   // rare: the exact path decides every element of the group
+    if (__builtin_expect(any, 0))   // rare: the exact path decides every element of the group (NaN inputs, degenerate channels)
         return encode_one(v[0], c, lut, pmaxf, qthr, M, sign_shift) | (encode_one(v[1], c, lut, pmaxf, qthr, M, sign_shift) << 8) |
                (encode_one(v[2], c, lut, pmaxf, qthr, M, sign_shift) << 16) | (encode_one(v[3], c, lut, pmaxf, qthr, M, sign_shift) << 24);
-    const uint32_t m2 = 1u << M;
-    const float rmax = (float)(2u << M);
     uint32_t word = 0u;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float ar = fabsf(r[j]);
-        uint32_t code = (((uint32_t)p[j] << M) + (uint32_t)ar) - m2;
-        if (sign_shift >= 0) code |= (__float_as_uint(r[j]) >> 31) << sign_shift;
-        code = ar <= rmax ? code : 0u;   // (false for NaN as well)
-        word |= code << (8 * j);
+    for (int j = 0; j < 4; ++j) word = __builtin_amdgcn_cvt_pk_u8_f32(cf[j], j, word);
+    if (sign_shift >= 0) {
+        const uint32_t t01 = __builtin_amdgcn_perm(__float_as_uint(v[1]), __float_as_uint(v[0]), 0x0c0c0703u);
+        const uint32_t t23 = __builtin_amdgcn_perm(__float_as_uint(v[3]), __float_as_uint(v[2]), 0x07030c0cu);
+        word |= ((t01 | t23) & 0x80808080u) >> (7 - sign_shift);
     }
     return word;
 }

@@ -20,12 +20,19 @@ dev = "cuda"
 
 def use(path):
     """switch the process to another build of the library (fp8q._lib caches one handle)"""
+    import ctypes
     _lib._lib = None
     if path:
         os.environ["FP8Q_SO"] = path
+        L = ctypes.CDLL(os.path.abspath(path))     # an older build may lack newer entry points: bind what it has
+        for name, (res, args) in _lib.SIGNATURES.items():
+            fn = getattr(L, name, None)
+            if fn is not None:
+                fn.restype, fn.argtypes = res, args
+        _lib._lib = L
     else:
         os.environ.pop("FP8Q_SO", None)
-    fp8q.lib()
+        fp8q.lib()
 
 
 def bench(fn, iters=200, warm=20):
@@ -107,6 +114,11 @@ def cases_enc():
         out.append((f"encode [{C},{inner}] M={M}", x.numel() * 5, lambda x=x, mv=mv, codes=codes, M=M: ops.encode(x, mv, M, 8, 1, out=codes)))
         out.append((f"   decode [{C},{inner}]", x.numel() * 5, lambda x=x, mv=mv, codes=codes, M=M, y=y: ops.decode(codes, mv, M, 8, 1, out=y)))
         out.append((f"   K1 [{C},{inner}]", x.numel() * 8, lambda x=x, mv=mv, y=y, M=M: ops.quantize(x, mv, M, 8, 1, out=y)))
+    for shape, pc in (((64, 64, 112, 112), False), ((16384, 4608), True), ((65536, 2304), True)):
+        x = torch.randn(*shape, device=dev)
+        mv = ops.minmax(x, True, want_maxval=True)[2] if pc else torch.tensor([3.0], device=dev)
+        codes = torch.empty(shape, dtype=torch.uint8, device=dev)
+        out.append((f"encode {list(shape)} {'per channel' if pc else 'per tensor'}", x.numel() * 5, lambda x=x, mv=mv, codes=codes: ops.encode(x, mv, 3, 8, 1, out=codes)))
     return out
 
 
