@@ -1,6 +1,6 @@
 // cabi_smoke.cpp -- the drop-in boundary used the way a non-Python host would use it: plain HIP runtime
 // calls for memory, plain pointers and sizes into libfp8q_hip.so (include/fp8q.h), no torch anywhere.
-// Checks K1, the fused min/max+quantize, the folding min/max (zeroed workspace, packed ranges, workspace check), the multi-tensor call and its prepared
+// Checks K1 (by value and with a device-resident mantissa width), the float64 lane, the device-side MSE grid + winner selection, the folded-BN epilogue, the fused min/max+quantize, the folding min/max (zeroed workspace, packed ranges, workspace check), the multi-tensor call and its prepared
 // plan, the storage codec and the FP-MSE grid search against the CPU
 // oracle (libfp8q_oracle.so, test infrastructure) bit for bit.  Built by tests/test_cabi_and_host.py
 // (hipcc cross-compiles it on the CPU box); run by the -m gpu test of the same file.
@@ -23,6 +23,13 @@ int orc_decode_u8(const uint8_t *codes, float *y, int64_t C, int64_t inner, cons
                   float mbits, int n_bits, int sign_bits);
 int orc_mse_grid_f32(const float *x, int64_t C, int64_t inner, const float *grid, int64_t n_cand, const float *mbits,
                      int n_m, int n_bits, int sign_bits, float *mses);
+int orc_quantize_f64(const double *x, double *y, int64_t C, int64_t inner, const float *maxval, int64_t n_maxval,
+                     float mbits, int n_bits, int sign_bits);
+int orc_minmax_f64(const double *x, int64_t C, int64_t inner, double *mn, double *mx);
+int orc_sse_grid_f64(const double *x, int64_t C, int64_t inner, const float *grid, int64_t n_cand, const float *mbits,
+                     int n_m, int n_bits, int sign_bits, double *out, int reduce_sum);
+int orc_affine_act_f32(const float *x, const float *res, float *y, int64_t N, int64_t C, int64_t HW, const float *mean,
+                       const float *invstd, const float *gamma, const float *beta, int act);
 }
 
 #define CK(x) do { int e_ = (int)(x); if (e_ != 0) { printf("FAIL %s -> %d (%s) at line %d\n", #x, e_, fp8q_strerror(e_), __LINE__); return 1; } } while (0)
@@ -223,6 +230,144 @@ int main()
             if (!(mses[i] >= rm[i] * (1.0f - 1e-5f) && mses[i] <= rm[i] * (1.0f + 1e-5f))) { printf("FAIL fp8q_mse_grid_f32[%d]: %g vs %g\n", i, mses[i], rm[i]); good = 0; }
         if (good) printf("ok   fp8q_mse_grid_f32 (14 mean squared errors within 1e-5 of the oracle)\n");
         ok &= good;
+    }
+    // K1 with the mantissa width in device memory (the MSE estimator's vote never leaves the GPU)
+    {
+        float *dmb;
+        CK(hipMalloc((void **)&dmb, 4));
+        for (int M = 1; M <= 5; M += 2) {
+            const float mbv = (float)M + 0.3f;      // rounded half-to-even on the device, as the host does by value
+            CK(hipMemcpy(dmb, &mbv, 4, hipMemcpyHostToDevice));
+            CK(fp8q_quantize_dm_f32(dx, dy, C, inner, dmv, C, dmb, 8, 1, st));
+            CK(hipStreamSynchronize(st));
+            CK(hipMemcpy(y, dy, n * 4, hipMemcpyDeviceToHost));
+            orc_quantize_f32(x, ref, C, inner, mv, C, mbv, 8, 1);
+            char what[64];
+            snprintf(what, sizeof what, "fp8q_quantize_dm_f32 (device mantissa bits %.1f)", mbv);
+            ok &= same_bits(y, ref, n, what);
+        }
+        CK(hipFree(dmb));
+    }
+    // device-side search grid + winner selection (sync-free MSE calibration)
+    {
+        const int n_cand = 111, n_m = 3;
+        const int64_t Cs = 5;
+        const float mb[3] = {2.0f, 3.0f, 4.0f};
+        float mxs[5] = {0.5f, 1.0f, 0.7361f, 2.5f, 0.01f};
+        float *dmxs, *dgrid, *dm, *dmbo, *dmvs, *dxm;
+        int *dvote;
+        void *sws;
+        float *hm = (float *)malloc(sizeof(float) * n_m * n_cand * Cs), *hgrid = (float *)malloc(sizeof(float) * n_cand * Cs);
+        CK(hipMalloc((void **)&dmxs, sizeof(mxs)));
+        CK(hipMalloc((void **)&dgrid, sizeof(float) * n_cand * Cs));
+        CK(hipMalloc((void **)&dm, sizeof(float) * n_m * n_cand * Cs));
+        CK(hipMalloc((void **)&dmbo, 4));
+        CK(hipMalloc((void **)&dvote, 4));
+        CK(hipMalloc((void **)&dmvs, sizeof(float) * Cs));
+        CK(hipMalloc((void **)&dxm, sizeof(float) * Cs));
+        CK(hipMalloc(&sws, fp8q_mse_select_workspace_bytes(Cs, n_m)));
+        CK(hipMemcpy(dmxs, mxs, sizeof(mxs), hipMemcpyHostToDevice));
+        CK(fp8q_mse_linspace_f32(dmxs, Cs, n_cand, 0.1, 1.2, dgrid, st));
+        CK(hipStreamSynchronize(st));
+        CK(hipMemcpy(hgrid, dgrid, sizeof(float) * n_cand * Cs, hipMemcpyDeviceToHost));
+        int good = 1;
+        for (int64_t c = 0; c < Cs; ++c) {     // torch.linspace endpoints: fl32(0.1 * mx), fl32(1.2 * mx), ascending in between
+            const float lo = (float)(0.1 * (double)mxs[c]), hi = (float)(1.2 * (double)mxs[c]);
+            if (hgrid[c] != lo || hgrid[(n_cand - 1) * Cs + c] != hi) good = 0;
+            for (int i = 1; i < n_cand; ++i)
+                if (!(hgrid[i * Cs + c] > hgrid[(i - 1) * Cs + c])) good = 0;
+        }
+        // a table with a known winner: width 1 wins in channels 0..2, width 2 in 3..4 -> vote = 1; argmin index 10 + c
+        for (int m = 0; m < n_m; ++m)
+            for (int i = 0; i < n_cand; ++i)
+                for (int64_t c = 0; c < Cs; ++c)
+                    hm[(m * n_cand + i) * Cs + c] = 1.0f + 0.001f * (float)i + ((m == (c < 3 ? 1 : 2)) && i == 10 + c ? -0.5f : 0.0f);
+        CK(hipMemcpy(dm, hm, sizeof(float) * n_m * n_cand * Cs, hipMemcpyHostToDevice));
+        CK(fp8q_mse_select_f32(dm, dgrid, Cs, n_cand, mb, n_m, 1, dmbo, dvote, dmvs, dxm, sws, fp8q_mse_select_workspace_bytes(Cs, n_m), st));
+        CK(hipStreamSynchronize(st));
+        float mbo, gmvs[5], gxm[5];
+        int vote;
+        CK(hipMemcpy(&mbo, dmbo, 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(&vote, dvote, 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(gmvs, dmvs, sizeof(gmvs), hipMemcpyDeviceToHost));
+        CK(hipMemcpy(gxm, dxm, sizeof(gxm), hipMemcpyDeviceToHost));
+        if (vote != 1 || mbo != 3.0f) good = 0;
+        for (int64_t c = 0; c < Cs; ++c) {     // channels 3, 4 voted for another width: THEIR argmin under the winning width is index 0
+            const int want = c < 3 ? 10 + (int)c : 0;
+            if (gmvs[c] != hgrid[want * Cs + c] || gxm[c] != -gmvs[c]) good = 0;
+        }
+        printf(good ? "ok   fp8q_mse_linspace_f32 + fp8q_mse_select_f32 (grid endpoints, vote, per-channel argmin)\n"
+                    : "FAIL fp8q_mse_linspace_f32 / fp8q_mse_select_f32\n");
+        ok &= good;
+    }
+    // the float64 lane: K1, row min/max and the candidate search on doubles, bit for bit / to 1e-13 against the oracle
+    {
+        double *xd = (double *)malloc(n * 8), *yd = (double *)malloc(n * 8), *rd = (double *)malloc(n * 8), *dxd, *dyd, *dmm, *dsse;
+        for (int64_t i = 0; i < n; ++i) xd[i] = (double)x[i] * 1.000000123;
+        CK(hipMalloc((void **)&dxd, n * 8));
+        CK(hipMalloc((void **)&dyd, n * 8));
+        CK(hipMalloc((void **)&dmm, 16));
+        CK(hipMemcpy(dxd, xd, n * 8, hipMemcpyHostToDevice));
+        CK(fp8q_quantize_f64(dxd, dyd, C, inner, dmv, C, 3.0f, 8, 1, st));
+        CK(hipStreamSynchronize(st));
+        CK(hipMemcpy(yd, dyd, n * 8, hipMemcpyDeviceToHost));
+        orc_quantize_f64(xd, rd, C, inner, mv, C, 3.0f, 8, 1);
+        int good = memcmp(yd, rd, n * 8) == 0;
+        printf(good ? "ok   fp8q_quantize_f64 (%lld doubles bit-identical)\n" : "FAIL fp8q_quantize_f64\n", (long long)n);
+        ok &= good;
+        void *w64;
+        const size_t w64b = fp8q_minmax_f64_workspace_bytes(1, n);
+        CK(hipMalloc(&w64, w64b));
+        CK(fp8q_minmax_f64(dxd, 1, n, dmm, dmm + 1, w64, w64b, st));
+        CK(hipStreamSynchronize(st));
+        double gmm[2], rmn64, rmx64;
+        CK(hipMemcpy(gmm, dmm, 16, hipMemcpyDeviceToHost));
+        orc_minmax_f64(xd, 1, n, &rmn64, &rmx64);
+        good = gmm[0] == rmn64 && gmm[1] == rmx64;
+        printf(good ? "ok   fp8q_minmax_f64\n" : "FAIL fp8q_minmax_f64\n");
+        ok &= good;
+        const int n_cand = 50;
+        const float mb1[1] = {3.0f};
+        float g50[50];
+        for (int i = 0; i < n_cand; ++i) g50[i] = 0.01f * (float)(i + 1);
+        float *dg50;
+        void *sw;
+        const size_t swb = fp8q_mse_f64_workspace_bytes(1, n, n_cand, 1);
+        CK(hipMalloc((void **)&dg50, sizeof(g50)));
+        CK(hipMalloc((void **)&dsse, n_cand * 8));
+        CK(hipMalloc(&sw, swb));
+        CK(hipMemcpy(dg50, g50, sizeof(g50), hipMemcpyHostToDevice));
+        CK(hipMemset(dsse, 0, n_cand * 8));
+        CK(fp8q_mse_grid_f64(dxd, 1, n, dg50, n_cand, mb1, 1, 8, 1, dsse, 1, sw, swb, st));
+        CK(hipStreamSynchronize(st));
+        double sse[50], rsse[50];
+        CK(hipMemcpy(sse, dsse, sizeof(sse), hipMemcpyDeviceToHost));
+        memset(rsse, 0, sizeof(rsse));
+        orc_sse_grid_f64(xd, 1, n, g50, n_cand, mb1, 1, 8, 1, rsse, 1);
+        good = 1;
+        for (int i = 0; i < n_cand; ++i)
+            if (!(sse[i] >= rsse[i] * (1 - 1e-13) && sse[i] <= rsse[i] * (1 + 1e-13))) good = 0;
+        printf(good ? "ok   fp8q_mse_grid_f64 (50 sums of squares within 1e-13 of the oracle)\n" : "FAIL fp8q_mse_grid_f64\n");
+        ok &= good;
+    }
+    // fused epilogue with the folded batch-norm vector (fp8q_bn_fold_f32 + fp8q_affine_act_quantize_ab_f32)
+    {
+        const int64_t N = 3, Cc = 100, HW = 147;        // the same buffer viewed as [3, 100, 147]
+        float bnv[4][100], *dbn, *dab, *t = (float *)malloc(n * 4);
+        for (int k = 0; k < 4; ++k)
+            for (int c = 0; c < 100; ++c) bnv[k][c] = (k == 0 ? -0.01f : 0.5f) + 0.003f * (float)((c * 7 + k * 13) % 31);
+        CK(hipMalloc((void **)&dbn, sizeof(bnv)));
+        CK(hipMalloc((void **)&dab, 100 * 8));
+        CK(hipMemcpy(dbn, bnv, sizeof(bnv), hipMemcpyHostToDevice));
+        CK(fp8q_bn_fold_f32(dbn, dbn + 100, dbn + 200, dbn + 300, Cc, dab, st));
+        const float one_mv = 0.2f;
+        CK(hipMemcpy(dmvo, &one_mv, 4, hipMemcpyHostToDevice));
+        CK(fp8q_affine_act_quantize_ab_f32(dx, nullptr, dy, N, Cc, HW, dab, 1, dmvo, 3.0f, 8, 1, st));
+        CK(hipStreamSynchronize(st));
+        CK(hipMemcpy(y, dy, n * 4, hipMemcpyDeviceToHost));
+        orc_affine_act_f32(x, nullptr, t, N, Cc, HW, bnv[0], bnv[1], bnv[2], bnv[3], 1);
+        orc_quantize_f32(t, ref, 1, n, &one_mv, 1, 3.0f, 8, 1);
+        ok &= same_bits(y, ref, n, "fp8q_bn_fold_f32 + fp8q_affine_act_quantize_ab_f32 (BN + ReLU + E4M3)");
     }
     // error behaviour: bad arguments are reported, nothing throws
     if (fp8q_quantize_f32(dx, dy, C, inner, dmv, C - 1, 2.0f, 8, 1, st) != FP8Q_EINVAL) { printf("FAIL: EINVAL expected\n"); ok = 0; }

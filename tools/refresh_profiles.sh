@@ -1,9 +1,9 @@
 #!/bin/bash
 # Regenerate the judged artefacts on a GPU box: bench line, rocprofv3 kernel stats of the same command, PMC traffic,
 # and the per-kernel profiles of K3 / K4 / the fused short-row kernel.
-# usage (from the repo root, on the GPU box): bash tools/refresh_profiles.sh r03     -> gpurun_out/<tag>_*
+# usage (from the repo root, on the GPU box): bash tools/refresh_profiles.sh r04     -> gpurun_out/<tag>_*
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=$PWD
 export TMPDIR=/tmp
 mkdir -p $R/gpurun_out
@@ -25,6 +25,13 @@ CHECK=0 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${
 for cfg in c3 c4 c4_search; do
     rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_${cfg}_kt -o $cfg -- python $R/bench.py --only-model-config $cfg > $R/gpurun_out/${TAG}_${cfg}.log 2> $R/gpurun_out/${TAG}_${cfg}.err
 done
+# the multi-tensor plan, the fused epilogue shapes and the short-row encode: GPU-side durations per (kernel, grid)
+for set in multi epi enc; do
+    ITERS=30 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_ab_${set}_kt -o $set -- python $R/tools/ab.py $set > $R/gpurun_out/${TAG}_ab_${set}.log 2>&1
+    python $R/tools/trace_by_grid.py $R/gpurun_out/${TAG}_ab_${set}_kt k_ > $R/gpurun_out/${TAG}_ab_${set}_by_grid.txt 2>&1
+done
+# BASELINE config 1 at full size (float64 lane): wall time of the whole script + its printout
+cd $R/fp8-quantization_amd && ( time python compute_quant_error.py ) > $R/gpurun_out/${TAG}_config1_full_size.txt 2>&1
 cd $R
 for d in c3_kt c4_kt c4_search_kt; do find gpurun_out/${TAG}_$d -mindepth 2 -name "*.csv" -exec cp {} gpurun_out/${TAG}_$d/ \; ; done
 for d in kt pf pw mse_kt mse_pmc mse_pmc2 k3_kt staged_kt; do   # rocprofv3 nests its files under <dir>/<host>/: flatten

@@ -65,10 +65,10 @@ def model_trace(tag, name, trace_csv, log, title, n_fwd=20):
             d[0] += 1
             d[1] += dur[i]
     cb = entry.get("calibration_batch") or entry.get("calibration_batch_fixed_mantissa") or entry.get("calibration_batch_mantissa_search_6") or {}
-    out.append(f"# CALIBRATION BATCH + fix_ranges (this library's kernels before the validation forwards): "
+    out.append(f"# CALIBRATION (the batch TWICE -- bench.py times a first and a steady-state pass -- + fix_ranges; this library's kernels before the validation forwards): "
                f"{sum(v[0] for v in cal.values())} launches, {sum(v[1] for v in cal.values()) / 1e3:.1f} us"
-               + (f"; by HIP events: {cb.get('library_us')} us in {cb.get('launches')} calls, wall {cb.get('wall_ms')} ms"
-                  f" (host-side estimator logic included)" if cb else ""))
+               + (f"; ONE steady-state pass by HIP events: {cb.get('library_us')} us in {cb.get('launches')} calls, wall {cb.get('wall_ms')} ms"
+                  f" (host-side estimator logic and the convolutions included; first pass: {(cb.get('first_pass') or {}).get('wall_ms')} ms)" if cb else ""))
     out.append("Name,Calls,TotalUs,AvgUs")
     for k, v in sorted(cal.items(), key=lambda kv: -kv[1][1]):
         out.append(f"{lib(k)},{v[0]},{v[1] / 1e3:.1f},{v[1] / v[0] / 1e3:.2f}")
