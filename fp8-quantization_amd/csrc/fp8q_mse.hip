@@ -539,6 +539,28 @@ k_mse_select_vote(const int *__restrict__ sel, const float *__restrict__ grid, i
 
 }  // namespace
 
+// fp8q_mse_sorted.hip: sort-once evaluation of many candidates on one long row
+size_t fp8q_mse_sorted_workspace_bytes(int64_t n);
+int fp8q_mse_sorted_launch(const float *x, int64_t n, const float *grid, int64_t n_cand, const QFmt *fmts, int n_m, float *mses,
+                           void *ws, size_t ws_bytes, hipStream_t st, int brute);
+
+// FP8Q_MSE_SORTED: 1 (default) = per-tensor rows of >= 2^20 elements with >= 256 (width, candidate) pairs of a signed format go
+// through the sorted evaluation; 0 = never; 2 = sorted routing with every candidate evaluated element by element (self-check)
+static int mse_sorted_mode()
+{
+    static const int v = [] {
+        const char *e = getenv("FP8Q_MSE_SORTED");
+        return e ? atoi(e) : 1;
+    }();
+    return v;
+}
+
+static bool mse_use_sorted(int64_t C, int64_t inner, int64_t n_cand, int n_m, int sign_bits)
+{
+    return mse_sorted_mode() != 0 && C == 1 && sign_bits == 1 && inner >= (1 << 20) && inner < (1ll << 31) &&
+           (int64_t)n_m * n_cand >= 256;
+}
+
 extern "C" {
 
 int fp8q_mse_linspace_f32(const float *mx, int64_t C, int n_cand, double lo_frac, double hi_frac, float *grid,
@@ -630,6 +652,13 @@ static RowGeo mse_row_geo(int64_t C, int64_t inner, int64_t n_cand, int n_m)
 size_t fp8q_mse_workspace_bytes(int64_t C, int64_t inner, int64_t n_cand, int n_m)
 {
     if (C <= 0 || inner <= 0 || n_cand <= 0 || n_m <= 0) return 16;
+    // (the format's sign is not known here: the sorted path's size is returned whenever the shape could take it)
+    if (mse_use_sorted(C, inner, n_cand, n_m, 1)) {
+        const size_t a = fp8q_mse_sorted_workspace_bytes(inner);
+        const int64_t ns0 = mse_use_row(C, inner) ? mse_row_geo(C, inner, n_cand, n_m).nblk : mse_nsplit(C, inner, n_cand, n_m);
+        const size_t b = (size_t)C * n_m * n_cand * ns0 * sizeof(double) + 16;
+        return a > b ? a : b;
+    }
     const int64_t ns = mse_use_row(C, inner) ? mse_row_geo(C, inner, n_cand, n_m).nblk : mse_nsplit(C, inner, n_cand, n_m);
     return (size_t)C * n_m * n_cand * ns * sizeof(double) + 16;
 }
@@ -657,6 +686,8 @@ int fp8q_mse_grid_f32(const float *x, int64_t C, int64_t inner, const float *gri
     a.inner = inner;
     a.C = C;
     hipStream_t st = (hipStream_t)stream;
+    if (mse_use_sorted(C, inner, n_cand, n_m, sign_bits))
+        return fp8q_mse_sorted_launch(x, inner, grid, n_cand, a.fmt, n_m, mses, ws, ws_bytes, st, mse_sorted_mode() == 2);
     int64_t nsplit = a.nsplit;
     if (mse_use_row(C, inner) && ((uintptr_t)x & 3) == 0) {
         const RowGeo g = mse_row_geo(C, inner, n_cand, n_m);

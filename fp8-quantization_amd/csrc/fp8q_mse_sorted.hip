@@ -1,0 +1,349 @@
+// fp8q_mse_sorted.hip -- K4 for MANY candidates on one long row: sort once, then every candidate costs ~200 binary searches.
+//
+// The candidate loops of FP_MSE_Estimator.forward (quantization/range_estimators.py:337-347) with the mantissa search of the
+// reference CLI's default evaluate 6 x 111 = 666 quantizers on the same tensor; LineSearchEstimator (:236-256) evaluates
+// 1000.  k_mse_row (fp8q_mse.hip) does that at 4-7 VALU issue slots per candidate-element and is VALU-bound: 3.1 ms for a
+// 25.7 M-element activation x 666.  But a quantizer is a STEP FUNCTION of |x|: for one candidate (maxval, M) the keys
+// k = |x| fall into <= (2^E + 1) 2^M + 2 cells, each mapped to one grid value q, and
+//     sum over a cell of (k - q)^2 = S2 - 2 q S1 + n q^2     with n, S1 = sum k, S2 = sum k^2 of the cell's keys.
+// So: (1) sort the keys once (radix sort of the 31 magnitude bits: non-negative floats order like their bit patterns),
+// (2) prefix sums of k and k^2 in double at 256-key granularity, (3) per candidate one workgroup: a lane per cell finds
+// the cell's two borders EXACTLY -- the smallest float for which the reference's own fp32 decisions
+// (floor(fl32(log2 k) + bias) >= p, rint(fl32(k / s_p)) >= r, k > maxval) flip, located by guess-and-walk on the exact
+// predicates -- turns them into positions by binary search, and reads n / S1 / S2 off the prefix sums (+ a partial block).
+// Every element is classified as K1 / the oracle classify it; what differs from the reference is only that (k - q)^2 is
+// summed in exact arithmetic (double) instead of fp32-rounded per element: ~1e-7 relative, inside K4's stated contract
+// (include/fp8q.h: table entries to 1e-5, the chosen candidate per SURVEY 8c).
+// Cost: the sort (~0.5 ms for 25.7 M keys) + ~0.1 ms per 666 candidates; used when n_m * n_cand >= 256 on a per-tensor
+// row of >= 2^20 elements of a signed format (fp8q_mse_grid_f32 routes; FP8Q_MSE_SORTED=0 disables).
+// The radix sort is rocPRIM's (header-only, part of ROCm): the one non-streaming primitive of the library.
+#include "fp8q_common.h"
+
+#include <string.h>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
+
+namespace {
+
+struct AbsBits {
+    __host__ __device__ uint32_t operator()(uint32_t b) const { return b & 0x7fffffffu; }
+};
+
+constexpr int kPre = 256;        // keys per prefix block
+constexpr int kSortMaxM = 8;
+
+struct SortedArgs {
+    QFmt fmt[kSortMaxM];
+    int n_m, n_cand;
+    int64_t n;                   // keys
+    int64_t nb;                  // prefix blocks = ceil(n / 256)
+};
+
+// block sums of k and k^2 (double): one wave per 256-key block
+__global__ void __launch_bounds__(kBlock)
+k_sorted_block_sums(const uint32_t *__restrict__ keys, int64_t n, int64_t nb, double *__restrict__ b1, double *__restrict__ b2)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= nb) return;
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t i = b * kPre + u * 64 + lane;
+        if (i < n) {
+            const double k = (double)__uint_as_float(keys[i]);
+            s1 += k;
+            s2 = fma(k, k, s2);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        s1 += __shfl_xor(s1, off, 64);
+        s2 += __shfl_xor(s2, off, 64);
+    }
+    if (lane == 0) {
+        b1[b] = s1;
+        b2[b] = s2;
+    }
+}
+
+// exclusive scan of the block sums, in place, one workgroup of 1024 (deterministic: fixed association)
+__global__ void __launch_bounds__(1024)
+k_sorted_scan(double *__restrict__ b1, double *__restrict__ b2, int64_t nb)
+{
+    __shared__ double t1[1024], t2[1024];
+    const int tid = threadIdx.x;
+    const int64_t per = (nb + 1023) / 1024, lo = tid * per, hi = lo + per < nb ? lo + per : nb;
+    double s1 = 0.0, s2 = 0.0;
+    for (int64_t i = lo; i < hi; ++i) {
+        s1 += b1[i];
+        s2 += b2[i];
+    }
+    t1[tid] = s1;
+    t2[tid] = s2;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {   // Hillis-Steele inclusive scan of the 1024 partials
+        double a1 = 0.0, a2 = 0.0;
+        if (tid >= off) {
+            a1 = t1[tid - off];
+            a2 = t2[tid - off];
+        }
+        __syncthreads();
+        t1[tid] += a1;
+        t2[tid] += a2;
+        __syncthreads();
+    }
+    if (tid == 1023) {      // grand totals behind the last block: prefix_at(n) when n is a multiple of 256
+        b1[nb] = t1[1023];
+        b2[nb] = t2[1023];
+    }
+    double r1 = tid ? t1[tid - 1] : 0.0, r2 = tid ? t2[tid - 1] : 0.0;
+    for (int64_t i = lo; i < hi; ++i) {
+        const double v1 = b1[i], v2 = b2[i];
+        b1[i] = r1;
+        b2[i] = r2;
+        r1 += v1;
+        r2 += v2;
+    }
+}
+
+__device__ __forceinline__ float next_up(float a) { return __uint_as_float(__float_as_uint(a) + 1u); }     // a >= 0, finite
+__device__ __forceinline__ float next_down(float a) { return __uint_as_float(__float_as_uint(a) - 1u); }   // a > 0
+
+// smallest non-negative float k with pred(k), for a predicate that is monotone (false ... false true ... true) on
+// [0, +inf]; `guess` should be close.  Walks at most 8 steps, then bisects the bit patterns (always terminates).
+template <class Pred>
+__device__ __forceinline__ float first_true(float guess, Pred pred)
+{
+    if (!(guess >= 0.0f)) guess = 0.0f;
+    if (!(guess < __builtin_inff())) guess = 0x1.fffffep127f;
+    float g = guess;
+    if (pred(g)) {
+        for (int i = 0; i < 8; ++i) {
+            if (g == 0.0f) return 0.0f;
+            const float d = next_down(g);
+            if (!pred(d)) return g;
+            g = d;
+        }
+        uint32_t lo = 0u, hi = __float_as_uint(g);            // pred(hi) true; find the first true in [lo, hi]
+        if (pred(0.0f)) return 0.0f;
+        while (hi - lo > 1u) {                                 // invariant: !pred(lo), pred(hi)
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            if (pred(__uint_as_float(mid))) hi = mid; else lo = mid;
+        }
+        return __uint_as_float(hi);
+    }
+    for (int i = 0; i < 8; ++i) {
+        g = next_up(g);
+        if (!(g < __builtin_inff())) return __builtin_inff();
+        if (pred(g)) return g;
+    }
+    uint32_t lo = __float_as_uint(g), hi = 0x7f800000u;       // !pred(lo); +inf counts as true
+    while (hi - lo > 1u) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (pred(__uint_as_float(mid))) hi = mid; else lo = mid;
+    }
+    return __uint_as_float(hi);
+}
+
+// number of keys < v (v >= 0 or +inf): lower bound on the bit patterns
+__device__ __forceinline__ int64_t lower_bound_keys(const uint32_t *__restrict__ keys, int64_t n, float v)
+{
+    const uint32_t vb = __float_as_uint(v);
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const int64_t mid = lo + ((hi - lo) >> 1);
+        if (keys[mid] < vb) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+struct Moments {
+    double s1, s2;
+};
+
+// sums of k and k^2 over keys[0 .. pos)
+__device__ __forceinline__ Moments prefix_at(const uint32_t *__restrict__ keys, const double *__restrict__ p1,
+                                             const double *__restrict__ p2, int64_t pos)
+{
+    const int64_t b = pos / kPre;
+    Moments m = {p1[b], p2[b]};
+    for (int64_t i = b * kPre; i < pos; ++i) {
+        const double k = (double)__uint_as_float(keys[i]);
+        m.s1 += k;
+        m.s2 = fma(k, k, m.s2);
+    }
+    return m;
+}
+
+// one workgroup per (mantissa width, candidate); a lane per cell (looping when a format has more than 256 cells)
+__global__ void __launch_bounds__(kBlock)
+k_mse_cells(const uint32_t *__restrict__ keys, const double *__restrict__ p1, const double *__restrict__ p2,
+            const float *__restrict__ grid, float *__restrict__ mses, SortedArgs a, double inv_inner, int brute)
+{
+    __shared__ float s_scale[kLutMax];     // s_p, p = 1 .. pmax (exact: lut_entry)
+    __shared__ float s_border[kLutMax];    // L_p: smallest key of binade p (L_1 = 0, L_(pmax+1) = +inf)
+    __shared__ double s_red[kBlock];
+    const int tid = threadIdx.x;
+    const int m = blockIdx.x / a.n_cand, cand = blockIdx.x - m * a.n_cand;
+    const QFmt f = a.fmt[m];
+    const float gv = grid[cand];
+    const float mv = fabsf(fmaxf(fabsf(-gv), gv));              // set_quant_range(-g, g): fp8_quantizer.py:236
+    const Chan ch = make_chan(mv, f);
+    const int64_t n = a.n;
+    const int M = (int)f.M, pmax = f.pmax;
+    float *out = mses + ((int64_t)m * a.n_cand + cand);
+    // non-finite keys: the reference's mean is NaN (a NaN element) or +inf (an infinite one: (x - xq)^2 = inf)
+    const uint32_t last = keys[n - 1];
+    const bool degenerate = !(fabsf(ch.bias) < __builtin_inff());   // maxval 0 / inf / NaN: every element quantizes to NaN
+    if (last > 0x7f800000u || degenerate) {
+        if (tid == 0) *out += __builtin_nanf("");
+        return;
+    }
+    if (last == 0x7f800000u) {
+        if (tid == 0) *out += __builtin_inff();
+        return;
+    }
+    const float pmaxf = (float)pmax;
+    auto p_of = [&](float k) -> float {                         // K1's exact binade decision (quant_exact)
+        const float ls = floorf(log2_tab(k, kFastTab) + ch.bias);
+        return __builtin_amdgcn_fmed3f(ls, 1.0f, pmaxf);
+    };
+    for (int p = tid + 1; p <= pmax + 1; p += kBlock) {
+        if (p <= pmax) s_scale[p] = lut_entry(ch, p, f.M).x;
+        float L = 0.0f;
+        if (p > pmax) {
+            L = __builtin_inff();
+        } else if (p >= 2) {
+            const float pf = (float)p;
+            L = first_true((float)ldexp(ch.g, p - ch.bi), [&](float k) { return p_of(k) >= pf; });   // ~2^(p - bias)
+        }
+        s_border[p] = L;
+    }
+    __syncthreads();
+    // A scale that is not a positive normal number (E = 7 formats with a tiny maxval underflow s_1 to 0: the reference
+    // then yields NaN for the elements of that binade) leaves the cell logic without meaning: such a candidate -- and
+    // every candidate when `brute` is set (FP8Q_MSE_SORTED=2: the self-check the tests use) -- is evaluated element by
+    // element with K1's exact arithmetic on the sorted keys (slow: one workgroup walks the whole tensor).
+    bool odd = brute != 0;
+    for (int p = 1; p <= pmax; ++p) odd |= !(s_scale[p] >= 0x1p-126f && s_scale[p] < __builtin_inff());
+    if (odd) {
+        double acc = 0.0;
+        for (int64_t i = tid; i < n; i += kBlock) {
+            const float k = __uint_as_float(keys[i]);
+            const float xc = fminf(k, mv);
+            const float sc = s_scale[(int)p_of(xc)];
+            const float d = k - rintf(xc / sc) * sc;
+            acc += (double)(d * d);
+        }
+        s_red[tid] = acc;
+        __syncthreads();
+        for (int off = kBlock / 2; off >= 1; off >>= 1) {
+            if (tid < off) s_red[tid] += s_red[tid + off];
+            __syncthreads();
+        }
+        if (tid == 0) *out += (float)(s_red[0] * inv_inner);
+        return;
+    }
+    const float clamp_from = next_up(mv);                        // keys >= this are clipped to maxval (mv finite here)
+    const int r_top = 2 << M, r_norm = 1 << M;
+    const int n_first = r_top + 1, n_other = r_norm + 1;
+    const int ncells = n_first + (pmax - 1) * n_other + 1;       // + the clamp cell
+    double acc = 0.0;
+    for (int c = tid; c < ncells; c += kBlock) {
+        float lo, hi, q;
+        if (c == ncells - 1) {                                   // clipped elements: xc = maxval
+            const float pc = p_of(mv), sc = s_scale[(int)pc];
+            q = rintf(mv / sc) * sc;
+            lo = clamp_from;
+            hi = __builtin_inff();
+        } else {
+            int p, r;
+            if (c < n_first) {
+                p = 1;
+                r = c;
+            } else {
+                const int cc = c - n_first;
+                p = 2 + cc / n_other;
+                r = r_norm + (cc - (p - 2) * n_other);
+            }
+            const float s = s_scale[p];
+            const float rf = (float)r;
+            const int r_lo = p == 1 ? 0 : r_norm;
+            // [T(r), T(r + 1)) within the binade, T(r) = smallest k with rint(fl32(k / s)) >= r (IEEE division, as K1 decides)
+            lo = s_border[p];
+            if (r > r_lo) lo = fmaxf(lo, first_true((float)(((double)r - 0.5) * (double)s), [&](float k) { return rintf(k / s) >= rf; }));
+            hi = fminf(s_border[p + 1], clamp_from);
+            if (r < r_top) hi = fminf(hi, first_true((float)(((double)r + 0.5) * (double)s), [&](float k) { return rintf(k / s) >= rf + 1.0f; }));
+            q = rf * s;                                          // the fp32 product K1 forms
+        }
+        if (lo < hi) {
+            const int64_t a0 = lower_bound_keys(keys, n, lo), a1 = lower_bound_keys(keys, n, hi);
+            if (a1 > a0) {
+                const Moments m0 = prefix_at(keys, p1, p2, a0), m1 = prefix_at(keys, p1, p2, a1);
+                const double qd = (double)q, cnt = (double)(a1 - a0);
+                acc += (m1.s2 - m0.s2) - 2.0 * qd * (m1.s1 - m0.s1) + cnt * qd * qd;
+            }
+        }
+    }
+    s_red[tid] = acc;
+    __syncthreads();
+    for (int off = kBlock / 2; off >= 1; off >>= 1) {            // fixed tree: deterministic
+        if (tid < off) s_red[tid] += s_red[tid + off];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double tot = s_red[0] < 0.0 ? 0.0 : s_red[0];     // (rounding of the prefix differences can leave -1e-20 for an exact fit)
+        *out += (float)(tot * inv_inner);
+    }
+}
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+size_t sort_temp_bytes(int64_t n)
+{
+    size_t bytes = 0;
+    auto in = rocprim::make_transform_iterator((const uint32_t *)nullptr, AbsBits());
+    (void)rocprim::radix_sort_keys(nullptr, bytes, in, (uint32_t *)nullptr, (size_t)n, 0, 31, (hipStream_t)0);
+    return bytes;
+}
+
+}  // namespace
+
+// (called from fp8q_mse.hip)
+size_t fp8q_mse_sorted_workspace_bytes(int64_t n)
+{
+    const int64_t nb = cdiv(n, kPre);
+    return align_up((size_t)n * 4, 256) + 2 * align_up((size_t)(nb + 1) * 8, 256) + align_up(sort_temp_bytes(n), 256) + 256;
+}
+
+int fp8q_mse_sorted_launch(const float *x, int64_t n, const float *grid, int64_t n_cand, const QFmt *fmts, int n_m, float *mses,
+                           void *ws, size_t ws_bytes, hipStream_t st, int brute)
+{
+    if (n_m > kSortMaxM || ws_bytes < fp8q_mse_sorted_workspace_bytes(n) || ((uintptr_t)ws & 7)) return FP8Q_EWORKSPACE;
+    const int64_t nb = cdiv(n, kPre);
+    char *w = (char *)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+    uint32_t *keys = (uint32_t *)w;
+    w += align_up((size_t)n * 4, 256);
+    double *p1 = (double *)w;
+    w += align_up((size_t)(nb + 1) * 8, 256);
+    double *p2 = (double *)w;
+    w += align_up((size_t)(nb + 1) * 8, 256);
+    size_t temp = sort_temp_bytes(n);
+    auto in = rocprim::make_transform_iterator(reinterpret_cast<const uint32_t *>(x), AbsBits());
+    if (hipError_t e = rocprim::radix_sort_keys((void *)w, temp, in, keys, (size_t)n, 0, 31, st); e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(k_sorted_block_sums, dim3((unsigned)cdiv(nb, 4)), dim3(kBlock), 0, st, keys, n, nb, p1, p2);
+    if (int rc = launch_rc()) return rc;
+    hipLaunchKernelGGL(k_sorted_scan, dim3(1), dim3(1024), 0, st, p1, p2, nb);
+    if (int rc = launch_rc()) return rc;
+    SortedArgs a;
+    for (int m = 0; m < n_m; ++m) a.fmt[m] = fmts[m];
+    a.n_m = n_m;
+    a.n_cand = (int)n_cand;
+    a.n = n;
+    a.nb = nb;
+    hipLaunchKernelGGL(k_mse_cells, dim3((unsigned)(n_m * n_cand)), dim3(kBlock), 0, st, keys, p1, p2, grid, mses, a,
+                       1.0 / (double)n, brute);
+    return launch_rc();
+}

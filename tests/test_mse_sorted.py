@@ -1,0 +1,82 @@
+"""K4's sort-once path (csrc/fp8q_mse_sorted.hip) against the element-by-element evaluation of the same arithmetic, the
+lane-per-element kernel and the CPU oracle.  FP8Q_MSE_SORTED is read once per process, so each mode runs in a subprocess."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCRIPT = r"""
+import sys, numpy as np, torch
+sys.path[:0] = [r"%s", r"%s"]
+import fp8q
+ops = fp8q.ops
+torch.manual_seed(5)
+n = (1 << 20) + 77
+cases = {}
+x = torch.randn(n, device="cuda") * 1.3
+cases["gauss"] = x
+cases["relu"] = torch.relu(x)                                  # half of the keys are exactly zero
+cases["pow2"] = torch.ldexp(torch.ones(n, device="cuda"), torch.randint(-12, 4, (n,), device="cuda")) * torch.where(torch.rand(n, device="cuda") < 0.5, -1.0, 1.0)
+cases["const"] = torch.full((n,), 0.731, device="cuda")
+t = x.clone(); t[12345] = float("inf"); cases["inf"] = t
+t = x.clone(); t[777] = float("nan"); cases["nan"] = t
+cases["tiny"] = x * 1e-30
+out = {}
+mb = [1.0, 2.0, 3.0, 4.0, 5.0, 6.0]
+for name, t in cases.items():
+    mx = t[torch.isfinite(t)].abs().max().reshape(1)
+    grid = ops.mse_linspace(mx, 111)
+    if name == "gauss":
+        grid[0, 0] = 0.0                                       # a degenerate candidate: NaN
+    mses = torch.zeros(6, 111, 1, device="cuda")
+    ops.mse_grid(t, False, grid, mb, 8, 1, mses)
+    ops.mse_grid(t, False, grid, mb, 8, 1, mses)               # accumulates
+    out[name] = mses.cpu().numpy()
+    out[name + "_grid"] = grid.cpu().numpy()
+    out[name + "_x"] = t.cpu().numpy() if name in ("gauss", "relu", "pow2") else np.zeros(1)
+np.savez(sys.argv[1], **out)
+""" % (ROOT, os.path.join(ROOT, "fp8-quantization_amd"))
+
+
+def _run(mode, tmp_path):
+    path = os.path.join(str(tmp_path), f"mode{mode}.npz")
+    env = dict(os.environ, FP8Q_MSE_SORTED=str(mode))
+    r = subprocess.run([sys.executable, "-c", SCRIPT, path], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return np.load(path)
+
+
+def test_sorted_path_equals_elementwise_evaluation_and_row_kernel(tmp_path):
+    import oracle
+    s, b, r = _run(1, tmp_path), _run(2, tmp_path), _run(0, tmp_path)     # sorted / brute (same routing) / lane-per-element kernel
+    for name in ("gauss", "relu", "pow2", "const", "tiny"):
+        S, B, R = s[name], b[name], r[name]
+        assert np.array_equal(np.isnan(S), np.isnan(B)) and np.array_equal(np.isnan(S), np.isnan(R)), name
+        ok = ~np.isnan(S)
+        if name == "gauss":
+            assert np.isnan(S[:, 0, 0]).all()                  # the zero candidate
+        # the brute pass classifies every element with the same exact predicates the cell borders are located with:
+        # agreement to the rounding of the sums (fp32-rounded squares there, exact here) shows no element sits in a wrong cell
+        # (absolute floor: the cell sums S2 - 2 q S1 + n q^2 cancel in double -- an MSE that is ~0 because the data sit on
+        # the grid, e.g. powers of two, is exact only to ~1e-15 of the data's mean square)
+        floor = 1e-12 * float(np.nanmax(S))
+        np.testing.assert_allclose(S[ok], B[ok], rtol=2e-6, atol=floor, err_msg=name)
+        # (pow2: every key sits exactly on a binade border -- the one place where k_mse_row's exponent-field shortcut is
+        # allowed to differ from the IEEE decision, see its header; the oracle comparison below is the judge there)
+        np.testing.assert_allclose(S[ok], R[ok], rtol=1e-5 if name != "pow2" else 1e-4, atol=floor, err_msg=name)
+        assert (S[ok] >= 0).all()
+        # the argmin the estimator would take: identical
+        if name != "pow2":       # (there several candidates represent the data exactly: MSE ~ 0 for all of them)
+            assert np.array_equal(np.nanargmin(np.where(ok, S, np.inf), axis=1), np.nanargmin(np.where(ok, R, np.inf), axis=1)), name
+    assert np.isinf(s["inf"]).all() and np.isinf(r["inf"]).all() and (s["inf"] > 0).all()
+    assert np.isnan(s["nan"]).all() and np.isnan(r["nan"]).all()
+    # against the CPU oracle on a subset of the candidates (two passes were accumulated)
+    for name in ("gauss", "relu", "pow2"):
+        idx = [1, 7, 55, 110]
+        ref = oracle.c_mse_grid(s[name + "_x"], False, s[name + "_grid"][idx], [2.0, 3.0, 5.0], 8, 1)
+        np.testing.assert_allclose(s[name][[1, 2, 4]][:, idx, :], 2 * ref, rtol=1e-5, atol=1e-12 * float(np.nanmax(s[name])), err_msg=name)
