@@ -68,44 +68,57 @@ k_sorted_block_sums(const uint32_t *__restrict__ keys, int64_t n, int64_t nb, do
     }
 }
 
-// exclusive scan of the block sums, in place, one workgroup of 1024 (deterministic: fixed association)
-__global__ void __launch_bounds__(1024)
-k_sorted_scan(double *__restrict__ b1, double *__restrict__ b2, int64_t nb)
+// Two-level exclusive scan of the block sums (deterministic: fixed association).  A single workgroup walking all
+// ~100 K entries spent 395 us in dependent, uncoalesced loads; here one workgroup per SUPERBLOCK of 1024 entries loads
+// them coalesced, scans them in LDS and writes the exclusive prefix WITHIN the superblock plus the superblock's total;
+// k_sorted_scan_top then turns the <= a few hundred totals into exclusive prefixes.  prefix_at() adds the two levels.
+constexpr int kSuper = 1024;
+
+__global__ void __launch_bounds__(kSuper)
+k_sorted_scan_super(double *__restrict__ b1, double *__restrict__ b2, int64_t nb, double *__restrict__ t1, double *__restrict__ t2)
 {
-    __shared__ double t1[1024], t2[1024];
+    __shared__ double s1[kSuper], s2[kSuper];
     const int tid = threadIdx.x;
-    const int64_t per = (nb + 1023) / 1024, lo = tid * per, hi = lo + per < nb ? lo + per : nb;
-    double s1 = 0.0, s2 = 0.0;
-    for (int64_t i = lo; i < hi; ++i) {
-        s1 += b1[i];
-        s2 += b2[i];
-    }
-    t1[tid] = s1;
-    t2[tid] = s2;
+    const int64_t i = (int64_t)blockIdx.x * kSuper + tid;
+    const double v1 = i < nb ? b1[i] : 0.0, v2 = i < nb ? b2[i] : 0.0;
+    s1[tid] = v1;
+    s2[tid] = v2;
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {   // Hillis-Steele inclusive scan of the 1024 partials
+    for (int off = 1; off < kSuper; off <<= 1) {   // Hillis-Steele inclusive scan
         double a1 = 0.0, a2 = 0.0;
         if (tid >= off) {
-            a1 = t1[tid - off];
-            a2 = t2[tid - off];
+            a1 = s1[tid - off];
+            a2 = s2[tid - off];
         }
         __syncthreads();
-        t1[tid] += a1;
-        t2[tid] += a2;
+        s1[tid] += a1;
+        s2[tid] += a2;
         __syncthreads();
     }
-    if (tid == 1023) {      // grand totals behind the last block: prefix_at(n) when n is a multiple of 256
-        b1[nb] = t1[1023];
-        b2[nb] = t2[1023];
+    if (i < nb) {                                   // exclusive, within the superblock
+        b1[i] = tid ? s1[tid - 1] : 0.0;
+        b2[i] = tid ? s2[tid - 1] : 0.0;
     }
-    double r1 = tid ? t1[tid - 1] : 0.0, r2 = tid ? t2[tid - 1] : 0.0;
-    for (int64_t i = lo; i < hi; ++i) {
-        const double v1 = b1[i], v2 = b2[i];
-        b1[i] = r1;
-        b2[i] = r2;
+    if (tid == kSuper - 1) {
+        t1[blockIdx.x] = s1[tid];
+        t2[blockIdx.x] = s2[tid];
+    }
+}
+
+__global__ void __launch_bounds__(64)
+k_sorted_scan_top(double *__restrict__ t1, double *__restrict__ t2, int64_t nsb)
+{
+    if (threadIdx.x != 0) return;                   // a few hundred entries: one lane, in order
+    double r1 = 0.0, r2 = 0.0;
+    for (int64_t i = 0; i < nsb; ++i) {
+        const double v1 = t1[i], v2 = t2[i];
+        t1[i] = r1;
+        t2[i] = r2;
         r1 += v1;
         r2 += v2;
     }
+    t1[nsb] = r1;                                   // grand totals: prefix_at(n) when n is a multiple of 256 * 1024
+    t2[nsb] = r2;
 }
 
 __device__ __forceinline__ float next_up(float a) { return __uint_as_float(__float_as_uint(a) + 1u); }     // a >= 0, finite
@@ -165,10 +178,12 @@ struct Moments {
 
 // sums of k and k^2 over keys[0 .. pos)
 __device__ __forceinline__ Moments prefix_at(const uint32_t *__restrict__ keys, const double *__restrict__ p1,
-                                             const double *__restrict__ p2, int64_t pos)
+                                             const double *__restrict__ p2, const double *__restrict__ t1,
+                                             const double *__restrict__ t2, int64_t nb, int64_t pos)
 {
     const int64_t b = pos / kPre;
-    Moments m = {p1[b], p2[b]};
+    // (b == nb: pos == n at a block border -- everything: the last superblock's entry would be out of range)
+    Moments m = b < nb ? Moments{t1[b / kSuper] + p1[b], t2[b / kSuper] + p2[b]} : Moments{t1[(nb + kSuper - 1) / kSuper], t2[(nb + kSuper - 1) / kSuper]};
     for (int64_t i = b * kPre; i < pos; ++i) {
         const double k = (double)__uint_as_float(keys[i]);
         m.s1 += k;
@@ -180,7 +195,7 @@ __device__ __forceinline__ Moments prefix_at(const uint32_t *__restrict__ keys, 
 // one workgroup per (mantissa width, candidate); a lane per cell (looping when a format has more than 256 cells)
 __global__ void __launch_bounds__(kBlock)
 k_mse_cells(const uint32_t *__restrict__ keys, const double *__restrict__ p1, const double *__restrict__ p2,
-            const float *__restrict__ grid, float *__restrict__ mses, SortedArgs a, double inv_inner, int brute)
+            const double *__restrict__ t1, const double *__restrict__ t2, const float *__restrict__ grid, float *__restrict__ mses, SortedArgs a, double inv_inner, int brute)
 {
     __shared__ float s_scale[kLutMax];     // s_p, p = 1 .. pmax (exact: lut_entry)
     __shared__ float s_border[kLutMax];    // L_p: smallest key of binade p (L_1 = 0, L_(pmax+1) = +inf)
@@ -281,7 +296,7 @@ k_mse_cells(const uint32_t *__restrict__ keys, const double *__restrict__ p1, co
         if (lo < hi) {
             const int64_t a0 = lower_bound_keys(keys, n, lo), a1 = lower_bound_keys(keys, n, hi);
             if (a1 > a0) {
-                const Moments m0 = prefix_at(keys, p1, p2, a0), m1 = prefix_at(keys, p1, p2, a1);
+                const Moments m0 = prefix_at(keys, p1, p2, t1, t2, a.nb, a0), m1 = prefix_at(keys, p1, p2, t1, t2, a.nb, a1);
                 const double qd = (double)q, cnt = (double)(a1 - a0);
                 acc += (m1.s2 - m0.s2) - 2.0 * qd * (m1.s1 - m0.s1) + cnt * qd * qd;
             }
@@ -315,7 +330,9 @@ size_t sort_temp_bytes(int64_t n)
 size_t fp8q_mse_sorted_workspace_bytes(int64_t n)
 {
     const int64_t nb = cdiv(n, kPre);
-    return align_up((size_t)n * 4, 256) + 2 * align_up((size_t)(nb + 1) * 8, 256) + align_up(sort_temp_bytes(n), 256) + 256;
+    const int64_t nsb = cdiv(nb, kSuper);
+    return align_up((size_t)n * 4, 256) + 2 * align_up((size_t)(nb + 1) * 8, 256) + 2 * align_up((size_t)(nsb + 1) * 8, 256) +
+           align_up(sort_temp_bytes(n), 256) + 256;
 }
 
 int fp8q_mse_sorted_launch(const float *x, int64_t n, const float *grid, int64_t n_cand, const QFmt *fmts, int n_m, float *mses,
@@ -330,12 +347,19 @@ int fp8q_mse_sorted_launch(const float *x, int64_t n, const float *grid, int64_t
     w += align_up((size_t)(nb + 1) * 8, 256);
     double *p2 = (double *)w;
     w += align_up((size_t)(nb + 1) * 8, 256);
+    const int64_t nsb = cdiv(nb, kSuper);
+    double *t1 = (double *)w;
+    w += align_up((size_t)(nsb + 1) * 8, 256);
+    double *t2 = (double *)w;
+    w += align_up((size_t)(nsb + 1) * 8, 256);
     size_t temp = sort_temp_bytes(n);
     auto in = rocprim::make_transform_iterator(reinterpret_cast<const uint32_t *>(x), AbsBits());
     if (hipError_t e = rocprim::radix_sort_keys((void *)w, temp, in, keys, (size_t)n, 0, 31, st); e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(k_sorted_block_sums, dim3((unsigned)cdiv(nb, 4)), dim3(kBlock), 0, st, keys, n, nb, p1, p2);
     if (int rc = launch_rc()) return rc;
-    hipLaunchKernelGGL(k_sorted_scan, dim3(1), dim3(1024), 0, st, p1, p2, nb);
+    hipLaunchKernelGGL(k_sorted_scan_super, dim3((unsigned)nsb), dim3(kSuper), 0, st, p1, p2, nb, t1, t2);
+    if (int rc = launch_rc()) return rc;
+    hipLaunchKernelGGL(k_sorted_scan_top, dim3(1), dim3(64), 0, st, t1, t2, nsb);
     if (int rc = launch_rc()) return rc;
     SortedArgs a;
     for (int m = 0; m < n_m; ++m) a.fmt[m] = fmts[m];
@@ -343,7 +367,7 @@ int fp8q_mse_sorted_launch(const float *x, int64_t n, const float *grid, int64_t
     a.n_cand = (int)n_cand;
     a.n = n;
     a.nb = nb;
-    hipLaunchKernelGGL(k_mse_cells, dim3((unsigned)(n_m * n_cand)), dim3(kBlock), 0, st, keys, p1, p2, grid, mses, a,
+    hipLaunchKernelGGL(k_mse_cells, dim3((unsigned)(n_m * n_cand)), dim3(kBlock), 0, st, keys, p1, p2, t1, t2, grid, mses, a,
                        1.0 / (double)n, brute);
     return launch_rc();
 }

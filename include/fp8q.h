@@ -151,6 +151,13 @@ int fp8q_minmax_quantize_f32(const float *x, float *y, int64_t C, int64_t inner,
  * neighbouring grid points are equally far from x, so the squared error is the same; table entries agree with the oracle's to
  * ~1e-6 relative (tests: <= 1e-5 on every entry, the CHOSEN (mantissa bits, maxval) equal to the oracle's choice or
  * its oracle-MSE within 1e-6 relative of the oracle's minimum -- SURVEY.md 8c).
+ * Per-tensor rows of >= 2^20 elements searched over >= 256 (width, candidate) pairs of a signed format -- the mantissa
+ * search of the reference CLI's default (6 x 111), LineSearchEstimator's 1000 candidates -- take a third route: |x| is
+ * radix-sorted once, prefix sums of k and k^2 are formed in double, and a candidate's quantization cells (the intervals of
+ * |x| that map to one grid value; their borders are located exactly with the reference's own fp32 decisions) are summed
+ * as S2 - 2 q S1 + n q^2.  Every element is classified as K1 classifies it; the squares are summed in exact arithmetic
+ * instead of fp32-rounded: ~1e-7 relative.  fp8q_mse_workspace_bytes() accounts for the keys (4 B / element + the sort's
+ * scratch).  FP8Q_MSE_SORTED=0 keeps the lane-per-element kernel.
  */
 size_t fp8q_mse_workspace_bytes(int64_t C, int64_t inner, int64_t n_cand, int n_m);
 int fp8q_mse_grid_f32(const float *x, int64_t C, int64_t inner, const float *grid, int64_t n_cand,
