@@ -108,17 +108,38 @@ k_sorted_scan_super(double *__restrict__ b1, double *__restrict__ b2, int64_t nb
 __global__ void __launch_bounds__(64)
 k_sorted_scan_top(double *__restrict__ t1, double *__restrict__ t2, int64_t nsb)
 {
-    if (threadIdx.x != 0) return;                   // a few hundred entries: one lane, in order
-    double r1 = 0.0, r2 = 0.0;
-    for (int64_t i = 0; i < nsb; ++i) {
+    // a few hundred entries, one wave: a lane owns a contiguous run, the runs' totals are scanned with shuffles
+    // (fixed association: deterministic); the grand totals go behind the last entry (prefix_at(n) at a block border)
+    const int lane = threadIdx.x;
+    const int64_t per = (nsb + 63) / 64, lo = lane * per, hi = lo + per < nsb ? lo + per : nsb;
+    double s1 = 0.0, s2 = 0.0;
+    for (int64_t i = lo; i < hi; ++i) {
+        s1 += t1[i];
+        s2 += t2[i];
+    }
+    double i1 = s1, i2 = s2;                                  // inclusive scan over the lanes
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double a1 = __shfl_up(i1, off, 64), a2 = __shfl_up(i2, off, 64);
+        if (lane >= off) {
+            i1 += a1;
+            i2 += a2;
+        }
+    }
+    const double u1 = __shfl_up(i1, 1, 64), u2 = __shfl_up(i2, 1, 64);   // (every lane takes part in the shuffle)
+    double r1 = lane ? u1 : 0.0, r2 = lane ? u2 : 0.0;          // exclusive prefix of this lane's run
+    const double tot1 = __shfl(i1, 63, 64), tot2 = __shfl(i2, 63, 64);
+    for (int64_t i = lo; i < hi; ++i) {
         const double v1 = t1[i], v2 = t2[i];
         t1[i] = r1;
         t2[i] = r2;
         r1 += v1;
         r2 += v2;
     }
-    t1[nsb] = r1;                                   // grand totals: prefix_at(n) when n is a multiple of 256 * 1024
-    t2[nsb] = r2;
+    if (lane == 0) {
+        t1[nsb] = tot1;
+        t2[nsb] = tot2;
+    }
 }
 
 __device__ __forceinline__ float next_up(float a) { return __uint_as_float(__float_as_uint(a) + 1u); }     // a >= 0, finite

@@ -80,6 +80,8 @@ def model_trace(tag, name, trace_csv, log, title, n_fwd=20):
 def short(k):   # (defined again below for the stats summaries; needed here first)
     if "at::native" in k or "at::cuda" in k:
         return None
+    if "rocprim" in k:
+        return "rocprim::radix_sort_onesweep" if "onesweep" in k else "rocprim::" + k.split("::")[-1][:40]
     return k.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0].replace(", ", ";")
 
 
@@ -96,6 +98,8 @@ os.makedirs("profiles", exist_ok=True)
 def short(k):
     if "at::native" in k or "at::cuda" in k:
         return None
+    if "rocprim" in k:
+        return "rocprim::radix_sort_onesweep" if "onesweep" in k else "rocprim::" + k.split("::")[-1][:40]
     return k.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0].replace(", ", ";")
 
 
