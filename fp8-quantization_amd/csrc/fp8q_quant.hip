@@ -929,8 +929,19 @@ struct MultiArgs {
 // ~6.5 us of a busy VALU), and at 3 chunks per block the kernel ends before the phases drift apart.  Requesting a
 // block's next chunk right before the current chunk's arithmetic (16 more VGPRs: 100) did not change that (20.4 vs
 // 20.1 us), nor did 950 / 1280 / 1425 / 2850 blocks (21.8 / 20.4 / 19.7 / 21.5 us).  One table phase for all of a
-// block's chunks would remove at most the ~1 us the tables cost.  Not pursued further: the launch replaces 21 launches
-// (130 us from Python), and the remaining 5 us are the arithmetic of a cache-resident stream.
+// block's chunks would remove at most the ~1 us the tables cost.  A fully software-pipelined variant was then written
+// and measured (k_multi_flat_pipe, removed again): arithmetic into registers first, the next chunk's data AND the
+// maxvals of its table rows requested before that arithmetic (unpredicated, fenced: the scheduler otherwise sinks the
+// requests below the stores), descriptor index made provably uniform (readfirstlane) and the ballot key hoisted so
+// that no vector load from the kernel-argument segment is left in the loop, one explicit s_waitcnt vmcnt(0) in front
+// of the stores -- i.e. NO wait in the loop ever covers a store (gfx950's single in-order vmcnt would otherwise drain a
+// chunk's stores before the next table phase; checked in the ISA) -- bit-exact, 117 VGPRs: 19.7 us by rocprofv3 against
+// 19.9.  Counters of the plain kernel (rocprofv3 --pmc, per launch): 4.76 M VALU wave-instructions (418 per wave and
+// chunk) = ~39 % of the VALU issue slots of a 19.9 us launch, 2.6 M SALU, LDS bank conflicts 1 % of LDS instructions,
+// waves waiting 61 % of their cycles.  Neither memory latency, store drains, the table phase nor occupancy (1...3
+// chunks per block measured equal) is THE limit; the launch is short enough (3 chunks per block) that its fixed phases
+// (launch ramp, table staging, first load round trip, last compute + store drain) make up the gap to the copy.
+// Not pursued further: the launch replaces 21 launches (130 us from Python).
 __global__ void __launch_bounds__(kBlock, 4)
 k_multi_flat(MultiArgs a)
 {
