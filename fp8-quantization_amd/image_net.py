@@ -99,11 +99,6 @@ def quant_params_dict(a):
     if not a.qmethod.startswith("fp_quantizer"):
         # the reference raises UnboundLocalError here (fp8_kwargs is only bound for fp_quantizer)
         raise SystemExit("validate-quantized supports --qmethod fp_quantizer only")
-    if a.fp8_learn_mantissa_bits:
-        # QAT-only (the reference trains mantissa_bits as an nn.Parameter, fp8_quantizer.py:105-110); this engine takes
-        # the mantissa width by value and has no gradient for it -- say so here, not deep inside learn_ranges()
-        raise SystemExit("--fp8-learn-mantissa-bits is a QAT feature outside this engine's path (PTQ validation): "
-                         "use --fp8-mse-include-mantissa-bits to SEARCH the mantissa width instead")
     w_opts, a_opts = {}, {}
     if a.num_candidates is not None:
         w_opts["num_candidates"] = a.num_candidates

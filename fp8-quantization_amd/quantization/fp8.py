@@ -45,14 +45,22 @@ class _FakeQuantSTE(torch.autograd.Function):
                  with bias = 2^E - log2(maxval) + const (the floor(log2|xc| + bias) part is detached) gives
                  ds/dmaxval = s / maxval, i.e. (y - xc) / maxval per element; reduced to maxval's shape.
 
-    The backward runs as a handful of torch ops (PTQ, the path this engine accelerates, never calls it).  Mantissa
-    bits are a by-value kernel argument: no gradient (FPQuantizer.learn_mantissa_bits raises)."""
+      d/dmbits   (learn_mantissa_bits: the width as an nn.Parameter, :105-110)  M = clamp(round_ste(mbits), 1, n_bits -
+                 sign_bits) enters through E = n_bits - sign_bits - M in the bias and through the scale exponent:
+                 s = 2^(p - M - bias(M)), bias'(M) = -ln2 2^E + 2^-M / (2 - 2^-M), so dy/dM = (y - xc) ln2 (-1 - bias'(M))
+                 per element, summed; round_ste passes the gradient, the clamp cuts it off outside [1, n_bits - sign_bits].
+
+    The backward runs as a handful of torch ops (PTQ, the path this engine accelerates, never calls it).  The kernel takes
+    the mantissa width by value (float(mbits): a host round trip per forward when the Parameter lives on the GPU -- QAT
+    territory, outside the accelerated path)."""
 
     @staticmethod
     def forward(ctx, x, maxval, mbits, n_bits, sign_bits):
-        y = _ops.quantize(x.detach(), maxval.detach(), mbits, n_bits, sign_bits)
+        mb_val = _host_float(mbits)
+        y = _ops.quantize(x.detach(), maxval.detach(), mb_val, n_bits, sign_bits)
         ctx.save_for_backward(x, maxval, y)
-        ctx.sign_bits = sign_bits
+        ctx.sign_bits, ctx.n_bits, ctx.mb_val = sign_bits, n_bits, mb_val
+        ctx.mbits_like = mbits if isinstance(mbits, torch.Tensor) else None
         return y
 
     @staticmethod
@@ -72,7 +80,19 @@ class _FakeQuantSTE(torch.autograd.Function):
             g = grad * w
             grad_mv = g.sum().reshape(maxval.shape) if maxval.numel() == 1 else \
                 g.reshape(maxval.numel(), -1).sum(1).reshape(maxval.shape)
-        return grad_x, grad_mv, None, None, None
+        grad_mb = None
+        if ctx.mbits_like is not None and ctx.needs_input_grad[2]:
+            hi = ctx.n_bits - ctx.sign_bits
+            r = float(np.float32(ctx.mb_val).round())          # torch.round: half to even, as np.round
+            if 1.0 <= r <= hi:
+                M = r
+                E = hi - M
+                dbias = -np.log(2.0) * 2.0 ** E + 2.0 ** -M / (2.0 - 2.0 ** -M)
+                xc = torch.min(torch.max(x, lo), mv)
+                grad_mb = ((grad * (y - xc)).sum() * (np.log(2.0) * (-1.0 - dbias))).reshape(ctx.mbits_like.shape).to(ctx.mbits_like.dtype)
+            else:
+                grad_mb = torch.zeros_like(ctx.mbits_like)
+        return grad_x, grad_mv, grad_mb, None, None
 
 
 def _host_float(t):
@@ -85,14 +105,16 @@ def _host_float(t):
 def quantize_to_fp8_ste_MM(x_float, n_bits, maxval, num_mantissa_bits, sign_bits):
     """Same call signature as fp8_quantizer.py:91-97.  maxval: tensor [1] or [C] on x's device.  num_mantissa_bits: a
     number / host tensor (passed to the kernel by value) or a 1-element tensor on x's GPU (read by the kernel)."""
+    mb_grad = isinstance(num_mantissa_bits, torch.Tensor) and num_mantissa_bits.requires_grad and torch.is_grad_enabled()
     on_device = (isinstance(num_mantissa_bits, torch.Tensor) and num_mantissa_bits.is_cuda and num_mantissa_bits.numel() == 1
-                 and x_float.dtype == torch.float32 and not (torch.is_grad_enabled() and x_float.requires_grad))
+                 and x_float.dtype == torch.float32 and not mb_grad
+                 and not (torch.is_grad_enabled() and x_float.requires_grad))
     mbits = num_mantissa_bits.detach().reshape(1).float() if on_device else _host_float(num_mantissa_bits)
     if not isinstance(maxval, torch.Tensor):
         maxval = torch.tensor([float(maxval)], dtype=torch.float32)
     maxval = maxval.to(device=x_float.device, dtype=torch.float32).reshape(-1)
-    if torch.is_grad_enabled() and (x_float.requires_grad or maxval.requires_grad):
-        return _FakeQuantSTE.apply(x_float, maxval, mbits, int(n_bits), int(sign_bits))
+    if torch.is_grad_enabled() and (x_float.requires_grad or maxval.requires_grad or mb_grad):
+        return _FakeQuantSTE.apply(x_float, maxval, num_mantissa_bits if mb_grad else mbits, int(n_bits), int(sign_bits))
     return _ops.quantize(x_float, maxval.detach(), mbits, int(n_bits), int(sign_bits))
 
 
@@ -162,10 +184,6 @@ class FPQuantizer(QuantizerBase):
                  learn_maxval=False, learn_mantissa_bits=False, mse_include_mantissa_bits=True,
                  allow_unsigned=False, **kwargs):
         super().__init__(*args, **kwargs)
-        if learn_mantissa_bits:
-            # fail at construction, not inside a later learn_ranges(): see learn_mantissa_bits()
-            raise NotImplementedError("learn_mantissa_bits=True: learnable mantissa bits are a QAT feature outside this "
-                                      "engine's path (the HIP quantizer takes the mantissa width by value)")
         m = mantissa_bits
         self.ebits = self.n_bits - m - 1
         self.default_bias = 2 ** (self.ebits - 1)
@@ -189,6 +207,9 @@ class FPQuantizer(QuantizerBase):
     # pending widths of a model over in one copy.
     @property
     def mantissa_bits(self):
+        p = self.__dict__["_parameters"].get("mantissa_bits") if "_parameters" in self.__dict__ else None
+        if p is not None:                       # learn_mantissa_bits(): the width is an nn.Parameter (:253-255)
+            return p
         host = self.__dict__.get("_mbits_host")
         if host is None:
             host = self.__dict__["_mbits_dev"].detach().reshape(1).float().cpu()     # synchronises
@@ -197,18 +218,32 @@ class FPQuantizer(QuantizerBase):
 
     @mantissa_bits.setter
     def mantissa_bits(self, value):
+        params = self.__dict__.get("_parameters")
+        if isinstance(value, nn.Parameter):
+            # (register_parameter would refuse: the class has an attribute of that name -- this property)
+            params["mantissa_bits"] = value
+            self.__dict__["_mbits_dev"], self.__dict__["_mbits_host"] = None, None
+            return
+        if params is not None and "mantissa_bits" in params:
+            del params["mantissa_bits"]
         if isinstance(value, torch.Tensor) and value.is_cuda:
             self.__dict__["_mbits_dev"], self.__dict__["_mbits_host"] = value, None
         else:
             self.__dict__["_mbits_dev"], self.__dict__["_mbits_host"] = None, value
 
     def _mantissa_bits_arg(self):
-        """what forward() passes to the kernel: the host value when it is known, else the pending device scalar"""
+        """what forward() passes to the kernel: the Parameter when the width is being learned, else the host value when
+        it is known, else the pending device scalar"""
+        p = self.__dict__["_parameters"].get("mantissa_bits")
+        if p is not None:
+            return p
         host = self.__dict__.get("_mbits_host")
         return host if host is not None else self.__dict__["_mbits_dev"]
 
     def _pending_mantissa_bits(self):
         """the device scalar not yet seen by the host, or None"""
+        if self.__dict__["_parameters"].get("mantissa_bits") is not None:
+            return None
         return self.__dict__.get("_mbits_dev") if self.__dict__.get("_mbits_host") is None else None
 
     def __setattr__(self, name, value):
@@ -270,11 +305,15 @@ class FPQuantizer(QuantizerBase):
         self.maxval = nn.Parameter(self.maxval)
 
     def learn_mantissa_bits(self):
-        # The reference makes mantissa_bits an nn.Parameter and lets autograd differentiate 2^E, log2(2 - 2^-M) and
-        # the scales with respect to it (fp8_quantizer.py:105-110).  Here the mantissa width is a by-value kernel
-        # argument: there is no gradient path, so say so instead of creating a Parameter that never trains.
-        raise NotImplementedError("learnable mantissa bits are a QAT feature outside this engine's path (PTQ): the HIP "
-                                  "quantizer takes the mantissa width by value and provides no gradient for it")
+        """:253-255: the mantissa width becomes an nn.Parameter; quantize_to_fp8_ste_MM's backward then yields
+        d/dmbits (see _FakeQuantSTE).  The forward still hands the kernel the width by value."""
+        self.learning_mantissa_bits = True
+        p = nn.Parameter(self.mantissa_bits.detach().clone().float())
+        # (not `self.mantissa_bits = p`: nn.Module.__setattr__ hands Parameters to register_parameter, which refuses a
+        # name the class already defines -- the `mantissa_bits` property)
+        self._parameters["mantissa_bits"] = p
+        self.__dict__["_mbits_dev"] = self.__dict__["_mbits_host"] = None
+        object.__setattr__(self, "_range_epoch", getattr(self, "_range_epoch", 0) + 1)
 
     def fix_ranges(self):
         for name in ("maxval", "mantissa_bits"):

@@ -621,13 +621,26 @@ def make_g10():
                 g = rng.randn(6, 50).astype(np.float32)
                 xt = torch.from_numpy(x.copy()).requires_grad_(True)
                 mt = torch.from_numpy(mv.copy()).requires_grad_(True)
-                y = quantize_to_fp8_ste_MM(xt, 8, mt, torch.Tensor([float(M)]), sb)
+                bt = torch.Tensor([float(M)]).requires_grad_(True)       # learn_mantissa_bits: the width as a Parameter (:105-110)
+                y = quantize_to_fp8_ste_MM(xt, 8, mt, bt, sb)
                 y.backward(torch.from_numpy(g))
                 out[f"c{cid}_x"], out[f"c{cid}_maxval"], out[f"c{cid}_g"] = x, mv, g
                 out[f"c{cid}_y"] = y.detach().numpy()
                 out[f"c{cid}_gx"], out[f"c{cid}_gmaxval"] = xt.grad.numpy(), mt.grad.numpy()
+                out[f"c{cid}_gmbits"] = bt.grad.numpy()
                 cases.append((cid, M, sb, int(per_channel)))
                 cid += 1
+    # non-integer and out-of-range widths: round_ste passes the gradient, clamp(1, n_bits - sign_bits) cuts it off outside
+    mb_cases = []
+    x = (rng.randn(4, 40) * 0.8).astype(np.float32)
+    g = rng.randn(4, 40).astype(np.float32)
+    for k, mb in enumerate((2.4, 3.5, 0.2, 0.6, 7.0, 7.4, 9.0)):
+        bt = torch.Tensor([mb]).requires_grad_(True)
+        y = quantize_to_fp8_ste_MM(torch.from_numpy(x.copy()), 8, torch.Tensor([1.3]), bt, 1)
+        y.backward(torch.from_numpy(g))
+        mb_cases.append((mb, float(bt.grad[0])))
+        out[f"mb{k}_y"] = y.detach().numpy()
+    out["mb_x"], out["mb_g"], out["mb_cases"] = x, g, np.array(mb_cases, dtype=np.float64)
     out["cases"] = np.array(cases, dtype=np.int64)
     np.savez_compressed(os.path.join(OUT, "g10_autograd.npz"), **out)
     print("g10:", cid, "cases")
