@@ -89,7 +89,7 @@ class _FakeQuantSTE(torch.autograd.Function):
                 E = hi - M
                 dbias = -np.log(2.0) * 2.0 ** E + 2.0 ** -M / (2.0 - 2.0 ** -M)
                 xc = torch.min(torch.max(x, lo), mv)
-                grad_mb = ((grad * (y - xc)).sum() * (np.log(2.0) * (-1.0 - dbias))).reshape(ctx.mbits_like.shape).to(ctx.mbits_like.dtype)
+                grad_mb = ((grad * (y - xc)).sum() * (np.log(2.0) * (-1.0 - dbias))).reshape(ctx.mbits_like.shape).to(device=ctx.mbits_like.device, dtype=ctx.mbits_like.dtype)
             else:
                 grad_mb = torch.zeros_like(ctx.mbits_like)
         return grad_x, grad_mv, grad_mb, None, None
