@@ -1,7 +1,7 @@
 """A/B timing of two builds of libfp8q_hip.so in ONE process on one GPU box (boxes of the pool differ by a few percent,
 so an old-vs-new comparison has to alternate the two libraries on the same box).
 
-    python tools/ab.py <set> [path/to/other/libfp8q_hip.so]        sets: epi  multi  mse  enc  k1
+    python tools/ab.py <set> [path/to/other/libfp8q_hip.so]        sets: epi  multi  mse  enc  k1  f64
 
 Without a second library only the current build is timed.  Times are the median of back-to-back launches by HIP events
 (small kernels: includes the launch gap, like the model's forward does)."""
@@ -120,6 +120,19 @@ def cases_enc():
         codes = torch.empty(shape, dtype=torch.uint8, device=dev)
         out.append((f"encode {list(shape)} {'per channel' if pc else 'per tensor'}", x.numel() * 5, lambda x=x, mv=mv, codes=codes: ops.encode(x, mv, 3, 8, 1, out=codes)))
     return out
+
+
+def cases_f64():
+    """the float64 lane: K1 at 16 B/element, row min/max at 8, the 1000-candidate line search of config 1 (5 M samples)"""
+    x = torch.randn(1 << 26, dtype=torch.float64, device=dev)          # 512 MiB
+    y = torch.empty_like(x)
+    mv = torch.tensor([2.7361], device=dev)
+    xs = torch.randn(5_000_000, dtype=torch.float64, device=dev)
+    thr = (torch.arange(1, 1001, device=dev, dtype=torch.float32) * 0.0105).view(1000, 1).contiguous()
+    sse = torch.zeros(1, 1000, 1, dtype=torch.float64, device=dev)
+    return [("K1 f64 [2^26] E4M3 per tensor", x.numel() * 16, lambda: ops.quantize(x, mv, 3, 8, 1, out=y)),
+            ("min/max f64 [2^26]", x.numel() * 8, lambda: ops.minmax_f64(x, False)),
+            ("K4 f64 5M samples x 1000 candidates (E4M3)", xs.numel() * 1000, lambda: ops.mse_grid_f64(xs, False, thr, [3.0], 8, 1, sse, reduce="sum"))]
 
 
 def cases_k1():
