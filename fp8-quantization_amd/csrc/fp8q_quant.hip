@@ -5,7 +5,7 @@
 // Every kernel here is elementwise or a reduction: the roofline is HBM bandwidth, not MFMA.
 // Common shape: 256-thread blocks (4 waves, one per SIMD), 16 B per lane per memory instruction
 // (1 KiB per wave-instruction), 4 independent loads in flight per lane, and -- what HBM turned out to
-// care about most (tools/pattern_sweep.hip) -- every block moves ALIGNED 16 KiB pieces, neighbouring
+// care about most (a copy-kernel sweep: docs/HISTORY.md) -- every block moves ALIGNED 16 KiB pieces, neighbouring
 // blocks neighbouring pieces, one piece (or one short tile) per block rather than a persistent grid.
 //
 // Kernels of this file:
@@ -301,7 +301,7 @@ k_rows_direct(const float *__restrict__ x, float *__restrict__ y, int64_t C,
 // ---------------------------------------------------------------------------------------------
 // Short rows, flat: k_rows_flat (MODE 0 = K1, MODE 1 = fused K2+K5+K1), x and y 16-byte aligned.
 // HBM wants what a plain grid-stride copy does: every block moves one ALIGNED 16 KiB chunk per step
-// and concurrently running blocks touch neighbouring chunks (tools/pattern_sweep.hip: 6.3-6.4 TB/s;
+// and concurrently running blocks touch neighbouring chunks (copy-kernel sweep, docs/HISTORY.md: 6.3-6.4 TB/s;
 // a block that owns 128 contiguous KiB, or row-aligned chunks of 16 464 B: 5.2-5.7).  So the tensor
 // is cut by ADDRESS, not by rows: chunk c = elements [4096 c, 4096 (c+1)); a tile = nch chunks
 // (t*nch + i) * gridDim + blockIdx, i < nch; rows are whatever overlaps a chunk (a row cut by a chunk

@@ -57,7 +57,7 @@ def test_roundtrip_on_non_geometric_scale_tables():
     """Where the reference's fp32 (p - M) - bias rounds differently in neighbouring binades (small |bias|, e.g.
     E3M4 with maxval 207), s_(p+1) != 2 s_p in the last bit.  K1 renders an element that rounds UP into the next
     binade as 2^(M+1) s_p, the decoder (like the reference's enumerator: one value per code) as 2^M s_(p+1): the same
-    grid point, a few fp32 ULP apart (ulp(k - bias) ln 2 relative); everything else round-trips bit for bit.  Found by tools/soak.py."""
+    grid point, a few fp32 ULP apart (ulp(k - bias) ln 2 relative); everything else round-trips bit for bit.  Found by a random-geometry soak (round 2; git history)."""
     rng = np.random.RandomState(3)
     worst = 0
     for M, mv, sb in ((4, 207.11018, 1), (5, 7.1219254, 1), (6, 12.418949, 0), (4, 305.43573, 1)):

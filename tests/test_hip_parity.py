@@ -520,7 +520,7 @@ def test_fused_rows_in_registers(ops, C, inner, M):
 def test_minmax_with_an_empty_split(ops, C, inner):
     """Rows a few elements longer than a whole number of 8192-element steps leave the last split of the
     two-stage min/max without any aligned group: its partial is {+inf, -inf} and must not leak into the result
-    (found by tools/soak.py: all-positive rows came back with max = +inf)."""
+    (found by a round-2 random-geometry soak: all-positive rows came back with max = +inf)."""
     rng = np.random.RandomState(C + inner)
     for x in (np.abs(rng.randn(C, inner)).astype(np.float32) + 0.5, -np.abs(rng.randn(C, inner)).astype(np.float32) - 0.5,
               rng.randn(C, inner).astype(np.float32)):
