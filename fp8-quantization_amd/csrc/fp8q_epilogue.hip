@@ -44,6 +44,16 @@ k_bn_fold(const float *__restrict__ mean, const float *__restrict__ invstd, cons
     if (c < C) ab[c] = bn_ab(mean, invstd, gamma, beta, (uint32_t)c, 1);
 }
 
+// {channel constants, table} of one per-tensor quantizer, laid out as k_affine_act_small copies them: float4 {maxval, lo,
+// bias, pthr} followed by float2 {s_p, 1 / s_p}, p = 0 .. pmax
+__global__ void __launch_bounds__(kBlock)
+k_quantizer_prepare(const float *__restrict__ maxval, QFmt f, float4 *__restrict__ prep)
+{
+    const Chan cfull = make_chan(maxval[0], f);
+    if (threadIdx.x == 0) prep[0] = make_float4(cfull.maxv, cfull.minv, cfull.bias, cfull.pthr);
+    for (int i = threadIdx.x; i <= f.pmax; i += kBlock) reinterpret_cast<float2 *>(prep + 1)[i] = lut_entry(cfull, i, f.M);
+}
+
 // act(t + r) -- the non-affine part of the epilogue
 __device__ __forceinline__ float res_act(float t, float r, const AffineArgs &a)
 {
@@ -196,7 +206,8 @@ template <bool EARLY, bool NT, int U>
 __global__ void __launch_bounds__(kBlock)
 k_affine_act_small(const float *__restrict__ x, const float *__restrict__ res, float *__restrict__ y,
                    const float *__restrict__ mean, const float *__restrict__ invstd, const float *__restrict__ gamma,
-                   const float *__restrict__ beta, const float *__restrict__ maxval, QFmt f, AffineArgs a)
+                   const float *__restrict__ beta, const float *__restrict__ maxval, QFmt f, AffineArgs a,
+                   const float4 *__restrict__ prep)
 {
     __shared__ float2 lut[kLutMax];
     const int tid = threadIdx.x;
@@ -239,9 +250,22 @@ k_affine_act_small(const float *__restrict__ x, const float *__restrict__ res, f
         for (int u = 0; u < U; ++u)
             if (base + u * kBlock + tid < nvec) fetch(base + u * kBlock + tid, g[u]);
     }
-    const Chan cfull = make_chan(maxval[0], f);
-    for (int i = tid; i <= f.pmax; i += kBlock) lut[i] = lut_entry(cfull, i, f.M);
-    const ChanLite c = lite(cfull);
+    // The quantizer's channel constants and {s, 1/s} table: rebuilt from maxval (a load, ~50 dependent double-precision
+    // operations, the table entries) -- or, with fixed ranges, copied from the block fp8q_quantizer_prepare_f32 wrote once:
+    // the same numbers, one 8-byte load per entry, 0.5-1 us less on the critical path of a 4-10 us launch.
+    ChanLite c;
+    if (prep) {
+        const float4 h = prep[0];
+        c.maxv = h.x;
+        c.minv = h.y;
+        c.bias = h.z;
+        c.pthr = h.w;
+        for (int i = tid; i <= f.pmax; i += kBlock) lut[i] = reinterpret_cast<const float2 *>(prep + 1)[i];
+    } else {
+        const Chan cfull = make_chan(maxval[0], f);
+        for (int i = tid; i <= f.pmax; i += kBlock) lut[i] = lut_entry(cfull, i, f.M);
+        c = lite(cfull);
+    }
     const float pmaxf = (float)f.pmax;
     __syncthreads();
     bool first = true;
@@ -410,7 +434,8 @@ int fp8q_bn_fold_f32(const float *mean, const float *invstd, const float *gamma,
 
 static int affine_quantize_impl(const float *x, const float *residual, float *y, int64_t N, int64_t C, int64_t HW,
                                 const float *mean, const float *invstd, const float *gamma, const float *beta, int has_bn,
-                                int act, const float *maxval, float mbits, int n_bits, int sign_bits, fp8q_stream_t stream);
+                                int act, const float *maxval, const float *prep, float mbits, int n_bits, int sign_bits,
+                                fp8q_stream_t stream);
 
 int fp8q_affine_act_quantize_f32(const float *x, const float *residual, float *y, int64_t N, int64_t C,
                                  int64_t HW, const float *mean, const float *invstd, const float *gamma,
@@ -419,22 +444,32 @@ int fp8q_affine_act_quantize_f32(const float *x, const float *residual, float *y
 {
     const int has_bn = mean != nullptr;
     if (has_bn && (!invstd || !gamma || !beta)) return FP8Q_EINVAL;
-    return affine_quantize_impl(x, residual, y, N, C, HW, mean, invstd, gamma, beta, has_bn, act, maxval, mbits, n_bits,
+    return affine_quantize_impl(x, residual, y, N, C, HW, mean, invstd, gamma, beta, has_bn, act, maxval, nullptr, mbits, n_bits,
                                 sign_bits, stream);
 }
 
-int fp8q_affine_act_quantize_ab_f32(const float *x, const float *residual, float *y, int64_t N, int64_t C, int64_t HW,
-                                    const float *alpha_beta, int act, const float *maxval, float mbits, int n_bits,
-                                    int sign_bits, fp8q_stream_t stream)
+int fp8q_quantizer_prepare_f32(const float *maxval, float mbits, int n_bits, int sign_bits, float *prep, fp8q_stream_t stream)
 {
-    if (!alpha_beta || ((uintptr_t)alpha_beta & 7)) return FP8Q_EINVAL;
-    return affine_quantize_impl(x, residual, y, N, C, HW, alpha_beta, nullptr, nullptr, nullptr, 2, act, maxval, mbits,
-                                n_bits, sign_bits, stream);
+    if (!maxval || !prep || ((uintptr_t)prep & 15)) return FP8Q_EINVAL;
+    QFmt f;
+    if (int rc = make_fmt(mbits, n_bits, sign_bits, &f)) return rc;
+    hipLaunchKernelGGL(k_quantizer_prepare, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, maxval, f, reinterpret_cast<float4 *>(prep));
+    return launch_rc();
+}
+
+int fp8q_affine_act_quantize_ab_f32(const float *x, const float *residual, float *y, int64_t N, int64_t C, int64_t HW,
+                                    const float *alpha_beta, int act, const float *maxval, const float *prep, float mbits,
+                                    int n_bits, int sign_bits, fp8q_stream_t stream)
+{
+    if (((uintptr_t)alpha_beta & 7) || ((uintptr_t)prep & 15)) return FP8Q_EINVAL;
+    return affine_quantize_impl(x, residual, y, N, C, HW, alpha_beta, nullptr, nullptr, nullptr, alpha_beta ? 2 : 0, act, maxval,
+                                prep, mbits, n_bits, sign_bits, stream);
 }
 
 static int affine_quantize_impl(const float *x, const float *residual, float *y, int64_t N, int64_t C, int64_t HW,
                                 const float *mean, const float *invstd, const float *gamma, const float *beta, int has_bn,
-                                int act, const float *maxval, float mbits, int n_bits, int sign_bits, fp8q_stream_t stream)
+                                int act, const float *maxval, const float *prep, float mbits, int n_bits, int sign_bits,
+                                fp8q_stream_t stream)
 {
     AffineArgs a;
     if (int rc = affine_args(N, C, HW, act, has_bn, residual != nullptr, &a)) return rc;
@@ -462,10 +497,10 @@ static int affine_quantize_impl(const float *x, const float *residual, float *y,
         else if (small && (a.HW >= 4 || !has_bn) && small_kind() != 0) {
             if (small_kind() == 2)
                 hipLaunchKernelGGL((k_affine_act_small<true, false, 1>), g, b, 0, (hipStream_t)stream, x + n0 * a.image, rp, y + n0 * a.image,
-                                   mean, invstd, gamma, beta, maxval, f, a);
+                                   mean, invstd, gamma, beta, maxval, f, a, reinterpret_cast<const float4 *>(prep));
             else
                 hipLaunchKernelGGL((k_affine_act_small<false, false, 1>), g, b, 0, (hipStream_t)stream, x + n0 * a.image, rp, y + n0 * a.image,
-                                   mean, invstd, gamma, beta, maxval, f, a);
+                                   mean, invstd, gamma, beta, maxval, f, a, reinterpret_cast<const float4 *>(prep));
         } else if (small)
             hipLaunchKernelGGL((k_affine_act<false, 1>), g, b, shm, (hipStream_t)stream, x + n0 * a.image, rp, y + n0 * a.image,
                                mean, invstd, gamma, beta, maxval, f, a);

@@ -50,7 +50,8 @@ SIGNATURES = {
     "fp8q_affine_act_quantize_f32": (_i, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i, _vp, _f, _i, _i,
                                           _vp]),
     "fp8q_bn_fold_f32": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _vp]),
-    "fp8q_affine_act_quantize_ab_f32": (_i, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _i, _vp, _f, _i, _i, _vp]),
+    "fp8q_quantizer_prepare_f32": (_i, [_vp, _f, _i, _i, _vp, _vp]),
+    "fp8q_affine_act_quantize_ab_f32": (_i, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _i, _vp, _vp, _f, _i, _i, _vp]),
     "fp8q_affine_act_minmax_workspace_bytes": (ctypes.c_size_t, [_i64, _i64, _i64]),
     "fp8q_affine_act_minmax_f32": (_i, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i,
                                         ctypes.c_double, _i, _vp, ctypes.c_size_t, _vp]),

@@ -591,9 +591,28 @@ def bn_fold(bn):
     return ab
 
 
-def affine_act_quantize(x, maxval, mbits, n_bits=8, sign_bits=1, bn=None, residual=None, act=0, out=None, bn_ab=None):
+PREP_FLOATS = 264      # FP8Q_PREP_BYTES / 4
+
+
+def quantizer_prepare(maxval, mbits, n_bits=8, sign_bits=1):
+    """[264] fp32 block of a FIXED-range per-tensor quantizer: its channel constants and {s, 1/s} table, as the fused
+    epilogue rebuilds them from maxval on every launch (fp8q_quantizer_prepare_f32).  Pass as affine_act_quantize(prep=)."""
+    _require(maxval, "maxval")
+    if maxval.numel() != 1:
+        raise Fp8qError("quantizer_prepare: per-tensor quantizers only (one maxval)")
+    prep = torch.empty(PREP_FLOATS, dtype=torch.float32, device=maxval.device)
+    with _on_device(maxval):
+        rc = lib().fp8q_quantizer_prepare_f32(maxval.contiguous().data_ptr(), float(mbits), int(n_bits), int(sign_bits),
+                                              prep.data_ptr(), _stream(maxval))
+    check(rc, "fp8q_quantizer_prepare_f32")
+    return prep
+
+
+def affine_act_quantize(x, maxval, mbits, n_bits=8, sign_bits=1, bn=None, residual=None, act=0, out=None, bn_ab=None,
+                        prep=None):
     """N2: quantize(act(bn(x) + residual)) in one pass.  bn = (mean, invstd, gamma, beta), each [C] -- or bn_ab = the
-    folded [C, 2] vector of bn_fold(bn) (same result, fewer loads); act: 0 none, 1 ReLU, 2 ReLU6; per-tensor maxval [1]."""
+    folded [C, 2] vector of bn_fold(bn) (same result, fewer loads); act: 0 none, 1 ReLU, 2 ReLU6; per-tensor maxval [1];
+    prep = quantizer_prepare(maxval, mbits, n_bits, sign_bits) of the SAME quantizer (fixed ranges: the table is not rebuilt)."""
     _require(x, "x")
     _require(maxval, "maxval", like=x)
     x = x.contiguous()
@@ -606,15 +625,20 @@ def affine_act_quantize(x, maxval, mbits, n_bits=8, sign_bits=1, bn=None, residu
     if maxval.numel() != 1:
         raise Fp8qError("the fused epilogue quantizes per tensor: maxval must have one element")
     y = _out(out, x)
-    if bn_ab is not None:
-        _require(bn_ab, "bn_ab", like=x)
-        if bn_ab.numel() != 2 * C or not bn_ab.is_contiguous():
-            raise Fp8qError("bn_ab must be a contiguous [C, 2] tensor (fp8q.ops.bn_fold)")
+    if prep is not None:
+        _require(prep, "prep", like=x)
+        if prep.numel() != PREP_FLOATS or not prep.is_contiguous() or prep.data_ptr() % 16:
+            raise Fp8qError("prep must be the [264] fp32 block of fp8q.ops.quantizer_prepare")
+    if bn_ab is not None or (prep is not None and bn is None):
+        if bn_ab is not None:
+            _require(bn_ab, "bn_ab", like=x)
+            if bn_ab.numel() != 2 * C or not bn_ab.is_contiguous():
+                raise Fp8qError("bn_ab must be a contiguous [C, 2] tensor (fp8q.ops.bn_fold)")
         with _on_device(x):
             rc = lib().fp8q_affine_act_quantize_ab_f32(
                 x.data_ptr(), residual.data_ptr() if residual is not None else None, y.data_ptr(), N, C, HW,
-                bn_ab.data_ptr(), int(act), maxval.contiguous().data_ptr(), float(mbits), int(n_bits), int(sign_bits),
-                _stream(x))
+                bn_ab.data_ptr() if bn_ab is not None else None, int(act), maxval.contiguous().data_ptr(),
+                prep.data_ptr() if prep is not None else None, float(mbits), int(n_bits), int(sign_bits), _stream(x))
         check(rc, "fp8q_affine_act_quantize_ab_f32")
         return y
     ptrs, keep = _bn_ptrs(bn, C, x.device)

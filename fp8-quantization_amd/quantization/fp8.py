@@ -290,6 +290,20 @@ class FPQuantizer(QuantizerBase):
         mv = torch.abs(torch.max(torch.abs(x_min), x_max)).detach().to(torch.float32)
         self.maxval = mv.reshape(1) if mv.dim() == 0 else mv
 
+    def _prepared(self):
+        """The [264] fp32 block of fp8q.ops.quantizer_prepare for this (per-tensor, fixed-range) quantizer, or None.
+        Cached until the range changes: every assignment of maxval / mantissa_bits / sign_bits bumps `_range_epoch`, an
+        in-place edit of the maxval tensor bumps its version."""
+        mv = self.maxval
+        if not (isinstance(mv, torch.Tensor) and mv.is_cuda and mv.numel() == 1) or isinstance(mv, nn.Parameter) \
+                or self._pending_mantissa_bits() is not None or isinstance(self.mantissa_bits, nn.Parameter):
+            return None
+        key = (getattr(self, "_range_epoch", None), mv.data_ptr(), mv._version, self.n_bits)
+        if self.__dict__.get("_prep_key") != key:
+            self.__dict__["_prep"] = _ops.quantizer_prepare(mv, float(self.mantissa_bits), self.n_bits, self.sign_bits)
+            self.__dict__["_prep_key"] = key
+        return self.__dict__["_prep"]
+
     def _set_maxval_tensor(self, mv):
         """engine fast path: maxval already computed on the device by the range kernel."""
         self.maxval = mv

@@ -165,8 +165,10 @@ class QuantizationManager(nn.Module):
                 q._set_maxval_tensor(est.last_maxval)
         if q.maxval.device != x.device:
             q.maxval = q.maxval.to(x.device)
+        # fixed ranges: the quantizer's constants and table are prepared once (small activations are latency-bound)
+        prep = q._prepared() if not self._estimating() and hasattr(_ops, "quantizer_prepare") else None
         return _ops.affine_act_quantize(x, q.maxval, float(q.mantissa_bits), q.n_bits, q.sign_bits, bn=bn,
-                                        residual=residual, act=act, bn_ab=bn_ab if bn is not None else None)
+                                        residual=residual, act=act, bn_ab=bn_ab if bn is not None else None, prep=prep)
 
     def extra_repr(self):
         return f"state={self.state.name}"

@@ -239,9 +239,19 @@ int fp8q_affine_act_quantize_f32(const float *x, const float *residual, float *y
  */
 int fp8q_bn_fold_f32(const float *mean, const float *invstd, const float *gamma, const float *beta, int64_t C,
                      float *alpha_beta, fp8q_stream_t stream);
+/*
+ * A per-tensor quantizer whose range is FIXED can also be prepared once: fp8q_quantizer_prepare_f32 writes the channel
+ * constants and the {s, 1/s} table every launch otherwise rebuilds from maxval (FP8Q_PREP_BYTES bytes, 16-byte aligned,
+ * device memory).  Passed as `prep` (NULL = rebuild), it takes 0.5-1 us off the critical path of launches on cache-sized
+ * activations (4-10 us each: most of a ResNet-18 / MobileNetV2 forward's quantizer launches).  `prep` must have been
+ * prepared from the same maxval VALUE, mbits, n_bits and sign_bits as the call it is passed to; results are bit-identical.
+ * alpha_beta may be NULL in the _ab entry point (no batch norm: the residual tails).
+ */
+#define FP8Q_PREP_BYTES 1056 /* float4 {maxval, lo, bias, threshold} + 130 x float2 {s_p, 1 / s_p} */
+int fp8q_quantizer_prepare_f32(const float *maxval, float mbits, int n_bits, int sign_bits, float *prep, fp8q_stream_t stream);
 int fp8q_affine_act_quantize_ab_f32(const float *x, const float *residual, float *y, int64_t N, int64_t C, int64_t HW,
-                                    const float *alpha_beta, int act, const float *maxval, float mbits, int n_bits,
-                                    int sign_bits, fp8q_stream_t stream);
+                                    const float *alpha_beta, int act, const float *maxval, const float *prep, float mbits,
+                                    int n_bits, int sign_bits, fp8q_stream_t stream);
 size_t fp8q_affine_act_minmax_workspace_bytes(int64_t N, int64_t C, int64_t HW);
 int fp8q_affine_act_minmax_f32(const float *x, const float *residual, int64_t N, int64_t C, int64_t HW,
                                const float *mean, const float *invstd, const float *gamma, const float *beta,

@@ -362,12 +362,21 @@ int main()
         CK(fp8q_bn_fold_f32(dbn, dbn + 100, dbn + 200, dbn + 300, Cc, dab, st));
         const float one_mv = 0.2f;
         CK(hipMemcpy(dmvo, &one_mv, 4, hipMemcpyHostToDevice));
-        CK(fp8q_affine_act_quantize_ab_f32(dx, nullptr, dy, N, Cc, HW, dab, 1, dmvo, 3.0f, 8, 1, st));
+        CK(fp8q_affine_act_quantize_ab_f32(dx, nullptr, dy, N, Cc, HW, dab, 1, dmvo, nullptr, 3.0f, 8, 1, st));
         CK(hipStreamSynchronize(st));
         CK(hipMemcpy(y, dy, n * 4, hipMemcpyDeviceToHost));
         orc_affine_act_f32(x, nullptr, t, N, Cc, HW, bnv[0], bnv[1], bnv[2], bnv[3], 1);
         orc_quantize_f32(t, ref, 1, n, &one_mv, 1, 3.0f, 8, 1);
         ok &= same_bits(y, ref, n, "fp8q_bn_fold_f32 + fp8q_affine_act_quantize_ab_f32 (BN + ReLU + E4M3)");
+        // the same launch with the quantizer's constants and table prepared once (fixed ranges)
+        float *dprep;
+        CK(hipMalloc((void **)&dprep, FP8Q_PREP_BYTES));
+        CK(fp8q_quantizer_prepare_f32(dmvo, 3.0f, 8, 1, dprep, st));
+        CK(hipMemset(dy, 0, n * 4));
+        CK(fp8q_affine_act_quantize_ab_f32(dx, nullptr, dy, N, Cc, HW, dab, 1, dmvo, dprep, 3.0f, 8, 1, st));
+        CK(hipStreamSynchronize(st));
+        CK(hipMemcpy(y, dy, n * 4, hipMemcpyDeviceToHost));
+        ok &= same_bits(y, ref, n, "fp8q_quantizer_prepare_f32 + fp8q_affine_act_quantize_ab_f32 (prepared table)");
     }
     // error behaviour: bad arguments are reported, nothing throws
     if (fp8q_quantize_f32(dx, dy, C, inner, dmv, C - 1, 2.0f, 8, 1, st) != FP8Q_EINVAL) { printf("FAIL: EINVAL expected\n"); ok = 0; }

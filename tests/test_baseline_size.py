@@ -428,8 +428,10 @@ class OracleInTheLoop:
         return y
 
     @classmethod
-    def affine_act_quantize(cls, x, maxval, mbits, n_bits=8, sign_bits=1, bn=None, residual=None, act=0, out=None, bn_ab=None):
-        # (bn_ab: the folded [C, 2] vector the layers also hand over -- the oracle forms alpha / beta' from `bn` itself)
+    def affine_act_quantize(cls, x, maxval, mbits, n_bits=8, sign_bits=1, bn=None, residual=None, act=0, out=None, bn_ab=None,
+                            prep=None):
+        # (bn_ab / prep: the folded BN vector and the prepared quantizer table the layers also hand over -- the oracle
+        # forms alpha / beta' from `bn` and the table from `maxval` itself)
         t = oracle.c_affine_act(_np(x), tuple(_np(b) for b in bn) if bn is not None else None,
                                 _np(residual) if residual is not None else None, act)
         return cls._dev(oracle.c_quantize(t, _np(maxval).reshape(-1), mbits, n_bits, sign_bits), x)

@@ -73,6 +73,12 @@ def test_fused_epilogue_bit_exact(shape, use_bn, use_res, act):
         y2 = ops.affine_act_quantize(xd, dev(mv), 3, 8, 1, bn=bnd, bn_ab=ab, residual=dev(res) if use_res else None,
                                      act=act).cpu().numpy()
         assert np.array_equal(np.isnan(y2), np.isnan(y)) and np.array_equal(y2[ok].view(np.int32), y[ok].view(np.int32))
+    # the quantizer's constants and table prepared once (fp8q_quantizer_prepare_f32): the same bits, with and without BN
+    prep = ops.quantizer_prepare(dev(mv), 3, 8, 1)
+    y3 = ops.affine_act_quantize(xd, dev(mv), 3, 8, 1, bn=tuple(dev(b) for b in bn) if bn else None,
+                                 bn_ab=ops.bn_fold(tuple(dev(b) for b in bn)) if bn else None,
+                                 residual=dev(res) if use_res else None, act=act, prep=prep).cpu().numpy()
+    assert np.array_equal(np.isnan(y3), np.isnan(y)) and np.array_equal(y3[ok].view(np.int32), y[ok].view(np.int32))
     # range of the same pre-quantization tensor, folded like allminmax
     t2 = t.copy()
     t2.reshape(-1)[:2] = 0            # drop the NaN / inf probes for the range check
