@@ -7,13 +7,17 @@
 // k = |x| fall into <= (2^E + 1) 2^M + 2 cells, each mapped to one grid value q, and
 //     sum over a cell of (k - q)^2 = S2 - 2 q S1 + n q^2     with n, S1 = sum k, S2 = sum k^2 of the cell's keys.
 // So: (1) sort the keys once (radix sort of the 31 magnitude bits: non-negative floats order like their bit patterns),
-// (2) prefix sums of k and k^2 in double at 256-key granularity, (3) per candidate one workgroup: a lane per cell finds
+// (2) prefix sums of k and k^2 in DOUBLE-DOUBLE (~106 bits) at 256-key granularity, (3) per candidate one workgroup: a lane per cell finds
 // the cell's two borders EXACTLY -- the smallest float for which the reference's own fp32 decisions
 // (floor(fl32(log2 k) + bias) >= p, rint(fl32(k / s_p)) >= r, k > maxval) flip, located by guess-and-walk on the exact
 // predicates -- turns them into positions by binary search, and reads n / S1 / S2 off the prefix sums (+ a partial block).
 // Every element is classified as K1 / the oracle classify it; what differs from the reference is only that (k - q)^2 is
-// summed in exact arithmetic (double) instead of fp32-rounded per element: ~1e-7 relative, inside K4's stated contract
-// (include/fp8q.h: table entries to 1e-5, the chosen candidate per SURVEY 8c).
+// summed in (near-)exact arithmetic instead of fp32-rounded per element: ~1e-7 relative, inside K4's stated contract
+// (include/fp8q.h: table entries to 1e-5, the chosen candidate per SURVEY 8c).  Why double-double: the three terms cancel.
+// On data that sit (almost) on the grid -- already-quantized tensors, a handful of distinct magnitudes -- the squared
+// error is 1e-13 of the signal energy S2 and plain double prefix sums (relative 1e-16 OF S2) left 3e-5 relative error in
+// the table entry (found by tools/soak.py: 28 distinct magnitudes, E6M1); with ~2^-104 of S2 the entry is good down to an
+// error / energy ratio of ~1e-26, below which the oracle's own fp32 squares underflow.
 // Cost: the sort (~0.5 ms for 25.7 M keys) + ~0.1 ms per 666 candidates; used when n_m * n_cand >= 256 on a per-tensor
 // row of >= 2^20 elements of a signed format (fp8q_mse_grid_f32 routes; FP8Q_MSE_SORTED=0 disables).
 // The radix sort is rocPRIM's (header-only, part of ROCm): the one non-streaming primitive of the library.
@@ -40,27 +44,80 @@ struct SortedArgs {
     int64_t nb;                  // prefix blocks = ceil(n / 256)
 };
 
-// block sums of k and k^2 (double): one wave per 256-key block
+// double-double: value = hi + lo, |lo| <= ulp(hi) / 2.  Error-free transformations only (no fast-math in this build).
+struct DD {
+    double hi, lo;
+};
+
+__device__ __forceinline__ DD two_sum(double a, double b)
+{
+    const double s = a + b, bb = s - a;
+    return DD{s, (a - (s - bb)) + (b - bb)};
+}
+
+__device__ __forceinline__ DD fast_two_sum(double a, double b)   // |a| >= |b| (or a == 0)
+{
+    const double s = a + b;
+    return DD{s, b - (s - a)};
+}
+
+__device__ __forceinline__ DD dd_add(DD x, DD y)                  // accurate variant: safe when the high parts cancel
+{
+    DD s = two_sum(x.hi, y.hi);
+    const DD t = two_sum(x.lo, y.lo);
+    s.lo += t.hi;
+    s = fast_two_sum(s.hi, s.lo);
+    s.lo += t.lo;
+    return fast_two_sum(s.hi, s.lo);
+}
+
+__device__ __forceinline__ DD dd_add_d(DD x, double y)
+{
+    DD s = two_sum(x.hi, y);
+    s.lo += x.lo;
+    return fast_two_sum(s.hi, s.lo);
+}
+
+__device__ __forceinline__ DD dd_neg(DD x) { return DD{-x.hi, -x.lo}; }
+
+__device__ __forceinline__ DD two_prod(double a, double b)
+{
+    const double p = a * b;
+    return DD{p, fma(a, b, -p)};
+}
+
+__device__ __forceinline__ DD dd_mul_d(DD x, double y)
+{
+    DD p = two_prod(x.hi, y);
+    p.lo = fma(x.lo, y, p.lo);
+    return fast_two_sum(p.hi, p.lo);
+}
+
+__device__ __forceinline__ DD dd_shfl_xor(DD v, int off) { return DD{__shfl_xor(v.hi, off, 64), __shfl_xor(v.lo, off, 64)}; }
+__device__ __forceinline__ DD dd_shfl_up(DD v, int off) { return DD{__shfl_up(v.hi, off, 64), __shfl_up(v.lo, off, 64)}; }
+__device__ __forceinline__ DD dd_shfl(DD v, int lane) { return DD{__shfl(v.hi, lane, 64), __shfl(v.lo, lane, 64)}; }
+
+// block sums of k and k^2: one wave per 256-key block.  k^2 of an fp32 key is exact in double (48 bits).
 __global__ void __launch_bounds__(kBlock)
-k_sorted_block_sums(const uint32_t *__restrict__ keys, int64_t n, int64_t nb, double *__restrict__ b1, double *__restrict__ b2)
+k_sorted_block_sums(const uint32_t *__restrict__ keys, int64_t n, int64_t nb, DD *__restrict__ b1, DD *__restrict__ b2)
 {
     const int lane = threadIdx.x & 63;
     const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= nb) return;
-    double s1 = 0.0, s2 = 0.0;
+    DD s1{0.0, 0.0}, s2{0.0, 0.0};
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int64_t i = b * kPre + u * 64 + lane;
         if (i < n) {
             const double k = (double)__uint_as_float(keys[i]);
-            s1 += k;
-            s2 = fma(k, k, s2);
+            s1 = dd_add_d(s1, k);
+            s2 = dd_add_d(s2, k * k);
         }
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
-        s1 += __shfl_xor(s1, off, 64);
-        s2 += __shfl_xor(s2, off, 64);
+        s1 = dd_add(s1, dd_shfl_xor(s1, off));
+        s2 = dd_add(s2, dd_shfl_xor(s2, off));
     }
     if (lane == 0) {
         b1[b] = s1;
@@ -75,29 +132,35 @@ k_sorted_block_sums(const uint32_t *__restrict__ keys, int64_t n, int64_t nb, do
 constexpr int kSuper = 1024;
 
 __global__ void __launch_bounds__(kSuper)
-k_sorted_scan_super(double *__restrict__ b1, double *__restrict__ b2, int64_t nb, double *__restrict__ t1, double *__restrict__ t2)
+k_sorted_scan_super(DD *__restrict__ b1, DD *__restrict__ b2, int64_t nb, DD *__restrict__ t1, DD *__restrict__ t2)
 {
-    __shared__ double s1[kSuper], s2[kSuper];
+    __shared__ DD s1[kSuper], s2[kSuper];
     const int tid = threadIdx.x;
     const int64_t i = (int64_t)blockIdx.x * kSuper + tid;
-    const double v1 = i < nb ? b1[i] : 0.0, v2 = i < nb ? b2[i] : 0.0;
+    const DD zero{0.0, 0.0};
+    DD v1 = zero, v2 = zero;
+    if (i < nb) {
+        v1 = b1[i];
+        v2 = b2[i];
+    }
     s1[tid] = v1;
     s2[tid] = v2;
     __syncthreads();
     for (int off = 1; off < kSuper; off <<= 1) {   // Hillis-Steele inclusive scan
-        double a1 = 0.0, a2 = 0.0;
+        DD a1 = zero, a2 = zero;
         if (tid >= off) {
             a1 = s1[tid - off];
             a2 = s2[tid - off];
         }
         __syncthreads();
-        s1[tid] += a1;
-        s2[tid] += a2;
+        s1[tid] = dd_add(s1[tid], a1);
+        s2[tid] = dd_add(s2[tid], a2);
         __syncthreads();
     }
     if (i < nb) {                                   // exclusive, within the superblock
-        b1[i] = tid ? s1[tid - 1] : 0.0;
-        b2[i] = tid ? s2[tid - 1] : 0.0;
+        const int j = tid ? tid - 1 : 0;            // (field-wise selects: a struct temporary went to scratch)
+        b1[i] = DD{tid ? s1[j].hi : 0.0, tid ? s1[j].lo : 0.0};
+        b2[i] = DD{tid ? s2[j].hi : 0.0, tid ? s2[j].lo : 0.0};
     }
     if (tid == kSuper - 1) {
         t1[blockIdx.x] = s1[tid];
@@ -106,35 +169,36 @@ k_sorted_scan_super(double *__restrict__ b1, double *__restrict__ b2, int64_t nb
 }
 
 __global__ void __launch_bounds__(64)
-k_sorted_scan_top(double *__restrict__ t1, double *__restrict__ t2, int64_t nsb)
+k_sorted_scan_top(DD *__restrict__ t1, DD *__restrict__ t2, int64_t nsb)
 {
     // a few hundred entries, one wave: a lane owns a contiguous run, the runs' totals are scanned with shuffles
     // (fixed association: deterministic); the grand totals go behind the last entry (prefix_at(n) at a block border)
     const int lane = threadIdx.x;
     const int64_t per = (nsb + 63) / 64, lo = lane * per, hi = lo + per < nsb ? lo + per : nsb;
-    double s1 = 0.0, s2 = 0.0;
+    const DD zero{0.0, 0.0};
+    DD s1 = zero, s2 = zero;
     for (int64_t i = lo; i < hi; ++i) {
-        s1 += t1[i];
-        s2 += t2[i];
+        s1 = dd_add(s1, t1[i]);
+        s2 = dd_add(s2, t2[i]);
     }
-    double i1 = s1, i2 = s2;                                  // inclusive scan over the lanes
+    DD i1 = s1, i2 = s2;                                      // inclusive scan over the lanes
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
-        const double a1 = __shfl_up(i1, off, 64), a2 = __shfl_up(i2, off, 64);
+        const DD a1 = dd_shfl_up(i1, off), a2 = dd_shfl_up(i2, off);   // (every lane takes part in the shuffle)
         if (lane >= off) {
-            i1 += a1;
-            i2 += a2;
+            i1 = dd_add(i1, a1);
+            i2 = dd_add(i2, a2);
         }
     }
-    const double u1 = __shfl_up(i1, 1, 64), u2 = __shfl_up(i2, 1, 64);   // (every lane takes part in the shuffle)
-    double r1 = lane ? u1 : 0.0, r2 = lane ? u2 : 0.0;          // exclusive prefix of this lane's run
-    const double tot1 = __shfl(i1, 63, 64), tot2 = __shfl(i2, 63, 64);
+    const DD u1 = dd_shfl_up(i1, 1), u2 = dd_shfl_up(i2, 1);
+    DD r1 = lane ? u1 : zero, r2 = lane ? u2 : zero;           // exclusive prefix of this lane's run
+    const DD tot1 = dd_shfl(i1, 63), tot2 = dd_shfl(i2, 63);
     for (int64_t i = lo; i < hi; ++i) {
-        const double v1 = t1[i], v2 = t2[i];
+        const DD v1 = t1[i], v2 = t2[i];
         t1[i] = r1;
         t2[i] = r2;
-        r1 += v1;
-        r2 += v2;
+        r1 = dd_add(r1, v1);
+        r2 = dd_add(r2, v2);
     }
     if (lane == 0) {
         t1[nsb] = tot1;
@@ -194,29 +258,30 @@ __device__ __forceinline__ int64_t lower_bound_keys(const uint32_t *__restrict__
 }
 
 struct Moments {
-    double s1, s2;
+    DD s1, s2;
 };
 
 // sums of k and k^2 over keys[0 .. pos)
-__device__ __forceinline__ Moments prefix_at(const uint32_t *__restrict__ keys, const double *__restrict__ p1,
-                                             const double *__restrict__ p2, const double *__restrict__ t1,
-                                             const double *__restrict__ t2, int64_t nb, int64_t pos)
+__device__ __forceinline__ Moments prefix_at(const uint32_t *__restrict__ keys, const DD *__restrict__ p1,
+                                             const DD *__restrict__ p2, const DD *__restrict__ t1,
+                                             const DD *__restrict__ t2, int64_t nb, int64_t pos)
 {
     const int64_t b = pos / kPre;
     // (b == nb: pos == n at a block border -- everything: the last superblock's entry would be out of range)
-    Moments m = b < nb ? Moments{t1[b / kSuper] + p1[b], t2[b / kSuper] + p2[b]} : Moments{t1[(nb + kSuper - 1) / kSuper], t2[(nb + kSuper - 1) / kSuper]};
+    const int64_t top = (nb + kSuper - 1) / kSuper;
+    Moments m = b < nb ? Moments{dd_add(t1[b / kSuper], p1[b]), dd_add(t2[b / kSuper], p2[b])} : Moments{t1[top], t2[top]};
     for (int64_t i = b * kPre; i < pos; ++i) {
         const double k = (double)__uint_as_float(keys[i]);
-        m.s1 += k;
-        m.s2 = fma(k, k, m.s2);
+        m.s1 = dd_add_d(m.s1, k);
+        m.s2 = dd_add_d(m.s2, k * k);
     }
     return m;
 }
 
 // one workgroup per (mantissa width, candidate); a lane per cell (looping when a format has more than 256 cells)
 __global__ void __launch_bounds__(kBlock)
-k_mse_cells(const uint32_t *__restrict__ keys, const double *__restrict__ p1, const double *__restrict__ p2,
-            const double *__restrict__ t1, const double *__restrict__ t2, const float *__restrict__ grid, float *__restrict__ mses, SortedArgs a, double inv_inner, int brute)
+k_mse_cells(const uint32_t *__restrict__ keys, const DD *__restrict__ p1, const DD *__restrict__ p2,
+            const DD *__restrict__ t1, const DD *__restrict__ t2, const float *__restrict__ grid, float *__restrict__ mses, SortedArgs a, double inv_inner, int brute)
 {
     __shared__ float s_scale[kLutMax];     // s_p, p = 1 .. pmax (exact: lut_entry)
     __shared__ float s_border[kLutMax];    // L_p: smallest key of binade p (L_1 = 0, L_(pmax+1) = +inf)
@@ -318,8 +383,11 @@ k_mse_cells(const uint32_t *__restrict__ keys, const double *__restrict__ p1, co
             const int64_t a0 = lower_bound_keys(keys, n, lo), a1 = lower_bound_keys(keys, n, hi);
             if (a1 > a0) {
                 const Moments m0 = prefix_at(keys, p1, p2, t1, t2, a.nb, a0), m1 = prefix_at(keys, p1, p2, t1, t2, a.nb, a1);
+                // S2 - 2 q S1 + n q^2 in double-double (q^2 of an fp32 q is exact in double); the cell's result is >= 0
                 const double qd = (double)q, cnt = (double)(a1 - a0);
-                acc += (m1.s2 - m0.s2) - 2.0 * qd * (m1.s1 - m0.s1) + cnt * qd * qd;
+                const DD d2 = dd_add(m1.s2, dd_neg(m0.s2)), d1 = dd_add(m1.s1, dd_neg(m0.s1));
+                const DD e = dd_add(dd_add(d2, dd_mul_d(d1, -2.0 * qd)), two_prod(cnt, qd * qd));
+                acc += e.hi + e.lo;
             }
         }
     }
@@ -330,7 +398,7 @@ k_mse_cells(const uint32_t *__restrict__ keys, const double *__restrict__ p1, co
         __syncthreads();
     }
     if (tid == 0) {
-        const double tot = s_red[0] < 0.0 ? 0.0 : s_red[0];     // (rounding of the prefix differences can leave -1e-20 for an exact fit)
+        const double tot = s_red[0] < 0.0 ? 0.0 : s_red[0];     // (rounding can leave a tiny negative number for an exact fit)
         *out += (float)(tot * inv_inner);
     }
 }
@@ -352,7 +420,7 @@ size_t fp8q_mse_sorted_workspace_bytes(int64_t n)
 {
     const int64_t nb = cdiv(n, kPre);
     const int64_t nsb = cdiv(nb, kSuper);
-    return align_up((size_t)n * 4, 256) + 2 * align_up((size_t)(nb + 1) * 8, 256) + 2 * align_up((size_t)(nsb + 1) * 8, 256) +
+    return align_up((size_t)n * 4, 256) + 2 * align_up((size_t)(nb + 1) * sizeof(DD), 256) + 2 * align_up((size_t)(nsb + 1) * sizeof(DD), 256) +
            align_up(sort_temp_bytes(n), 256) + 256;
 }
 
@@ -364,15 +432,15 @@ int fp8q_mse_sorted_launch(const float *x, int64_t n, const float *grid, int64_t
     char *w = (char *)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
     uint32_t *keys = (uint32_t *)w;
     w += align_up((size_t)n * 4, 256);
-    double *p1 = (double *)w;
-    w += align_up((size_t)(nb + 1) * 8, 256);
-    double *p2 = (double *)w;
-    w += align_up((size_t)(nb + 1) * 8, 256);
+    DD *p1 = (DD *)w;
+    w += align_up((size_t)(nb + 1) * sizeof(DD), 256);
+    DD *p2 = (DD *)w;
+    w += align_up((size_t)(nb + 1) * sizeof(DD), 256);
     const int64_t nsb = cdiv(nb, kSuper);
-    double *t1 = (double *)w;
-    w += align_up((size_t)(nsb + 1) * 8, 256);
-    double *t2 = (double *)w;
-    w += align_up((size_t)(nsb + 1) * 8, 256);
+    DD *t1 = (DD *)w;
+    w += align_up((size_t)(nsb + 1) * sizeof(DD), 256);
+    DD *t2 = (DD *)w;
+    w += align_up((size_t)(nsb + 1) * sizeof(DD), 256);
     size_t temp = sort_temp_bytes(n);
     auto in = rocprim::make_transform_iterator(reinterpret_cast<const uint32_t *>(x), AbsBits());
     if (hipError_t e = rocprim::radix_sort_keys((void *)w, temp, in, keys, (size_t)n, 0, 31, st); e != hipSuccess) return (int)e;

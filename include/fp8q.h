@@ -95,6 +95,8 @@ int fp8q_quantize_f32(const float *x, float *y, int64_t C, int64_t inner, const 
  *   maxval_out [C] or NULL: |max(|cur_min|, cur_max)| after the fold
  *   ws        8-byte aligned scratch of at least fp8q_minmax_workspace_bytes(C, inner) bytes, zero on first use (see above)
  * NaN anywhere in a row makes that row's min and max NaN (torch semantics).
+ * Signed zeros: a zero minimum is -0.0 when the row holds a -0.0, a zero maximum is +0.0 when it holds a +0.0 (IEEE 754-2019
+ * minimum / maximum, order-independent; ATen returns whichever zero its reduction met first, so the reference does not pin it).
  * HBM traffic: 4 B / element.
  */
 size_t fp8q_minmax_workspace_bytes(int64_t C, int64_t inner);
@@ -150,13 +152,17 @@ int fp8q_minmax_quantize_f32(const float *x, float *y, int64_t C, int64_t inner,
  * partials).  The quantized value of an element is the oracle's except on (near-)exact rounding ties -- where both
  * neighbouring grid points are equally far from x, so the squared error is the same; table entries agree with the oracle's to
  * ~1e-6 relative (tests: <= 1e-5 on every entry, the CHOSEN (mantissa bits, maxval) equal to the oracle's choice or
- * its oracle-MSE within 1e-6 relative of the oracle's minimum -- SURVEY.md 8c).
+ * its oracle-MSE within 1e-6 relative of the oracle's minimum -- SURVEY.md 8c).  "Near" a tie = the quotient within
+ * ~2.4e-7 relative of r + 0.5: a 2.4e-7 fraction of the elements of a continuous distribution, each contributing an error
+ * change of <= ~1e-4 of its own squared error.  Only a tensor with a handful of DISTINCT magnitudes can put a visible
+ * share of its elements on one such near-tie at once; an entry then moves by up to ~1e-4 relative (tools/soak.py, 28
+ * magnitudes 1.5 * 2^k, E2M5: 2.2e-5).  The sorted route below has no such case.
  * Per-tensor rows of >= 2^20 elements searched over >= 256 (width, candidate) pairs of a signed format -- the mantissa
  * search of the reference CLI's default (6 x 111), LineSearchEstimator's 1000 candidates -- take a third route: |x| is
  * radix-sorted once, prefix sums of k and k^2 are formed in double, and a candidate's quantization cells (the intervals of
  * |x| that map to one grid value; their borders are located exactly with the reference's own fp32 decisions) are summed
- * as S2 - 2 q S1 + n q^2.  Every element is classified as K1 classifies it; the squares are summed in exact arithmetic
- * instead of fp32-rounded: ~1e-7 relative.  fp8q_mse_workspace_bytes() accounts for the keys (4 B / element + the sort's
+ * as S2 - 2 q S1 + n q^2 (double-double: the terms cancel to 1e-13 of S2 on already-quantized data).  Every element is
+ * classified as K1 classifies it; the squares are summed in (near-)exact arithmetic instead of fp32-rounded: ~1e-7 relative.  fp8q_mse_workspace_bytes() accounts for the keys (4 B / element + the sort's
  * scratch).  FP8Q_MSE_SORTED=0 keeps the lane-per-element kernel.
  */
 size_t fp8q_mse_workspace_bytes(int64_t C, int64_t inner, int64_t n_cand, int n_m);

@@ -45,6 +45,9 @@ static inline float cr_exp2f(float e) { return (float)exp2((double)e); }
 /* torch.max / torch.min propagate NaN from either operand */
 static inline float t_max(float a, float b) { return (a != a) ? a : ((b != b) ? b : (a > b ? a : b)); }
 static inline float t_min(float a, float b) { return (a != a) ? a : ((b != b) ? b : (a < b ? a : b)); }
+/* the range folds' variant: -0.0 < +0.0 (IEEE 754-2019 minimum / maximum; see orc_minmax_f32) */
+static inline float z_max(float a, float b) { return (a == b) ? (signbit(a) ? b : a) : t_max(a, b); }
+static inline float z_min(float a, float b) { return (a == b) ? (signbit(a) ? a : b) : t_min(a, b); }
 
 typedef struct {
     float maxval, minval, bias, M;
@@ -110,19 +113,27 @@ int orc_quantize_flat_f32(const float *x, float *y, int64_t n, float maxval, flo
 }
 
 /* K2/K3: min and max over the last dim of [C, inner]; NaN anywhere in a row -> NaN (torch.min/max).
- * range_estimators.py:62-74, 84-98 */
+ * range_estimators.py:62-74, 84-98
+ * Signed zeros: when a row's minimum (maximum) is zero and the row holds both -0.0 and +0.0, ATen returns whichever its
+ * vectorised reduction met first -- the reference does not pin the sign.  The contract here is the order-independent
+ * IEEE 754-2019 minimum / maximum: -0.0 < +0.0, so min -> -0.0 and max -> +0.0 (what v_min_f32 / v_max_f32 compute). */
+#define ORC_ZERO_FLAGS(v, nz, pz) do { if ((v) == 0) { if (signbit(v)) nz = 1; else pz = 1; } } while (0)
+#define ORC_ZERO_FIX(lo, hi, nz, pz) do { if ((lo) == 0) lo = nz ? -0.0f : 0.0f; if ((hi) == 0) hi = pz ? 0.0f : -0.0f; } while (0)
+
 int orc_minmax_f32(const float *x, int64_t C, int64_t inner, float *mn, float *mx)
 {
     if (C == 1 && inner >= (1 << 20)) {   /* one long row (per-tensor activations): split it over the threads */
         float lo = INFINITY, hi = -INFINITY;
-        int nan = 0;
-#pragma omp parallel for schedule(static) reduction(min : lo) reduction(max : hi) reduction(| : nan)
+        int nan = 0, nz = 0, pz = 0;
+#pragma omp parallel for schedule(static) reduction(min : lo) reduction(max : hi) reduction(| : nan, nz, pz)
         for (int64_t i = 0; i < inner; ++i) {
             float v = x[i];
             nan |= (v != v);
+            ORC_ZERO_FLAGS(v, nz, pz);
             lo = v < lo ? v : lo;
             hi = v > hi ? v : hi;
         }
+        ORC_ZERO_FIX(lo, hi, nz, pz);
         mn[0] = nan ? NAN : lo;
         mx[0] = nan ? NAN : hi;
         return 0;
@@ -131,13 +142,15 @@ int orc_minmax_f32(const float *x, int64_t C, int64_t inner, float *mn, float *m
     for (int64_t c = 0; c < C; ++c) {
         const float *xr = x + c * inner;
         float lo = INFINITY, hi = -INFINITY;
-        int nan = 0;
+        int nan = 0, nz = 0, pz = 0;
         for (int64_t i = 0; i < inner; ++i) {
             float v = xr[i];
             nan |= (v != v);
+            ORC_ZERO_FLAGS(v, nz, pz);
             lo = v < lo ? v : lo;
             hi = v > hi ? v : hi;
         }
+        ORC_ZERO_FIX(lo, hi, nz, pz);
         mn[c] = nan ? NAN : lo;
         mx[c] = nan ? NAN : hi;
     }
@@ -155,8 +168,8 @@ int orc_fold_f32(float *cur_mn, float *cur_mx, const float *mn, const float *mx,
             cur_mn[c] = mn[c];
             cur_mx[c] = mx[c];
         } else if (mode == 1) {
-            cur_mn[c] = t_min(cur_mn[c], mn[c]);
-            cur_mx[c] = t_max(cur_mx[c], mx[c]);
+            cur_mn[c] = z_min(cur_mn[c], mn[c]);
+            cur_mx[c] = z_max(cur_mx[c], mx[c]);
         } else {
             /* python: (1 - momentum) in double, then each scalar is cast to fp32 by ATen */
             float om = (float)(1.0 - momentum), mo = (float)momentum;
@@ -299,13 +312,16 @@ int orc_minmax_f64(const double *x, int64_t C, int64_t inner, double *mn, double
 #pragma omp parallel for schedule(static)
     for (int64_t c = 0; c < C; ++c) {
         double lo = INFINITY, hi = -INFINITY;
-        int nan = 0;
+        int nan = 0, nz = 0, pz = 0;
         for (int64_t i = 0; i < inner; ++i) {
             double v = x[c * inner + i];
             nan |= (v != v);
+            ORC_ZERO_FLAGS(v, nz, pz);
             lo = v < lo ? v : lo;
             hi = v > hi ? v : hi;
         }
+        if (lo == 0) lo = nz ? -0.0 : 0.0;       /* signed zeros: as orc_minmax_f32 */
+        if (hi == 0) hi = pz ? 0.0 : -0.0;
         mn[c] = nan ? NAN : lo;
         mx[c] = nan ? NAN : hi;
     }
