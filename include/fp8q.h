@@ -154,9 +154,11 @@ int fp8q_minmax_quantize_f32(const float *x, float *y, int64_t C, int64_t inner,
  * ~1e-6 relative (tests: <= 1e-5 on every entry, the CHOSEN (mantissa bits, maxval) equal to the oracle's choice or
  * its oracle-MSE within 1e-6 relative of the oracle's minimum -- SURVEY.md 8c).  "Near" a tie = the quotient within
  * ~2.4e-7 relative of r + 0.5: a 2.4e-7 fraction of the elements of a continuous distribution, each contributing an error
- * change of <= ~1e-4 of its own squared error.  Only a tensor with a handful of DISTINCT magnitudes can put a visible
- * share of its elements on one such near-tie at once; an entry then moves by up to ~1e-4 relative (tools/soak.py, 28
- * magnitudes 1.5 * 2^k, E2M5: 2.2e-5).  The sorted route below has no such case.
+ * change of <= ~1e-4 of its own squared error.  Only when a few elements carry the entry does that show: a tensor with a
+ * handful of DISTINCT magnitudes (all elements of one magnitude share a near-tie) or a heavy-tailed one whose squared error
+ * is dominated by its largest element; the entry then moves by up to ~1e-4 relative (tools/soak.py: 28 magnitudes
+ * 1.5 * 2^k, E2M5, and a Cauchy sample, E4M3: 2.2e-5 and 2.1e-5, once per ~10^5 table entries).  The sorted route below
+ * has no such case.
  * Per-tensor rows of >= 2^20 elements searched over >= 256 (width, candidate) pairs of a signed format -- the mantissa
  * search of the reference CLI's default (6 x 111), LineSearchEstimator's 1000 candidates -- take a third route: |x| is
  * radix-sorted once, prefix sums of k and k^2 are formed in double, and a candidate's quantization cells (the intervals of
