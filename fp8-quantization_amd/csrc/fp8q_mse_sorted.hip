@@ -16,7 +16,7 @@
 // (include/fp8q.h: table entries to 1e-5, the chosen candidate per SURVEY 8c).  Why double-double: the three terms cancel.
 // On data that sit (almost) on the grid -- already-quantized tensors, a handful of distinct magnitudes -- the squared
 // error is 1e-13 of the signal energy S2 and plain double prefix sums (relative 1e-16 OF S2) left 3e-5 relative error in
-// the table entry (found by tools/soak.py: 28 distinct magnitudes, E6M1); with ~2^-104 of S2 the entry is good down to an
+// the table entry (found by tests/soak.py: 28 distinct magnitudes, E6M1); with ~2^-104 of S2 the entry is good down to an
 // error / energy ratio of ~1e-26, below which the oracle's own fp32 squares underflow.
 // Cost: the sort (~0.5 ms for 25.7 M keys) + ~0.1 ms per 666 candidates; used when n_m * n_cand >= 256 on a per-tensor
 // row of >= 2^20 elements of a signed format (fp8q_mse_grid_f32 routes; FP8Q_MSE_SORTED=0 disables).

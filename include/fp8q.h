@@ -159,7 +159,7 @@ int fp8q_minmax_quantize_f32(const float *x, float *y, int64_t C, int64_t inner,
  * is dominated by its largest element; the entry then moves by up to ~1e-4 relative.  One such tie is structural: for
  * M = 1, 3, 5 the search grid's last candidate 1.2 * max|x| puts the largest element itself at (2^(M+1) - 1) / 1.2 =
  * 2.5 / 12.5 / 52.5 scale steps, a tie in real arithmetic that only the fp32 rounding of 1.2 * max|x| breaks
- * (tools/soak.py: 2.2e-5 on 28 magnitudes 1.5 * 2^k with E2M5, 1.2e-5 ... 3.2e-5 on Cauchy samples with E4M3, always at
+ * (tests/soak.py: 2.2e-5 on 28 magnitudes 1.5 * 2^k with E2M5, 1.2e-5 ... 3.2e-5 on Cauchy samples with E4M3, always at
  * that candidate; profiles/r04_soak.txt).  The sorted route below has no such case.
  * Per-tensor rows of >= 2^20 elements searched over >= 256 (width, candidate) pairs of a signed format -- the mantissa
  * search of the reference CLI's default (6 x 111), LineSearchEstimator's 1000 candidates -- take a third route: |x| is

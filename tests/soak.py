@@ -1,7 +1,8 @@
 #!/usr/bin/env python
-"""Time-bounded random parity soak of every C-ABI entry point against the CPU oracle (GPU box only).
+"""(test infrastructure: lives under tests/ because it drives the oracle; not collected by pytest)
+Time-bounded random parity soak of every C-ABI entry point against the CPU oracle (GPU box only).
 
-    python tools/soak.py [--seconds 300] [--seed 0]  > gpurun_out/r04_soak.txt
+    python tests/soak.py [--seconds 300] [--seed 0]  > gpurun_out/r04_soak.txt
 
 Every case draws a shape, a format, a range and special values at random, runs the HIP path and the oracle on the same
 inputs and demands BIT equality (fp32 / fp64 values, codes, ranges).  The search kernel's sort-once route is compared
@@ -239,9 +240,150 @@ def case_sorted(rng):
     return n * 666
 
 
+def case_ranges(rng):
+    """K2/K3/K5 with the three folds (+ the packed record of the range all-reduce)"""
+    pc = bool(rng.randint(2))
+    C = int(rng.choice([1, 2, 3, 17, 64, 129, 1000, 4099])) if pc else 1
+    inner = int(rng.choice(INNERS)) * (1 if pc else int(rng.choice([1, 97, 3001])))
+    x = data(rng, C, inner)
+    xd = torch.from_numpy(x).cuda()
+    rows = C if pc else 1
+    mode = int(rng.randint(3))
+    mom = float(rng.choice([0.9, 0.5, 0.99]))
+    mn, mx = oracle.c_minmax(x, pc)
+    if rng.randint(2):      # a previous estimate to fold into
+        pmn = (-np.abs(rng.standard_normal(rows))).astype(np.float32)
+        pmx = np.abs(rng.standard_normal(rows)).astype(np.float32)
+        if rng.randint(6) == 0:
+            pmn[rng.randint(rows)] = np.nan
+        rmn, rmx = oracle.c_fold(pmn, pmx, mn, mx, mode, mom)
+        cmn, cmx = torch.from_numpy(pmn.copy()).cuda(), torch.from_numpy(pmx.copy()).cuda()
+        packed = ops.new_packed(rows, "cuda") if rng.randint(2) else None
+        gmn, gmx, gmv = ops.minmax(xd, pc, cmn, cmx, mode=mode, momentum=mom, want_maxval=True, packed=packed)
+    else:
+        rmn, rmx = mn, mx
+        packed = ops.new_packed(rows, "cuda") if rng.randint(2) else None
+        gmn, gmx, gmv = ops.minmax(xd, pc, mode=mode, momentum=mom, want_maxval=True, packed=packed)
+    rmv = oracle.c_absmax(rmn, rmx)
+    got = [t.cpu().numpy().reshape(-1) for t in (gmn, gmx, gmv)]
+    for name, g, r in zip(("min", "max", "maxval"), got, (rmn, rmx, rmv)):
+        bad = np.flatnonzero(bits(g) != bits(r))
+        assert bad.size == 0, ("ranges " + name, C, inner, pc, mode, "row", int(bad[0]), float(g[bad[0]]), float(r[bad[0]]))
+    if packed is not None:
+        a, b, c = ops.ranges_unpack(packed)
+        for name, g, r in zip(("min", "max", "maxval"), (a, b, c), (rmn, rmx, rmv)):
+            g = g.cpu().numpy().reshape(-1)
+            # the record carries -min: a zero minimum comes back as the negated zero of what was stored
+            assert np.array_equal(np.where(np.isnan(g), np.float32(7), g), np.where(np.isnan(r), np.float32(7), r)), ("packed " + name, C, inner, pc, mode)
+    return x.size
+
+
+def case_mse_small(rng):
+    """K4 on per-channel weights and short / mid rows (k_mse_grid, k_mse_row), against the oracle at the stated tolerance"""
+    pc = bool(rng.randint(3))
+    C = int(rng.choice([1, 3, 32, 96, 320])) if pc else 1
+    inner = int(rng.choice([1, 9, 27, 147, 576, 2047, 2048, 4608, 50000]))
+    x = data(rng, C, inner)
+    x = np.nan_to_num(x, nan=0.25, posinf=3.0, neginf=-3.0)
+    M, nb, sb = fmt(rng)
+    n_cand = int(rng.choice([1, 7, 111]))
+    widths = [M] if rng.randint(2) else [1.0, 3.0, 4.0]
+    rows = C if pc else 1
+    top = np.abs(x.reshape(rows, -1)).max(1) + 1e-6
+    grid = (np.linspace(0.1, 1.2, n_cand)[:, None] * top[None, :]).astype(np.float32)
+    out = torch.zeros(len(widths), n_cand, rows, device="cuda")
+    ops.mse_grid(torch.from_numpy(x).cuda(), pc, torch.from_numpy(grid).cuda(), widths, nb, sb, out)
+    ref = oracle.c_mse_grid(x, pc, grid, widths, nb, sb).astype(np.float64)
+    got = out.cpu().numpy().astype(np.float64)
+    assert np.array_equal(np.isnan(got), np.isnan(ref)), ("K4 NaN pattern", C, inner, pc, widths, nb, sb)
+    ok = ~np.isnan(ref)
+    rel = np.abs(got[ok] - ref[ok]) / (np.abs(ref[ok]) + 1e-30 * (np.abs(ref[ok]).max() if ok.any() else 1.0) + 1e-300)
+    if rel.size and rel.max() > 1e-5:
+        NEAR_TIE.append((C * inner, widths, LAST_KIND[0], float(rel.max())))
+    assert not rel.size or rel.max() <= 2e-4, ("K4 small rows vs oracle", C, inner, pc, widths, nb, sb, n_cand, float(rel.max()))
+    return x.size * n_cand * len(widths)
+
+
+def case_select(rng):
+    """device-side search grid (bit-equal to torch.linspace) and selection (torch.min / argmin / mode semantics)"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_ops
+    C = int(rng.choice([1, 2, 7, 64, 1000]))
+    n_m = int(rng.choice([1, 2, 6]))
+    n_cand = int(rng.choice([2, 111]))
+    mx = (np.abs(rng.standard_normal(C)) * 10.0 ** rng.uniform(-6, 6) + 1e-30).astype(np.float32)
+    if rng.randint(5) == 0:
+        mx[rng.randint(C)] = 0.0
+    g = ops.mse_linspace(torch.from_numpy(mx).cuda(), n_cand)
+    gr = oracle_ops.mse_linspace(torch.from_numpy(mx), n_cand)
+    assert np.array_equal(bits(g.cpu().numpy()), bits(gr.numpy())), ("linspace", C, n_cand)
+    mses = np.abs(rng.standard_normal((n_m, n_cand, C))).astype(np.float32)
+    r = rng.randint(4)
+    if r == 0:      # ties everywhere: a few distinct values
+        mses = np.round(mses * 2) / 2
+    elif r == 1:
+        mses.reshape(-1)[rng.randint(mses.size, size=3)] = np.nan
+    elif r == 2:
+        mses.reshape(-1)[rng.randint(mses.size, size=3)] = np.inf
+    widths = [float(i + 1) for i in range(n_m)]
+    got = ops.mse_select(torch.from_numpy(mses).cuda(), g, widths, 1)
+    ref = oracle_ops.mse_select(torch.from_numpy(mses), gr, widths, 1)
+    for name, a, b in zip(("mbits", "vote", "maxval", "minval"), got, ref):
+        assert np.array_equal(bits(a.cpu().numpy().astype(np.float32)), bits(b.numpy().astype(np.float32))), ("select " + name, C, n_m, n_cand, r)
+    return mses.size
+
+
+def case_multi_ranges(rng):
+    """per-channel ranges + quantize of many tensors in two launches"""
+    n = int(rng.randint(1, 30))
+    items, refs = [], []
+    tot = 0
+    for _ in range(n):
+        C = int(rng.choice([1, 8, 64, 512]))
+        inner = int(rng.choice([4, 9, 27, 147, 576, 4608, 1000]))
+        x = data(rng, C, inner)
+        M, nb, sb = fmt(rng)
+        mn, mx = oracle.c_minmax(x, True)
+        mv = oracle.c_absmax(mn, mx)
+        refs.append((oracle.c_quantize(x, mv, M, nb, sb), mv))
+        items.append((torch.from_numpy(x).cuda(), torch.empty(C, device="cuda"), M, nb, sb))
+        tot += x.size
+    outs = ops.multi_minmax_quantize(items)
+    for i, (o, (r, mv)) in enumerate(zip(outs, refs)):
+        assert np.array_equal(bits(items[i][1].cpu().numpy()), bits(mv)), ("multi ranges", i, tuple(items[i][0].shape))
+        assert np.array_equal(bits(o.cpu().numpy()), bits(r)), ("multi_minmax_quantize", i, tuple(items[i][0].shape), items[i][2:])
+    return tot
+
+
+def case_f64_search(rng):
+    """float64 lane: row min/max and the candidate search (sum and mean)"""
+    pc = bool(rng.randint(2))
+    C = int(rng.choice([1, 3, 64]))
+    inner = int(rng.choice([1, 5, 147, 2049, 10007, 200000]))
+    x = data(rng, C, inner, np.float64)
+    x = np.nan_to_num(x, nan=0.25, posinf=3.0, neginf=-3.0)
+    xd = torch.from_numpy(x).cuda()
+    mn, mx = ops.minmax_f64(xd, pc)
+    rmn, rmx = oracle.c_minmax_f64(x, pc)
+    assert np.array_equal(bits(mn.cpu().numpy()), bits(rmn)) and np.array_equal(bits(mx.cpu().numpy()), bits(rmx)), ("f64 min/max", C, inner, pc)
+    rows = C if pc else 1
+    n_cand = int(rng.choice([3, 100]))
+    top = np.abs(x.reshape(rows, -1)).max(1) + 1e-9
+    grid = (np.linspace(0.05, 1.1, n_cand)[:, None] * top[None, :]).astype(np.float32)
+    widths = [float(rng.choice([1, 2, 3, 4, 5]))]
+    red = str(rng.choice(["sum", "mean"]))
+    out = torch.zeros(1, n_cand, rows, dtype=torch.float64, device="cuda")
+    ops.mse_grid_f64(xd, pc, torch.from_numpy(grid).cuda(), widths, 8, 1, out, reduce=red)
+    ref = oracle.c_sse_grid_f64(x, pc, grid, widths, 8, 1, reduce=red)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-12, atol=1e-300, err_msg=str(("f64 search", C, inner, pc, widths, red)))
+    return x.size * n_cand
+
+
 FAMILIES = [("K1 fp32 (+ device mantissa width)", case_k1, 6), ("fused min/max + quantize", case_fused, 4),
             ("storage codes", case_codes, 3), ("epilogue (bn / folded / prepared / min-max)", case_epilogue, 4),
-            ("multi-tensor K1", case_multi, 1), ("K1 fp64", case_f64, 3), ("K4 sort-once vs row kernel vs oracle", case_sorted, 1)]
+            ("multi-tensor K1", case_multi, 1), ("K1 fp64", case_f64, 3), ("K4 sort-once vs row kernel vs oracle", case_sorted, 1), ("ranges: min/max, folds, packed record", case_ranges, 4),
+            ("K4 per-channel / short rows", case_mse_small, 3), ("search grid + selection", case_select, 2),
+            ("multi-tensor ranges + K1", case_multi_ranges, 1), ("fp64 min/max + search", case_f64_search, 2)]
 
 
 def main():
@@ -265,7 +407,7 @@ def main():
                 stats[name][0] += 1
         ops.check_workspaces()
         it += 1
-    print(f"# tools/soak.py --seconds {args.seconds:g} --seed {args.seed}: {it} rounds in {time.time() - t0:.0f} s on "
+    print(f"# tests/soak.py --seconds {args.seconds:g} --seed {args.seed}: {it} rounds in {time.time() - t0:.0f} s on "
           f"{torch.cuda.get_device_name(0)}; every comparison bit-exact against oracle/ (K4: within its stated tolerance)")
     for name, (cases, elems) in stats.items():
         print(f"{name:48s} cases {cases:6d}   elements {elems:.3e}")

@@ -24,7 +24,7 @@ cases["relu"] = torch.relu(x)                                  # half of the key
 cases["pow2"] = torch.ldexp(torch.ones(n, device="cuda"), torch.randint(-12, 4, (n,), device="cuda")) * torch.where(torch.rand(n, device="cuda") < 0.5, -1.0, 1.0)
 cases["const"] = torch.full((n,), 0.731, device="cuda")
 # 28 distinct magnitudes 1.5 * 2^k: for many candidates nearly every key sits on a grid point, the squared error is ~1e-13 of
-# the signal energy (what tools/soak.py caught: plain double prefix sums left 3e-5 relative error there)
+# the signal energy (what tests/soak.py caught: plain double prefix sums left 3e-5 relative error there)
 cases["ongrid"] = torch.ldexp(torch.full((n,), 1.5, device="cuda"), torch.randint(-20, 8, (n,), device="cuda")) * torch.where(torch.rand(n, device="cuda") < 0.5, -1.0, 1.0)
 t = x.clone(); t[12345] = float("inf"); cases["inf"] = t
 t = x.clone(); t[777] = float("nan"); cases["nan"] = t
