@@ -63,7 +63,10 @@ k_mse_grid(const float *__restrict__ x, const float *__restrict__ grid, double *
     const float *lutk = lut + koff;                             // lutk[e8] == lut[p]
     const int jk = (int)f.M + ch.bi - koff;                     // ldexp exponent M + bi - p == jk - e8
     const float *xr = x + c * a.inner;
-    const bool tie_at_bound = f.pmax == 1;
+    // E = 0 formats: see the loop.  Ranges outside the fast path's preconditions (Chan::pthr < 0: |bias| >= 100, i.e. a
+    // scale or its reciprocal may be denormal, zero or infinite -- E = 7 with maxval < ~2^(M-22): s_1 underflows to 0 and
+    // the reference's 0 / 0 makes every zero element NaN) divide as the reference does, like k_mse_row's exact path.
+    const bool exact_div = f.pmax == 1 || ch.pthr < 0.0f;
     double acc = 0.0;
 
     for (int64_t t0 = (int64_t)split * kMseTile; t0 < a.inner; t0 += (int64_t)a.nsplit * kMseTile) {
@@ -90,7 +93,9 @@ k_mse_grid(const float *__restrict__ x, const float *__restrict__ grid, double *
                     // E = 0 (mantissa bits = n_bits - sign_bits): maxval / s_1 = 2^M - 0.5 is an exact TIE, so every
                     // clipped element sits on one and the fp32 rounding of the quotient decides all of them at
                     // once: there the IEEE division of the reference is reproduced (uniform branch per block)
-                    const float r = tie_at_bound ? rintf(xc / sc) : rintf(ldexpf(tt, jk - e8));
+                    float r;
+                    if (__builtin_expect(exact_div, 0)) r = rintf(xc / sc);
+                    else r = rintf(ldexpf(tt, jk - e8));
                     const float d = xv - r * sc;
                     pa = fmaf(d, d, pa);
                 }

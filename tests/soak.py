@@ -295,7 +295,13 @@ def case_mse_small(rng):
     ops.mse_grid(torch.from_numpy(x).cuda(), pc, torch.from_numpy(grid).cuda(), widths, nb, sb, out)
     ref = oracle.c_mse_grid(x, pc, grid, widths, nb, sb).astype(np.float64)
     got = out.cpu().numpy().astype(np.float64)
-    assert np.array_equal(np.isnan(got), np.isnan(ref)), ("K4 NaN pattern", C, inner, pc, widths, nb, sb)
+    badn = np.argwhere(np.isnan(got) != np.isnan(ref))
+    if badn.size:
+        wi, ci, ri = (int(v) for v in badn[0])
+        np.savez(os.path.join(ROOT, "gpurun_out", "soak_fail_k4_small.npz"), x=x, grid=grid, got=got, ref=ref)
+        raise AssertionError(("K4 NaN pattern", C, inner, pc, widths, nb, sb, "at (width, cand, row)", (wi, ci, ri), "hip", float(got[wi, ci, ri]),
+                              "oracle", float(ref[wi, ci, ri]), "candidate", float(grid[ci, ri]), "row data", x.reshape(rows, -1)[ri].tolist()[:16],
+                              "mismatches", int(badn.shape[0])))
     ok = ~np.isnan(ref)
     rel = np.abs(got[ok] - ref[ok]) / (np.abs(ref[ok]) + 1e-30 * (np.abs(ref[ok]).max() if ok.any() else 1.0) + 1e-300)
     if rel.size and rel.max() > 1e-5:
