@@ -89,13 +89,20 @@ k_mse_grid(const float *__restrict__ x, const float *__restrict__ grid, double *
                     const float tt = xc * c1;
                     int e8 = (int)__builtin_amdgcn_ubfe(__float_as_uint(tt), 23u, 8u);
                     e8 = max(min(e8, e_hi), e_lo);
-                    const float sc = lutk[e8];
+                    float sc = lutk[e8];
                     // E = 0 (mantissa bits = n_bits - sign_bits): maxval / s_1 = 2^M - 0.5 is an exact TIE, so every
                     // clipped element sits on one and the fp32 rounding of the quotient decides all of them at
                     // once: there the IEEE division of the reference is reproduced (uniform branch per block)
                     float r;
-                    if (__builtin_expect(exact_div, 0)) r = rintf(xc / sc);
-                    else r = rintf(ldexpf(tt, jk - e8));
+                    if (__builtin_expect(exact_div, 0)) {
+                        // (bias > 128: binade 1 lies below the exponent field's range, a zero or tiny t would read
+                        // e8 = 0 as binade bi - 127 -- K1's exact decision instead)
+                        const float ls = __builtin_amdgcn_fmed3f(floorf(log2_tab(fabsf(xc), kFastTab) + ch.bias), 1.0f, (float)f.pmax);
+                        sc = lut[(int)ls];
+                        r = rintf(xc / sc);
+                    } else {
+                        r = rintf(ldexpf(tt, jk - e8));
+                    }
                     const float d = xv - r * sc;
                     pa = fmaf(d, d, pa);
                 }
@@ -387,8 +394,6 @@ k_mse_row(const float *__restrict__ x, const float *__restrict__ grid, double *_
                     // exact per-element path (scales not exactly geometric in fp32, tiny / huge / degenerate ranges)
                     const QFmt f = a.fmt[k.m];
                     const Chan ch = make_chan(k.maxv, f);
-                    const int koff = ch.bi - 127;
-                    const int e_lo = 1 - koff, e_hi = f.pmax - koff;
 #pragma unroll 1
                     for (int u = 0; u < kMseRowEpl / 2; ++u) {
                         const float e[2] = {xv[u].x, xv[u].y};
@@ -396,10 +401,10 @@ k_mse_row(const float *__restrict__ x, const float *__restrict__ grid, double *_
 #pragma unroll
                         for (int q = 0; q < 2; ++q) {
                             const float xc = __builtin_amdgcn_fmed3f(e[q], ch.minv, ch.maxv);
-                            const float tt = xc * k.c1;
-                            int e8 = (int)__builtin_amdgcn_ubfe(__float_as_uint(tt), 23u, 8u);
-                            e8 = max(min(e8, e_hi), e_lo);
-                            const float sc = scale_exact(ch, (float)(e8 + koff), f.M);
+                            // K1's exact binade decision (the exponent field of xc * 2^bf cannot express binade 1 when
+                            // bias > 128, and non-geometric scales give no "either side of a border" equivalence)
+                            const float ls = __builtin_amdgcn_fmed3f(floorf(log2_tab(fabsf(xc), kFastTab) + ch.bias), 1.0f, (float)f.pmax);
+                            const float sc = scale_exact(ch, ls, f.M);
                             dd[q] = e[q] - rintf(xc / sc) * sc;   // IEEE division, as the reference: exact at ties too
                         }
                         pa = __builtin_elementwise_fma(vf2{dd[0], dd[1]}, vf2{dd[0], dd[1]}, pa);
