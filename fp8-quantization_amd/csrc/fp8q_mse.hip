@@ -74,7 +74,7 @@ k_mse_grid(const float *__restrict__ x, const float *__restrict__ grid, double *
         __syncthreads();
         for (int i = tid; i < kMseTile; i += kMseBlock) xs[i] = i < n ? xr[t0 + i] : 0.0f;
         __syncthreads();
-        // zero padding: q(0) = 0 exactly, contributes nothing (degenerate maxval -> NaN anyway)
+        // zero padding: q(0) = 0 exactly, contributes nothing (the exact-division path masks it: there q(0) can be NaN)
         const int n32 = (n + 31) & ~31;
         for (int j = 0; j < n32; j += 32) {
             float pa = 0.0f;
@@ -100,6 +100,7 @@ k_mse_grid(const float *__restrict__ x, const float *__restrict__ grid, double *
                         const float ls = __builtin_amdgcn_fmed3f(floorf(log2_tab(fabsf(xc), kFastTab) + ch.bias), 1.0f, (float)f.pmax);
                         sc = lut[(int)ls];
                         r = rintf(xc / sc);
+                        if (j + u * 4 + q >= n) r = sc = 0.0f;   // zero padding: here q(0) may be NaN (s_1 = 0), a real zero's is
                     } else {
                         r = rintf(ldexpf(tt, jk - e8));
                     }
@@ -406,6 +407,8 @@ k_mse_row(const float *__restrict__ x, const float *__restrict__ grid, double *_
                             const float ls = __builtin_amdgcn_fmed3f(floorf(log2_tab(fabsf(xc), kFastTab) + ch.bias), 1.0f, (float)f.pmax);
                             const float sc = scale_exact(ch, ls, f.M);
                             dd[q] = e[q] - rintf(xc / sc) * sc;   // IEEE division, as the reference: exact at ties too
+                            // zero padding of the row's last tile: q(0) may be NaN here (s_1 = 0), and only a real zero's counts
+                            if (e0 + (u >> 1) * 256 + lane * 4 + (u & 1) * 2 + q >= a.inner) dd[q] = 0.0f;
                         }
                         pa = __builtin_elementwise_fma(vf2{dd[0], dd[1]}, vf2{dd[0], dd[1]}, pa);
                     }
