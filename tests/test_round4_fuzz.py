@@ -104,3 +104,51 @@ def test_sorted_mse_awkward_sizes_vs_oracle(n, kind):
     assert np.array_equal(np.isnan(got), np.isnan(ref))
     ok = ~np.isnan(ref)
     np.testing.assert_allclose(got[ok], ref[ok], rtol=1e-5, atol=1e-24 * float(np.nanmax(got)))
+
+
+@pytest.mark.parametrize("inner", [1, 31, 2047, 2048, 5000])
+def test_mse_degenerate_candidates_divide_like_the_reference(inner):
+    """found by tests/soak.py: an E7M1 (8 bits, unsigned) candidate below ~2^-21 underflows its first scale to 0, so the
+    reference's 0 / 0 turns every ZERO element into NaN -- but not the zero padding of a tile -- while a denormal element
+    in a higher binade is quantized normally; bias > 128 also puts binade 1 below the exponent-field range the fast
+    kernels read p from.  Both lane-per-candidate (short rows) and lane-per-element (>= 2048) kernels, against the oracle."""
+    import fp8q
+    rows = {"zero": np.zeros(inner, np.float32), "denormal": np.full(inner, 1e-42, np.float32),
+            "mixed": np.where(np.arange(inner) % 3 == 0, 0.0, 3e-8).astype(np.float32)}
+    grid = np.array([[1e-7], [3e-7], [1e-3]], np.float32)
+    for name, x in rows.items():
+        for mb, sb in (([1.0], 0), ([1.0, 7.0], 0), ([1.0, 2.0], 1)):
+            out = torch.zeros(len(mb), 3, 1, device="cuda")
+            fp8q.ops.mse_grid(torch.from_numpy(x).cuda().reshape(1, -1), False, torch.from_numpy(grid).cuda(), mb, 8, sb, out)
+            ref = oracle.c_mse_grid(x.reshape(1, -1), False, grid, mb, 8, sb)
+            got = out.cpu().numpy()
+            assert np.array_equal(np.isnan(got), np.isnan(ref)), (name, inner, mb, sb, got.ravel(), ref.ravel())
+            ok = ~np.isnan(ref)
+            np.testing.assert_allclose(got[ok], ref[ok], rtol=1e-5, atol=0, err_msg=str((name, inner, mb, sb)))
+    if inner == 1:
+        assert np.isnan(oracle.c_mse_grid(np.zeros((1, 1), np.float32), False, grid[:1], [1.0], 8, 0)).all()   # the case itself
+
+
+def test_minmax_signed_zero_contract():
+    """found by tests/soak.py: a zero minimum is -0.0 when the row holds one, a zero maximum +0.0 (IEEE 754-2019
+    minimum / maximum; include/fp8q.h) -- in every min/max route and in the oracle, whatever the element order"""
+    import fp8q
+    rng = np.random.RandomState(3)
+    for C, inner in ((1000, 27), (64, 147), (3, 5000), (1, 1 << 21), (8, 2049)):
+        x = np.maximum(rng.standard_normal((C, inner)), 0.0).astype(np.float32)
+        x[:, rng.randint(inner)] = -0.0
+        x[0] = -np.abs(x[0])                                    # a row whose maximum is a zero
+        x[0, : 2] = [0.0, -0.0]
+        xd = torch.from_numpy(x).cuda()
+        rmn, rmx = oracle.c_minmax(x, True)
+        assert np.signbit(rmn[1:]).all() and not np.signbit(rmx[0])
+        mn, mx = fp8q.ops.minmax(xd, True)
+        assert np.array_equal(mn.cpu().numpy().view(np.int32), rmn.view(np.int32)), (C, inner)
+        assert np.array_equal(mx.cpu().numpy().view(np.int32), rmx.view(np.int32)), (C, inner)
+        if inner <= fp8q.ops.fused_max_inner():
+            _, fmn, fmx, _ = fp8q.ops.minmax_quantize(xd, 2.0)
+            assert np.array_equal(fmn.cpu().numpy().view(np.int32), rmn.view(np.int32)), (C, inner)
+            assert np.array_equal(fmx.cpu().numpy().view(np.int32), rmx.view(np.int32)), (C, inner)
+        tmn, tmx = fp8q.ops.minmax(xd, False)
+        omn, omx = oracle.c_minmax(x, False)
+        assert tmn.cpu().numpy().view(np.int32)[0] == omn.view(np.int32)[0] and tmx.cpu().numpy().view(np.int32)[0] == omx.view(np.int32)[0]
