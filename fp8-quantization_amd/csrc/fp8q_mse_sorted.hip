@@ -97,29 +97,43 @@ __device__ __forceinline__ DD dd_shfl_xor(DD v, int off) { return DD{__shfl_xor(
 __device__ __forceinline__ DD dd_shfl_up(DD v, int off) { return DD{__shfl_up(v.hi, off, 64), __shfl_up(v.lo, off, 64)}; }
 __device__ __forceinline__ DD dd_shfl(DD v, int lane) { return DD{__shfl(v.hi, lane, 64), __shfl(v.lo, lane, 64)}; }
 
-// block sums of k and k^2: one wave per 256-key block.  k^2 of an fp32 key is exact in double (48 bits).
+// block sums of k and k^2: 16 lanes per 256-key block (16 consecutive keys per lane, then a 4-step butterfly inside the
+// lane group: with one wave per block the six double-double butterfly steps were 3/4 of the kernel -- 73 us for 25.7 M
+// keys).  k^2 of an fp32 key is exact in double (48 bits).
 __global__ void __launch_bounds__(kBlock)
 k_sorted_block_sums(const uint32_t *__restrict__ keys, int64_t n, int64_t nb, DD *__restrict__ b1, DD *__restrict__ b2)
 {
-    const int lane = threadIdx.x & 63;
-    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b >= nb) return;
+    const int sub = threadIdx.x & 15;
+    const int64_t b = (int64_t)blockIdx.x * (kBlock / 16) + (threadIdx.x >> 4);
     DD s1{0.0, 0.0}, s2{0.0, 0.0};
+    if (b < nb) {                                   // (lanes of a group agree; the shuffles below stay inside the group)
+        const int64_t i0 = b * kPre + sub * 16;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int64_t i = b * kPre + u * 64 + lane;
-        if (i < n) {
-            const double k = (double)__uint_as_float(keys[i]);
-            s1 = dd_add_d(s1, k);
-            s2 = dd_add_d(s2, k * k);
+        for (int u = 0; u < 4; ++u) {
+            const int64_t i = i0 + u * 4;
+            uint32_t kv[4] = {0u, 0u, 0u, 0u};      // +0.0 adds nothing
+            if (i + 3 < n) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(keys + i);
+                kv[0] = v.x, kv[1] = v.y, kv[2] = v.z, kv[3] = v.w;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (i + q < n) kv[q] = keys[i + q];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double k = (double)__uint_as_float(kv[q]);
+                s1 = dd_add_d(s1, k);
+                s2 = dd_add_d(s2, k * k);
+            }
         }
     }
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
+    for (int off = 8; off >= 1; off >>= 1) {
         s1 = dd_add(s1, dd_shfl_xor(s1, off));
         s2 = dd_add(s2, dd_shfl_xor(s2, off));
     }
-    if (lane == 0) {
+    if (sub == 0 && b < nb) {
         b1[b] = s1;
         b2[b] = s2;
     }
@@ -444,7 +458,7 @@ int fp8q_mse_sorted_launch(const float *x, int64_t n, const float *grid, int64_t
     size_t temp = sort_temp_bytes(n);
     auto in = rocprim::make_transform_iterator(reinterpret_cast<const uint32_t *>(x), AbsBits());
     if (hipError_t e = rocprim::radix_sort_keys((void *)w, temp, in, keys, (size_t)n, 0, 31, st); e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(k_sorted_block_sums, dim3((unsigned)cdiv(nb, 4)), dim3(kBlock), 0, st, keys, n, nb, p1, p2);
+    hipLaunchKernelGGL(k_sorted_block_sums, dim3((unsigned)cdiv(nb, kBlock / 16)), dim3(kBlock), 0, st, keys, n, nb, p1, p2);
     if (int rc = launch_rc()) return rc;
     hipLaunchKernelGGL(k_sorted_scan_super, dim3((unsigned)nsb), dim3(kSuper), 0, st, p1, p2, nb, t1, t2);
     if (int rc = launch_rc()) return rc;
