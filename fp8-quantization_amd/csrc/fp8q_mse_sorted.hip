@@ -101,7 +101,8 @@ __device__ __forceinline__ DD dd_shfl(DD v, int lane) { return DD{__shfl(v.hi, l
 // lane group: with one wave per block the six double-double butterfly steps were 3/4 of the kernel -- 73 us for 25.7 M
 // keys).  k^2 of an fp32 key is exact in double (48 bits).
 __global__ void __launch_bounds__(kBlock)
-k_sorted_block_sums(const uint32_t *__restrict__ keys, int64_t n, int64_t nb, DD *__restrict__ b1, DD *__restrict__ b2)
+k_sorted_block_sums(const uint32_t *__restrict__ keys, int64_t n, int64_t nb, DD *__restrict__ b1, DD *__restrict__ b2,
+                    uint32_t *__restrict__ kb)
 {
     const int sub = threadIdx.x & 15;
     const int64_t b = (int64_t)blockIdx.x * (kBlock / 16) + (threadIdx.x >> 4);
@@ -136,6 +137,7 @@ k_sorted_block_sums(const uint32_t *__restrict__ keys, int64_t n, int64_t nb, DD
     if (sub == 0 && b < nb) {
         b1[b] = s1;
         b2[b] = s2;
+        kb[b] = keys[b * kPre];                     // the block's first key: lower_bound_keys()'s first level
     }
 }
 
@@ -259,16 +261,26 @@ __device__ __forceinline__ float first_true(float guess, Pred pred)
     return __uint_as_float(hi);
 }
 
-// number of keys < v (v >= 0 or +inf): lower bound on the bit patterns
-__device__ __forceinline__ int64_t lower_bound_keys(const uint32_t *__restrict__ keys, int64_t n, float v)
+// number of keys < v (v >= 0 or +inf): lower bound on the bit patterns.  Two levels: first over the blocks' first keys
+// (kb: n / 256 entries, cache-resident -- a plain bisection of the 100 MB key array paid ~15 HBM round trips per border
+// and was most of k_mse_cells' time), then inside the one block that can hold the border.
+__device__ __forceinline__ int64_t lower_bound_keys(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ kb, int64_t n,
+                                                    int64_t nb, float v)
 {
     const uint32_t vb = __float_as_uint(v);
-    int64_t lo = 0, hi = n;
+    int64_t lo = 0, hi = nb;                        // blocks whose first key is < v
     while (lo < hi) {
         const int64_t mid = lo + ((hi - lo) >> 1);
-        if (keys[mid] < vb) lo = mid + 1; else hi = mid;
+        if (kb[mid] < vb) lo = mid + 1; else hi = mid;
     }
-    return lo;
+    if (lo == 0) return 0;
+    // kb[lo - 1] < v <= kb[lo]: everything before block lo - 1's second key is < v, everything from block lo on is not
+    int64_t a = (lo - 1) * kPre + 1, b = lo * kPre < n ? lo * kPre : n;
+    while (a < b) {
+        const int64_t mid = a + ((b - a) >> 1);
+        if (keys[mid] < vb) a = mid + 1; else b = mid;
+    }
+    return a;
 }
 
 struct Moments {
@@ -294,7 +306,7 @@ __device__ __forceinline__ Moments prefix_at(const uint32_t *__restrict__ keys, 
 
 // one workgroup per (mantissa width, candidate); a lane per cell (looping when a format has more than 256 cells)
 __global__ void __launch_bounds__(kBlock)
-k_mse_cells(const uint32_t *__restrict__ keys, const DD *__restrict__ p1, const DD *__restrict__ p2,
+k_mse_cells(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ kb, const DD *__restrict__ p1, const DD *__restrict__ p2,
             const DD *__restrict__ t1, const DD *__restrict__ t2, const float *__restrict__ grid, float *__restrict__ mses, SortedArgs a, double inv_inner, int brute)
 {
     __shared__ float s_scale[kLutMax];     // s_p, p = 1 .. pmax (exact: lut_entry)
@@ -394,7 +406,7 @@ k_mse_cells(const uint32_t *__restrict__ keys, const DD *__restrict__ p1, const 
             q = rf * s;                                          // the fp32 product K1 forms
         }
         if (lo < hi) {
-            const int64_t a0 = lower_bound_keys(keys, n, lo), a1 = lower_bound_keys(keys, n, hi);
+            const int64_t a0 = lower_bound_keys(keys, kb, n, a.nb, lo), a1 = lower_bound_keys(keys, kb, n, a.nb, hi);
             if (a1 > a0) {
                 const Moments m0 = prefix_at(keys, p1, p2, t1, t2, a.nb, a0), m1 = prefix_at(keys, p1, p2, t1, t2, a.nb, a1);
                 // S2 - 2 q S1 + n q^2 in double-double (q^2 of an fp32 q is exact in double); the cell's result is >= 0
@@ -434,7 +446,8 @@ size_t fp8q_mse_sorted_workspace_bytes(int64_t n)
 {
     const int64_t nb = cdiv(n, kPre);
     const int64_t nsb = cdiv(nb, kSuper);
-    return align_up((size_t)n * 4, 256) + 2 * align_up((size_t)(nb + 1) * sizeof(DD), 256) + 2 * align_up((size_t)(nsb + 1) * sizeof(DD), 256) +
+    return align_up((size_t)n * 4, 256) + align_up((size_t)nb * 4, 256) + 2 * align_up((size_t)(nb + 1) * sizeof(DD), 256) +
+           2 * align_up((size_t)(nsb + 1) * sizeof(DD), 256) +
            align_up(sort_temp_bytes(n), 256) + 256;
 }
 
@@ -446,6 +459,8 @@ int fp8q_mse_sorted_launch(const float *x, int64_t n, const float *grid, int64_t
     char *w = (char *)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
     uint32_t *keys = (uint32_t *)w;
     w += align_up((size_t)n * 4, 256);
+    uint32_t *kb = (uint32_t *)w;
+    w += align_up((size_t)nb * 4, 256);
     DD *p1 = (DD *)w;
     w += align_up((size_t)(nb + 1) * sizeof(DD), 256);
     DD *p2 = (DD *)w;
@@ -458,7 +473,7 @@ int fp8q_mse_sorted_launch(const float *x, int64_t n, const float *grid, int64_t
     size_t temp = sort_temp_bytes(n);
     auto in = rocprim::make_transform_iterator(reinterpret_cast<const uint32_t *>(x), AbsBits());
     if (hipError_t e = rocprim::radix_sort_keys((void *)w, temp, in, keys, (size_t)n, 0, 31, st); e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(k_sorted_block_sums, dim3((unsigned)cdiv(nb, kBlock / 16)), dim3(kBlock), 0, st, keys, n, nb, p1, p2);
+    hipLaunchKernelGGL(k_sorted_block_sums, dim3((unsigned)cdiv(nb, kBlock / 16)), dim3(kBlock), 0, st, keys, n, nb, p1, p2, kb);
     if (int rc = launch_rc()) return rc;
     hipLaunchKernelGGL(k_sorted_scan_super, dim3((unsigned)nsb), dim3(kSuper), 0, st, p1, p2, nb, t1, t2);
     if (int rc = launch_rc()) return rc;
@@ -470,7 +485,7 @@ int fp8q_mse_sorted_launch(const float *x, int64_t n, const float *grid, int64_t
     a.n_cand = (int)n_cand;
     a.n = n;
     a.nb = nb;
-    hipLaunchKernelGGL(k_mse_cells, dim3((unsigned)(n_m * n_cand)), dim3(kBlock), 0, st, keys, p1, p2, t1, t2, grid, mses, a,
+    hipLaunchKernelGGL(k_mse_cells, dim3((unsigned)(n_m * n_cand)), dim3(kBlock), 0, st, keys, kb, p1, p2, t1, t2, grid, mses, a,
                        1.0 / (double)n, brute);
     return launch_rc();
 }
