@@ -261,47 +261,93 @@ __device__ __forceinline__ float first_true(float guess, Pred pred)
     return __uint_as_float(hi);
 }
 
-// number of keys < v (v >= 0 or +inf): lower bound on the bit patterns.  Two levels: first over the blocks' first keys
+// number of keys < v (v >= 0 or +inf), for v0 and v1: lower bound on the bit patterns.  Two levels: first over the blocks' first keys
 // (kb: n / 256 entries, cache-resident -- a plain bisection of the 100 MB key array paid ~15 HBM round trips per border
 // and was most of k_mse_cells' time), then inside the one block that can hold the border.
-__device__ __forceinline__ int64_t lower_bound_keys(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ kb, int64_t n,
-                                                    int64_t nb, float v)
+// Both borders of a cell at once: the two chains of dependent loads overlap (a lane has nothing else to do meanwhile).
+__device__ __forceinline__ void lower_bound_keys2(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ kb, int64_t n,
+                                                  int64_t nb, float v0, float v1, int64_t &r0, int64_t &r1)
 {
-    const uint32_t vb = __float_as_uint(v);
-    int64_t lo = 0, hi = nb;                        // blocks whose first key is < v
-    while (lo < hi) {
-        const int64_t mid = lo + ((hi - lo) >> 1);
-        if (kb[mid] < vb) lo = mid + 1; else hi = mid;
+    const uint32_t vb0 = __float_as_uint(v0), vb1 = __float_as_uint(v1);
+    int64_t lo0 = 0, hi0 = nb, lo1 = 0, hi1 = nb;   // blocks whose first key is < v
+    while (lo0 < hi0 || lo1 < hi1) {
+        const bool act0 = lo0 < hi0, act1 = lo1 < hi1;
+        const int64_t m0 = lo0 + ((hi0 - lo0) >> 1), m1 = lo1 + ((hi1 - lo1) >> 1);
+        const uint32_t k0 = kb[act0 ? m0 : 0], k1 = kb[act1 ? m1 : 0];
+        if (act0) {
+            if (k0 < vb0) lo0 = m0 + 1; else hi0 = m0;
+        }
+        if (act1) {
+            if (k1 < vb1) lo1 = m1 + 1; else hi1 = m1;
+        }
     }
-    if (lo == 0) return 0;
     // kb[lo - 1] < v <= kb[lo]: everything before block lo - 1's second key is < v, everything from block lo on is not
-    int64_t a = (lo - 1) * kPre + 1, b = lo * kPre < n ? lo * kPre : n;
-    while (a < b) {
-        const int64_t mid = a + ((b - a) >> 1);
-        if (keys[mid] < vb) a = mid + 1; else b = mid;
+    int64_t a0 = lo0 ? (lo0 - 1) * kPre + 1 : 0, b0 = lo0 ? (lo0 * kPre < n ? lo0 * kPre : n) : 0;
+    int64_t a1 = lo1 ? (lo1 - 1) * kPre + 1 : 0, b1 = lo1 ? (lo1 * kPre < n ? lo1 * kPre : n) : 0;
+    while (a0 < b0 || a1 < b1) {
+        const bool act0 = a0 < b0, act1 = a1 < b1;
+        const int64_t m0 = a0 + ((b0 - a0) >> 1), m1 = a1 + ((b1 - a1) >> 1);
+        const uint32_t k0 = keys[act0 ? m0 : 0], k1 = keys[act1 ? m1 : 0];
+        if (act0) {
+            if (k0 < vb0) a0 = m0 + 1; else b0 = m0;
+        }
+        if (act1) {
+            if (k1 < vb1) a1 = m1 + 1; else b1 = m1;
+        }
     }
-    return a;
+    r0 = a0;
+    r1 = a1;
 }
 
 struct Moments {
     DD s1, s2;
 };
 
-// sums of k and k^2 over keys[0 .. pos)
-__device__ __forceinline__ Moments prefix_at(const uint32_t *__restrict__ keys, const DD *__restrict__ p1,
-                                             const DD *__restrict__ p2, const DD *__restrict__ t1,
-                                             const DD *__restrict__ t2, int64_t nb, int64_t pos)
+// sums of k and k^2 over keys[0 .. pos0) and keys[0 .. pos1): the block prefixes + the keys of the partial block, the two
+// partial walks side by side (four independent double-double chains instead of two; a finished walk adds +0.0, which
+// leaves a double-double unchanged)
+__device__ __forceinline__ void prefix_at2(const uint32_t *__restrict__ keys, const DD *__restrict__ p1, const DD *__restrict__ p2,
+                                           const DD *__restrict__ t1, const DD *__restrict__ t2, int64_t nb, int64_t n, int64_t pos0,
+                                           int64_t pos1, Moments &m0, Moments &m1)
 {
-    const int64_t b = pos / kPre;
-    // (b == nb: pos == n at a block border -- everything: the last superblock's entry would be out of range)
     const int64_t top = (nb + kSuper - 1) / kSuper;
-    Moments m = b < nb ? Moments{dd_add(t1[b / kSuper], p1[b]), dd_add(t2[b / kSuper], p2[b])} : Moments{t1[top], t2[top]};
-    for (int64_t i = b * kPre; i < pos; ++i) {
-        const double k = (double)__uint_as_float(keys[i]);
-        m.s1 = dd_add_d(m.s1, k);
-        m.s2 = dd_add_d(m.s2, k * k);
+    auto head = [&](int64_t b) -> Moments {
+        // (b == nb: pos == n at a block border -- everything: the last superblock's entry would be out of range)
+        return b < nb ? Moments{dd_add(t1[b / kSuper], p1[b]), dd_add(t2[b / kSuper], p2[b])} : Moments{t1[top], t2[top]};
+    };
+    const int64_t bl0 = pos0 / kPre, bl1 = pos1 / kPre;
+    m0 = head(bl0);
+    m1 = head(bl1);
+    // 16 keys of each walk per trip, all eight 16-byte loads issued before the first add: one key per trip waited a full
+    // memory round trip per key (up to 255 of them) and was most of the kernel.  Blocks start 1 KiB-aligned and the key
+    // array is padded to 256 B, so the loads stay inside the workspace; keys at or beyond pos are masked to +0.0.
+    int64_t i0 = bl0 * kPre, i1 = bl1 * kPre;
+    while (i0 < pos0 || i1 < pos1) {
+        const uint4 *q0 = reinterpret_cast<const uint4 *>(keys + (i0 < pos0 ? i0 : 0));
+        const uint4 *q1 = reinterpret_cast<const uint4 *>(keys + (i1 < pos1 ? i1 : 0));
+        uint4 v0[4], v1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            v0[u] = q0[u];
+            v1[u] = q1[u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t w0[4] = {v0[u].x, v0[u].y, v0[u].z, v0[u].w}, w1[4] = {v1[u].x, v1[u].y, v1[u].z, v1[u].w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int j = 4 * u + c;
+                const double k0 = i0 + j < pos0 ? (double)__uint_as_float(w0[c]) : 0.0;
+                const double k1 = i1 + j < pos1 ? (double)__uint_as_float(w1[c]) : 0.0;
+                m0.s1 = dd_add_d(m0.s1, k0);
+                m0.s2 = dd_add_d(m0.s2, k0 * k0);
+                m1.s1 = dd_add_d(m1.s1, k1);
+                m1.s2 = dd_add_d(m1.s2, k1 * k1);
+            }
+        }
+        i0 += 16;
+        i1 += 16;
     }
-    return m;
 }
 
 // one workgroup per (mantissa width, candidate); a lane per cell (looping when a format has more than 256 cells)
@@ -406,9 +452,11 @@ k_mse_cells(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ kb, 
             q = rf * s;                                          // the fp32 product K1 forms
         }
         if (lo < hi) {
-            const int64_t a0 = lower_bound_keys(keys, kb, n, a.nb, lo), a1 = lower_bound_keys(keys, kb, n, a.nb, hi);
+            int64_t a0, a1;
+            lower_bound_keys2(keys, kb, n, a.nb, lo, hi, a0, a1);
             if (a1 > a0) {
-                const Moments m0 = prefix_at(keys, p1, p2, t1, t2, a.nb, a0), m1 = prefix_at(keys, p1, p2, t1, t2, a.nb, a1);
+                Moments m0, m1;
+                prefix_at2(keys, p1, p2, t1, t2, a.nb, n, a0, a1, m0, m1);
                 // S2 - 2 q S1 + n q^2 in double-double (q^2 of an fp32 q is exact in double); the cell's result is >= 0
                 const double qd = (double)q, cnt = (double)(a1 - a0);
                 const DD d2 = dd_add(m1.s2, dd_neg(m0.s2)), d1 = dd_add(m1.s1, dd_neg(m0.s1));
