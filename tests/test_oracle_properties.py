@@ -80,3 +80,33 @@ def test_minmax_fold_is_associative(seed, splits):
         cur = oracle.c_fold(cur[0], cur[1], mn, mx, 1)
     np.testing.assert_array_equal(cur[0], whole[0])
     np.testing.assert_array_equal(cur[1], whole[1])
+
+
+def test_minmax_signed_zero_is_order_independent():
+    """IEEE 754-2019 minimum / maximum: a zero minimum is -0.0 iff the row holds a -0.0, a zero maximum +0.0 iff it holds a
+    +0.0 -- whatever the order of the elements (ATen returns whichever zero its reduction met first; include/fp8q.h)."""
+    import oracle
+    rng = np.random.RandomState(0)
+    base = np.array([0.0, -0.0, 0.0, 0.0, -0.0, 0.5, 0.25], np.float32)
+    for _ in range(20):
+        row = rng.permutation(base)
+        mn, mx = oracle.c_minmax(row.reshape(1, -1), True)
+        assert mn[0] == 0 and np.signbit(mn[0]) and mx[0] == 0.5
+        mn, mx = oracle.c_minmax(-row.reshape(1, -1), True)
+        assert mx[0] == 0 and not np.signbit(mx[0]) and mn[0] == -0.5
+        mn64, mx64 = oracle.c_minmax_f64(-row.astype(np.float64).reshape(1, -1), True)
+        assert mx64[0] == 0 and not np.signbit(mx64[0])
+    only_pos = np.zeros((1, 5), np.float32)
+    mn, mx = oracle.c_minmax(only_pos, True)
+    assert not np.signbit(mn[0]) and not np.signbit(mx[0])
+    mn, mx = oracle.c_minmax(-only_pos, True)
+    assert np.signbit(mn[0]) and np.signbit(mx[0])
+    long_row = np.zeros((1, (1 << 20) + 5), np.float32)      # the thread-parallel branch
+    long_row[0, 12345] = -0.0
+    mn, mx = oracle.c_minmax(long_row, True)
+    assert np.signbit(mn[0]) and not np.signbit(mx[0])
+    # the allminmax fold of two estimates
+    cmn, cmx = oracle.c_fold(np.float32([0.0]), np.float32([-0.0]), np.float32([-0.0]), np.float32([0.0]), 1)
+    assert np.signbit(cmn[0]) and not np.signbit(cmx[0])
+    cmn, cmx = oracle.c_fold(np.float32([-0.0]), np.float32([0.0]), np.float32([0.0]), np.float32([-0.0]), 1)
+    assert np.signbit(cmn[0]) and not np.signbit(cmx[0])
