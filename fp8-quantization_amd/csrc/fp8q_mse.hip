@@ -552,26 +552,32 @@ k_mse_select_vote(const int *__restrict__ sel, const float *__restrict__ grid, i
 
 }  // namespace
 
-// fp8q_mse_sorted.hip: sort-once evaluation of many candidates on one long row
-size_t fp8q_mse_sorted_workspace_bytes(int64_t n);
-int fp8q_mse_sorted_launch(const float *x, int64_t n, const float *grid, int64_t n_cand, const QFmt *fmts, int n_m, float *mses,
-                           void *ws, size_t ws_bytes, hipStream_t st, int brute);
+// fp8q_mse_hist.hip: partition-once / interval-histogram evaluation of all candidates on one long row
+size_t fp8q_mse_hist_workspace_bytes(int64_t n, int64_t n_pairs);
+bool fp8q_mse_hist_supported(const QFmt *fmts, int n_m, int n_bits);
+int fp8q_mse_hist_launch(const float *x, int64_t n, const float *grid, int64_t n_cand, const QFmt *fmts, int n_m, float *mses,
+                         void *ws, size_t ws_bytes, hipStream_t st, int brute);
 
-// FP8Q_MSE_SORTED: 1 (default) = per-tensor rows of >= 2^20 elements with >= 256 (width, candidate) pairs of a signed format go
-// through the sorted evaluation; 0 = never; 2 = sorted routing with every candidate evaluated element by element (self-check)
-static int mse_sorted_mode()
+// FP8Q_MSE_HIST: 1 (default) = long per-tensor rows of a signed format of <= 8 bits go through the interval-histogram
+// evaluation; 0 = never (the lane-per-element kernel everywhere); 2 = same routing with every candidate evaluated element by
+// element (the self-check of the cell logic the tests use)
+static int mse_hist_mode()
 {
     static const int v = [] {
-        const char *e = getenv("FP8Q_MSE_SORTED");
+        const char *e = getenv("FP8Q_MSE_HIST");
         return e ? atoi(e) : 1;
     }();
     return v;
 }
 
-static bool mse_use_sorted(int64_t C, int64_t inner, int64_t n_cand, int n_m, int sign_bits)
+// The route costs ~kHistFixed of launches plus ~kHistPerKey per element whatever the number of candidates; k_mse_row costs
+// ~kRowPerPair per (element, width, candidate).  (Measured on MI355X: profiles/r05_mse_kernel_stats.csv.)
+static bool mse_use_hist_shape(int64_t C, int64_t inner, int64_t n_cand, int n_m)
 {
-    return mse_sorted_mode() != 0 && C == 1 && sign_bits == 1 && inner >= (1 << 20) && inner < (1ll << 31) &&
-           (int64_t)n_m * n_cand >= 256;
+    if (mse_hist_mode() == 0 || C != 1 || inner < (1 << 18) || inner >= (1ll << 31)) return false;
+    const double row = (double)inner * (double)(n_m * n_cand) * 0.19e-12;
+    const double hist = 60e-6 + (double)inner * 7e-12;
+    return row > hist;
 }
 
 extern "C" {
@@ -665,9 +671,9 @@ static RowGeo mse_row_geo(int64_t C, int64_t inner, int64_t n_cand, int n_m)
 size_t fp8q_mse_workspace_bytes(int64_t C, int64_t inner, int64_t n_cand, int n_m)
 {
     if (C <= 0 || inner <= 0 || n_cand <= 0 || n_m <= 0) return 16;
-    // (the format's sign is not known here: the sorted path's size is returned whenever the shape could take it)
-    if (mse_use_sorted(C, inner, n_cand, n_m, 1)) {
-        const size_t a = fp8q_mse_sorted_workspace_bytes(inner);
+    // (the format is not known here: the histogram route's size is returned whenever the shape could take it)
+    if (mse_use_hist_shape(C, inner, n_cand, n_m)) {
+        const size_t a = fp8q_mse_hist_workspace_bytes(inner, n_cand * n_m);
         const int64_t ns0 = mse_use_row(C, inner) ? mse_row_geo(C, inner, n_cand, n_m).nblk : mse_nsplit(C, inner, n_cand, n_m);
         const size_t b = (size_t)C * n_m * n_cand * ns0 * sizeof(double) + 16;
         return a > b ? a : b;
@@ -699,8 +705,8 @@ int fp8q_mse_grid_f32(const float *x, int64_t C, int64_t inner, const float *gri
     a.inner = inner;
     a.C = C;
     hipStream_t st = (hipStream_t)stream;
-    if (mse_use_sorted(C, inner, n_cand, n_m, sign_bits))
-        return fp8q_mse_sorted_launch(x, inner, grid, n_cand, a.fmt, n_m, mses, ws, ws_bytes, st, mse_sorted_mode() == 2);
+    if (mse_use_hist_shape(C, inner, n_cand, n_m) && fp8q_mse_hist_supported(a.fmt, n_m, n_bits))
+        return fp8q_mse_hist_launch(x, inner, grid, n_cand, a.fmt, n_m, mses, ws, ws_bytes, st, mse_hist_mode() == 2);
     int64_t nsplit = a.nsplit;
     if (mse_use_row(C, inner) && ((uintptr_t)x & 3) == 0) {
         const RowGeo g = mse_row_geo(C, inner, n_cand, n_m);

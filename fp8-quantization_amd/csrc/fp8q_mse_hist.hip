@@ -1,0 +1,1019 @@
+// fp8q_mse_hist.hip -- K4 for one long row (per-tensor activations): partition once, then every candidate costs ~200 lookups.
+//
+// The candidate loops of FP_MSE_Estimator.forward (quantization/range_estimators.py:337-347) evaluate 111 (x 6 with the
+// mantissa search of the reference CLI's default) quantizers on the same tensor; LineSearchEstimator (:236-256) evaluates
+// 1000.  k_mse_row (fp8q_mse.hip) does that at 4-7 VALU issue slots per candidate-element and is VALU-bound.  But a
+// quantizer is a STEP FUNCTION of |x|: for one candidate (maxval, M) the keys k = |x| fall into <= (2^E + 1) 2^M + 2 cells,
+// each mapped to one grid value q, and
+//     sum over a cell of (k - q)^2 = S2 - 2 q S1 + n q^2     with n, S1 = sum k, S2 = sum k^2 of the cell's keys.
+// All cells of all candidates are unions of the INTERVALS between consecutive cell borders (~15 K borders for 111
+// candidates, ~100 K for 666), so what is needed is n / S1 / S2 per interval -- a histogram with moments, not a sort:
+//   1. k_mse_borders  one workgroup per candidate: the exact border of every cell -- the smallest float for which the
+//                     reference's own fp32 decisions (floor(fl32(log2 k) + bias) >= p, rint(fl32(k / s_p)) >= r,
+//                     k > maxval) flip, located by guess-and-walk on the exact predicates -- and the cell's grid value.
+//   2. k_part_hist / k_part_scatter   ONE most-significant-digit partition of the nonzero keys by their top 11 bits
+//                     (exponent + 3 fraction bits: 2048 coarse buckets): LDS histogram, then a tile-local counting sort in
+//                     LDS so that every (tile, bucket) run leaves as contiguous 4-byte stores.  Zeros (half of a post-ReLU
+//                     tensor) contribute nothing to any candidate and are dropped.
+//   3. k_border_sort  the borders, bucketed the same way, are sorted per bucket in LDS (bitonic network on
+//                     {value, owner} pairs); every border learns its global rank.
+//   4. k_moments      per (bucket, slice of its keys): the bucket's sorted borders sit in LDS, a key finds its interval
+//                     with a 64-entry sub-bin table + a short bisection and adds {1, d, d^2}, d = its low 20 bits, to the
+//                     interval's LDS counters with INTEGER atomics: exact, order-independent -> deterministic.
+//   5. k_iv_scan_*    intervals -> S1, S2 as exact double-double numbers (k = (A_bucket + d) * ulp), exclusive prefix.
+//   6. k_mse_eval     one workgroup per candidate, a lane per cell: two prefix lookups, S2 - 2 q S1 + n q^2 in
+//                     double-double (the three terms cancel: on data that sit on the grid the squared error is 1e-13 of
+//                     the signal energy), fixed-tree sum, mses += mean.
+// Every element is classified exactly as K1 / the oracle classify it; what differs from the reference is only that
+// (k - q)^2 is summed in (near-)exact arithmetic instead of fp32-rounded per element: ~1e-7 relative, inside K4's stated
+// contract (include/fp8q.h).  Cost for a 25.7 M-element activation: ~8 B of HBM traffic per key for the partition + 4 B for
+// the moments, independent of the number of candidates.  No library primitive: everything here is hand-written.
+#include "fp8q_common.h"
+
+namespace {
+
+constexpr int kHShift = 20;                         // key bits below the coarse bucket: d = key & (2^20 - 1)
+constexpr int kHBuckets = 1 << (31 - kHShift);      // 2048 = 8 exponent bits + 3 fraction bits
+constexpr uint32_t kHMask = (1u << kHShift) - 1u;
+constexpr int kHSubBits = 6;                        // sub-bin table of k_moments: next 6 key bits
+constexpr int kHSub = 1 << kHSubBits;
+constexpr int kPartTile = 8192;                     // keys per partition tile (32 per thread)
+constexpr int kHistMaxM = 8;
+constexpr int kSuper = 1024;                        // intervals per scan superblock
+constexpr int kSortLds = 4096;                      // borders of one bucket sorted in LDS (more: same network on global memory)
+
+typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(4)));
+
+struct HistArgs {
+    QFmt fmt[kHistMaxM];
+    int ncells[kHistMaxM];       // cells of width m: 2^(M+1) + 1 + (pmax - 1)(2^M + 1) + 1 (the clamp cell)
+    int n_m, n_cand;
+    int stride;                  // max ncells: row pitch of the per-candidate border tables
+    int64_t n;                   // elements of the row
+};
+
+// ---- double-double: value = hi + lo, |lo| <= ulp(hi) / 2.  Error-free transformations only (no fast-math in this build).
+struct DD {
+    double hi, lo;
+};
+
+__device__ __forceinline__ DD two_sum(double a, double b)
+{
+    const double s = a + b, bb = s - a;
+    return DD{s, (a - (s - bb)) + (b - bb)};
+}
+
+__device__ __forceinline__ DD fast_two_sum(double a, double b)   // |a| >= |b| (or a == 0)
+{
+    const double s = a + b;
+    return DD{s, b - (s - a)};
+}
+
+__device__ __forceinline__ DD dd_add(DD x, DD y)                  // accurate variant: safe when the high parts cancel
+{
+    DD s = two_sum(x.hi, y.hi);
+    const DD t = two_sum(x.lo, y.lo);
+    s.lo += t.hi;
+    s = fast_two_sum(s.hi, s.lo);
+    s.lo += t.lo;
+    return fast_two_sum(s.hi, s.lo);
+}
+
+__device__ __forceinline__ DD dd_add_d(DD x, double y)
+{
+    DD s = two_sum(x.hi, y);
+    s.lo += x.lo;
+    return fast_two_sum(s.hi, s.lo);
+}
+
+__device__ __forceinline__ DD dd_neg(DD x) { return DD{-x.hi, -x.lo}; }
+
+__device__ __forceinline__ DD two_prod(double a, double b)
+{
+    const double p = a * b;
+    return DD{p, fma(a, b, -p)};
+}
+
+__device__ __forceinline__ DD dd_mul_d(DD x, double y)
+{
+    DD p = two_prod(x.hi, y);
+    p.lo = fma(x.lo, y, p.lo);
+    return fast_two_sum(p.hi, p.lo);
+}
+
+__device__ __forceinline__ DD dd_shfl_up(DD v, int off) { return DD{__shfl_up(v.hi, off, 64), __shfl_up(v.lo, off, 64)}; }
+__device__ __forceinline__ DD dd_shfl(DD v, int lane) { return DD{__shfl(v.hi, lane, 64), __shfl(v.lo, lane, 64)}; }
+
+// an unsigned 64-bit integer as an exact double-double (two 32-bit halves are exact doubles)
+__device__ __forceinline__ DD dd_from_u64(uint64_t v)
+{
+    return fast_two_sum((double)(v >> 32) * 4294967296.0, (double)(uint32_t)v);
+}
+
+__device__ __forceinline__ DD dd_scale2(DD x, int e) { return DD{ldexp(x.hi, e), ldexp(x.lo, e)}; }   // exact (no underflow: see k_iv_scan_super)
+
+// ---- block scans ------------------------------------------------------------------------------------------------------
+// exclusive scan of one value per thread over a block of NT threads (NT / 64 waves); `total` = the block's sum.
+// s_w: NT / 64 words of LDS; ends with a barrier, so it can be called again right away.
+template <int NT>
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *s_w, uint32_t &total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) {
+        const uint32_t t = s_w[w];
+        if (w < wave) base += t;
+        tot += t;
+    }
+    __syncthreads();
+    total = tot;
+    return base + incl - v;
+}
+
+// ---- 2. partition -----------------------------------------------------------------------------------------------------
+// 32 keys of a tile per thread (|x| bit patterns); a tile's last, partial part reads element by element
+__device__ __forceinline__ void load_tile_keys(const uint32_t *__restrict__ x, int64_t n, int64_t base, uint32_t (&k)[32])
+{
+    const int tid = threadIdx.x;
+    if (base + kPartTile <= n) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const u32x4u v = *reinterpret_cast<const u32x4u *>(x + base + u * 1024 + tid * 4);
+            k[4 * u] = v.x & 0x7fffffffu;
+            k[4 * u + 1] = v.y & 0x7fffffffu;
+            k[4 * u + 2] = v.z & 0x7fffffffu;
+            k[4 * u + 3] = v.w & 0x7fffffffu;
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int64_t i = base + u * 1024 + tid * 4 + q;
+                k[4 * u + q] = i < n ? (x[i] & 0x7fffffffu) : 0u;
+            }
+    }
+}
+
+// Workgroup w of both partition passes owns the tiles [w * tpw, (w + 1) * tpw): pass A leaves its bucket counts as row w of
+// `ktab`, k_tab_scan turns every column into exclusive prefixes over the workgroups, and pass B starts workgroup w's run of
+// bucket b at koff[b] + ktab[w][b] -- no global atomics anywhere (a first version reserved space with one returning atomic
+// per (tile, bucket) on a 2048-word cursor array: 1.9 M atomics into two memory channels, 481 us for 25.7 M keys).
+__global__ void __launch_bounds__(kBlock)
+k_part_hist(const uint32_t *__restrict__ x, int64_t n, int64_t ntiles, int tpw, uint32_t *__restrict__ ktab,
+            uint32_t *__restrict__ kmax)
+{
+    __shared__ uint32_t s_hist[kHBuckets];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < kHBuckets; i += kBlock) s_hist[i] = 0u;
+    __syncthreads();
+    uint32_t mk = 0u;
+    const int64_t t0 = (int64_t)blockIdx.x * tpw, t1 = min(t0 + tpw, ntiles);
+    for (int64_t t = t0; t < t1; ++t) {
+        uint32_t k[32];
+        load_tile_keys(x, n, t * kPartTile, k);
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            mk = max(mk, k[j]);
+            if (k[j]) atomicAdd(&s_hist[k[j] >> kHShift], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < kHBuckets; i += kBlock) ktab[(int64_t)blockIdx.x * kHBuckets + i] = s_hist[i];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mk = max(mk, (uint32_t)__shfl_xor((int)mk, off, 64));
+    __shared__ uint32_t s_mk[kBlock / 64];
+    if ((tid & 63) == 0) s_mk[tid >> 6] = mk;
+    __syncthreads();
+    if (tid == 0) kmax[blockIdx.x] = max(max(s_mk[0], s_mk[1]), max(s_mk[2], s_mk[3]));
+}
+
+// Exclusive prefix down every column of a [rows, 2048] count table (in place) + the column totals.  One workgroup scans 64
+// columns: thread (q, col) walks a quarter of the rows of its column, the quarters are stitched through LDS.
+// blockIdx.y selects the table: 0 = keys (rows = partition workgroups), 1 = borders (rows = candidates).
+__global__ void __launch_bounds__(kBlock)
+k_tab_scan(uint32_t *__restrict__ ktab, int krows, uint32_t *__restrict__ ktot, uint32_t *__restrict__ btab, int brows,
+           uint32_t *__restrict__ btot)
+{
+    __shared__ uint32_t s_q[4][64];
+    uint32_t *tab = blockIdx.y ? btab : ktab;
+    const int rows = blockIdx.y ? brows : krows;
+    uint32_t *tot = blockIdx.y ? btot : ktot;
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+    const int per = (rows + 3) / 4, r0 = q * per, r1 = min(r0 + per, rows);
+    uint32_t sum = 0u;
+    for (int r = r0; r < r1; ++r) sum += tab[(int64_t)r * kHBuckets + col];
+    s_q[q][threadIdx.x & 63] = sum;
+    __syncthreads();
+    uint32_t run = 0u;
+    for (int w = 0; w < q; ++w) run += s_q[w][threadIdx.x & 63];
+    for (int r = r0; r < r1; ++r) {
+        const int64_t i = (int64_t)r * kHBuckets + col;
+        const uint32_t c = tab[i];
+        tab[i] = run;
+        run += c;
+    }
+    if (q == 3) tot[col] = run;
+}
+
+// scatter: per tile a counting sort by bucket in LDS (ranks from returning LDS atomics), then position p of the sorted
+// tile goes to delta[bucket] + p: consecutive lanes write consecutive addresses within a run.  The order of the keys inside
+// a (workgroup, bucket) run depends on the LDS atomics' timing; nothing downstream depends on it (integer moments).
+__global__ void __launch_bounds__(kBlock)
+k_part_scatter(const uint32_t *__restrict__ x, int64_t n, int64_t ntiles, int tpw, const uint32_t *__restrict__ koff,
+               const uint32_t *__restrict__ ktab, uint32_t *__restrict__ out)
+{
+    __shared__ uint32_t s_hist[kHBuckets];     // counts, then the bucket's first position in the sorted tile
+    __shared__ uint32_t s_delta[kHBuckets];    // global index of the run minus its first position
+    __shared__ uint32_t s_keys[kPartTile];
+    __shared__ uint32_t s_w[kBlock / 64];
+    const int tid = threadIdx.x;
+    constexpr int kPer = kHBuckets / kBlock;   // 8 consecutive buckets per thread in the scan
+    uint32_t cur[kPer];                        // where this workgroup's next key of buckets tid * 8 .. tid * 8 + 7 goes
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) cur[q] = koff[tid * kPer + q] + ktab[(int64_t)blockIdx.x * kHBuckets + tid * kPer + q];
+    const int64_t t0 = (int64_t)blockIdx.x * tpw, t1 = min(t0 + tpw, ntiles);
+    for (int64_t t = t0; t < t1; ++t) {
+        for (int i = tid; i < kHBuckets; i += kBlock) s_hist[i] = 0u;
+        __syncthreads();
+        uint32_t k[32];
+        uint16_t rk[32];
+        load_tile_keys(x, n, t * kPartTile, k);
+#pragma unroll
+        for (int j = 0; j < 32; ++j) rk[j] = k[j] ? (uint16_t)atomicAdd(&s_hist[k[j] >> kHShift], 1u) : (uint16_t)0;
+        __syncthreads();
+        uint32_t c[kPer], sum = 0u;
+#pragma unroll
+        for (int q = 0; q < kPer; ++q) {
+            c[q] = s_hist[tid * kPer + q];
+            sum += c[q];
+        }
+        uint32_t total;
+        uint32_t run = block_excl_scan<kBlock>(sum, s_w, total);
+#pragma unroll
+        for (int q = 0; q < kPer; ++q) {
+            const int b = tid * kPer + q;
+            s_delta[b] = cur[q] - run;
+            cur[q] += c[q];
+            s_hist[b] = run;
+            run += c[q];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 32; ++j)
+            if (k[j]) s_keys[s_hist[k[j] >> kHShift] + rk[j]] = k[j];
+        __syncthreads();
+        for (uint32_t p = tid; p < total; p += kBlock) {
+            const uint32_t key = s_keys[p];
+            out[s_delta[key >> kHShift] + p] = key;
+        }
+        __syncthreads();
+    }
+}
+
+// ---- 1. borders -------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float next_up(float a) { return __uint_as_float(__float_as_uint(a) + 1u); }     // a >= 0, finite
+__device__ __forceinline__ float next_down(float a) { return __uint_as_float(__float_as_uint(a) - 1u); }   // a > 0
+
+// smallest non-negative float k with pred(k), for a predicate that is monotone (false ... false true ... true) on
+// [0, +inf]; `guess` should be close.  Walks at most 8 steps, then bisects the bit patterns (always terminates).
+template <class Pred>
+__device__ __forceinline__ float first_true(float guess, Pred pred)
+{
+    if (!(guess >= 0.0f)) guess = 0.0f;
+    if (!(guess < __builtin_inff())) guess = 0x1.fffffep127f;
+    float g = guess;
+    if (pred(g)) {
+        for (int i = 0; i < 8; ++i) {
+            if (g == 0.0f) return 0.0f;
+            const float d = next_down(g);
+            if (!pred(d)) return g;
+            g = d;
+        }
+        uint32_t lo = 0u, hi = __float_as_uint(g);            // pred(hi) true; find the first true in [lo, hi]
+        if (pred(0.0f)) return 0.0f;
+        while (hi - lo > 1u) {                                 // invariant: !pred(lo), pred(hi)
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            if (pred(__uint_as_float(mid))) hi = mid; else lo = mid;
+        }
+        return __uint_as_float(hi);
+    }
+    for (int i = 0; i < 8; ++i) {
+        g = next_up(g);
+        if (!(g < __builtin_inff())) return __builtin_inff();
+        if (pred(g)) return g;
+    }
+    uint32_t lo = __float_as_uint(g), hi = 0x7f800000u;       // !pred(lo); +inf counts as true
+    while (hi - lo > 1u) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (pred(__uint_as_float(mid))) hi = mid; else lo = mid;
+    }
+    return __uint_as_float(hi);
+}
+
+constexpr int kFlagCells = 0, kFlagBrute = 1, kFlagNaN = 2;
+
+// The cells of candidate (m, cand) in ascending order: binade p = 1 holds r = 0 .. 2^(M+1), binades p >= 2 hold
+// r = 2^M .. 2^(M+1), then the clamp cell (keys above maxval).  Cell c covers [T[c], T[c+1]) (T of the clamp cell's end is
+// +inf) and maps to q[c]; T is non-decreasing, an empty cell has T[c] == T[c+1].
+// T(p, r) = min(clamp_from, clamp(first k of binade p with rint(fl32(k / s_p)) >= r, L_p, L_(p+1))), L_p = smallest key of
+// binade p by K1's exact decision.  A candidate whose scales are not positive normal numbers (E = 7 formats with a tiny
+// maxval underflow s_1 to 0: the reference then yields NaN for the elements of that binade) has no cells: it is flagged for
+// the element-by-element evaluation; maxval 0 / inf / NaN makes every element NaN.
+__global__ void __launch_bounds__(kBlock)
+k_mse_borders(const float *__restrict__ grid, HistArgs a, int brute, float *__restrict__ bt, float *__restrict__ bq,
+              int *__restrict__ cflag, uint32_t *__restrict__ btab)
+{
+    __shared__ float s_scale[kLutMax];     // s_p, p = 1 .. pmax (exact: lut_entry)
+    __shared__ float s_border[kLutMax];    // L_p (L_1 = 0, L_(pmax+1) = +inf)
+    __shared__ uint32_t s_hist[kHBuckets]; // this candidate's borders per coarse bucket -> row j of btab
+    const int tid = threadIdx.x;
+    for (int i = tid; i < kHBuckets; i += kBlock) s_hist[i] = 0u;
+    uint32_t *row = btab + (int64_t)blockIdx.x * kHBuckets;
+    const int j = blockIdx.x, m = j / a.n_cand, cand = j - m * a.n_cand;
+    const QFmt f = a.fmt[m];
+    const float gv = grid[cand];
+    const float mv = fabsf(fmaxf(fabsf(-gv), gv));              // set_quant_range(-g, g): fp8_quantizer.py:236
+    const Chan ch = make_chan(mv, f);
+    const int M = (int)f.M, pmax = f.pmax;
+    if (!(fabsf(ch.bias) < __builtin_inff())) {                 // maxval 0 / inf / NaN: every element quantizes to NaN
+        if (tid == 0) cflag[j] = kFlagNaN;
+        for (int i = tid; i < kHBuckets; i += kBlock) row[i] = 0u;
+        return;
+    }
+    const float pmaxf = (float)pmax;
+    auto p_of = [&](float k) -> float {                         // K1's exact binade decision (quant_exact)
+        const float ls = floorf(log2_tab(k, kFastTab) + ch.bias);
+        return __builtin_amdgcn_fmed3f(ls, 1.0f, pmaxf);
+    };
+    for (int p = tid + 1; p <= pmax + 1; p += kBlock) {
+        if (p <= pmax) s_scale[p] = lut_entry(ch, p, f.M).x;
+        float L = 0.0f;
+        if (p > pmax) {
+            L = __builtin_inff();
+        } else if (p >= 2) {
+            const float pf = (float)p;
+            L = first_true((float)ldexp(ch.g, p - ch.bi), [&](float k) { return p_of(k) >= pf; });   // ~2^(p - bias)
+        }
+        s_border[p] = L;
+    }
+    __syncthreads();
+    bool odd = brute != 0;
+    for (int p = 1; p <= pmax; ++p) odd |= !(s_scale[p] >= 0x1p-126f && s_scale[p] < __builtin_inff());
+    if (odd) {
+        if (tid == 0) cflag[j] = kFlagBrute;
+        for (int i = tid; i < kHBuckets; i += kBlock) row[i] = 0u;
+        return;
+    }
+    if (tid == 0) cflag[j] = kFlagCells;
+    const float clamp_from = next_up(mv);                        // keys >= this are clipped to maxval (mv finite here)
+    const int r_top = 2 << M, r_norm = 1 << M;
+    const int n_first = r_top + 1, n_other = r_norm + 1;
+    const int ncells = a.ncells[m];                              // n_first + (pmax - 1) * n_other + 1
+    float *T = bt + (int64_t)j * a.stride, *Q = bq + (int64_t)j * a.stride;
+    for (int c = tid; c < ncells; c += kBlock) {
+        float lo, q;
+        if (c == ncells - 1) {                                   // clipped elements: xc = maxval
+            const float sc = s_scale[(int)p_of(mv)];
+            q = rintf(mv / sc) * sc;
+            lo = clamp_from;
+        } else {
+            int p, r;
+            if (c < n_first) {
+                p = 1;
+                r = c;
+            } else {
+                const int cc = c - n_first;
+                p = 2 + cc / n_other;
+                r = r_norm + (cc - (p - 2) * n_other);
+            }
+            const float s = s_scale[p];
+            const float rf = (float)r;
+            const int r_lo = p == 1 ? 0 : r_norm;
+            lo = s_border[p];
+            if (r > r_lo) {
+                // smallest k with rint(fl32(k / s)) >= r (IEEE division, as K1 decides), kept inside the binade
+                const float ft = first_true((float)(((double)r - 0.5) * (double)s), [&](float k) { return rintf(k / s) >= rf; });
+                lo = fmaxf(lo, fminf(ft, s_border[p + 1]));
+            }
+            lo = fminf(lo, clamp_from);
+            q = rf * s;                                          // the fp32 product K1 forms
+        }
+        T[c] = lo;
+        Q[c] = q;
+        if (c) atomicAdd(&s_hist[__float_as_uint(lo) >> kHShift], 1u);
+    }
+    __syncthreads();
+    for (int i = tid; i < kHBuckets; i += kBlock) row[i] = s_hist[i];
+}
+
+// ---- plan: offsets of keys and borders per bucket, the work units of k_moments ------------------------------------------
+// A unit = (bucket, chunk of <= bcap sorted borders of the bucket, slice of the bucket's keys).  The slice length grows
+// with the number of borders so that flushing the LDS counters stays a small part of a unit's work.
+struct __attribute__((aligned(32))) Unit {
+    uint32_t b_ch;      // bucket | chunk << 16
+    uint32_t key0, kn;  // first key (index into the partitioned array) and count
+    uint32_t bo, nb;    // the bucket's first sorted border and its border count
+    uint32_t pad[3];
+};
+
+__device__ __forceinline__ uint32_t slice_len(uint32_t nb, int slice_min)
+{
+    uint32_t s = ((16u * (nb + 1u)) + 4095u) & ~4095u;
+    if (s < (uint32_t)slice_min) s = (uint32_t)slice_min;
+    if (s > 65536u) s = 65536u;       // counters pack {n, sum d} into 64 bits: n < 2^24, sum d < 2^40
+    return s;
+}
+
+__global__ void __launch_bounds__(1024)
+k_mse_plan(const uint32_t *__restrict__ hist, const uint32_t *__restrict__ bhist, const uint32_t *__restrict__ kmax, int nkmax,
+           uint32_t *__restrict__ koff, uint32_t *__restrict__ boff, Unit *__restrict__ units, uint32_t *__restrict__ nunits,
+           uint32_t *__restrict__ maxkey, uint32_t units_max, int bcap, int slice_min)
+{
+    __shared__ uint32_t s_w[16];
+    const int tid = threadIdx.x;
+    uint32_t ck[2], cb[2], cu[2], sk = 0, sb = 0, su = 0;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int b = tid * 2 + q;
+        ck[q] = hist[b];
+        cb[q] = bhist[b];
+        const uint32_t nch = cb[q] ? (cb[q] + bcap - 1) / bcap : 1u;
+        const uint32_t sl = slice_len(cb[q] < (uint32_t)bcap ? cb[q] : (uint32_t)bcap, slice_min);
+        cu[q] = ck[q] ? nch * ((ck[q] + sl - 1) / sl) : 0u;
+        sk += ck[q];
+        sb += cb[q];
+        su += cu[q];
+    }
+    uint32_t tk, tb, tu;
+    uint32_t ek = block_excl_scan<1024>(sk, s_w, tk);
+    uint32_t eb = block_excl_scan<1024>(sb, s_w, tb);
+    uint32_t eu = block_excl_scan<1024>(su, s_w, tu);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int b = tid * 2 + q;
+        koff[b] = ek;
+        boff[b] = eb;
+        if (ck[q]) {
+            const uint32_t nch = cb[q] ? (cb[q] + bcap - 1) / bcap : 1u;
+            const uint32_t sl = slice_len(cb[q] < (uint32_t)bcap ? cb[q] : (uint32_t)bcap, slice_min);
+            uint32_t u = eu;
+            for (uint32_t chn = 0; chn < nch; ++chn)
+                for (uint32_t k0 = 0; k0 < ck[q]; k0 += sl, ++u)
+                    if (u < units_max) units[u] = Unit{(uint32_t)b | (chn << 16), ek + k0, min(sl, ck[q] - k0), eb, cb[q], {0u, 0u, 0u}};
+        }
+        ek += ck[q];
+        eb += cb[q];
+        eu += cu[q];
+    }
+    if (tid == 1023) {
+        koff[kHBuckets] = tk;
+        boff[kHBuckets] = tb;
+        nunits[0] = tu < units_max ? tu : units_max;   // (units_max is a proven bound: see hist_layout)
+    }
+    // the largest key of the row (non-finite data): max over the partition workgroups
+    uint32_t mk = 0u;
+    for (int i = tid; i < nkmax; i += 1024) mk = max(mk, kmax[i]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mk = max(mk, (uint32_t)__shfl_xor((int)mk, off, 64));
+    if ((tid & 63) == 0) s_w[tid >> 6] = mk;
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 16; ++w) mk = max(mk, s_w[w]);
+        maxkey[0] = mk;
+    }
+}
+
+// every border (cells 1 .. ncells - 1 of the candidates that have cells) into its bucket's segment, tagged with its owner:
+// candidate j's borders of bucket b start at boff[b] + btab[j][b] (k_tab_scan), ranks inside the run from LDS atomics
+__global__ void __launch_bounds__(kBlock)
+k_border_scatter(const float *__restrict__ bt, const int *__restrict__ cflag, HistArgs a, const uint32_t *__restrict__ boff,
+                 const uint32_t *__restrict__ btab, uint64_t *__restrict__ pairs)
+{
+    __shared__ uint32_t s_cnt[kHBuckets];
+    const int tid = threadIdx.x, j = blockIdx.x, m = j / a.n_cand;
+    if (cflag[j] != kFlagCells) return;
+    for (int i = tid; i < kHBuckets; i += kBlock) s_cnt[i] = 0u;
+    __syncthreads();
+    const uint32_t *row = btab + (int64_t)j * kHBuckets;
+    const int ncells = a.ncells[m];
+    for (int c = 1 + tid; c < ncells; c += kBlock) {
+        const uint32_t idx = (uint32_t)j * (uint32_t)a.stride + (uint32_t)c;
+        const uint32_t bits = __float_as_uint(bt[idx]);
+        const uint32_t b = bits >> kHShift;
+        const uint32_t pos = boff[b] + row[b] + atomicAdd(&s_cnt[b], 1u);
+        pairs[pos] = ((uint64_t)bits << 32) | (uint64_t)idx;
+    }
+}
+
+// ---- 3. sort the borders of each bucket ---------------------------------------------------------------------------------
+// Bitonic network in its all-ascending form (the first step of every merge compares i with its mirror image in the block,
+// the others i with i + j): every comparator moves the smaller element to the lower index, so a tail of "+inf" padding
+// never moves and comparators that touch it are simply skipped -- any length works.
+template <class Ptr>
+__device__ __forceinline__ void bitonic_sort(Ptr d, int n)
+{
+    int l2 = 0;
+    while ((1 << l2) < n) ++l2;
+    const int half = (1 << l2) >> 1;
+    for (int lk = 1; lk <= l2; ++lk) {
+        for (int lj = lk - 1; lj >= 0; --lj) {
+            const int j = 1 << lj;
+            for (int i = threadIdx.x; i < half; i += kBlock) {
+                const int t = i & (j - 1), blk = i >> lj;
+                int lo, hi;
+                if (lj == lk - 1) {
+                    lo = (blk << lk) + t;
+                    hi = (blk << lk) + (1 << lk) - 1 - t;
+                } else {
+                    lo = (blk << (lj + 1)) + t;
+                    hi = lo + j;
+                }
+                if (hi < n) {
+                    const uint64_t x = d[lo], y = d[hi];
+                    if (x > y) {
+                        d[lo] = y;
+                        d[hi] = x;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// one workgroup per bucket: sorted border values -> sb, every border's prefix index -> rank[owner].
+// Interval ids: bucket b owns ids boff[b] + b + i, i = 0 .. nb (interval i = keys of the bucket in [border i-1, border i));
+// "everything below border i of bucket b" = the intervals with ids < boff[b] + b + i + 1.
+__global__ void __launch_bounds__(kBlock)
+k_border_sort(uint64_t *__restrict__ pairs, const uint32_t *__restrict__ boff, uint32_t *__restrict__ sb,
+              uint32_t *__restrict__ rank)
+{
+    __shared__ uint64_t s_p[kSortLds];
+    const int b = blockIdx.x;
+    const uint32_t o = boff[b];
+    const int nb = (int)(boff[b + 1] - o);
+    if (nb == 0) return;
+    uint64_t *g = pairs + o;
+    if (nb <= kSortLds) {
+        for (int i = threadIdx.x; i < nb; i += kBlock) s_p[i] = g[i];
+        __syncthreads();
+        bitonic_sort(s_p, nb);
+        for (int i = threadIdx.x; i < nb; i += kBlock) {
+            const uint64_t v = s_p[i];
+            sb[o + i] = (uint32_t)(v >> 32);
+            rank[(uint32_t)v] = o + (uint32_t)b + (uint32_t)i + 1u;
+        }
+    } else {
+        __syncthreads();
+        bitonic_sort(g, nb);     // (global memory: a workgroup's own stores are visible to it after the barrier)
+        for (int i = threadIdx.x; i < nb; i += kBlock) {
+            const uint64_t v = g[i];
+            sb[o + i] = (uint32_t)(v >> 32);
+            rank[(uint32_t)v] = o + (uint32_t)b + (uint32_t)i + 1u;
+        }
+    }
+}
+
+// ---- 4. moments of the intervals ----------------------------------------------------------------------------------------
+// dynamic LDS: uint64 cntA[bcap + 1] {n << 40 | sum d} | uint64 cntB[bcap + 1] {sum d^2} | uint32 bord[bcap] | uint32 tab[65]
+__global__ void __launch_bounds__(kBlock)
+k_moments(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ sb, const Unit *__restrict__ units,
+          const uint32_t *__restrict__ nunits, uint32_t *__restrict__ g_n, unsigned long long *__restrict__ g_d,
+          unsigned long long *__restrict__ g_d2lo, unsigned long long *__restrict__ g_d2hi, int bcap)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long *cntA = reinterpret_cast<unsigned long long *>(smem);
+    unsigned long long *cntB = cntA + (bcap + 1);
+    uint32_t *bord = reinterpret_cast<uint32_t *>(cntB + (bcap + 1));
+    uint32_t *tab = bord + bcap;
+    const int tid = threadIdx.x;
+    const uint32_t nu = nunits[0];
+    for (uint32_t u = blockIdx.x; u < nu; u += gridDim.x) {
+        const Unit un = units[u];
+        const uint32_t b = un.b_ch & 0xffffu, chn = un.b_ch >> 16;
+        const uint32_t bo = un.bo;
+        const int nb = (int)un.nb;
+        const int a0 = (int)chn * bcap;
+        const int cnt = min(nb - a0, bcap);                       // borders of this chunk (0 when the bucket has none)
+        const bool last = a0 + cnt == nb;                         // the chunk that owns the interval behind the last border
+        const uint32_t prev = a0 > 0 ? sb[bo + a0 - 1] : 0u;      // keys below it belong to an earlier chunk
+        for (int i = tid; i < cnt; i += kBlock) bord[i] = sb[bo + a0 + i];
+        for (int i = tid; i <= cnt; i += kBlock) cntA[i] = cntB[i] = 0ull;
+        __syncthreads();
+        if (tid <= kHSub) {
+            // tab[s] = borders below sub-bin s of this bucket (s = 64: below the next bucket = cnt when the chunk is the last)
+            const uint32_t v = (b << kHShift) + ((uint32_t)tid << (kHShift - kHSubBits));
+            int lo = 0, hi = cnt;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (bord[mid] < v) lo = mid + 1; else hi = mid;
+            }
+            tab[tid] = (uint32_t)lo;
+        }
+        __syncthreads();
+        const uint32_t *kp = keys + un.key0;
+        const int kn = (int)un.kn;
+        for (int i0 = tid * 4; i0 < kn; i0 += kBlock * 4) {
+            uint32_t kv[4];
+            if (i0 + 3 < kn) {
+                const u32x4u v = *reinterpret_cast<const u32x4u *>(kp + i0);
+                kv[0] = v.x, kv[1] = v.y, kv[2] = v.z, kv[3] = v.w;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) kv[q] = i0 + q < kn ? kp[i0 + q] : 0u;   // 0: skipped below
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t key = kv[q];
+                if (key == 0u || key < prev) continue;            // (a real key is never 0: zeros were dropped)
+                const uint32_t s = (key >> (kHShift - kHSubBits)) & (kHSub - 1);
+                int lo = (int)tab[s], hi = (int)tab[s + 1];
+                while (lo < hi) {                                 // borders <= key
+                    const int mid = (lo + hi) >> 1;
+                    if (bord[mid] <= key) lo = mid + 1; else hi = mid;
+                }
+                if (lo == cnt && !last) continue;
+                const unsigned long long d = key & kHMask;
+                atomicAdd(&cntA[lo], (1ull << 40) + d);
+                atomicAdd(&cntB[lo], d * d);
+            }
+        }
+        __syncthreads();
+        const uint32_t gid0 = bo + b + (uint32_t)a0;
+        for (int i = tid; i <= cnt; i += kBlock) {
+            const unsigned long long A = cntA[i];
+            if (A == 0ull || (i == cnt && !last)) continue;
+            const unsigned long long B = cntB[i];
+            atomicAdd(&g_n[gid0 + i], (uint32_t)(A >> 40));
+            atomicAdd(&g_d[gid0 + i], A & ((1ull << 40) - 1ull));
+            atomicAdd(&g_d2lo[gid0 + i], B & 0xffffffffull);
+            if (B >> 32) atomicAdd(&g_d2hi[gid0 + i], B >> 32);
+        }
+        __syncthreads();
+    }
+}
+
+// ---- 5. intervals -> S1, S2 (double-double), exclusive prefix -------------------------------------------------------------
+// A key of bucket b = (e << 3) | t is (A + d) * 2^ex with A = [e != 0] 2^23 + t 2^20, ex = max(e, 1) - 150, so over an
+// interval   S1 = 2^ex (n A + D),   S2 = 2^(2 ex) (n A^2 + 2 A D + D2)   with D = sum d, D2 = sum d^2: integers below 2^80,
+// exact in double-double; the scaling is by powers of two >= 2^-298 on numbers >= 1 (no underflow in either part).
+// One workgroup per superblock of 1024 intervals: exclusive prefix WITHIN the superblock + the superblock's totals;
+// k_iv_scan_top turns the totals into exclusive prefixes; prefix_at() adds the two levels (fixed association: deterministic).
+__global__ void __launch_bounds__(kSuper)
+k_iv_scan_super(const uint32_t *__restrict__ boff, const uint32_t *__restrict__ g_n, const unsigned long long *__restrict__ g_d,
+                const unsigned long long *__restrict__ g_d2lo, const unsigned long long *__restrict__ g_d2hi, int64_t ni,
+                DD *__restrict__ p1, DD *__restrict__ p2, uint32_t *__restrict__ pn, DD *__restrict__ t1, DD *__restrict__ t2,
+                uint32_t *__restrict__ tn)
+{
+    __shared__ DD s1[kSuper], s2[kSuper];
+    __shared__ uint32_t sn[kSuper];
+    const int tid = threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * kSuper + tid;
+    const DD zero{0.0, 0.0};
+    DD v1 = zero, v2 = zero;
+    uint32_t vn = 0u;
+    if (i < ni) vn = g_n[i];
+    if (vn) {
+        // the interval's bucket: the last b with boff[b] + b <= i
+        int lo = 0, hi = kHBuckets - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if ((int64_t)boff[mid] + mid <= i) lo = mid; else hi = mid - 1;
+        }
+        const int e = lo >> 3, t = lo & 7;
+        const double A = (double)((e ? (1u << 23) : 0u) + ((uint32_t)t << kHShift));
+        const int ex = (e ? e : 1) - 150;
+        const double nd = (double)vn;
+        const unsigned long long D = g_d[i];
+        // D2 = hi 2^32 + lo, both below 2^63
+        const DD d2 = dd_add(dd_from_u64(g_d2lo[i]), dd_scale2(dd_from_u64(g_d2hi[i]), 32));
+        v1 = dd_scale2(dd_add(two_prod(nd, A), dd_from_u64(D)), ex);
+        const DD cross = two_prod(2.0 * A, (double)D);             // D < 2^51: exact as a double
+        v2 = dd_scale2(dd_add(dd_add(two_prod(nd, A * A), cross), d2), 2 * ex);
+    }
+    s1[tid] = v1;
+    s2[tid] = v2;
+    sn[tid] = vn;
+    __syncthreads();
+    for (int off = 1; off < kSuper; off <<= 1) {   // Hillis-Steele inclusive scan
+        DD a1 = zero, a2 = zero;
+        uint32_t an = 0u;
+        if (tid >= off) {
+            a1 = s1[tid - off];
+            a2 = s2[tid - off];
+            an = sn[tid - off];
+        }
+        __syncthreads();
+        s1[tid] = dd_add(s1[tid], a1);
+        s2[tid] = dd_add(s2[tid], a2);
+        sn[tid] += an;
+        __syncthreads();
+    }
+    if (i <= ni) {                                  // exclusive, within the superblock (entry ni: everything)
+        const int j = tid ? tid - 1 : 0;            // (field-wise selects: a struct temporary went to scratch)
+        p1[i] = DD{tid ? s1[j].hi : 0.0, tid ? s1[j].lo : 0.0};
+        p2[i] = DD{tid ? s2[j].hi : 0.0, tid ? s2[j].lo : 0.0};
+        pn[i] = tid ? sn[j] : 0u;
+    }
+    if (tid == kSuper - 1) {
+        t1[blockIdx.x] = s1[tid];
+        t2[blockIdx.x] = s2[tid];
+        tn[blockIdx.x] = sn[tid];
+    }
+}
+
+__global__ void __launch_bounds__(64)
+k_iv_scan_top(DD *__restrict__ t1, DD *__restrict__ t2, uint32_t *__restrict__ tn, int64_t nsb)
+{
+    // a few hundred entries, one wave: a lane owns a contiguous run, the runs' totals are scanned with shuffles
+    const int lane = threadIdx.x;
+    const int64_t per = (nsb + 63) / 64, lo = lane * per, hi = lo + per < nsb ? lo + per : nsb;
+    const DD zero{0.0, 0.0};
+    DD s1 = zero, s2 = zero;
+    uint32_t sn = 0u;
+    for (int64_t i = lo; i < hi; ++i) {
+        s1 = dd_add(s1, t1[i]);
+        s2 = dd_add(s2, t2[i]);
+        sn += tn[i];
+    }
+    DD i1 = s1, i2 = s2;                                      // inclusive scan over the lanes
+    uint32_t in = sn;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const DD a1 = dd_shfl_up(i1, off), a2 = dd_shfl_up(i2, off);   // (every lane takes part in the shuffle)
+        const uint32_t an = __shfl_up(in, off, 64);
+        if (lane >= off) {
+            i1 = dd_add(i1, a1);
+            i2 = dd_add(i2, a2);
+            in += an;
+        }
+    }
+    const DD u1 = dd_shfl_up(i1, 1), u2 = dd_shfl_up(i2, 1);
+    const uint32_t un = __shfl_up(in, 1, 64);
+    DD r1 = lane ? u1 : zero, r2 = lane ? u2 : zero;           // exclusive prefix of this lane's run
+    uint32_t rn = lane ? un : 0u;
+    for (int64_t i = lo; i < hi; ++i) {
+        const DD v1 = t1[i], v2 = t2[i];
+        const uint32_t vn = tn[i];
+        t1[i] = r1;
+        t2[i] = r2;
+        tn[i] = rn;
+        r1 = dd_add(r1, v1);
+        r2 = dd_add(r2, v2);
+        rn += vn;
+    }
+}
+
+// ---- 6. candidates --------------------------------------------------------------------------------------------------------
+// one workgroup per (mantissa width, candidate); a lane per cell (looping when a format has more than 256 cells)
+__global__ void __launch_bounds__(kBlock)
+k_mse_eval(const float *__restrict__ x, const float *__restrict__ grid, const float *__restrict__ bt, const float *__restrict__ bq,
+           const uint32_t *__restrict__ rank, const int *__restrict__ cflag, const uint32_t *__restrict__ maxkey,
+           const DD *__restrict__ p1, const DD *__restrict__ p2, const uint32_t *__restrict__ pn, const DD *__restrict__ t1,
+           const DD *__restrict__ t2, const uint32_t *__restrict__ tn, int64_t ni, float *__restrict__ mses, HistArgs a,
+           double inv_inner)
+{
+    __shared__ double s_red[kBlock];
+    __shared__ float s_scale[kLutMax];
+    const int tid = threadIdx.x;
+    const int j = blockIdx.x, m = j / a.n_cand;
+    float *out = mses + j;
+    // non-finite keys: the reference's mean is NaN (a NaN element) or +inf (an infinite one: (x - xq)^2 = inf)
+    const uint32_t last = maxkey[0];
+    const int flag = cflag[j];
+    if (last > 0x7f800000u || flag == kFlagNaN) {
+        if (tid == 0) *out += __builtin_nanf("");
+        return;
+    }
+    if (last == 0x7f800000u) {
+        if (tid == 0) *out += __builtin_inff();
+        return;
+    }
+    double acc = 0.0;
+    if (flag == kFlagBrute) {
+        // element by element with K1's exact arithmetic (slow: one workgroup walks the whole tensor): candidates whose
+        // scales leave the normal range, and every candidate under FP8Q_MSE_HIST=2 (the self-check the tests use)
+        const QFmt f = a.fmt[m];
+        const float gv = grid[j - m * a.n_cand];
+        const float mv = fabsf(fmaxf(fabsf(-gv), gv));
+        const Chan ch = make_chan(mv, f);
+        const float pmaxf = (float)f.pmax;
+        for (int p = tid + 1; p <= f.pmax; p += kBlock) s_scale[p] = lut_entry(ch, p, f.M).x;
+        __syncthreads();
+        for (int64_t i = tid; i < a.n; i += kBlock) {
+            const float k = fabsf(x[i]);
+            const float xc = fminf(k, mv);
+            const float ls = floorf(log2_tab(xc, kFastTab) + ch.bias);
+            const float sc = s_scale[(int)__builtin_amdgcn_fmed3f(ls, 1.0f, pmaxf)];
+            const float d = k - rintf(xc / sc) * sc;
+            acc += (double)(d * d);
+        }
+    } else {
+        const int ncells = a.ncells[m];
+        const float *T = bt + (int64_t)j * a.stride, *Q = bq + (int64_t)j * a.stride;
+        const uint32_t *R = rank + (int64_t)j * a.stride;
+        for (int c = tid; c < ncells; c += kBlock) {
+            const float lo = T[c], hi = c + 1 < ncells ? T[c + 1] : __builtin_inff();
+            if (!(lo < hi)) continue;
+            const int64_t i0 = c ? (int64_t)R[c] : 0, i1 = c + 1 < ncells ? (int64_t)R[c + 1] : ni;
+            const int64_t b0 = i0 / kSuper, b1 = i1 / kSuper;
+            const uint32_t cnt = (tn[b1] + pn[i1]) - (tn[b0] + pn[i0]);
+            if (cnt == 0u) continue;
+            const DD m1lo = dd_add(t1[b0], p1[i0]), m1hi = dd_add(t1[b1], p1[i1]);
+            const DD m2lo = dd_add(t2[b0], p2[i0]), m2hi = dd_add(t2[b1], p2[i1]);
+            // S2 - 2 q S1 + n q^2 in double-double (q^2 of an fp32 q is exact in double); the cell's result is >= 0
+            const double qd = (double)Q[c];
+            const DD d2 = dd_add(m2hi, dd_neg(m2lo)), d1 = dd_add(m1hi, dd_neg(m1lo));
+            const DD e = dd_add(dd_add(d2, dd_mul_d(d1, -2.0 * qd)), two_prod((double)cnt, qd * qd));
+            acc += e.hi + e.lo;
+        }
+    }
+    s_red[tid] = acc;
+    __syncthreads();
+    for (int off = kBlock / 2; off >= 1; off >>= 1) {            // fixed tree: deterministic
+        if (tid < off) s_red[tid] += s_red[tid + off];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double tot = s_red[0] < 0.0 ? 0.0 : s_red[0];     // (rounding can leave a tiny negative number for an exact fit)
+        *out += (float)(tot * inv_inner);
+    }
+}
+
+// ---- host -----------------------------------------------------------------------------------------------------------------
+size_t align_up(size_t v, size_t al) { return (v + al - 1) / al * al; }
+
+int env_int(const char *name, int dflt, int lo, int hi)
+{
+    const char *e = getenv(name);
+    if (!e) return dflt;
+    const long v = atol(e);
+    return v < lo ? lo : (v > hi ? hi : (int)v);
+}
+
+// tuning knobs (defaults are the measured best): borders per k_moments chunk, smallest key slice
+int hist_bcap() { static const int v = env_int("FP8Q_MSE_BCAP", 2048, 16, 6144); return v; }
+int hist_slice_min() { static const int v = env_int("FP8Q_MSE_SLICE", 8192, 1024, 65536); return v & ~3; }
+
+constexpr int kStrideBound = 260;   // cells of one candidate of a signed format of <= 8 bits: (2^E + 1) 2^M + 2 <= 258
+
+struct HistLayout {
+    size_t keys, zero0, zero_bytes;           // [zero0, zero0 + zero_bytes): cleared before every call
+    size_t gn, gd, gd2lo, gd2hi;
+    size_t hist, bhist, ktab, btab, kmax, maxkey, nunits;
+    size_t koff, boff, units, bt, bq, rank, cflag, pairs, sb, p1, p2, pn, t1, t2, tn;
+    size_t total;
+    int64_t nbord, ni, nsb;
+    uint32_t units_max;
+};
+
+constexpr int kPartWgs = 768;       // partition workgroups (3 per CU: 48 KB of LDS each): rows of the key count table
+
+HistLayout hist_layout(int64_t n, int64_t n_pairs, int stride, int bcap, int slice_min)
+{
+    HistLayout L;
+    L.nbord = n_pairs * stride;                       // borders: at most stride - 1 per candidate
+    L.ni = L.nbord + kHBuckets;                       // intervals: one more than its borders per bucket
+    L.nsb = cdiv(L.ni + 1, kSuper);
+    // units: sum over the buckets of chunks x slices <= (sum of slices) x (largest chunk count)
+    const int64_t max_chunks = cdiv(L.nbord, bcap) + 1, max_slices = cdiv(n, slice_min) + kHBuckets;
+    const int64_t um = max_chunks * max_slices;
+    L.units_max = (uint32_t)(um > (1 << 22) ? (1 << 22) : um);
+    size_t o = 0;
+    auto take = [&](size_t bytes) {
+        const size_t at = o;
+        o += align_up(bytes, 256);
+        return at;
+    };
+    L.keys = take((size_t)n * 4 + 16);
+    L.zero0 = o;
+    L.gn = take((size_t)(L.ni + 1) * 4);
+    L.gd = take((size_t)(L.ni + 1) * 8);
+    L.gd2lo = take((size_t)(L.ni + 1) * 8);
+    L.gd2hi = take((size_t)(L.ni + 1) * 8);
+    L.zero_bytes = o - L.zero0;
+    L.hist = take(kHBuckets * 4);
+    L.bhist = take(kHBuckets * 4);
+    L.ktab = take((size_t)kPartWgs * kHBuckets * 4);
+    L.btab = take((size_t)n_pairs * kHBuckets * 4);
+    L.kmax = take(kPartWgs * 4);
+    L.maxkey = take(4);
+    L.nunits = take(4);
+    L.koff = take((kHBuckets + 1) * 4);
+    L.boff = take((kHBuckets + 1) * 4);
+    L.units = take((size_t)L.units_max * sizeof(Unit));
+    L.bt = take((size_t)L.nbord * 4);
+    L.bq = take((size_t)L.nbord * 4);
+    L.rank = take((size_t)L.nbord * 4);
+    L.cflag = take((size_t)n_pairs * 4);
+    L.pairs = take((size_t)L.nbord * 8);
+    L.sb = take((size_t)L.nbord * 4);
+    L.p1 = take((size_t)(L.nsb * kSuper) * sizeof(DD));
+    L.p2 = take((size_t)(L.nsb * kSuper) * sizeof(DD));
+    L.pn = take((size_t)(L.nsb * kSuper) * 4);
+    L.t1 = take((size_t)(L.nsb + 1) * sizeof(DD));
+    L.t2 = take((size_t)(L.nsb + 1) * sizeof(DD));
+    L.tn = take((size_t)(L.nsb + 1) * 4);
+    L.total = o + 256;
+    return L;
+}
+
+}  // namespace
+
+// (called from fp8q_mse.hip)
+size_t fp8q_mse_hist_workspace_bytes(int64_t n, int64_t n_pairs)
+{
+    return hist_layout(n, n_pairs, kStrideBound, hist_bcap(), hist_slice_min()).total;
+}
+
+// formats this route takes: signed, at most 8 bits (the cell tables are sized for them)
+bool fp8q_mse_hist_supported(const QFmt *fmts, int n_m, int n_bits)
+{
+    if (n_m > kHistMaxM || n_bits > 8) return false;
+    for (int m = 0; m < n_m; ++m)
+        if (fmts[m].sign_bits != 1 || (fmts[m].pmax + 1) * (1 << (int)fmts[m].M) + 2 > kStrideBound) return false;
+    return true;
+}
+
+int fp8q_mse_hist_launch(const float *x, int64_t n, const float *grid, int64_t n_cand, const QFmt *fmts, int n_m, float *mses,
+                         void *ws, size_t ws_bytes, hipStream_t st, int brute)
+{
+    if (n_m > kHistMaxM || n >= (1ll << 31) || ((uintptr_t)ws & 7)) return FP8Q_EWORKSPACE;
+    HistArgs a;
+    memset(&a, 0, sizeof(a));
+    a.n_m = n_m;
+    a.n_cand = (int)n_cand;
+    a.n = n;
+    a.stride = 0;
+    for (int m = 0; m < n_m; ++m) {
+        a.fmt[m] = fmts[m];
+        const int M = (int)fmts[m].M;
+        a.ncells[m] = (2 << M) + 1 + (fmts[m].pmax - 1) * ((1 << M) + 1) + 1;
+        if (a.ncells[m] > a.stride) a.stride = a.ncells[m];
+    }
+    if (a.stride > kStrideBound) return FP8Q_EUNSUPPORTED;
+    const int bcap = hist_bcap(), slice_min = hist_slice_min();
+    const int64_t n_pairs = (int64_t)n_m * n_cand;
+    const HistLayout L = hist_layout(n, n_pairs, a.stride, bcap, slice_min);
+    if (ws_bytes < L.total) return FP8Q_EWORKSPACE;
+    char *w = (char *)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+    auto at = [&](size_t off) { return (void *)(w + off); };
+    uint32_t *keys = (uint32_t *)at(L.keys), *hist = (uint32_t *)at(L.hist), *bhist = (uint32_t *)at(L.bhist);
+    uint32_t *ktab = (uint32_t *)at(L.ktab), *btab = (uint32_t *)at(L.btab), *kmax = (uint32_t *)at(L.kmax);
+    uint32_t *maxkey = (uint32_t *)at(L.maxkey), *nunits = (uint32_t *)at(L.nunits), *gn = (uint32_t *)at(L.gn);
+    unsigned long long *gd = (unsigned long long *)at(L.gd), *gd2lo = (unsigned long long *)at(L.gd2lo),
+                       *gd2hi = (unsigned long long *)at(L.gd2hi);
+    uint32_t *koff = (uint32_t *)at(L.koff), *boff = (uint32_t *)at(L.boff);
+    Unit *units = (Unit *)at(L.units);
+    float *bt = (float *)at(L.bt), *bq = (float *)at(L.bq);
+    uint32_t *rank = (uint32_t *)at(L.rank), *sb = (uint32_t *)at(L.sb), *pn = (uint32_t *)at(L.pn), *tn = (uint32_t *)at(L.tn);
+    int *cflag = (int *)at(L.cflag);
+    uint64_t *pairs = (uint64_t *)at(L.pairs);
+    DD *p1 = (DD *)at(L.p1), *p2 = (DD *)at(L.p2), *t1 = (DD *)at(L.t1), *t2 = (DD *)at(L.t2);
+
+    if (hipError_t e = hipMemsetAsync(at(L.zero0), 0, L.zero_bytes, st); e != hipSuccess) return hip_rc(e);
+    const uint32_t *xb = reinterpret_cast<const uint32_t *>(x);
+    const int64_t ntiles = cdiv(n, kPartTile);
+    const int tpw = (int)cdiv(ntiles, kPartWgs);              // tiles per partition workgroup
+    const int pwgs = (int)cdiv(ntiles, tpw);                  // <= kPartWgs, none of them empty
+    hipLaunchKernelGGL(k_mse_borders, dim3((unsigned)n_pairs), dim3(kBlock), 0, st, grid, a, brute, bt, bq, cflag, btab);
+    if (int rc = launch_rc()) return rc;
+    hipLaunchKernelGGL(k_part_hist, dim3((unsigned)pwgs), dim3(kBlock), 0, st, xb, n, ntiles, tpw, ktab, kmax);
+    if (int rc = launch_rc()) return rc;
+    hipLaunchKernelGGL(k_tab_scan, dim3(kHBuckets / 64, 2), dim3(kBlock), 0, st, ktab, pwgs, hist, btab, (int)n_pairs, bhist);
+    if (int rc = launch_rc()) return rc;
+    hipLaunchKernelGGL(k_mse_plan, dim3(1), dim3(1024), 0, st, hist, bhist, kmax, pwgs, koff, boff, units, nunits, maxkey,
+                       L.units_max, bcap, slice_min);
+    if (int rc = launch_rc()) return rc;
+    hipLaunchKernelGGL(k_border_scatter, dim3((unsigned)n_pairs), dim3(kBlock), 0, st, bt, cflag, a, boff, btab, pairs);
+    if (int rc = launch_rc()) return rc;
+    hipLaunchKernelGGL(k_part_scatter, dim3((unsigned)pwgs), dim3(kBlock), 0, st, xb, n, ntiles, tpw, koff, ktab, keys);
+    if (int rc = launch_rc()) return rc;
+    hipLaunchKernelGGL(k_border_sort, dim3(kHBuckets), dim3(kBlock), 0, st, pairs, boff, sb, rank);
+    if (int rc = launch_rc()) return rc;
+    const size_t shmem = (size_t)(bcap + 1) * 16 + (size_t)bcap * 4 + (kHSub + 1) * 4;
+    if (shmem > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_moments, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return hip_rc(e);
+    }
+    hipLaunchKernelGGL(k_moments, dim3(2048), dim3(kBlock), shmem, st, keys, sb, units, nunits, gn, gd, gd2lo, gd2hi, bcap);
+    if (int rc = launch_rc()) return rc;
+    hipLaunchKernelGGL(k_iv_scan_super, dim3((unsigned)L.nsb), dim3(kSuper), 0, st, boff, gn, gd, gd2lo, gd2hi, L.ni, p1, p2, pn, t1,
+                       t2, tn);
+    if (int rc = launch_rc()) return rc;
+    hipLaunchKernelGGL(k_iv_scan_top, dim3(1), dim3(64), 0, st, t1, t2, tn, L.nsb);
+    if (int rc = launch_rc()) return rc;
+    hipLaunchKernelGGL(k_mse_eval, dim3((unsigned)n_pairs), dim3(kBlock), 0, st, x, grid, bt, bq, rank, cflag, maxkey, p1, p2, pn, t1,
+                       t2, tn, L.ni, mses, a, 1.0 / (double)n);
+    return launch_rc();
+}

@@ -1,6 +1,6 @@
 """Compile csrc/*.hip -> csrc/libfp8q_hip.so for gfx950 (hipcc cross-compiles, no GPU needed).
 
-Six translation units (quantize / min-max family, MSE grid, fused epilogue, storage codes, the float64 lane, the sorted MSE search) compiled in parallel and
+Six translation units (quantize / min-max family, MSE grid, fused epilogue, storage codes, the float64 lane, the interval-histogram MSE search) compiled in parallel and
 linked into one library.  In-tree build: the .so is git-ignored but travels to the GPU box with the repo snapshot.
 """
 import concurrent.futures
@@ -12,7 +12,7 @@ import tempfile
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(HERE), "csrc")
 SO = os.path.join(CSRC, "libfp8q_hip.so")
-SOURCES = ["fp8q_quant.hip", "fp8q_mse.hip", "fp8q_epilogue.hip", "fp8q_codec.hip", "fp8q_f64.hip", "fp8q_mse_sorted.hip"]
+SOURCES = ["fp8q_quant.hip", "fp8q_mse.hip", "fp8q_epilogue.hip", "fp8q_codec.hip", "fp8q_f64.hip", "fp8q_mse_hist.hip"]
 HEADERS = ["fp8q_common.h", "fp8q_device.h", "fp8q_tables.h", os.path.join("..", "..", "include", "fp8q.h")]
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]
 

@@ -1,5 +1,5 @@
-"""K4's sort-once path (csrc/fp8q_mse_sorted.hip) against the element-by-element evaluation of the same arithmetic, the
-lane-per-element kernel and the CPU oracle.  FP8Q_MSE_SORTED is read once per process, so each mode runs in a subprocess."""
+"""K4's partition-once (interval histogram) path (csrc/fp8q_mse_hist.hip) against the element-by-element evaluation of the same arithmetic, the
+lane-per-element kernel and the CPU oracle.  FP8Q_MSE_HIST is read once per process, so each mode runs in a subprocess."""
 import os
 import subprocess
 import sys
@@ -48,13 +48,13 @@ np.savez(sys.argv[1], **out)
 
 def _run(mode, tmp_path):
     path = os.path.join(str(tmp_path), f"mode{mode}.npz")
-    env = dict(os.environ, FP8Q_MSE_SORTED=str(mode))
+    env = dict(os.environ, FP8Q_MSE_HIST=str(mode))
     r = subprocess.run([sys.executable, "-c", SCRIPT, path], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     return np.load(path)
 
 
-def test_sorted_path_equals_elementwise_evaluation_and_row_kernel(tmp_path):
+def test_hist_path_equals_elementwise_evaluation_and_row_kernel(tmp_path):
     import oracle
     s, b, r = _run(1, tmp_path), _run(2, tmp_path), _run(0, tmp_path)     # sorted / brute (same routing) / lane-per-element kernel
     for name in ("gauss", "relu", "pow2", "ongrid", "const", "tiny"):
