@@ -11,15 +11,18 @@
 //   1. k_mse_borders  one workgroup per candidate: the exact border of every cell -- the smallest float for which the
 //                     reference's own fp32 decisions (floor(fl32(log2 k) + bias) >= p, rint(fl32(k / s_p)) >= r,
 //                     k > maxval) flip, located by guess-and-walk on the exact predicates -- and the cell's grid value.
-//   2. k_part_hist / k_part_scatter   ONE most-significant-digit partition of the nonzero keys by their top 11 bits
-//                     (exponent + 3 fraction bits: 2048 coarse buckets): LDS histogram, then a tile-local counting sort in
-//                     LDS so that every (tile, bucket) run leaves as contiguous 4-byte stores.  Zeros (half of a post-ReLU
-//                     tensor) contribute nothing to any candidate and are dropped.
-//   3. k_border_sort  the borders, bucketed the same way, are sorted per bucket in LDS (bitonic network on
-//                     {value, owner} pairs); every border learns its global rank.
-//   4. k_moments      per (bucket, slice of its keys): the bucket's sorted borders sit in LDS, a key finds its interval
-//                     with a 64-entry sub-bin table + a short bisection and adds {1, d, d^2}, d = its low 20 bits, to the
-//                     interval's LDS counters with INTEGER atomics: exact, order-independent -> deterministic.
+//   2. part_hist / part_scatter   ONE most-significant-digit partition of the nonzero keys by their top 11 bits
+//                     (exponent + 3 fraction bits: 2048 coarse buckets): LDS histogram per workgroup -> count table ->
+//                     column scan (no global atomics), then a tile-local counting sort in LDS so that every (tile, bucket)
+//                     run leaves as contiguous 4-byte stores.  Both passes run at the chip's copy rate.  Zeros (half of a
+//                     post-ReLU tensor) contribute nothing to any candidate and are dropped.
+//   3. border_sort    the borders, bucketed the same way, are sorted per bucket in LDS: one more radix step on the next 10
+//                     key bits (1024 sub-bins, ~2 borders each), ranks inside a sub-bin by counting; every border learns
+//                     its global rank, every bucket gets its sub-bin table.
+//   4. k_moments      per (bucket, slice of its keys): the bucket's sorted borders and sub-bin table sit in LDS, a key finds
+//                     its interval with two table entries + a bisection over the handful of borders between them and adds
+//                     {1, d, d^2}, d = its low 20 bits, to the interval's LDS counters with INTEGER atomics: exact,
+//                     order-independent -> deterministic.
 //   5. k_iv_scan_*    intervals -> S1, S2 as exact double-double numbers (k = (A_bucket + d) * ulp), exclusive prefix.
 //   6. k_mse_eval     one workgroup per candidate, a lane per cell: two prefix lookups, S2 - 2 q S1 + n q^2 in
 //                     double-double (the three terms cancel: on data that sit on the grid the squared error is 1e-13 of
@@ -35,12 +38,14 @@ namespace {
 constexpr int kHShift = 20;                         // key bits below the coarse bucket: d = key & (2^20 - 1)
 constexpr int kHBuckets = 1 << (31 - kHShift);      // 2048 = 8 exponent bits + 3 fraction bits
 constexpr uint32_t kHMask = (1u << kHShift) - 1u;
-constexpr int kHSubBits = 6;                        // sub-bin table of k_moments: next 6 key bits
+constexpr int kHSubBits = 10;                       // sub-bin table of k_moments: next 10 key bits
 constexpr int kHSub = 1 << kHSubBits;
 constexpr int kPartTile = 8192;                     // keys per partition tile (32 per thread)
 constexpr int kHistMaxM = 8;
+constexpr int kStrideBound = 260;                   // cells of one candidate of a signed format of <= 8 bits: (2^E + 1) 2^M + 2 <= 258
 constexpr int kSuper = 1024;                        // intervals per scan superblock
-constexpr int kSortLds = 4096;                      // borders of one bucket sorted in LDS (more: same network on global memory)
+constexpr int kSortLds = 4096;                      // borders of one bucket sorted in LDS (more: a bitonic network on global memory)
+constexpr int kPartLds = 4 * (2 * kHBuckets + kPartTile + 4);   // bytes of LDS of a scatter workgroup: 49168 (3 per CU)
 
 typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(4)));
 
@@ -168,16 +173,15 @@ __device__ __forceinline__ void load_tile_keys(const uint32_t *__restrict__ x, i
 // `ktab`, k_tab_scan turns every column into exclusive prefixes over the workgroups, and pass B starts workgroup w's run of
 // bucket b at koff[b] + ktab[w][b] -- no global atomics anywhere (a first version reserved space with one returning atomic
 // per (tile, bucket) on a 2048-word cursor array: 1.9 M atomics into two memory channels, 481 us for 25.7 M keys).
-__global__ void __launch_bounds__(kBlock)
-k_part_hist(const uint32_t *__restrict__ x, int64_t n, int64_t ntiles, int tpw, uint32_t *__restrict__ ktab,
-            uint32_t *__restrict__ kmax)
+__device__ __forceinline__ void part_hist_body(int w, uint32_t *s_hist, const uint32_t *__restrict__ x, int64_t n, int64_t ntiles,
+                                               int tpw, uint32_t *__restrict__ ktab, uint32_t *__restrict__ kmax)
 {
-    __shared__ uint32_t s_hist[kHBuckets];
     const int tid = threadIdx.x;
+    uint32_t *s_mk = s_hist + kHBuckets;
     for (int i = tid; i < kHBuckets; i += kBlock) s_hist[i] = 0u;
     __syncthreads();
     uint32_t mk = 0u;
-    const int64_t t0 = (int64_t)blockIdx.x * tpw, t1 = min(t0 + tpw, ntiles);
+    const int64_t t0 = (int64_t)w * tpw, t1 = min(t0 + tpw, ntiles);
     for (int64_t t = t0; t < t1; ++t) {
         uint32_t k[32];
         load_tile_keys(x, n, t * kPartTile, k);
@@ -188,60 +192,31 @@ k_part_hist(const uint32_t *__restrict__ x, int64_t n, int64_t ntiles, int tpw, 
         }
     }
     __syncthreads();
-    for (int i = tid; i < kHBuckets; i += kBlock) ktab[(int64_t)blockIdx.x * kHBuckets + i] = s_hist[i];
+    for (int i = tid; i < kHBuckets; i += kBlock) ktab[(int64_t)w * kHBuckets + i] = s_hist[i];
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) mk = max(mk, (uint32_t)__shfl_xor((int)mk, off, 64));
-    __shared__ uint32_t s_mk[kBlock / 64];
     if ((tid & 63) == 0) s_mk[tid >> 6] = mk;
     __syncthreads();
-    if (tid == 0) kmax[blockIdx.x] = max(max(s_mk[0], s_mk[1]), max(s_mk[2], s_mk[3]));
-}
-
-// Exclusive prefix down every column of a [rows, 2048] count table (in place) + the column totals.  One workgroup scans 64
-// columns: thread (q, col) walks a quarter of the rows of its column, the quarters are stitched through LDS.
-// blockIdx.y selects the table: 0 = keys (rows = partition workgroups), 1 = borders (rows = candidates).
-__global__ void __launch_bounds__(kBlock)
-k_tab_scan(uint32_t *__restrict__ ktab, int krows, uint32_t *__restrict__ ktot, uint32_t *__restrict__ btab, int brows,
-           uint32_t *__restrict__ btot)
-{
-    __shared__ uint32_t s_q[4][64];
-    uint32_t *tab = blockIdx.y ? btab : ktab;
-    const int rows = blockIdx.y ? brows : krows;
-    uint32_t *tot = blockIdx.y ? btot : ktot;
-    const int col = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
-    const int per = (rows + 3) / 4, r0 = q * per, r1 = min(r0 + per, rows);
-    uint32_t sum = 0u;
-    for (int r = r0; r < r1; ++r) sum += tab[(int64_t)r * kHBuckets + col];
-    s_q[q][threadIdx.x & 63] = sum;
-    __syncthreads();
-    uint32_t run = 0u;
-    for (int w = 0; w < q; ++w) run += s_q[w][threadIdx.x & 63];
-    for (int r = r0; r < r1; ++r) {
-        const int64_t i = (int64_t)r * kHBuckets + col;
-        const uint32_t c = tab[i];
-        tab[i] = run;
-        run += c;
-    }
-    if (q == 3) tot[col] = run;
+    if (tid == 0) kmax[w] = max(max(s_mk[0], s_mk[1]), max(s_mk[2], s_mk[3]));
 }
 
 // scatter: per tile a counting sort by bucket in LDS (ranks from returning LDS atomics), then position p of the sorted
 // tile goes to delta[bucket] + p: consecutive lanes write consecutive addresses within a run.  The order of the keys inside
 // a (workgroup, bucket) run depends on the LDS atomics' timing; nothing downstream depends on it (integer moments).
-__global__ void __launch_bounds__(kBlock)
-k_part_scatter(const uint32_t *__restrict__ x, int64_t n, int64_t ntiles, int tpw, const uint32_t *__restrict__ koff,
-               const uint32_t *__restrict__ ktab, uint32_t *__restrict__ out)
+__device__ __forceinline__ void part_scatter_body(int w, uint32_t *s_raw, const uint32_t *__restrict__ x, int64_t n, int64_t ntiles,
+                                                  int tpw, const uint32_t *__restrict__ koff, const uint32_t *__restrict__ ktab,
+                                                  uint32_t *__restrict__ out)
 {
-    __shared__ uint32_t s_hist[kHBuckets];     // counts, then the bucket's first position in the sorted tile
-    __shared__ uint32_t s_delta[kHBuckets];    // global index of the run minus its first position
-    __shared__ uint32_t s_keys[kPartTile];
-    __shared__ uint32_t s_w[kBlock / 64];
+    uint32_t *s_hist = s_raw;                    // counts, then the bucket's first position in the sorted tile
+    uint32_t *s_delta = s_raw + kHBuckets;       // global index of the run minus its first position
+    uint32_t *s_keys = s_raw + 2 * kHBuckets;    // kPartTile
+    uint32_t *s_w = s_keys + kPartTile;          // 4
     const int tid = threadIdx.x;
-    constexpr int kPer = kHBuckets / kBlock;   // 8 consecutive buckets per thread in the scan
-    uint32_t cur[kPer];                        // where this workgroup's next key of buckets tid * 8 .. tid * 8 + 7 goes
+    constexpr int kPer = kHBuckets / kBlock;     // 8 consecutive buckets per thread in the scan
+    uint32_t cur[kPer];                          // where this workgroup's next key of buckets tid * 8 .. tid * 8 + 7 goes
 #pragma unroll
-    for (int q = 0; q < kPer; ++q) cur[q] = koff[tid * kPer + q] + ktab[(int64_t)blockIdx.x * kHBuckets + tid * kPer + q];
-    const int64_t t0 = (int64_t)blockIdx.x * tpw, t1 = min(t0 + tpw, ntiles);
+    for (int q = 0; q < kPer; ++q) cur[q] = koff[tid * kPer + q] + ktab[(int64_t)w * kHBuckets + tid * kPer + q];
+    const int64_t t0 = (int64_t)w * tpw, t1 = min(t0 + tpw, ntiles);
     for (int64_t t = t0; t < t1; ++t) {
         for (int i = tid; i < kHBuckets; i += kBlock) s_hist[i] = 0u;
         __syncthreads();
@@ -278,6 +253,48 @@ k_part_scatter(const uint32_t *__restrict__ x, int64_t n, int64_t ntiles, int tp
         }
         __syncthreads();
     }
+}
+
+// Exclusive prefix down every column of a [rows, 2048] count table (in place) + the column totals.  One workgroup of 1024
+// threads scans 32 columns: thread (g, col) walks 1/32 of the rows of its column, the groups are stitched through LDS
+// (64 columns x 4 groups in 256 threads left most of the chip idle: 43 us for the 768 x 2048 key table).
+// blockIdx.y selects the table: 0 = keys (rows = partition workgroups), 1 = borders (rows = candidates; entries
+// {count | first cell << 16}: only the column totals of the counts are needed, the table stays as it is).
+// The launch also clears the interval counters of k_moments (`zero`, a multiple of 16 bytes).
+__global__ void __launch_bounds__(1024)
+k_tab_scan(uint32_t *__restrict__ ktab, int krows, uint32_t *__restrict__ ktot, uint32_t *__restrict__ btab, int brows,
+           uint32_t *__restrict__ btot, uint4 *__restrict__ zero, int64_t zero_n16)
+{
+    __shared__ uint32_t s_q[32][33];
+    const int64_t nthreads = (int64_t)gridDim.x * gridDim.y * 1024;
+    for (int64_t i = ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 1024 + threadIdx.x; i < zero_n16; i += nthreads)
+        zero[i] = make_uint4(0u, 0u, 0u, 0u);
+    uint32_t *tab = blockIdx.y ? btab : ktab;
+    const int rows = blockIdx.y ? brows : krows;
+    uint32_t *tot = blockIdx.y ? btot : ktot;
+    const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int col = blockIdx.x * 32 + c;
+    const int per = (rows + 31) / 32, r0 = g * per, r1 = min(r0 + per, rows);
+    const uint32_t mask = blockIdx.y ? 0xffffu : 0xffffffffu;
+    uint32_t sum = 0u;
+#pragma unroll 8
+    for (int r = r0; r < r1; ++r) sum += tab[(int64_t)r * kHBuckets + col] & mask;
+    s_q[g][c] = sum;
+    __syncthreads();
+    uint32_t run = 0u;
+    for (int w = 0; w < g; ++w) run += s_q[w][c];
+    if (blockIdx.y) {
+        if (g == 31) tot[col] = run + sum;
+        return;
+    }
+#pragma unroll 8
+    for (int r = r0; r < r1; ++r) {
+        const int64_t i = (int64_t)r * kHBuckets + col;
+        const uint32_t v = tab[i];
+        tab[i] = run;
+        run += v;
+    }
+    if (g == 31) tot[col] = run;
 }
 
 // ---- 1. borders -------------------------------------------------------------------------------------------------------
@@ -329,17 +346,18 @@ constexpr int kFlagCells = 0, kFlagBrute = 1, kFlagNaN = 2;
 // binade p by K1's exact decision.  A candidate whose scales are not positive normal numbers (E = 7 formats with a tiny
 // maxval underflow s_1 to 0: the reference then yields NaN for the elements of that binade) has no cells: it is flagged for
 // the element-by-element evaluation; maxval 0 / inf / NaN makes every element NaN.
-__global__ void __launch_bounds__(kBlock)
-k_mse_borders(const float *__restrict__ grid, HistArgs a, int brute, float *__restrict__ bt, float *__restrict__ bq,
-              int *__restrict__ cflag, uint32_t *__restrict__ btab)
+// Row j of btab = per coarse bucket {this candidate's borders there | the cell index of the first of them << 16}.
+__device__ __forceinline__ void borders_body(int j, uint32_t *s_hist, const float *__restrict__ grid, const HistArgs &a, int brute,
+                                             float *__restrict__ bt, float *__restrict__ bq, int *__restrict__ cflag,
+                                             uint32_t *__restrict__ btab)
 {
-    __shared__ float s_scale[kLutMax];     // s_p, p = 1 .. pmax (exact: lut_entry)
-    __shared__ float s_border[kLutMax];    // L_p (L_1 = 0, L_(pmax+1) = +inf)
-    __shared__ uint32_t s_hist[kHBuckets]; // this candidate's borders per coarse bucket -> row j of btab
+    float *s_scale = reinterpret_cast<float *>(s_hist + kHBuckets);   // s_p, p = 1 .. pmax (exact: lut_entry)
+    float *s_border = s_scale + kLutMax;                               // L_p (L_1 = 0, L_(pmax+1) = +inf)
+    uint32_t *s_w = reinterpret_cast<uint32_t *>(s_border + kLutMax);
     const int tid = threadIdx.x;
     for (int i = tid; i < kHBuckets; i += kBlock) s_hist[i] = 0u;
-    uint32_t *row = btab + (int64_t)blockIdx.x * kHBuckets;
-    const int j = blockIdx.x, m = j / a.n_cand, cand = j - m * a.n_cand;
+    uint32_t *row = btab + (int64_t)j * kHBuckets;
+    const int m = j / a.n_cand, cand = j - m * a.n_cand;
     const QFmt f = a.fmt[m];
     const float gv = grid[cand];
     const float mv = fabsf(fmaxf(fabsf(-gv), gv));              // set_quant_range(-g, g): fp8_quantizer.py:236
@@ -380,6 +398,7 @@ k_mse_borders(const float *__restrict__ grid, HistArgs a, int brute, float *__re
     const int n_first = r_top + 1, n_other = r_norm + 1;
     const int ncells = a.ncells[m];                              // n_first + (pmax - 1) * n_other + 1
     float *T = bt + (int64_t)j * a.stride, *Q = bq + (int64_t)j * a.stride;
+    float *s_T = s_border + kLutMax + 8, *s_Q = s_T + kStrideBound;   // the cells' raw lower ends and grid values
     for (int c = tid; c < ncells; c += kBlock) {
         float lo, q;
         if (c == ncells - 1) {                                   // clipped elements: xc = maxval
@@ -408,12 +427,55 @@ k_mse_borders(const float *__restrict__ grid, HistArgs a, int brute, float *__re
             lo = fminf(lo, clamp_from);
             q = rf * s;                                          // the fp32 product K1 forms
         }
-        T[c] = lo;
-        Q[c] = q;
-        if (c) atomicAdd(&s_hist[__float_as_uint(lo) >> kHShift], 1u);
+        s_T[c] = lo;
+        s_Q[c] = q;
     }
     __syncthreads();
-    for (int i = tid; i < kHBuckets; i += kBlock) row[i] = s_hist[i];
+    // Cells that start at or above clamp_from hold no element (the clamp decides there): the whole top binade p = 2^E -- it
+    // begins at maxval * 2 / (2 - 2^-M) -- and the last cells below it.  Left in, they put ~150 equal borders per candidate
+    // group into one sub-bin (the rank loop of the border sort is quadratic in that: 118 us per launch).  The FIRST of them
+    // becomes the clamp cell [clamp_from, +inf) -> q(maxval); the others get T = +inf: empty, not registered as borders.
+    for (int c = tid; c < ncells; c += kBlock) {
+        float lo = s_T[c], q = s_Q[c];
+        if (c >= 1 && lo >= clamp_from) {
+            const bool first = !(s_T[c - 1] >= clamp_from);
+            lo = first ? clamp_from : __builtin_inff();
+            q = s_Q[ncells - 1];
+        }
+        T[c] = lo;
+        Q[c] = q;
+        if (c && lo < __builtin_inff()) atomicAdd(&s_hist[__float_as_uint(lo) >> kHShift], 1u);
+    }
+    __syncthreads();
+    // T is sorted, so the borders of bucket b are the cells 1 + (borders in lower buckets) ...: an exclusive scan of the row
+    constexpr int kPer = kHBuckets / kBlock;
+    uint32_t cnt[kPer], sum = 0u;
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) {
+        cnt[q] = s_hist[tid * kPer + q];
+        sum += cnt[q];
+    }
+    uint32_t total;
+    uint32_t run = 1u + block_excl_scan<kBlock>(sum, s_w, total);
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) {
+        row[tid * kPer + q] = cnt[q] | (run << 16);      // (both below 2^9: kStrideBound)
+        run += cnt[q];
+    }
+}
+
+// stage 1, one launch: the candidates' borders (workgroups 0 .. n_pairs - 1) next to the key histogram (the rest)
+__global__ void __launch_bounds__(kBlock)
+k_stage1(const uint32_t *__restrict__ x, int64_t n, int64_t ntiles, int tpw, uint32_t *__restrict__ ktab, uint32_t *__restrict__ kmax,
+         const float *__restrict__ grid, HistArgs a, int brute, float *__restrict__ bt, float *__restrict__ bq, int *__restrict__ cflag,
+         uint32_t *__restrict__ btab)
+{
+    __shared__ uint32_t s_raw[kHBuckets + 2 * kLutMax + 16 + 2 * kStrideBound];
+    const int n_pairs = a.n_m * a.n_cand;
+    if ((int)blockIdx.x < n_pairs)
+        borders_body((int)blockIdx.x, s_raw, grid, a, brute, bt, bq, cflag, btab);
+    else
+        part_hist_body((int)blockIdx.x - n_pairs, s_raw, x, n, ntiles, tpw, ktab, kmax);
 }
 
 // ---- plan: offsets of keys and borders per bucket, the work units of k_moments ------------------------------------------
@@ -423,7 +485,8 @@ struct __attribute__((aligned(32))) Unit {
     uint32_t b_ch;      // bucket | chunk << 16
     uint32_t key0, kn;  // first key (index into the partitioned array) and count
     uint32_t bo, nb;    // the bucket's first sorted border and its border count
-    uint32_t pad[3];
+    uint32_t li;        // the bucket's position in the list of buckets that have borders (its sub-bin table)
+    uint32_t pad[2];
 };
 
 __device__ __forceinline__ uint32_t slice_len(uint32_t nb, int slice_min)
@@ -437,11 +500,12 @@ __device__ __forceinline__ uint32_t slice_len(uint32_t nb, int slice_min)
 __global__ void __launch_bounds__(1024)
 k_mse_plan(const uint32_t *__restrict__ hist, const uint32_t *__restrict__ bhist, const uint32_t *__restrict__ kmax, int nkmax,
            uint32_t *__restrict__ koff, uint32_t *__restrict__ boff, Unit *__restrict__ units, uint32_t *__restrict__ nunits,
-           uint32_t *__restrict__ maxkey, uint32_t units_max, int bcap, int slice_min)
+           uint32_t *__restrict__ maxkey, uint32_t *__restrict__ blist, uint32_t units_max, int bcap, int slice_min)
 {
     __shared__ uint32_t s_w[16];
+    __shared__ uint32_t s_uoff[kHBuckets + 1], s_ck[kHBuckets], s_cb[kHBuckets], s_ko[kHBuckets], s_bo[kHBuckets], s_li[kHBuckets];
     const int tid = threadIdx.x;
-    uint32_t ck[2], cb[2], cu[2], sk = 0, sb = 0, su = 0;
+    uint32_t ck[2], cb[2], cu[2], sk = 0, sb = 0, su = 0, sl_ = 0;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int b = tid * 2 + q;
@@ -453,24 +517,25 @@ k_mse_plan(const uint32_t *__restrict__ hist, const uint32_t *__restrict__ bhist
         sk += ck[q];
         sb += cb[q];
         su += cu[q];
+        sl_ += cb[q] ? 1u : 0u;
     }
-    uint32_t tk, tb, tu;
+    uint32_t tk, tb, tu, tl;
     uint32_t ek = block_excl_scan<1024>(sk, s_w, tk);
     uint32_t eb = block_excl_scan<1024>(sb, s_w, tb);
     uint32_t eu = block_excl_scan<1024>(su, s_w, tu);
+    uint32_t el = block_excl_scan<1024>(sl_, s_w, tl);
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int b = tid * 2 + q;
         koff[b] = ek;
         boff[b] = eb;
-        if (ck[q]) {
-            const uint32_t nch = cb[q] ? (cb[q] + bcap - 1) / bcap : 1u;
-            const uint32_t sl = slice_len(cb[q] < (uint32_t)bcap ? cb[q] : (uint32_t)bcap, slice_min);
-            uint32_t u = eu;
-            for (uint32_t chn = 0; chn < nch; ++chn)
-                for (uint32_t k0 = 0; k0 < ck[q]; k0 += sl, ++u)
-                    if (u < units_max) units[u] = Unit{(uint32_t)b | (chn << 16), ek + k0, min(sl, ck[q] - k0), eb, cb[q], {0u, 0u, 0u}};
-        }
+        s_uoff[b] = eu;
+        s_ck[b] = ck[q];
+        s_cb[b] = cb[q];
+        s_ko[b] = ek;
+        s_bo[b] = eb;
+        s_li[b] = el;
+        if (cb[q]) blist[el++] = (uint32_t)b;
         ek += ck[q];
         eb += cb[q];
         eu += cu[q];
@@ -478,7 +543,26 @@ k_mse_plan(const uint32_t *__restrict__ hist, const uint32_t *__restrict__ bhist
     if (tid == 1023) {
         koff[kHBuckets] = tk;
         boff[kHBuckets] = tb;
+        s_uoff[kHBuckets] = tu;
         nunits[0] = tu < units_max ? tu : units_max;   // (units_max is a proven bound: see hist_layout)
+        nunits[1] = tl;                                // buckets that have borders
+    }
+    __syncthreads();
+    // the units, all threads: unit u belongs to the last bucket whose first unit is <= u; inside a bucket the chunks of one
+    // key slice are neighbours (they read the same keys)
+    const uint32_t nu = tu < units_max ? tu : units_max;
+    for (uint32_t u = tid; u < nu; u += 1024) {
+        int lo = 0, hi = kHBuckets;                    // s_uoff[lo] <= u < s_uoff[hi]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (s_uoff[mid] <= u) lo = mid; else hi = mid;
+        }
+        const uint32_t b = (uint32_t)lo, nbk = s_cb[b], nk = s_ck[b];
+        const uint32_t nch = nbk ? (nbk + bcap - 1) / bcap : 1u;
+        const uint32_t sl = slice_len(nbk < (uint32_t)bcap ? nbk : (uint32_t)bcap, slice_min);
+        const uint32_t local = u - s_uoff[b], si = local / nch, chn = local - si * nch;
+        const uint32_t k0 = si * sl;
+        units[u] = Unit{b | (chn << 16), s_ko[b] + k0, min(sl, nk - k0), s_bo[b], nbk, s_li[b], {0u, 0u}};
     }
     // the largest key of the row (non-finite data): max over the partition workgroups
     uint32_t mk = 0u;
@@ -490,28 +574,6 @@ k_mse_plan(const uint32_t *__restrict__ hist, const uint32_t *__restrict__ bhist
     if (tid == 0) {
         for (int w = 1; w < 16; ++w) mk = max(mk, s_w[w]);
         maxkey[0] = mk;
-    }
-}
-
-// every border (cells 1 .. ncells - 1 of the candidates that have cells) into its bucket's segment, tagged with its owner:
-// candidate j's borders of bucket b start at boff[b] + btab[j][b] (k_tab_scan), ranks inside the run from LDS atomics
-__global__ void __launch_bounds__(kBlock)
-k_border_scatter(const float *__restrict__ bt, const int *__restrict__ cflag, HistArgs a, const uint32_t *__restrict__ boff,
-                 const uint32_t *__restrict__ btab, uint64_t *__restrict__ pairs)
-{
-    __shared__ uint32_t s_cnt[kHBuckets];
-    const int tid = threadIdx.x, j = blockIdx.x, m = j / a.n_cand;
-    if (cflag[j] != kFlagCells) return;
-    for (int i = tid; i < kHBuckets; i += kBlock) s_cnt[i] = 0u;
-    __syncthreads();
-    const uint32_t *row = btab + (int64_t)j * kHBuckets;
-    const int ncells = a.ncells[m];
-    for (int c = 1 + tid; c < ncells; c += kBlock) {
-        const uint32_t idx = (uint32_t)j * (uint32_t)a.stride + (uint32_t)c;
-        const uint32_t bits = __float_as_uint(bt[idx]);
-        const uint32_t b = bits >> kHShift;
-        const uint32_t pos = boff[b] + row[b] + atomicAdd(&s_cnt[b], 1u);
-        pairs[pos] = ((uint64_t)bits << 32) | (uint64_t)idx;
     }
 }
 
@@ -551,51 +613,209 @@ __device__ __forceinline__ void bitonic_sort(Ptr d, int n)
     }
 }
 
-// one workgroup per bucket: sorted border values -> sb, every border's prefix index -> rank[owner].
+// inclusive scan of tab[0 .. kHSub] in place (tab[s + 1] held the entries of sub-bin s: afterwards tab[s] = entries below
+// sub-bin s, tab[kHSub] = all)
+__device__ __forceinline__ void subbin_scan(uint32_t *tab, uint32_t *s_w)
+{
+    constexpr int kTabPer = (kHSub + kBlock) / kBlock;   // 5 entries per thread (1025 entries)
+    const int tid = threadIdx.x;
+    uint32_t c[kTabPer], sum = 0u;
+#pragma unroll
+    for (int q = 0; q < kTabPer; ++q) {
+        const int i = tid * kTabPer + q;
+        c[q] = i <= kHSub ? tab[i] : 0u;
+        sum += c[q];
+    }
+    uint32_t total;
+    uint32_t run = block_excl_scan<kBlock>(sum, s_w, total);
+#pragma unroll
+    for (int q = 0; q < kTabPer; ++q) {
+        const int i = tid * kTabPer + q;
+        run += c[q];
+        if (i <= kHSub) tab[i] = run;
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ uint32_t subbin_of(uint32_t v) { return (v >> (kHShift - kHSubBits)) & (kHSub - 1); }
+
+// One bucket: gather its borders from the candidates' sorted tables (candidate j has `count` of them there, starting at cell
+// `first`: btab), sort them by (value, owner) and tell every border its prefix index.
 // Interval ids: bucket b owns ids boff[b] + b + i, i = 0 .. nb (interval i = keys of the bucket in [border i-1, border i));
 // "everything below border i of bucket b" = the intervals with ids < boff[b] + b + i + 1.
-__global__ void __launch_bounds__(kBlock)
-k_border_sort(uint64_t *__restrict__ pairs, const uint32_t *__restrict__ boff, uint32_t *__restrict__ sb,
-              uint32_t *__restrict__ rank)
+// The sort is one more most-significant-digit step: the bucket's borders share their top 11 key bits, the next 10 bits
+// (sub-bin) place a border to within ~2 positions -- count, scan, place -- and the rank inside a sub-bin is the number of
+// smaller {value, owner} pairs there.  (A 66-stage bitonic network on 2048 pairs took 39 us per launch.)  The scan is also
+// the bucket's sub-bin table for k_moments.  More than kSortLds borders (never seen): the network on global memory.
+__device__ __forceinline__ void border_sort_body(int b, uint32_t *s_raw, const float *__restrict__ bt, const uint32_t *__restrict__ btab,
+                                                 const uint32_t *__restrict__ bhist, int n_pairs, int stride,
+                                                 uint32_t *__restrict__ sb, uint32_t *__restrict__ rank,
+                                                 uint32_t *__restrict__ gtab, uint64_t *__restrict__ pairs)
 {
-    __shared__ uint64_t s_p[kSortLds];
-    const int b = blockIdx.x;
-    const uint32_t o = boff[b];
-    const int nb = (int)(boff[b + 1] - o);
+    uint64_t *e = reinterpret_cast<uint64_t *>(s_raw);                  // kSortLds pairs {value bits << 32 | owner}, as gathered
+    uint16_t *perm = reinterpret_cast<uint16_t *>(s_raw + 2 * kSortLds); // kSortLds: position in sub-bin order -> index into e
+    uint32_t *tab = s_raw + 2 * kSortLds + kSortLds / 2;               // kHSub + 2
+    uint32_t *cur = tab + kHSub + 2;                                   // kHSub + 2
+    uint32_t *s_w = cur + kHSub + 2;                                   // 4 + the gather cursor + 2 x 4 for the offsets
+    const int tid = threadIdx.x;
+    const int nb = (int)bhist[b];
     if (nb == 0) return;
-    uint64_t *g = pairs + o;
-    if (nb <= kSortLds) {
-        for (int i = threadIdx.x; i < nb; i += kBlock) s_p[i] = g[i];
-        __syncthreads();
-        bitonic_sort(s_p, nb);
-        for (int i = threadIdx.x; i < nb; i += kBlock) {
-            const uint64_t v = s_p[i];
-            sb[o + i] = (uint32_t)(v >> 32);
-            rank[(uint32_t)v] = o + (uint32_t)b + (uint32_t)i + 1u;
+    // this bucket's first border (boff[b]) and its position among the buckets that have borders, from the column totals
+    uint32_t o, li;
+    {
+        uint32_t so = 0u, sl = 0u;
+        for (int i = tid; i < b; i += kBlock) {
+            const uint32_t c = bhist[i];
+            so += c;
+            sl += c ? 1u : 0u;
         }
-    } else {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            so += __shfl_xor(so, off, 64);
+            sl += __shfl_xor(sl, off, 64);
+        }
+        if ((tid & 63) == 0) {
+            s_w[8 + (tid >> 6)] = so;
+            s_w[12 + (tid >> 6)] = sl;
+        }
         __syncthreads();
-        bitonic_sort(g, nb);     // (global memory: a workgroup's own stores are visible to it after the barrier)
-        for (int i = threadIdx.x; i < nb; i += kBlock) {
-            const uint64_t v = g[i];
-            sb[o + i] = (uint32_t)(v >> 32);
-            rank[(uint32_t)v] = o + (uint32_t)b + (uint32_t)i + 1u;
+        o = s_w[8] + s_w[9] + s_w[10] + s_w[11];
+        li = s_w[12] + s_w[13] + s_w[14] + s_w[15];
+    }
+    {
+        const bool in_lds = nb <= kSortLds;
+        uint64_t *dst = in_lds ? e : pairs + o;
+        for (int i = tid; i <= kHSub + 1; i += kBlock) tab[i] = 0u;
+        if (tid == 0) s_w[4] = 0u;
+        __syncthreads();
+        // gather (any order) + count per sub-bin: four candidates per thread and trip, their table entries loaded together
+        for (int j0 = 0; j0 < n_pairs; j0 += 4 * kBlock) {
+            uint32_t ent[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int j = j0 + q * kBlock + tid;
+                ent[q] = j < n_pairs ? btab[(int64_t)j * kHBuckets + b] : 0u;
+            }
+            uint32_t pos[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pos[q] = (ent[q] & 0xffffu) ? atomicAdd(&s_w[4], ent[q] & 0xffffu) : 0u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t c = ent[q] & 0xffffu, cs = ent[q] >> 16;
+                const uint32_t j = (uint32_t)(j0 + q * kBlock + tid);
+                for (uint32_t i = 0; i < c; ++i) {
+                    const uint32_t idx = j * (uint32_t)stride + cs + i;
+                    const uint32_t v = __float_as_uint(bt[idx]);
+                    dst[pos[q] + i] = ((uint64_t)v << 32) | (uint64_t)idx;
+                    atomicAdd(&tab[subbin_of(v) + 1], 1u);
+                }
+            }
+        }
+        __syncthreads();
+        subbin_scan(tab, s_w);
+        uint32_t *gt = gtab + (int64_t)li * (kHSub + 1);
+        for (int i = tid; i <= kHSub; i += kBlock) {
+            const uint32_t v = tab[i];
+            gt[i] = v;
+            cur[i] = v;
+        }
+        __syncthreads();
+        if (in_lds) {
+            for (int i = tid; i < nb; i += kBlock)            // place into the sub-bin's segment (any order inside it)
+                perm[atomicAdd(&cur[subbin_of((uint32_t)(e[i] >> 32))], 1u)] = (uint16_t)i;
+            __syncthreads();
+            for (int i = tid; i < nb; i += kBlock) {
+                const uint64_t me = e[i];
+                const uint32_t s = subbin_of((uint32_t)(me >> 32));
+                const uint32_t s0 = tab[s], s1 = tab[s + 1];
+                uint32_t r = s0;
+                for (uint32_t k = s0; k < s1; ++k) r += e[perm[k]] < me ? 1u : 0u;
+                sb[o + r] = (uint32_t)(me >> 32);
+                rank[(uint32_t)me] = o + (uint32_t)b + r + 1u;
+            }
+        } else {
+            bitonic_sort(dst, nb);     // (global memory: a workgroup's own stores are visible to it after the barrier)
+            for (int i = tid; i < nb; i += kBlock) {
+                const uint64_t v = dst[i];
+                sb[o + i] = (uint32_t)(v >> 32);
+                rank[(uint32_t)v] = o + (uint32_t)b + (uint32_t)i + 1u;
+            }
         }
     }
 }
 
-// ---- 4. moments of the intervals ----------------------------------------------------------------------------------------
-// dynamic LDS: uint64 cntA[bcap + 1] {n << 40 | sum d} | uint64 cntB[bcap + 1] {sum d^2} | uint32 bord[bcap] | uint32 tab[65]
+// the border sort: one workgroup per coarse bucket (most have no borders and leave at once); needs only the column totals
+// `bhist`, so it runs BEFORE the plan and never next to the key scatter (there, with the memory system saturated, its chains
+// of dependent loads took 35 us per bucket)
 __global__ void __launch_bounds__(kBlock)
-k_moments(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ sb, const Unit *__restrict__ units,
-          const uint32_t *__restrict__ nunits, uint32_t *__restrict__ g_n, unsigned long long *__restrict__ g_d,
-          unsigned long long *__restrict__ g_d2lo, unsigned long long *__restrict__ g_d2hi, int bcap)
+k_border_sort(const float *__restrict__ bt, const uint32_t *__restrict__ btab, const uint32_t *__restrict__ bhist, int n_pairs,
+              int stride, uint32_t *__restrict__ sb, uint32_t *__restrict__ rank, uint32_t *__restrict__ gtab,
+              uint64_t *__restrict__ pairs)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t s_raw[2 * kSortLds + kSortLds / 2 + 2 * (kHSub + 2) + 16];
+    border_sort_body((int)blockIdx.x, s_raw, bt, btab, bhist, n_pairs, stride, sb, rank, gtab, pairs);
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_part_scatter(const uint32_t *__restrict__ x, int64_t n, int64_t ntiles, int tpw, const uint32_t *__restrict__ koff,
+               const uint32_t *__restrict__ ktab, uint32_t *__restrict__ keys)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t s_raw[kPartLds / 4];
+    part_scatter_body((int)blockIdx.x, s_raw, x, n, ntiles, tpw, koff, ktab, keys);
+}
+
+// ---- 4. moments of the intervals ----------------------------------------------------------------------------------------
+// dynamic LDS: uint64 cntA[bcap + 1] {n << 40 | sum d} | uint64 cntB[bcap + 1] {sum d^2} | uint32 bord[bcap] | uint32 tab[1025]
+// tab[s] = borders of the chunk below sub-bin s (the key's next 10 bits), from the bucket's table (border_sort_body): a key's
+// interval is found with the two table entries of its sub-bin and a bisection over the handful of borders between them
+// (with 64 sub-bins the bisection -- 5-7 dependent LDS reads per key -- was 2/3 of the kernel).  16 keys per lane are in
+// flight (four 16-byte loads) and searched side by side, four at a time.
+__device__ __forceinline__ void moments_keys4(const uint32_t (&kv)[4], const uint32_t *tab, const uint32_t *bord, unsigned long long *cntA,
+                                              unsigned long long *cntB, uint32_t prev, int cnt, bool last, int csh, int cpy)
+{
+    int lo[4], hi[4];
+    bool any = false;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t s = subbin_of(kv[q]);
+        lo[q] = (int)tab[s];
+        hi[q] = (int)tab[s + 1];
+        any |= lo[q] < hi[q];
+    }
+    while (any) {                                         // borders <= key
+        any = false;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (lo[q] < hi[q]) {
+                const int mid = (lo[q] + hi[q]) >> 1;
+                if (bord[mid] <= kv[q]) lo[q] = mid + 1; else hi[q] = mid;
+                any |= lo[q] < hi[q];
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t key = kv[q];
+        // (a real key is never 0: zeros were dropped); keys below `prev` or behind the chunk's last border: another chunk's
+        if (key == 0u || key < prev || (lo[q] == cnt && !last)) continue;
+        const unsigned long long d = key & kHMask;
+        const int at = (lo[q] << csh) + cpy;
+        atomicAdd(&cntA[at], (1ull << 40) + d);
+        atomicAdd(&cntB[at], d * d);
+    }
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_moments(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ sb, const uint32_t *__restrict__ gtab,
+          const Unit *__restrict__ units, const uint32_t *__restrict__ nunits, uint32_t *__restrict__ g_n,
+          unsigned long long *__restrict__ g_d, unsigned long long *__restrict__ g_d2lo, unsigned long long *__restrict__ g_d2hi,
+          int bcap)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long *cntA = reinterpret_cast<unsigned long long *>(smem);
     unsigned long long *cntB = cntA + (bcap + 1);
     uint32_t *bord = reinterpret_cast<uint32_t *>(cntB + (bcap + 1));
-    uint32_t *tab = bord + bcap;
+    uint32_t *tab = bord + bcap;                  // kHSub + 1 entries
     const int tid = threadIdx.x;
     const uint32_t nu = nunits[0];
     for (uint32_t u = blockIdx.x; u < nu; u += gridDim.x) {
@@ -607,53 +827,47 @@ k_moments(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ sb, co
         const int cnt = min(nb - a0, bcap);                       // borders of this chunk (0 when the bucket has none)
         const bool last = a0 + cnt == nb;                         // the chunk that owns the interval behind the last border
         const uint32_t prev = a0 > 0 ? sb[bo + a0 - 1] : 0u;      // keys below it belong to an earlier chunk
-        for (int i = tid; i < cnt; i += kBlock) bord[i] = sb[bo + a0 + i];
-        for (int i = tid; i <= cnt; i += kBlock) cntA[i] = cntB[i] = 0ull;
-        __syncthreads();
-        if (tid <= kHSub) {
-            // tab[s] = borders below sub-bin s of this bucket (s = 64: below the next bucket = cnt when the chunk is the last)
-            const uint32_t v = (b << kHShift) + ((uint32_t)tid << (kHShift - kHSubBits));
-            int lo = 0, hi = cnt;
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if (bord[mid] < v) lo = mid + 1; else hi = mid;
-            }
-            tab[tid] = (uint32_t)lo;
+        const uint32_t *gt = gtab + (int64_t)un.li * (kHSub + 1);
+        for (int i = tid; i <= kHSub; i += kBlock) {
+            const int v = nb ? (int)gt[i] - a0 : 0;               // the bucket's table, relative to the chunk
+            tab[i] = (uint32_t)min(max(v, 0), cnt);
         }
+        for (int i = tid; i < cnt; i += kBlock) bord[i] = sb[bo + a0 + i];
+        // 2^csh copies of every interval's counters, interleaved (copy c of interval i at (i << csh) + c: neighbouring
+        // banks), a lane uses copy lane % 2^csh: with ~100 intervals per bucket (111 candidates) two thirds of the kernel's
+        // LDS cycles were conflicts of lanes adding to the same counter
+        int csh = 0;
+        while (csh < 3 && ((cnt + 1) << (csh + 1)) <= bcap + 1) ++csh;
+        const int ncnt = (cnt + 1) << csh, cpy = tid & ((1 << csh) - 1);
+        for (int i = tid; i < ncnt; i += kBlock) cntA[i] = cntB[i] = 0ull;
         __syncthreads();
         const uint32_t *kp = keys + un.key0;
         const int kn = (int)un.kn;
-        for (int i0 = tid * 4; i0 < kn; i0 += kBlock * 4) {
-            uint32_t kv[4];
-            if (i0 + 3 < kn) {
-                const u32x4u v = *reinterpret_cast<const u32x4u *>(kp + i0);
-                kv[0] = v.x, kv[1] = v.y, kv[2] = v.z, kv[3] = v.w;
-            } else {
+        for (int r0 = 0; r0 < kn; r0 += 16 * kBlock) {
+            uint32_t kv[4][4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) kv[q] = i0 + q < kn ? kp[i0 + q] : 0u;   // 0: skipped below
-            }
+            for (int v = 0; v < 4; ++v) {
+                const int i0 = r0 + v * 4 * kBlock + tid * 4;
+                if (i0 + 3 < kn) {
+                    const u32x4u w = *reinterpret_cast<const u32x4u *>(kp + i0);
+                    kv[v][0] = w.x, kv[v][1] = w.y, kv[v][2] = w.z, kv[v][3] = w.w;
+                } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const uint32_t key = kv[q];
-                if (key == 0u || key < prev) continue;            // (a real key is never 0: zeros were dropped)
-                const uint32_t s = (key >> (kHShift - kHSubBits)) & (kHSub - 1);
-                int lo = (int)tab[s], hi = (int)tab[s + 1];
-                while (lo < hi) {                                 // borders <= key
-                    const int mid = (lo + hi) >> 1;
-                    if (bord[mid] <= key) lo = mid + 1; else hi = mid;
+                    for (int q = 0; q < 4; ++q) kv[v][q] = i0 + q < kn ? kp[i0 + q] : 0u;   // 0: skipped
                 }
-                if (lo == cnt && !last) continue;
-                const unsigned long long d = key & kHMask;
-                atomicAdd(&cntA[lo], (1ull << 40) + d);
-                atomicAdd(&cntB[lo], d * d);
             }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) moments_keys4(kv[v], tab, bord, cntA, cntB, prev, cnt, last, csh, cpy);
         }
         __syncthreads();
         const uint32_t gid0 = bo + b + (uint32_t)a0;
         for (int i = tid; i <= cnt; i += kBlock) {
-            const unsigned long long A = cntA[i];
+            unsigned long long A = 0ull, B = 0ull;
+            for (int c = 0; c < (1 << csh); ++c) {
+                A += cntA[(i << csh) + c];
+                B += cntB[(i << csh) + c];
+            }
             if (A == 0ull || (i == cnt && !last)) continue;
-            const unsigned long long B = cntB[i];
             atomicAdd(&g_n[gid0 + i], (uint32_t)(A >> 40));
             atomicAdd(&g_d[gid0 + i], A & ((1ull << 40) - 1ull));
             atomicAdd(&g_d2lo[gid0 + i], B & 0xffffffffull);
@@ -677,18 +891,21 @@ k_iv_scan_super(const uint32_t *__restrict__ boff, const uint32_t *__restrict__ 
 {
     __shared__ DD s1[kSuper], s2[kSuper];
     __shared__ uint32_t sn[kSuper];
+    __shared__ uint32_t s_first[kHBuckets];       // first interval id of every bucket
     const int tid = threadIdx.x;
     const int64_t i = (int64_t)blockIdx.x * kSuper + tid;
+    for (int b = tid; b < kHBuckets; b += kSuper) s_first[b] = boff[b] + (uint32_t)b;
     const DD zero{0.0, 0.0};
     DD v1 = zero, v2 = zero;
     uint32_t vn = 0u;
     if (i < ni) vn = g_n[i];
+    __syncthreads();
     if (vn) {
-        // the interval's bucket: the last b with boff[b] + b <= i
+        // the interval's bucket: the last b whose first interval is <= i
         int lo = 0, hi = kHBuckets - 1;
         while (lo < hi) {
             const int mid = (lo + hi + 1) >> 1;
-            if ((int64_t)boff[mid] + mid <= i) lo = mid; else hi = mid - 1;
+            if ((int64_t)s_first[mid] <= i) lo = mid; else hi = mid - 1;
         }
         const int e = lo >> 3, t = lo & 7;
         const double A = (double)((e ? (1u << 23) : 0u) + ((uint32_t)t << kHShift));
@@ -825,7 +1042,7 @@ k_mse_eval(const float *__restrict__ x, const float *__restrict__ grid, const fl
         for (int c = tid; c < ncells; c += kBlock) {
             const float lo = T[c], hi = c + 1 < ncells ? T[c + 1] : __builtin_inff();
             if (!(lo < hi)) continue;
-            const int64_t i0 = c ? (int64_t)R[c] : 0, i1 = c + 1 < ncells ? (int64_t)R[c + 1] : ni;
+            const int64_t i0 = c ? (int64_t)R[c] : 0, i1 = hi < __builtin_inff() ? (int64_t)R[c + 1] : ni;   // (T = +inf: not a border)
             const int64_t b0 = i0 / kSuper, b1 = i1 / kSuper;
             const uint32_t cnt = (tn[b1] + pn[i1]) - (tn[b0] + pn[i0]);
             if (cnt == 0u) continue;
@@ -862,15 +1079,14 @@ int env_int(const char *name, int dflt, int lo, int hi)
 }
 
 // tuning knobs (defaults are the measured best): borders per k_moments chunk, smallest key slice
-int hist_bcap() { static const int v = env_int("FP8Q_MSE_BCAP", 2048, 16, 6144); return v; }
-int hist_slice_min() { static const int v = env_int("FP8Q_MSE_SLICE", 8192, 1024, 65536); return v & ~3; }
+int hist_bcap() { static const int v = env_int("FP8Q_MSE_BCAP", 1024, 16, 6144); return v; }
+int hist_slice_min() { static const int v = env_int("FP8Q_MSE_SLICE", 16384, 1024, 65536); return v & ~3; }
 
-constexpr int kStrideBound = 260;   // cells of one candidate of a signed format of <= 8 bits: (2^E + 1) 2^M + 2 <= 258
 
 struct HistLayout {
-    size_t keys, zero0, zero_bytes;           // [zero0, zero0 + zero_bytes): cleared before every call
+    size_t keys, zero0, zero_bytes;           // [zero0, zero0 + zero_bytes): cleared in every call (k_tab_scan)
     size_t gn, gd, gd2lo, gd2hi;
-    size_t hist, bhist, ktab, btab, kmax, maxkey, nunits;
+    size_t hist, bhist, ktab, btab, kmax, maxkey, nunits, blist, gtab;
     size_t koff, boff, units, bt, bq, rank, cflag, pairs, sb, p1, p2, pn, t1, t2, tn;
     size_t total;
     int64_t nbord, ni, nsb;
@@ -908,7 +1124,10 @@ HistLayout hist_layout(int64_t n, int64_t n_pairs, int stride, int bcap, int sli
     L.btab = take((size_t)n_pairs * kHBuckets * 4);
     L.kmax = take(kPartWgs * 4);
     L.maxkey = take(4);
-    L.nunits = take(4);
+    L.nunits = take(8);
+    L.blist = take(kHBuckets * 4);
+    // sub-bin tables: one per bucket that has borders -- at most min(2048, borders) of them
+    L.gtab = take((size_t)(L.nbord < kHBuckets ? L.nbord : kHBuckets) * (kHSub + 1) * 4);
     L.koff = take((kHBuckets + 1) * 4);
     L.boff = take((kHBuckets + 1) * 4);
     L.units = take((size_t)L.units_max * sizeof(Unit));
@@ -971,6 +1190,7 @@ int fp8q_mse_hist_launch(const float *x, int64_t n, const float *grid, int64_t n
     uint32_t *keys = (uint32_t *)at(L.keys), *hist = (uint32_t *)at(L.hist), *bhist = (uint32_t *)at(L.bhist);
     uint32_t *ktab = (uint32_t *)at(L.ktab), *btab = (uint32_t *)at(L.btab), *kmax = (uint32_t *)at(L.kmax);
     uint32_t *maxkey = (uint32_t *)at(L.maxkey), *nunits = (uint32_t *)at(L.nunits), *gn = (uint32_t *)at(L.gn);
+    uint32_t *blist = (uint32_t *)at(L.blist), *gtab = (uint32_t *)at(L.gtab);
     unsigned long long *gd = (unsigned long long *)at(L.gd), *gd2lo = (unsigned long long *)at(L.gd2lo),
                        *gd2hi = (unsigned long long *)at(L.gd2hi);
     uint32_t *koff = (uint32_t *)at(L.koff), *boff = (uint32_t *)at(L.boff);
@@ -981,32 +1201,29 @@ int fp8q_mse_hist_launch(const float *x, int64_t n, const float *grid, int64_t n
     uint64_t *pairs = (uint64_t *)at(L.pairs);
     DD *p1 = (DD *)at(L.p1), *p2 = (DD *)at(L.p2), *t1 = (DD *)at(L.t1), *t2 = (DD *)at(L.t2);
 
-    if (hipError_t e = hipMemsetAsync(at(L.zero0), 0, L.zero_bytes, st); e != hipSuccess) return hip_rc(e);
     const uint32_t *xb = reinterpret_cast<const uint32_t *>(x);
     const int64_t ntiles = cdiv(n, kPartTile);
     const int tpw = (int)cdiv(ntiles, kPartWgs);              // tiles per partition workgroup
     const int pwgs = (int)cdiv(ntiles, tpw);                  // <= kPartWgs, none of them empty
-    hipLaunchKernelGGL(k_mse_borders, dim3((unsigned)n_pairs), dim3(kBlock), 0, st, grid, a, brute, bt, bq, cflag, btab);
+    hipLaunchKernelGGL(k_stage1, dim3((unsigned)(n_pairs + pwgs)), dim3(kBlock), 0, st, xb, n, ntiles, tpw, ktab, kmax, grid, a, brute,
+                       bt, bq, cflag, btab);
     if (int rc = launch_rc()) return rc;
-    hipLaunchKernelGGL(k_part_hist, dim3((unsigned)pwgs), dim3(kBlock), 0, st, xb, n, ntiles, tpw, ktab, kmax);
+    hipLaunchKernelGGL(k_tab_scan, dim3(kHBuckets / 32, 2), dim3(1024), 0, st, ktab, pwgs, hist, btab, (int)n_pairs, bhist,
+                       (uint4 *)at(L.zero0), (int64_t)(L.zero_bytes / 16));
     if (int rc = launch_rc()) return rc;
-    hipLaunchKernelGGL(k_tab_scan, dim3(kHBuckets / 64, 2), dim3(kBlock), 0, st, ktab, pwgs, hist, btab, (int)n_pairs, bhist);
+    hipLaunchKernelGGL(k_border_sort, dim3(kHBuckets), dim3(kBlock), 0, st, bt, btab, bhist, (int)n_pairs, a.stride, sb, rank, gtab, pairs);
     if (int rc = launch_rc()) return rc;
-    hipLaunchKernelGGL(k_mse_plan, dim3(1), dim3(1024), 0, st, hist, bhist, kmax, pwgs, koff, boff, units, nunits, maxkey,
+    hipLaunchKernelGGL(k_mse_plan, dim3(1), dim3(1024), 0, st, hist, bhist, kmax, pwgs, koff, boff, units, nunits, maxkey, blist,
                        L.units_max, bcap, slice_min);
     if (int rc = launch_rc()) return rc;
-    hipLaunchKernelGGL(k_border_scatter, dim3((unsigned)n_pairs), dim3(kBlock), 0, st, bt, cflag, a, boff, btab, pairs);
-    if (int rc = launch_rc()) return rc;
     hipLaunchKernelGGL(k_part_scatter, dim3((unsigned)pwgs), dim3(kBlock), 0, st, xb, n, ntiles, tpw, koff, ktab, keys);
-    if (int rc = launch_rc()) return rc;
-    hipLaunchKernelGGL(k_border_sort, dim3(kHBuckets), dim3(kBlock), 0, st, pairs, boff, sb, rank);
     if (int rc = launch_rc()) return rc;
     const size_t shmem = (size_t)(bcap + 1) * 16 + (size_t)bcap * 4 + (kHSub + 1) * 4;
     if (shmem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)k_moments, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return hip_rc(e);
     }
-    hipLaunchKernelGGL(k_moments, dim3(2048), dim3(kBlock), shmem, st, keys, sb, units, nunits, gn, gd, gd2lo, gd2hi, bcap);
+    hipLaunchKernelGGL(k_moments, dim3(2048), dim3(kBlock), shmem, st, keys, sb, gtab, units, nunits, gn, gd, gd2lo, gd2hi, bcap);
     if (int rc = launch_rc()) return rc;
     hipLaunchKernelGGL(k_iv_scan_super, dim3((unsigned)L.nsb), dim3(kSuper), 0, st, boff, gn, gd, gd2lo, gd2hi, L.ni, p1, p2, pn, t1,
                        t2, tn);

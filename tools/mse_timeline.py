@@ -6,10 +6,9 @@ rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Time
 calls, cur = [], None
 for r in rows:
     name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
-    if name == "__amd_rocclr_fillBufferAligned" or cur is None and name.startswith("k_mse_borders"):
-        if cur: calls.append(cur)
+    if name.startswith("k_stage1"):
         cur = []
-    if cur is not None and (name.startswith("k_") or name.startswith("__amd_rocclr_fill")):
+    if cur is not None and name.startswith("k_"):
         cur.append((name, int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Grid_Size_X"]))
         if name.startswith("k_mse_eval"):
             calls.append(cur)

@@ -1,0 +1,9 @@
+import csv, sys, glob, collections
+for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
+    acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
+        acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+    for k, d in acc.items():
+        if k.startswith("k_"):
+            print(k, {c: f"{v/3:.3g}" for c, v in d.items()})
