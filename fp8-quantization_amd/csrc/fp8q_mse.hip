@@ -67,6 +67,7 @@ k_mse_grid(const float *__restrict__ x, const float *__restrict__ grid, double *
     // scale or its reciprocal may be denormal, zero or infinite -- E = 7 with maxval < ~2^(M-22): s_1 underflows to 0 and
     // the reference's 0 / 0 makes every zero element NaN) divide as the reference does, like k_mse_row's exact path.
     const bool exact_div = f.pmax == 1 || ch.pthr < 0.0f;
+    const float tie_thr = 0.5f - 5.0f * __builtin_ldexpf(1.0f, (int)f.M - 23);   // (kTieW of the row kernel; f.M <= 16)
     double acc = 0.0;
 
     for (int64_t t0 = (int64_t)split * kMseTile; t0 < a.inner; t0 += (int64_t)a.nsplit * kMseTile) {
@@ -102,7 +103,16 @@ k_mse_grid(const float *__restrict__ x, const float *__restrict__ grid, double *
                         r = rintf(xc / sc);
                         if (j + u * 4 + q >= n) r = sc = 0.0f;   // zero padding: here q(0) may be NaN (s_1 = 0), a real zero's is
                     } else {
-                        r = rintf(ldexpf(tt, jk - e8));
+                        const float qf = ldexpf(tt, jk - e8);
+                        r = rintf(qf);
+                        // within kTieW ulps of a rounding tie (t carries up to 4 ulps of error against the reference's quotient):
+                        // the reference's own binade decision and division for this element (rare: ~1e-5 2^M of the
+                        // (element, candidate) pairs)
+                        if (__builtin_expect(fabsf(qf - r) >= tie_thr, 0)) {
+                            const float ls = __builtin_amdgcn_fmed3f(floorf(log2_tab(fabsf(xc), kFastTab) + ch.bias), 1.0f, (float)f.pmax);
+                            sc = lut[(int)ls];
+                            r = rintf(xc / sc);
+                        }
                     }
                     const float d = xv - r * sc;
                     pa = fmaf(d, d, pa);
@@ -215,12 +225,33 @@ __device__ __forceinline__ float wave_max_f(float v)
 // exponent extraction, no clamp of it to binade 1 and no float add / sub pair: 5 issue slots per element instead of 7, 4
 // when the candidate's range covers the whole tile (CLAMP = false: the v_med3 goes too).  Zero stays zero; a carry out of the fraction moves the value into the next binade, as rounding
 // up must.  TWO = the candidate has two scale mantissas (m0b below |t| = thr).
+//
+// Near ties (round 5).  t carries up to 4 ulps of error against the reference's fl32(xc / s_p) (2^bf and 1 / fl32(2^-bf) differ
+// by a rounding each, the product and the reference's quotient are rounded once more), so an element whose quotient lies
+// within 4 ulps of r + 1/2 may take the other neighbour -- its squared error moves by up to 4 * 2^-21 * 2^(M+1) of itself,
+// which shows in a table entry that a few elements carry (the search grid's last candidate 1.2 max|x| puts the largest element
+// on such a tie for M = 1, 3, 5).  Both loops therefore track how close the lane's elements come to a tie -- `near`: the
+// smallest distance in ulps of t, biased by kTieW, as an unsigned number shifted to the top of the word (one v_lshl_add_u32 +
+// one v_min_u32 per element) / `nearf`: the largest |t - round(t)| - (half step - kTieW ulps) -- and the caller exchanges
+// the squared error of the elements that came within kTieW ulps for the reference's (mse_tie_patch).  Exact ties round half up here
+// and half to even there: same distance, same squared error to the last bits of r * m0 -- they are re-evaluated too.
+constexpr uint32_t kTieW = 5u;    // ulps of t around a tie that count as "near" (the bound above is 4)
+
+// (a << k) + c in one instruction (written as C the compiler re-associates it into an add and a shift; one SGPR operand at most)
+__device__ __forceinline__ uint32_t lshl_add(uint32_t a, uint32_t k, uint32_t c)
+{
+    uint32_t d;
+    asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(k), "v"(c));
+    return d;
+}
+
 template <bool CLAMP, bool TWO>
 __device__ __forceinline__ vf2 mse_cand_int(const vf2 (&xv)[kMseRowEpl / 2], float minv, float maxv, float c1s, float m0s, float m0b, float thr,
-                                            uint32_t half, uint32_t msk)
+                                            uint32_t half, uint32_t msk, uint32_t ksh, uint32_t nadd, uint32_t &near)
 {
     const vf2 c1 = {c1s, c1s}, m0 = {m0s, m0s};
     vf2 pa = {0.0f, 0.0f};
+    uint32_t mn = 0xffffffffu;
 #pragma unroll
     for (int u = 0; u < kMseRowEpl / 2; ++u) {
         const vf2 xx = xv[u];
@@ -232,24 +263,28 @@ __device__ __forceinline__ vf2 mse_cand_int(const vf2 (&xv)[kMseRowEpl / 2], flo
         // where both neighbours are equally far from x -- the squared error is the same (to the last bits of r * m0)
         const uint32_t r0 = (b0 + half) & msk;
         const uint32_t r1 = (b1 + half) & msk;
+        // (the dropped bits + kTieW) mod 2^sh, moved to the top of the word: <= 2 kTieW << ksh within kTieW ulps of a tie
+        mn = min(mn, min(lshl_add(b0, ksh, nadd), lshl_add(b1, ksh, nadd)));
         const vf2 rr = {__uint_as_float(r0), __uint_as_float(r1)};
         vf2 ms = m0;
         if (TWO) ms = vf2{fabsf(tt.x) < thr ? m0b : m0s, fabsf(tt.y) < thr ? m0b : m0s};
         const vf2 d = xx - rr * ms;
         pa = __builtin_elementwise_fma(d, d, pa);
     }
+    near = mn;
     return pa;
 }
 
 // The general fast loop: the float magic-number rounding (t + C) - C, C = 1.5 * 2^(max(exponent(t), exponent of binade 1)
 // + 23 - M) -- the max is the subnormal range's fixed step, which the integer loop above cannot do.  7 issue slots per
-// element, 6 without the clamp.
+// element, 6 without the clamp (+ ~3 for the near-tie watch: half step = 2^(exponent(C) - 24) from C's bits, kf = 1 - kTieW 2^(M-22)).
 template <bool CLAMP, bool TWO>
 __device__ __forceinline__ vf2 mse_cand_magic(const vf2 (&xv)[kMseRowEpl / 2], float minv, float maxv, float c1s, float m0s, float m0b, float thr,
-                                              uint32_t lo, uint32_t kadd)
+                                              uint32_t lo, uint32_t kadd, float kf, float &nearf)
 {
     const vf2 c1 = {c1s, c1s}, m0 = {m0s, m0s};
     vf2 pa = {0.0f, 0.0f};
+    float mx = -__builtin_inff();
 #pragma unroll
     for (int u = 0; u < kMseRowEpl / 2; ++u) {
         const vf2 xx = xv[u];
@@ -260,15 +295,64 @@ __device__ __forceinline__ vf2 mse_cand_magic(const vf2 (&xv)[kMseRowEpl / 2], f
         const uint32_t b1 = max(__float_as_uint(tt.y) & 0x7f800000u, lo) + kadd;
         const vf2 cc = {__uint_as_float(b0), __uint_as_float(b1)};
         const vf2 rr = (tt + cc) - cc;          // t rounded to M fraction bits, half to even
+        const vf2 dt = tt - rr;
+        const vf2 hs = {__uint_as_float(b0 - 0x0C400000u), __uint_as_float(b1 - 0x0C400000u)};   // half a rounding step
+        const vf2 hk = hs * vf2{kf, kf};
+        mx = fmaxf(mx, fmaxf(fabsf(dt.x) - hk.x, fabsf(dt.y) - hk.y));
         vf2 ms = m0;
         if (TWO) ms = vf2{fabsf(tt.x) < thr ? m0b : m0s, fabsf(tt.y) < thr ? m0b : m0s};
         const vf2 d = xx - rr * ms;
         pa = __builtin_elementwise_fma(d, d, pa);
     }
+    nearf = mx;
     return pa;
 }
 
-__global__ void __launch_bounds__(64)
+// A candidate that came near a tie on this lane: walk the lane's 64 elements once more -- read again from memory, so that this
+// rare path neither keeps the caller's register tile alive nor indexes it dynamically (k_mse_row is compiled for 3 waves per
+// SIMD: variants that held the tile here cost the fast loops a third of their occupancy) -- with the fast loop's own test, and exchange the squared error of every element within kTieW ulps of a tie,
+// as the fast loop formed it, for the reference's: K1's exact binade decision, the exact scale, IEEE division, round half
+// even.  Returns the correction of the lane's sum.  A few 1e-4 of the (lane, candidate) pairs on continuous data.
+__device__ __forceinline__ float mse_tie_patch(const float *__restrict__ xt /* the tile */, int lane, int64_t left /* elements from the tile's start */,
+                                            QFmt f, float maxv, float c1s, float m0s, float m0b, float thr, uint32_t lo, uint32_t kadd,
+                                            int use_int, int two)
+{
+    const Chan ch = make_chan(maxv, f);
+    const uint32_t sh = kadd >> 23;
+    const uint32_t half = 1u << (sh - 1u), msk = ~((1u << sh) - 1u), ksh = 32u - sh, nadd = (half + kTieW) << ksh;
+    const uint32_t nthr = (2u * kTieW) << ksh;
+    const float kf = 1.0f - (float)kTieW * __builtin_ldexpf(1.0f, (int)f.M - 22);
+    float delta = 0.0f;
+#pragma unroll 1
+    for (int j = 0; j < kMseRowEpl; ++j) {
+        const int off = (j >> 2) * 256 + lane * 4 + (j & 3);
+        if (off >= left) break;                        // zero padding of the row's last tile (q(0) = 0 either way)
+        const float x = xt[off];
+        const float xc = __builtin_amdgcn_fmed3f(x, ch.minv, ch.maxv);   // (a no-op where the fast loop skipped the clamp)
+        const float tt = xc * c1s;
+        float rr;
+        bool near;
+        if (use_int) {
+            rr = __uint_as_float((__float_as_uint(tt) + half) & msk);
+            near = (__float_as_uint(tt) << ksh) + nadd <= nthr;
+        } else {
+            const uint32_t b = max(__float_as_uint(tt) & 0x7f800000u, lo) + kadd;
+            const float cc = __uint_as_float(b);
+            rr = (tt + cc) - cc;
+            near = fabsf(tt - rr) - __uint_as_float(b - 0x0C400000u) * kf >= 0.0f;
+        }
+        if (!near) continue;
+        const float ms = (two && fabsf(tt) < thr) ? m0b : m0s;
+        const float df = x - rr * ms;
+        const float ls = __builtin_amdgcn_fmed3f(floorf(log2_tab(fabsf(xc), kFastTab) + ch.bias), 1.0f, (float)f.pmax);
+        const float sc = scale_exact(ch, ls, f.M);
+        const float de = x - rintf(xc / sc) * sc;
+        delta += de * de - df * df;
+    }
+    return delta;
+}
+
+__global__ void __launch_bounds__(64, 3)   // 3 waves per SIMD: the rare near-tie path may spill, the fast loops must not lose occupancy to it
 k_mse_row(const float *__restrict__ x, const float *__restrict__ grid, double *__restrict__ ws, MseArgs a,
           int64_t ntiles, int tpb, int ngroup, int gsize)
 {
@@ -372,24 +456,36 @@ k_mse_row(const float *__restrict__ x, const float *__restrict__ grid, double *_
                 if (int_ok) {
                     const uint32_t sh = k.kadd >> 23;                       // 23 - M: position of the last kept fraction bit
                     const uint32_t half = 1u << (sh - 1u), msk = ~((1u << sh) - 1u);
+                    const uint32_t ksh = 32u - sh, nadd = (half + kTieW) << ksh;
                     const bool cover = tmn >= k.minv && tmx <= k.maxv;   // the candidate's range covers the tile: nothing to clamp
                     const float thr = __uint_as_float(k.thr);
+                    uint32_t near;
                     if (k.fast == 1) {
-                        pa = cover ? mse_cand_int<false, false>(xv, k.minv, k.maxv, k.c1, k.m0, k.m0b, thr, half, msk)
-                                   : mse_cand_int<true, false>(xv, k.minv, k.maxv, k.c1, k.m0, k.m0b, thr, half, msk);
+                        pa = cover ? mse_cand_int<false, false>(xv, k.minv, k.maxv, k.c1, k.m0, k.m0b, thr, half, msk, ksh, nadd, near)
+                                   : mse_cand_int<true, false>(xv, k.minv, k.maxv, k.c1, k.m0, k.m0b, thr, half, msk, ksh, nadd, near);
                     } else {
-                        pa = cover ? mse_cand_int<false, true>(xv, k.minv, k.maxv, k.c1, k.m0, k.m0b, thr, half, msk)
-                                   : mse_cand_int<true, true>(xv, k.minv, k.maxv, k.c1, k.m0, k.m0b, thr, half, msk);
+                        pa = cover ? mse_cand_int<false, true>(xv, k.minv, k.maxv, k.c1, k.m0, k.m0b, thr, half, msk, ksh, nadd, near)
+                                   : mse_cand_int<true, true>(xv, k.minv, k.maxv, k.c1, k.m0, k.m0b, thr, half, msk, ksh, nadd, near);
+                    }
+                    if (__builtin_expect(near <= (((2u * kTieW) << ksh) | ((1u << ksh) - 1u)), 0)) {   // some lanes, rarely
+                        const QFmt f = a.fmt[k.m];
+                        pa.x += mse_tie_patch(xr + e0, lane, a.inner - e0, f, k.maxv, k.c1, k.m0, k.m0b, thr, k.lo, k.kadd, 1, k.fast == 2);
                     }
                 } else if (k.fast != 0) {
                     const bool cover = tmn >= k.minv && tmx <= k.maxv;   // nothing to clamp for this candidate on this tile
                     const float thr = __uint_as_float(k.thr);
+                    const float kf = 1.0f - (float)kTieW * __builtin_ldexpf(1.0f, 1 - (int)(k.kadd >> 23));   // 1 - kTieW 2^(M-22)
+                    float nearf;
                     if (k.fast == 1) {
-                        pa = cover ? mse_cand_magic<false, false>(xv, k.minv, k.maxv, k.c1, k.m0, k.m0b, thr, k.lo, k.kadd)
-                                   : mse_cand_magic<true, false>(xv, k.minv, k.maxv, k.c1, k.m0, k.m0b, thr, k.lo, k.kadd);
+                        pa = cover ? mse_cand_magic<false, false>(xv, k.minv, k.maxv, k.c1, k.m0, k.m0b, thr, k.lo, k.kadd, kf, nearf)
+                                   : mse_cand_magic<true, false>(xv, k.minv, k.maxv, k.c1, k.m0, k.m0b, thr, k.lo, k.kadd, kf, nearf);
                     } else {   // two scale mantissas: the low binades (|t| below thr) use m0b
-                        pa = cover ? mse_cand_magic<false, true>(xv, k.minv, k.maxv, k.c1, k.m0, k.m0b, thr, k.lo, k.kadd)
-                                   : mse_cand_magic<true, true>(xv, k.minv, k.maxv, k.c1, k.m0, k.m0b, thr, k.lo, k.kadd);
+                        pa = cover ? mse_cand_magic<false, true>(xv, k.minv, k.maxv, k.c1, k.m0, k.m0b, thr, k.lo, k.kadd, kf, nearf)
+                                   : mse_cand_magic<true, true>(xv, k.minv, k.maxv, k.c1, k.m0, k.m0b, thr, k.lo, k.kadd, kf, nearf);
+                    }
+                    if (__builtin_expect(nearf >= 0.0f, 0)) {
+                        const QFmt f = a.fmt[k.m];
+                        pa.x += mse_tie_patch(xr + e0, lane, a.inner - e0, f, k.maxv, k.c1, k.m0, k.m0b, thr, k.lo, k.kadd, 0, k.fast == 2);
                     }
                 } else {
                     // exact per-element path (scales not exactly geometric in fp32, tiny / huge / degenerate ranges)
@@ -570,13 +666,16 @@ static int mse_hist_mode()
     return v;
 }
 
-// The route costs ~kHistFixed of launches plus ~kHistPerKey per element whatever the number of candidates; k_mse_row costs
-// ~kRowPerPair per (element, width, candidate).  (Measured on MI355X: profiles/r05_mse_kernel_stats.csv.)
+// The route's cost does not depend on the data: ~55 us of small launches + ~0.1 us per (width, candidate) pair for the borders
+// + ~4.3 ps per element (partition at the copy rate + the moments); k_mse_row costs ~0.19 ps per (element, pair).
+// (MI355X, tools/mb_mse_sizes.py: 111 pairs break even at ~4 M elements, 666 pairs at ~1 M; profiles/r05_mse_sizes.txt.)
+// Which route a row takes depends on its shape only, so a tensor is evaluated the same way on every call.
 static bool mse_use_hist_shape(int64_t C, int64_t inner, int64_t n_cand, int n_m)
 {
     if (mse_hist_mode() == 0 || C != 1 || inner < (1 << 18) || inner >= (1ll << 31)) return false;
-    const double row = (double)inner * (double)(n_m * n_cand) * 0.19e-12;
-    const double hist = 60e-6 + (double)inner * 7e-12;
+    const double pairs = (double)(n_m * n_cand);
+    const double row = (double)inner * pairs * 0.19e-12;
+    const double hist = 55e-6 + pairs * 0.095e-6 + (double)inner * 4.3e-12;
     return row > hist;
 }
 

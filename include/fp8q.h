@@ -146,28 +146,32 @@ int fp8q_minmax_quantize_f32(const float *x, float *y, int64_t C, int64_t inner,
  *   x     [C, inner];  grid [n_cand, C] candidate maxvals;  mbits [n_m] (host array)
  *   mses  [n_m, n_cand, C] fp32, accumulated:  += mean over the row of (x - q(x))^2
  *   ws    scratch of at least fp8q_mse_workspace_bytes(C, inner, n_cand, n_m) bytes
- * NOT bit-exact per element against the oracle (unlike every other entry point): for rows >= 2048 elements the kernel
- * forms x / s as x * 2^frac(bias) * 2^j and rounds that by a magic-number add or directly on its bits (round half up
- * on the magnitude) instead of the reference's IEEE division + table lookup, and it sums in another order (double
- * partials).  The quantized value of an element is the oracle's except on (near-)exact rounding ties -- where both
- * neighbouring grid points are equally far from x, so the squared error is the same; table entries agree with the oracle's to
- * ~1e-6 relative (tests: <= 1e-5 on every entry, the CHOSEN (mantissa bits, maxval) equal to the oracle's choice or
- * its oracle-MSE within 1e-6 relative of the oracle's minimum -- SURVEY.md 8c).  "Near" a tie = the quotient within
- * ~2.4e-7 relative of r + 0.5: a 2.4e-7 fraction of the elements of a continuous distribution, each contributing an error
- * change of <= ~1e-4 of its own squared error.  Only when a few elements carry the entry does that show: a tensor with a
- * handful of DISTINCT magnitudes (all elements of one magnitude share a near-tie) or a heavy-tailed one whose squared error
- * is dominated by its largest element; the entry then moves by up to ~1e-4 relative.  One such tie is structural: for
- * M = 1, 3, 5 the search grid's last candidate 1.2 * max|x| puts the largest element itself at (2^(M+1) - 1) / 1.2 =
- * 2.5 / 12.5 / 52.5 scale steps, a tie in real arithmetic that only the fp32 rounding of 1.2 * max|x| breaks
- * (tests/soak.py: 2.2e-5 on 28 magnitudes 1.5 * 2^k with E2M5, 1.2e-5 ... 3.2e-5 on Cauchy samples with E4M3, always at
- * that candidate; profiles/r04_soak.txt).  The sorted route below has no such case.
- * Per-tensor rows of >= 2^20 elements searched over >= 256 (width, candidate) pairs of a signed format -- the mantissa
- * search of the reference CLI's default (6 x 111), LineSearchEstimator's 1000 candidates -- take a third route: |x| is
- * radix-sorted once, prefix sums of k and k^2 are formed in double, and a candidate's quantization cells (the intervals of
- * |x| that map to one grid value; their borders are located exactly with the reference's own fp32 decisions) are summed
- * as S2 - 2 q S1 + n q^2 (double-double: the terms cancel to 1e-13 of S2 on already-quantized data).  Every element is
- * classified as K1 classifies it; the squares are summed in (near-)exact arithmetic instead of fp32-rounded: ~1e-7 relative.  fp8q_mse_workspace_bytes() accounts for the keys (4 B / element + the sort's
- * scratch).  FP8Q_MSE_SORTED=0 keeps the lane-per-element kernel.
+ * Table entries agree with the oracle's to ~1e-7 relative (tests and tests/soak.py: <= 1e-5 on EVERY entry; the CHOSEN
+ * (mantissa bits, maxval) equal to the oracle's choice or its oracle-MSE within 1e-6 relative of the oracle's minimum --
+ * SURVEY.md 8c).  Every element takes the grid point the reference gives it; what differs is the summation: fp32 squares
+ * summed in another order (double partials) or, on the interval-histogram route, exact sums.  Three routes, chosen by the
+ * SHAPE of the call only (a tensor is evaluated the same way every time):
+ *   rows < 2048 elements      lane = candidate, x broadcast from LDS: x * 2^frac(bias) scaled by the binade's power of two and
+ *                             rounded with v_rndne; elements within 5 ulps of a rounding tie (the product carries up to 4 ulps
+ *                             of error against the reference's fl32(x / s)) take the reference's own division;
+ *   longer rows               lane = element, candidates walked with wave-uniform constants: the same product rounded on its
+ *                             bits / by a magic-number add; every lane watches how close its elements come to a tie and the
+ *                             elements within 5 ulps are re-evaluated with the reference's division (round 5: before, such an
+ *                             element could take the other neighbour, which moved entries carried by a few elements -- the
+ *                             search grid's last candidate 1.2 max|x| puts the largest element on a tie for M = 1, 3, 5 -- by up
+ *                             to 4e-5);
+ *   per-tensor rows of a signed format of <= 8 bits, long enough to pay for ~60 us of fixed cost (>= ~4 M elements for 111
+ *   (width, candidate) pairs, >= ~1 M for 666: FP_MSE_Estimator with the mantissa search, LineSearchEstimator's 1000
+ *   candidates)               the interval histogram (csrc/fp8q_mse_hist.hip): a quantizer is a step function of |x|, so the
+ *                             exact borders of all cells of all candidates (the smallest float at which the reference's own
+ *                             fp32 decisions flip) cut |x| into intervals; the nonzero keys are partitioned ONCE by their top
+ *                             11 bits, integer moments {n, sum d, sum d^2} of every interval are accumulated with LDS atomics
+ *                             (exact, order-independent: the result is deterministic), and a candidate's cells are summed as
+ *                             S2 - 2 q S1 + n q^2 in double-double (the terms cancel to 1e-13 of S2 on already-quantized
+ *                             data).  Cost independent of the number of candidates: ~4 ps per element.
+ * fp8q_mse_workspace_bytes() accounts for the partitioned keys (4 B / element) and the border tables when the shape can take
+ * the third route.  FP8Q_MSE_HIST=0 keeps the lane-per-element kernel; =2 evaluates every candidate of that route element
+ * by element (the tests' cross-check of the cell logic).
  */
 size_t fp8q_mse_workspace_bytes(int64_t C, int64_t inner, int64_t n_cand, int n_m);
 int fp8q_mse_grid_f32(const float *x, int64_t C, int64_t inner, const float *grid, int64_t n_cand,
