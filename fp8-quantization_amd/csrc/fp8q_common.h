@@ -68,7 +68,25 @@ struct FoldArgs {
     unsigned *status = nullptr;  // workspace header word: the reducer counts its timeouts here (FP8Q_ETIMEDOUT)
     int spin_limit = 1 << 23;    // polls before the reducer gives up (~2 s); FP8Q_K3_SPIN_LIMIT
     int fault = 0;               // FP8Q_TEST_FAULT=drop_publish: split 0 never publishes (exercises the timeout path)
+    // optional: the MSE estimator's search grid of the row, written by the thread that stores the row's range
+    // (fp8q_minmax_linspace_f32: the first calibration batch needs max|x| and linspace(lo * max|x|, hi * max|x|, steps))
+    float *lin_grid = nullptr;   // [lin_steps, lin_C]
+    int lin_steps = 0;
+    int64_t lin_C = 0;
+    double lin_lo = 0.0, lin_hi = 0.0;
 };
+
+// grid[i, row] = torch.linspace(lo * mx, hi * mx, steps)[i] bit for bit (range_estimators.py:296-305: the products are
+// python-float (double) multiplications of mx.item(), narrowed to float32 by linspace).  ATen's CPU kernel, for fewer steps
+// than its parallel grain, evaluates element i as fl32(start + step * i) for i < steps / 2 and fl32(end - step * (steps - 1 - i))
+// after, each with one fused multiply-add, step = fl32(fl32(end - start) / (steps - 1)).
+__device__ __forceinline__ float linspace_at(float mx, double lo_frac, double hi_frac, int steps, int i)
+{
+    const double m = (double)mx;
+    const float start = (float)(lo_frac * m), end = (float)(hi_frac * m);
+    const float step = (end - start) / (float)(steps - 1);
+    return i < steps / 2 ? fmaf(step, (float)i, start) : fmaf(-step, (float)(steps - 1 - i), end);
+}
 
 // spin limit / fault injection of the single-launch min/max, read once (tests shorten the 2 s and drop a publisher)
 inline void fold_debug_env(FoldArgs &fa)
@@ -109,7 +127,10 @@ __device__ __forceinline__ void fold_store(float mn, float mx, int64_t row, floa
     }
     if (cur_min) cur_min[row] = mn;
     if (cur_max) cur_max[row] = mx;
-    if (maxval_out) maxval_out[row] = fabsf(tmax(fabsf(mn), mx));  // fp8_quantizer.py:236
+    const float absmax = fabsf(tmax(fabsf(mn), mx));               // fp8_quantizer.py:236
+    if (maxval_out) maxval_out[row] = absmax;
+    if (fa.lin_grid)
+        for (int i = 0; i < fa.lin_steps; ++i) fa.lin_grid[(int64_t)i * fa.lin_C + row] = linspace_at(absmax, fa.lin_lo, fa.lin_hi, fa.lin_steps, i);
     if (fa.packed) {
         // NaN must win on every rank (torch.min / torch.max): it travels as a flag, the value as -inf, so that the
         // collective itself never sees a NaN (what MAX does with one is the communication library's business)

@@ -548,11 +548,9 @@ k_mse_final(const double *__restrict__ ws, float *__restrict__ mses, int64_t C, 
 // Device-side search grid and winner selection of FP_MSE_Estimator: with these two, a calibration batch needs no host
 // round trip (the reference synchronises at range_estimators.py:305, :353 and :360).
 // ---------------------------------------------------------------------------------------------
-// grid[i, c] = torch.linspace(0.1 * mx_c, 1.2 * mx_c, steps)[i] bit for bit (range_estimators.py:296-305: the products
-// are python-float (double) multiplications of mx.item(), narrowed to float32 by linspace).  ATen's CPU kernel, for
-// fewer steps than its parallel grain, evaluates element i as fl32(start + step * i) for i < steps / 2 and
-// fl32(end - step * (steps - 1 - i)) after, each with one fused multiply-add, step = fl32(fl32(end - start) / (steps - 1)).
-// (fp8q.ops checks this kernel against torch.linspace itself once per process.)
+// grid[i, c] = torch.linspace(0.1 * mx_c, 1.2 * mx_c, steps)[i] bit for bit: linspace_at() (fp8q_common.h; fp8q.ops checks it
+// against torch.linspace itself once per process).  The first calibration batch gets its grid from the abs-max pass itself
+// (fp8q_minmax_linspace_f32); this kernel serves the batch-sharded case, where the maximum is all-reduced first.
 __global__ void __launch_bounds__(kBlock)
 k_mse_linspace(const float *__restrict__ mx, int64_t C, int steps, double lo_frac, double hi_frac, float *__restrict__ grid)
 {
@@ -560,10 +558,7 @@ k_mse_linspace(const float *__restrict__ mx, int64_t C, int steps, double lo_fra
     if (idx >= C * steps) return;
     const int i = (int)(idx / C);
     const int64_t c = idx - (int64_t)i * C;
-    const double m = (double)mx[c];
-    const float start = (float)(lo_frac * m), end = (float)(hi_frac * m);
-    const float step = (end - start) / (float)(steps - 1);
-    grid[idx] = i < steps / 2 ? fmaf(step, (float)i, start) : fmaf(-step, (float)(steps - 1 - i), end);
+    grid[idx] = linspace_at(mx[c], lo_frac, hi_frac, steps, i);
 }
 
 // torch.min / torch.argmin over one dimension: the first index of the smallest value, a NaN counting as smaller than
@@ -593,41 +588,52 @@ __device__ __forceinline__ ArgMin wave_argmin(ArgMin a)
     return a;
 }
 
-// stage 1: one wave per channel.  For every mantissa width m: the minimum over the candidates and its first index;
-// then the channel's best width (range_estimators.py:350-351: mses.min(1)[0].argmin(0)).
-// sel: int32 [C, 1 + n_m] = {best width index, argmin_i for width 0, ..., argmin_i for width n_m - 1}
+// Winner selection in ONE launch (round 4: two dependent ones, 930 launches of 3-34 us per MobileNetV2 calibration batch).
+// Phase 1, one wave per channel: for every mantissa width m the minimum over the candidates and its first index, then the
+// channel's best width (range_estimators.py:350-351: mses.min(1)[0].argmin(0)) ->
+//     sel: int32 [C, 1 + n_m] = {best width index, argmin_i for width 0, ..., argmin_i for width n_m - 1}
+// Phase 2, the LAST workgroup to finish phase 1 (a ticket in the workspace header: zero between calls -- atomicInc wraps it
+// back; per-tensor quantizers, C <= 4, are a single workgroup and need none): plurality vote over the channels' best widths
+// (torch.mode: the most frequent value, the smallest one on a tie -- :352-354), then per channel the winning width's argmin
+// candidate and its maxval (:356-362).
 __global__ void __launch_bounds__(kBlock)
-k_mse_select_rows(const float *__restrict__ mses, int64_t C, int n_m, int n_cand, int *__restrict__ sel)
-{
-    const int lane = threadIdx.x & 63;
-    const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (c >= C) return;
-    ArgMin best_m = {__builtin_inff(), 0x7fffffff};
-    for (int m = 0; m < n_m; ++m) {
-        ArgMin a = {__builtin_inff(), 0x7fffffff};
-        for (int i = lane; i < n_cand; i += 64) {
-            const ArgMin o = {mses[((int64_t)m * n_cand + i) * C + c], i};
-            if (argmin_less(o, a)) a = o;
-        }
-        a = wave_argmin(a);
-        if (lane == 0) sel[c * (1 + n_m) + 1 + m] = a.idx;
-        const ArgMin o = {a.v, m};
-        if (argmin_less(o, best_m)) best_m = o;
-    }
-    if (lane == 0) sel[c * (1 + n_m)] = best_m.idx;
-}
-
-// stage 2 (one block): plurality vote over the channels' best widths (torch.mode: the most frequent value, the
-// smallest one on a tie -- :352-354), then per channel the winning width's argmin candidate and its maxval (:356-362).
-__global__ void __launch_bounds__(kBlock)
-k_mse_select_vote(const int *__restrict__ sel, const float *__restrict__ grid, int64_t C, int n_m, MseArgs a /* fmt[m].M = width m */,
-                  float *__restrict__ mbits_out, int *__restrict__ vote_out, float *__restrict__ maxval_out, float *__restrict__ xmin_out, float sign)
+k_mse_select(const float *__restrict__ mses, const float *__restrict__ grid, int64_t C, int n_m, int n_cand, int *__restrict__ sel,
+             unsigned *__restrict__ ticket, MseArgs a /* fmt[m].M = width m */, float *__restrict__ mbits_out, int *__restrict__ vote_out,
+             float *__restrict__ maxval_out, float *__restrict__ xmin_out, float sign)
 {
     __shared__ int hist[kMseMaxM];
-    __shared__ int s_vote;
+    __shared__ int s_vote, s_last;
+    const int lane = threadIdx.x & 63;
+    const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c < C) {
+        ArgMin best_m = {__builtin_inff(), 0x7fffffff};
+        for (int m = 0; m < n_m; ++m) {
+            ArgMin am = {__builtin_inff(), 0x7fffffff};
+            for (int i = lane; i < n_cand; i += 64) {
+                const ArgMin o = {mses[((int64_t)m * n_cand + i) * C + c], i};
+                if (argmin_less(o, am)) am = o;
+            }
+            am = wave_argmin(am);
+            if (lane == 0) sel[c * (1 + n_m) + 1 + m] = am.idx;
+            const ArgMin o = {am.v, m};
+            if (argmin_less(o, best_m)) best_m = o;
+        }
+        if (lane == 0) sel[c * (1 + n_m)] = best_m.idx;
+    }
+    if (gridDim.x > 1) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      // this workgroup's sel rows leave the XCD's L2 ...
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // ... before the ticket can be seen
+            s_last = atomicInc(ticket, gridDim.x - 1u) == gridDim.x - 1u;
+        }
+        __syncthreads();
+        if (!s_last) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
     if (threadIdx.x < kMseMaxM) hist[threadIdx.x] = 0;
     __syncthreads();
-    for (int64_t c = threadIdx.x; c < C; c += kBlock) atomicAdd(&hist[sel[c * (1 + n_m)]], 1);
+    for (int64_t cc = threadIdx.x; cc < C; cc += kBlock) atomicAdd(&hist[sel[cc * (1 + n_m)]], 1);
     __syncthreads();
     if (threadIdx.x == 0) {
         int v = 0;
@@ -639,10 +645,10 @@ k_mse_select_vote(const int *__restrict__ sel, const float *__restrict__ grid, i
     }
     __syncthreads();
     const int v = s_vote;
-    for (int64_t c = threadIdx.x; c < C; c += kBlock) {
-        const float mv = grid[(int64_t)sel[c * (1 + n_m) + 1 + v] * C + c];
-        maxval_out[c] = mv;
-        if (xmin_out) xmin_out[c] = sign * mv;       // sign_bits * -1.0 * maxval (:369)
+    for (int64_t cc = threadIdx.x; cc < C; cc += kBlock) {
+        const float mv = grid[(int64_t)sel[cc * (1 + n_m) + 1 + v] * C + cc];
+        maxval_out[cc] = mv;
+        if (xmin_out) xmin_out[cc] = sign * mv;       // sign_bits * -1.0 * maxval (:369)
     }
 }
 
@@ -667,14 +673,15 @@ static int mse_hist_mode()
 }
 
 // The route's cost does not depend on the data: ~55 us of small launches + ~0.1 us per (width, candidate) pair for the borders
-// + ~4.3 ps per element (partition at the copy rate + the moments); k_mse_row costs ~0.19 ps per (element, pair).
-// (MI355X, tools/mb_mse_sizes.py: 111 pairs break even at ~4 M elements, 666 pairs at ~1 M; profiles/r05_mse_sizes.txt.)
+// + ~4.3 ps per element (partition at the copy rate + the moments); k_mse_row costs ~0.27 ps per (element, pair) (0.19 before
+// it watched for near-ties).  (MI355X, tools/mb_mse_sizes.py: 111 pairs break even at ~2.5 M elements, 666 pairs at ~0.7 M;
+// profiles/r05_mse_sizes.txt.)
 // Which route a row takes depends on its shape only, so a tensor is evaluated the same way on every call.
 static bool mse_use_hist_shape(int64_t C, int64_t inner, int64_t n_cand, int n_m)
 {
     if (mse_hist_mode() == 0 || C != 1 || inner < (1 << 18) || inner >= (1ll << 31)) return false;
     const double pairs = (double)(n_m * n_cand);
-    const double row = (double)inner * pairs * 0.19e-12;
+    const double row = (double)inner * pairs * 0.27e-12;
     const double hist = 55e-6 + pairs * 0.095e-6 + (double)inner * 4.3e-12;
     return row > hist;
 }
@@ -690,7 +697,7 @@ int fp8q_mse_linspace_f32(const float *mx, int64_t C, int n_cand, double lo_frac
     return launch_rc();
 }
 
-size_t fp8q_mse_select_workspace_bytes(int64_t C, int n_m) { return C > 0 && n_m > 0 ? (size_t)C * (1 + n_m) * sizeof(int) + 16 : 16; }
+size_t fp8q_mse_select_workspace_bytes(int64_t C, int n_m) { return C > 0 && n_m > 0 ? (size_t)C * (1 + n_m) * sizeof(int) + 32 : 32; }
 
 int fp8q_mse_select_f32(const float *mses, const float *grid, int64_t C, int64_t n_cand, const float *mbits_host, int n_m,
                         int sign_bits, float *mbits_out, int *vote_out, float *maxval_out, float *xmin_out, void *ws,
@@ -703,10 +710,9 @@ int fp8q_mse_select_f32(const float *mses, const float *grid, int64_t C, int64_t
     MseArgs a;
     memset(&a, 0, sizeof(a));
     for (int m = 0; m < n_m; ++m) a.fmt[m].M = mbits_host[m];   // the candidate widths as given (the vote returns one of them)
-    hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_mse_select_rows, dim3((unsigned)cdiv(C, 4)), dim3(kBlock), 0, st, mses, C, n_m, (int)n_cand, (int *)ws);
-    if (int rc = launch_rc()) return rc;
-    hipLaunchKernelGGL(k_mse_select_vote, dim3(1), dim3(kBlock), 0, st, (const int *)ws, grid, C, n_m, a, mbits_out, vote_out, maxval_out, xmin_out, -(float)sign_bits);
+    // ws: {reserved word, ticket, 2 reserved words} | sel
+    hipLaunchKernelGGL(k_mse_select, dim3((unsigned)cdiv(C, 4)), dim3(kBlock), 0, (hipStream_t)stream, mses, grid, C, n_m, (int)n_cand,
+                       (int *)((char *)ws + 16), (unsigned *)ws + 1, a, mbits_out, vote_out, maxval_out, xmin_out, -(float)sign_bits);
     return launch_rc();
 }
 
@@ -752,7 +758,7 @@ static RowGeo mse_row_geo(int64_t C, int64_t inner, int64_t n_cand, int n_m)
     const int64_t resident = 256 * 12;   // CUs x waves (144 VGPRs: 3 per SIMD)
     const int64_t g0 = cdiv(total, kMseRowGroup);
     double best = -1.0;
-    for (int64_t ng = g0; ng <= g0 * 4 && ng <= total; ++ng) {
+    for (int64_t ng = g0; ng <= g0 * 16 && ng <= total; ++ng) {
         const int64_t gs = cdiv(total, ng), waves = g.nblk * ng * (C > 0 ? C : 1);
         const double rounds = (double)cdiv(waves, resident);
         const double fill = (double)waves / (rounds * (double)resident);

@@ -1855,9 +1855,15 @@ static bool minmax_debug_ws()
     return on;
 }
 
+struct LinArgs {
+    float *grid = nullptr;
+    int steps = 0;
+    double lo = 0.0, hi = 0.0;
+};
+
 static int minmax_impl(const float *x, int64_t C, int64_t inner, float *cur_min, float *cur_max, float *maxval_out,
                        float *packed, int fold_mode, double momentum, int first, void *ws, size_t ws_bytes,
-                       fp8q_stream_t stream)
+                       fp8q_stream_t stream, LinArgs lin = LinArgs())
 {
     if (!x || !cur_min || !cur_max || C <= 0 || inner <= 0 || fold_mode < 0 || fold_mode > 2)
         return FP8Q_EINVAL;
@@ -1869,6 +1875,11 @@ static int minmax_impl(const float *x, int64_t C, int64_t inner, float *cur_min,
     fa.om = (float)(1.0 - momentum);
     fa.mo = (float)momentum;
     fa.packed = packed;
+    fa.lin_grid = lin.grid;
+    fa.lin_steps = lin.steps;
+    fa.lin_C = C;
+    fa.lin_lo = lin.lo;
+    fa.lin_hi = lin.hi;
     if (C > 1) {   // per-channel rows of 128..8192 elements: one launch, the row in registers
         QFmt f = {};
         const int rc = launch_rows_reg(false, x, nullptr, C, inner, cur_min, cur_max, maxval_out, f, fa, st);
@@ -1918,6 +1929,19 @@ int fp8q_minmax_packed_f32(const float *x, int64_t C, int64_t inner, float *cur_
 {
     if (!packed) return FP8Q_EINVAL;
     return minmax_impl(x, C, inner, cur_min, cur_max, maxval_out, packed, fold_mode, momentum, first, ws, ws_bytes, stream);
+}
+
+int fp8q_minmax_linspace_f32(const float *x, int64_t C, int64_t inner, float *cur_min, float *cur_max, float *maxval_out,
+                             float *grid, int n_cand, double lo_frac, double hi_frac, void *ws, size_t ws_bytes,
+                             fp8q_stream_t stream)
+{
+    if (!grid || !maxval_out || n_cand < 2 || n_cand > (1 << 20)) return FP8Q_EINVAL;
+    LinArgs lin;
+    lin.grid = grid;
+    lin.steps = n_cand;
+    lin.lo = lo_frac;
+    lin.hi = hi_frac;
+    return minmax_impl(x, C, inner, cur_min, cur_max, maxval_out, nullptr, FP8Q_FOLD_CURRENT, 0.0, 1, ws, ws_bytes, stream, lin);
 }
 
 int fp8q_minmax_workspace_check(void *ws, size_t ws_bytes, int clear, fp8q_stream_t stream)

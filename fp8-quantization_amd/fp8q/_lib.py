@@ -37,6 +37,8 @@ SIGNATURES = {
     "fp8q_mse_grid_f32": (_i, [_vp, _i64, _i64, _vp, _i64, ctypes.POINTER(_f), _i, _i, _i, _vp, _vp,
                                ctypes.c_size_t, _vp]),
     "fp8q_mse_linspace_f32": (_i, [_vp, _i64, _i, ctypes.c_double, ctypes.c_double, _vp, _vp]),
+    "fp8q_minmax_linspace_f32": (_i, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _i, ctypes.c_double, ctypes.c_double, _vp,
+                                      ctypes.c_size_t, _vp]),
     "fp8q_mse_select_workspace_bytes": (ctypes.c_size_t, [_i64, _i]),
     "fp8q_mse_select_f32": (_i, [_vp, _vp, _i64, _i64, ctypes.POINTER(_f), _i, _i, _vp, _vp, _vp, _vp, _vp,
                                  ctypes.c_size_t, _vp]),

@@ -76,19 +76,31 @@ def _rows(x, per_channel):
     return 1, x.numel()
 
 
-def _workspace(dev, nbytes, zeroed=False):
+_WS_RETIRED_MAX = 4
+
+
+def _workspace(dev, nbytes, zeroed=False, kind=None):
     """Per-(device, stream) scratch buffer.  zeroed=True: the min/max entry points' workspace, whose leading ticket
     counters must be zero on first use and are left zero by every call (include/fp8q.h) -- allocated zero-filled and
-    never shared with the kernels that scribble over their scratch (MSE partial sums)."""
+    never shared with the kernels that scribble over their scratch (MSE partial sums).  kind="select": the winner
+    selection's buffer -- allocated zero-filled too (its header holds a ticket that every call leaves zero), but the rest
+    of it is ordinary scratch, so it is neither shared with the min/max workspace nor inspected by check_workspaces()."""
     key = (dev.index, _raw_stream(dev.index) if _raw_stream is not None else torch.cuda.current_stream(dev).cuda_stream,
-           zeroed)
+           zeroed, kind)
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
         if ws is not None and zeroed:
             # a min/max workspace outgrown: its header may hold a time-out count that nobody has looked at yet --
-            # keep it until the next check_workspaces() instead of dropping the report with the buffer
+            # keep it until the next check_workspaces() instead of dropping the report with the buffer.  The list is
+            # bounded: callers that never run check_workspaces() (the C-ABI-style flow) get the oldest entries
+            # inspected here (this synchronises, once per _WS_RETIRED_MAX growths).
             _ws_retired.append((key, ws))
-        alloc = torch.zeros if zeroed else torch.empty
+            while len(_ws_retired) > _WS_RETIRED_MAX:
+                old_key, old = _ws_retired.pop(0)
+                with torch.cuda.device(old.device):
+                    rc = lib().fp8q_minmax_workspace_check(old.data_ptr(), old.numel(), 1, old_key[1])
+                check(rc, "fp8q_minmax_workspace_check (retired workspace)")
+        alloc = torch.zeros if (zeroed or kind == "select") else torch.empty
         ws = alloc(max(int(nbytes), 1 << 16), dtype=torch.uint8, device=dev)
         _ws_cache[key] = ws
     return ws
@@ -282,7 +294,7 @@ def check_workspaces(clear=True):
     todo = [(k, w) for k, w in list(_ws_cache.items()) if k[2]] + list(_ws_retired)
     del _ws_retired[:]
     failures = []
-    for (dev_index, stream, _zeroed), ws in todo:
+    for (dev_index, stream, _zeroed, _kind), ws in todo:
         with torch.cuda.device(dev_index):
             rc = lib().fp8q_minmax_workspace_check(ws.data_ptr(), ws.numel(), int(bool(clear)), stream)
         if rc:
@@ -401,24 +413,39 @@ def mse_grid(x, per_channel, grid, mbits_list, n_bits, sign_bits, mses):
     return mses
 
 
-_linspace_checked = {}
+_linspace_checked = {}     # (steps, fractions) -> True: the device kernel reproduces torch.linspace; False: host fall-back
 
 
 def _linspace_self_check(steps, lo_frac, hi_frac, device):
-    """Once per process and (steps, fractions): the device search-grid kernel against torch.linspace itself on a few
-    ranges (another ATen build could evaluate linspace differently).  Synchronises; raises on a mismatch."""
+    """Once per process and (steps, fractions): the device search-grid formula against torch.linspace itself on a few
+    ranges -- the kernel hard-codes ATen's CPU evaluation (the steps / 2 split, one fused multiply-add per element),
+    which another ATen build could do differently.  Synchronises (once).  Returns True when the device path may be used;
+    on a mismatch the decision is cached and the search grids are made by torch.linspace on the host from then on
+    (a host round trip per FIRST calibration batch of a quantizer -- slower, never wrong)."""
     key = (steps, lo_frac, hi_frac)
-    if _linspace_checked.get(key):
-        return
+    ok = _linspace_checked.get(key)
+    if ok is not None:
+        return ok
     probe = torch.tensor([1.0, 0.7361, 3.3e-5, 123.456, 6.0e4, 0.0131, 2.5], dtype=torch.float32)
     got = torch.empty((steps, probe.numel()), dtype=torch.float32, device=device)
     dev_probe = probe.to(device)
     check(lib().fp8q_mse_linspace_f32(dev_probe.data_ptr(), probe.numel(), steps, lo_frac, hi_frac, got.data_ptr(),
                                       _stream(got)), "fp8q_mse_linspace_f32")
     want = torch.stack([torch.linspace(lo_frac * float(v), hi_frac * float(v), steps) for v in probe.tolist()], 1)
-    if not torch.equal(got.cpu().view(torch.int32), want.view(torch.int32)):
-        raise Fp8qError("fp8q_mse_linspace_f32 does not reproduce torch.linspace on this PyTorch build")
-    _linspace_checked[key] = True
+    ok = bool(torch.equal(got.cpu().view(torch.int32), want.view(torch.int32)))
+    if not ok:
+        import warnings
+        warnings.warn("fp8q_mse_linspace_f32 does not reproduce torch.linspace on this PyTorch build: the MSE search "
+                      "grids are computed by torch.linspace on the host (one synchronisation per quantizer)")
+    _linspace_checked[key] = ok
+    return ok
+
+
+def _linspace_host(mx, steps, lo_frac, hi_frac):
+    """the reference's own construction (range_estimators.py:296-305), per channel, on the host"""
+    vals = mx.detach().cpu().tolist()
+    cols = [torch.linspace(lo_frac * float(v), hi_frac * float(v), steps) for v in vals]
+    return torch.stack(cols, 1).contiguous().to(mx.device)
 
 
 def mse_linspace(mx, steps=111, lo_frac=0.1, hi_frac=1.2):
@@ -430,12 +457,38 @@ def mse_linspace(mx, steps=111, lo_frac=0.1, hi_frac=1.2):
     if C == 0:
         return torch.empty((steps, 0), dtype=torch.float32, device=mx.device)
     with _on_device(mx):
-        _linspace_self_check(int(steps), float(lo_frac), float(hi_frac), mx.device)
+        if not _linspace_self_check(int(steps), float(lo_frac), float(hi_frac), mx.device):
+            return _linspace_host(mx, int(steps), float(lo_frac), float(hi_frac))
         grid = torch.empty((steps, C), dtype=torch.float32, device=mx.device)
         rc = lib().fp8q_mse_linspace_f32(mx.data_ptr(), C, int(steps), float(lo_frac), float(hi_frac), grid.data_ptr(),
                                          _stream(mx))
     check(rc, "fp8q_mse_linspace_f32")
     return grid
+
+
+def minmax_linspace(x, per_channel, steps=111, lo_frac=0.1, hi_frac=1.2):
+    """First calibration batch of FP_MSE_Estimator in ONE launch (fp8q_minmax_linspace_f32): row min / max, max|x| and
+    the search grid of that maximum.  Returns (min [C], max [C], absmax [C], grid [steps, C])."""
+    _require(x, "x")
+    x = x.contiguous()
+    C, inner = _rows(x, per_channel)
+    if C == 0 or inner == 0:
+        raise Fp8qError("min/max of an empty tensor")
+    with _on_device(x):
+        if not _linspace_self_check(int(steps), float(lo_frac), float(hi_frac), x.device):
+            mn, mx, mv = minmax(x, per_channel, want_maxval=True)
+            return mn, mx, mv, _linspace_host(mv, int(steps), float(lo_frac), float(hi_frac))
+        stats = torch.empty((3 + int(steps), C), dtype=torch.float32, device=x.device)    # one allocation
+        L = lib()
+        nbytes = _mm_ws_bytes.get((C, inner))
+        if nbytes is None:
+            nbytes = _mm_ws_bytes[(C, inner)] = L.fp8q_minmax_workspace_bytes(C, inner)
+        ws = _workspace(x.device, nbytes, zeroed=True)
+        rc = L.fp8q_minmax_linspace_f32(x.data_ptr(), C, inner, stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(),
+                                        stats[3].data_ptr(), int(steps), float(lo_frac), float(hi_frac), ws.data_ptr(),
+                                        ws.numel(), _stream(x))
+    check(rc, "fp8q_minmax_linspace_f32")
+    return stats[0], stats[1], stats[2], stats[3:]
 
 
 def mse_select(mses, grid, mbits_list, sign_bits=1):
@@ -456,7 +509,7 @@ def mse_select(mses, grid, mbits_list, sign_bits=1):
     mb = torch.empty(1, dtype=torch.float32, device=dev)
     vote = torch.empty(1, dtype=torch.int32, device=dev)
     L = lib()
-    ws = _workspace(dev, L.fp8q_mse_select_workspace_bytes(C, n_m))
+    ws = _workspace(dev, L.fp8q_mse_select_workspace_bytes(C, n_m), kind="select")     # (zero header: the last-workgroup ticket)
     mbh = (ctypes.c_float * n_m)(*[float(v) for v in mbits_list])
     with _on_device(mses):
         rc = L.fp8q_mse_select_f32(mses.data_ptr(), grid.data_ptr(), C, n_cand, mbh, n_m, int(sign_bits), mb.data_ptr(),

@@ -218,12 +218,17 @@ class FP_MSE_Estimator(RangeEstimatorBase):
             if x.dtype == torch.float64:
                 mn, hi = _ops.minmax_f64(x, self.per_channel)
                 mx = torch.max(mn.abs(), hi.abs()).float()      # == float32 of the python float the reference multiplies
+            elif not self._dist_batch():
+                # max|x| and the grid [111, C] (== torch.linspace per channel) in the abs-max launch itself
+                self.search_grid = _ops.minmax_linspace(x, self.per_channel, self.N_GRID)[3]
+                mx = None
             else:
                 _, _, mx = _ops.minmax(x, self.per_channel, want_maxval=True)
             if self._dist_batch():                          # batch-sharded: the grid comes from the global max
                 import torch.distributed as dist
                 dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=self._group())
-            self.search_grid = _ops.mse_linspace(mx, self.N_GRID)          # [111, C], == torch.linspace per channel
+            if mx is not None:
+                self.search_grid = _ops.mse_linspace(mx, self.N_GRID)          # [111, C], == torch.linspace per channel
             self.mses = torch.zeros(n_m, self.N_GRID, self.search_grid.shape[1], device=x.device)
         return self.search_grid, self.mses
 

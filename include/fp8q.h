@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define FP8Q_VERSION 400 /* 0.4.0: float64 lane (fp8q_quantize_f64, fp8q_minmax_f64, fp8q_mse_grid_f64); sync-free MSE calibration */
+#define FP8Q_VERSION 500 /* 0.5.0: K4 interval-histogram route (hand-written partition, no library sort), one-launch winner selection (zeroed workspace header) */
 
 #define FP8Q_OK 0
 #define FP8Q_EINVAL (-1)       /* null pointer, negative size, n_maxval not in {1, C}, ... */
@@ -189,13 +189,22 @@ int fp8q_mse_grid_f32(const float *x, int64_t C, int64_t inner, const float *gri
  *                          mbits_out[0] = mbits_host[vote] (DEVICE scalar), vote_out[0] = its index (may be NULL), per
  *                          channel maxval_out[c] = grid[argmin_i mses[vote, i, c], c] and xmin_out[c] = -sign_bits *
  *                          maxval (may be NULL).  torch.min / argmin semantics: first index of the minimum, NaN first.
- *                          ws: at least fp8q_mse_select_workspace_bytes(C, n_m) bytes, 4-byte aligned.
+ *                          ONE launch (round 5).  ws: at least fp8q_mse_select_workspace_bytes(C, n_m) bytes, 4-byte
+ *                          aligned; its first 16 bytes follow the min/max workspace contract (zero before the first call
+ *                          that uses the buffer, zero again after every call: word 1 is the ticket by which the last
+ *                          workgroup of a per-channel call finds out that it is the last).
  *   fp8q_quantize_dm_f32   K1 (fp8q_quantize_f32) with the mantissa width read from a DEVICE scalar, so that the batch
  *                          that follows the vote in the same calibration forward needs no host round trip.  One row
  *                          per workgroup column whatever the row length: a calibration path, not the tuned K1 routes.
  */
 int fp8q_mse_linspace_f32(const float *mx, int64_t C, int n_cand, double lo_frac, double hi_frac, float *grid,
                           fp8q_stream_t stream);
+/* The first calibration batch of FP_MSE_Estimator in one launch: the row min / max (fp8q_minmax_f32, current fold), K5's
+ * maxval_out[c] = |max(|min|, max)| = max|x| of the row, and the search grid of that maximum (what fp8q_mse_linspace_f32
+ * would make of maxval_out), written by the thread that stores the row's range.  grid [n_cand, C]; workspace as fp8q_minmax_f32. */
+int fp8q_minmax_linspace_f32(const float *x, int64_t C, int64_t inner, float *cur_min, float *cur_max, float *maxval_out,
+                             float *grid, int n_cand, double lo_frac, double hi_frac, void *ws, size_t ws_bytes,
+                             fp8q_stream_t stream);
 size_t fp8q_mse_select_workspace_bytes(int64_t C, int n_m);
 int fp8q_mse_select_f32(const float *mses, const float *grid, int64_t C, int64_t n_cand, const float *mbits_host, int n_m,
                         int sign_bits, float *mbits_out, int *vote_out, float *maxval_out, float *xmin_out, void *ws,

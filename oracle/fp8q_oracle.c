@@ -116,7 +116,10 @@ int orc_quantize_flat_f32(const float *x, float *y, int64_t n, float maxval, flo
  * range_estimators.py:62-74, 84-98
  * Signed zeros: when a row's minimum (maximum) is zero and the row holds both -0.0 and +0.0, ATen returns whichever its
  * vectorised reduction met first -- the reference does not pin the sign.  The contract here is the order-independent
- * IEEE 754-2019 minimum / maximum: -0.0 < +0.0, so min -> -0.0 and max -> +0.0 (what v_min_f32 / v_max_f32 compute). */
+ * IEEE 754-2019 minimum / maximum: -0.0 < +0.0, so min -> -0.0 and max -> +0.0 (what v_min_f32 / v_max_f32 compute).
+ * Pinned by tests/golden/g3b_signed_zero.npz (rows of mixed zeros in both orders, run through the reference: its signs
+ * follow the element order, its values, maxval and quantized rows are what this contract gives):
+ * tests/test_oracle_golden.py::test_signed_zero_contract_of_minmax_is_pinned_by_a_fixture. */
 #define ORC_ZERO_FLAGS(v, nz, pz) do { if ((v) == 0) { if (signbit(v)) nz = 1; else pz = 1; } } while (0)
 #define ORC_ZERO_FIX(lo, hi, nz, pz) do { if ((lo) == 0) lo = nz ? -0.0f : 0.0f; if ((hi) == 0) hi = pz ? 0.0f : -0.0f; } while (0)
 

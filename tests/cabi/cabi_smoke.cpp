@@ -266,6 +266,7 @@ int main()
         CK(hipMalloc((void **)&dmvs, sizeof(float) * Cs));
         CK(hipMalloc((void **)&dxm, sizeof(float) * Cs));
         CK(hipMalloc(&sws, fp8q_mse_select_workspace_bytes(Cs, n_m)));
+        CK(hipMemset(sws, 0, fp8q_mse_select_workspace_bytes(Cs, n_m)));   // header contract: zero before the first call
         CK(hipMemcpy(dmxs, mxs, sizeof(mxs), hipMemcpyHostToDevice));
         CK(fp8q_mse_linspace_f32(dmxs, Cs, n_cand, 0.1, 1.2, dgrid, st));
         CK(hipStreamSynchronize(st));

@@ -15,6 +15,7 @@ Fixture files:
   g1_quantize.npz    quantize_to_fp8_ste_MM   (fp8_quantizer.py:91-133)
   g2_grids.npz       generate_all_values_fp   (fp8_quantizer.py:13-41)
   g3_estimators.npz  Current/All/RunningMinMax (range_estimators.py:56-125) + set_quant_range
+  g3b_signed_zero.npz the same estimators on rows that mix -0.0 and +0.0 (pins the signed-zero contract of min / max)
   g4_mse.npz         FP_MSE_Estimator         (range_estimators.py:285-369)
   g5_quant_error.npz compute_quant_error.py (config 1) at 200 k samples + closed-form integrals
   g6_manager.npz     QuantizationManager.forward state machine (quantization_manager.py:114-122)
@@ -646,6 +647,39 @@ def make_g10():
     print("g10:", cid, "cases")
 
 
+def make_g3b():
+    """rows that hold both -0.0 and +0.0 (and all-zero rows of either sign): the reference's min / max, the maxval its
+    quantizer derives from them (fp8_quantizer.py:236) and the quantized rows.  ATen's min / max of mixed zeros depends on
+    the order of the elements; the build's contract is IEEE 754-2019 minimum / maximum (-0 < +0): the fixture pins the
+    VALUES everywhere, the maxval bit for bit, and records where the reference's signs agree with that contract."""
+    nz, pz = np.float32(-0.0), np.float32(0.0)
+    rows = np.array([[nz, pz, nz, pz, nz, pz, nz, pz],
+                     [pz, nz, pz, nz, pz, nz, pz, nz],
+                     [nz] * 8,
+                     [pz] * 8,
+                     [pz, nz, 1e-3, nz, pz, 1e-3, nz, pz],
+                     [nz, pz, -1e-3, pz, nz, -1e-3, pz, nz],
+                     [nz, nz, nz, nz, pz, pz, pz, pz],
+                     [pz, pz, pz, pz, nz, nz, nz, nz]], dtype=np.float32)
+    x = torch.from_numpy(rows.copy())
+    out = {"x": rows}
+    for pc in (True, False):
+        est = RangeEstimators.current_minmax.cls(per_channel=pc)
+        mn, mx = est(x)
+        out[f"pc{int(pc)}_min"], out[f"pc{int(pc)}_max"] = mn.numpy().reshape(-1), mx.numpy().reshape(-1)
+        est = RangeEstimators.allminmax.cls(per_channel=pc)
+        est(x)
+        mn, mx = est(torch.flip(x, dims=[1]))         # second batch: the same values in the opposite order
+        out[f"all_pc{int(pc)}_min"], out[f"all_pc{int(pc)}_max"] = mn.numpy().reshape(-1), mx.numpy().reshape(-1)
+    q = FPQuantizer(n_bits=8, per_channel=True, mantissa_bits=3, maxval=None, set_maxval=True)
+    q.set_quant_range(out_t(out["pc1_min"]), out_t(out["pc1_max"]))
+    out["maxval"] = q.maxval.numpy()
+    with np.errstate(all="ignore"):
+        out["q"] = q(x).numpy()                       # all-zero rows: maxval 0 -> NaN rows (a reproduced quirk)
+    np.savez_compressed(os.path.join(OUT, "g3b_signed_zero.npz"), **out)
+    print("g3b ok")
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     if only:          # e.g.  python -B make_golden.py g1b g10
@@ -659,6 +693,7 @@ if __name__ == "__main__":
     make_g1c()
     make_g2()
     make_g3()
+    make_g3b()
     make_g4()
     make_g5()
     make_g6()

@@ -80,6 +80,11 @@ def mse_linspace(mx, steps=111, lo_frac=0.1, hi_frac=1.2):
     return torch.stack([torch.linspace(lo_frac * v, hi_frac * v, steps) for v in mx.reshape(-1).tolist()], 1)
 
 
+def minmax_linspace(x, per_channel, steps=111, lo_frac=0.1, hi_frac=1.2):
+    mn, mx, mv = minmax(x, per_channel, want_maxval=True)
+    return mn, mx, mv, mse_linspace(mv, steps, lo_frac, hi_frac)
+
+
 def mse_select(mses, grid, mbits_list, sign_bits=1):
     """range_estimators.py:350-369 with the reference's own torch calls"""
     best_m_per_ch = mses.min(1)[0].argmin(0)
@@ -111,7 +116,7 @@ def patched():
     """with oracle_ops.patched(): ... -> fp8q.ops.* run on the CPU oracle inside the block."""
     import fp8q
     names = ("quantize", "minmax", "minmax_quantize", "mse_grid", "fused_max_inner", "new_packed", "ranges_unpack",
-             "mse_linspace", "mse_select", "minmax_f64", "mse_grid_f64")
+             "mse_linspace", "minmax_linspace", "mse_select", "minmax_f64", "mse_grid_f64")
     saved = {n: getattr(fp8q.ops, n) for n in names}
     try:
         for n in names:

@@ -188,6 +188,30 @@ def test_out_and_device_arguments_are_validated(ops):
     assert torch.equal(ops.quantize(x, mv1, 3, out=o).view_as(x), ops.quantize(x, mv1, 3))
 
 
+def test_signed_zero_rows_follow_the_pinned_contract(ops, golden_dir):
+    """g3b (rows mixing -0.0 and +0.0): the kernels' min / max equal the oracle's bit for bit on every route (per channel,
+    per tensor, running fold, fused min/max + quantize), maxval and the quantized rows equal the reference's"""
+    g = np.load(os.path.join(golden_dir, "g3b_signed_zero.npz"))
+    x = g["x"]
+    xd = torch.from_numpy(x).cuda()
+    for pc in (True, False):
+        mn, mx, mv = ops.minmax(xd, pc, want_maxval=True)
+        rmn, rmx = oracle.c_minmax(x, pc)
+        assert np.array_equal(mn.cpu().numpy().view(np.int32), rmn.view(np.int32))
+        assert np.array_equal(mx.cpu().numpy().view(np.int32), rmx.view(np.int32))
+        assert np.array_equal(mn.cpu().numpy(), g[f"pc{int(pc)}_min"]) and np.array_equal(mx.cpu().numpy(), g[f"pc{int(pc)}_max"])
+    mn, mx = ops.minmax(xd, True)
+    mn, mx = ops.minmax(torch.from_numpy(x[:, ::-1].copy()).cuda(), True, mn, mx, mode=ops.FOLD_ALL)
+    assert np.array_equal(mn.cpu().numpy(), g["all_pc1_min"]) and np.array_equal(mx.cpu().numpy(), g["all_pc1_max"])
+    y, rmn, rmx, mv = ops.minmax_quantize(xd, 3, 8, 1)
+    assert np.array_equal(mv.cpu().numpy().view(np.int32), g["maxval"].view(np.int32))
+    q = y.cpu().numpy()
+    assert np.array_equal(np.isnan(q), np.isnan(g["q"]))
+    ok = ~np.isnan(q)
+    assert np.array_equal(np.signbit(q[ok]), np.signbit(g["q"][ok]))                     # signed zeros kept
+    assert np.abs(q[ok].view(np.int32).astype(np.int64) - g["q"][ok].view(np.int32)).max() <= 2   # (log2 / 2^x: <= 2 ulp, DESIGN 2)
+
+
 def test_retired_workspace_is_still_checked(ops):
     """check_workspaces() also inspects min/max workspaces that a larger request has replaced since the last check."""
     import fp8q

@@ -24,6 +24,38 @@ def test_linspace_kernel_equals_torch_linspace():
     assert torch.equal(got.view(torch.int32), want.view(torch.int32))
 
 
+@pytest.mark.parametrize("shape,per_channel", [((64, 3, 7, 7), True), ((1280, 320), True), ((32, 1, 3, 3), True), ((512, 4608), True),
+                                               ((5, 70000), True), ((8, 16, 28, 28), False), ((64, 32, 56, 56), False), ((3,), False)])
+def test_minmax_linspace_in_one_launch(shape, per_channel):
+    """the first calibration batch's abs-max launch also writes the search grid (fp8q_minmax_linspace_f32): every min/max
+    route (rows in registers, staged, direct, split rows with the reducer block) against minmax + torch.linspace"""
+    import fp8q
+    g = torch.Generator().manual_seed(len(shape) + shape[0])
+    x = torch.randn(*shape, generator=g) * 3.0
+    mn, mx, mv, grid = fp8q.ops.minmax_linspace(x.cuda(), per_channel, 111)
+    rmn, rmx, rmv = fp8q.ops.minmax(x.cuda(), per_channel, want_maxval=True)
+    for a, b in ((mn, rmn), (mx, rmx), (mv, rmv)):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    want = torch.stack([torch.linspace(0.1 * float(v), 1.2 * float(v), 111) for v in rmv.cpu().tolist()], 1)
+    assert grid.shape == want.shape and torch.equal(grid.cpu().view(torch.int32), want.view(torch.int32))
+
+
+def test_linspace_falls_back_to_the_host_when_the_kernel_formula_does_not_match(monkeypatch):
+    """another ATen build could evaluate torch.linspace differently: then the grids come from torch.linspace on the host
+    (a cached decision, a warning) instead of an exception that would stop every MSE calibration"""
+    import fp8q
+    ops = fp8q.ops
+    monkeypatch.setattr(ops, "_linspace_checked", {(111, 0.1, 1.2): False})
+    mx = torch.tensor([0.5, 2.0, 3.3e-5], device="cuda")
+    got = ops.mse_linspace(mx, 111)
+    want = torch.stack([torch.linspace(0.1 * float(v), 1.2 * float(v), 111) for v in mx.cpu().tolist()], 1)
+    assert got.is_cuda and torch.equal(got.cpu().view(torch.int32), want.view(torch.int32))
+    x = torch.randn(6, 40, device="cuda")
+    mn, mxx, mv, grid = ops.minmax_linspace(x, True, 111)
+    want = torch.stack([torch.linspace(0.1 * float(v), 1.2 * float(v), 111) for v in x.abs().amax(1).cpu().tolist()], 1)
+    assert torch.equal(grid.cpu().view(torch.int32), want.view(torch.int32))
+
+
 @pytest.mark.parametrize("C,n_m,n_cand", [(1, 6, 111), (1, 1, 111), (32, 6, 111), (1280, 6, 111), (5, 3, 7), (2049, 2, 130)])
 def test_select_kernel_equals_torch_ops(C, n_m, n_cand):
     import fp8q

@@ -150,7 +150,7 @@ def test_debug_ws_refuses_a_dirty_workspace():
         from fp8q import ops
         x = torch.randn(1 << 22, device="cuda")
         a = ops.minmax(x, False)
-        ws = [w for (d, s, z), w in ops._ws_cache.items() if z][0]
+        ws = [w for (d, s, z, _k), w in ops._ws_cache.items() if z][0]
         ws.view(torch.int64)[7] = 99            # violate the contract
         try:
             ops.minmax(x, False)
