@@ -33,7 +33,8 @@ compute stub and scaled-down tensors, and prints every collective with its byte 
 
 The JSON line also carries:
   roofline      the dominant kernel's algorithmic bytes (8 B/element) / its HIP-event launch time
-  cpu_baseline  the CPU oracle (oracle/fp8q_oracle.c, OpenMP) on a bounded sample, rank 0, N=1
+  cpu_baseline  value: the reference's eager ATen op chain on the host cores (kind "reference-equivalent"); port_value: the
+                fused C port of the oracle (oracle/fp8q_oracle.c, OpenMP); bounded samples, rank 0, N=1
   extras        other kernels of the path on their own shapes (not part of `value`)
 """
 import argparse
@@ -1016,15 +1017,19 @@ def main():
             sample_ch = 1 << 18
             xc = x[:sample_ch].cpu()
             mvc = maxval[:sample_ch].cpu()
-            cb, ref, n_ch = cpu_baseline(xc.numpy(), mvc.numpy())
+            port, ref, n_ch = cpu_baseline(xc.numpy(), mvc.numpy())
+            # `value` = the reference's CPU path: its own eager ATen op chain on the host cores (oracle/torch_eager.py restates
+            # fp8_quantizer.py:91-133 op for op; the reference files do not travel to the GPU box).  The fused C port of the
+            # oracle (OpenMP, all threads) rides along as port_*: the "fair fused CPU" figure of SURVEY.md 8(d).
+            cb = torch_eager_cpu(xc, mvc, min(n_ch, 1 << 16))
+            cb.update(port_value=port["value"], port_unit=port["unit"], port_cores=port["cores"], port_kind=port["kind"],
+                      port_sample=port["sample"])
             line["cpu_baseline"] = cb
-            # the sample doubles as a parity check of the timed kernel's output
+            # the port's sample doubles as a parity check of the timed kernel's output
             import numpy as np
             got = y[:n_ch].cpu().numpy()
             line["cpu_baseline"]["gpu_output_bit_exact_on_sample"] = bool(
                 np.array_equal(got.view(np.int32), ref.view(np.int32)))
-            # same object, next to the port: the reference's own op chain on the host cores (reported, not a target)
-            line["cpu_baseline"]["reference_equivalent"] = torch_eager_cpu(xc, mvc, min(n_ch, 1 << 16))
     del x, y, shard
     if world > 1:
         del full

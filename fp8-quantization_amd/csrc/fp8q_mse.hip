@@ -323,31 +323,47 @@ __device__ __forceinline__ float mse_tie_patch(const float *__restrict__ xt /* t
     const uint32_t nthr = (2u * kTieW) << ksh;
     const float kf = 1.0f - (float)kTieW * __builtin_ldexpf(1.0f, (int)f.M - 22);
     float delta = 0.0f;
+    // 16 elements per trip, their four 16-byte loads in flight together (one element per trip made a small tensor wait 64
+    // memory round trips -- ~100 us -- for the structural tie of its last candidate)
 #pragma unroll 1
-    for (int j = 0; j < kMseRowEpl; ++j) {
-        const int off = (j >> 2) * 256 + lane * 4 + (j & 3);
-        if (off >= left) break;                        // zero padding of the row's last tile (q(0) = 0 either way)
-        const float x = xt[off];
-        const float xc = __builtin_amdgcn_fmed3f(x, ch.minv, ch.maxv);   // (a no-op where the fast loop skipped the clamp)
-        const float tt = xc * c1s;
-        float rr;
-        bool near;
-        if (use_int) {
-            rr = __uint_as_float((__float_as_uint(tt) + half) & msk);
-            near = (__float_as_uint(tt) << ksh) + nadd <= nthr;
-        } else {
-            const uint32_t b = max(__float_as_uint(tt) & 0x7f800000u, lo) + kadd;
-            const float cc = __uint_as_float(b);
-            rr = (tt + cc) - cc;
-            near = fabsf(tt - rr) - __uint_as_float(b - 0x0C400000u) * kf >= 0.0f;
+    for (int g = 0; g < kMseRowEpl / 16; ++g) {
+        float xe[16];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int off = (g * 4 + v) * 256 + lane * 4;
+            if (off + 3 < left) {
+                const vf4 w = ld16u<false>(xt + off);
+                xe[4 * v] = w.x, xe[4 * v + 1] = w.y, xe[4 * v + 2] = w.z, xe[4 * v + 3] = w.w;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) xe[4 * v + q] = off + q < left ? xt[off + q] : 0.0f;   // zero padding: q(0) = 0 either way
+            }
         }
-        if (!near) continue;
-        const float ms = (two && fabsf(tt) < thr) ? m0b : m0s;
-        const float df = x - rr * ms;
-        const float ls = __builtin_amdgcn_fmed3f(floorf(log2_tab(fabsf(xc), kFastTab) + ch.bias), 1.0f, (float)f.pmax);
-        const float sc = scale_exact(ch, ls, f.M);
-        const float de = x - rintf(xc / sc) * sc;
-        delta += de * de - df * df;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float x = xe[e];
+            const float xc = __builtin_amdgcn_fmed3f(x, ch.minv, ch.maxv);   // (a no-op where the fast loop skipped the clamp)
+            const float tt = xc * c1s;
+            float rr;
+            bool near;
+            if (use_int) {
+                rr = __uint_as_float((__float_as_uint(tt) + half) & msk);
+                near = (__float_as_uint(tt) << ksh) + nadd <= nthr;
+            } else {
+                const uint32_t b = max(__float_as_uint(tt) & 0x7f800000u, lo) + kadd;
+                const float cc = __uint_as_float(b);
+                rr = (tt + cc) - cc;
+                near = fabsf(tt - rr) - __uint_as_float(b - 0x0C400000u) * kf >= 0.0f;
+            }
+            if (__builtin_expect(near, 0)) {
+                const float ms = (two && fabsf(tt) < thr) ? m0b : m0s;
+                const float df = x - rr * ms;
+                const float ls = __builtin_amdgcn_fmed3f(floorf(log2_tab(fabsf(xc), kFastTab) + ch.bias), 1.0f, (float)f.pmax);
+                const float sc = scale_exact(ch, ls, f.M);
+                const float de = x - rintf(xc / sc) * sc;
+                delta += de * de - df * df;
+            }
+        }
     }
     return delta;
 }
@@ -673,15 +689,15 @@ static int mse_hist_mode()
 }
 
 // The route's cost does not depend on the data: ~55 us of small launches + ~0.1 us per (width, candidate) pair for the borders
-// + ~4.3 ps per element (partition at the copy rate + the moments); k_mse_row costs ~0.27 ps per (element, pair) (0.19 before
-// it watched for near-ties).  (MI355X, tools/mb_mse_sizes.py: 111 pairs break even at ~2.5 M elements, 666 pairs at ~0.7 M;
-// profiles/r05_mse_sizes.txt.)
+// + ~4.3 ps per element (partition at the copy rate + the moments); k_mse_row costs ~25 us + ~0.25 ps per (element, pair)
+// (0.19 ps before it watched for near-ties).  (MI355X, tools/mb_mse_sizes.py: 111 pairs break even at ~1.7 M elements, 666
+// pairs at ~0.6 M; profiles/r05_mse_sizes.txt.)
 // Which route a row takes depends on its shape only, so a tensor is evaluated the same way on every call.
 static bool mse_use_hist_shape(int64_t C, int64_t inner, int64_t n_cand, int n_m)
 {
     if (mse_hist_mode() == 0 || C != 1 || inner < (1 << 18) || inner >= (1ll << 31)) return false;
     const double pairs = (double)(n_m * n_cand);
-    const double row = (double)inner * pairs * 0.27e-12;
+    const double row = 25e-6 + (double)inner * pairs * 0.25e-12;
     const double hist = 55e-6 + pairs * 0.095e-6 + (double)inner * 4.3e-12;
     return row > hist;
 }
@@ -758,7 +774,7 @@ static RowGeo mse_row_geo(int64_t C, int64_t inner, int64_t n_cand, int n_m)
     const int64_t resident = 256 * 12;   // CUs x waves (144 VGPRs: 3 per SIMD)
     const int64_t g0 = cdiv(total, kMseRowGroup);
     double best = -1.0;
-    for (int64_t ng = g0; ng <= g0 * 16 && ng <= total; ++ng) {
+    for (int64_t ng = g0; ng <= g0 * 4 && ng <= total; ++ng) {
         const int64_t gs = cdiv(total, ng), waves = g.nblk * ng * (C > 0 ? C : 1);
         const double rounds = (double)cdiv(waves, resident);
         const double fill = (double)waves / (rounds * (double)resident);

@@ -68,6 +68,22 @@ def _out(out, like, dtype=None, name="out"):
     return out
 
 
+def _dense_flat(x):
+    """x as a flat [numel] view over its own storage when x is dense but not contiguous (channels-last activations, a
+    transposed matrix: every element of the storage span belongs to x exactly once), else None.  Per-tensor K1 and the
+    per-tensor min/max are elementwise / order-free, so they can run on the storage as it lies -- no NCHW copy (8 B per
+    element) -- and the result keeps x's strides, as the reference's elementwise ATen ops do."""
+    if x.is_contiguous() or x.numel() == 0:
+        return None
+    dims = sorted((st, sz) for st, sz in zip(x.stride(), x.shape) if sz > 1)
+    expect = 1
+    for st, sz in dims:
+        if st != expect:
+            return None
+        expect *= sz
+    return x.as_strided((x.numel(),), (1,), x.storage_offset())
+
+
 def _rows(x, per_channel):
     """[C, inner] view geometry: channel = dim 0 (reference: x.view(x.shape[0], -1))."""
     if per_channel:
@@ -111,9 +127,16 @@ def quantize(x, maxval, mbits, n_bits=8, sign_bits=1, out=None):
     float64; mbits: a number, or a 1-element CUDA float32 tensor (read by the kernel: no host round trip)."""
     _require(x, "x", (torch.float32, torch.float64))
     _require(maxval, "maxval", like=x)
-    x = x.contiguous()
     maxval = maxval.contiguous().view(-1)
     n_mv = maxval.numel()
+    flat = _dense_flat(x) if (n_mv == 1 and out is None) else None
+    if flat is not None:            # per tensor on a dense non-contiguous layout: the storage as it lies, x's strides kept
+        res = torch.empty_like(x)                            # (preserve_format: x's strides)
+        flat_out = _dense_flat(res) if res.stride() == x.stride() else None
+        if flat_out is not None:
+            quantize(flat, maxval, mbits, n_bits, sign_bits, out=flat_out)
+            return res
+    x = x.contiguous()
     C, inner = _rows(x, n_mv != 1)
     if n_mv != 1 and n_mv != C:
         raise Fp8qError(f"maxval has {n_mv} elements, expected 1 or {C}")
@@ -313,7 +336,8 @@ def minmax(x, per_channel, cur_min=None, cur_max=None, mode=FOLD_CURRENT, moment
     Returns (cur_min, cur_max[, maxval]) as [C] tensors.
     """
     _require(x, "x")
-    x = x.contiguous()
+    flat = None if per_channel else _dense_flat(x)      # per tensor: any dense layout, no copy
+    x = flat if flat is not None else x.contiguous()
     C, inner = _rows(x, per_channel)
     if C == 0 or inner == 0:
         raise Fp8qError("min/max of an empty tensor")
@@ -395,7 +419,8 @@ def mse_grid(x, per_channel, grid, mbits_list, n_bits, sign_bits, mses):
     _require(x, "x")
     _require(grid, "grid", like=x)
     _require(mses, "mses", like=x)
-    x = x.contiguous()
+    flat = None if per_channel else _dense_flat(x)      # a per-tensor mean does not depend on the layout
+    x = flat if flat is not None else x.contiguous()
     C, inner = _rows(x, per_channel)
     n_m = len(mbits_list)
     n_cand = grid.shape[0]
@@ -470,7 +495,8 @@ def minmax_linspace(x, per_channel, steps=111, lo_frac=0.1, hi_frac=1.2):
     """First calibration batch of FP_MSE_Estimator in ONE launch (fp8q_minmax_linspace_f32): row min / max, max|x| and
     the search grid of that maximum.  Returns (min [C], max [C], absmax [C], grid [steps, C])."""
     _require(x, "x")
-    x = x.contiguous()
+    flat = None if per_channel else _dense_flat(x)
+    x = flat if flat is not None else x.contiguous()
     C, inner = _rows(x, per_channel)
     if C == 0 or inner == 0:
         raise Fp8qError("min/max of an empty tensor")

@@ -15,8 +15,16 @@ def quant_scalar_nearest(x, grid):
     return grid[int(np.argmin(np.abs(x - grid)))]
 
 
+# A float32 grid (what an INT quantizer's generate_grid() hands over) is integrated in the reference's own mixed precision,
+# operation for operation (quantization/refprec.py): that is what the reference prints for INT8.  False: float64 throughout.
+INT_GRID_REFERENCE_PRECISION = True
+
+
 def integrate_pdf_grid_func_analyt(distr, grid, distr_attr_func_name):
     """sum over the Voronoi cells of the grid of distr.<func>(cell_lo, cell_hi, grid_point)."""
+    if INT_GRID_REFERENCE_PRECISION and isinstance(grid, np.ndarray) and grid.dtype == np.float32:
+        from .refprec import integrate_float32_grid
+        return integrate_float32_grid(distr, grid, distr_attr_func_name)
     grid = np.sort(np.asarray(grid, dtype=np.float64))
     f = getattr(distr, distr_attr_func_name)
     lo, hi = distr.range_min, distr.range_max

@@ -41,7 +41,7 @@ def assert_bit_exact(y, y_ref, what=""):
 
 def test_library_loaded(ops):
     import fp8q
-    assert fp8q.lib().fp8q_version() == 400
+    assert fp8q.lib().fp8q_version() == 500
     assert os.path.exists(fp8q.so_path())
 
 
@@ -186,6 +186,38 @@ def test_out_and_device_arguments_are_validated(ops):
     # a good `out=` of another SHAPE with the same element count is fine (the kernel sees [C, inner] either way)
     o = torch.empty(8 * 147, device="cuda")
     assert torch.equal(ops.quantize(x, mv1, 3, out=o).view_as(x), ops.quantize(x, mv1, 3))
+
+
+def test_per_tensor_ops_run_on_dense_layouts_without_a_copy(ops, monkeypatch):
+    """channels-last activations / transposed matrices: per-tensor K1, min/max and the MSE table are layout-agnostic, so
+    they run on the storage as it lies (no .contiguous() copy: 8 B per element) and K1's result keeps the input's strides,
+    as the reference's elementwise ATen ops do"""
+    torch.manual_seed(3)
+    x = torch.randn(6, 16, 9, 11, device="cuda").contiguous(memory_format=torch.channels_last)
+    mv = torch.tensor([1.7], device="cuda")
+    calls = []
+    orig = torch.Tensor.contiguous
+    monkeypatch.setattr(torch.Tensor, "contiguous", lambda self, *a, **k: (calls.append(tuple(self.shape)), orig(self, *a, **k))[1])
+    y = ops.quantize(x, mv, 3, 8, 1)
+    mn, mx = ops.minmax(x, False)
+    grid = torch.linspace(0.2, 3.0, 111, device="cuda").reshape(111, 1)
+    mses = ops.mse_grid(x, False, grid, [3.0], 8, 1, torch.zeros(1, 111, 1, device="cuda"))
+    monkeypatch.undo()
+    assert (6, 16, 9, 11) not in calls, calls                              # the 4-D tensor was never copied
+    assert y.stride() == x.stride() and y.is_contiguous(memory_format=torch.channels_last)
+    xc = x.contiguous()
+    assert torch.equal(y, ops.quantize(xc, mv, 3, 8, 1))                   # element for element the same values
+    rmn, rmx = ops.minmax(xc, False)
+    assert torch.equal(mn, rmn) and torch.equal(mx, rmx)
+    want = ops.mse_grid(xc, False, grid, [3.0], 8, 1, torch.zeros(1, 111, 1, device="cuda"))
+    torch.testing.assert_close(mses, want, rtol=1e-6, atol=0)              # (another summation order)
+    t = torch.randn(300, 70, device="cuda").t()                            # a transposed matrix
+    yt = ops.quantize(t, mv, 2, 8, 1)
+    assert yt.stride() == t.stride() and torch.equal(yt, ops.quantize(t.contiguous(), mv, 2, 8, 1))
+    s = torch.randn(8, 64, device="cuda")[:, ::2]                          # NOT dense: the copy path, contiguous result
+    assert torch.equal(ops.quantize(s, mv, 3, 8, 1), ops.quantize(s.contiguous(), mv, 3, 8, 1))
+    pc = ops.quantize(x, torch.rand(6, device="cuda") + 0.5, 3, 8, 1)      # per channel: rows are dim 0 -> the NCHW view
+    assert pc.is_contiguous()
 
 
 def test_signed_zero_rows_follow_the_pinned_contract(ops, golden_dir):

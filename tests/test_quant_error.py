@@ -39,12 +39,13 @@ def test_analytic_mse_on_reference_ranges(g5):
     for name, d in _distrs().items():
         for eb, rmin, rmax, mse, dp in g5[f"{name}_rows"]:
             if eb == 0:
-                grid = rmax / 127.0 * np.arange(-128, 128)        # SymmetricUniformQuantizer.generate_grid
-                # The reference hands the INT grid to its integrator as a float32 array, so the
-                # closed forms (a^3/3 - b^3/3 ... on cells of width 0.008) cancel catastrophically in
-                # float32: its INT8 numbers carry noise of +7.5 % (uniform), -0.14 % (gauss), +1.2 %
-                # (student) relative to the float64 evaluation done here.  Not reproduced.
-                tol = {"uniform": 0.09, "gauss": 0.003, "student": 0.02}[name]
+                # SymmetricUniformQuantizer.generate_grid: a FLOAT32 array reaches the integrator (quant_error_estimator.py
+                # :141-143), whose closed forms then run partly in float32 (cells 0.008 wide: catastrophic cancellation,
+                # +7.5 % / -0.14 % / +1.2 % against float64).  quantization/refprec.py evaluates the same expression
+                # trees: the reference's numbers to the last bit
+                grid = (torch.tensor(rmax, dtype=torch.float32) / 127.0 * (torch.arange(-128.0, 128.0) - 0.0)).numpy()
+                assert grid.dtype == np.float32
+                tol = 1e-14
             else:
                 grid = generate_all_float_values_scaled(8, int(eb), 2 ** (int(eb) - 1), rmax)
                 tol = 2e-6    # the reference scales the grid through a float32 tensor
@@ -78,8 +79,8 @@ def test_compute_quant_error_vs_reference(g5, name):
     """Whole config-1 procedure on the GPU in the reference's own precision (float64 samples, float64 line search):
     every format picks the reference's candidate -- the SAME index, hence the same float32 range -- and the analytic
     MSEs follow to 1e-6 (FP formats; the reference scales their grid through a float32 tensor).  The INT8 row (a few
-    elementwise torch ops, not part of the FP8 path) picks the same candidate too; its ANALYTIC error keeps the note
-    below: the reference integrates a float32 grid."""
+    elementwise torch ops, not part of the FP8 path) picks the same candidate too and its analytic errors are the
+    reference's to 1e-12 (round 5: the float32 grid is integrated in the reference's own mixed precision)."""
     import compute_quant_error as cqe
     from quantization.range_estimators import LineSearchEstimator
     d = _distrs()[name]
@@ -98,9 +99,8 @@ def test_compute_quant_error_vs_reference(g5, name):
     for (eb, M, rmax, mse, sqnr, dp, dps), (reb, rrmin, rrmax, rmse, rdp) in zip(rows, g5[f"{name}_rows"]):
         assert eb == reb
         assert rmax == rrmax, (name, eb, rmax, rrmax)                      # the same candidate -> the same float32 range
-        # INT8: the reference hands its integrator a float32 grid (catastrophic cancellation in the closed forms): its
-        # own numbers carry noise of +7.5 % / -0.14 % / +1.2 % against the float64 evaluation done here
-        tol = {"uniform": 0.09, "gauss": 0.003, "student": 0.02}[name] if eb == 0 else 2e-6
+        # INT8: the float32 grid is integrated in the reference's own mixed precision (quantization/refprec.py) -> its digits
+        tol = 1e-12 if eb == 0 else 2e-6
         assert abs(mse - rmse) <= tol * rmse, (name, eb, mse, rmse)
         assert abs(dp - rdp) <= tol * rdp, (name, eb, dp, rdp)
     if name == "gauss":   # BASELINE config 1 headline pair: E4M3 31.6 dB vs INT8 40.6 dB
