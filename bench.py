@@ -660,10 +660,15 @@ def north_star_path(args, ops, dev, rank, world, backend):
         fd.quantize_weights_sharded_bucketed(ws, MBITS, NBITS, SIGN)
     dt = wall(lambda: fd.quantize_weights_sharded_bucketed(ws, MBITS, NBITS, SIGN), reps)
     n_r18 = sum(t.numel() for t in ws)
+    # the default wire form at N > 1: 1-byte storage codes + fp32 ranges (a quarter of the fp32 bytes); fp32 for comparison
+    dt32 = wall(lambda: fd.quantize_weights_sharded_bucketed(ws, MBITS, NBITS, SIGN, wire="fp32"), reps) if world > 1 else dt
+    wire_b = 1 if world > 1 else 4
     res["resnet18_weights_one_allgather"] = dict(
         tensors=len(ws), elements=n_r18, step_us=round(dt * 1e6, 1), gelem_s=round(n_r18 / dt / 1e9, 2),
+        wire="codes_u8 + fp32 ranges" if world > 1 else "fp32 (one rank: nothing is shipped)",
+        fp32_wire_step_us=round(dt32 * 1e6, 1), fp32_wire_gelem_s=round(n_r18 / dt32 / 1e9, 2),
         scaling="strong (the model is fixed; every rank quantizes 1/N of every tensor's channels)",
-        xgmi_bytes_received_per_rank=int(n_r18 * 4 * (world - 1) / world))
+        xgmi_bytes_received_per_rank=int(n_r18 * wire_b * (world - 1) / world))
     del ws
 
     # ---- config 5: allminmax fold -> range all-reduce -> E4M3 quantize of the per-rank slab ----
@@ -795,7 +800,9 @@ def dry_run(args, world, rank):
             [(512, 256, 3, 3), (512, 512, 3, 3), (512, 256, 1, 1)] + [(512, 512, 3, 3)] * 2 + [(1000, 512)]
         ws = [torch.randn(*sh, generator=g) * 0.05 for sh in shapes]
         section("resnet18_weights_one_allgather: quantize_weights_sharded_bucketed (REAL shapes)",
-                lambda: fd.quantize_weights_sharded_bucketed(ws, MBITS, NBITS, SIGN, ops=ops))
+                lambda: fd.quantize_weights_sharded_bucketed(ws, MBITS, NBITS, SIGN, ops=ops))          # default wire: 1-byte codes
+        section("resnet18_weights_one_allgather, fp32 wire (round 4's form)",
+                lambda: fd.quantize_weights_sharded_bucketed(ws, MBITS, NBITS, SIGN, ops=ops, wire="fp32"))
         xs = torch.randn(8, 64, 64, generator=torch.Generator().manual_seed(1234 + rank))
         section("c5: calibrate_quantize_sharded", lambda: fd.calibrate_quantize_sharded(xs, 3, 8, 1, ops=ops))
         one = torch.ones(1)
@@ -812,7 +819,8 @@ def dry_run(args, world, rank):
                                                           "all_gather_into_tensor ranges": {"send_bytes_per_rank": (1 << 18) * 4}},
             "resnet18_weights_one_allgather": {"all_gather_into_tensor bucket": {
                 "send_bytes_per_rank": seq["resnet18_weights_one_allgather: quantize_weights_sharded_bucketed (REAL shapes)"][0]["send_bytes"],
-                "note": "real shapes: this IS the full-size count (values + ranges of every tensor's shard, padded to 16 B)"}},
+                "fp32_wire_send_bytes_per_rank": seq["resnet18_weights_one_allgather, fp32 wire (round 4's form)"][0]["send_bytes"],
+                "note": "real shapes: this IS the full-size count (1-byte codes + fp32 ranges of every tensor's shard, padded to 16 B)"}},
             "c5 [512,4096,512] per rank": {"all_reduce MAX": {"send_bytes_per_rank": 16, "note": "{-min, max, nan flags}: 4 floats"}},
         }
         print(json.dumps({"dry_run": True, "ranks": R, "ranks_seen": int(one.item()), "backend": "gloo (CPU tensors, compute stub)",

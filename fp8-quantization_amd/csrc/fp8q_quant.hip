@@ -902,6 +902,7 @@ struct MultiDesc {
     int single_row;
     uint32_t magic;
     uint32_t chunk0;     // first global chunk id of this tensor
+    int n_bits;          // (storage codes: the sign bit's position)
     QFmt f;
 };
 
@@ -942,6 +943,11 @@ struct MultiArgs {
 // chunks per block measured equal) is THE limit; the launch is short enough (3 chunks per block) that its fixed phases
 // (launch ramp, table staging, first load round trip, last compute + store drain) make up the gap to the copy.
 // Not pursued further: the launch replaces 21 launches (130 us from Python).
+// MODE 0: K1 (fp32 -> fp32).  MODE 3 / 4 (round 5): the storage codes of N3 for many tensors at once -- encode (fp32 -> 1 byte,
+// x = values, y = codes) / decode (1 byte -> fp32, x = codes, y = values): what the bucketed all-gather of channel-sharded
+// weights packs into / unpacks from its send buffer in one launch each (fp8q_multi_minmax_encode_u8, fp8q_multi_decode_u8).
+// Same chunks, tables and row bookkeeping; a group is 4 elements = one 16-byte load and one 4-byte store or vice versa.
+template <int MODE>
 __global__ void __launch_bounds__(kBlock, 4)
 k_multi_flat(MultiArgs a)
 {
@@ -959,28 +965,39 @@ k_multi_flat(MultiArgs a)
         const uint32_t c0 = l < a.n ? a.d[l].chunk0 : 0xffffffffu;
         return __popcll(__ballot(c0 <= g)) - 1;   // chunk0 ascends from 0: uniform, >= 0
     };
-    auto issue = [&](uint32_t g, int t, vf4 (&w)[U]) {   // the chunk's 16-byte groups: 4 per lane
+    auto issue = [&](uint32_t g, int t, vf4 (&w)[U], uint32_t (&wc)[U]) {   // the chunk's groups of 4 elements: 4 per lane
         const MultiDesc &d = a.d[t];
         const int64_t elo = (int64_t)(g - d.chunk0) * kChunkElems;
         const int64_t rem = d.nvec * 4 - elo;
         const int ng = (rem < kChunkElems ? (int)rem : kChunkElems) >> 2;
-        const vf4 *xv = reinterpret_cast<const vf4 *>(d.x + elo);
+        if (MODE == 4) {
+            const uint32_t *xc = reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(d.x) + elo);
 #pragma unroll
-        for (int u = 0; u < U; ++u)
-            if (tid + u * kBlock < ng) w[u] = ld16<false>(xv + tid + u * kBlock);
+            for (int u = 0; u < U; ++u)
+                if (tid + u * kBlock < ng) wc[u] = xc[tid + u * kBlock];
+        } else {
+            const vf4 *xv = reinterpret_cast<const vf4 *>(d.x + elo);
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (tid + u * kBlock < ng) w[u] = ld16<false>(xv + tid + u * kBlock);
+        }
     };
     for (uint32_t g = blockIdx.x; g < a.total_chunks; g += gridDim.x) {
         const int t = tensor_of(g);
         vf4 v[U];
-        issue(g, t, v);   // in flight during the table phase (requesting the block's NEXT chunk here as well measured slower:
+        uint32_t vc[U];
+        issue(g, t, v, vc);   // in flight during the table phase (requesting the block's NEXT chunk here as well measured slower:
                           // 21.1 vs 19.1 us for ResNet-18's 21 tensors)
         const MultiDesc &d = a.d[t];
         const QFmt f = d.f;
         const int inner = d.inner, lut_stride = f.pmax + 1;
         const float pmaxf = (float)f.pmax;
         const int64_t elo = (int64_t)(g - d.chunk0) * kChunkElems;
-        const float *x = d.x + elo;
-        float *y = d.y + elo;
+        const float *x = d.x + elo;                                                       // (MODE 4: codes, see xb)
+        float *y = d.y + elo;                                                             // (MODE 3: codes, see yb)
+        const uint8_t *xb = reinterpret_cast<const uint8_t *>(d.x) + elo;
+        uint8_t *yb = reinterpret_cast<uint8_t *>(d.y) + elo;
+        const int Mi = (int)f.M, sign_shift = f.sign_bits == 1 ? d.n_bits - 1 : -1;
         const int64_t rem = d.nvec * 4 - elo;
         const int len = rem < kChunkElems ? (int)rem : kChunkElems;
         const int ng = len >> 2;
@@ -1003,7 +1020,12 @@ k_multi_flat(MultiArgs a)
         if (tid < tail) {   // the tensor's last <= 3 elements
             const int e = len + tid;
             const int r = d.single_row ? 0 : div_small((uint32_t)(phase + e), d.magic);
-            y[e] = quant_one(x[e], lite_of(chl[r]), lut + r * lut_stride, pmaxf, f.qthr);
+            if (MODE == 3)
+                yb[e] = (uint8_t)encode_one(x[e], lite_of(chl[r]), lut + r * lut_stride, pmaxf, f.qthr, Mi, sign_shift);
+            else if (MODE == 4)
+                y[e] = decode_one(xb[e], lut + r * lut_stride, Mi, sign_shift);
+            else
+                y[e] = quant_one(x[e], lite_of(chl[r]), lut + r * lut_stride, pmaxf, f.qthr);
         }
         vf4 *yv = reinterpret_cast<vf4 *>(y);
 #pragma unroll
@@ -1013,7 +1035,27 @@ k_multi_flat(MultiArgs a)
             const int o = phase + 4 * q;
             const int lrow = d.single_row ? 0 : div_small((uint32_t)o, d.magic);
             const int b = d.single_row ? 4 : inner - (o - lrow * inner);   // elements left in this row (>= 1)
+            if (MODE == 4) {   // b..3 of the group are the next row's: its table
+                const float2 *la = lut + lrow * lut_stride, *lb = la + lut_stride;
+                const uint32_t w = vc[u];
+                st16<false>(yv + q, vf4{decode_one(w & 255u, la, Mi, sign_shift), decode_one((w >> 8) & 255u, b > 1 ? la : lb, Mi, sign_shift),
+                                        decode_one((w >> 16) & 255u, b > 2 ? la : lb, Mi, sign_shift),
+                                        decode_one(w >> 24, b > 3 ? la : lb, Mi, sign_shift)});
+                continue;
+            }
             const float in[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+            if (MODE == 3) {
+                uint32_t wd = encode_group4(in, lite_of(chl[lrow]), lut + lrow * lut_stride, pmaxf, f.qthr, Mi, sign_shift);
+                if (b < 4) {
+                    const ChanLite cl = lite_of(chl[lrow + 1]);
+                    const float2 *lt = lut + (lrow + 1) * lut_stride;
+#pragma unroll
+                    for (int k = 1; k < 4; ++k)
+                        if (k >= b) wd = (wd & ~(255u << (8 * k))) | (encode_one(in[k], cl, lt, pmaxf, f.qthr, Mi, sign_shift) << (8 * k));
+                }
+                reinterpret_cast<uint32_t *>(yb)[q] = wd;
+                continue;
+            }
             float e[4] = {in[0], in[1], in[2], in[3]};
             quant_group<4>(e, lite_of(chl[lrow]), lut + lrow * lut_stride, pmaxf, f.qthr);
             if (b < 4) {   // e[b..3] belong to the next row (rows are >= 4 long: one boundary per group at most)
@@ -1988,7 +2030,8 @@ int fp8q_minmax_quantize_f32(const float *x, float *y, int64_t C, int64_t inner,
 
 // A prepared multi-tensor launch: the descriptors validated, classified and packed into kernel arguments once.
 struct PlanStep {
-    bool batched;              // true: one k_multi_flat launch of `args`; false: one fp8q_quantize_f32 call of `single`
+    int mode = 0;              // 0: K1, 3: encode to storage codes, 4: decode (k_multi_flat<MODE>)
+    bool batched;              // true: one k_multi_flat launch of `args`; false: one single-tensor call of `single`
     MultiArgs args;
     size_t shmem;
     fp8q_tensor_desc single;
@@ -2000,7 +2043,7 @@ struct fp8q_multi_plan {
     std::vector<PlanStep> steps;
 };
 
-static int plan_build(const fp8q_tensor_desc *descs, int n, fp8q_multi_plan &plan)
+static int plan_build(const fp8q_tensor_desc *descs, int n, fp8q_multi_plan &plan, int mode = 0)
 {
     if (n < 0 || (n > 0 && !descs)) return FP8Q_EINVAL;
     // validate everything first: nothing is built (or enqueued) if any descriptor is bad
@@ -2010,8 +2053,10 @@ static int plan_build(const fp8q_tensor_desc *descs, int n, fp8q_multi_plan &pla
         QFmt f;
         if (int rc = make_fmt(t.mbits, t.n_bits, t.sign_bits, &f)) return rc;
         if (t.C > 0 && t.inner > 0 && (!t.x || !t.y || !t.maxval)) return FP8Q_EINVAL;
+        if (mode != 0 && (t.n_bits > 8 || t.n_bits - t.sign_bits - (int)f.M < 1)) return mode && t.n_bits > 8 ? FP8Q_EINVAL : FP8Q_EUNSUPPORTED;
     }
     PlanStep cur;
+    cur.mode = mode;
     cur.batched = true;
     cur.args.n = 0;
     cur.args.rpc_max = 0;
@@ -2038,12 +2083,16 @@ static int plan_build(const fp8q_tensor_desc *descs, int n, fp8q_multi_plan &pla
         const int64_t inner = per_channel ? t.inner : nelem;
         const int64_t rpc = per_channel ? (inner + (kChunkElems + 3) - 2) / inner + 1 : 1;
         const int64_t per_row = 16 + 16 + (int64_t)(f.pmax + 1) * 8;
-        const bool batchable = (((uintptr_t)t.x | (uintptr_t)t.y) & 15) == 0 && nelem >= 4 && nelem < (1ll << 31) &&
+        // 16-byte groups of fp32 on the value side, 4-byte groups of codes on the other
+        const uintptr_t mis = mode == 3 ? (((uintptr_t)t.x & 15) | ((uintptr_t)t.y & 3))
+                            : mode == 4 ? (((uintptr_t)t.x & 3) | ((uintptr_t)t.y & 15)) : (((uintptr_t)t.x | (uintptr_t)t.y) & 15);
+        const bool batchable = mis == 0 && nelem >= 4 && nelem < (1ll << 31) &&
                                (!per_channel || (inner >= 4 && inner <= kMagicMaxDivisor)) &&
                                rpc * per_row <= 36 * 1024 && nelem * 4 < kNtBytes;
         if (!batchable) {   // unaligned, very short rows, or a tensor big enough to deserve its own launch
             flush();
             PlanStep one;
+            one.mode = mode;
             one.batched = false;
             one.args.n = 0;
             one.args.rpc_max = 0;
@@ -2065,6 +2114,7 @@ static int plan_build(const fp8q_tensor_desc *descs, int n, fp8q_multi_plan &pla
         d.rpc = (int)rpc;
         d.magic = per_channel ? magic_of((int)inner) : 0u;
         d.chunk0 = cur.args.total_chunks;
+        d.n_bits = t.n_bits;
         d.f = f;
         cur.args.total_chunks += (uint32_t)cdiv(d.nvec, kChunkGroups);
         // per table row: the channel constants (16 B) + pmax + 1 entries {s, 1/s}; every tensor of the launch uses the
@@ -2087,14 +2137,26 @@ static int plan_launch(const fp8q_multi_plan &plan, hipStream_t st)
                 const int v = e ? atoi(e) : 0;
                 return v >= 1 ? v : 1024;
             }();
-            hipLaunchKernelGGL(k_multi_flat, dim3((unsigned)balanced_blocks(s.args.total_chunks, grid_env)), dim3(kBlock),
-                               s.shmem, st, s.args);
+            const dim3 grid((unsigned)balanced_blocks(s.args.total_chunks, grid_env));
+            if (s.mode == 3)
+                hipLaunchKernelGGL(k_multi_flat<3>, grid, dim3(kBlock), s.shmem, st, s.args);
+            else if (s.mode == 4)
+                hipLaunchKernelGGL(k_multi_flat<4>, grid, dim3(kBlock), s.shmem, st, s.args);
+            else
+                hipLaunchKernelGGL(k_multi_flat<0>, grid, dim3(kBlock), s.shmem, st, s.args);
             if (int rc = launch_rc()) return rc;
         } else {
             const fp8q_tensor_desc &t = s.single;
-            if (int rc = fp8q_quantize_f32(t.x, t.y, t.C, t.inner, t.maxval, t.n_maxval, t.mbits, t.n_bits,
-                                           t.sign_bits, (fp8q_stream_t)st))
-                return rc;
+            int rc;
+            if (s.mode == 3)
+                rc = fp8q_encode_u8(t.x, reinterpret_cast<uint8_t *>(t.y), t.C, t.inner, t.maxval, t.n_maxval, t.mbits, t.n_bits,
+                                    t.sign_bits, (fp8q_stream_t)st);
+            else if (s.mode == 4)
+                rc = fp8q_decode_u8(reinterpret_cast<const uint8_t *>(t.x), t.y, t.C, t.inner, t.maxval, t.n_maxval, t.mbits, t.n_bits,
+                                    t.sign_bits, (fp8q_stream_t)st);
+            else
+                rc = fp8q_quantize_f32(t.x, t.y, t.C, t.inner, t.maxval, t.n_maxval, t.mbits, t.n_bits, t.sign_bits, (fp8q_stream_t)st);
+            if (rc) return rc;
         }
     }
     return FP8Q_OK;
@@ -2113,7 +2175,33 @@ int fp8q_multi_quantize_f32(const fp8q_tensor_desc *descs, int n, fp8q_stream_t 
     }
 }
 
+static int multi_codec(const fp8q_tensor_desc *descs, int n, fp8q_stream_t stream, int mode)
+{
+    try {
+        fp8q_multi_plan plan;
+        if (int rc = plan_build(descs, n, plan, mode)) return rc;
+        return plan_launch(plan, (hipStream_t)stream);
+    } catch (...) {
+        return (int)hipErrorOutOfMemory;
+    }
+}
+
+int fp8q_multi_encode_u8(const fp8q_tensor_desc *descs, int n, fp8q_stream_t stream) { return multi_codec(descs, n, stream, 3); }
+int fp8q_multi_decode_u8(const fp8q_tensor_desc *descs, int n, fp8q_stream_t stream) { return multi_codec(descs, n, stream, 4); }
+
+static int multi_minmax_then(const fp8q_tensor_desc *descs, float *const *maxval_out, int n, fp8q_stream_t stream, int mode);
+
 int fp8q_multi_minmax_quantize_f32(const fp8q_tensor_desc *descs, float *const *maxval_out, int n, fp8q_stream_t stream)
+{
+    return multi_minmax_then(descs, maxval_out, n, stream, 0);
+}
+
+int fp8q_multi_minmax_encode_u8(const fp8q_tensor_desc *descs, float *const *maxval_out, int n, fp8q_stream_t stream)
+{
+    return multi_minmax_then(descs, maxval_out, n, stream, 3);
+}
+
+static int multi_minmax_then(const fp8q_tensor_desc *descs, float *const *maxval_out, int n, fp8q_stream_t stream, int mode)
 {
     if (n < 0 || (n > 0 && (!descs || !maxval_out))) return FP8Q_EINVAL;
     for (int i = 0; i < n; ++i) {   // per-channel ranges only; nothing is enqueued if a descriptor is bad
@@ -2153,7 +2241,8 @@ int fp8q_multi_minmax_quantize_f32(const fp8q_tensor_desc *descs, float *const *
     if (int rc = flush()) return rc;
     std::vector<fp8q_tensor_desc> q(descs, descs + n);
     for (int i = 0; i < n; ++i) q[i].maxval = maxval_out[i];
-    return fp8q_multi_quantize_f32(q.data(), n, stream);   // same stream: reads the ranges just written
+    // same stream: reads the ranges just written
+    return mode == 3 ? fp8q_multi_encode_u8(q.data(), n, stream) : fp8q_multi_quantize_f32(q.data(), n, stream);
 }
 
 int fp8q_multi_plan_create(const fp8q_tensor_desc *descs, int n, fp8q_multi_plan **plan_out)

@@ -63,6 +63,9 @@ SIGNATURES = {
     "fp8q_decode_u8": (_i, [_vp, _vp, _i64, _i64, _vp, _i64, _f, _i, _i, _vp]),
     "fp8q_multi_quantize_f32": (_i, [ctypes.POINTER(TensorDesc), _i, _vp]),
     "fp8q_multi_minmax_quantize_f32": (_i, [ctypes.POINTER(TensorDesc), ctypes.POINTER(_vp), _i, _vp]),
+    "fp8q_multi_encode_u8": (_i, [ctypes.POINTER(TensorDesc), _i, _vp]),
+    "fp8q_multi_minmax_encode_u8": (_i, [ctypes.POINTER(TensorDesc), ctypes.POINTER(_vp), _i, _vp]),
+    "fp8q_multi_decode_u8": (_i, [ctypes.POINTER(TensorDesc), _i, _vp]),
     "fp8q_multi_plan_create": (_i, [ctypes.POINTER(TensorDesc), _i, ctypes.POINTER(_vp)]),
     "fp8q_multi_plan_launch": (_i, [_vp, _vp]),
     "fp8q_multi_plan_launches": (_i, [_vp]),

@@ -275,17 +275,31 @@ def quantize_weight_sharded(w, mbits, n_bits=8, sign_bits=1, maxval=None, group=
     return out
 
 
-def quantize_weights_sharded_bucketed(weights, mbits, n_bits=8, sign_bits=1, group=None, ops=None, bucket_bytes=None):
+def quantize_weights_sharded_bucketed(weights, mbits, n_bits=8, sign_bits=1, group=None, ops=None, bucket_bytes=None,
+                                      wire=None):
     """All weight tensors of a model, channel-sharded, with ONE collective per bucket: every rank quantizes its
     channels of every tensor (current_minmax ranges) straight into a packed send buffer, the ranks exchange that
-    buffer with a single all-gather (ResNet-18: 46.7 MB in total, 5.8 MB per peer link on the xGMI mesh -- one
-    large transfer instead of 21 small ones), and every rank unpacks the full quantized tensors and ranges.
+    buffer with a single all-gather (one large transfer instead of 21 small ones), and every rank unpacks the full
+    quantized tensors and ranges.
+
+    wire="codes" (the default with more than one rank): the send buffer holds 1-byte STORAGE CODES and
+    the fp32 ranges -- ResNet-18: 11.7 MB in total, 1.46 MB per rank, a quarter of the fp32 form -- written by one
+    multi-tensor range launch + one multi-tensor encode launch per bucket (fp8q_multi_minmax_encode_u8) and decoded,
+    straight out of the receive buffer into the result tensors, by one multi-tensor decode launch per 32 (tensor, rank)
+    parts (fp8q_multi_decode_u8).  wire="fp32": the quantized fp32 values travel (46.7 MB / 5.8 MB per rank; the form of
+    round 4, and what a single rank uses: there is nothing to ship).  Both give bit-identical tensors.
 
     bucket_bytes=None puts everything into one bucket.  With a limit (per-rank send bytes, e.g. 8 << 20) the tensors
     are packed into consecutive buckets and every bucket's all-gather is launched asynchronously (on RCCL's own
     stream) while the next bucket is being quantized on the compute stream; all handles are waited for before
     unpacking.  Result per tensor identical to quantize_weight_sharded.  Returns [(w_q, maxval), ...]."""
     ops = ops or _default_ops()
+    if wire is None:
+        wire = "codes" if (_multi(group) and n_bits <= 8 and hasattr(ops, "encode")) else "fp32"
+    if wire not in ("codes", "fp32"):
+        raise ValueError(f"wire must be 'codes' or 'fp32', got {wire!r}")
+    if wire == "codes":
+        return _bucketed_codes(weights, mbits, n_bits, sign_bits, group, ops, bucket_bytes)
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     if not weights:
@@ -348,6 +362,81 @@ def quantize_weights_sharded_bucketed(weights, mbits, n_bits=8, sign_bits=1, gro
             mvs.append(recvs[bi][r, off_m: off_m + (b_ - a_)])
         out.append((torch.cat(parts).view_as(w), torch.cat(mvs)))
     return out
+
+
+def _bucketed_codes(weights, mbits, n_bits, sign_bits, group, ops, bucket_bytes):
+    """quantize_weights_sharded_bucketed with 1-byte codes on the wire.  Bucket layout (uint8), per tensor:
+    [codes of `per` channels, padded to 16 B | `per` fp32 ranges, padded to 16 B], per = ceil(C / world)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if not weights:
+        return []
+    dev0 = weights[0].device
+    pad16 = lambda v: -(-v // 16) * 16
+    geo, totals = [], [0]
+    for w in weights:
+        C = w.shape[0]
+        inner = w.numel() // max(C, 1)
+        per = -(-C // world)
+        need = pad16(per * inner) + pad16(per * 4)
+        if bucket_bytes is not None and totals[-1] > 0 and totals[-1] + need > bucket_bytes:
+            totals.append(0)
+        geo.append((len(totals) - 1, C, inner, per, totals[-1], totals[-1] + pad16(per * inner)))
+        totals[-1] += need
+    sends = [torch.zeros(t, dtype=torch.uint8, device=dev0) for t in totals]
+    recvs, handles = [None] * len(totals), []
+
+    def exchange(bi):
+        if _multi(group):
+            recvs[bi] = torch.empty(world * totals[bi], dtype=torch.uint8, device=dev0)
+            h = dist.all_gather_into_tensor(recvs[bi], sends[bi], group=group, async_op=len(totals) > 1)
+            if h is not None:
+                handles.append(h)
+            recvs[bi] = recvs[bi].view(world, totals[bi])
+        else:
+            recvs[bi] = sends[bi].view(1, totals[bi])
+
+    multi = getattr(ops, "multi_minmax_encode", None)     # ranges + codes of a whole bucket in two launches
+    pending = []
+    for i, (w, (bi, C, inner, per, off_c, off_m)) in enumerate(zip(weights, geo)):
+        lo, hi = channel_partition(C, world)[rank]
+        if hi > lo:
+            shard = w[lo:hi].contiguous()
+            dst_c = sends[bi][off_c: off_c + (hi - lo) * inner].view((hi - lo,) + tuple(shard.shape[1:]))
+            dst_m = sends[bi][off_m: off_m + (hi - lo) * 4].view(torch.float32)
+            if multi is not None:
+                pending.append((shard, dst_m, mbits, n_bits, sign_bits, dst_c))
+            else:
+                mv = ops.minmax(shard, True, want_maxval=True)[2]
+                dst_m.copy_(mv)
+                dst_c.copy_(ops.encode(shard, mv, mbits, n_bits, sign_bits).view_as(dst_c))
+        if i + 1 == len(weights) or geo[i + 1][0] != bi:   # bucket complete: ship it, go on with the next
+            if pending:
+                multi(pending)
+                pending = []
+            exchange(bi)
+    for h in handles:
+        h.wait()
+    # decode every (tensor, rank) part from where it was received into its place in the result: no re-assembly copies
+    outs, items = [], []
+    for w, (bi, C, inner, per, off_c, off_m) in zip(weights, geo):
+        y = torch.empty(w.shape, dtype=torch.float32, device=dev0)
+        mvs = []
+        for r, (a_, b_) in enumerate(channel_partition(C, world)):
+            if b_ == a_:
+                continue
+            codes = recvs[bi][r, off_c: off_c + (b_ - a_) * inner].view((b_ - a_,) + tuple(w.shape[1:]))
+            mv = recvs[bi][r, off_m: off_m + (b_ - a_) * 4].view(torch.float32)
+            items.append((codes, mv, mbits, n_bits, sign_bits, y[a_:b_]))
+            mvs.append(mv)
+        outs.append((y, torch.cat(mvs) if len(mvs) != 1 else mvs[0].clone()))
+    mdec = getattr(ops, "multi_decode", None)
+    if mdec is not None:
+        mdec(items)
+    else:
+        for codes, mv, mb, nb, sb, dst in items:
+            dst.copy_(ops.decode(codes, mv, mb, nb, sb).view_as(dst))
+    return outs
 
 
 N_MSE_GRID = 111   # candidates of FP_MSE_Estimator (range_estimators.py:305)

@@ -231,6 +231,69 @@ def multi_minmax_quantize(items):
     return outs
 
 
+def _pack_codec_descs(items, encode):
+    """descriptors of (values-or-codes, maxval, mbits[, n_bits[, sign_bits[, out]]]) items for the multi-tensor codec:
+    encode: x float32 -> out uint8; decode: x uint8 -> out float32.  Returns (descs, outs, keep)."""
+    from ._lib import TensorDesc
+    descs = (TensorDesc * len(items))()
+    outs, keep = [], []
+    src_dt, dst_dt = (torch.float32, torch.uint8) if encode else (torch.uint8, torch.float32)
+    for d, it in zip(descs, items):
+        x, maxval, mbits = it[0], it[1], it[2]
+        n_bits = it[3] if len(it) > 3 else 8
+        sign_bits = it[4] if len(it) > 4 else 1
+        out = it[5] if len(it) > 5 else None
+        _require(x, "x", src_dt)
+        _require(maxval, "maxval", like=x)
+        if keep and x.device != keep[0][0].device:
+            raise Fp8qError("multi-tensor codec: all tensors must be on one device")
+        x = x.contiguous()
+        maxval = maxval.contiguous().view(-1)
+        n_mv = maxval.numel()
+        C, inner = _rows(x, n_mv != 1)
+        if n_mv != 1 and n_mv != C:
+            raise Fp8qError(f"maxval has {n_mv} elements, expected 1 or {C}")
+        y = _out(out, x, dtype=dst_dt)
+        d.x, d.y, d.maxval = x.data_ptr(), y.data_ptr(), maxval.data_ptr()
+        d.C, d.inner, d.n_maxval = C, inner, n_mv
+        d.mbits, d.n_bits, d.sign_bits = float(mbits), int(n_bits), int(sign_bits)
+        outs.append(y)
+        keep.append((x, maxval))
+    return descs, outs, keep
+
+
+def multi_minmax_encode(items):
+    """Per-channel current_minmax ranges + storage codes of many tensors in TWO launches (fp8q_multi_minmax_encode_u8):
+    items (x, maxval_out [C] (receives the ranges), mbits[, n_bits[, sign_bits[, out uint8]]]).  Returns the code tensors
+    (bit-identical to encode(x, minmax(x, True).maxval) per item)."""
+    import ctypes
+    items = [tuple(it) for it in items]
+    if not items:
+        return []
+    descs, outs, keep = _pack_codec_descs(items, True)
+    for (x, mv), it in zip(keep, items):
+        if mv.data_ptr() != it[1].data_ptr() or mv.numel() != (x.shape[0] if x.dim() > 0 else 1):
+            raise Fp8qError("multi_minmax_encode: maxval_out must be a contiguous [C] tensor (it receives the ranges)")
+    mv_out = (ctypes.c_void_p * len(items))(*[mv.data_ptr() for _, mv in keep])
+    with _on_device(keep[0][0]):
+        rc = lib().fp8q_multi_minmax_encode_u8(descs, mv_out, len(items), _stream(keep[0][0]))
+    check(rc, "fp8q_multi_minmax_encode_u8")
+    return outs
+
+
+def multi_decode(items):
+    """Storage codes of many tensors back to float32 in one launch per 32 tensors (fp8q_multi_decode_u8):
+    items (codes uint8, maxval, mbits[, n_bits[, sign_bits[, out float32]]])."""
+    items = [tuple(it) for it in items]
+    if not items:
+        return []
+    descs, outs, keep = _pack_codec_descs(items, False)
+    with _on_device(keep[0][0]):
+        rc = lib().fp8q_multi_decode_u8(descs, len(items), _stream(keep[0][0]))
+    check(rc, "fp8q_multi_decode_u8")
+    return outs
+
+
 class MultiPlan:
     """Prepared multi-tensor K1 (fp8q_multi_plan_*): the descriptors of `items` are validated and packed once;
     launch() re-quantizes every tensor into its output with one ctypes call and one kernel launch per 32 tensors.

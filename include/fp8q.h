@@ -336,6 +336,18 @@ int fp8q_multi_quantize_f32(const fp8q_tensor_desc *descs, int n, fp8q_stream_t 
  * multi-GPU weight path runs on its shards before the all-gather (fp8q.dist.quantize_weights_sharded_bucketed).
  */
 int fp8q_multi_minmax_quantize_f32(const fp8q_tensor_desc *descs, float *const *maxval_out, int n, fp8q_stream_t stream);
+/*
+ * Storage codes (fp8q_encode_u8 / fp8q_decode_u8) for many tensors at once: what the bucketed all-gather of channel-sharded
+ * weights puts on the wire -- 1 byte per element instead of 4.  Same descriptor table; the CODE side is typed through the
+ * float pointers of fp8q_tensor_desc:  _encode_: x = fp32 values (16-byte aligned), y = (float *) of the uint8 codes
+ * (4-byte aligned);  _decode_: x = (const float *) of the codes, y = fp32 values.  Other alignments take one
+ * fp8q_encode_u8 / fp8q_decode_u8 call per tensor.  _minmax_encode_: per-channel current_minmax ranges first
+ * (maxval_out, as fp8q_multi_minmax_quantize_f32), then the codes: two launches for a whole bucket.
+ * Bit-identical to the single-tensor entry points; n_bits <= 8 and at least one exponent bit (FP8Q_EUNSUPPORTED otherwise).
+ */
+int fp8q_multi_encode_u8(const fp8q_tensor_desc *descs, int n, fp8q_stream_t stream);
+int fp8q_multi_minmax_encode_u8(const fp8q_tensor_desc *descs, float *const *maxval_out, int n, fp8q_stream_t stream);
+int fp8q_multi_decode_u8(const fp8q_tensor_desc *descs, int n, fp8q_stream_t stream);
 
 /*
  * Prepared multi-tensor launch.  fp8q_multi_quantize_f32 validates, classifies and packs its descriptors on every

@@ -52,7 +52,10 @@ def test_dry_run_ranks_prints_the_call_sequence_cpu():
     codes = seq["weights_allgather.codes_u8: quantize_weight_sharded_codes"]
     assert codes[0]["dtype"] == "uint8" and codes[0]["send_bytes"] == 1024 * 147
     r18 = seq["resnet18_weights_one_allgather: quantize_weights_sharded_bucketed (REAL shapes)"]
-    assert len(r18) == 1 and abs(r18[0]["send_bytes"] - (11678912 + 4800) * 4 / 4) < 0.01 * 11678912     # 1/4 of the model per rank
+    # 1/4 of the model per rank, as 1-byte codes + fp32 ranges (round 5: the default wire form); the fp32 form is 4 x that
+    assert len(r18) == 1 and r18[0]["dtype"] == "uint8" and abs(r18[0]["send_bytes"] - (11678912 + 4800 * 4) / 4) < 0.01 * 11678912 / 4
+    r18f = seq["resnet18_weights_one_allgather, fp32 wire (round 4's form)"]
+    assert len(r18f) == 1 and r18f[0]["dtype"] == "float32" and abs(r18f[0]["send_bytes"] - (11678912 + 4800) * 4 / 4) < 0.01 * 11678912
     c5 = seq["c5: calibrate_quantize_sharded"]
     assert c5 == [dict(op="all_reduce", dtype="float32", send_bytes=16, reduce="MAX")]
     full = d["full_size_bytes"]["headline (value at --gpus N)"]

@@ -119,6 +119,66 @@ def test_hip_codec_per_channel(shape):
     np.testing.assert_array_equal(y.cpu().numpy().view(np.int32), oracle.c_decode(codes.cpu().numpy(), mv, 2, 8, 1).view(np.int32))
 
 
+R18_SHAPES = [(64, 3, 7, 7)] + [(64, 64, 3, 3)] * 2 + [(128, 64, 3, 3), (128, 64, 1, 1), (256, 256, 3, 3), (512, 256, 1, 1),
+                                                       (512, 512, 3, 3), (1000, 512)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,sb", [(2, 1), (3, 1), (3, 0), (5, 1)])
+def test_hip_multi_tensor_codec_equals_the_single_tensor_entry_points(M, sb):
+    """fp8q_multi_minmax_encode_u8 / fp8q_multi_decode_u8 (k_multi_flat<3> / <4>): a model's weight tensors -- odd row
+    lengths, rows that straddle 16-byte groups and chunks, ragged tails, > 32 tensors (two launches), a per-tensor range,
+    unaligned views (single-tensor fall-back inside the call) -- bit-identical to minmax + encode / decode per tensor"""
+    import fp8q
+    ops = fp8q.ops
+    rng = np.random.RandomState(M * 10 + sb)
+    shapes = R18_SHAPES + [(5, 7), (33, 4099), (3, 5, 5, 5), (1, 9)] + [(16, 10)] * 30
+    xs = [dev((rng.randn(*sh) * rng.uniform(0.01, 3)).astype(np.float32)) for sh in shapes]
+    if sb == 0:
+        xs = [x.abs() for x in xs]
+    xs[3][5] = 0.0                                                   # an all-zero channel: maxval 0 -> code 0 everywhere
+    mvs = [torch.empty(x.shape[0], device="cuda") for x in xs]
+    codes = ops.multi_minmax_encode([(x, mv, M, 8, sb) for x, mv in zip(xs, mvs)])
+    for x, mv, c in zip(xs, mvs, codes):
+        rmv = ops.minmax(x, True, want_maxval=True)[2]
+        assert torch.equal(mv.view(torch.int32), rmv.view(torch.int32))
+        assert c.dtype == torch.uint8 and torch.equal(c, ops.encode(x, rmv, M, 8, sb)), tuple(x.shape)
+    ys = ops.multi_decode([(c, mv, M, 8, sb) for c, mv in zip(codes, mvs)])
+    for x, mv, c, y in zip(xs, mvs, codes, ys):
+        want = ops.decode(c, mv, M, 8, sb)
+        assert torch.equal(torch.isnan(y), torch.isnan(want)) and torch.equal(y[~torch.isnan(y)].view(torch.int32), want[~torch.isnan(want)].view(torch.int32))
+    # views into packed buffers at odd offsets (what the bucketed all-gather decodes from): codes 1-byte aligned, values 4-byte
+    buf = torch.zeros(3 + 33 * 4099, dtype=torch.uint8, device="cuda")
+    cv = buf[3:].view(33, 4099)
+    cv.copy_(codes[len(R18_SHAPES) + 1])
+    out = torch.zeros(1 + 33 * 4099, device="cuda")[1:].view(33, 4099)
+    ops.multi_decode([(cv, mvs[len(R18_SHAPES) + 1], M, 8, sb, out)])
+    assert torch.equal(out.view(torch.int32), ys[len(R18_SHAPES) + 1].view(torch.int32))
+    # a per-tensor range through the multi-tensor decode
+    pt = dev((rng.randn(4, 1000) * 2).astype(np.float32)).abs() if sb == 0 else dev((rng.randn(4, 1000) * 2).astype(np.float32))
+    mv1 = torch.tensor([2.5], device="cuda")
+    c1 = ops.encode(pt, mv1, M, 8, sb)
+    assert torch.equal(ops.multi_decode([(c1, mv1, M, 8, sb)])[0].view(torch.int32), ops.decode(c1, mv1, M, 8, sb).view(torch.int32))
+
+
+@pytest.mark.gpu
+def test_bucketed_weight_exchange_with_codes_on_the_wire_single_process():
+    """fp8q.dist.quantize_weights_sharded_bucketed(wire="codes") on the HIP ops (one rank, no process group): the packed
+    byte buffer, two launches in, one multi-tensor decode out -- the fp32 wire form's bits"""
+    import fp8q
+    from fp8q import dist as fd
+    rng = np.random.RandomState(5)
+    ws = [dev((rng.randn(*sh) * 0.05).astype(np.float32)) for sh in R18_SHAPES + [(1, 7), (13, 3, 3, 3)]]
+    a = fd.quantize_weights_sharded_bucketed(ws, 2, 8, 1, wire="codes")
+    b = fd.quantize_weights_sharded_bucketed(ws, 2, 8, 1, wire="fp32")
+    for (qa, ma), (qb, mb), w in zip(a, b, ws):
+        assert qa.shape == w.shape and torch.equal(ma.view(torch.int32), mb.view(torch.int32))
+        assert torch.equal(qa.view(torch.int32), qb.view(torch.int32))
+    c = fd.quantize_weights_sharded_bucketed(ws, 2, 8, 1, wire="codes", bucket_bytes=1 << 16)     # several buckets
+    for (qa, ma), (qc, mc) in zip(a, c):
+        assert torch.equal(qa.view(torch.int32), qc.view(torch.int32)) and torch.equal(ma, mc)
+
+
 @pytest.mark.gpu
 def test_hip_codec_short_row_geometries():
     """Per-channel tensors with short rows take the chunked kernel (k_rows_flat encode / decode modes): odd row

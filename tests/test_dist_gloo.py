@@ -308,8 +308,45 @@ def _bucket_weights():
 def _bucket_job(rank, world, bucket_bytes=None):
     from fp8q import dist as fd
     out = fd.quantize_weights_sharded_bucketed([torch.from_numpy(w) for w in _bucket_weights()], 2, 8, 1, ops=OracleOps,
+                                               bucket_bytes=bucket_bytes, wire="fp32")
+    return [(q.numpy(), mv.numpy()) for q, mv in out]
+
+
+def _bucket_job_codes(rank, world, bucket_bytes=None, ops=None):
+    """the default wire form at world > 1: 1-byte storage codes + fp32 ranges"""
+    from fp8q import dist as fd
+    out = fd.quantize_weights_sharded_bucketed([torch.from_numpy(w) for w in _bucket_weights()], 2, 8, 1, ops=ops or OracleOps,
                                                bucket_bytes=bucket_bytes)
     return [(q.numpy(), mv.numpy()) for q, mv in out]
+
+
+def _bucket_job_codes_small(rank, world):
+    return _bucket_job_codes(rank, world, bucket_bytes=200)       # several buckets, async all-gathers
+
+
+class MultiCodecOracleOps(OracleOps):
+    """+ the multi-tensor range+encode / decode entry points (what fp8q.ops has): two launches per bucket, one decode"""
+    calls = [0, 0]
+
+    @classmethod
+    def multi_minmax_encode(cls, items):
+        cls.calls[0] += 1
+        for x, mv_out, mbits, n_bits, sign_bits, out in items:
+            mv = OracleOps.minmax(x, True, want_maxval=True)[2]
+            mv_out.copy_(mv)
+            out.copy_(OracleOps.encode(x, mv, mbits, n_bits, sign_bits).view_as(out))
+
+    @classmethod
+    def multi_decode(cls, items):
+        cls.calls[1] += 1
+        for codes, mv, mbits, n_bits, sign_bits, out in items:
+            out.copy_(OracleOps.decode(codes.contiguous(), mv.contiguous(), mbits, n_bits, sign_bits).view_as(out))
+
+
+def _bucket_job_codes_multi(rank, world):
+    res = _bucket_job_codes(rank, world, ops=MultiCodecOracleOps)
+    assert MultiCodecOracleOps.calls == [1, 1], MultiCodecOracleOps.calls       # one bucket: one encode call, one decode call
+    return res
 
 
 class MultiOracleOps(OracleOps):
@@ -331,7 +368,7 @@ class MultiOracleOps(OracleOps):
 def _bucket_job_multi(rank, world):
     from fp8q import dist as fd
     out = fd.quantize_weights_sharded_bucketed([torch.from_numpy(w) for w in _bucket_weights()], 2, 8, 1, ops=MultiOracleOps,
-                                               bucket_bytes=600)
+                                               bucket_bytes=600, wire="fp32")
     assert MultiOracleOps.calls[0] == 3, MultiOracleOps.calls      # one call per bucket, not one per tensor
     return [(q.numpy(), mv.numpy()) for q, mv in out]
 
@@ -349,7 +386,8 @@ def test_bucketed_weight_quantization_one_all_gather():
     only rank 0 owns), or packed into several buckets whose all-gathers are launched asynchronously while the next
     bucket is quantized: every rank ends up with exactly the single-process quantized tensors and ranges."""
     ws = _bucket_weights()
-    for job in (_bucket_job, _bucket_job_small, _bucket_job_tiny, _bucket_job_multi):
+    for job in (_bucket_job, _bucket_job_small, _bucket_job_tiny, _bucket_job_multi, _bucket_job_codes, _bucket_job_codes_small,
+                _bucket_job_codes_multi):
         for res in run(job):
             for w, (q, mv) in zip(ws, res):
                 mn, mx = oracle.c_minmax(w, True)
@@ -457,6 +495,12 @@ def _w4_job(rank, world):
     qc, mvc, codes = fd.quantize_weight_sharded_codes(w3, 3, 8, 1, ops=OracleOps)
     buck = fd.quantize_weights_sharded_bucketed([torch.from_numpy(t) for t in _bucket_weights()], 2, 8, 1, ops=OracleOps,
                                                 bucket_bytes=600)
+    # the default above ships 1-byte codes (4 ranks: uneven partitions, ranks without channels); the fp32 wire form must
+    # give the same bits
+    buck32 = fd.quantize_weights_sharded_bucketed([torch.from_numpy(t) for t in _bucket_weights()], 2, 8, 1, ops=OracleOps,
+                                                  wire="fp32")
+    for (a, am), (b, bm) in zip(buck, buck32):
+        assert torch.equal(am, bm) and torch.equal(torch.isnan(a), torch.isnan(b)) and torch.equal(a[~torch.isnan(a)], b[~torch.isnan(b)])
     return (q.numpy(), mv.numpy(), q3.numpy(), mv3.numpy(), qc.numpy(), mvc.numpy(), codes.numpy(),
             [(a.numpy(), b.numpy()) for a, b in buck])
 
