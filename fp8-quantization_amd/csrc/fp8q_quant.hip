@@ -942,7 +942,12 @@ struct MultiArgs {
 // waves waiting 61 % of their cycles.  Neither memory latency, store drains, the table phase nor occupancy (1...3
 // chunks per block measured equal) is THE limit; the launch is short enough (3 chunks per block) that its fixed phases
 // (launch ramp, table staging, first load round trip, last compute + store drain) make up the gap to the copy.
-// Not pursued further: the launch replaces 21 launches (130 us from Python).
+// Round 5, the last structural attempt (profiles/r05_multi_stagger_ab.txt): blocks started out of phase -- block b waits
+// (b % 4) x s x 0.9 us before its first load, so that a quarter of the chip computes while another quarter loads -- measured
+// 19.96 / 21.7 / 23.6 / 25.8 / 28.3 us for s = 0 / 1 / 2 / 3 / 4 (rocprofv3, 170 launches each): every step of stagger is
+// simply added to the launch, nothing overlaps better.  The phases are not what separates this launch from the copy; with 3
+// chunks per block its fixed parts are (launch ramp, table staging, first round trip, last compute + store drain).  Closed.
+// The launch replaces 21 launches (130 us from Python).
 // MODE 0: K1 (fp32 -> fp32).  MODE 3 / 4 (round 5): the storage codes of N3 for many tensors at once -- encode (fp32 -> 1 byte,
 // x = values, y = codes) / decode (1 byte -> fp32, x = codes, y = values): what the bucketed all-gather of channel-sharded
 // weights packs into / unpacks from its send buffer in one launch each (fp8q_multi_minmax_encode_u8, fp8q_multi_decode_u8).
