@@ -216,15 +216,24 @@ class FP_MSE_Estimator(RangeEstimatorBase):
         if self.search_grid is None:
             assert self.mses is None
             if x.dtype == torch.float64:
+                # the reference multiplies the FLOAT64 maximum (mx.item(), a python float) by 0.1 / 1.2 and lets
+                # torch.linspace narrow the products: fl32(0.1 * mx64), which fl32(0.1 * fl32(mx64)) misses by an ulp half
+                # of the time.  float64 data is config 1's side road: build the grid the reference's way, on the host
                 mn, hi = _ops.minmax_f64(x, self.per_channel)
-                mx = torch.max(mn.abs(), hi.abs()).float()      # == float32 of the python float the reference multiplies
+                mx64 = torch.max(mn.abs(), hi.abs())
+                if self._dist_batch():
+                    import torch.distributed as dist
+                    dist.all_reduce(mx64, op=dist.ReduceOp.MAX, group=self._group())
+                self.search_grid = torch.stack([torch.linspace(0.1 * v, 1.2 * v, self.N_GRID) for v in mx64.cpu().tolist()],
+                                               1).contiguous().to(x.device)
+                mx = None
             elif not self._dist_batch():
                 # max|x| and the grid [111, C] (== torch.linspace per channel) in the abs-max launch itself
                 self.search_grid = _ops.minmax_linspace(x, self.per_channel, self.N_GRID)[3]
                 mx = None
             else:
                 _, _, mx = _ops.minmax(x, self.per_channel, want_maxval=True)
-            if self._dist_batch():                          # batch-sharded: the grid comes from the global max
+            if mx is not None and self._dist_batch():       # batch-sharded: the grid comes from the global max
                 import torch.distributed as dist
                 dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=self._group())
             if mx is not None:
@@ -237,7 +246,7 @@ class FP_MSE_Estimator(RangeEstimatorBase):
         if x.dtype == torch.float64:        # the reference adds a float64 mean into its float32 table (:346-347)
             inc = torch.zeros(mses.shape, dtype=torch.float64, device=mses.device)
             _ops.mse_grid_f64(x, self.per_channel, grid, mbit_list, q.n_bits, q.sign_bits, inc, reduce="mean")
-            mses += inc.float()
+            mses.copy_((mses.double() + inc).float())       # float32 += float64: ATen adds in float64, then rounds once
         else:
             _ops.mse_grid(x, self.per_channel, grid, mbit_list, q.n_bits, q.sign_bits, mses)
 

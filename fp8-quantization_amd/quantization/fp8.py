@@ -218,11 +218,20 @@ class FPQuantizer(QuantizerBase):
 
     @mantissa_bits.setter
     def mantissa_bits(self, value):
+        # (reached through __setattr__ below, which keeps nn.Module.__setattr__ away from this name: it would hand a
+        # Parameter to register_parameter -- refused, the class defines `mantissa_bits` -- and refuse a plain tensor while
+        # the width is a Parameter)
         params = self.__dict__.get("_parameters")
         if isinstance(value, nn.Parameter):
-            # (register_parameter would refuse: the class has an attribute of that name -- this property)
             params["mantissa_bits"] = value
             self.__dict__["_mbits_dev"], self.__dict__["_mbits_host"] = None, None
+            return
+        cur = params.get("mantissa_bits") if params is not None else None
+        if cur is not None and value is not None:
+            # the width is being learned (learn_mantissa_bits) and somebody assigns a value -- the MSE estimator's vote in
+            # estimate_ranges_train: keep the Parameter, replace its value
+            with torch.no_grad():
+                cur.copy_(torch.as_tensor(value, dtype=cur.dtype).reshape(cur.shape).to(cur.device))
             return
         if params is not None and "mantissa_bits" in params:
             del params["mantissa_bits"]
@@ -251,6 +260,9 @@ class FPQuantizer(QuantizerBase):
         # these ranges (the layers' quantized-weight cache) key on it instead of on tensor addresses
         if name in FPQuantizer._RANGE_ATTRS:
             object.__setattr__(self, "_range_epoch", getattr(self, "_range_epoch", 0) + 1)
+        if name == "mantissa_bits":
+            FPQuantizer.mantissa_bits.fset(self, value)
+            return
         super().__setattr__(name, value)
 
     # -- hot path ---------------------------------------------------------------------------
@@ -322,12 +334,8 @@ class FPQuantizer(QuantizerBase):
         """:253-255: the mantissa width becomes an nn.Parameter; quantize_to_fp8_ste_MM's backward then yields
         d/dmbits (see _FakeQuantSTE).  The forward still hands the kernel the width by value."""
         self.learning_mantissa_bits = True
-        p = nn.Parameter(self.mantissa_bits.detach().clone().float())
-        # (not `self.mantissa_bits = p`: nn.Module.__setattr__ hands Parameters to register_parameter, which refuses a
-        # name the class already defines -- the `mantissa_bits` property)
-        self._parameters["mantissa_bits"] = p
-        self.__dict__["_mbits_dev"] = self.__dict__["_mbits_host"] = None
-        object.__setattr__(self, "_range_epoch", getattr(self, "_range_epoch", 0) + 1)
+        # on the quantizer's device (maxval's): a host Parameter inside a CUDA model would stay behind until the next .to()
+        self.mantissa_bits = nn.Parameter(self.mantissa_bits.detach().clone().float().to(self.maxval.device))
 
     def fix_ranges(self):
         for name in ("maxval", "mantissa_bits"):

@@ -17,6 +17,7 @@ Fixture files:
   g3_estimators.npz  Current/All/RunningMinMax (range_estimators.py:56-125) + set_quant_range
   g3b_signed_zero.npz the same estimators on rows that mix -0.0 and +0.0 (pins the signed-zero contract of min / max)
   g4_mse.npz         FP_MSE_Estimator         (range_estimators.py:285-369)
+  g4c_mse_f64.npz    the same estimator on float64 data (grid from the float64 maximum, float64 means into the float32 table)
   g5_quant_error.npz compute_quant_error.py (config 1) at 200 k samples + closed-form integrals
   g6_manager.npz     QuantizationManager.forward state machine (quantization_manager.py:114-122)
   g7_tinycnn.npz     quantize_model on a tiny CNN (autoquant_utils.py:292-381), config-3 settings
@@ -249,6 +250,26 @@ def make_g4():
     out["relu_sign_bits"] = np.array(q.sign_bits)
     np.savez_compressed(os.path.join(OUT, "g4_mse.npz"), **out)
     print("g4 ok")
+
+
+def make_g4c():
+    """FP_MSE_Estimator on FLOAT64 data (ATen's type promotion: the search grid from a float64 maximum, float64 means
+    added into the float32 table), two accumulating batches, per tensor and per channel"""
+    out = {}
+    torch.manual_seed(4)
+    for name, shape, pc, incl in (("pt", (2, 8, 14, 14), False, True), ("pc", (12, 3, 3, 3), True, False)):
+        q = FPQuantizer(n_bits=8, per_channel=pc, mantissa_bits=3, maxval=None, set_maxval=True, mse_include_mantissa_bits=incl)
+        est = RangeEstimators.MSE.cls(per_channel=pc, quantizer=q)
+        xs = [torch.randn(*shape, dtype=torch.float64) * 0.37, torch.randn(*shape, dtype=torch.float64) * 0.21]
+        for b, x in enumerate(xs):
+            mn, mx = est(x)
+            out[f"{name}_x{b}"] = x.numpy()
+            out[f"{name}_mses{b}"] = est.mses.numpy().copy()
+            out[f"{name}_max{b}"] = mx.numpy().copy()
+            out[f"{name}_mbits{b}"] = np.array(float(q.mantissa_bits))
+        out[f"{name}_grid"] = est.search_grid.numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "g4c_mse_f64.npz"), **out)
+    print("g4c ok")
 
 
 def make_g6():
@@ -695,6 +716,7 @@ if __name__ == "__main__":
     make_g3()
     make_g3b()
     make_g4()
+    make_g4c()
     make_g5()
     make_g6()
     make_g7()

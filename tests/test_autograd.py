@@ -77,6 +77,12 @@ def test_learn_maxval_and_mantissa_bits_get_gradients(golden_dir):
         q2(x).sum().backward()
     assert q2.mantissa_bits.grad is not None and torch.isfinite(q2.mantissa_bits.grad).all()
     assert float(q2.mantissa_bits.grad.abs().sum()) > 0
+    # assigning a value while the width is being learned (the MSE estimator's vote in estimate_ranges_train) keeps the
+    # Parameter and replaces its value (nn.Module.__setattr__ alone would raise TypeError here)
+    q2.mantissa_bits = torch.Tensor([4.0])
+    assert isinstance(q2.mantissa_bits, torch.nn.Parameter) and float(q2.mantissa_bits) == 4.0
+    assert q2.mantissa_bits.device == q2.maxval.device
+    q2.mantissa_bits = torch.Tensor([3.0])
     q2.fix_ranges()                                    # back to a plain tensor, as parameter_to_fixed does
     assert not isinstance(q2.mantissa_bits, torch.nn.Parameter) and float(q2.mantissa_bits) == 3.0
     assert "mantissa_bits" not in dict(q2.named_parameters())

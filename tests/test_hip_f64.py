@@ -130,3 +130,26 @@ def test_line_search_losses_equal_the_references(g5, name):
         got = out.cpu().numpy()[0, :, 0]
         np.testing.assert_allclose(got, loss[1:], rtol=1e-12)
         assert int(np.argmin(got)) + 1 == int(np.argmin(loss))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,pc,incl", [("pt", False, True), ("pc", True, False)])
+def test_fp_mse_estimator_on_float64_data_vs_reference(golden_dir, name, pc, incl):
+    """g4c: FP_MSE_Estimator fed float64 tensors.  The search grid is the reference's bit for bit (products of the FLOAT64
+    maximum, narrowed by torch.linspace), the accumulated table follows to 1e-6 (float64 means added into the float32 table
+    in float64, as ATen's in-place float32 += float64 does), the same mantissa width and maxval come out."""
+    import os
+    from quantization.quantizers.fp8_quantizer import FPQuantizer
+    from quantization.range_estimators import FP_MSE_Estimator
+    g = np.load(os.path.join(golden_dir, "g4c_mse_f64.npz"))
+    q = FPQuantizer(n_bits=8, per_channel=pc, mantissa_bits=3, maxval=None, set_maxval=True, mse_include_mantissa_bits=incl)
+    est = FP_MSE_Estimator(per_channel=pc, quantizer=q)
+    for b in range(2):
+        x = torch.from_numpy(g[f"{name}_x{b}"]).cuda()
+        assert x.dtype == torch.float64
+        mn, mx = est(x)
+        if b == 0:
+            assert np.array_equal(est.search_grid.cpu().numpy().view(np.int32), g[f"{name}_grid"].view(np.int32))
+        np.testing.assert_allclose(est.mses.cpu().numpy(), g[f"{name}_mses{b}"], rtol=1e-6)
+        assert float(q.mantissa_bits) == float(g[f"{name}_mbits{b}"])
+        np.testing.assert_array_equal(mx.cpu().numpy().reshape(-1), g[f"{name}_max{b}"].reshape(-1))
