@@ -305,10 +305,10 @@ def extras(ops, dev):
         except Exception as e:   # noqa: BLE001 -- informational entry only
             out["resnet18_all_21_weight_tensors_plan_hipgraph_e5m2"] = {"error": repr(e)[:200]}
     # K4: the grid search of FP_MSE_Estimator (range_estimators.py:337-347) on a MobileNetV2 activation, 111 candidate
-    # ranges x {1, 6} mantissa widths in one pass (the reference: 111 * |m| full quantizer passes).  ALU-bound: the
-    # inner loop issues 7 VALU instructions per candidate-element (k_mse_row: 1 v_med3 + 3 integer + 3 packed fp32
-    # that process two elements each = 10 lane-operations); peak issue rate 256 CU x 4 SIMD x 16 lanes x 2.4 GHz =
-    # 39.3 T instruction-lanes/s (78.6 T lane-operations/s if everything were packed).
+    # ranges x {1, 6} mantissa widths in one pass over x (the reference: 111 * |m| full quantizer passes).  Round 5: a
+    # tensor of this size takes the interval-histogram route (csrc/fp8q_mse_hist.hip: ONE hand-written partition of the
+    # keys at the copy rate + integer moments per interval; ~12 B of HBM traffic per element whatever the number of
+    # candidates) -- HBM / LDS-atomic bound, no longer the VALU-bound lane-per-element loop (523 us / 3.1 ms in round 4).
     a4 = x[: 64 * 32 * 112 * 112].view(64, 32, 112, 112)
     mx4 = float(a4.abs().max())
     grid = torch.linspace(0.1 * mx4, 1.2 * mx4, 111, device=dev).view(111, 1).contiguous()
@@ -319,8 +319,9 @@ def extras(ops, dev):
         ce = a4.numel() * 111 * len(mb)
         out[f"k4_mse_111cand_{len(mb)}m_64x32x112x112"] = dict(
             us=round(med * 1e6, 1), t_cand_elem_s=round(ce / med / 1e12, 3), hbm_gb_s=round(a4.numel() * 4 / med / 1e9, 1),
-            bound="valu (4-7 issue slots per candidate-element by path: bit-level rounding with / without clamp, "
-                  "float magic-number rounding with / without clamp; counters under profiles/)")
+            algorithmic_bytes_per_element=12, frac_of_8tbs_at_12B=round(a4.numel() * 12 / med / 8e12, 3),
+            route="interval histogram: k_stage1 (borders + key histogram) -> k_tab_scan -> k_border_sort -> k_mse_plan -> "
+                  "k_part_scatter -> k_moments -> k_iv_scan_super/top -> k_mse_eval; per-kernel times: profiles/r05_mse_timeline.txt")
     del x, y
     return out
 

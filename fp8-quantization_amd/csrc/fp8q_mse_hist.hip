@@ -497,18 +497,21 @@ __device__ __forceinline__ uint32_t slice_len(uint32_t nb, int slice_min)
     return s;
 }
 
-__global__ void __launch_bounds__(1024)
-k_mse_plan(const uint32_t *__restrict__ hist, const uint32_t *__restrict__ bhist, const uint32_t *__restrict__ kmax, int nkmax,
-           uint32_t *__restrict__ koff, uint32_t *__restrict__ boff, Unit *__restrict__ units, uint32_t *__restrict__ nunits,
-           uint32_t *__restrict__ maxkey, uint32_t *__restrict__ blist, uint32_t units_max, int bcap, int slice_min)
+// (a device function: it runs as one more workgroup of the border-sort launch -- both need only the column totals)
+__device__ __forceinline__ void plan_body(uint32_t *s_raw, const uint32_t *__restrict__ hist, const uint32_t *__restrict__ bhist,
+                                          const uint32_t *__restrict__ kmax, int nkmax, uint32_t *__restrict__ koff,
+                                          uint32_t *__restrict__ boff, Unit *__restrict__ units, uint32_t *__restrict__ nunits,
+                                          uint32_t *__restrict__ maxkey, uint32_t units_max, int bcap, int slice_min)
 {
-    __shared__ uint32_t s_w[16];
-    __shared__ uint32_t s_uoff[kHBuckets + 1], s_ck[kHBuckets], s_cb[kHBuckets], s_ko[kHBuckets], s_bo[kHBuckets], s_li[kHBuckets];
+    uint32_t *s_uoff = s_raw;                      // kHBuckets + 1 (+ 3 pad)
+    uint32_t *s_ck = s_uoff + kHBuckets + 4, *s_cb = s_ck + kHBuckets, *s_ko = s_cb + kHBuckets, *s_bo = s_ko + kHBuckets;
+    uint32_t *s_li = s_bo + kHBuckets, *s_w = s_li + kHBuckets;       // s_w: 8
     const int tid = threadIdx.x;
-    uint32_t ck[2], cb[2], cu[2], sk = 0, sb = 0, su = 0, sl_ = 0;
+    constexpr int kPer = kHBuckets / kBlock;       // 8 consecutive buckets per thread
+    uint32_t ck[kPer], cb[kPer], cu[kPer], sk = 0, sb = 0, su = 0, sl_ = 0;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int b = tid * 2 + q;
+    for (int q = 0; q < kPer; ++q) {
+        const int b = tid * kPer + q;
         ck[q] = hist[b];
         cb[q] = bhist[b];
         const uint32_t nch = cb[q] ? (cb[q] + bcap - 1) / bcap : 1u;
@@ -520,13 +523,13 @@ k_mse_plan(const uint32_t *__restrict__ hist, const uint32_t *__restrict__ bhist
         sl_ += cb[q] ? 1u : 0u;
     }
     uint32_t tk, tb, tu, tl;
-    uint32_t ek = block_excl_scan<1024>(sk, s_w, tk);
-    uint32_t eb = block_excl_scan<1024>(sb, s_w, tb);
-    uint32_t eu = block_excl_scan<1024>(su, s_w, tu);
-    uint32_t el = block_excl_scan<1024>(sl_, s_w, tl);
+    uint32_t ek = block_excl_scan<kBlock>(sk, s_w, tk);
+    uint32_t eb = block_excl_scan<kBlock>(sb, s_w, tb);
+    uint32_t eu = block_excl_scan<kBlock>(su, s_w, tu);
+    uint32_t el = block_excl_scan<kBlock>(sl_, s_w, tl);
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int b = tid * 2 + q;
+    for (int q = 0; q < kPer; ++q) {
+        const int b = tid * kPer + q;
         koff[b] = ek;
         boff[b] = eb;
         s_uoff[b] = eu;
@@ -535,12 +538,12 @@ k_mse_plan(const uint32_t *__restrict__ hist, const uint32_t *__restrict__ bhist
         s_ko[b] = ek;
         s_bo[b] = eb;
         s_li[b] = el;
-        if (cb[q]) blist[el++] = (uint32_t)b;
+        el += cb[q] ? 1u : 0u;
         ek += ck[q];
         eb += cb[q];
         eu += cu[q];
     }
-    if (tid == 1023) {
+    if (tid == kBlock - 1) {
         koff[kHBuckets] = tk;
         boff[kHBuckets] = tb;
         s_uoff[kHBuckets] = tu;
@@ -551,7 +554,7 @@ k_mse_plan(const uint32_t *__restrict__ hist, const uint32_t *__restrict__ bhist
     // the units, all threads: unit u belongs to the last bucket whose first unit is <= u; inside a bucket the chunks of one
     // key slice are neighbours (they read the same keys)
     const uint32_t nu = tu < units_max ? tu : units_max;
-    for (uint32_t u = tid; u < nu; u += 1024) {
+    for (uint32_t u = tid; u < nu; u += kBlock) {
         int lo = 0, hi = kHBuckets;                    // s_uoff[lo] <= u < s_uoff[hi]
         while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
@@ -566,15 +569,13 @@ k_mse_plan(const uint32_t *__restrict__ hist, const uint32_t *__restrict__ bhist
     }
     // the largest key of the row (non-finite data): max over the partition workgroups
     uint32_t mk = 0u;
-    for (int i = tid; i < nkmax; i += 1024) mk = max(mk, kmax[i]);
+    for (int i = tid; i < nkmax; i += kBlock) mk = max(mk, kmax[i]);
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) mk = max(mk, (uint32_t)__shfl_xor((int)mk, off, 64));
+    __syncthreads();
     if ((tid & 63) == 0) s_w[tid >> 6] = mk;
     __syncthreads();
-    if (tid == 0) {
-        for (int w = 1; w < 16; ++w) mk = max(mk, s_w[w]);
-        maxkey[0] = mk;
-    }
+    if (tid == 0) maxkey[0] = max(max(s_w[0], s_w[1]), max(s_w[2], s_w[3]));
 }
 
 // ---- 3. sort the borders of each bucket ---------------------------------------------------------------------------------
@@ -745,15 +746,23 @@ __device__ __forceinline__ void border_sort_body(int b, uint32_t *s_raw, const f
 }
 
 // the border sort: one workgroup per coarse bucket (most have no borders and leave at once); needs only the column totals
-// `bhist`, so it runs BEFORE the plan and never next to the key scatter (there, with the memory system saturated, its chains
-// of dependent loads took 35 us per bucket)
+// `bhist`, so it runs BEFORE the key scatter and never next to it (there, with the memory system saturated, its chains of
+// dependent loads took 35 us per bucket).  The plan -- one more workgroup -- needs the same totals: same launch.
+constexpr int kSortRaw = 2 * kSortLds + kSortLds / 2 + 2 * (kHSub + 2) + 16;      // words of LDS
+static_assert(kSortRaw >= 6 * kHBuckets + 16, "the plan's tables fit in the sort's LDS");
+
 __global__ void __launch_bounds__(kBlock)
-k_border_sort(const float *__restrict__ bt, const uint32_t *__restrict__ btab, const uint32_t *__restrict__ bhist, int n_pairs,
-              int stride, uint32_t *__restrict__ sb, uint32_t *__restrict__ rank, uint32_t *__restrict__ gtab,
-              uint64_t *__restrict__ pairs)
+k_border_sort_plan(const float *__restrict__ bt, const uint32_t *__restrict__ btab, const uint32_t *__restrict__ bhist, int n_pairs,
+                   int stride, uint32_t *__restrict__ sb, uint32_t *__restrict__ rank, uint32_t *__restrict__ gtab,
+                   uint64_t *__restrict__ pairs, const uint32_t *__restrict__ hist, const uint32_t *__restrict__ kmax, int nkmax,
+                   uint32_t *__restrict__ koff, uint32_t *__restrict__ boff, Unit *__restrict__ units, uint32_t *__restrict__ nunits,
+                   uint32_t *__restrict__ maxkey, uint32_t units_max, int bcap, int slice_min)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t s_raw[2 * kSortLds + kSortLds / 2 + 2 * (kHSub + 2) + 16];
-    border_sort_body((int)blockIdx.x, s_raw, bt, btab, bhist, n_pairs, stride, sb, rank, gtab, pairs);
+    __shared__ __attribute__((aligned(16))) uint32_t s_raw[kSortRaw];
+    if (blockIdx.x == 0)
+        plan_body(s_raw, hist, bhist, kmax, nkmax, koff, boff, units, nunits, maxkey, units_max, bcap, slice_min);
+    else
+        border_sort_body((int)blockIdx.x - 1, s_raw, bt, btab, bhist, n_pairs, stride, sb, rank, gtab, pairs);
 }
 
 __global__ void __launch_bounds__(kBlock)
@@ -889,8 +898,8 @@ k_iv_scan_super(const uint32_t *__restrict__ boff, const uint32_t *__restrict__ 
                 DD *__restrict__ p1, DD *__restrict__ p2, uint32_t *__restrict__ pn, DD *__restrict__ t1, DD *__restrict__ t2,
                 uint32_t *__restrict__ tn)
 {
-    __shared__ DD s1[kSuper], s2[kSuper];
-    __shared__ uint32_t sn[kSuper];
+    __shared__ DD s1[2 * (kSuper / 64)], s2[2 * (kSuper / 64)];     // wave totals, then their inclusive scan
+    __shared__ uint32_t sn[2 * (kSuper / 64)];
     __shared__ uint32_t s_first[kHBuckets];       // first interval id of every bucket
     const int tid = threadIdx.x;
     const int64_t i = (int64_t)blockIdx.x * kSuper + tid;
@@ -918,34 +927,73 @@ k_iv_scan_super(const uint32_t *__restrict__ boff, const uint32_t *__restrict__ 
         const DD cross = two_prod(2.0 * A, (double)D);             // D < 2^51: exact as a double
         v2 = dd_scale2(dd_add(dd_add(two_prod(nd, A * A), cross), d2), 2 * ex);
     }
-    s1[tid] = v1;
-    s2[tid] = v2;
-    sn[tid] = vn;
-    __syncthreads();
-    for (int off = 1; off < kSuper; off <<= 1) {   // Hillis-Steele inclusive scan
-        DD a1 = zero, a2 = zero;
-        uint32_t an = 0u;
-        if (tid >= off) {
-            a1 = s1[tid - off];
-            a2 = s2[tid - off];
-            an = sn[tid - off];
+    // inclusive scan inside every wave (shuffles), the 16 wave totals scanned by the first wave, stitched: 3 barriers instead
+    // of the 20 of a Hillis-Steele scan over LDS (the kernel took 10-12 us for <= 170 workgroups); fixed association
+    const int lane = tid & 63, wave = tid >> 6;
+    DD i1 = v1, i2 = v2;
+    uint32_t in = vn;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const DD a1 = dd_shfl_up(i1, off), a2 = dd_shfl_up(i2, off);   // (every lane takes part in the shuffle)
+        const uint32_t an = __shfl_up(in, off, 64);
+        if (lane >= off) {
+            i1 = dd_add(i1, a1);
+            i2 = dd_add(i2, a2);
+            in += an;
         }
-        __syncthreads();
-        s1[tid] = dd_add(s1[tid], a1);
-        s2[tid] = dd_add(s2[tid], a2);
-        sn[tid] += an;
-        __syncthreads();
     }
-    if (i <= ni) {                                  // exclusive, within the superblock (entry ni: everything)
-        const int j = tid ? tid - 1 : 0;            // (field-wise selects: a struct temporary went to scratch)
-        p1[i] = DD{tid ? s1[j].hi : 0.0, tid ? s1[j].lo : 0.0};
-        p2[i] = DD{tid ? s2[j].hi : 0.0, tid ? s2[j].lo : 0.0};
-        pn[i] = tid ? sn[j] : 0u;
+    if (lane == 63) {
+        s1[wave] = i1;
+        s2[wave] = i2;
+        sn[wave] = in;
     }
-    if (tid == kSuper - 1) {
-        t1[blockIdx.x] = s1[tid];
-        t2[blockIdx.x] = s2[tid];
-        tn[blockIdx.x] = sn[tid];
+    __syncthreads();
+    if (wave == 0) {
+        constexpr int kW = kSuper / 64;
+        DD w1 = lane < kW ? s1[lane] : zero, w2 = lane < kW ? s2[lane] : zero;
+        uint32_t wn = lane < kW ? sn[lane] : 0u;
+#pragma unroll
+        for (int off = 1; off < kW; off <<= 1) {
+            const DD a1 = dd_shfl_up(w1, off), a2 = dd_shfl_up(w2, off);
+            const uint32_t an = __shfl_up(wn, off, 64);
+            if (lane >= off) {
+                w1 = dd_add(w1, a1);
+                w2 = dd_add(w2, a2);
+                wn += an;
+            }
+        }
+        if (lane < kW) {              // inclusive totals up to and including wave `lane`
+            s1[kW + lane] = w1;
+            s2[kW + lane] = w2;
+            sn[kW + lane] = wn;
+        }
+    }
+    __syncthreads();
+    {
+        constexpr int kW = kSuper / 64;
+        // exclusive prefix of this thread = (waves before) + (lanes before in this wave)
+        DD e1 = dd_shfl_up(i1, 1), e2 = dd_shfl_up(i2, 1);
+        uint32_t en = __shfl_up(in, 1, 64);
+        if (lane == 0) {
+            e1 = zero;
+            e2 = zero;
+            en = 0u;
+        }
+        if (wave > 0) {
+            e1 = dd_add(s1[kW + wave - 1], e1);
+            e2 = dd_add(s2[kW + wave - 1], e2);
+            en += sn[kW + wave - 1];
+        }
+        if (i <= ni) {                                  // exclusive, within the superblock (entry ni: everything)
+            p1[i] = e1;
+            p2[i] = e2;
+            pn[i] = en;
+        }
+        if (tid == kSuper - 1) {                        // the superblock's totals
+            t1[blockIdx.x] = s1[2 * kW - 1];
+            t2[blockIdx.x] = s2[2 * kW - 1];
+            tn[blockIdx.x] = sn[2 * kW - 1];
+        }
     }
 }
 
@@ -1086,7 +1134,7 @@ int hist_slice_min() { static const int v = env_int("FP8Q_MSE_SLICE", 16384, 102
 struct HistLayout {
     size_t keys, zero0, zero_bytes;           // [zero0, zero0 + zero_bytes): cleared in every call (k_tab_scan)
     size_t gn, gd, gd2lo, gd2hi;
-    size_t hist, bhist, ktab, btab, kmax, maxkey, nunits, blist, gtab;
+    size_t hist, bhist, ktab, btab, kmax, maxkey, nunits, gtab;
     size_t koff, boff, units, bt, bq, rank, cflag, pairs, sb, p1, p2, pn, t1, t2, tn;
     size_t total;
     int64_t nbord, ni, nsb;
@@ -1125,7 +1173,6 @@ HistLayout hist_layout(int64_t n, int64_t n_pairs, int stride, int bcap, int sli
     L.kmax = take(kPartWgs * 4);
     L.maxkey = take(4);
     L.nunits = take(8);
-    L.blist = take(kHBuckets * 4);
     // sub-bin tables: one per bucket that has borders -- at most min(2048, borders) of them
     L.gtab = take((size_t)(L.nbord < kHBuckets ? L.nbord : kHBuckets) * (kHSub + 1) * 4);
     L.koff = take((kHBuckets + 1) * 4);
@@ -1190,7 +1237,7 @@ int fp8q_mse_hist_launch(const float *x, int64_t n, const float *grid, int64_t n
     uint32_t *keys = (uint32_t *)at(L.keys), *hist = (uint32_t *)at(L.hist), *bhist = (uint32_t *)at(L.bhist);
     uint32_t *ktab = (uint32_t *)at(L.ktab), *btab = (uint32_t *)at(L.btab), *kmax = (uint32_t *)at(L.kmax);
     uint32_t *maxkey = (uint32_t *)at(L.maxkey), *nunits = (uint32_t *)at(L.nunits), *gn = (uint32_t *)at(L.gn);
-    uint32_t *blist = (uint32_t *)at(L.blist), *gtab = (uint32_t *)at(L.gtab);
+    uint32_t *gtab = (uint32_t *)at(L.gtab);
     unsigned long long *gd = (unsigned long long *)at(L.gd), *gd2lo = (unsigned long long *)at(L.gd2lo),
                        *gd2hi = (unsigned long long *)at(L.gd2hi);
     uint32_t *koff = (uint32_t *)at(L.koff), *boff = (uint32_t *)at(L.boff);
@@ -1211,10 +1258,8 @@ int fp8q_mse_hist_launch(const float *x, int64_t n, const float *grid, int64_t n
     hipLaunchKernelGGL(k_tab_scan, dim3(kHBuckets / 32, 2), dim3(1024), 0, st, ktab, pwgs, hist, btab, (int)n_pairs, bhist,
                        (uint4 *)at(L.zero0), (int64_t)(L.zero_bytes / 16));
     if (int rc = launch_rc()) return rc;
-    hipLaunchKernelGGL(k_border_sort, dim3(kHBuckets), dim3(kBlock), 0, st, bt, btab, bhist, (int)n_pairs, a.stride, sb, rank, gtab, pairs);
-    if (int rc = launch_rc()) return rc;
-    hipLaunchKernelGGL(k_mse_plan, dim3(1), dim3(1024), 0, st, hist, bhist, kmax, pwgs, koff, boff, units, nunits, maxkey, blist,
-                       L.units_max, bcap, slice_min);
+    hipLaunchKernelGGL(k_border_sort_plan, dim3(kHBuckets + 1), dim3(kBlock), 0, st, bt, btab, bhist, (int)n_pairs, a.stride, sb, rank,
+                       gtab, pairs, hist, kmax, pwgs, koff, boff, units, nunits, maxkey, L.units_max, bcap, slice_min);
     if (int rc = launch_rc()) return rc;
     hipLaunchKernelGGL(k_part_scatter, dim3((unsigned)pwgs), dim3(kBlock), 0, st, xb, n, ntiles, tpw, koff, ktab, keys);
     if (int rc = launch_rc()) return rc;

@@ -389,6 +389,19 @@ def check_workspaces(clear=True):
         check(failures[0], f"fp8q_minmax_workspace_check ({len(failures)} of {len(todo)} workspaces failed)")
 
 
+def release_workspaces(keep_bytes=1 << 24):
+    """Drop the scratch buffers larger than `keep_bytes` (the MSE search's partitioned keys: 4 B per element of the largest
+    activation it has seen, ~300 MB for MobileNetV2 at batch 64) -- they are re-allocated on demand.  The zeroed min/max
+    workspaces stay (small, and their headers carry state).  QuantizedModel.fix_ranges() calls this once calibration is
+    over; callers that drive fp8q.ops directly may do the same.  Returns the bytes released."""
+    freed = 0
+    for key, ws in list(_ws_cache.items()):
+        if not key[2] and key[3] is None and ws.numel() > keep_bytes:
+            freed += ws.numel()
+            del _ws_cache[key]
+    return freed
+
+
 def minmax(x, per_channel, cur_min=None, cur_max=None, mode=FOLD_CURRENT, momentum=0.9,
            want_maxval=False, packed=None):
     """K2/K3(/K5): batch min/max folded into the running estimate (range_estimators.py:61-125).

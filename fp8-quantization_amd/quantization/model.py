@@ -315,6 +315,7 @@ class QuantizedModel(nn.Module):
         # launches could not report (a reducer block that timed out -> NaN range; a dirty workspace)
         import fp8q
         fp8q.ops.check_workspaces()
+        fp8q.ops.release_workspaces()        # the MSE search's scratch (4 B per element of the largest activation): not needed again
         self.prequantize_weights()
 
     def prequantize_weights(self):
