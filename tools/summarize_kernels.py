@@ -136,12 +136,16 @@ stats("mse", "python tools/mb_mse.py")
 stats("k3", "python tools/mb_k3.py")
 stats("staged", "python tools/mb_staged.py")
 
-mse = counters(["mse_pmc", "mse_pmc2"], "mse")
+mse = counters(["mse_pmc", "mse_pmc2", "mse_pmc3", "mse_pmc4"], "mse")
 if mse:
-    out = {"source": "rocprofv3 --pmc {SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE} and "
-                     "{SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_WAIT_INST_LDS} (separate passes) -- python "
-                     "tools/mb_mse.py: means over all launches of the script ([64,32,112,112] x 111 candidates with 1, 1 and 6 "
-                     "mantissa widths for k_mse_row; [512,512,3,3] per channel for k_mse_grid)",
+    out = {"source": "rocprofv3 --pmc {SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE}, "
+                     "{SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS}, {FETCH_SIZE}, {WRITE_SIZE} (four separate "
+                     "passes) -- python tools/mb_mse_one.py 1: the interval-histogram route of K4 on [64,32,112,112] x 111 candidates "
+                     "(E4M3), three launches of the whole chain; means per launch of each kernel",
+           "traffic": "FETCH_SIZE / WRITE_SIZE are in KB; FETCH_SIZE x 1024 x 2 on gfx950 for 16-B/lane coalesced streams "
+                      "(MI355X_MICROARCH.md HBM section), WRITE_SIZE x 1024.  Algorithmic bytes of the chain: 4 B/element read by the key "
+                      "histogram (k_stage1), 4 + 4 B/element by the scatter (k_part_scatter), 4 B/element read by k_moments = 16 B per "
+                      "nonzero element, 12 on the wire when the second read of x still sits in the Infinity Cache",
            "how_to_read": "SQ_INSTS_VALU = wave-level VALU instructions per launch (x64 lanes = lane-instructions; a v_pk_* "
                           "counts once and does two elements); VALU issue utilisation = SQ_ACTIVE_INST_VALU * 4 / "
                           "(GRBM_GUI_ACTIVE * 1024 SIMDs) if the counter ticks once per issued wave-instruction",
