@@ -678,7 +678,7 @@ int fp8q_mse_hist_launch(const float *x, int64_t n, const float *grid, int64_t n
 
 // FP8Q_MSE_HIST: 1 (default) = long per-tensor rows of a signed format of <= 8 bits go through the interval-histogram
 // evaluation; 0 = never (the lane-per-element kernel everywhere); 2 = same routing with every candidate evaluated element by
-// element (the self-check of the cell logic the tests use)
+// element (the self-check of the cell logic the tests use); 3 = the route for every per-tensor row of >= 2^16 elements (tuning)
 static int mse_hist_mode()
 {
     static const int v = [] {
@@ -689,15 +689,18 @@ static int mse_hist_mode()
 }
 
 // The route's cost does not depend on the data: ~55 us of small launches + ~0.1 us per (width, candidate) pair for the borders
-// + ~4.3 ps per element (partition at the copy rate + the moments); k_mse_row costs ~25 us + ~0.25 ps per (element, pair)
-// (0.19 ps before it watched for near-ties).  (MI355X, tools/mb_mse_sizes.py: 111 pairs break even at ~1.7 M elements, 666
-// pairs at ~0.6 M; profiles/r05_mse_sizes.txt.)
+// + ~4.3 ps per element (partition at the copy rate + the moments); k_mse_row costs ~40 us + ~0.26 ps per (element, pair)
+// on activation-like data (0.19 ps before it watched for near-ties; ReLU6 outputs, whose many elements at the clipping
+// value share every near-tie, are its worst case and the histogram's best).  Fitted on MobileNetV2's 19 activation shapes at
+// batch 64 (tools/mb_mse_c4.py, profiles/r05_mse_c4_shapes.txt): 111 pairs break even at ~1 M elements, 666 at ~0.5 M.
 // Which route a row takes depends on its shape only, so a tensor is evaluated the same way on every call.
 static bool mse_use_hist_shape(int64_t C, int64_t inner, int64_t n_cand, int n_m)
 {
-    if (mse_hist_mode() == 0 || C != 1 || inner < (1 << 18) || inner >= (1ll << 31)) return false;
+    if (mse_hist_mode() == 0 || C != 1 || inner >= (1ll << 31)) return false;
+    if (mse_hist_mode() == 3) return inner >= (1 << 16);
+    if (inner < (1 << 18)) return false;
     const double pairs = (double)(n_m * n_cand);
-    const double row = 25e-6 + (double)inner * pairs * 0.25e-12;
+    const double row = 40e-6 + (double)inner * pairs * 0.26e-12;
     const double hist = 55e-6 + pairs * 0.095e-6 + (double)inner * 4.3e-12;
     return row > hist;
 }
