@@ -44,6 +44,7 @@ constexpr int kPartTile = 8192;                     // keys per partition tile (
 constexpr int kHistMaxM = 8;
 constexpr int kStrideBound = 260;                   // cells of one candidate of a signed format of <= 8 bits: (2^E + 1) 2^M + 2 <= 258
 constexpr int kSuper = 1024;                        // intervals per scan superblock
+constexpr int kTopLds = 512;                        // superblock totals that k_mse_eval scans for itself in LDS
 constexpr int kSortLds = 4096;                      // borders of one bucket sorted in LDS (more: a bitonic network on global memory)
 constexpr int kPartLds = 4 * (2 * kHBuckets + kPartTile + 4);   // bytes of LDS of a scatter workgroup: 49168 (3 per CU)
 
@@ -1045,11 +1046,13 @@ __global__ void __launch_bounds__(kBlock)
 k_mse_eval(const float *__restrict__ x, const float *__restrict__ grid, const float *__restrict__ bt, const float *__restrict__ bq,
            const uint32_t *__restrict__ rank, const int *__restrict__ cflag, const uint32_t *__restrict__ maxkey,
            const DD *__restrict__ p1, const DD *__restrict__ p2, const uint32_t *__restrict__ pn, const DD *__restrict__ t1,
-           const DD *__restrict__ t2, const uint32_t *__restrict__ tn, int64_t ni, float *__restrict__ mses, HistArgs a,
+           const DD *__restrict__ t2, const uint32_t *__restrict__ tn, int64_t ni, int nsb, float *__restrict__ mses, HistArgs a,
            double inv_inner)
 {
     __shared__ double s_red[kBlock];
     __shared__ float s_scale[kLutMax];
+    __shared__ DD s_t1[kTopLds], s_t2[kTopLds], s_w1[kBlock / 64], s_w2[kBlock / 64];
+    __shared__ uint32_t s_tn[kTopLds], s_wn[kBlock / 64];
     const int tid = threadIdx.x;
     const int j = blockIdx.x, m = j / a.n_cand;
     float *out = mses + j;
@@ -1084,6 +1087,68 @@ k_mse_eval(const float *__restrict__ x, const float *__restrict__ grid, const fl
             acc += (double)(d * d);
         }
     } else {
+        // exclusive prefix of the superblock totals, made by every workgroup for itself in LDS (<= kTopLds superblocks: a
+        // separate one-wave launch for a few dozen entries cost 4.6 us on the device and a launch on the host; beyond
+        // that k_iv_scan_top has run and t1 / t2 / tn already hold the prefixes)
+        const DD *q1 = t1, *q2 = t2;
+        const uint32_t *qn = tn;
+        if (nsb <= kTopLds) {
+            const DD zero{0.0, 0.0};
+            const int lane = tid & 63, wave = tid >> 6;
+            DD carry1 = zero, carry2 = zero;
+            uint32_t carryn = 0u;
+            for (int base = 0; base < nsb; base += kBlock) {           // (one trip for up to 256 superblocks)
+                const int i = base + tid;
+                DD v1 = i < nsb ? t1[i] : zero, v2 = i < nsb ? t2[i] : zero;
+                uint32_t vn = i < nsb ? tn[i] : 0u;
+                DD i1 = v1, i2 = v2;
+                uint32_t in = vn;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const DD a1 = dd_shfl_up(i1, off), a2 = dd_shfl_up(i2, off);
+                    const uint32_t an = __shfl_up(in, off, 64);
+                    if (lane >= off) {
+                        i1 = dd_add(i1, a1);
+                        i2 = dd_add(i2, a2);
+                        in += an;
+                    }
+                }
+                if (lane == 63) {
+                    s_w1[wave] = i1;
+                    s_w2[wave] = i2;
+                    s_wn[wave] = in;
+                }
+                __syncthreads();
+                DD e1 = dd_shfl_up(i1, 1), e2 = dd_shfl_up(i2, 1);
+                uint32_t en = __shfl_up(in, 1, 64);
+                if (lane == 0) {
+                    e1 = zero;
+                    e2 = zero;
+                    en = 0u;
+                }
+                DD c1 = carry1, c2 = carry2;
+                uint32_t cn = carryn;
+                for (int w = 0; w < wave; ++w) {                        // fixed association
+                    c1 = dd_add(c1, s_w1[w]);
+                    c2 = dd_add(c2, s_w2[w]);
+                    cn += s_wn[w];
+                }
+                if (i < nsb) {
+                    s_t1[i] = dd_add(c1, e1);
+                    s_t2[i] = dd_add(c2, e2);
+                    s_tn[i] = cn + en;
+                }
+                for (int w = 0; w < kBlock / 64; ++w) {
+                    carry1 = dd_add(carry1, s_w1[w]);
+                    carry2 = dd_add(carry2, s_w2[w]);
+                    carryn += s_wn[w];
+                }
+                __syncthreads();
+            }
+            q1 = s_t1;
+            q2 = s_t2;
+            qn = s_tn;
+        }
         const int ncells = a.ncells[m];
         const float *T = bt + (int64_t)j * a.stride, *Q = bq + (int64_t)j * a.stride;
         const uint32_t *R = rank + (int64_t)j * a.stride;
@@ -1092,10 +1157,10 @@ k_mse_eval(const float *__restrict__ x, const float *__restrict__ grid, const fl
             if (!(lo < hi)) continue;
             const int64_t i0 = c ? (int64_t)R[c] : 0, i1 = hi < __builtin_inff() ? (int64_t)R[c + 1] : ni;   // (T = +inf: not a border)
             const int64_t b0 = i0 / kSuper, b1 = i1 / kSuper;
-            const uint32_t cnt = (tn[b1] + pn[i1]) - (tn[b0] + pn[i0]);
+            const uint32_t cnt = (qn[b1] + pn[i1]) - (qn[b0] + pn[i0]);
             if (cnt == 0u) continue;
-            const DD m1lo = dd_add(t1[b0], p1[i0]), m1hi = dd_add(t1[b1], p1[i1]);
-            const DD m2lo = dd_add(t2[b0], p2[i0]), m2hi = dd_add(t2[b1], p2[i1]);
+            const DD m1lo = dd_add(q1[b0], p1[i0]), m1hi = dd_add(q1[b1], p1[i1]);
+            const DD m2lo = dd_add(q2[b0], p2[i0]), m2hi = dd_add(q2[b1], p2[i1]);
             // S2 - 2 q S1 + n q^2 in double-double (q^2 of an fp32 q is exact in double); the cell's result is >= 0
             const double qd = (double)Q[c];
             const DD d2 = dd_add(m2hi, dd_neg(m2lo)), d1 = dd_add(m1hi, dd_neg(m1lo));
@@ -1273,9 +1338,11 @@ int fp8q_mse_hist_launch(const float *x, int64_t n, const float *grid, int64_t n
     hipLaunchKernelGGL(k_iv_scan_super, dim3((unsigned)L.nsb), dim3(kSuper), 0, st, boff, gn, gd, gd2lo, gd2hi, L.ni, p1, p2, pn, t1,
                        t2, tn);
     if (int rc = launch_rc()) return rc;
-    hipLaunchKernelGGL(k_iv_scan_top, dim3(1), dim3(64), 0, st, t1, t2, tn, L.nsb);
-    if (int rc = launch_rc()) return rc;
+    if (L.nsb > kTopLds) {          // (more than half a million intervals: thousands of candidates)
+        hipLaunchKernelGGL(k_iv_scan_top, dim3(1), dim3(64), 0, st, t1, t2, tn, L.nsb);
+        if (int rc = launch_rc()) return rc;
+    }
     hipLaunchKernelGGL(k_mse_eval, dim3((unsigned)n_pairs), dim3(kBlock), 0, st, x, grid, bt, bq, rank, cflag, maxkey, p1, p2, pn, t1,
-                       t2, tn, L.ni, mses, a, 1.0 / (double)n);
+                       t2, tn, L.ni, (int)L.nsb, mses, a, 1.0 / (double)n);
     return launch_rc();
 }

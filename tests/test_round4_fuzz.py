@@ -106,6 +106,22 @@ def test_sorted_mse_awkward_sizes_vs_oracle(n, kind):
     np.testing.assert_allclose(got[ok], ref[ok], rtol=1e-5, atol=1e-24 * float(np.nanmax(got)))
 
 
+@pytest.mark.parametrize("n_cand,M", [(1000, 3.0), (2000, 6.0), (3000, 6.0)])
+def test_hist_mse_many_candidates_vs_oracle(n_cand, M):
+    """LineSearchEstimator-sized candidate sets on the interval-histogram route: 136 K ... 580 K intervals, i.e. the
+    superblock totals scanned inside k_mse_eval in one trip (<= 256 superblocks), in two (<= 512), and by the separate
+    k_iv_scan_top launch (more); a sample of the table against the oracle"""
+    import fp8q
+    g = torch.Generator(device="cuda").manual_seed(n_cand)
+    x = torch.randn(1 << 20, device="cuda", generator=g) * 1.7
+    grid = torch.linspace(0.02, 9.0, n_cand, device="cuda").reshape(n_cand, 1).contiguous()
+    mses = torch.zeros(1, n_cand, 1, device="cuda")
+    fp8q.ops.mse_grid(x, False, grid, [M], 8, 1, mses)
+    idx = sorted(set(np.linspace(0, n_cand - 1, 24).astype(int).tolist()))
+    ref = oracle.c_mse_grid(x.cpu().numpy(), False, grid.cpu().numpy()[idx], [M], 8, 1)
+    np.testing.assert_allclose(mses.cpu().numpy()[:, idx, :], ref, rtol=1e-5)
+
+
 @pytest.mark.parametrize("inner", [1, 31, 2047, 2048, 5000])
 def test_mse_degenerate_candidates_divide_like_the_reference(inner):
     """found by tests/soak.py: an E7M1 (8 bits, unsigned) candidate below ~2^-21 underflows its first scale to 0, so the
