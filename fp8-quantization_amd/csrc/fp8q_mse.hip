@@ -47,7 +47,20 @@ k_mse_grid(const float *__restrict__ x, const float *__restrict__ grid, double *
     const float gv = active ? grid[(int64_t)cand * a.C + c] : 1.0f;
     const Chan ch = make_chan(fabsf(fmaxf(fabsf(-gv), gv)), f);
     lut[0] = __builtin_nanf("");
-    for (int p = 1; p <= f.pmax; ++p) lut[p] = scale_exact(ch, (float)p, f.M);
+    {
+        // lut_row()'s shortcut: when fl32(k - bias) is exact at both ends of the table it is exact in between and every
+        // entry is ldexp(fl32(g), k - bi) -- one instruction instead of scale_exact()'s ~30 double-precision operations
+        // (for short rows -- MobileNetV2's [C, 1, 3, 3] and [C_out, C_in] weights -- building 64-entry tables per
+        // candidate was most of the kernel: 70 us per call with the mantissa search)
+        const float k1 = 1.0f - f.M, kp = (float)f.pmax - f.M;
+        const bool lin = ch.pthr >= 0.0f && (k1 - (k1 - ch.bias)) == ch.bias && (kp - (kp - ch.bias)) == ch.bias;
+        if (lin) {
+            const int j0 = (int)k1 - ch.bi - 1;
+            for (int p = 1; p <= f.pmax; ++p) lut[p] = ldexpf(ch.m0, j0 + p);
+        } else {
+            for (int p = 1; p <= f.pmax; ++p) lut[p] = scale_exact(ch, (float)p, f.M);
+        }
+    }
     // p = floor(log2|xc| + bias) without a logarithm: with bias = bi + bf, log2|xc| + bias = log2(|xc| 2^bf) + bi,
     // so p is the exponent field of fl32(|xc| * 2^bf) plus a constant.  An element within a few ulps of a binade
     // border can land on either side; both sides give the same grid point there (2^(M+1) steps of s_p = 2^M
