@@ -42,7 +42,7 @@ constexpr int kHSubBits = 10;                       // sub-bin table of k_moment
 constexpr int kHSub = 1 << kHSubBits;
 constexpr int kPartTile = 8192;                     // keys per partition tile (32 per thread)
 constexpr int kHistMaxM = 8;
-constexpr int kStrideBound = 260;                   // cells of one candidate of a signed format of <= 8 bits: (2^E + 1) 2^M + 2 <= 258
+constexpr int kStrideBound = 520;                   // cells of one candidate of a format of <= 8 bits: (2^E + 1) 2^M + 2 <= 514 (unsigned, M = 8)
 constexpr int kSuper = 1024;                        // intervals per scan superblock
 constexpr int kTopLds = 512;                        // superblock totals that k_mse_eval scans for itself in LDS
 constexpr int kSortLds = 4096;                      // borders of one bucket sorted in LDS (more: a bitonic network on global memory)
@@ -55,6 +55,7 @@ struct HistArgs {
     int ncells[kHistMaxM];       // cells of width m: 2^(M+1) + 1 + (pmax - 1)(2^M + 1) + 1 (the clamp cell)
     int n_m, n_cand;
     int stride;                  // max ncells: row pitch of the per-candidate border tables
+    int uns;                     // unsigned formats (sign_bits == 0): a negative element is clipped to 0 -> its error is x^2
     int64_t n;                   // elements of the row
 };
 
@@ -146,7 +147,8 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *s_w, u
 }
 
 // ---- 2. partition -----------------------------------------------------------------------------------------------------
-// 32 keys of a tile per thread (|x| bit patterns); a tile's last, partial part reads element by element
+// 32 elements of a tile per thread, as bit patterns (sign included: tile_key() makes the key); a tile's last, partial part
+// reads element by element
 __device__ __forceinline__ void load_tile_keys(const uint32_t *__restrict__ x, int64_t n, int64_t base, uint32_t (&k)[32])
 {
     const int tid = threadIdx.x;
@@ -154,10 +156,10 @@ __device__ __forceinline__ void load_tile_keys(const uint32_t *__restrict__ x, i
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const u32x4u v = *reinterpret_cast<const u32x4u *>(x + base + u * 1024 + tid * 4);
-            k[4 * u] = v.x & 0x7fffffffu;
-            k[4 * u + 1] = v.y & 0x7fffffffu;
-            k[4 * u + 2] = v.z & 0x7fffffffu;
-            k[4 * u + 3] = v.w & 0x7fffffffu;
+            k[4 * u] = v.x;
+            k[4 * u + 1] = v.y;
+            k[4 * u + 2] = v.z;
+            k[4 * u + 3] = v.w;
         }
     } else {
 #pragma unroll
@@ -165,45 +167,71 @@ __device__ __forceinline__ void load_tile_keys(const uint32_t *__restrict__ x, i
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int64_t i = base + u * 1024 + tid * 4 + q;
-                k[4 * u + q] = i < n ? (x[i] & 0x7fffffffu) : 0u;
+                k[4 * u + q] = i < n ? x[i] : 0u;
             }
     }
+}
+
+// the key of an element: |x|; 0 (= dropped, like a zero) for a negative element of an UNSIGNED format -- it is clipped to 0,
+// its squared error is x^2 whatever the candidate (summed separately: part_hist_body)
+template <bool UNS>
+__device__ __forceinline__ uint32_t tile_key(uint32_t raw)
+{
+    return (UNS && (raw >> 31)) ? 0u : (raw & 0x7fffffffu);
 }
 
 // Workgroup w of both partition passes owns the tiles [w * tpw, (w + 1) * tpw): pass A leaves its bucket counts as row w of
 // `ktab`, k_tab_scan turns every column into exclusive prefixes over the workgroups, and pass B starts workgroup w's run of
 // bucket b at koff[b] + ktab[w][b] -- no global atomics anywhere (a first version reserved space with one returning atomic
 // per (tile, bucket) on a 2048-word cursor array: 1.9 M atomics into two memory channels, 481 us for 25.7 M keys).
+template <bool UNS>
 __device__ __forceinline__ void part_hist_body(int w, uint32_t *s_hist, const uint32_t *__restrict__ x, int64_t n, int64_t ntiles,
-                                               int tpw, uint32_t *__restrict__ ktab, uint32_t *__restrict__ kmax)
+                                               int tpw, uint32_t *__restrict__ ktab, uint32_t *__restrict__ kmax, double *__restrict__ kneg)
 {
     const int tid = threadIdx.x;
     uint32_t *s_mk = s_hist + kHBuckets;
+    double *s_ng = reinterpret_cast<double *>(s_hist + kHBuckets + 8);
     for (int i = tid; i < kHBuckets; i += kBlock) s_hist[i] = 0u;
     __syncthreads();
     uint32_t mk = 0u;
+    double neg = 0.0;       // sum of x^2 over the negative elements (unsigned formats); fp32 squares are exact in double
     const int64_t t0 = (int64_t)w * tpw, t1 = min(t0 + tpw, ntiles);
     for (int64_t t = t0; t < t1; ++t) {
         uint32_t k[32];
         load_tile_keys(x, n, t * kPartTile, k);
 #pragma unroll
         for (int j = 0; j < 32; ++j) {
-            mk = max(mk, k[j]);
-            if (k[j]) atomicAdd(&s_hist[k[j] >> kHShift], 1u);
+            mk = max(mk, k[j] & 0x7fffffffu);
+            const uint32_t key = tile_key<UNS>(k[j]);
+            if (UNS && (k[j] >> 31)) {
+                const double v = (double)__uint_as_float(k[j]);
+                neg += v * v;
+            }
+            if (key) atomicAdd(&s_hist[key >> kHShift], 1u);
         }
     }
     __syncthreads();
     for (int i = tid; i < kHBuckets; i += kBlock) ktab[(int64_t)w * kHBuckets + i] = s_hist[i];
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) mk = max(mk, (uint32_t)__shfl_xor((int)mk, off, 64));
-    if ((tid & 63) == 0) s_mk[tid >> 6] = mk;
+    for (int off = 32; off >= 1; off >>= 1) {
+        mk = max(mk, (uint32_t)__shfl_xor((int)mk, off, 64));
+        if (UNS) neg += __shfl_xor(neg, off, 64);               // fixed tree: deterministic
+    }
+    if ((tid & 63) == 0) {
+        s_mk[tid >> 6] = mk;
+        if (UNS) s_ng[tid >> 6] = neg;
+    }
     __syncthreads();
-    if (tid == 0) kmax[w] = max(max(s_mk[0], s_mk[1]), max(s_mk[2], s_mk[3]));
+    if (tid == 0) {
+        kmax[w] = max(max(s_mk[0], s_mk[1]), max(s_mk[2], s_mk[3]));
+        if (UNS) kneg[w] = (s_ng[0] + s_ng[1]) + (s_ng[2] + s_ng[3]);
+    }
 }
 
 // scatter: per tile a counting sort by bucket in LDS (ranks from returning LDS atomics), then position p of the sorted
 // tile goes to delta[bucket] + p: consecutive lanes write consecutive addresses within a run.  The order of the keys inside
 // a (workgroup, bucket) run depends on the LDS atomics' timing; nothing downstream depends on it (integer moments).
+template <bool UNS>
 __device__ __forceinline__ void part_scatter_body(int w, uint32_t *s_raw, const uint32_t *__restrict__ x, int64_t n, int64_t ntiles,
                                                   int tpw, const uint32_t *__restrict__ koff, const uint32_t *__restrict__ ktab,
                                                   uint32_t *__restrict__ out)
@@ -225,7 +253,10 @@ __device__ __forceinline__ void part_scatter_body(int w, uint32_t *s_raw, const 
         uint16_t rk[32];
         load_tile_keys(x, n, t * kPartTile, k);
 #pragma unroll
-        for (int j = 0; j < 32; ++j) rk[j] = k[j] ? (uint16_t)atomicAdd(&s_hist[k[j] >> kHShift], 1u) : (uint16_t)0;
+        for (int j = 0; j < 32; ++j) {
+            k[j] = tile_key<UNS>(k[j]);
+            rk[j] = k[j] ? (uint16_t)atomicAdd(&s_hist[k[j] >> kHShift], 1u) : (uint16_t)0;
+        }
         __syncthreads();
         uint32_t c[kPer], sum = 0u;
 #pragma unroll
@@ -466,17 +497,18 @@ __device__ __forceinline__ void borders_body(int j, uint32_t *s_hist, const floa
 }
 
 // stage 1, one launch: the candidates' borders (workgroups 0 .. n_pairs - 1) next to the key histogram (the rest)
+template <bool UNS>
 __global__ void __launch_bounds__(kBlock)
 k_stage1(const uint32_t *__restrict__ x, int64_t n, int64_t ntiles, int tpw, uint32_t *__restrict__ ktab, uint32_t *__restrict__ kmax,
-         const float *__restrict__ grid, HistArgs a, int brute, float *__restrict__ bt, float *__restrict__ bq, int *__restrict__ cflag,
-         uint32_t *__restrict__ btab)
+         double *__restrict__ kneg, const float *__restrict__ grid, HistArgs a, int brute, float *__restrict__ bt, float *__restrict__ bq,
+         int *__restrict__ cflag, uint32_t *__restrict__ btab)
 {
-    __shared__ uint32_t s_raw[kHBuckets + 2 * kLutMax + 16 + 2 * kStrideBound];
+    __shared__ __attribute__((aligned(8))) uint32_t s_raw[kHBuckets + 2 * kLutMax + 16 + 2 * kStrideBound];
     const int n_pairs = a.n_m * a.n_cand;
     if ((int)blockIdx.x < n_pairs)
         borders_body((int)blockIdx.x, s_raw, grid, a, brute, bt, bq, cflag, btab);
     else
-        part_hist_body((int)blockIdx.x - n_pairs, s_raw, x, n, ntiles, tpw, ktab, kmax);
+        part_hist_body<UNS>((int)blockIdx.x - n_pairs, s_raw, x, n, ntiles, tpw, ktab, kmax, kneg);
 }
 
 // ---- plan: offsets of keys and borders per bucket, the work units of k_moments ------------------------------------------
@@ -500,7 +532,7 @@ __device__ __forceinline__ uint32_t slice_len(uint32_t nb, int slice_min)
 
 // (a device function: it runs as one more workgroup of the border-sort launch -- both need only the column totals)
 __device__ __forceinline__ void plan_body(uint32_t *s_raw, const uint32_t *__restrict__ hist, const uint32_t *__restrict__ bhist,
-                                          const uint32_t *__restrict__ kmax, int nkmax, uint32_t *__restrict__ koff,
+                                          const uint32_t *__restrict__ kmax, const double *__restrict__ kneg, int nkmax, uint32_t *__restrict__ koff,
                                           uint32_t *__restrict__ boff, Unit *__restrict__ units, uint32_t *__restrict__ nunits,
                                           uint32_t *__restrict__ maxkey, uint32_t units_max, int bcap, int slice_min)
 {
@@ -577,6 +609,18 @@ __device__ __forceinline__ void plan_body(uint32_t *s_raw, const uint32_t *__res
     if ((tid & 63) == 0) s_w[tid >> 6] = mk;
     __syncthreads();
     if (tid == 0) maxkey[0] = max(max(s_w[0], s_w[1]), max(s_w[2], s_w[3]));
+    if (kneg) {
+        // unsigned formats: the negative elements' sum of squares, over the partition workgroups in a fixed order
+        double *s_ng = reinterpret_cast<double *>(s_uoff);      // (the unit tables are no longer read: barrier above)
+        double v = 0.0;
+        for (int i = tid; i < nkmax; i += kBlock) v += kneg[i];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        __syncthreads();
+        if ((tid & 63) == 0) s_ng[tid >> 6] = v;
+        __syncthreads();
+        if (tid == 0) reinterpret_cast<double *>(maxkey)[1] = (s_ng[0] + s_ng[1]) + (s_ng[2] + s_ng[3]);
+    }
 }
 
 // ---- 3. sort the borders of each bucket ---------------------------------------------------------------------------------
@@ -755,23 +799,25 @@ static_assert(kSortRaw >= 6 * kHBuckets + 16, "the plan's tables fit in the sort
 __global__ void __launch_bounds__(kBlock)
 k_border_sort_plan(const float *__restrict__ bt, const uint32_t *__restrict__ btab, const uint32_t *__restrict__ bhist, int n_pairs,
                    int stride, uint32_t *__restrict__ sb, uint32_t *__restrict__ rank, uint32_t *__restrict__ gtab,
-                   uint64_t *__restrict__ pairs, const uint32_t *__restrict__ hist, const uint32_t *__restrict__ kmax, int nkmax,
+                   uint64_t *__restrict__ pairs, const uint32_t *__restrict__ hist, const uint32_t *__restrict__ kmax,
+                   const double *__restrict__ kneg, int nkmax,
                    uint32_t *__restrict__ koff, uint32_t *__restrict__ boff, Unit *__restrict__ units, uint32_t *__restrict__ nunits,
                    uint32_t *__restrict__ maxkey, uint32_t units_max, int bcap, int slice_min)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_raw[kSortRaw];
     if (blockIdx.x == 0)
-        plan_body(s_raw, hist, bhist, kmax, nkmax, koff, boff, units, nunits, maxkey, units_max, bcap, slice_min);
+        plan_body(s_raw, hist, bhist, kmax, kneg, nkmax, koff, boff, units, nunits, maxkey, units_max, bcap, slice_min);
     else
         border_sort_body((int)blockIdx.x - 1, s_raw, bt, btab, bhist, n_pairs, stride, sb, rank, gtab, pairs);
 }
 
+template <bool UNS>
 __global__ void __launch_bounds__(kBlock)
 k_part_scatter(const uint32_t *__restrict__ x, int64_t n, int64_t ntiles, int tpw, const uint32_t *__restrict__ koff,
                const uint32_t *__restrict__ ktab, uint32_t *__restrict__ keys)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_raw[kPartLds / 4];
-    part_scatter_body((int)blockIdx.x, s_raw, x, n, ntiles, tpw, koff, ktab, keys);
+    part_scatter_body<UNS>((int)blockIdx.x, s_raw, x, n, ntiles, tpw, koff, ktab, keys);
 }
 
 // ---- 4. moments of the intervals ----------------------------------------------------------------------------------------
@@ -1079,11 +1125,11 @@ k_mse_eval(const float *__restrict__ x, const float *__restrict__ grid, const fl
         for (int p = tid + 1; p <= f.pmax; p += kBlock) s_scale[p] = lut_entry(ch, p, f.M).x;
         __syncthreads();
         for (int64_t i = tid; i < a.n; i += kBlock) {
-            const float k = fabsf(x[i]);
-            const float xc = fminf(k, mv);
-            const float ls = floorf(log2_tab(xc, kFastTab) + ch.bias);
+            const float xv = x[i];
+            const float xc = __builtin_amdgcn_fmed3f(xv, ch.minv, ch.maxv);          // (unsigned formats: negative -> 0)
+            const float ls = floorf(log2_tab(fabsf(xc), kFastTab) + ch.bias);
             const float sc = s_scale[(int)__builtin_amdgcn_fmed3f(ls, 1.0f, pmaxf)];
-            const float d = k - rintf(xc / sc) * sc;
+            const float d = xv - rintf(xc / sc) * sc;
             acc += (double)(d * d);
         }
     } else {
@@ -1175,7 +1221,8 @@ k_mse_eval(const float *__restrict__ x, const float *__restrict__ grid, const fl
         __syncthreads();
     }
     if (tid == 0) {
-        const double tot = s_red[0] < 0.0 ? 0.0 : s_red[0];     // (rounding can leave a tiny negative number for an exact fit)
+        double tot = s_red[0] < 0.0 ? 0.0 : s_red[0];           // (rounding can leave a tiny negative number for an exact fit)
+        if (a.uns && flag != kFlagBrute) tot += reinterpret_cast<const double *>(maxkey)[1];   // negative elements: x^2 each
         *out += (float)(tot * inv_inner);
     }
 }
@@ -1199,7 +1246,7 @@ int hist_slice_min() { static const int v = env_int("FP8Q_MSE_SLICE", 16384, 102
 struct HistLayout {
     size_t keys, zero0, zero_bytes;           // [zero0, zero0 + zero_bytes): cleared in every call (k_tab_scan)
     size_t gn, gd, gd2lo, gd2hi;
-    size_t hist, bhist, ktab, btab, kmax, maxkey, nunits, gtab;
+    size_t hist, bhist, ktab, btab, kmax, kneg, maxkey, nunits, gtab;
     size_t koff, boff, units, bt, bq, rank, cflag, pairs, sb, p1, p2, pn, t1, t2, tn;
     size_t total;
     int64_t nbord, ni, nsb;
@@ -1236,7 +1283,8 @@ HistLayout hist_layout(int64_t n, int64_t n_pairs, int stride, int bcap, int sli
     L.ktab = take((size_t)kPartWgs * kHBuckets * 4);
     L.btab = take((size_t)n_pairs * kHBuckets * 4);
     L.kmax = take(kPartWgs * 4);
-    L.maxkey = take(4);
+    L.kneg = take(kPartWgs * 8);
+    L.maxkey = take(16);           // {largest key, pad, double: sum of squares of the negative elements (unsigned formats)}
     L.nunits = take(8);
     // sub-bin tables: one per bucket that has borders -- at most min(2048, borders) of them
     L.gtab = take((size_t)(L.nbord < kHBuckets ? L.nbord : kHBuckets) * (kHSub + 1) * 4);
@@ -1267,12 +1315,12 @@ size_t fp8q_mse_hist_workspace_bytes(int64_t n, int64_t n_pairs)
     return hist_layout(n, n_pairs, kStrideBound, hist_bcap(), hist_slice_min()).total;
 }
 
-// formats this route takes: signed, at most 8 bits (the cell tables are sized for them)
+// formats this route takes: at most 8 bits, signed or unsigned (the cell tables are sized for them)
 bool fp8q_mse_hist_supported(const QFmt *fmts, int n_m, int n_bits)
 {
     if (n_m > kHistMaxM || n_bits > 8) return false;
     for (int m = 0; m < n_m; ++m)
-        if (fmts[m].sign_bits != 1 || (fmts[m].pmax + 1) * (1 << (int)fmts[m].M) + 2 > kStrideBound) return false;
+        if (fmts[m].sign_bits != fmts[0].sign_bits || (fmts[m].pmax + 1) * (1 << (int)fmts[m].M) + 2 > kStrideBound) return false;
     return true;
 }
 
@@ -1286,6 +1334,7 @@ int fp8q_mse_hist_launch(const float *x, int64_t n, const float *grid, int64_t n
     a.n_cand = (int)n_cand;
     a.n = n;
     a.stride = 0;
+    a.uns = fmts[0].sign_bits == 0;
     for (int m = 0; m < n_m; ++m) {
         a.fmt[m] = fmts[m];
         const int M = (int)fmts[m].M;
@@ -1301,6 +1350,7 @@ int fp8q_mse_hist_launch(const float *x, int64_t n, const float *grid, int64_t n
     auto at = [&](size_t off) { return (void *)(w + off); };
     uint32_t *keys = (uint32_t *)at(L.keys), *hist = (uint32_t *)at(L.hist), *bhist = (uint32_t *)at(L.bhist);
     uint32_t *ktab = (uint32_t *)at(L.ktab), *btab = (uint32_t *)at(L.btab), *kmax = (uint32_t *)at(L.kmax);
+    double *kneg = a.uns ? (double *)at(L.kneg) : nullptr;
     uint32_t *maxkey = (uint32_t *)at(L.maxkey), *nunits = (uint32_t *)at(L.nunits), *gn = (uint32_t *)at(L.gn);
     uint32_t *gtab = (uint32_t *)at(L.gtab);
     unsigned long long *gd = (unsigned long long *)at(L.gd), *gd2lo = (unsigned long long *)at(L.gd2lo),
@@ -1317,16 +1367,23 @@ int fp8q_mse_hist_launch(const float *x, int64_t n, const float *grid, int64_t n
     const int64_t ntiles = cdiv(n, kPartTile);
     const int tpw = (int)cdiv(ntiles, kPartWgs);              // tiles per partition workgroup
     const int pwgs = (int)cdiv(ntiles, tpw);                  // <= kPartWgs, none of them empty
-    hipLaunchKernelGGL(k_stage1, dim3((unsigned)(n_pairs + pwgs)), dim3(kBlock), 0, st, xb, n, ntiles, tpw, ktab, kmax, grid, a, brute,
-                       bt, bq, cflag, btab);
+    if (a.uns)
+        hipLaunchKernelGGL(k_stage1<true>, dim3((unsigned)(n_pairs + pwgs)), dim3(kBlock), 0, st, xb, n, ntiles, tpw, ktab, kmax, kneg,
+                           grid, a, brute, bt, bq, cflag, btab);
+    else
+        hipLaunchKernelGGL(k_stage1<false>, dim3((unsigned)(n_pairs + pwgs)), dim3(kBlock), 0, st, xb, n, ntiles, tpw, ktab, kmax, kneg,
+                           grid, a, brute, bt, bq, cflag, btab);
     if (int rc = launch_rc()) return rc;
     hipLaunchKernelGGL(k_tab_scan, dim3(kHBuckets / 32, 2), dim3(1024), 0, st, ktab, pwgs, hist, btab, (int)n_pairs, bhist,
                        (uint4 *)at(L.zero0), (int64_t)(L.zero_bytes / 16));
     if (int rc = launch_rc()) return rc;
     hipLaunchKernelGGL(k_border_sort_plan, dim3(kHBuckets + 1), dim3(kBlock), 0, st, bt, btab, bhist, (int)n_pairs, a.stride, sb, rank,
-                       gtab, pairs, hist, kmax, pwgs, koff, boff, units, nunits, maxkey, L.units_max, bcap, slice_min);
+                       gtab, pairs, hist, kmax, kneg, pwgs, koff, boff, units, nunits, maxkey, L.units_max, bcap, slice_min);
     if (int rc = launch_rc()) return rc;
-    hipLaunchKernelGGL(k_part_scatter, dim3((unsigned)pwgs), dim3(kBlock), 0, st, xb, n, ntiles, tpw, koff, ktab, keys);
+    if (a.uns)
+        hipLaunchKernelGGL(k_part_scatter<true>, dim3((unsigned)pwgs), dim3(kBlock), 0, st, xb, n, ntiles, tpw, koff, ktab, keys);
+    else
+        hipLaunchKernelGGL(k_part_scatter<false>, dim3((unsigned)pwgs), dim3(kBlock), 0, st, xb, n, ntiles, tpw, koff, ktab, keys);
     if (int rc = launch_rc()) return rc;
     const size_t shmem = (size_t)(bcap + 1) * 16 + (size_t)bcap * 4 + (kHSub + 1) * 4;
     if (shmem > 64 * 1024) {

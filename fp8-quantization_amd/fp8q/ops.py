@@ -486,6 +486,9 @@ def copy(x, out=None):
     return y
 
 
+_mse_ws_bytes = {}
+
+
 def mse_grid(x, per_channel, grid, mbits_list, n_bits, sign_bits, mses):
     """K4: mses[n_m, n_cand, C] += row-mean((x - q(x; m, grid[i, c]))^2)  (range_estimators.py:337-347).
 
@@ -505,7 +508,11 @@ def mse_grid(x, per_channel, grid, mbits_list, n_bits, sign_bits, mses):
     if tuple(mses.shape) != (n_m, n_cand, C) or not mses.is_contiguous():
         raise Fp8qError(f"mses must be contiguous [{n_m}, {n_cand}, {C}]")
     L = lib()
-    ws = _workspace(x.device, L.fp8q_mse_workspace_bytes(C, inner, n_cand, n_m))
+    key = (C, inner, n_cand, n_m)
+    nbytes = _mse_ws_bytes.get(key)
+    if nbytes is None:     # a pure function of the shape: one ctypes call per shape, not per launch
+        nbytes = _mse_ws_bytes[key] = L.fp8q_mse_workspace_bytes(C, inner, n_cand, n_m)
+    ws = _workspace(x.device, nbytes)
     mb = (ctypes.c_float * n_m)(*[float(v) for v in mbits_list])
     with _on_device(x):
         rc = L.fp8q_mse_grid_f32(x.data_ptr(), C, inner, grid.data_ptr(), n_cand, mb, n_m, int(n_bits),

@@ -160,9 +160,9 @@ int fp8q_minmax_quantize_f32(const float *x, float *y, int64_t C, int64_t inner,
  *                             element could take the other neighbour, which moved entries carried by a few elements -- the
  *                             search grid's last candidate 1.2 max|x| puts the largest element on a tie for M = 1, 3, 5 -- by up
  *                             to 4e-5);
- *   per-tensor rows of a signed format of <= 8 bits, long enough to pay for ~60 us of fixed cost (>= ~4 M elements for 111
- *   (width, candidate) pairs, >= ~1 M for 666: FP_MSE_Estimator with the mantissa search, LineSearchEstimator's 1000
- *   candidates)               the interval histogram (csrc/fp8q_mse_hist.hip): a quantizer is a step function of |x|, so the
+ *   per-tensor rows of a format of <= 8 bits (signed or unsigned), long enough to pay for ~60 us of fixed cost (>= ~1 M elements
+ *   for 111 (width, candidate) pairs, >= ~0.5 M for 666: FP_MSE_Estimator with the mantissa search, LineSearchEstimator's
+ *   1000 candidates)               the interval histogram (csrc/fp8q_mse_hist.hip): a quantizer is a step function of |x|, so the
  *                             exact borders of all cells of all candidates (the smallest float at which the reference's own
  *                             fp32 decisions flip) cut |x| into intervals; the nonzero keys are partitioned ONCE by their top
  *                             11 bits, integer moments {n, sum d, sum d^2} of every interval are accumulated with LDS atomics

@@ -215,16 +215,17 @@ def case_sorted(rng):
     top = float(np.abs(x).max()) or 1.0
     grid = torch.linspace(0.1 * top, 1.2 * top, 111, device="cuda").reshape(111, 1).contiguous()
     widths = [1.0, 2.0, 3.0, 4.0, 5.0, 6.0]
+    sb = int(rng.choice([1, 1, 0]))                                # unsigned formats: negative elements clip to 0 (error x^2)
     srt = torch.zeros(6, 111, 1, device="cuda")
-    ops.mse_grid(xd, False, grid, widths, 8, 1, srt)              # 666 pairs on >= 2^20 elements: the interval-histogram route
+    ops.mse_grid(xd, False, grid, widths, 8, sb, srt)              # 666 pairs on >= 2^20 elements: the interval-histogram route
     row = torch.zeros(6, 111, 1, device="cuda")
     for i in range(6):                                             # 111 pairs per call on < 4 M elements: the lane-per-element kernel
-        ops.mse_grid(xd, False, grid, widths[i:i + 1], 8, 1, row[i:i + 1])
+        ops.mse_grid(xd, False, grid, widths[i:i + 1], 8, sb, row[i:i + 1])
     s, r = srt.cpu().numpy().astype(np.float64), row.cpu().numpy().astype(np.float64)
     floor = 1e-24 * max(r.max(), 1e-300)
     rel = np.abs(s - r) / (np.abs(r) + floor)
     w = int(np.unravel_index(np.argmax(rel), rel.shape)[0]) if rel.max() > 1e-5 else int(rng.randint(6))   # the worst width, if any
-    o = oracle.c_mse_grid(x, False, grid.cpu().numpy(), [widths[w]], 8, 1).astype(np.float64)[0]
+    o = oracle.c_mse_grid(x, False, grid.cpu().numpy(), [widths[w]], 8, sb).astype(np.float64)[0]
     es, er = np.abs(s[w] - o) / (np.abs(o) + floor), np.abs(r[w] - o) / (np.abs(o) + floor)
     # include/fp8q.h: both routes within 1e-5 relative of the oracle on EVERY entry (measured ~1e-7): since round 5 the
     # lane-per-element kernels re-evaluate elements near a rounding tie with the reference's division
@@ -232,7 +233,7 @@ def case_sorted(rng):
         i = int(np.argmax(np.maximum(es, er)))
         np.savez(os.path.join(ROOT, "gpurun_out", "soak_fail_k4.npz"), x=x, grid=grid.cpu().numpy(), sorted=s, row=r, oracle_w=o, w=w)
         raise AssertionError(("K4 vs oracle", n, "width", widths[w], "candidate", i, "sorted", float(s[w, i, 0]), "row", float(r[w, i, 0]),
-                              "oracle", float(o[i, 0]), "rel sorted", float(es.max()), "rel row", float(er.max()), "data kind", LAST_KIND[0]))
+                              "sign_bits", sb, "oracle", float(o[i, 0]), "rel sorted", float(es.max()), "rel row", float(er.max()), "data kind", LAST_KIND[0]))
     return n * 666
 
 

@@ -106,6 +106,35 @@ def test_sorted_mse_awkward_sizes_vs_oracle(n, kind):
     np.testing.assert_allclose(got[ok], ref[ok], rtol=1e-5, atol=1e-24 * float(np.nanmax(got)))
 
 
+@pytest.mark.parametrize("kind", ["relu6", "mixed", "negative", "nan"])
+def test_hist_mse_unsigned_formats_vs_oracle(kind):
+    """unsigned formats (allow_unsigned: sign_bits = 0) on the interval-histogram route: a negative element is clipped to 0,
+    so its squared error is x^2 for every candidate -- summed apart from the partition (exact squares in double, fixed
+    order) and added to every candidate; the mantissa search then covers M = 1 ... 7 (up to 386 cells per candidate)"""
+    import fp8q
+    n = (1 << 20) + 13
+    g = torch.Generator(device="cuda").manual_seed(17)
+    x = torch.randn(n, device="cuda", generator=g) * 2.0
+    if kind == "relu6":
+        x = torch.clamp(x * 2, 0, 6)
+    elif kind == "negative":
+        x = -x.abs()
+        x[7] = 0.5
+    elif kind == "nan":
+        x[1234] = float("nan")
+    mx = x[torch.isfinite(x)].abs().max().reshape(1)
+    grid = fp8q.ops.mse_linspace(mx, 111)
+    mb = [1.0, 2.0, 3.0, 4.0, 5.0, 6.0, 7.0]
+    mses = torch.zeros(7, 111, 1, device="cuda")
+    fp8q.ops.mse_grid(x, False, grid, mb, 8, 0, mses)
+    idx = [0, 9, 55, 110]
+    ref = oracle.c_mse_grid(x.cpu().numpy(), False, grid.cpu().numpy()[idx], mb, 8, 0)
+    got = mses.cpu().numpy()[:, idx, :]
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    ok = ~np.isnan(ref)
+    np.testing.assert_allclose(got[ok], ref[ok], rtol=1e-5)
+
+
 @pytest.mark.parametrize("n_cand,M", [(1000, 3.0), (2000, 6.0), (3000, 6.0)])
 def test_hist_mse_many_candidates_vs_oracle(n_cand, M):
     """LineSearchEstimator-sized candidate sets on the interval-histogram route: 136 K ... 580 K intervals, i.e. the
