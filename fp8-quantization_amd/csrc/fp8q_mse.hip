@@ -745,7 +745,7 @@ static bool mse_use_hist_shape(int64_t C, int64_t inner, int64_t n_cand, int n_m
 {
     if (mse_hist_mode() == 0 || C != 1 || inner >= (1ll << 31)) return false;
     if (mse_hist_mode() == 3) return inner >= (1 << 16);
-    if (inner < (1 << 18)) return false;
+    if (inner < (1 << 18) || (int64_t)n_m * n_cand > 4096) return false;   // (8 KB of border-count table per pair)
     const double pairs = (double)(n_m * n_cand);
     const double row = 40e-6 + (double)inner * pairs * 0.26e-12;
     const double hist = 55e-6 + pairs * 0.095e-6 + (double)inner * 4.3e-12;

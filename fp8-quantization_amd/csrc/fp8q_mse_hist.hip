@@ -582,6 +582,7 @@ __device__ __forceinline__ void plan_body(uint32_t *s_raw, const uint32_t *__res
         s_uoff[kHBuckets] = tu;
         nunits[0] = tu < units_max ? tu : units_max;   // (units_max is a proven bound: see hist_layout)
         nunits[1] = tl;                                // buckets that have borders
+        nunits[2] = tu > units_max ? 1u : 0u;          // never seen; if it happens the call reports NaN instead of dropping work
     }
     __syncthreads();
     // the units, all threads: unit u belongs to the last bucket whose first unit is <= u; inside a bucket the chunks of one
@@ -1093,7 +1094,7 @@ k_mse_eval(const float *__restrict__ x, const float *__restrict__ grid, const fl
            const uint32_t *__restrict__ rank, const int *__restrict__ cflag, const uint32_t *__restrict__ maxkey,
            const DD *__restrict__ p1, const DD *__restrict__ p2, const uint32_t *__restrict__ pn, const DD *__restrict__ t1,
            const DD *__restrict__ t2, const uint32_t *__restrict__ tn, int64_t ni, int nsb, float *__restrict__ mses, HistArgs a,
-           double inv_inner)
+           double inv_inner, const uint32_t *__restrict__ nunits)
 {
     __shared__ double s_red[kBlock];
     __shared__ float s_scale[kLutMax];
@@ -1105,7 +1106,7 @@ k_mse_eval(const float *__restrict__ x, const float *__restrict__ grid, const fl
     // non-finite keys: the reference's mean is NaN (a NaN element) or +inf (an infinite one: (x - xq)^2 = inf)
     const uint32_t last = maxkey[0];
     const int flag = cflag[j];
-    if (last > 0x7f800000u || flag == kFlagNaN) {
+    if (last > 0x7f800000u || flag == kFlagNaN || nunits[2]) {
         if (tid == 0) *out += __builtin_nanf("");
         return;
     }
@@ -1261,8 +1262,11 @@ HistLayout hist_layout(int64_t n, int64_t n_pairs, int stride, int bcap, int sli
     L.nbord = n_pairs * stride;                       // borders: at most stride - 1 per candidate
     L.ni = L.nbord + kHBuckets;                       // intervals: one more than its borders per bucket
     L.nsb = cdiv(L.ni + 1, kSuper);
-    // units: sum over the buckets of chunks x slices <= (sum of slices) x (largest chunk count)
-    const int64_t max_chunks = cdiv(L.nbord, bcap) + 1, max_slices = cdiv(n, slice_min) + kHBuckets;
+    // units: sum over the buckets of chunks x slices <= (sum of slices) x (largest chunk count).  A candidate has at most
+    // 2^M / 4 + 3 borders in one coarse bucket (an eighth of a binade: bucket length / s_p < 2^M / 4), and 2^M <= stride / 3;
+    // should a bucket ever hold more, k_mse_plan raises the overflow flag and every table entry of the call becomes NaN
+    const int64_t per_bucket = n_pairs * (stride / 12 + 4);
+    const int64_t max_chunks = cdiv(per_bucket, bcap) + 1, max_slices = cdiv(n, slice_min) + kHBuckets;
     const int64_t um = max_chunks * max_slices;
     L.units_max = (uint32_t)(um > (1 << 22) ? (1 << 22) : um);
     size_t o = 0;
@@ -1285,7 +1289,7 @@ HistLayout hist_layout(int64_t n, int64_t n_pairs, int stride, int bcap, int sli
     L.kmax = take(kPartWgs * 4);
     L.kneg = take(kPartWgs * 8);
     L.maxkey = take(16);           // {largest key, pad, double: sum of squares of the negative elements (unsigned formats)}
-    L.nunits = take(8);
+    L.nunits = take(16);
     // sub-bin tables: one per bucket that has borders -- at most min(2048, borders) of them
     L.gtab = take((size_t)(L.nbord < kHBuckets ? L.nbord : kHBuckets) * (kHSub + 1) * 4);
     L.koff = take((kHBuckets + 1) * 4);
@@ -1400,6 +1404,6 @@ int fp8q_mse_hist_launch(const float *x, int64_t n, const float *grid, int64_t n
         if (int rc = launch_rc()) return rc;
     }
     hipLaunchKernelGGL(k_mse_eval, dim3((unsigned)n_pairs), dim3(kBlock), 0, st, x, grid, bt, bq, rank, cflag, maxkey, p1, p2, pn, t1,
-                       t2, tn, L.ni, (int)L.nsb, mses, a, 1.0 / (double)n);
+                       t2, tn, L.ni, (int)L.nsb, mses, a, 1.0 / (double)n, nunits);
     return launch_rc();
 }
