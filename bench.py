@@ -20,7 +20,8 @@ to it: `value_kernel_only` (the same elements / the kernel phase alone: what `va
 `collective_us`, `xgmi_gb_s` (bytes each rank receives / collective time), and from `north_star_path`, which times the
 two exchange steps north_star names at any N (N = 1: the collectives are no-ops and the figures are the kernels' own):
 `value_codes_wire` (same flow with 1-byte storage codes on the wire), `value_resnet18_strong` (ResNet-18's 21 weight
-tensors, one bucketed all-gather; strong scaling), `value_c5` (BASELINE config 5 including its all-reduce).
+tensors, one bucketed all-gather -- 1-byte codes + fp32 ranges on the wire since round 5, `fp32_wire_*` next to it in
+`north_star_path` --; strong scaling), `value_c5` (BASELINE config 5 including its all-reduce).
   weights_allgather  one [N * 2^18, 3, 7, 7] weight tensor held by every rank; rank r finds the ranges of and quantizes
                      channels channel_partition(C, N)[r] (fused min/max+quantize), then the shards and their per-channel
                      ranges are re-assembled with RCCL all-gathers -- fp32 on the wire, and 1-byte storage codes

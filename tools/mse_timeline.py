@@ -5,7 +5,7 @@ import csv, statistics, sys
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
 calls, cur = [], None
 for r in rows:
-    name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
+    name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
     if name.startswith("k_stage1"):
         cur = []
     if cur is not None and name.startswith("k_"):
