@@ -331,7 +331,9 @@ class LineSearchEstimator(RangeEstimatorBase):
         super().__init__(*args, **kwargs)
         assert opt_method in OptMethod
         if opt_method != OptMethod.grid:
-            raise NotImplementedError("only the grid search is on the GPU path")
+            # range_estimators.py:186-196 names _golden_section_symmetric / _golden_section_asymmetric for this option,
+            # but the reference defines neither (nor _perform_2D_search): it ends in AttributeError on the first batch
+            raise NotImplementedError("only the grid search exists (the reference names golden-section methods it never defines)")
         if self.quantizer is None:
             raise NotImplementedError("A Quantizer must be given as an argument to the MSE RangeEstimator")
         self.opt_method = opt_method
