@@ -8,7 +8,7 @@
 //     sum over a cell of (k - q)^2 = S2 - 2 q S1 + n q^2     with n, S1 = sum k, S2 = sum k^2 of the cell's keys.
 // All cells of all candidates are unions of the INTERVALS between consecutive cell borders (~15 K borders for 111
 // candidates, ~100 K for 666), so what is needed is n / S1 / S2 per interval -- a histogram with moments, not a sort:
-//   1. k_mse_borders  one workgroup per candidate: the exact border of every cell -- the smallest float for which the
+//   1. borders_body   one workgroup per candidate (k_stage1): the exact border of every cell -- the smallest float for which the
 //                     reference's own fp32 decisions (floor(fl32(log2 k) + bias) >= p, rint(fl32(k / s_p)) >= r,
 //                     k > maxval) flip, located by guess-and-walk on the exact predicates -- and the cell's grid value.
 //   2. part_hist / part_scatter   ONE most-significant-digit partition of the nonzero keys by their top 11 bits
@@ -1264,7 +1264,7 @@ HistLayout hist_layout(int64_t n, int64_t n_pairs, int stride, int bcap, int sli
     L.nsb = cdiv(L.ni + 1, kSuper);
     // units: sum over the buckets of chunks x slices <= (sum of slices) x (largest chunk count).  A candidate has at most
     // 2^M / 4 + 3 borders in one coarse bucket (an eighth of a binade: bucket length / s_p < 2^M / 4), and 2^M <= stride / 3;
-    // should a bucket ever hold more, k_mse_plan raises the overflow flag and every table entry of the call becomes NaN
+    // should a bucket ever hold more, plan_body raises the overflow flag and every table entry of the call becomes NaN
     const int64_t per_bucket = n_pairs * (stride / 12 + 4);
     const int64_t max_chunks = cdiv(per_bucket, bcap) + 1, max_slices = cdiv(n, slice_min) + kHBuckets;
     const int64_t um = max_chunks * max_slices;
