@@ -25,14 +25,17 @@ def _line(stdout):
 
 def test_bare_multi_gpu_invocation_starts_its_ranks_cpu():
     """`python bench.py --gpus 2` with no launcher must start 2 ranks itself (it used to sys.exit with a hint).  Without a
-    GPU every rank then refuses -- the engine has no CPU path -- which is visible as one refusal PER RANK and a
-    non-zero exit code."""
+    GPU a rank then refuses -- the engine has no CPU path -- and the launcher's failure report (ChildFailedError naming
+    bench.py) shows that the ranks were started by torch.distributed.run; exit code non-zero.  (The launcher stops the
+    other rank as soon as the first one has failed, so the second refusal is not always printed.)"""
     import torch
     if torch.cuda.is_available():
         pytest.skip("CPU-side check of the launcher; the GPU box runs the real thing below")
     r = _run(["--gpus", "2", "--backend", "gloo", "--steps", "1", "--warmup", "0"], 600)
     assert r.returncode != 0
-    assert (r.stdout + r.stderr).count("bench.py needs a GPU") >= 2, (r.stdout + r.stderr)[-3000:]
+    out = r.stdout + r.stderr
+    assert out.count("bench.py needs a GPU") >= 1, out[-3000:]
+    assert "ChildFailedError" in out and "bench.py FAILED" in out, out[-3000:]
     assert "launch with: python -m torch.distributed.run" not in r.stdout + r.stderr
 
 
