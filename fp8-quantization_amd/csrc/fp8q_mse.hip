@@ -23,13 +23,14 @@ struct MseArgs {
     int n_cand;
     int cgroups;   // ceil(n_cand / 128)
     int nsplit;
+    int tile;      // k_mse_grid: elements of a row per workgroup and trip (<= kMseTile, a multiple of 32): mse_tile()
     int64_t inner;
     int64_t C;
 };
 
 __global__ void __launch_bounds__(kMseBlock)
 k_mse_grid(const float *__restrict__ x, const float *__restrict__ grid, double *__restrict__ ws,
-           MseArgs a)
+           MseArgs a, float *__restrict__ mses, double inv_inner)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *xs = reinterpret_cast<float *>(smem);
@@ -83,10 +84,11 @@ k_mse_grid(const float *__restrict__ x, const float *__restrict__ grid, double *
     const float tie_thr = 0.5f - 5.0f * __builtin_ldexpf(1.0f, (int)f.M - 23);   // (kTieW of the row kernel; f.M <= 16)
     double acc = 0.0;
 
-    for (int64_t t0 = (int64_t)split * kMseTile; t0 < a.inner; t0 += (int64_t)a.nsplit * kMseTile) {
-        const int n = (int)((a.inner - t0) < kMseTile ? (a.inner - t0) : kMseTile);
+    const int tile = a.tile;
+    for (int64_t t0 = (int64_t)split * tile; t0 < a.inner; t0 += (int64_t)a.nsplit * tile) {
+        const int n = (int)((a.inner - t0) < tile ? (a.inner - t0) : tile);
         __syncthreads();
-        for (int i = tid; i < kMseTile; i += kMseBlock) xs[i] = i < n ? xr[t0 + i] : 0.0f;
+        for (int i = tid; i < tile; i += kMseBlock) xs[i] = i < n ? xr[t0 + i] : 0.0f;
         __syncthreads();
         // zero padding: q(0) = 0 exactly, contributes nothing (the exact-division path masks it: there q(0) can be NaN)
         const int n32 = (n + 31) & ~31;
@@ -134,7 +136,13 @@ k_mse_grid(const float *__restrict__ x, const float *__restrict__ grid, double *
             acc += (double)pa;
         }
     }
-    if (active) ws[((c * a.n_m + m) * a.n_cand + cand) * a.nsplit + split] = acc;
+    if (!active) return;
+    // a row that one workgroup covers (nsplit == 1: depthwise and narrow pointwise weights, half of MobileNetV2's tensors)
+    // needs no second launch: the table entry is this lane's alone -- the same (float)(sum * inv_inner) k_mse_final_tile forms
+    if (a.nsplit == 1)
+        mses[((int64_t)m * a.n_cand + cand) * a.C + c] += (float)((0.0 + acc) * inv_inner);
+    else
+        ws[((c * a.n_m + m) * a.n_cand + cand) * a.nsplit + split] = acc;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -782,10 +790,28 @@ int fp8q_mse_select_f32(const float *mses, const float *grid, int64_t C, int64_t
     return launch_rc();
 }
 
+// k_mse_grid's tile: a lane walks its candidate over a whole tile, one element after the other (~0.085 us per element when
+// a SIMD holds a single wave: dependent LDS lookups), so a per-channel weight with few channels and rows of a few hundred
+// elements -- MobileNetV2's [160, 960] pointwise convolutions: 160 workgroups, 82 us -- left most of the chip idle.  Rows
+// are cut finer (down to 64 elements) until the launch has ~4096 workgroups; every cut repeats the candidate set-up.
+static int mse_tile(int64_t C, int64_t inner, int64_t n_cand, int n_m)
+{
+    static const int env = [] {   // FP8Q_MSE_GRID_TILE=2048: whole rows per workgroup, as before round 5 (A/B)
+        const char *e = getenv("FP8Q_MSE_GRID_TILE");
+        const int v = e ? atoi(e) : 0;
+        return v >= 32 && v <= kMseTile ? (v & ~31) : 0;
+    }();
+    if (env) return env;
+    const int64_t base = C * n_m * cdiv(n_cand, kMseBlock);
+    int tl = kMseTile;
+    while (tl > 64 && base * cdiv(inner, tl) < 4096) tl >>= 1;
+    return tl;
+}
+
 static int mse_nsplit(int64_t C, int64_t inner, int64_t n_cand, int n_m)
 {
     const int64_t cg = cdiv(n_cand, kMseBlock);
-    int64_t ns = cdiv(inner, kMseTile);
+    int64_t ns = cdiv(inner, mse_tile(C, inner, n_cand, n_m));
     int64_t cap = (4 * kTargetBlocks) / (C * n_m * cg > 0 ? C * n_m * cg : 1);
     if (cap < 1) cap = 1;
     if (ns > cap) ns = cap;
@@ -873,6 +899,7 @@ int fp8q_mse_grid_f32(const float *x, int64_t C, int64_t inner, const float *gri
     a.n_cand = (int)n_cand;
     a.cgroups = (int)cdiv(n_cand, kMseBlock);
     a.nsplit = mse_nsplit(C, inner, n_cand, n_m);
+    a.tile = mse_tile(C, inner, n_cand, n_m);
     a.inner = inner;
     a.C = C;
     hipStream_t st = (hipStream_t)stream;
@@ -893,7 +920,8 @@ int fp8q_mse_grid_f32(const float *x, int64_t C, int64_t inner, const float *gri
             if (e != hipSuccess) return (int)e;
         }
         hipLaunchKernelGGL(k_mse_grid, dim3((unsigned)a.nsplit, (unsigned)(n_m * a.cgroups), (unsigned)C),
-                           dim3(kMseBlock), shmem, st, x, grid, (double *)ws, a);
+                           dim3(kMseBlock), shmem, st, x, grid, (double *)ws, a, mses, 1.0 / (double)inner);
+        if (a.nsplit == 1) return launch_rc();
     }
     if (int rc = launch_rc()) return rc;
     const int64_t rows = C * n_m * n_cand;
