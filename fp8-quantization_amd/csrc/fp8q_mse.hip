@@ -93,46 +93,89 @@ k_mse_grid(const float *__restrict__ x, const float *__restrict__ grid, double *
         // zero padding: q(0) = 0 exactly, contributes nothing (the exact-division path masks it: there q(0) can be NaN)
         const int n32 = (n + 31) & ~31;
         for (int j = 0; j < n32; j += 32) {
-            float pa = 0.0f;
+            // Branch-free pass over the group: the fast quotient for every element + how close any of them came to a tie.
+            // (One compare-and-branch per element -- v_cmp -> s_and_saveexec -> s_cbranch, a VALU -> SALU round trip the
+            // next element's work cannot overlap at the 2 waves per SIMD the per-lane tables allow -- made the loop ~3x
+            // slower than its 13 VALU operations.)  A lane whose sub-group held a near-tie, or whose candidate needs the exact
+            // division, repeats it element by element below with the reference's own division.
+            // Four sub-groups of 8 elements, each with its own partial sum and tie distance: a redo costs 8 elements, not 32
+            // (the search grid's last candidate puts the row's largest element on a tie for M = 1, 3, 5 -- every row pays
+            // one redo --, and at M = 6 / 7 a tenth of all 32-element groups would hold a near-tie in some lane).
+            float ps[4], nd[4];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const float4 v = *reinterpret_cast<const float4 *>(xs + j + u * 4);
-                const float e[4] = {v.x, v.y, v.z, v.w};
+            for (int g = 0; g < 4; ++g) {
+                float pa = 0.0f, dmax = exact_div ? __builtin_inff() : 0.0f;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float xv = e[q];
-                    const float xc = __builtin_amdgcn_fmed3f(xv, ch.minv, ch.maxv);
-                    const float tt = xc * c1;
-                    int e8 = (int)__builtin_amdgcn_ubfe(__float_as_uint(tt), 23u, 8u);
-                    e8 = max(min(e8, e_hi), e_lo);
-                    float sc = lutk[e8];
-                    // E = 0 (mantissa bits = n_bits - sign_bits): maxval / s_1 = 2^M - 0.5 is an exact TIE, so every
-                    // clipped element sits on one and the fp32 rounding of the quotient decides all of them at
-                    // once: there the IEEE division of the reference is reproduced (uniform branch per block)
-                    float r;
-                    if (__builtin_expect(exact_div, 0)) {
-                        // (bias > 128: binade 1 lies below the exponent field's range, a zero or tiny t would read
-                        // e8 = 0 as binade bi - 127 -- K1's exact decision instead)
-                        const float ls = __builtin_amdgcn_fmed3f(floorf(log2_tab(fabsf(xc), kFastTab) + ch.bias), 1.0f, (float)f.pmax);
-                        sc = lut[(int)ls];
-                        r = rintf(xc / sc);
-                        if (j + u * 4 + q >= n) r = sc = 0.0f;   // zero padding: here q(0) may be NaN (s_1 = 0), a real zero's is
-                    } else {
+                for (int u = 0; u < 2; ++u) {
+                    const float4 v = *reinterpret_cast<const float4 *>(xs + j + g * 8 + u * 4);
+                    const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float xv = e[q];
+                        const float xc = __builtin_amdgcn_fmed3f(xv, ch.minv, ch.maxv);
+                        const float tt = xc * c1;
+                        int e8 = (int)__builtin_amdgcn_ubfe(__float_as_uint(tt), 23u, 8u);
+                        e8 = max(min(e8, e_hi), e_lo);
+                        const float sc = lutk[e8];
                         const float qf = ldexpf(tt, jk - e8);
-                        r = rintf(qf);
-                        // within kTieW ulps of a rounding tie (t carries up to 4 ulps of error against the reference's quotient):
-                        // the reference's own binade decision and division for this element (rare: ~1e-5 2^M of the
-                        // (element, candidate) pairs)
-                        if (__builtin_expect(fabsf(qf - r) >= tie_thr, 0)) {
-                            const float ls = __builtin_amdgcn_fmed3f(floorf(log2_tab(fabsf(xc), kFastTab) + ch.bias), 1.0f, (float)f.pmax);
-                            sc = lut[(int)ls];
-                            r = rintf(xc / sc);
+                        const float r = rintf(qf);
+                        dmax = fmaxf(dmax, fabsf(qf - r));      // (a NaN quotient is not "near": it takes the fast formula, as before)
+                        const float d = xv - r * sc;
+                        pa = fmaf(d, d, pa);
+                    }
+                }
+                ps[g] = pa;
+                nd[g] = dmax;
+            }
+            if (__builtin_expect(fmaxf(fmaxf(nd[0], nd[1]), fmaxf(nd[2], nd[3])) >= tie_thr, 0)) {
+#pragma unroll 1
+                for (int g = 0; g < 4; ++g) {
+                    const float dmax = g == 0 ? nd[0] : g == 1 ? nd[1] : g == 2 ? nd[2] : nd[3];
+                    if (!(dmax >= tie_thr)) continue;
+                    float pa = 0.0f;
+#pragma unroll 1
+                    for (int u = 0; u < 2; ++u) {
+                        const float4 v = *reinterpret_cast<const float4 *>(xs + j + g * 8 + u * 4);
+                        const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float xv = e[q];
+                            const float xc = __builtin_amdgcn_fmed3f(xv, ch.minv, ch.maxv);
+                            const float tt = xc * c1;
+                            int e8 = (int)__builtin_amdgcn_ubfe(__float_as_uint(tt), 23u, 8u);
+                            e8 = max(min(e8, e_hi), e_lo);
+                            float sc = lutk[e8];
+                            // E = 0 (mantissa bits = n_bits - sign_bits): maxval / s_1 = 2^M - 0.5 is an exact TIE, so every
+                            // clipped element sits on one and the fp32 rounding of the quotient decides all of them at
+                            // once: there the IEEE division of the reference is reproduced
+                            float r;
+                            if (exact_div) {
+                                // (bias > 128: binade 1 lies below the exponent field's range, a zero or tiny t would read
+                                // e8 = 0 as binade bi - 127 -- K1's exact decision instead)
+                                const float ls = __builtin_amdgcn_fmed3f(floorf(log2_tab(fabsf(xc), kFastTab) + ch.bias), 1.0f, (float)f.pmax);
+                                sc = lut[(int)ls];
+                                r = rintf(xc / sc);
+                                if (j + g * 8 + u * 4 + q >= n) r = sc = 0.0f;   // zero padding: here q(0) may be NaN (s_1 = 0), a real zero's is
+                            } else {
+                                const float qf = ldexpf(tt, jk - e8);
+                                r = rintf(qf);
+                                // within kTieW ulps of a rounding tie (t carries up to 4 ulps of error against the reference's
+                                // quotient): the reference's own binade decision and division for this element (rare:
+                                // ~1e-5 2^M of the (element, candidate) pairs)
+                                if (fabsf(qf - r) >= tie_thr) {
+                                    const float ls = __builtin_amdgcn_fmed3f(floorf(log2_tab(fabsf(xc), kFastTab) + ch.bias), 1.0f, (float)f.pmax);
+                                    sc = lut[(int)ls];
+                                    r = rintf(xc / sc);
+                                }
+                            }
+                            const float d = xv - r * sc;
+                            pa = fmaf(d, d, pa);
                         }
                     }
-                    const float d = xv - r * sc;
-                    pa = fmaf(d, d, pa);
+                    if (g == 0) ps[0] = pa; else if (g == 1) ps[1] = pa; else if (g == 2) ps[2] = pa; else ps[3] = pa;
                 }
             }
+            const float pa = (ps[0] + ps[1]) + (ps[2] + ps[3]);
             acc += (double)pa;
         }
     }
