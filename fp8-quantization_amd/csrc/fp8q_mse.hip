@@ -8,10 +8,11 @@ namespace {
 // One lane = one candidate maxval; every lane walks the SAME x tile, broadcast out of LDS, so a
 // candidate's squared error accumulates in one register and no cross-lane reduction exists.
 // Block = 128 lanes (candidates i0..i0+127 of one mantissa width m, one row c, one split of the
-// row).  Per-candidate scale LUT (and its reciprocal) in LDS, built with scale_exact(): the
-// scales are the same numbers K1 uses; rint(xc * (1/s)) differs from rint(xc / s) only at exact
-// ties, where |x - q| is the same either way.
-// Dynamic LDS: float xs[kMseTile] | float lut[128 * stride] | float ilut[128 * stride]
+// row: MseArgs::tile elements per trip, mse_tile()).  Per-candidate scale table s_p in LDS, the
+// same numbers K1 uses (scale_exact() / its ldexp shortcut); the quotient is formed from the bits
+// of xc * 2^bf and every element within 5 ulps of a rounding tie is redone with the reference's
+// own binade decision and IEEE division (see the loop).
+// Dynamic LDS: float xs[kMseTile] | float lut[128 * stride], stride = (pmax + 1) | 1
 // ---------------------------------------------------------------------------------------------
 constexpr int kMseBlock = 128;
 constexpr int kMseTile = 2048;
