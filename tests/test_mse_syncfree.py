@@ -56,7 +56,8 @@ def test_linspace_falls_back_to_the_host_when_the_kernel_formula_does_not_match(
     assert torch.equal(grid.cpu().view(torch.int32), want.view(torch.int32))
 
 
-@pytest.mark.parametrize("C,n_m,n_cand", [(1, 6, 111), (1, 1, 111), (32, 6, 111), (1280, 6, 111), (5, 3, 7), (2049, 2, 130)])
+@pytest.mark.parametrize("C,n_m,n_cand", [(1, 6, 111), (1, 1, 111), (32, 6, 111), (1280, 6, 111), (5, 3, 7), (2049, 2, 130), (16, 2, 9),
+                                           (17, 2, 4), (64, 1, 111), (65, 6, 5)])
 def test_select_kernel_equals_torch_ops(C, n_m, n_cand):
     import fp8q
     rng = np.random.RandomState(C + n_m)
