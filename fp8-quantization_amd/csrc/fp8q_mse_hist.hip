@@ -29,8 +29,8 @@
 //                     the signal energy), fixed-tree sum, mses += mean.
 // Every element is classified exactly as K1 / the oracle classify it; what differs from the reference is only that
 // (k - q)^2 is summed in (near-)exact arithmetic instead of fp32-rounded per element: ~1e-7 relative, inside K4's stated
-// contract (include/fp8q.h).  Cost for a 25.7 M-element activation: ~8 B of HBM traffic per key for the partition + 4 B for
-// the moments, independent of the number of candidates.  No library primitive: everything here is hand-written.
+// contract (include/fp8q.h).  Cost for a 25.7 M-element activation: 12 B of HBM traffic per key for the partition (histogram pass 4, scatter
+// 4 + 4) + 4 B for the moments, independent of the number of candidates.  No library primitive: everything here is hand-written.
 #include "fp8q_common.h"
 
 namespace {
