@@ -53,6 +53,29 @@ def test_argument_validation_without_gpu():
     assert L.fp8q_fused_max_inner() >= 4608                                           # largest ResNet-18 filter
 
 
+def test_mse_partial_sum_workspace_follows_the_row_cut():
+    """fp8q_mse_workspace_bytes is pure host logic: the lane-per-candidate kernel (rows < 2048 elements) cuts a row into tiles
+    of 2048 ... 64 elements until the launch has ~4096 workgroups (csrc/fp8q_mse.hip:mse_tile) and keeps one double per
+    (channel, width, candidate, split); rows that one workgroup covers need no partial sums beyond the 16-byte floor."""
+    import fp8q
+    L = fp8q.lib()
+
+    def expect(C, inner, n_cand, n_m):
+        base = C * n_m * -(-n_cand // 128)
+        tile = 2048
+        while tile > 64 and base * -(-inner // tile) < 4096:
+            tile //= 2
+        ns = max(1, min(-(-inner // tile), max(1, 8192 // base)))
+        return C * n_m * n_cand * ns * 8 + 16
+
+    for C, inner, n_cand, n_m in [(160, 960, 111, 1), (960, 9, 111, 1), (1000, 1280, 111, 1), (1000, 1280, 111, 6), (64, 384, 111, 1),
+                                  (32, 27, 111, 6), (1280, 320, 111, 1), (5, 2047, 300, 2)]:
+        assert L.fp8q_mse_workspace_bytes(C, inner, n_cand, n_m) == expect(C, inner, n_cand, n_m), (C, inner, n_cand, n_m)
+    assert expect(160, 960, 111, 1) == 160 * 111 * 15 * 8 + 16          # [160, 960] pointwise weights: 15 tiles of 64 elements
+    assert expect(960, 9, 111, 1) == 960 * 111 * 8 + 16                 # depthwise: one split (the kernel writes the table itself)
+    assert L.fp8q_mse_workspace_bytes(0, 5, 111, 1) == 16
+
+
 def test_no_cpu_fallback():
     import fp8q
     from quantization.quantizers.fp8_quantizer import FPQuantizer
