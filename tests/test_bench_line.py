@@ -39,6 +39,19 @@ def test_bare_multi_gpu_invocation_starts_its_ranks_cpu():
     assert "launch with: python -m torch.distributed.run" not in r.stdout + r.stderr
 
 
+def test_dry_run_eight_ranks_cpu():
+    """the world size the driver's scaling run ends with: 8 gloo ranks walk the same call sequence; a rank ships 1/8 of the
+    model as 1-byte codes in ONE all-gather and the calibration flow still has exactly one 16-byte all-reduce"""
+    r = _run(["--dry-run-ranks", "8"], 900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"dry_run"' in ln][0])
+    assert d["ranks"] == 8 and d["ranks_seen"] == 8
+    seq = d["call_sequence_as_executed"]
+    r18 = seq["resnet18_weights_one_allgather: quantize_weights_sharded_bucketed (REAL shapes)"]
+    assert len(r18) == 1 and r18[0]["dtype"] == "uint8" and abs(r18[0]["send_bytes"] - (11678912 + 4800 * 4) / 8) < 0.01 * 11678912 / 8
+    assert seq["c5: calibrate_quantize_sharded"] == [dict(op="all_reduce", dtype="float32", send_bytes=16, reduce="MAX")]
+
+
 def test_dry_run_ranks_prints_the_call_sequence_cpu():
     """`python bench.py --dry-run-ranks 4`: no GPU, 4 gloo ranks, the N-rank call sequence of the bench (headline flow,
     codes variant, ResNet-18 bucketed all-gather at its real shapes, config 5) with every collective's byte count."""
