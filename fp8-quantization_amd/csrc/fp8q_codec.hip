@@ -87,7 +87,8 @@ static int codec_launch(bool encode, const float *x, uint8_t *codes, float *y, i
                         const float *maxval, int64_t n_maxval, float mbits, int n_bits, int sign_bits,
                         fp8q_stream_t stream)
 {
-    if (C < 0 || inner < 0 || (n_maxval != 1 && n_maxval != C) || n_bits > 8) return FP8Q_EINVAL;
+    if (C < 0 || inner < 0 || (n_maxval != 1 && n_maxval != C)) return FP8Q_EINVAL;
+    if (n_bits > 8) return FP8Q_EUNSUPPORTED;   // a code is one byte (include/fp8q.h)
     QFmt f;
     if (int rc = make_fmt(mbits, n_bits, sign_bits, &f)) return rc;
     if (n_bits - sign_bits - (int)f.M < 1) return FP8Q_EUNSUPPORTED;   // no exponent bit: 2^(M+1) steps do not fit M bits

@@ -979,4 +979,48 @@ int fp8q_mse_grid_f32(const float *x, int64_t C, int64_t inner, const float *gri
     return launch_rc();
 }
 
+size_t fp8q_mse_calibrate_workspace_bytes(int64_t C, int64_t inner, int64_t n_cand, int n_m, size_t *minmax_bytes, size_t *select_bytes)
+{
+    if (minmax_bytes) *minmax_bytes = fp8q_minmax_workspace_bytes(C, inner);
+    if (select_bytes) *select_bytes = fp8q_mse_select_workspace_bytes(C, n_m);
+    return fp8q_mse_workspace_bytes(C, inner, n_cand, n_m);
+}
+
+// QuantizationManager.forward in estimate_ranges state with FP_MSE_Estimator (quantization_manager.py:114-122 around
+// range_estimators.py:318-369) as ONE call into the library: what used to be four entry points called from Python
+// (fp8q_minmax_linspace_f32, fp8q_mse_grid_f32, fp8q_mse_select_f32, fp8q_quantize[_dm]_f32: ~45 us of host time each
+// through ctypes + torch allocations) is enqueued from here; the host side of a calibration batch was the critical path
+// of BASELINE config 4 (profiles/r06_host_profile.txt).
+int fp8q_mse_calibrate_f32(const float *x, float *y, int64_t C, int64_t inner, const fp8q_mse_state *s, int first, int n_cand,
+                           const float *mbits_host, int n_m, int n_bits, int sign_bits, void *ws_minmax, size_t ws_minmax_bytes,
+                           void *ws_select, size_t ws_select_bytes, void *ws_mse, size_t ws_mse_bytes, fp8q_stream_t stream)
+{
+    if (!s || !x || !s->grid || !s->mses || !s->maxval || !s->mbits || !mbits_host || C <= 0 || inner <= 0 || n_cand < 2 ||
+        n_m <= 0 || n_m > kMseMaxM)
+        return FP8Q_EINVAL;
+    for (int m = 0; m < n_m; ++m) {   // every format is checked before the first launch
+        QFmt f;
+        if (int rc = make_fmt(mbits_host[m], n_bits, sign_bits, &f)) return rc;
+    }
+    if (C > 65535) return FP8Q_ETOOMANY;
+    if (!ws_mse || ws_mse_bytes < fp8q_mse_workspace_bytes(C, inner, n_cand, n_m) || ((uintptr_t)ws_mse & 7)) return FP8Q_EWORKSPACE;
+    if (!ws_select || ws_select_bytes < fp8q_mse_select_workspace_bytes(C, n_m) || ((uintptr_t)ws_select & 3)) return FP8Q_EWORKSPACE;
+    if (first) {
+        // max|x| per row, the search grid of that maximum, and the cleared table -- one launch (:295-316)
+        if (!s->cur_min || !s->cur_max || !s->absmax) return FP8Q_EINVAL;
+        if (int rc = fp8q_minmax_linspace_zero_f32(x, C, inner, s->cur_min, s->cur_max, s->absmax, s->grid, n_cand, 0.1, 1.2, s->mses,
+                                                   n_m * n_cand, ws_minmax, ws_minmax_bytes, stream))
+            return rc;
+    }
+    if (int rc = fp8q_mse_grid_f32(x, C, inner, s->grid, n_cand, mbits_host, n_m, n_bits, sign_bits, s->mses, ws_mse, ws_mse_bytes, stream))
+        return rc;
+    if (int rc = fp8q_mse_select_f32(s->mses, s->grid, C, n_cand, mbits_host, n_m, sign_bits, s->mbits, s->vote, s->maxval, s->xmin,
+                                     ws_select, ws_select_bytes, stream))
+        return rc;
+    if (!y) return FP8Q_OK;
+    // the batch itself, with the range (and width) just chosen (:119-122: estimate, set the range, then quantize)
+    if (n_m == 1) return fp8q_quantize_f32(x, y, C, inner, s->maxval, C, mbits_host[0], n_bits, sign_bits, stream);
+    return fp8q_quantize_dm_f32(x, y, C, inner, s->maxval, C, s->mbits, n_bits, sign_bits, stream);
+}
+
 }  // extern "C"

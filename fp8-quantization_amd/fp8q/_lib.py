@@ -14,6 +14,12 @@ _i = ctypes.c_int
 
 
 
+class MseState(ctypes.Structure):
+    """fp8q_mse_state (include/fp8q.h): device pointers of one MSE estimator's persistent state"""
+    _fields_ = [("cur_min", _vp), ("cur_max", _vp), ("absmax", _vp), ("grid", _vp), ("mses", _vp), ("maxval", _vp),
+                ("xmin", _vp), ("mbits", _vp), ("vote", _vp)]
+
+
 class TensorDesc(ctypes.Structure):
     """fp8q_tensor_desc (include/fp8q.h)"""
     _fields_ = [("x", _vp), ("y", _vp), ("maxval", _vp), ("C", _i64), ("inner", _i64), ("n_maxval", _i64),
@@ -43,6 +49,12 @@ SIGNATURES = {
     "fp8q_mse_select_f32": (_i, [_vp, _vp, _i64, _i64, ctypes.POINTER(_f), _i, _i, _vp, _vp, _vp, _vp, _vp,
                                  ctypes.c_size_t, _vp]),
     "fp8q_quantize_dm_f32": (_i, [_vp, _vp, _i64, _i64, _vp, _i64, _vp, _i, _i, _vp]),
+    "fp8q_minmax_linspace_zero_f32": (_i, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _i, ctypes.c_double, ctypes.c_double, _vp, _i,
+                                           _vp, ctypes.c_size_t, _vp]),
+    "fp8q_mse_calibrate_workspace_bytes": (ctypes.c_size_t, [_i64, _i64, _i64, _i, ctypes.POINTER(ctypes.c_size_t),
+                                                             ctypes.POINTER(ctypes.c_size_t)]),
+    "fp8q_mse_calibrate_f32": (_i, [_vp, _vp, _i64, _i64, ctypes.POINTER(MseState), _i, _i, ctypes.POINTER(_f), _i, _i, _i,
+                                    _vp, ctypes.c_size_t, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t, _vp]),
     "fp8q_quantize_f64": (_i, [_vp, _vp, _i64, _i64, _vp, _i64, _f, _i, _i, _vp]),
     "fp8q_minmax_f64_workspace_bytes": (ctypes.c_size_t, [_i64, _i64]),
     "fp8q_minmax_f64": (_i, [_vp, _i64, _i64, _vp, _vp, _vp, ctypes.c_size_t, _vp]),

@@ -59,6 +59,18 @@ def _local_minmax_quantize(ops, shard, mbits, n_bits, sign_bits, out=None):
     return ops.quantize(shard, mv, mbits, n_bits, sign_bits, out=out), mv
 
 
+def codes_wire_ok(mbits, n_bits, sign_bits):
+    """True when the format has a 1-byte storage code (fp8q_encode_u8: n_bits <= 8 and at least one exponent bit).  K1 and the
+    reference's clamp (fp8_quantizer.py:105-106: M = clamp(round(mbits), 1, n_bits - sign_bits)) also accept E = 0 -- a plain
+    fixed-point grid --, which the codec refuses (FP8Q_EUNSUPPORTED): such formats travel as fp32 values."""
+    if n_bits > 8:
+        return False
+    import numpy as np
+    hi = n_bits - sign_bits
+    m = int(min(max(float(np.round(np.float32(mbits))), 1.0), float(hi)))       # round half to even, as torch.round
+    return hi - m >= 1
+
+
 def channel_partition(n_channels, world_size):
     """[lo, hi) of every rank; the first (C mod W) ranks get one extra channel."""
     base, extra = divmod(n_channels, world_size)
@@ -295,7 +307,7 @@ def quantize_weights_sharded_bucketed(weights, mbits, n_bits=8, sign_bits=1, gro
     unpacking.  Result per tensor identical to quantize_weight_sharded.  Returns [(w_q, maxval), ...]."""
     ops = ops or _default_ops()
     if wire is None:
-        wire = "codes" if (_multi(group) and n_bits <= 8 and hasattr(ops, "encode")) else "fp32"
+        wire = "codes" if (_multi(group) and hasattr(ops, "encode") and codes_wire_ok(mbits, n_bits, sign_bits)) else "fp32"
     if wire not in ("codes", "fp32"):
         raise ValueError(f"wire must be 'codes' or 'fp32', got {wire!r}")
     if wire == "codes":

@@ -615,7 +615,7 @@ def mse_select(mses, grid, mbits_list, sign_bits=1):
     n_cand, C = grid.shape
     dev = mses.device
     out = torch.empty((2, C), dtype=torch.float32, device=dev)
-    mb = torch.empty(1, dtype=torch.float32, device=dev)
+    mb = vote_slot(dev)                  # the device's vote arena: fix_ranges() brings every pending width over in one copy
     vote = torch.empty(1, dtype=torch.int32, device=dev)
     L = lib()
     ws = _workspace(dev, L.fp8q_mse_select_workspace_bytes(C, n_m), kind="select")     # (zero header: the last-workgroup ticket)
@@ -626,6 +626,123 @@ def mse_select(mses, grid, mbits_list, sign_bits=1):
                                    _stream(mses))
     check(rc, "fp8q_mse_select_f32")
     return mb, vote, out[0], out[1]
+
+
+# ---- mantissa-width votes: one arena per device --------------------------------------------------------------------------
+# Every MSE estimator's voted width is a device scalar that the host wants exactly once, at fix_ranges().  Scalars that live
+# in ONE buffer come over with one device-to-host copy (QuantizedModel.fix_ranges: materialize_mantissa_bits); gathering 116
+# separately allocated scalars needed a torch.cat, whose kernel alone took 16 ms to load the first time a process used it.
+_VOTE_SLOTS = 4096
+_vote_arenas = {}      # device index -> [buffer, next free slot]
+_vote_buffers = []     # every arena buffer still referenced by a view (weak): (weakref, base address)
+
+
+def vote_slot(device):
+    """A [1] float32 view into the device's vote arena (a fresh arena when the current one is full)."""
+    import weakref
+    ent = _vote_arenas.get(device.index)
+    if ent is None or ent[1] >= _VOTE_SLOTS:
+        buf = torch.zeros(_VOTE_SLOTS, dtype=torch.float32, device=device)
+        ent = _vote_arenas[device.index] = [buf, 0]
+        _vote_buffers[:] = [(r, a) for r, a in _vote_buffers if r() is not None]
+        _vote_buffers.append((weakref.ref(buf), buf.data_ptr()))
+    i = ent[1]
+    ent[1] = i + 1
+    return ent[0][i:i + 1]
+
+
+def vote_arena_of(t):
+    """(arena buffer, slot) if the 1-element CUDA float32 tensor t lies in a vote arena (vote_slot), else None.  By address:
+    an arena's range belongs to it for as long as the buffer is alive, whatever chain of views / detach() led to t."""
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.numel() == 1):
+        return None
+    p = t.data_ptr()
+    for r, addr in _vote_buffers:
+        if addr <= p < addr + 4 * _VOTE_SLOTS:
+            buf = r()
+            if buf is not None and buf.device == t.device:
+                return buf, (p - addr) // 4
+    return None
+
+
+_cal_ws_bytes = {}
+
+
+class MseCalibration:
+    """The persistent device state of one FP_MSE_Estimator and its quantizer, bound once, stepped with ONE library call per
+    batch (fp8q_mse_calibrate_f32): abs-max + search grid (first batch), the MSE table of every (width, candidate), the
+    vote / argmin, and the quantization of the batch with the winner -- QuantizationManager.forward in estimate state
+    (quantization_manager.py:114-122 around range_estimators.py:318-369).  One allocation holds every result vector:
+      block = [cur_min | cur_max | absmax | maxval | xmin] (5 C) | grid (n_cand C) | mses (n_m n_cand C) | vote (1, int32)
+    The voted width lives in the device's vote arena (vote_slot)."""
+
+    def __init__(self, C, device, mbits_list, n_bits, sign_bits, n_cand=111, grid=None, mses=None):
+        import ctypes
+        from ._lib import MseState
+        self.C, self.n_cand, self.n_m = int(C), int(n_cand), len(mbits_list)
+        self.n_bits, self.sign_bits = int(n_bits), int(sign_bits)
+        self.mbits_list = [float(v) for v in mbits_list]
+        C, n_m = self.C, self.n_m
+        adopt = grid is not None and mses is not None
+        n_tab = 0 if adopt else (n_cand * C + n_m * n_cand * C)
+        blk = torch.empty(5 * C + n_tab + 1, dtype=torch.float32, device=device)
+        self._blk = blk
+        self.cur_min, self.cur_max, self.absmax, self.maxval, self.xmin = (blk[i * C:(i + 1) * C] for i in range(5))
+        if adopt:           # tables made by the generic path (an earlier batch in another layout): keep accumulating into them
+            _require(grid, "grid")
+            _require(mses, "mses", like=grid)
+            if tuple(grid.shape) != (n_cand, C) or tuple(mses.shape) != (n_m, n_cand, C) or not grid.is_contiguous() \
+                    or not mses.is_contiguous() or grid.device != blk.device:
+                raise Fp8qError("MseCalibration: grid / mses of the wrong shape")
+            self.grid, self.mses = grid, mses
+        else:
+            self.grid = blk[5 * C:5 * C + n_cand * C].view(n_cand, C)
+            self.mses = blk[5 * C + n_cand * C:5 * C + n_tab].view(n_m, n_cand, C)
+        self.vote = blk[5 * C + n_tab:].view(torch.int32)
+        self.mbits = vote_slot(blk.device)
+        self.first = not adopt
+        self._state = MseState(self.cur_min.data_ptr(), self.cur_max.data_ptr(), self.absmax.data_ptr(), self.grid.data_ptr(),
+                               self.mses.data_ptr(), self.maxval.data_ptr(), self.xmin.data_ptr(), self.mbits.data_ptr(),
+                               self.vote.data_ptr())
+        self._sref = ctypes.byref(self._state)
+        self._mb = (ctypes.c_float * n_m)(*self.mbits_list)
+        self._fn = lib().fp8q_mse_calibrate_f32
+        self._dev = blk.device
+        self._idx = blk.device.index
+
+    def _sizes(self, inner):
+        import ctypes
+        key = (self.C, inner, self.n_cand, self.n_m)
+        sz = _cal_ws_bytes.get(key)
+        if sz is None:
+            a, b = ctypes.c_size_t(), ctypes.c_size_t()
+            c = lib().fp8q_mse_calibrate_workspace_bytes(self.C, inner, self.n_cand, self.n_m, ctypes.byref(a), ctypes.byref(b))
+            sz = _cal_ws_bytes[key] = (int(a.value), int(b.value), int(c))
+        return sz
+
+    def step(self, x, quantize=True):
+        """x: contiguous CUDA float32 with C rows (per tensor: C == 1).  Returns the quantized batch (or None)."""
+        inner = x.numel() // self.C
+        mm, sel, mse = self._sizes(inner)
+        dev = self._dev
+        ws_mm = _workspace(dev, mm, zeroed=True)
+        ws_sel = _workspace(dev, sel, kind="select")
+        ws_mse = _workspace(dev, mse)
+        y = torch.empty_like(x) if quantize else None
+        first, self.first = self.first, False
+        if torch.cuda.current_device() != self._idx:
+            with _on_device(x):
+                rc = self._fn(x.data_ptr(), y.data_ptr() if quantize else None, self.C, inner, self._sref, int(first), self.n_cand,
+                              self._mb, self.n_m, self.n_bits, self.sign_bits, ws_mm.data_ptr(), ws_mm.numel(), ws_sel.data_ptr(),
+                              ws_sel.numel(), ws_mse.data_ptr(), ws_mse.numel(), _stream(x))
+        else:
+            rc = self._fn(x.data_ptr(), y.data_ptr() if quantize else None, self.C, inner, self._sref, int(first), self.n_cand,
+                          self._mb, self.n_m, self.n_bits, self.sign_bits, ws_mm.data_ptr(), ws_mm.numel(), ws_sel.data_ptr(),
+                          ws_sel.numel(), ws_mse.data_ptr(), ws_mse.numel(), _raw_stream(self._idx) if _raw_stream is not None else _stream(x))
+        if rc:
+            self.first = first
+            check(rc, "fp8q_mse_calibrate_f32")
+        return y
 
 
 def minmax_f64(x, per_channel):

@@ -203,11 +203,59 @@ class FP_MSE_Estimator(RangeEstimatorBase):
         self.num_candidates = num_candidates
         self.mses = self.search_grid = None
         self._mbit_list = None
+        self.__dict__["_cal"] = None
 
     def reset(self):
         super().reset()
         self.mses = self.search_grid = None
         self._mbit_list = None
+        self.__dict__["_cal"] = None
+
+    # ---- the one-call calibration step (fp8q_mse_calibrate_f32) ---------------------------------------------------------
+    def one_call_ok(self, x):
+        """True when estimate + set_quant_range + quantize of this batch can run as ONE library call with the same
+        results as the protocol calls: plain FP8 quantizer that takes its range from us (set_maxval), signed-ness fixed,
+        float32 data in the layout the kernels read, single process, nothing learned."""
+        q = self.quantizer
+        return (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.numel() > 0 and x.dim() > 0
+                and q.set_maxval and not q.allow_unsigned and self.dist_group is None
+                and not q.__dict__["_parameters"]                      # maxval / mantissa_bits being learned
+                and (not self.per_channel or x.shape[0] <= 65535)
+                and not (x.requires_grad and torch.is_grad_enabled()))
+
+    def calibrate_quantize(self, x):
+        """QuantizationManager.forward for this estimator (quantization_manager.py:114-122): update the MSE tables with x,
+        choose (mantissa width, maxval), hand both to the quantizer and quantize x with them -- one ctypes call, four to
+        eleven kernel launches, no host round trip.  The estimator's observable state (`search_grid`, `mses`,
+        `last_maxval`) and the quantizer's (`maxval`, `mantissa_bits`, `_range_epoch`) end up as after
+        `xmin, xmax = est(x); q.set_quant_range(xmin, xmax); q(x)`; tensors are views of one per-estimator block that
+        the next batch updates in place."""
+        q = self.quantizer
+        qd = q.__dict__
+        C = x.shape[0] if self.per_channel else 1
+        cal = self.__dict__.get("_cal")
+        if cal is None or cal.C != C or cal.sign_bits != q.sign_bits or cal.n_bits != q.n_bits or cal.mses is not self.mses:
+            if q.mse_include_mantissa_bits:
+                mbit_list = [float(m) for m in range(1, q.n_bits - q.sign_bits)]
+            else:
+                mbit_list = [float(q.mantissa_bits)]
+            if self.mses is not None and len(mbit_list) != self.mses.shape[0]:
+                mbit_list = self._mbit_list
+            self._mbit_list = mbit_list
+            if self.mses is not None and (self.mses.dtype != torch.float32 or self.mses.device != x.device
+                                          or self.mses.shape[2] != C):
+                return None                         # tables of another kind (float64 data, another device): protocol calls
+            cal = _ops.MseCalibration(C, x.device, mbit_list, q.n_bits, q.sign_bits, self.N_GRID, self.search_grid, self.mses)
+            self.__dict__["_cal"] = cal
+            self.search_grid, self.mses = cal.grid, cal.mses
+        y = cal.step(x)
+        # what the protocol calls would leave behind (estimators.forward + set_quant_range), without nn.Module.__setattr__:
+        qd["maxval"] = cal.maxval
+        qd["_range_epoch"] = qd.get("_range_epoch", 0) + 1
+        if cal.n_m > 1:
+            qd["_mbits_dev"], qd["_mbits_host"] = cal.mbits, None       # the vote stays on the device until somebody reads it
+        self.__dict__["last_maxval"] = cal.maxval
+        return y
 
     def _dist_batch(self):
         return self._dist_active()

@@ -102,6 +102,10 @@ class QuantizationManager(nn.Module):
         fast = (type(q) is FPQuantizer and type(est) in _MINMAX and not q.allow_unsigned
                 and not getattr(est, "percentile", None) and x.is_cuda
                 and not (x.requires_grad and torch.is_grad_enabled()))   # weights are Parameters: fine under no_grad
+        if type(est) is FP_MSE_Estimator and type(q) is FPQuantizer and est.one_call_ok(x):
+            y = est.calibrate_quantize(x)            # estimate + set_quant_range + quantize: one library call
+            if y is not None:
+                return y
         if not fast:
             xmin, xmax = est(x)                      # generic protocol, reference order
             if (type(q) is FPQuantizer and type(est) is FP_MSE_Estimator and q.set_maxval and not q.allow_unsigned

@@ -32,9 +32,24 @@ def materialize_mantissa_bits(model):
     pending = [(q, t) for q, t in pending if t is not None]
     if not pending:
         return 0
-    host = torch.cat([t.detach().reshape(1).float() for _, t in pending]).cpu()
-    for (q, _), v in zip(pending, host):
-        q.__dict__["_mbits_host"] = v.reshape(1).clone()       # (not an assignment: the range epoch stays)
+    # votes written by this engine live in a per-device arena (fp8q.ops.vote_slot): ONE device-to-host copy per arena; a width
+    # that somebody else put on the device (an assigned CUDA tensor) is gathered the ordinary way
+    from fp8q import ops as _ops
+    hosts, rest = {}, []
+    for q, t in pending:
+        where = _ops.vote_arena_of(t)
+        if where is None:
+            rest.append((q, t))
+            continue
+        buf, slot = where
+        host = hosts.get(id(buf))
+        if host is None:
+            host = hosts[id(buf)] = (buf, buf.cpu())
+        q.__dict__["_mbits_host"] = host[1][slot:slot + 1].clone()       # (not an assignment: the range epoch stays)
+    if rest:
+        host = torch.cat([t.detach().reshape(1).float() for _, t in rest]).cpu()
+        for (q, _), v in zip(rest, host):
+            q.__dict__["_mbits_host"] = v.reshape(1).clone()
     return len(pending)
 
 

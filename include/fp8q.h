@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define FP8Q_VERSION 500 /* 0.5.0: K4 interval-histogram route (hand-written partition, no library sort), one-launch winner selection (zeroed workspace header) */
+#define FP8Q_VERSION 600 /* 0.6.0: one-call MSE calibration step (fp8q_mse_calibrate_f32), fused small-tensor routes */
 
 #define FP8Q_OK 0
 #define FP8Q_EINVAL (-1)       /* null pointer, negative size, n_maxval not in {1, C}, ... */
@@ -211,6 +211,43 @@ int fp8q_mse_select_f32(const float *mses, const float *grid, int64_t C, int64_t
                         size_t ws_bytes, fp8q_stream_t stream);
 int fp8q_quantize_dm_f32(const float *x, float *y, int64_t C, int64_t inner, const float *maxval, int64_t n_maxval,
                          const float *mbits_dev, int n_bits, int sign_bits, fp8q_stream_t stream);
+
+/* fp8q_minmax_linspace_f32 that also clears column c of a [zero_rows, C] fp32 table (the estimator's accumulated MSE table)
+ * from the thread that writes row c's grid: the first calibration batch needs no memset launch.  C <= 65535 (FP8Q_ETOOMANY). */
+int fp8q_minmax_linspace_zero_f32(const float *x, int64_t C, int64_t inner, float *cur_min, float *cur_max, float *maxval_out,
+                                  float *grid, int n_cand, double lo_frac, double hi_frac, float *zero_tab, int zero_rows,
+                                  void *ws, size_t ws_bytes, fp8q_stream_t stream);
+
+/*
+ * One calibration step of a quantizer whose range comes from FP_MSE_Estimator, in ONE call:
+ * QuantizationManager.forward in estimate_ranges state (quantization/quantization_manager.py:114-122) around
+ * FP_MSE_Estimator.forward (quantization/range_estimators.py:318-369) --
+ *   first != 0   row max|x| -> search grid linspace(0.1 max|x|, 1.2 max|x|, n_cand) per row, table cleared      (:295-316)
+ *   always       mses[n_m, n_cand, C] += row-mean((x - q(x; mbits[m], grid[i, c]))^2)   (fp8q_mse_grid_f32)   (:337-347)
+ *                vote of the mantissa width, per-row argmin -> state.mbits / vote / maxval / xmin (fp8q_mse_select_f32) (:350-369)
+ *   y != NULL    y = quantize(x; maxval, voted width)  (fp8q_quantize_f32 when n_m == 1, else fp8q_quantize_dm_f32)
+ * Everything is enqueued on `stream`; nothing comes back to the host.  The state is caller-owned device memory
+ * (any layout; the torch host allocates one block per estimator) and persists between the batches of a calibration.
+ * Workspaces: ws_minmax as fp8q_minmax_f32 (zeroed, left zero; only read when first != 0), ws_select as fp8q_mse_select_f32
+ * (zero header), ws_mse as fp8q_mse_grid_f32; fp8q_mse_calibrate_workspace_bytes returns the last size and writes the other two.
+ * Results are those of the four entry points called one after the other (bit for bit).
+ */
+typedef struct fp8q_mse_state {
+    float *cur_min, *cur_max; /* [C] row minimum / maximum of the first batch */
+    float *absmax;            /* [C] max|x| of the first batch: defines the grid */
+    float *grid;              /* [n_cand, C] */
+    float *mses;              /* [n_m, n_cand, C], accumulated over the batches */
+    float *maxval;            /* [C] the winner's clipping value (what set_quant_range(xmin, maxval) stores) */
+    float *xmin;              /* [C] -sign_bits * maxval; may be NULL */
+    float *mbits;             /* [1] voted mantissa width */
+    int *vote;                /* [1] its index in mbits_host; may be NULL */
+} fp8q_mse_state;
+size_t fp8q_mse_calibrate_workspace_bytes(int64_t C, int64_t inner, int64_t n_cand, int n_m, size_t *minmax_bytes,
+                                          size_t *select_bytes);
+int fp8q_mse_calibrate_f32(const float *x, float *y, int64_t C, int64_t inner, const fp8q_mse_state *state, int first,
+                           int n_cand, const float *mbits_host, int n_m, int n_bits, int sign_bits, void *ws_minmax,
+                           size_t ws_minmax_bytes, void *ws_select, size_t ws_select_bytes, void *ws_mse, size_t ws_mse_bytes,
+                           fp8q_stream_t stream);
 
 /*
  * The float64 lane -- BASELINE config 1.  compute_quant_error.py:19-20 draws float64 samples; LineSearchEstimator

@@ -397,6 +397,36 @@ def test_bucketed_weight_quantization_one_all_gather():
                 assert np.array_equal(np.isnan(q), np.isnan(ref)) and np.array_equal(q[~np.isnan(ref)], ref[~np.isnan(ref)])
 
 
+class RefusingCodecOps(OracleOps):
+    """a codec that would refuse the format (what fp8q_encode_u8 answers for a format without an exponent bit)"""
+
+    @staticmethod
+    def encode(*a, **k):
+        raise AssertionError("the codes wire was chosen for a format without an exponent bit")
+
+
+def _bucket_job_no_exponent_bit(rank, world):
+    """mantissa_bits = n_bits - sign_bits: E = 0, which K1 and the reference's clamp accept (fp8_quantizer.py:105-106) and
+    the storage codec refuses -- the default wire form must fall back to fp32 values instead of raising"""
+    from fp8q import dist as fd
+    assert not fd.codes_wire_ok(7, 8, 1) and not fd.codes_wire_ok(9.0, 8, 1) and not fd.codes_wire_ok(3, 12, 1)
+    assert fd.codes_wire_ok(6.4, 8, 1) and fd.codes_wire_ok(2, 8, 1) and fd.codes_wire_ok(7, 8, 0) and not fd.codes_wire_ok(6.5, 7, 1)
+    out = fd.quantize_weights_sharded_bucketed([torch.from_numpy(w) for w in _bucket_weights()], 7, 8, 1, ops=RefusingCodecOps,
+                                               bucket_bytes=600)
+    return [(q.numpy(), mv.numpy()) for q, mv in out]
+
+
+def test_bucketed_default_wire_falls_back_to_fp32_without_an_exponent_bit():
+    ws = _bucket_weights()
+    for res in run(_bucket_job_no_exponent_bit):
+        for w, (q, mv) in zip(ws, res):
+            mn, mx = oracle.c_minmax(w, True)
+            rmv = oracle.c_absmax(mn, mx)
+            np.testing.assert_array_equal(mv, rmv)
+            ref = oracle.c_quantize(w, rmv, 7, 8, 1)
+            assert np.array_equal(np.isnan(q), np.isnan(ref)) and np.array_equal(q[~np.isnan(ref)], ref[~np.isnan(ref)])
+
+
 def _dp_model():
     import torch.nn as nn
     from quantization.autoquant_utils import quantize_model

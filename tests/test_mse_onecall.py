@@ -1,0 +1,200 @@
+"""The one-call MSE calibration step (fp8q_mse_calibrate_f32 behind FP_MSE_Estimator.calibrate_quantize) against the
+protocol calls it replaces (estimator.forward -> set_quant_range -> quantizer.forward: quantization_manager.py:114-122 of the
+reference) -- bit for bit -- and the host-side promises around it: no synchronisation in the pass, at most two in fix_ranges().
+"""
+import warnings
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _manager(per_channel, search, one_call, mbits=3):
+    from quantization.quantizers.fp8_quantizer import FPQuantizer
+    from quantization.range_estimators import FP_MSE_Estimator
+    from quantization.quantization_manager import QuantizationManager
+    mgr = QuantizationManager(qmethod=FPQuantizer, init=FP_MSE_Estimator, per_channel=per_channel,
+                              qparams=dict(n_bits=8, mantissa_bits=mbits, set_maxval=True, mse_include_mantissa_bits=search))
+    if not one_call:
+        mgr.range_estimator.one_call_ok = lambda x: False
+    return mgr
+
+
+def _bits(t):
+    return t.detach().contiguous().view(torch.int32)
+
+
+@pytest.mark.parametrize("shape,per_channel", [((8, 16, 28, 28), False), ((64, 32, 56, 56), False), ((48, 3, 5, 5), True),
+                                               ((96, 1, 3, 3), True), ((24, 4100), True), ((7,), False), ((160, 960), True)])
+@pytest.mark.parametrize("search", [True, False])
+def test_one_call_equals_protocol_calls(shape, per_channel, search):
+    torch.manual_seed(sum(shape))
+    batches = [torch.randn(shape, device="cuda") * (0.5 + i) for i in range(3)]
+    if not per_channel:
+        batches[1] = torch.relu(batches[1])
+    a, b = _manager(per_channel, search, True), _manager(per_channel, search, False)
+    for x in batches:
+        ya, yb = a(x), b(x)
+        assert a.range_estimator.__dict__.get("_cal") is not None and b.range_estimator.__dict__.get("_cal") is None
+        assert torch.equal(_bits(ya), _bits(yb))
+        ea, eb = a.range_estimator, b.range_estimator
+        assert torch.equal(_bits(ea.search_grid), _bits(eb.search_grid))
+        assert torch.equal(_bits(ea.mses), _bits(eb.mses))
+        assert torch.equal(_bits(a.quantizer.maxval), _bits(b.quantizer.maxval))
+        assert torch.equal(_bits(ea.last_maxval), _bits(eb.last_maxval))
+    assert (a.quantizer._pending_mantissa_bits() is not None) == search
+    assert float(a.quantizer.mantissa_bits) == float(b.quantizer.mantissa_bits)
+    a.fix_ranges()
+    b.fix_ranges()
+    assert torch.equal(_bits(a(batches[0])), _bits(b(batches[0])))
+
+
+def test_one_call_survives_a_ragged_batch_and_a_layout_change():
+    """the tables depend on the number of channels only: a smaller last batch, or a batch in another memory format (which takes
+    the protocol calls), keeps accumulating into the same estimator"""
+    torch.manual_seed(5)
+    xs = [torch.randn(16, 8, 14, 14, device="cuda"), torch.randn(5, 8, 14, 14, device="cuda"),
+          torch.randn(16, 8, 14, 14, device="cuda").to(memory_format=torch.channels_last), torch.randn(16, 8, 14, 14, device="cuda")]
+    a, b = _manager(False, True, True), _manager(False, True, False)
+    for x in xs:
+        ya, yb = a(x), b(x)
+        assert torch.equal(_bits(ya), _bits(yb)) and ya.stride() == yb.stride()
+        assert torch.equal(_bits(a.range_estimator.mses), _bits(b.range_estimator.mses))
+        assert torch.equal(_bits(a.quantizer.maxval), _bits(b.quantizer.maxval))
+    # and the other way round: protocol calls first (channels-last), the one-call step adopts their tables
+    c = _manager(False, False, True)
+    for x in (xs[2], xs[0], xs[3]):
+        c(x)
+    d = _manager(False, False, False)
+    for x in (xs[2], xs[0], xs[3]):
+        d(x)
+    assert c.range_estimator.__dict__.get("_cal") is not None
+    assert torch.equal(_bits(c.range_estimator.mses), _bits(d.range_estimator.mses))
+    assert torch.equal(_bits(c.quantizer.maxval), _bits(d.quantizer.maxval))
+
+
+def test_reset_starts_a_new_search():
+    torch.manual_seed(6)
+    x1, x2 = torch.randn(4, 8, 9, 9, device="cuda"), torch.randn(4, 8, 9, 9, device="cuda") * 7
+    a = _manager(False, True, True)
+    a(x1)
+    a.reset_ranges()
+    a(x2)
+    b = _manager(False, True, False)
+    b(x2)
+    assert torch.equal(_bits(a.range_estimator.mses), _bits(b.range_estimator.mses))
+    assert torch.equal(_bits(a.quantizer.maxval), _bits(b.quantizer.maxval))
+
+
+def test_calibrate_entry_point_validates_before_it_enqueues():
+    import ctypes
+    import fp8q
+    from fp8q._lib import MseState
+    L = fp8q.lib()
+    x = torch.randn(4, 64, device="cuda")
+    cal = fp8q.ops.MseCalibration(4, x.device, [3.0], 8, 1)
+    before = cal.mses.clone()
+    mb = (ctypes.c_float * 1)(3.0)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ws = torch.zeros(1 << 16, dtype=torch.uint8, device="cuda")
+    args = lambda n_bits, wsn: (x.data_ptr(), None, 4, 64, ctypes.byref(cal._state), 1, 111, mb, 1, n_bits, 1, ws.data_ptr(), ws.numel(),      # noqa: E731
+                                ws.data_ptr(), ws.numel(), ws.data_ptr(), wsn, st)
+    assert L.fp8q_mse_calibrate_f32(*args(40, ws.numel())) == -1           # FP8Q_EINVAL: format
+    assert L.fp8q_mse_calibrate_f32(*args(8, 8)) != 0                      # workspace too small
+    torch.cuda.synchronize()
+    assert torch.equal(_bits(cal.mses), _bits(before))                     # nothing ran
+    nul = MseState()
+    assert L.fp8q_mse_calibrate_f32(x.data_ptr(), None, 4, 64, ctypes.byref(nul), 1, 111, mb, 1, 8, 1, ws.data_ptr(), ws.numel(),
+                                    ws.data_ptr(), ws.numel(), ws.data_ptr(), ws.numel(), st) == -1
+
+
+class _CountSyncs:
+    """torch's own synchronisations (sync debug mode "warn") + this library's synchronising entry point"""
+
+    def __enter__(self):
+        torch.cuda.synchronize()
+        self._caught = warnings.catch_warnings(record=True)
+        self._log = self._caught.__enter__()
+        warnings.simplefilter("always")
+        torch.cuda.set_sync_debug_mode("warn")
+        return self
+
+    def __exit__(self, *exc):
+        torch.cuda.set_sync_debug_mode("default")
+        self.torch_syncs = [str(w.message) for w in self._log if "called a synchronizing" in str(w.message)]
+        self._caught.__exit__(*exc)
+        return False
+
+
+def test_model_calibration_pass_is_sync_free_and_fix_ranges_syncs_at_most_twice(monkeypatch):
+    """BASELINE config 4's procedure on a small net: the MSE calibration forward enqueues only; fix_ranges() -- votes to the
+    host, workspace check -- synchronises at most twice."""
+    import fp8q
+    from quantization.autoquant_utils import quantize_model
+    from quantization.base_quantized_model import QuantizedModel
+    from quantization.quantization_manager import QMethods
+    from quantization.range_estimators import RangeEstimators
+    from torch import nn
+
+    class Net(QuantizedModel):
+        def __init__(self):
+            super().__init__((1, 3, 16, 16))
+            seq = nn.Sequential(nn.Conv2d(3, 8, 3, padding=1), nn.BatchNorm2d(8), nn.ReLU6(), nn.Conv2d(8, 8, 3, padding=1, groups=8),
+                                nn.BatchNorm2d(8), nn.ReLU6(), nn.Conv2d(8, 16, 1), nn.BatchNorm2d(16))
+            self.features = quantize_model(seq, method=QMethods.fp_quantizer.cls, n_bits=8, per_channel_weights=True,
+                                           weight_range_method=RangeEstimators.MSE.cls, act_range_method=RangeEstimators.MSE.cls,
+                                           fp8_kwargs=dict(mantissa_bits=3, set_maxval=True, mse_include_mantissa_bits=True))
+
+        def forward(self, x):
+            return self.features(x)
+
+    torch.manual_seed(0)
+    net = Net().cuda().eval()
+    x = torch.randn(8, 3, 16, 16, device="cuda")
+    fp8q.ops.mse_linspace(torch.ones(1, device="cuda"))       # the once-per-process self-check synchronises
+    with torch.no_grad():
+        net.set_quant_state(True, True)
+        net.estimate_ranges()
+        net(x)                                                # allocations
+        with _CountSyncs() as c1:
+            net(x)
+        assert c1.torch_syncs == []
+        checks = []
+        real = fp8q.ops.check_workspaces
+        monkeypatch.setattr(fp8q.ops, "check_workspaces", lambda *a, **k: (checks.append(1), real(*a, **k))[1])
+        with _CountSyncs() as c2:
+            net.fix_ranges()
+        n_ws = sum(1 for k in fp8q.ops._ws_cache if k[2])      # one synchronising check per live min/max workspace
+        assert len(c2.torch_syncs) <= 1, c2.torch_syncs        # the votes: one device-to-host copy
+        assert len(checks) == 1 and n_ws <= 1
+        with _CountSyncs() as c3:
+            net(x)
+        assert c3.torch_syncs == []
+    widths = [float(m.quantizer.mantissa_bits) for m in net.modules() if hasattr(m, "quantizer") and hasattr(m.quantizer, "maxval")]
+    assert widths and all(1.0 <= w <= 6.0 for w in widths)
+
+
+def test_the_sync_counter_counts():
+    t = torch.ones(3, device="cuda")
+    with _CountSyncs() as c:
+        t.sum().item()
+        t.cpu()
+    assert len(c.torch_syncs) == 2, c.torch_syncs
+
+
+def test_votes_live_in_one_arena_and_come_over_in_one_copy():
+    import fp8q
+    from quantization.model import materialize_mantissa_bits
+    mgrs = torch.nn.ModuleList([_manager(False, True, True) for _ in range(6)])
+    torch.manual_seed(3)
+    for i, m in enumerate(mgrs):
+        m(torch.randn(4, 4, 8, 8, device="cuda") * (i + 1))
+    where = [fp8q.ops.vote_arena_of(m.quantizer._pending_mantissa_bits()) for m in mgrs]
+    assert all(w is not None for w in where) and len({id(w[0]) for w in where}) == 1
+    assert len({w[1] for w in where}) == len(mgrs)
+    want = [float(m.quantizer._pending_mantissa_bits().cpu()) for m in mgrs]
+    with _CountSyncs() as c:
+        assert materialize_mantissa_bits(mgrs) == len(mgrs)
+    assert len(c.torch_syncs) <= 1
+    assert [float(m.quantizer.mantissa_bits) for m in mgrs] == want
