@@ -74,10 +74,6 @@ struct FoldArgs {
     int lin_steps = 0;
     int64_t lin_C = 0;
     double lin_lo = 0.0, lin_hi = 0.0;
-    // optional: a [zero_n, lin_C] fp32 table whose column `row` the same thread clears (the estimator's accumulated MSE table:
-    // fp8q_mse_calibrate_f32's first batch needs no separate memset launch)
-    float *zero_tab = nullptr;
-    int zero_n = 0;
 };
 
 // grid[i, row] = torch.linspace(lo * mx, hi * mx, steps)[i] bit for bit (range_estimators.py:296-305: the products are
@@ -135,8 +131,6 @@ __device__ __forceinline__ void fold_store(float mn, float mx, int64_t row, floa
     if (maxval_out) maxval_out[row] = absmax;
     if (fa.lin_grid)
         for (int i = 0; i < fa.lin_steps; ++i) fa.lin_grid[(int64_t)i * fa.lin_C + row] = linspace_at(absmax, fa.lin_lo, fa.lin_hi, fa.lin_steps, i);
-    if (fa.zero_tab)
-        for (int i = 0; i < fa.zero_n; ++i) fa.zero_tab[(int64_t)i * fa.lin_C + row] = 0.0f;
     if (fa.packed) {
         // NaN must win on every rank (torch.min / torch.max): it travels as a flag, the value as -inf, so that the
         // collective itself never sees a NaN (what MAX does with one is the communication library's business)

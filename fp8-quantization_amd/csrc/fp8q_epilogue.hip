@@ -21,6 +21,7 @@ struct AffineArgs {
     int cpp;            // most channels one 4096-element piece can overlap (size of the LDS constants)
     uint32_t magic;     // o / HW for o < 4096 + HW (magic_of); unused when HW > kAffineMagicMaxHW
     uint64_t magic48;   // floor(2^48 / HW) + 1:  n / HW == (n * magic48) >> 48  for n * HW < 2^48 (calibration twin)
+    int passthrough;    // y = t itself, no quantizer (fp8q_affine_act_f32: what an MSE estimator searches on; maxval unused)
 };
 constexpr int kAffinePiece = kBlock * 4 * 4;   // elements per block and step (16 KiB)
 constexpr int kAffineMagicMaxHW = kMagicMaxDivisor;   // above: a piece spans <= 2 planes (compare instead of divide)
@@ -80,9 +81,12 @@ k_affine_act(const float *__restrict__ x, const float *__restrict__ res, float *
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float2 *cst = reinterpret_cast<float2 *>(smem);   // [cpp] {alpha, beta'} (has_bn only)
     const int tid = threadIdx.x;
-    const Chan cfull = make_chan(maxval[0], f);
-    for (int i = tid; i <= f.pmax; i += kBlock) lut[i] = lut_entry(cfull, i, f.M);
-    const ChanLite c = lite(cfull);
+    ChanLite c = {};
+    if (!a.passthrough) {
+        const Chan cfull = make_chan(maxval[0], f);
+        for (int i = tid; i <= f.pmax; i += kBlock) lut[i] = lut_entry(cfull, i, f.M);
+        c = lite(cfull);
+    }
     const float pmaxf = (float)f.pmax;
     const int64_t base0 = (int64_t)blockIdx.y * a.image;
     const int nvec = (int)(a.image >> 2);
@@ -168,7 +172,7 @@ k_affine_act(const float *__restrict__ x, const float *__restrict__ res, float *
                 e[4 * u + 2] = t[2];
                 e[4 * u + 3] = t[3];
             }
-            quant_group<U * 4>(e, c, lut, pmaxf, f.qthr);
+            if (!a.passthrough) quant_group<U * 4>(e, c, lut, pmaxf, f.qthr);
 #pragma unroll
             for (int u = 0; u < U; ++u)
                 st16<NT>(yv + base + u * kBlock + tid, vf4{e[4 * u], e[4 * u + 1], e[4 * u + 2], e[4 * u + 3]});
@@ -180,7 +184,7 @@ k_affine_act(const float *__restrict__ x, const float *__restrict__ res, float *
                 const vf4 r = a.has_res ? ld16<NT>(rv + j) : vf4{0.0f, 0.0f, 0.0f, 0.0f};
                 float e[4] = {v.x, v.y, v.z, v.w};
                 transform(u * kBlock + tid, e, r);
-                quant_group<4>(e, c, lut, pmaxf, f.qthr);
+                if (!a.passthrough) quant_group<4>(e, c, lut, pmaxf, f.qthr);
                 st16<NT>(yv + j, vf4{e[0], e[1], e[2], e[3]});
             }
         }
@@ -253,8 +257,9 @@ k_affine_act_small(const float *__restrict__ x, const float *__restrict__ res, f
     // The quantizer's channel constants and {s, 1/s} table: rebuilt from maxval (a load, ~50 dependent double-precision
     // operations, the table entries) -- or, with fixed ranges, copied from the block fp8q_quantizer_prepare_f32 wrote once:
     // the same numbers, one 8-byte load per entry, 0.5-1 us less on the critical path of a 4-10 us launch.
-    ChanLite c;
-    if (prep) {
+    ChanLite c = {};
+    if (a.passthrough) {
+    } else if (prep) {
         const float4 h = prep[0];
         c.maxv = h.x;
         c.minv = h.y;
@@ -294,7 +299,7 @@ k_affine_act_small(const float *__restrict__ x, const float *__restrict__ res, f
 #pragma unroll
                 for (int k = 0; k < 4; ++k) e[k] = res_act(e[k], rr[k], a);
             }
-            quant_group<4>(e, c, lut, pmaxf, f.qthr);
+            if (!a.passthrough) quant_group<4>(e, c, lut, pmaxf, f.qthr);
             st16<NT>(yv + j, vf4{e[0], e[1], e[2], e[3]});
         }
     }
@@ -379,6 +384,7 @@ static int affine_args(int64_t N, int64_t C, int64_t HW, int act, int has_bn, bo
     a->cpp = (int)(cpp < C ? cpp : C);
     a->magic = HW <= kAffineMagicMaxHW ? magic_of((int)HW) : 0u;
     a->magic48 = (1ull << 48) / (uint64_t)HW + 1ull;
+    a->passthrough = 0;
     return FP8Q_OK;
 }
 
@@ -435,7 +441,7 @@ int fp8q_bn_fold_f32(const float *mean, const float *invstd, const float *gamma,
 static int affine_quantize_impl(const float *x, const float *residual, float *y, int64_t N, int64_t C, int64_t HW,
                                 const float *mean, const float *invstd, const float *gamma, const float *beta, int has_bn,
                                 int act, const float *maxval, const float *prep, float mbits, int n_bits, int sign_bits,
-                                fp8q_stream_t stream);
+                                fp8q_stream_t stream, int passthrough = 0);
 
 int fp8q_affine_act_quantize_f32(const float *x, const float *residual, float *y, int64_t N, int64_t C,
                                  int64_t HW, const float *mean, const float *invstd, const float *gamma,
@@ -466,17 +472,27 @@ int fp8q_affine_act_quantize_ab_f32(const float *x, const float *residual, float
                                 prep, mbits, n_bits, sign_bits, stream);
 }
 
+int fp8q_affine_act_f32(const float *x, const float *residual, float *y, int64_t N, int64_t C, int64_t HW, const float *alpha_beta,
+                        int act, fp8q_stream_t stream)
+{
+    if ((uintptr_t)alpha_beta & 7) return FP8Q_EINVAL;
+    // the quantizing kernels with the quantizer switched off: same geometry, same BN arithmetic (what the quantizer will see)
+    return affine_quantize_impl(x, residual, y, N, C, HW, alpha_beta, nullptr, nullptr, nullptr, alpha_beta ? 2 : 0, act, nullptr, nullptr,
+                                3.0f, 8, 1, stream, 1);
+}
+
 static int affine_quantize_impl(const float *x, const float *residual, float *y, int64_t N, int64_t C, int64_t HW,
                                 const float *mean, const float *invstd, const float *gamma, const float *beta, int has_bn,
                                 int act, const float *maxval, const float *prep, float mbits, int n_bits, int sign_bits,
-                                fp8q_stream_t stream)
+                                fp8q_stream_t stream, int passthrough)
 {
     AffineArgs a;
     if (int rc = affine_args(N, C, HW, act, has_bn, residual != nullptr, &a)) return rc;
+    a.passthrough = passthrough != 0;
     QFmt f;
     if (int rc = make_fmt(mbits, n_bits, sign_bits, &f)) return rc;
     if (N == 0) return FP8Q_OK;
-    if (!x || !y || !maxval) return FP8Q_EINVAL;
+    if (!x || !y || (!maxval && !passthrough)) return FP8Q_EINVAL;
     if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual) & 15) return FP8Q_EINVAL;
     static const int64_t small_elems = [] {   // FP8Q_EPI_SMALL_M: tensors below this many M elements run 4 KiB pieces per block
         const char *e = getenv("FP8Q_EPI_SMALL_M");

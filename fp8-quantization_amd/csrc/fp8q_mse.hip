@@ -27,7 +27,11 @@ struct MseArgs {
     int tile;      // k_mse_grid: elements of a row per workgroup and trip (<= kMseTile, a multiple of 32): mse_tile()
     int64_t inner;
     int64_t C;
+    int overwrite;   // the table entries are written, not added to (first batch of fp8q_mse_calibrate_f32: no cleared table needed;
+                     // same bits as adding to +0: an entry is never -0)
 };
+
+__device__ __forceinline__ void table_add(float *p, float v, int overwrite) { *p = overwrite ? v : *p + v; }
 
 __global__ void __launch_bounds__(kMseBlock)
 k_mse_grid(const float *__restrict__ x, const float *__restrict__ grid, double *__restrict__ ws,
@@ -184,7 +188,7 @@ k_mse_grid(const float *__restrict__ x, const float *__restrict__ grid, double *
     // a row that one workgroup covers (nsplit == 1: depthwise and narrow pointwise weights, half of MobileNetV2's tensors)
     // needs no second launch: the table entry is this lane's alone -- the same (float)(sum * inv_inner) k_mse_final_tile forms
     if (a.nsplit == 1)
-        mses[((int64_t)m * a.n_cand + cand) * a.C + c] += (float)((0.0 + acc) * inv_inner);
+        table_add(mses + ((int64_t)m * a.n_cand + cand) * a.C + c, (float)((0.0 + acc) * inv_inner), a.overwrite);
     else
         ws[((c * a.n_m + m) * a.n_cand + cand) * a.nsplit + split] = acc;
 }
@@ -608,7 +612,7 @@ k_mse_row(const float *__restrict__ x, const float *__restrict__ grid, double *_
 // mses[m, i, c] += (sum over the splits of row (c, m, i)) / inner: one wave per row of partial sums, in double
 __global__ void __launch_bounds__(kBlock)
 k_mse_final(const double *__restrict__ ws, float *__restrict__ mses, int64_t C, int n_m, int n_cand,
-            int64_t nsplit, double inv_inner)
+            int64_t nsplit, double inv_inner, int overwrite)
 {
     const int64_t total = C * n_m * n_cand;
     const int lane = threadIdx.x & 63;
@@ -621,7 +625,7 @@ k_mse_final(const double *__restrict__ ws, float *__restrict__ mses, int64_t C, 
     if (lane == 0) {
         const int64_t c = j / ((int64_t)n_m * n_cand);
         const int64_t mi = j - c * n_m * n_cand;   // m * n_cand + i
-        mses[mi * C + c] += (float)(sum * inv_inner);
+        table_add(mses + mi * C + c, (float)(sum * inv_inner), overwrite);
     }
 }
 
@@ -634,7 +638,7 @@ constexpr int kFinTC = 16, kFinTM = 64;
 
 __global__ void __launch_bounds__(kBlock)
 k_mse_final_tile(const double *__restrict__ ws, float *__restrict__ mses, int64_t C, int64_t NM /* n_m * n_cand */, int nsplit,
-                 double inv_inner)
+                 double inv_inner, int overwrite)
 {
     __shared__ float tile[kFinTC][kFinTM + 1];
     const int64_t c0 = (int64_t)blockIdx.y * kFinTC, m0 = (int64_t)blockIdx.x * kFinTM;
@@ -655,7 +659,7 @@ k_mse_final_tile(const double *__restrict__ ws, float *__restrict__ mses, int64_
     for (int k = 0; k < kFinTC * kFinTM / kBlock; ++k) {
         const int lm = (tid >> 4) + 16 * k, lc = tid & 15;
         const int64_t c = c0 + lc, mi = m0 + lm;
-        if (c < C && mi < NM) mses[mi * C + c] += tile[lc][lm];
+        if (c < C && mi < NM) table_add(mses + mi * C + c, tile[lc][lm], overwrite);
     }
 }
 
@@ -774,7 +778,7 @@ k_mse_select(const float *__restrict__ mses, const float *__restrict__ grid, int
 size_t fp8q_mse_hist_workspace_bytes(int64_t n, int64_t n_pairs);
 bool fp8q_mse_hist_supported(const QFmt *fmts, int n_m, int n_bits);
 int fp8q_mse_hist_launch(const float *x, int64_t n, const float *grid, int64_t n_cand, const QFmt *fmts, int n_m, float *mses,
-                         void *ws, size_t ws_bytes, hipStream_t st, int brute);
+                         void *ws, size_t ws_bytes, hipStream_t st, int brute, int overwrite);
 
 // FP8Q_MSE_HIST: 1 (default) = long per-tensor rows of a signed format of <= 8 bits go through the interval-histogram
 // evaluation; 0 = never (the lane-per-element kernel everywhere); 2 = same routing with every candidate evaluated element by
@@ -924,9 +928,9 @@ size_t fp8q_mse_workspace_bytes(int64_t C, int64_t inner, int64_t n_cand, int n_
     return (size_t)C * n_m * n_cand * ns * sizeof(double) + 16;
 }
 
-int fp8q_mse_grid_f32(const float *x, int64_t C, int64_t inner, const float *grid, int64_t n_cand,
-                      const float *mbits_host, int n_m, int n_bits, int sign_bits, float *mses,
-                      void *ws, size_t ws_bytes, fp8q_stream_t stream)
+static int mse_grid_impl(const float *x, int64_t C, int64_t inner, const float *grid, int64_t n_cand,
+                         const float *mbits_host, int n_m, int n_bits, int sign_bits, float *mses,
+                         void *ws, size_t ws_bytes, fp8q_stream_t stream, int overwrite)
 {
     if (!x || !grid || !mbits_host || !mses || C <= 0 || inner <= 0 || n_cand <= 0 || n_m <= 0 ||
         n_m > kMseMaxM || n_cand > (1 << 20))
@@ -947,9 +951,10 @@ int fp8q_mse_grid_f32(const float *x, int64_t C, int64_t inner, const float *gri
     a.tile = mse_tile(C, inner, n_cand, n_m);
     a.inner = inner;
     a.C = C;
+    a.overwrite = overwrite;
     hipStream_t st = (hipStream_t)stream;
     if (mse_use_hist_shape(C, inner, n_cand, n_m) && fp8q_mse_hist_supported(a.fmt, n_m, n_bits))
-        return fp8q_mse_hist_launch(x, inner, grid, n_cand, a.fmt, n_m, mses, ws, ws_bytes, st, mse_hist_mode() == 2);
+        return fp8q_mse_hist_launch(x, inner, grid, n_cand, a.fmt, n_m, mses, ws, ws_bytes, st, mse_hist_mode() == 2, overwrite);
     int64_t nsplit = a.nsplit;
     if (mse_use_row(C, inner) && ((uintptr_t)x & 3) == 0) {
         const RowGeo g = mse_row_geo(C, inner, n_cand, n_m);
@@ -972,11 +977,18 @@ int fp8q_mse_grid_f32(const float *x, int64_t C, int64_t inner, const float *gri
     const int64_t rows = C * n_m * n_cand;
     if (nsplit <= 32 && cdiv(C, kFinTC) <= 65535)
         hipLaunchKernelGGL(k_mse_final_tile, dim3((unsigned)cdiv(n_m * n_cand, kFinTM), (unsigned)cdiv(C, kFinTC)), dim3(kBlock), 0, st,
-                           (const double *)ws, mses, C, (int64_t)n_m * n_cand, (int)nsplit, 1.0 / (double)inner);
+                           (const double *)ws, mses, C, (int64_t)n_m * n_cand, (int)nsplit, 1.0 / (double)inner, overwrite);
     else
         hipLaunchKernelGGL(k_mse_final, dim3((unsigned)cdiv(rows, 4)), dim3(kBlock), 0, st, (const double *)ws, mses, C,
-                           n_m, (int)n_cand, nsplit, 1.0 / (double)inner);
+                           n_m, (int)n_cand, nsplit, 1.0 / (double)inner, overwrite);
     return launch_rc();
+}
+
+int fp8q_mse_grid_f32(const float *x, int64_t C, int64_t inner, const float *grid, int64_t n_cand,
+                      const float *mbits_host, int n_m, int n_bits, int sign_bits, float *mses,
+                      void *ws, size_t ws_bytes, fp8q_stream_t stream)
+{
+    return mse_grid_impl(x, C, inner, grid, n_cand, mbits_host, n_m, n_bits, sign_bits, mses, ws, ws_bytes, stream, 0);
 }
 
 size_t fp8q_mse_calibrate_workspace_bytes(int64_t C, int64_t inner, int64_t n_cand, int n_m, size_t *minmax_bytes, size_t *select_bytes)
@@ -1006,13 +1018,15 @@ int fp8q_mse_calibrate_f32(const float *x, float *y, int64_t C, int64_t inner, c
     if (!ws_mse || ws_mse_bytes < fp8q_mse_workspace_bytes(C, inner, n_cand, n_m) || ((uintptr_t)ws_mse & 7)) return FP8Q_EWORKSPACE;
     if (!ws_select || ws_select_bytes < fp8q_mse_select_workspace_bytes(C, n_m) || ((uintptr_t)ws_select & 3)) return FP8Q_EWORKSPACE;
     if (first) {
-        // max|x| per row, the search grid of that maximum, and the cleared table -- one launch (:295-316)
+        // max|x| per row and the search grid of that maximum in one launch (:295-316); the table needs no clearing: the
+        // first batch's entries are written, not added
         if (!s->cur_min || !s->cur_max || !s->absmax) return FP8Q_EINVAL;
-        if (int rc = fp8q_minmax_linspace_zero_f32(x, C, inner, s->cur_min, s->cur_max, s->absmax, s->grid, n_cand, 0.1, 1.2, s->mses,
-                                                   n_m * n_cand, ws_minmax, ws_minmax_bytes, stream))
+        if (int rc = fp8q_minmax_linspace_f32(x, C, inner, s->cur_min, s->cur_max, s->absmax, s->grid, n_cand, 0.1, 1.2, ws_minmax,
+                                              ws_minmax_bytes, stream))
             return rc;
     }
-    if (int rc = fp8q_mse_grid_f32(x, C, inner, s->grid, n_cand, mbits_host, n_m, n_bits, sign_bits, s->mses, ws_mse, ws_mse_bytes, stream))
+    if (int rc = mse_grid_impl(x, C, inner, s->grid, n_cand, mbits_host, n_m, n_bits, sign_bits, s->mses, ws_mse, ws_mse_bytes, stream,
+                               first != 0))
         return rc;
     if (int rc = fp8q_mse_select_f32(s->mses, s->grid, C, n_cand, mbits_host, n_m, sign_bits, s->mbits, s->vote, s->maxval, s->xmin,
                                      ws_select, ws_select_bytes, stream))

@@ -56,6 +56,7 @@ struct HistArgs {
     int n_m, n_cand;
     int stride;                  // max ncells: row pitch of the per-candidate border tables
     int uns;                     // unsigned formats (sign_bits == 0): a negative element is clipped to 0 -> its error is x^2
+    int overwrite;               // table entries are written, not added to (first batch of fp8q_mse_calibrate_f32)
     int64_t n;                   // elements of the row
 };
 
@@ -1107,11 +1108,11 @@ k_mse_eval(const float *__restrict__ x, const float *__restrict__ grid, const fl
     const uint32_t last = maxkey[0];
     const int flag = cflag[j];
     if (last > 0x7f800000u || flag == kFlagNaN || nunits[2]) {
-        if (tid == 0) *out += __builtin_nanf("");
+        if (tid == 0) *out = a.overwrite ? __builtin_nanf("") : *out + __builtin_nanf("");
         return;
     }
     if (last == 0x7f800000u) {
-        if (tid == 0) *out += __builtin_inff();
+        if (tid == 0) *out = a.overwrite ? __builtin_inff() : *out + __builtin_inff();
         return;
     }
     double acc = 0.0;
@@ -1224,7 +1225,7 @@ k_mse_eval(const float *__restrict__ x, const float *__restrict__ grid, const fl
     if (tid == 0) {
         double tot = s_red[0] < 0.0 ? 0.0 : s_red[0];           // (rounding can leave a tiny negative number for an exact fit)
         if (a.uns && flag != kFlagBrute) tot += reinterpret_cast<const double *>(maxkey)[1];   // negative elements: x^2 each
-        *out += (float)(tot * inv_inner);
+        *out = a.overwrite ? (float)(tot * inv_inner) : *out + (float)(tot * inv_inner);
     }
 }
 
@@ -1329,7 +1330,7 @@ bool fp8q_mse_hist_supported(const QFmt *fmts, int n_m, int n_bits)
 }
 
 int fp8q_mse_hist_launch(const float *x, int64_t n, const float *grid, int64_t n_cand, const QFmt *fmts, int n_m, float *mses,
-                         void *ws, size_t ws_bytes, hipStream_t st, int brute)
+                         void *ws, size_t ws_bytes, hipStream_t st, int brute, int overwrite)
 {
     if (n_m > kHistMaxM || n >= (1ll << 31) || ((uintptr_t)ws & 7)) return FP8Q_EWORKSPACE;
     HistArgs a;
@@ -1339,6 +1340,7 @@ int fp8q_mse_hist_launch(const float *x, int64_t n, const float *grid, int64_t n
     a.n = n;
     a.stride = 0;
     a.uns = fmts[0].sign_bits == 0;
+    a.overwrite = overwrite;
     for (int m = 0; m < n_m; ++m) {
         a.fmt[m] = fmts[m];
         const int M = (int)fmts[m].M;

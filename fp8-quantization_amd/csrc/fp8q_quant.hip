@@ -1906,8 +1906,6 @@ struct LinArgs {
     float *grid = nullptr;
     int steps = 0;
     double lo = 0.0, hi = 0.0;
-    float *zero_tab = nullptr;   // [zero_n, C]: cleared column by column next to the grid (see FoldArgs)
-    int zero_n = 0;
 };
 
 static int minmax_impl(const float *x, int64_t C, int64_t inner, float *cur_min, float *cur_max, float *maxval_out,
@@ -1929,11 +1927,9 @@ static int minmax_impl(const float *x, int64_t C, int64_t inner, float *cur_min,
     fa.lin_C = C;
     fa.lin_lo = lin.lo;
     fa.lin_hi = lin.hi;
-    fa.zero_tab = lin.zero_tab;
-    fa.zero_n = lin.zero_n;
     // (the row-kernel launchers below cut C into slabs themselves and pass slab-local rows to fold_store together with
     // slab-offset range pointers, while the grid / table base stays that of row 0: tables per row need C <= 65535 there)
-    if ((lin.grid || lin.zero_tab) && C > 65535) return FP8Q_ETOOMANY;
+    if (lin.grid && C > 65535) return FP8Q_ETOOMANY;
     if (C > 1) {   // per-channel rows of 128..8192 elements: one launch, the row in registers
         QFmt f = {};
         const int rc = launch_rows_reg(false, x, nullptr, C, inner, cur_min, cur_max, maxval_out, f, fa, st);
@@ -1985,27 +1981,17 @@ int fp8q_minmax_packed_f32(const float *x, int64_t C, int64_t inner, float *cur_
     return minmax_impl(x, C, inner, cur_min, cur_max, maxval_out, packed, fold_mode, momentum, first, ws, ws_bytes, stream);
 }
 
-int fp8q_minmax_linspace_zero_f32(const float *x, int64_t C, int64_t inner, float *cur_min, float *cur_max, float *maxval_out,
-                                  float *grid, int n_cand, double lo_frac, double hi_frac, float *zero_tab, int zero_rows,
-                                  void *ws, size_t ws_bytes, fp8q_stream_t stream)
+int fp8q_minmax_linspace_f32(const float *x, int64_t C, int64_t inner, float *cur_min, float *cur_max, float *maxval_out,
+                             float *grid, int n_cand, double lo_frac, double hi_frac, void *ws, size_t ws_bytes,
+                             fp8q_stream_t stream)
 {
-    if (!grid || !maxval_out || n_cand < 2 || n_cand > (1 << 20) || zero_rows < 0 || (zero_rows > 0 && !zero_tab)) return FP8Q_EINVAL;
+    if (!grid || !maxval_out || n_cand < 2 || n_cand > (1 << 20)) return FP8Q_EINVAL;
     LinArgs lin;
     lin.grid = grid;
     lin.steps = n_cand;
     lin.lo = lo_frac;
     lin.hi = hi_frac;
-    lin.zero_tab = zero_rows > 0 ? zero_tab : nullptr;
-    lin.zero_n = zero_rows;
     return minmax_impl(x, C, inner, cur_min, cur_max, maxval_out, nullptr, FP8Q_FOLD_CURRENT, 0.0, 1, ws, ws_bytes, stream, lin);
-}
-
-int fp8q_minmax_linspace_f32(const float *x, int64_t C, int64_t inner, float *cur_min, float *cur_max, float *maxval_out,
-                             float *grid, int n_cand, double lo_frac, double hi_frac, void *ws, size_t ws_bytes,
-                             fp8q_stream_t stream)
-{
-    return fp8q_minmax_linspace_zero_f32(x, C, inner, cur_min, cur_max, maxval_out, grid, n_cand, lo_frac, hi_frac, nullptr, 0, ws,
-                                         ws_bytes, stream);
 }
 
 int fp8q_minmax_workspace_check(void *ws, size_t ws_bytes, int clear, fp8q_stream_t stream)

@@ -49,8 +49,6 @@ SIGNATURES = {
     "fp8q_mse_select_f32": (_i, [_vp, _vp, _i64, _i64, ctypes.POINTER(_f), _i, _i, _vp, _vp, _vp, _vp, _vp,
                                  ctypes.c_size_t, _vp]),
     "fp8q_quantize_dm_f32": (_i, [_vp, _vp, _i64, _i64, _vp, _i64, _vp, _i, _i, _vp]),
-    "fp8q_minmax_linspace_zero_f32": (_i, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _i, ctypes.c_double, ctypes.c_double, _vp, _i,
-                                           _vp, ctypes.c_size_t, _vp]),
     "fp8q_mse_calibrate_workspace_bytes": (ctypes.c_size_t, [_i64, _i64, _i64, _i, ctypes.POINTER(ctypes.c_size_t),
                                                              ctypes.POINTER(ctypes.c_size_t)]),
     "fp8q_mse_calibrate_f32": (_i, [_vp, _vp, _i64, _i64, ctypes.POINTER(MseState), _i, _i, ctypes.POINTER(_f), _i, _i, _i,
@@ -66,6 +64,7 @@ SIGNATURES = {
     "fp8q_bn_fold_f32": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "fp8q_quantizer_prepare_f32": (_i, [_vp, _f, _i, _i, _vp, _vp]),
     "fp8q_affine_act_quantize_ab_f32": (_i, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _i, _vp, _vp, _f, _i, _i, _vp]),
+    "fp8q_affine_act_f32": (_i, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _i, _vp]),
     "fp8q_affine_act_minmax_workspace_bytes": (ctypes.c_size_t, [_i64, _i64, _i64]),
     "fp8q_affine_act_minmax_f32": (_i, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i,
                                         ctypes.c_double, _i, _vp, ctypes.c_size_t, _vp]),

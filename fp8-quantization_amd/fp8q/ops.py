@@ -930,6 +930,29 @@ def affine_act_quantize(x, maxval, mbits, n_bits=8, sign_bits=1, bn=None, residu
     return y
 
 
+def affine_act(x, bn_ab=None, residual=None, act=0, out=None):
+    """act(bn(x) + residual) without a quantizer (fp8q_affine_act_f32): what an MSE estimator behind a BN + activation searches
+    on.  bn_ab: the folded [C, 2] vector of bn_fold(), or None."""
+    _require(x, "x")
+    x = x.contiguous()
+    N, C, HW = _nchw(x)
+    if residual is not None:
+        _require(residual, "residual", like=x)
+        residual = residual.contiguous()
+        if residual.shape != x.shape:
+            raise Fp8qError("residual must have x's shape")
+    if bn_ab is not None:
+        _require(bn_ab, "bn_ab", like=x)
+        if bn_ab.numel() != 2 * C or not bn_ab.is_contiguous():
+            raise Fp8qError("bn_ab must be a contiguous [C, 2] tensor (fp8q.ops.bn_fold)")
+    y = _out(out, x)
+    with _on_device(x):
+        rc = lib().fp8q_affine_act_f32(x.data_ptr(), residual.data_ptr() if residual is not None else None, y.data_ptr(), N, C, HW,
+                                       bn_ab.data_ptr() if bn_ab is not None else None, int(act), _stream(x))
+    check(rc, "fp8q_affine_act_f32")
+    return y
+
+
 def affine_act_minmax(x, cur_min=None, cur_max=None, mode=FOLD_CURRENT, momentum=0.9, bn=None, residual=None,
                       act=0, packed=None):
     """N2: per-tensor min/max of act(bn(x) + residual), folded into the running estimate.

@@ -144,12 +144,22 @@ class QuantizationManager(nn.Module):
         if x.dtype != __import__("torch").float32 or not x.is_contiguous() or not _ops.affine_act_supported(x):
             return False
         if self._estimating():
+            if type(est) is FP_MSE_Estimator:      # act(bn(x) + residual) in one pass, then the one-call search on it
+                return est.one_call_ok(x)
             return (type(est) in _MINMAX and not q.allow_unsigned and not getattr(est, "percentile", None))
         return True
 
     def forward_fused(self, x, bn=None, residual=None, act=0, bn_ab=None):
         """quantize(act(bn(x) + residual)); range update first when estimating (reference order)."""
         q, est = self.quantizer, self.range_estimator
+        if self._estimating() and type(est) is FP_MSE_Estimator:
+            # the search needs the tensor the quantizer will see: the epilogue with the quantizer switched off (8 B / element
+            # instead of torch's batch_norm + activation passes), then estimate + set_quant_range + quantize in one call
+            ab = bn_ab if bn is not None else None
+            if bn is not None and ab is None:
+                ab = _ops.bn_fold(bn)
+            t = _ops.affine_act(x, ab, residual, act) if (ab is not None or residual is not None or act) else x
+            return self.forward(t)
         if self._estimating():
             cur_min, cur_max = est.current_xmin, est.current_xmax
             if cur_min is not None and est._fold_mode != _ops.FOLD_CURRENT:

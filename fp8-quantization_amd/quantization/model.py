@@ -92,12 +92,14 @@ def load_quantizer_ranges(model, ranges, strict=True):
 
 
 def _plan_layers(model):
-    """[(layer, weight, quantizer, maxval)] of every layer a multi-tensor plan can cover: FP8 weight quantizer with
-    fixed ranges on a contiguous CUDA fp32 weight that autograd is not tracking."""
+    """[(layer, weight, quantizer, maxval, swap)] of every layer a multi-tensor plan can cover: FP8 weight quantizer with
+    fixed ranges on a contiguous CUDA fp32 weight that autograd is not tracking.  swap: a transposed convolution with
+    per-channel ranges -- its weight is [in, out, ...] and the quantizer works on the [out, in, ...] copy
+    (reference autoquant_utils.py:46-58); the plan quantizes that copy."""
     import os
 
     from .fp8 import FPQuantizer
-    from .layers import QuantizationHijacker
+    from .layers import QuantizationHijacker, QuantConvTransposeBase
     from .manager import Qstates
     if os.environ.get("FP8Q_CACHE_WEIGHTS", "1") == "0":
         return []
@@ -105,8 +107,11 @@ def _plan_layers(model):
     for m in model.modules():
         if not isinstance(m, QuantizationHijacker) or not getattr(m, "_qw", False):
             continue
-        if type(m).quantize_weights is not QuantizationHijacker.quantize_weights:
-            continue   # transposed convolutions permute the weight around the quantizer
+        swap = False
+        if type(m).quantize_weights is QuantConvTransposeBase.quantize_weights:
+            swap = bool(m.per_channel_weights)
+        elif type(m).quantize_weights is not QuantizationHijacker.quantize_weights:
+            continue   # a layer with its own idea of quantize_weights: leave it to the layer
         mgr = m.weight_quantizer
         q = getattr(mgr, "quantizer", None)
         if not isinstance(q, FPQuantizer) or mgr.state != Qstates.fix_ranges or q.maxval is None:
@@ -116,11 +121,20 @@ def _plan_layers(model):
             continue
         if w.requires_grad and torch.is_grad_enabled():
             continue
-        mv = q.maxval.detach()
-        if not (mv.is_cuda and mv.dtype == torch.float32) or mv.numel() not in (1, w.shape[0]):
+        if swap and w.dim() < 2:
             continue
-        found.append((m, w, q, mv))
+        mv = q.maxval.detach()
+        if not (mv.is_cuda and mv.dtype == torch.float32) or mv.numel() not in (1, w.shape[1] if swap else w.shape[0]):
+            continue
+        found.append((m, w, q, mv, swap))
     return found
+
+
+def _store_planned(mods, outs):
+    """hand every layer its quantized weight; a swapped layer gets it back in its own [in, out, ...] layout"""
+    for (m, w, q, src), y in zip(mods, outs):
+        m._wq_cache = y if src is None else y.transpose(1, 0).contiguous()
+        m._wq_key = m._weight_cache_key(m.get_weight_bias()[0], q)
 
 
 def prequantize_weights(model):
@@ -133,18 +147,17 @@ def prequantize_weights(model):
     if not found:
         _PLANS.pop(model, None)
         return 0
-    mods = [(m, w, q) for m, w, q, mv in found]
-    items = [(w.detach(), mv, float(q.mantissa_bits), int(q.n_bits), int(q.sign_bits)) for m, w, q, mv in found]
+    # (layer, weight, quantizer, the [out, in, ...] copy of a swapped layer's weight or None)
+    mods = [(m, w, q, w.detach().transpose(1, 0).contiguous() if swap else None) for m, w, q, mv, swap in found]
+    items = [(w.detach() if src is None else src, mv, float(q.mantissa_bits), int(q.n_bits), int(q.sign_bits))
+             for (m, w, q, src), (_, _, _, mv, _) in zip(mods, found)]
     import fp8q
     # a prepared plan (fp8q_multi_plan_*): descriptors validated and packed once here; requantize_weights() replays
     # it with one launch whenever the weights' or the ranges' CONTENTS change (QAT steps, range updates in place)
     plan = fp8q.ops.MultiPlan(items)
-    outs = plan.launch()
-    for (m, w, q), y in zip(mods, outs):
-        m._wq_cache = y
-        m._wq_key = m._weight_cache_key(w, q)
-    _PLANS[model] = (plan, mods, [_plan_signature(m, q) for m, w, q in mods])
-    return len(outs)
+    _store_planned(mods, plan.launch())
+    _PLANS[model] = (plan, mods, [_plan_signature(m, q) + (w.data_ptr(), tuple(w.shape)) for m, w, q, src in mods])
+    return len(mods)
 
 
 def requantize_weights(model):
@@ -162,17 +175,17 @@ def requantize_weights(model):
     now = _plan_layers(model)
     if len(now) != len(mods):
         return prequantize_weights(model)
-    for (m, w, q), (x, mv), sig, (m2, w2, q2, mv2) in zip(mods, plan._keep, sigs, now):
-        if (m2 is not m or q2 is not q or w2.data_ptr() != x.data_ptr() or tuple(w2.shape) != tuple(x.shape)
+    for (m, w, q, src), (x, mv), sig, (m2, w2, q2, mv2, swap2) in zip(mods, plan._keep, sigs, now):
+        if (m2 is not m or q2 is not q or w2.data_ptr() != sig[-2] or tuple(w2.shape) != sig[-1] or swap2 != (src is not None)
                 or mv2.data_ptr() != mv.data_ptr() or mv2.numel() != mv.numel()):
             return prequantize_weights(model)
         cur = _plan_signature(m, q)
-        if cur[:3] != sig[:3] or cur[4:] != sig[4:]:      # the range epoch (index 3) moves with in-place range updates: fine
+        if cur[:3] != sig[:3] or cur[4:] != sig[4:6]:     # the range epoch (index 3) moves with in-place range updates: fine
             return prequantize_weights(model)
-    plan.launch()
-    for (m, w, q), y in zip(mods, plan.outs):
-        m._wq_cache = y
-        m._wq_key = m._weight_cache_key(m.get_weight_bias()[0], q)
+    for m, w, q, src in mods:
+        if src is not None:
+            src.copy_(m.get_weight_bias()[0].detach().transpose(1, 0))     # the plan reads this copy: refresh it in place
+    _store_planned(mods, plan.launch())
     return len(mods)
 
 

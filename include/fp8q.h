@@ -201,7 +201,8 @@ int fp8q_mse_linspace_f32(const float *mx, int64_t C, int n_cand, double lo_frac
                           fp8q_stream_t stream);
 /* The first calibration batch of FP_MSE_Estimator in one launch: the row min / max (fp8q_minmax_f32, current fold), K5's
  * maxval_out[c] = |max(|min|, max)| = max|x| of the row, and the search grid of that maximum (what fp8q_mse_linspace_f32
- * would make of maxval_out), written by the thread that stores the row's range.  grid [n_cand, C]; workspace as fp8q_minmax_f32. */
+ * would make of maxval_out), written by the thread that stores the row's range.  grid [n_cand, C]; workspace as fp8q_minmax_f32.
+ * C <= 65535 (FP8Q_ETOOMANY, as fp8q_mse_grid_f32). */
 int fp8q_minmax_linspace_f32(const float *x, int64_t C, int64_t inner, float *cur_min, float *cur_max, float *maxval_out,
                              float *grid, int n_cand, double lo_frac, double hi_frac, void *ws, size_t ws_bytes,
                              fp8q_stream_t stream);
@@ -212,17 +213,12 @@ int fp8q_mse_select_f32(const float *mses, const float *grid, int64_t C, int64_t
 int fp8q_quantize_dm_f32(const float *x, float *y, int64_t C, int64_t inner, const float *maxval, int64_t n_maxval,
                          const float *mbits_dev, int n_bits, int sign_bits, fp8q_stream_t stream);
 
-/* fp8q_minmax_linspace_f32 that also clears column c of a [zero_rows, C] fp32 table (the estimator's accumulated MSE table)
- * from the thread that writes row c's grid: the first calibration batch needs no memset launch.  C <= 65535 (FP8Q_ETOOMANY). */
-int fp8q_minmax_linspace_zero_f32(const float *x, int64_t C, int64_t inner, float *cur_min, float *cur_max, float *maxval_out,
-                                  float *grid, int n_cand, double lo_frac, double hi_frac, float *zero_tab, int zero_rows,
-                                  void *ws, size_t ws_bytes, fp8q_stream_t stream);
-
 /*
  * One calibration step of a quantizer whose range comes from FP_MSE_Estimator, in ONE call:
  * QuantizationManager.forward in estimate_ranges state (quantization/quantization_manager.py:114-122) around
  * FP_MSE_Estimator.forward (quantization/range_estimators.py:318-369) --
- *   first != 0   row max|x| -> search grid linspace(0.1 max|x|, 1.2 max|x|, n_cand) per row, table cleared      (:295-316)
+ *   first != 0   row max|x| -> search grid linspace(0.1 max|x|, 1.2 max|x|, n_cand) per row; this batch's table entries are
+ *                written instead of added (the table need not be cleared beforehand)                            (:295-316)
  *   always       mses[n_m, n_cand, C] += row-mean((x - q(x; mbits[m], grid[i, c]))^2)   (fp8q_mse_grid_f32)   (:337-347)
  *                vote of the mantissa width, per-row argmin -> state.mbits / vote / maxval / xmin (fp8q_mse_select_f32) (:350-369)
  *   y != NULL    y = quantize(x; maxval, voted width)  (fp8q_quantize_f32 when n_m == 1, else fp8q_quantize_dm_f32)
@@ -312,6 +308,13 @@ int fp8q_quantizer_prepare_f32(const float *maxval, float mbits, int n_bits, int
 int fp8q_affine_act_quantize_ab_f32(const float *x, const float *residual, float *y, int64_t N, int64_t C, int64_t HW,
                                     const float *alpha_beta, int act, const float *maxval, const float *prep, float mbits,
                                     int n_bits, int sign_bits, fp8q_stream_t stream);
+
+/* The epilogue WITHOUT the quantizer: y = act(bn(x) + residual) (same kernels, same BN arithmetic, the quantizer switched off).
+ * What an MSE range estimator behind a BN + activation searches on during calibration (quantized_folded_bn.py:39-55 followed by
+ * range_estimators.py:318-369): one 8 B / element pass instead of torch's batch_norm + activation passes.  alpha_beta: the folded
+ * [C, 2] vector of fp8q_bn_fold_f32, or NULL (no batch norm). */
+int fp8q_affine_act_f32(const float *x, const float *residual, float *y, int64_t N, int64_t C, int64_t HW, const float *alpha_beta,
+                        int act, fp8q_stream_t stream);
 size_t fp8q_affine_act_minmax_workspace_bytes(int64_t N, int64_t C, int64_t HW);
 int fp8q_affine_act_minmax_f32(const float *x, const float *residual, int64_t N, int64_t C, int64_t HW,
                                const float *mean, const float *invstd, const float *gamma, const float *beta,

@@ -25,6 +25,8 @@ Fixture files:
   g9_mobilenetv2.npz QuantizedMobileNetV2 (models/mobilenet_v2_quantized.py:29-92) + MSE, config 4 at 64x64
   g1b_bulk.npz       quantize_to_fp8_ste_MM on 4 x 4 M seeded normals: output hash + sparse difference to the C oracle
   g10_autograd.npz   backward of quantize_to_fp8_ste_MM (d/dx, d/dmaxval)
+  g11_wrappers.npz   quantize_model on two toy nets built of the wrappers g7-g9 do not reach: QuantConv1d, QuantConvTranspose1d/2d
+                     (dims 0/1 swapped around the per-channel quantizer), BNQConv1d, BNQLinear, QuantLayerNorm (autoquant_utils.py:20-174)
   g1c_quantize_f64.npz quantize_to_fp8_ste_MM on FLOAT64 inputs (ATen type promotion: bias float32, the rest float64)
   (g5 also holds LineSearchEstimator.loss_array -- 1001 float64 sums per distribution and format -- and the chosen index)
 """
@@ -354,6 +356,85 @@ def make_g7():
             out[f"{tag}_maxval_{n}"] = m.quantizer.maxval.numpy().copy()
     np.savez_compressed(os.path.join(OUT, "g7_tinycnn.npz"), **out)
     print("g7 ok")
+
+
+def wrapper_nets():
+    """Two toy nets that go through every operator wrapper g7-g9 do not touch (autoquant_utils.py:20-31, 46-87, 94-105,
+    120-122, 166-174): net1d = Conv1d+BN1d+ReLU (BNQConv1d), Conv1d+ReLU6 (QuantConv1d), ConvTranspose1d
+    (QuantConvTranspose1d: weight dims 0/1 swapped around the per-channel quantizer), Flatten, Linear+BN1d+ReLU (BNQLinear),
+    LayerNorm (QuantLayerNorm), Linear; net2d = Conv2d+ReLU, ConvTranspose2d+BN-free+ReLU (QuantConvTranspose), ConvTranspose2d
+    with groups, AdaptiveAvgPool2d, Flatten, Linear.  Committed weights < 100 KB."""
+    torch.manual_seed(11)
+    net1d = nn.Sequential(nn.Conv1d(4, 8, 3, padding=1, bias=False), nn.BatchNorm1d(8), nn.ReLU(),
+                          nn.Conv1d(8, 8, 3, padding=1, bias=True), nn.ReLU6(),
+                          nn.ConvTranspose1d(8, 6, 4, stride=2, padding=1, bias=True),
+                          nn.Flatten(), nn.Linear(6 * 32, 16, bias=False), nn.BatchNorm1d(16), nn.ReLU(),
+                          nn.LayerNorm(16), nn.Linear(16, 5))
+    net2d = nn.Sequential(nn.Conv2d(3, 6, 3, padding=1), nn.ReLU(),
+                          nn.ConvTranspose2d(6, 10, 3, stride=2, padding=1, output_padding=1, bias=False), nn.ReLU(),
+                          nn.ConvTranspose2d(10, 4, 2, stride=1, groups=2, bias=True),
+                          nn.AdaptiveAvgPool2d(1), nn.Flatten(), nn.Linear(4, 7))
+    with torch.no_grad():
+        for net in (net1d, net2d):
+            for m in net.modules():
+                if isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d)):
+                    m.running_mean.normal_(0, 0.2)
+                    m.running_var.uniform_(0.5, 1.5)
+                    m.weight.uniform_(0.5, 1.5)
+                    m.bias.normal_(0, 0.1)
+                if isinstance(m, nn.LayerNorm):
+                    m.weight.uniform_(0.5, 1.5)
+                    m.bias.normal_(0, 0.1)
+    return net1d.eval(), net2d.eval()
+
+
+def make_g11():
+    """The operator wrappers no other fixture reaches, through the reference's quantize_model with BASELINE config-3 settings
+    (fp_quantizer E5M2 and E4M3, per-channel current_minmax weights, per-tensor allminmax activations) and, for the weights,
+    per-TENSOR ranges as well (the transposed convolutions swap dims only when per_channel_weights is set)."""
+    from quantization.autoquant_utils import quantize_model
+    from quantization.base_quantized_classes import QuantizedModule
+    out = {}
+    nets = dict(zip(("net1d", "net2d"), wrapper_nets()))
+    torch.manual_seed(12)
+    data = dict(net1d=(torch.randn(8, 4, 16), torch.randn(8, 4, 16) * 1.3),
+                net2d=(torch.randn(8, 3, 8, 8), torch.randn(8, 3, 8, 8) * 1.3))
+    for name, net in nets.items():
+        for k, v in net.state_dict().items():
+            out[f"{name}_sd_{k}"] = v.numpy().copy()
+        out[f"{name}_calib"], out[f"{name}_val"] = data[name][0].numpy(), data[name][1].numpy()
+        for tag, M, pcw in (("e5m2", 2, True), ("e4m3", 3, True), ("e4m3_pt", 3, False)):
+            qparams = dict(method=QMethods.fp_quantizer.cls, act_method=None,
+                           weight_range_method=RangeEstimators.current_minmax.cls,
+                           act_range_method=RangeEstimators.allminmax.cls, n_bits=8, n_bits_act=8,
+                           per_channel_weights=pcw, percentile=None, quantize_input=False,
+                           fp8_kwargs=dict(maxval=None, mantissa_bits=M, set_maxval=True, learn_maxval=False,
+                                           learn_mantissa_bits=False, mse_include_mantissa_bits=False,
+                                           allow_unsigned=False))
+            q = quantize_model(copy_net(net), tie_activation_quantizers=True, **qparams).eval()
+            out[f"{name}_{tag}_classes"] = np.array([type(m).__name__ for m in q])
+
+            def each(fn):
+                for m in q.modules():
+                    if isinstance(m, QuantizedModule):
+                        fn(m)
+            calib, val = data[name]
+            with torch.no_grad():
+                out[f"{name}_{tag}_fp_logits"] = q(val).numpy().copy()
+                each(lambda m: m.quantized())
+                out[f"{name}_{tag}_calib_logits"] = q(calib).numpy().copy()
+                each(lambda m: m.fix_ranges())
+                out[f"{name}_{tag}_val_logits"] = q(val).numpy().copy()
+                # every layer's quantized weight (what run_forward receives), in the layer's own layout
+                for n, m in q.named_modules():
+                    if hasattr(m, "weight_quantizer") and hasattr(m, "get_params"):
+                        out[f"{name}_{tag}_wq_{n}"] = m.get_params()[0].numpy().copy()
+            mgrs = [(n, m) for n, m in q.named_modules() if isinstance(m, QuantizationManager)]
+            out[f"{name}_{tag}_mgr_names"] = np.array([n for n, _ in mgrs])
+            for n, m in mgrs:
+                out[f"{name}_{tag}_maxval_{n}"] = m.quantizer.maxval.numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "g11_wrappers.npz"), **out)
+    print("g11 ok:", len(out), "arrays")
 
 
 def edge_inputs_f64(M, maxval, sign_bits, n_bits=8):
@@ -722,4 +803,5 @@ if __name__ == "__main__":
     make_g7()
     make_g8()
     make_g9()
+    make_g11()
     assert not os.path.exists(os.path.join(REF, "quantization", "__pycache__")), "pycache leaked"
