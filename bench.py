@@ -364,14 +364,16 @@ class LaunchTimer:
         if cal is not None:
             self.saved_step = real_step = cal.step
 
-            def step(self_cal, x, quantize=True):
+            def step(self_cal, x, quantize=True, pre=None):
                 if not timer.on:
-                    return real_step(self_cal, x, quantize)
+                    return real_step(self_cal, x, quantize, pre)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                out = real_step(self_cal, x, quantize)
+                out = real_step(self_cal, x, quantize, pre)
                 e1.record()
-                timer.rec.append(("mse_calibrate", e0, e1, x.numel(), x.numel() * self.MSE_CALIBRATE_BPE))
+                extra = 4 * x.numel() if (pre is not None and pre[1] is not None) else 0       # the residual
+                timer.rec.append(("mse_calibrate_fused_epilogue" if pre is not None else "mse_calibrate", e0, e1, x.numel(),
+                                  x.numel() * self.MSE_CALIBRATE_BPE + extra))
                 return out
             cal.step = step
 
@@ -587,7 +589,11 @@ def model_configs(ops, dev, only=None):
                     if "fp32_forward_ms" not in entry:
                         entry["fp32_forward_ms"] = _wall_ms(lambda: m(x))
                     cal = calibrate(m)
-                    k4 = cal["by_entry"].get("mse_grid") or cal["by_entry"].get("mse_calibrate")
+                    k4 = cal["by_entry"].get("mse_grid")
+                    if k4 is None:      # the one-call step: search + selection + quantization of every MSE quantizer
+                        parts = [cal["by_entry"].get(k) for k in ("mse_calibrate", "mse_calibrate_fused_epilogue")]
+                        parts = [p_ for p_ in parts if p_]
+                        k4 = dict(us=sum(p_["us"] for p_ in parts), elements=sum(p_["elements"] for p_ in parts)) if parts else None
                     if k4:
                         n_m = 6 if search else 1
                         cal["k4_share_of_library_time"] = round(k4["us"] / max(cal["library_us"], 1e-3), 3)

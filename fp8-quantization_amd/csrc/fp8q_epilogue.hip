@@ -310,11 +310,15 @@ k_affine_act_small(const float *__restrict__ x, const float *__restrict__ res, f
 // trade-offs differ from the quantizing kernel: a persistent grid of <= 2048 blocks with 4 KiB steps, plain
 // loads and the constants straight from global measured best (36 us at [64,64,112,112]; 16 KiB steps, LDS-staged
 // constants, nontemporal loads or one piece per block: 42-55 us).
+// STORE: the transformed tensor t is also written (fp8q_affine_act_minmax_linspace_f32: the first calibration batch of an MSE
+// estimator behind a BN + activation needs t itself, its abs-max and the search grid of that maximum -- one pass instead of
+// torch's batch_norm + activation + this library's abs-max pass).
+template <bool STORE>
 __global__ void __launch_bounds__(kBlock)
 k_affine_minmax(const float *__restrict__ x, const float *__restrict__ res, const float *__restrict__ mean,
                 const float *__restrict__ invstd, const float *__restrict__ gamma,
                 const float *__restrict__ beta, AffineArgs a, int64_t N, unsigned long long *slots, int nparts,
-                unsigned tag, float *cur_min, float *cur_max, float *maxval_out, FoldArgs fa)
+                unsigned tag, float *cur_min, float *cur_max, float *maxval_out, FoldArgs fa, float *__restrict__ t_out)
 {
     const int nby = nparts / (int)gridDim.x;   // block rows that stream; one more row holds the reducer (nparts > 1)
     if ((int)blockIdx.y == nby) {
@@ -356,6 +360,7 @@ k_affine_minmax(const float *__restrict__ x, const float *__restrict__ res, cons
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) mm_acc(mm, e[q]);
+        if (STORE) reinterpret_cast<vf4 *>(t_out + base)[j] = vf4{e[0], e[1], e[2], e[3]};
     }
     }
     block_minmax_publish(mm, slots, (int)(blockIdx.y * gridDim.x + blockIdx.x), nparts, tag, 0, cur_min, cur_max,
@@ -539,10 +544,12 @@ size_t fp8q_affine_act_minmax_workspace_bytes(int64_t N, int64_t C, int64_t HW)
 static int affine_minmax_impl(const float *x, const float *residual, int64_t N, int64_t C, int64_t HW,
                               const float *mean, const float *invstd, const float *gamma, const float *beta,
                               int act, float *cur_min, float *cur_max, float *maxval_out, float *packed, int fold_mode,
-                              double momentum, int first, void *ws, size_t ws_bytes, fp8q_stream_t stream)
+                              double momentum, int first, void *ws, size_t ws_bytes, fp8q_stream_t stream,
+                              int has_bn = -1, float *t_out = nullptr, float *lin_grid = nullptr, int lin_steps = 0,
+                              double lin_lo = 0.0, double lin_hi = 0.0)
 {
-    const int has_bn = mean != nullptr;
-    if (has_bn && (!invstd || !gamma || !beta)) return FP8Q_EINVAL;
+    if (has_bn < 0) has_bn = mean != nullptr;
+    if (has_bn == 1 && (!invstd || !gamma || !beta)) return FP8Q_EINVAL;
     AffineArgs a;
     if (int rc = affine_args(N, C, HW, act, has_bn, residual != nullptr, &a)) return rc;
     if (N <= 0 || !x || !cur_min || !cur_max || fold_mode < 0 || fold_mode > 2) return FP8Q_EINVAL;
@@ -566,12 +573,22 @@ static int affine_minmax_impl(const float *x, const float *residual, int64_t N, 
     fa.mo = (float)momentum;
     fa.packed = packed;
     fa.status = (unsigned *)ws;
+    fa.lin_grid = lin_grid;
+    fa.lin_steps = lin_steps;
+    fa.lin_C = 1;
+    fa.lin_lo = lin_lo;
+    fa.lin_hi = lin_hi;
     fold_debug_env(fa);
     const int nparts = (int)(bx * by);
     // one more block row for the reducer when there is more than one streaming block (by <= 65535 - 1: affine_grid)
-    hipLaunchKernelGGL(k_affine_minmax, dim3((unsigned)bx, (unsigned)(nparts > 1 ? by + 1 : by)), dim3(kBlock), 0, st, x,
-                       residual, mean, invstd, gamma, beta, a, N, (unsigned long long *)((char *)ws + kMinmaxWsHeader), nparts,
-                       next_minmax_tag(), cur_min, cur_max, maxval_out, fa);
+    if (t_out)
+        hipLaunchKernelGGL(k_affine_minmax<true>, dim3((unsigned)bx, (unsigned)(nparts > 1 ? by + 1 : by)), dim3(kBlock), 0, st, x,
+                           residual, mean, invstd, gamma, beta, a, N, (unsigned long long *)((char *)ws + kMinmaxWsHeader), nparts,
+                           next_minmax_tag(), cur_min, cur_max, maxval_out, fa, t_out);
+    else
+        hipLaunchKernelGGL(k_affine_minmax<false>, dim3((unsigned)bx, (unsigned)(nparts > 1 ? by + 1 : by)), dim3(kBlock), 0, st, x,
+                           residual, mean, invstd, gamma, beta, a, N, (unsigned long long *)((char *)ws + kMinmaxWsHeader), nparts,
+                           next_minmax_tag(), cur_min, cur_max, maxval_out, fa, nullptr);
     return launch_rc();
 }
 
@@ -593,6 +610,16 @@ int fp8q_affine_act_minmax_packed_f32(const float *x, const float *residual, int
     if (!packed) return FP8Q_EINVAL;
     return affine_minmax_impl(x, residual, N, C, HW, mean, invstd, gamma, beta, act, cur_min, cur_max, maxval_out, packed,
                               fold_mode, momentum, first, ws, ws_bytes, stream);
+}
+
+int fp8q_affine_act_minmax_linspace_f32(const float *x, const float *residual, float *t, int64_t N, int64_t C, int64_t HW,
+                                        const float *alpha_beta, int act, float *cur_min, float *cur_max, float *maxval_out,
+                                        float *grid, int n_cand, double lo_frac, double hi_frac, void *ws, size_t ws_bytes,
+                                        fp8q_stream_t stream)
+{
+    if (!t || !grid || !maxval_out || n_cand < 2 || n_cand > (1 << 20) || ((uintptr_t)alpha_beta & 7) || ((uintptr_t)t & 15)) return FP8Q_EINVAL;
+    return affine_minmax_impl(x, residual, N, C, HW, alpha_beta, nullptr, nullptr, nullptr, act, cur_min, cur_max, maxval_out, nullptr,
+                              FP8Q_FOLD_CURRENT, 0.0, 1, ws, ws_bytes, stream, alpha_beta ? 2 : 0, t, grid, n_cand, lo_frac, hi_frac);
 }
 
 }  // extern "C"

@@ -1,5 +1,6 @@
 // fp8q_mse.hip -- K4: FP-MSE grid search (FP_MSE_Estimator / LineSearchEstimator candidates in one pass over x).
 #include "fp8q_common.h"
+#include "fp8q_select.h"
 
 namespace {
 
@@ -611,22 +612,25 @@ k_mse_row(const float *__restrict__ x, const float *__restrict__ grid, double *_
 
 // mses[m, i, c] += (sum over the splits of row (c, m, i)) / inner: one wave per row of partial sums, in double
 __global__ void __launch_bounds__(kBlock)
-k_mse_final(const double *__restrict__ ws, float *__restrict__ mses, int64_t C, int n_m, int n_cand,
-            int64_t nsplit, double inv_inner, int overwrite)
+k_mse_final(const double *__restrict__ ws, float *mses, int64_t C, int n_m, int n_cand,
+            int64_t nsplit, double inv_inner, int overwrite, const float *__restrict__ grid, SelOne so)
 {
     const int64_t total = C * n_m * n_cand;
     const int lane = threadIdx.x & 63;
     const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // ws row: ((c * n_m + m) * n_cand + i)
-    if (j >= total) return;
-    double sum = 0.0;
-    for (int64_t s2 = lane; s2 < nsplit; s2 += 64) sum += ws[j * nsplit + s2];
+    if (j < total) {
+        double sum = 0.0;
+        for (int64_t s2 = lane; s2 < nsplit; s2 += 64) sum += ws[j * nsplit + s2];
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
-    if (lane == 0) {
-        const int64_t c = j / ((int64_t)n_m * n_cand);
-        const int64_t mi = j - c * n_m * n_cand;   // m * n_cand + i
-        table_add(mses + mi * C + c, (float)(sum * inv_inner), overwrite);
+        for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+        if (lane == 0) {
+            const int64_t c = j / ((int64_t)n_m * n_cand);
+            const int64_t mi = j - c * n_m * n_cand;   // m * n_cand + i
+            table_add(mses + mi * C + c, (float)(sum * inv_inner), overwrite);
+        }
     }
+    // per-tensor quantizers: the last workgroup also selects the winner (fp8q_select.h)
+    if (so.enabled && last_workgroup(so.ticket, gridDim.x)) select_one_row(mses, grid, n_m, n_cand, so);
 }
 
 // The same for FEW splits per row (per-channel weights: 1-32 partial sums, but C x n_m x n_cand rows -- 852 K for a
@@ -637,8 +641,8 @@ k_mse_final(const double *__restrict__ ws, float *__restrict__ mses, int64_t C, 
 constexpr int kFinTC = 16, kFinTM = 64;
 
 __global__ void __launch_bounds__(kBlock)
-k_mse_final_tile(const double *__restrict__ ws, float *__restrict__ mses, int64_t C, int64_t NM /* n_m * n_cand */, int nsplit,
-                 double inv_inner, int overwrite)
+k_mse_final_tile(const double *__restrict__ ws, float *mses, int64_t C, int64_t NM /* n_m * n_cand */, int nsplit,
+                 double inv_inner, int overwrite, const float *__restrict__ grid, int n_m, int n_cand, SelOne so)
 {
     __shared__ float tile[kFinTC][kFinTM + 1];
     const int64_t c0 = (int64_t)blockIdx.y * kFinTC, m0 = (int64_t)blockIdx.x * kFinTM;
@@ -661,6 +665,7 @@ k_mse_final_tile(const double *__restrict__ ws, float *__restrict__ mses, int64_
         const int64_t c = c0 + lc, mi = m0 + lm;
         if (c < C && mi < NM) table_add(mses + mi * C + c, tile[lc][lm], overwrite);
     }
+    if (so.enabled && last_workgroup(so.ticket, gridDim.x * gridDim.y)) select_one_row(mses, grid, n_m, n_cand, so);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -678,33 +683,6 @@ k_mse_linspace(const float *__restrict__ mx, int64_t C, int steps, double lo_fra
     const int i = (int)(idx / C);
     const int64_t c = idx - (int64_t)i * C;
     grid[idx] = linspace_at(mx[c], lo_frac, hi_frac, steps, i);
-}
-
-// torch.min / torch.argmin over one dimension: the first index of the smallest value, a NaN counting as smaller than
-// everything (the first NaN wins).  Key = (isnan desc, value asc, index asc).
-struct ArgMin {
-    float v;
-    int idx;
-};
-
-__device__ __forceinline__ bool argmin_less(const ArgMin &a, const ArgMin &b)
-{
-    const bool an = a.v != a.v, bn = b.v != b.v;
-    if (an != bn) return an;
-    if (!an && a.v != b.v) return a.v < b.v;
-    return a.idx < b.idx;
-}
-
-__device__ __forceinline__ ArgMin wave_argmin(ArgMin a)
-{
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        ArgMin o;
-        o.v = __shfl_xor(a.v, off, 64);
-        o.idx = __shfl_xor(a.idx, off, 64);
-        if (argmin_less(o, a)) a = o;
-    }
-    return a;
 }
 
 // Winner selection in ONE launch (round 4: two dependent ones, 930 launches of 3-34 us per MobileNetV2 calibration batch).
@@ -778,7 +756,7 @@ k_mse_select(const float *__restrict__ mses, const float *__restrict__ grid, int
 size_t fp8q_mse_hist_workspace_bytes(int64_t n, int64_t n_pairs);
 bool fp8q_mse_hist_supported(const QFmt *fmts, int n_m, int n_bits);
 int fp8q_mse_hist_launch(const float *x, int64_t n, const float *grid, int64_t n_cand, const QFmt *fmts, int n_m, float *mses,
-                         void *ws, size_t ws_bytes, hipStream_t st, int brute, int overwrite);
+                         void *ws, size_t ws_bytes, hipStream_t st, int brute, int overwrite, const SelOne *sel);
 
 // FP8Q_MSE_HIST: 1 (default) = long per-tensor rows of a signed format of <= 8 bits go through the interval-histogram
 // evaluation; 0 = never (the lane-per-element kernel everywhere); 2 = same routing with every candidate evaluated element by
@@ -930,8 +908,13 @@ size_t fp8q_mse_workspace_bytes(int64_t C, int64_t inner, int64_t n_cand, int n_
 
 static int mse_grid_impl(const float *x, int64_t C, int64_t inner, const float *grid, int64_t n_cand,
                          const float *mbits_host, int n_m, int n_bits, int sign_bits, float *mses,
-                         void *ws, size_t ws_bytes, fp8q_stream_t stream, int overwrite)
+                         void *ws, size_t ws_bytes, fp8q_stream_t stream, int overwrite, const SelOne *sel = nullptr,
+                         int *sel_done = nullptr)
 {
+    SelOne so;
+    memset(&so, 0, sizeof(so));
+    if (sel && C == 1) so = *sel;      // the winner selection rides on the launch that finishes the table (one row only)
+    if (sel_done) *sel_done = 0;
     if (!x || !grid || !mbits_host || !mses || C <= 0 || inner <= 0 || n_cand <= 0 || n_m <= 0 ||
         n_m > kMseMaxM || n_cand > (1 << 20))
         return FP8Q_EINVAL;
@@ -954,7 +937,10 @@ static int mse_grid_impl(const float *x, int64_t C, int64_t inner, const float *
     a.overwrite = overwrite;
     hipStream_t st = (hipStream_t)stream;
     if (mse_use_hist_shape(C, inner, n_cand, n_m) && fp8q_mse_hist_supported(a.fmt, n_m, n_bits))
-        return fp8q_mse_hist_launch(x, inner, grid, n_cand, a.fmt, n_m, mses, ws, ws_bytes, st, mse_hist_mode() == 2, overwrite);
+    {
+        if (sel_done) *sel_done = so.enabled;
+        return fp8q_mse_hist_launch(x, inner, grid, n_cand, a.fmt, n_m, mses, ws, ws_bytes, st, mse_hist_mode() == 2, overwrite, &so);
+    }
     int64_t nsplit = a.nsplit;
     if (mse_use_row(C, inner) && ((uintptr_t)x & 3) == 0) {
         const RowGeo g = mse_row_geo(C, inner, n_cand, n_m);
@@ -977,10 +963,12 @@ static int mse_grid_impl(const float *x, int64_t C, int64_t inner, const float *
     const int64_t rows = C * n_m * n_cand;
     if (nsplit <= 32 && cdiv(C, kFinTC) <= 65535)
         hipLaunchKernelGGL(k_mse_final_tile, dim3((unsigned)cdiv(n_m * n_cand, kFinTM), (unsigned)cdiv(C, kFinTC)), dim3(kBlock), 0, st,
-                           (const double *)ws, mses, C, (int64_t)n_m * n_cand, (int)nsplit, 1.0 / (double)inner, overwrite);
+                           (const double *)ws, mses, C, (int64_t)n_m * n_cand, (int)nsplit, 1.0 / (double)inner, overwrite, grid, n_m,
+                           (int)n_cand, so);
     else
         hipLaunchKernelGGL(k_mse_final, dim3((unsigned)cdiv(rows, 4)), dim3(kBlock), 0, st, (const double *)ws, mses, C,
-                           n_m, (int)n_cand, nsplit, 1.0 / (double)inner, overwrite);
+                           n_m, (int)n_cand, nsplit, 1.0 / (double)inner, overwrite, grid, so);
+    if (sel_done) *sel_done = so.enabled;
     return launch_rc();
 }
 
@@ -1003,9 +991,10 @@ size_t fp8q_mse_calibrate_workspace_bytes(int64_t C, int64_t inner, int64_t n_ca
 // (fp8q_minmax_linspace_f32, fp8q_mse_grid_f32, fp8q_mse_select_f32, fp8q_quantize[_dm]_f32: ~45 us of host time each
 // through ctypes + torch allocations) is enqueued from here; the host side of a calibration batch was the critical path
 // of BASELINE config 4 (profiles/r06_host_profile.txt).
-int fp8q_mse_calibrate_f32(const float *x, float *y, int64_t C, int64_t inner, const fp8q_mse_state *s, int first, int n_cand,
-                           const float *mbits_host, int n_m, int n_bits, int sign_bits, void *ws_minmax, size_t ws_minmax_bytes,
-                           void *ws_select, size_t ws_select_bytes, void *ws_mse, size_t ws_mse_bytes, fp8q_stream_t stream)
+int fp8q_mse_calibrate_f32(float *x, float *y, int64_t C, int64_t inner, const fp8q_mse_state *s, int first, int n_cand,
+                           const float *mbits_host, int n_m, int n_bits, int sign_bits, const fp8q_affine_pre *pre, void *ws_minmax,
+                           size_t ws_minmax_bytes, void *ws_select, size_t ws_select_bytes, void *ws_mse, size_t ws_mse_bytes,
+                           fp8q_stream_t stream)
 {
     if (!s || !x || !s->grid || !s->mses || !s->maxval || !s->mbits || !mbits_host || C <= 0 || inner <= 0 || n_cand < 2 ||
         n_m <= 0 || n_m > kMseMaxM)
@@ -1015,22 +1004,40 @@ int fp8q_mse_calibrate_f32(const float *x, float *y, int64_t C, int64_t inner, c
         if (int rc = make_fmt(mbits_host[m], n_bits, sign_bits, &f)) return rc;
     }
     if (C > 65535) return FP8Q_ETOOMANY;
+    if (pre && (C != 1 || !pre->x || pre->N <= 0 || pre->N * pre->C * pre->HW != inner)) return FP8Q_EINVAL;
     if (!ws_mse || ws_mse_bytes < fp8q_mse_workspace_bytes(C, inner, n_cand, n_m) || ((uintptr_t)ws_mse & 7)) return FP8Q_EWORKSPACE;
     if (!ws_select || ws_select_bytes < fp8q_mse_select_workspace_bytes(C, n_m) || ((uintptr_t)ws_select & 3)) return FP8Q_EWORKSPACE;
     if (first) {
         // max|x| per row and the search grid of that maximum in one launch (:295-316); the table needs no clearing: the
-        // first batch's entries are written, not added
+        // first batch's entries are written, not added.  Behind a BN + activation the same launch also writes t.
         if (!s->cur_min || !s->cur_max || !s->absmax) return FP8Q_EINVAL;
-        if (int rc = fp8q_minmax_linspace_f32(x, C, inner, s->cur_min, s->cur_max, s->absmax, s->grid, n_cand, 0.1, 1.2, ws_minmax,
-                                              ws_minmax_bytes, stream))
-            return rc;
+        const int rc = pre ? fp8q_affine_act_minmax_linspace_f32(pre->x, pre->residual, x, pre->N, pre->C, pre->HW, pre->alpha_beta, pre->act,
+                                                                 s->cur_min, s->cur_max, s->absmax, s->grid, n_cand, 0.1, 1.2, ws_minmax,
+                                                                 ws_minmax_bytes, stream)
+                           : fp8q_minmax_linspace_f32(x, C, inner, s->cur_min, s->cur_max, s->absmax, s->grid, n_cand, 0.1, 1.2, ws_minmax,
+                                                      ws_minmax_bytes, stream);
+        if (rc) return rc;
+    } else if (pre) {
+        if (int rc = fp8q_affine_act_f32(pre->x, pre->residual, x, pre->N, pre->C, pre->HW, pre->alpha_beta, pre->act, stream)) return rc;
     }
+    SelOne so;
+    memset(&so, 0, sizeof(so));
+    so.mbits_out = s->mbits;
+    so.vote_out = s->vote;
+    so.maxval_out = s->maxval;
+    so.xmin_out = s->xmin;
+    so.ticket = (unsigned *)ws_select + 1;      // the selection workspace's header word: zero between calls
+    so.sign = -(float)sign_bits;
+    for (int m = 0; m < n_m; ++m) so.M[m] = mbits_host[m];
+    so.enabled = 1;
+    int sel_done = 0;
     if (int rc = mse_grid_impl(x, C, inner, s->grid, n_cand, mbits_host, n_m, n_bits, sign_bits, s->mses, ws_mse, ws_mse_bytes, stream,
-                               first != 0))
+                               first != 0, &so, &sel_done))
         return rc;
-    if (int rc = fp8q_mse_select_f32(s->mses, s->grid, C, n_cand, mbits_host, n_m, sign_bits, s->mbits, s->vote, s->maxval, s->xmin,
-                                     ws_select, ws_select_bytes, stream))
-        return rc;
+    if (!sel_done)
+        if (int rc = fp8q_mse_select_f32(s->mses, s->grid, C, n_cand, mbits_host, n_m, sign_bits, s->mbits, s->vote, s->maxval, s->xmin,
+                                         ws_select, ws_select_bytes, stream))
+            return rc;
     if (!y) return FP8Q_OK;
     // the batch itself, with the range (and width) just chosen (:119-122: estimate, set the range, then quantize)
     if (n_m == 1) return fp8q_quantize_f32(x, y, C, inner, s->maxval, C, mbits_host[0], n_bits, sign_bits, stream);

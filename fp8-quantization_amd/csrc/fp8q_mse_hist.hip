@@ -32,6 +32,7 @@
 // contract (include/fp8q.h).  Cost for a 25.7 M-element activation: 12 B of HBM traffic per key for the partition (histogram pass 4, scatter
 // 4 + 4) + 4 B for the moments, independent of the number of candidates.  No library primitive: everything here is hand-written.
 #include "fp8q_common.h"
+#include "fp8q_select.h"
 
 namespace {
 
@@ -1094,8 +1095,8 @@ __global__ void __launch_bounds__(kBlock)
 k_mse_eval(const float *__restrict__ x, const float *__restrict__ grid, const float *__restrict__ bt, const float *__restrict__ bq,
            const uint32_t *__restrict__ rank, const int *__restrict__ cflag, const uint32_t *__restrict__ maxkey,
            const DD *__restrict__ p1, const DD *__restrict__ p2, const uint32_t *__restrict__ pn, const DD *__restrict__ t1,
-           const DD *__restrict__ t2, const uint32_t *__restrict__ tn, int64_t ni, int nsb, float *__restrict__ mses, HistArgs a,
-           double inv_inner, const uint32_t *__restrict__ nunits)
+           const DD *__restrict__ t2, const uint32_t *__restrict__ tn, int64_t ni, int nsb, float *mses, HistArgs a,
+           double inv_inner, const uint32_t *__restrict__ nunits, SelOne so)
 {
     __shared__ double s_red[kBlock];
     __shared__ float s_scale[kLutMax];
@@ -1107,16 +1108,17 @@ k_mse_eval(const float *__restrict__ x, const float *__restrict__ grid, const fl
     // non-finite keys: the reference's mean is NaN (a NaN element) or +inf (an infinite one: (x - xq)^2 = inf)
     const uint32_t last = maxkey[0];
     const int flag = cflag[j];
-    if (last > 0x7f800000u || flag == kFlagNaN || nunits[2]) {
-        if (tid == 0) *out = a.overwrite ? __builtin_nanf("") : *out + __builtin_nanf("");
-        return;
-    }
-    if (last == 0x7f800000u) {
-        if (tid == 0) *out = a.overwrite ? __builtin_inff() : *out + __builtin_inff();
-        return;
+    const bool is_nan = last > 0x7f800000u || flag == kFlagNaN || nunits[2], is_inf = !is_nan && last == 0x7f800000u;
+    if (is_nan || is_inf) {
+        if (tid == 0) {
+            const float v = is_nan ? __builtin_nanf("") : __builtin_inff();
+            *out = a.overwrite ? v : *out + v;
+        }
+        // (falls through to the selection ticket below: every workgroup of the launch takes part)
     }
     double acc = 0.0;
-    if (flag == kFlagBrute) {
+    if (is_nan || is_inf) {
+    } else if (flag == kFlagBrute) {
         // element by element with K1's exact arithmetic (slow: one workgroup walks the whole tensor): candidates whose
         // scales leave the normal range, and every candidate under FP8Q_MSE_HIST=2 (the self-check the tests use)
         const QFmt f = a.fmt[m];
@@ -1222,11 +1224,13 @@ k_mse_eval(const float *__restrict__ x, const float *__restrict__ grid, const fl
         if (tid < off) s_red[tid] += s_red[tid + off];
         __syncthreads();
     }
-    if (tid == 0) {
+    if (tid == 0 && !(is_nan || is_inf)) {
         double tot = s_red[0] < 0.0 ? 0.0 : s_red[0];           // (rounding can leave a tiny negative number for an exact fit)
         if (a.uns && flag != kFlagBrute) tot += reinterpret_cast<const double *>(maxkey)[1];   // negative elements: x^2 each
         *out = a.overwrite ? (float)(tot * inv_inner) : *out + (float)(tot * inv_inner);
     }
+    // the winner of the search: the last workgroup to finish its entry selects (fp8q_select.h; per-tensor quantizers)
+    if (so.enabled && last_workgroup(so.ticket, gridDim.x)) select_one_row(mses, grid, a.n_m, a.n_cand, so);
 }
 
 // ---- host -----------------------------------------------------------------------------------------------------------------
@@ -1330,7 +1334,7 @@ bool fp8q_mse_hist_supported(const QFmt *fmts, int n_m, int n_bits)
 }
 
 int fp8q_mse_hist_launch(const float *x, int64_t n, const float *grid, int64_t n_cand, const QFmt *fmts, int n_m, float *mses,
-                         void *ws, size_t ws_bytes, hipStream_t st, int brute, int overwrite)
+                         void *ws, size_t ws_bytes, hipStream_t st, int brute, int overwrite, const SelOne *sel)
 {
     if (n_m > kHistMaxM || n >= (1ll << 31) || ((uintptr_t)ws & 7)) return FP8Q_EWORKSPACE;
     HistArgs a;
@@ -1405,7 +1409,10 @@ int fp8q_mse_hist_launch(const float *x, int64_t n, const float *grid, int64_t n
         hipLaunchKernelGGL(k_iv_scan_top, dim3(1), dim3(64), 0, st, t1, t2, tn, L.nsb);
         if (int rc = launch_rc()) return rc;
     }
+    SelOne so;
+    memset(&so, 0, sizeof(so));
+    if (sel) so = *sel;
     hipLaunchKernelGGL(k_mse_eval, dim3((unsigned)n_pairs), dim3(kBlock), 0, st, x, grid, bt, bq, rank, cflag, maxkey, p1, p2, pn, t1,
-                       t2, tn, L.ni, (int)L.nsb, mses, a, 1.0 / (double)n, nunits);
+                       t2, tn, L.ni, (int)L.nsb, mses, a, 1.0 / (double)n, nunits, so);
     return launch_rc();
 }

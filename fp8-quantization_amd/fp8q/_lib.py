@@ -20,6 +20,11 @@ class MseState(ctypes.Structure):
                 ("xmin", _vp), ("mbits", _vp), ("vote", _vp)]
 
 
+class AffinePre(ctypes.Structure):
+    """fp8q_affine_pre (include/fp8q.h): the BN + activation (+ residual) in front of a per-tensor MSE-calibrated quantizer"""
+    _fields_ = [("x", _vp), ("residual", _vp), ("alpha_beta", _vp), ("N", _i64), ("C", _i64), ("HW", _i64), ("act", _i)]
+
+
 class TensorDesc(ctypes.Structure):
     """fp8q_tensor_desc (include/fp8q.h)"""
     _fields_ = [("x", _vp), ("y", _vp), ("maxval", _vp), ("C", _i64), ("inner", _i64), ("n_maxval", _i64),
@@ -52,7 +57,7 @@ SIGNATURES = {
     "fp8q_mse_calibrate_workspace_bytes": (ctypes.c_size_t, [_i64, _i64, _i64, _i, ctypes.POINTER(ctypes.c_size_t),
                                                              ctypes.POINTER(ctypes.c_size_t)]),
     "fp8q_mse_calibrate_f32": (_i, [_vp, _vp, _i64, _i64, ctypes.POINTER(MseState), _i, _i, ctypes.POINTER(_f), _i, _i, _i,
-                                    _vp, ctypes.c_size_t, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t, _vp]),
+                                    ctypes.POINTER(AffinePre), _vp, ctypes.c_size_t, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t, _vp]),
     "fp8q_quantize_f64": (_i, [_vp, _vp, _i64, _i64, _vp, _i64, _f, _i, _i, _vp]),
     "fp8q_minmax_f64_workspace_bytes": (ctypes.c_size_t, [_i64, _i64]),
     "fp8q_minmax_f64": (_i, [_vp, _i64, _i64, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
@@ -65,6 +70,8 @@ SIGNATURES = {
     "fp8q_quantizer_prepare_f32": (_i, [_vp, _f, _i, _i, _vp, _vp]),
     "fp8q_affine_act_quantize_ab_f32": (_i, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _i, _vp, _vp, _f, _i, _i, _vp]),
     "fp8q_affine_act_f32": (_i, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _i, _vp]),
+    "fp8q_affine_act_minmax_linspace_f32": (_i, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _i, _vp, _vp, _vp, _vp, _i, ctypes.c_double,
+                                                 ctypes.c_double, _vp, ctypes.c_size_t, _vp]),
     "fp8q_affine_act_minmax_workspace_bytes": (ctypes.c_size_t, [_i64, _i64, _i64]),
     "fp8q_affine_act_minmax_f32": (_i, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i,
                                         ctypes.c_double, _i, _vp, ctypes.c_size_t, _vp]),

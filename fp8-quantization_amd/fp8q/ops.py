@@ -92,9 +92,6 @@ def _rows(x, per_channel):
     return 1, x.numel()
 
 
-_WS_RETIRED_MAX = 4
-
-
 def _workspace(dev, nbytes, zeroed=False, kind=None):
     """Per-(device, stream) scratch buffer.  zeroed=True: the min/max entry points' workspace, whose leading ticket
     counters must be zero on first use and are left zero by every call (include/fp8q.h) -- allocated zero-filled and
@@ -106,16 +103,11 @@ def _workspace(dev, nbytes, zeroed=False, kind=None):
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
         if ws is not None and zeroed:
-            # a min/max workspace outgrown: its header may hold a time-out count that nobody has looked at yet --
-            # keep it until the next check_workspaces() instead of dropping the report with the buffer.  The list is
-            # bounded: callers that never run check_workspaces() (the C-ABI-style flow) get the oldest entries
-            # inspected here (this synchronises, once per _WS_RETIRED_MAX growths).
+            # a min/max workspace outgrown: its header may hold a time-out count that nobody has looked at yet -- keep it until
+            # the next check_workspaces() instead of dropping the report with the buffer.  Never inspected HERE: that would
+            # synchronise inside an unrelated enqueue-only op (and raise another call's failure from it).  The list stays
+            # short: a workspace only ever grows, and these buffers are tens of kilobytes.
             _ws_retired.append((key, ws))
-            while len(_ws_retired) > _WS_RETIRED_MAX:
-                old_key, old = _ws_retired.pop(0)
-                with torch.cuda.device(old.device):
-                    rc = lib().fp8q_minmax_workspace_check(old.data_ptr(), old.numel(), 1, old_key[1])
-                check(rc, "fp8q_minmax_workspace_check (retired workspace)")
         alloc = torch.zeros if (zeroed or kind == "select") else torch.empty
         ws = alloc(max(int(nbytes), 1 << 16), dtype=torch.uint8, device=dev)
         _ws_cache[key] = ws
@@ -389,14 +381,19 @@ def check_workspaces(clear=True):
         check(failures[0], f"fp8q_minmax_workspace_check ({len(failures)} of {len(todo)} workspaces failed)")
 
 
-def release_workspaces(keep_bytes=1 << 24):
+def release_workspaces(keep_bytes=1 << 24, device=None):
     """Drop the scratch buffers larger than `keep_bytes` (the MSE search's partitioned keys: 4 B per element of the largest
     activation it has seen, ~300 MB for MobileNetV2 at batch 64) -- they are re-allocated on demand.  The zeroed min/max
-    workspaces stay (small, and their headers carry state).  QuantizedModel.fix_ranges() calls this once calibration is
-    over; callers that drive fp8q.ops directly may do the same.  Returns the bytes released."""
+    workspaces stay (small, and their headers carry state).  device: only that device's buffers (QuantizedModel.fix_ranges()
+    passes its own device once calibration is over, so that another model still calibrating on another GPU of the process keeps
+    its scratch); None: every device.  Streams are not told apart: a model calibrating on another stream of the SAME device
+    re-allocates on its next batch.  Returns the bytes released."""
+    idx = None if device is None else torch.device(device).index
     freed = 0
     for key, ws in list(_ws_cache.items()):
-        if not key[2] and key[3] is None and ws.numel() > keep_bytes:
+        if idx is not None and key[0] != idx:
+            continue
+        if not key[2] and key[3] in (None, "pre") and ws.numel() > keep_bytes:
             freed += ws.numel()
             del _ws_cache[key]
     return freed
@@ -493,6 +490,10 @@ def mse_grid(x, per_channel, grid, mbits_list, n_bits, sign_bits, mses):
     """K4: mses[n_m, n_cand, C] += row-mean((x - q(x; m, grid[i, c]))^2)  (range_estimators.py:337-347).
 
     grid: CUDA fp32 [n_cand, C]; mbits_list: python floats; mses: CUDA fp32, updated in place.
+    A per-tensor call takes any dense layout as it lies (no NCHW copy).  The table then depends on the memory format in its
+    last bits (~1e-7 relative): the lane-per-element routes add fp32 squares in storage order (the interval-histogram route's
+    integer moments are order-free), so a near-tie between two candidates can fall differently for the same values in NCHW
+    and in channels-last -- inside K4's stated contract (include/fp8q.h: 1e-5 per entry), as any other summation order is.
     """
     import ctypes
     _require(x, "x")
@@ -710,35 +711,61 @@ class MseCalibration:
         self._dev = blk.device
         self._idx = blk.device.index
 
-    def _sizes(self, inner):
+    def _sizes(self, inner, pre_geo=None):
         import ctypes
-        key = (self.C, inner, self.n_cand, self.n_m)
+        key = (self.C, inner, self.n_cand, self.n_m, pre_geo)
         sz = _cal_ws_bytes.get(key)
         if sz is None:
             a, b = ctypes.c_size_t(), ctypes.c_size_t()
             c = lib().fp8q_mse_calibrate_workspace_bytes(self.C, inner, self.n_cand, self.n_m, ctypes.byref(a), ctypes.byref(b))
-            sz = _cal_ws_bytes[key] = (int(a.value), int(b.value), int(c))
+            mm = int(a.value)
+            if pre_geo is not None:
+                mm = max(mm, int(lib().fp8q_affine_act_minmax_workspace_bytes(*pre_geo)))
+            sz = _cal_ws_bytes[key] = (mm, int(b.value), int(c))
         return sz
 
-    def step(self, x, quantize=True):
-        """x: contiguous CUDA float32 with C rows (per tensor: C == 1).  Returns the quantized batch (or None)."""
+    def step(self, x, quantize=True, pre=None):
+        """x: contiguous CUDA float32 with C rows (per tensor: C == 1).  Returns the quantized batch (or None).
+        pre = (bn_ab or None, residual or None, act): x is the PRODUCER's output [N, C, ...]; the search and the
+        quantization run on act(bn(x) + residual), formed inside the same call (per-tensor quantizers only)."""
         inner = x.numel() // self.C
-        mm, sel, mse = self._sizes(inner)
         dev = self._dev
+        pre_ref, keep = None, None
+        xin = x
+        if pre is not None:
+            import ctypes
+            from ._lib import AffinePre
+            ab, res, act = pre
+            N, C, HW = _nchw(x)
+            if self.C != 1 or (ab is not None and (ab.numel() != 2 * C or not ab.is_contiguous() or ab.device != x.device)) \
+                    or (res is not None and (res.shape != x.shape or not res.is_contiguous() or res.dtype != x.dtype
+                                             or res.device != x.device)):
+                raise Fp8qError("MseCalibration.step: bad `pre` (per-tensor quantizer, folded [C, 2] BN vector, residual like x)")
+            mm, sel, mse = self._sizes(inner, (N, C, HW))
+            t = _workspace(dev, 4 * inner, kind="pre")         # the tensor the quantizer sees: scratch, consumed by this call
+            keep = AffinePre(x.data_ptr(), res.data_ptr() if res is not None else None, ab.data_ptr() if ab is not None else None,
+                             N, C, HW, int(act))
+            pre_ref = ctypes.byref(keep)
+            xin = t
+        else:
+            mm, sel, mse = self._sizes(inner)
         ws_mm = _workspace(dev, mm, zeroed=True)
         ws_sel = _workspace(dev, sel, kind="select")
         ws_mse = _workspace(dev, mse)
         y = torch.empty_like(x) if quantize else None
         first, self.first = self.first, False
-        if torch.cuda.current_device() != self._idx:
-            with _on_device(x):
-                rc = self._fn(x.data_ptr(), y.data_ptr() if quantize else None, self.C, inner, self._sref, int(first), self.n_cand,
-                              self._mb, self.n_m, self.n_bits, self.sign_bits, ws_mm.data_ptr(), ws_mm.numel(), ws_sel.data_ptr(),
-                              ws_sel.numel(), ws_mse.data_ptr(), ws_mse.numel(), _stream(x))
-        else:
-            rc = self._fn(x.data_ptr(), y.data_ptr() if quantize else None, self.C, inner, self._sref, int(first), self.n_cand,
-                          self._mb, self.n_m, self.n_bits, self.sign_bits, ws_mm.data_ptr(), ws_mm.numel(), ws_sel.data_ptr(),
-                          ws_sel.numel(), ws_mse.data_ptr(), ws_mse.numel(), _raw_stream(self._idx) if _raw_stream is not None else _stream(x))
+        other = torch.cuda.current_device() != self._idx
+        if other:
+            prev = torch.cuda.current_device()
+            torch.cuda.set_device(self._idx)
+        try:
+            rc = self._fn(xin.data_ptr(), y.data_ptr() if quantize else None, self.C, inner, self._sref, int(first), self.n_cand,
+                          self._mb, self.n_m, self.n_bits, self.sign_bits, pre_ref, ws_mm.data_ptr(), ws_mm.numel(), ws_sel.data_ptr(),
+                          ws_sel.numel(), ws_mse.data_ptr(), ws_mse.numel(),
+                          _raw_stream(self._idx) if _raw_stream is not None else _stream(x))
+        finally:
+            if other:
+                torch.cuda.set_device(prev)
         if rc:
             self.first = first
             check(rc, "fp8q_mse_calibrate_f32")

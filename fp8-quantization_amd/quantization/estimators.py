@@ -223,7 +223,7 @@ class FP_MSE_Estimator(RangeEstimatorBase):
                 and (not self.per_channel or x.shape[0] <= 65535)
                 and not (x.requires_grad and torch.is_grad_enabled()))
 
-    def calibrate_quantize(self, x):
+    def calibrate_quantize(self, x, pre=None):
         """QuantizationManager.forward for this estimator (quantization_manager.py:114-122): update the MSE tables with x,
         choose (mantissa width, maxval), hand both to the quantizer and quantize x with them -- one ctypes call, four to
         eleven kernel launches, no host round trip.  The estimator's observable state (`search_grid`, `mses`,
@@ -248,7 +248,7 @@ class FP_MSE_Estimator(RangeEstimatorBase):
             cal = _ops.MseCalibration(C, x.device, mbit_list, q.n_bits, q.sign_bits, self.N_GRID, self.search_grid, self.mses)
             self.__dict__["_cal"] = cal
             self.search_grid, self.mses = cal.grid, cal.mses
-        y = cal.step(x)
+        y = cal.step(x, pre=pre)
         # what the protocol calls would leave behind (estimators.forward + set_quant_range), without nn.Module.__setattr__:
         qd["maxval"] = cal.maxval
         qd["_range_epoch"] = qd.get("_range_epoch", 0) + 1

@@ -154,12 +154,17 @@ class QuantizationManager(nn.Module):
         q, est = self.quantizer, self.range_estimator
         if self._estimating() and type(est) is FP_MSE_Estimator:
             # the search needs the tensor the quantizer will see: the epilogue with the quantizer switched off (8 B / element
-            # instead of torch's batch_norm + activation passes), then estimate + set_quant_range + quantize in one call
+            # instead of torch's batch_norm + activation passes; the first batch's abs-max and search grid come out of the same
+            # launch), then search + set_quant_range + quantize -- all inside ONE library call
             ab = bn_ab if bn is not None else None
             if bn is not None and ab is None:
                 ab = _ops.bn_fold(bn)
-            t = _ops.affine_act(x, ab, residual, act) if (ab is not None or residual is not None or act) else x
-            return self.forward(t)
+            if ab is None and residual is None and not act:
+                return self.forward(x)
+            y = est.calibrate_quantize(x, pre=(ab, residual, act)) if est.one_call_ok(x) else None
+            if y is not None:
+                return y
+            return self.forward(_ops.affine_act(x, ab, residual, act))
         if self._estimating():
             cur_min, cur_max = est.current_xmin, est.current_xmax
             if cur_min is not None and est._fold_mode != _ops.FOLD_CURRENT:

@@ -343,7 +343,8 @@ class QuantizedModel(nn.Module):
         # launches could not report (a reducer block that timed out -> NaN range; a dirty workspace)
         import fp8q
         fp8q.ops.check_workspaces()
-        fp8q.ops.release_workspaces()        # the MSE search's scratch (4 B per element of the largest activation): not needed again
+        dev = next((p.device for p in self.parameters() if p.is_cuda), None)
+        fp8q.ops.release_workspaces(device=dev)   # the MSE search's scratch (4 B per element of the largest activation): not needed again
         self.prequantize_weights()
 
     def prequantize_weights(self):

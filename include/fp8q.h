@@ -227,7 +227,19 @@ int fp8q_quantize_dm_f32(const float *x, float *y, int64_t C, int64_t inner, con
  * Workspaces: ws_minmax as fp8q_minmax_f32 (zeroed, left zero; only read when first != 0), ws_select as fp8q_mse_select_f32
  * (zero header), ws_mse as fp8q_mse_grid_f32; fp8q_mse_calibrate_workspace_bytes returns the last size and writes the other two.
  * Results are those of the four entry points called one after the other (bit for bit).
+ * pre != NULL (per-tensor quantizers, C == 1, inner == N * C * HW of pre): the quantizer sits behind a batch norm + activation
+ * (+ residual); `x` is then a caller-owned scratch of `inner` floats that RECEIVES t = act(bn(pre->x) + residual) -- written by
+ * fp8q_affine_act_minmax_linspace_f32 (first batch: abs-max and grid from the same launch) or fp8q_affine_act_f32 -- and the
+ * search / quantization run on it: quantized_folded_bn.py:39-55 + quantization_manager.py:114-122 in one call.
+ * ws_minmax then needs max(fp8q_minmax_workspace_bytes, fp8q_affine_act_minmax_workspace_bytes) bytes.
  */
+typedef struct fp8q_affine_pre {
+    const float *x;          /* [N, C, HW] the producer's output (convolution / linear) */
+    const float *residual;   /* [N, C, HW] or NULL */
+    const float *alpha_beta; /* folded [C, 2] batch-norm vector (fp8q_bn_fold_f32) or NULL */
+    int64_t N, C, HW;
+    int act;                 /* 0 none, 1 ReLU, 2 ReLU6 */
+} fp8q_affine_pre;
 typedef struct fp8q_mse_state {
     float *cur_min, *cur_max; /* [C] row minimum / maximum of the first batch */
     float *absmax;            /* [C] max|x| of the first batch: defines the grid */
@@ -240,10 +252,10 @@ typedef struct fp8q_mse_state {
 } fp8q_mse_state;
 size_t fp8q_mse_calibrate_workspace_bytes(int64_t C, int64_t inner, int64_t n_cand, int n_m, size_t *minmax_bytes,
                                           size_t *select_bytes);
-int fp8q_mse_calibrate_f32(const float *x, float *y, int64_t C, int64_t inner, const fp8q_mse_state *state, int first,
-                           int n_cand, const float *mbits_host, int n_m, int n_bits, int sign_bits, void *ws_minmax,
-                           size_t ws_minmax_bytes, void *ws_select, size_t ws_select_bytes, void *ws_mse, size_t ws_mse_bytes,
-                           fp8q_stream_t stream);
+int fp8q_mse_calibrate_f32(float *x, float *y, int64_t C, int64_t inner, const fp8q_mse_state *state, int first,
+                           int n_cand, const float *mbits_host, int n_m, int n_bits, int sign_bits, const fp8q_affine_pre *pre,
+                           void *ws_minmax, size_t ws_minmax_bytes, void *ws_select, size_t ws_select_bytes, void *ws_mse,
+                           size_t ws_mse_bytes, fp8q_stream_t stream);
 
 /*
  * The float64 lane -- BASELINE config 1.  compute_quant_error.py:19-20 draws float64 samples; LineSearchEstimator
@@ -315,6 +327,14 @@ int fp8q_affine_act_quantize_ab_f32(const float *x, const float *residual, float
  * [C, 2] vector of fp8q_bn_fold_f32, or NULL (no batch norm). */
 int fp8q_affine_act_f32(const float *x, const float *residual, float *y, int64_t N, int64_t C, int64_t HW, const float *alpha_beta,
                         int act, fp8q_stream_t stream);
+/* The same pass for the FIRST calibration batch of an MSE estimator: t = act(bn(x) + residual) is written AND its minimum /
+ * maximum / abs-max and the search grid linspace(lo_frac * max|t|, hi_frac * max|t|, n_cand) ([n_cand, 1]) come out of the same
+ * launch (what fp8q_affine_act_f32 + fp8q_minmax_linspace_f32 on t give, bit for bit; 8 B / element instead of 12).
+ * ws: as fp8q_affine_act_minmax_f32 (zeroed, left zero; fp8q_affine_act_minmax_workspace_bytes). */
+int fp8q_affine_act_minmax_linspace_f32(const float *x, const float *residual, float *t, int64_t N, int64_t C, int64_t HW,
+                                        const float *alpha_beta, int act, float *cur_min, float *cur_max, float *maxval_out,
+                                        float *grid, int n_cand, double lo_frac, double hi_frac, void *ws, size_t ws_bytes,
+                                        fp8q_stream_t stream);
 size_t fp8q_affine_act_minmax_workspace_bytes(int64_t N, int64_t C, int64_t HW);
 int fp8q_affine_act_minmax_f32(const float *x, const float *residual, int64_t N, int64_t C, int64_t HW,
                                const float *mean, const float *invstd, const float *gamma, const float *beta,

@@ -152,6 +152,19 @@ class LaunchChecker:
                 checker._check_multi_quantize({"items": self._items}, outs, None)
                 return outs
         monkeypatch.setattr(ops, "MultiPlan", CheckedPlan)
+        # the one-call MSE calibration step (fp8q_mse_calibrate_f32): epilogue (optional), abs-max + grid, table, selection and
+        # the quantized batch -- each recomputed by the oracle from the step's own input
+        self.count["mse_calibrate"] = 0
+        real_step = ops.MseCalibration.step
+
+        def step(cal, x, quantize=True, pre=None):
+            first = cal.first
+            before = None if first else _np(cal.mses).copy()
+            y = real_step(cal, x, quantize, pre)
+            checker.count["mse_calibrate"] += 1
+            checker._check_mse_calibrate(cal, x, pre, first, before, y)
+            return y
+        monkeypatch.setattr(ops.MseCalibration, "step", step)
 
     def _wrap(self, name):
         real, sig = self.real[name], inspect.signature(self.real[name])
@@ -275,6 +288,40 @@ class LaunchChecker:
         st["quantizers"] += 1
         st["channels"] += int(differ.size)
         st["channels_with_another_candidate"] += int(differ.sum())
+
+    def _check_mse_calibrate(self, cal, x, pre, first, before, y):
+        assert first and before is None, "one calibration batch per estimator in this test"
+        per_channel = cal.C != 1
+        if pre is not None:
+            ab, res, act = pre
+            bn = None
+            if ab is not None:      # the folded vector {alpha, beta'}: mean 0, invstd alpha, gamma 1, beta beta' reproduce it exactly
+                abn = _np(ab)
+                bn = (np.zeros(abn.shape[0], np.float32), abn[:, 0].copy(), np.ones(abn.shape[0], np.float32), abn[:, 1].copy())
+            t_np = oracle.c_affine_act(_np(x), bn, _np(res) if res is not None else None, act)
+            t = torch.from_numpy(t_np).to(x.device)
+        else:
+            t, t_np = x.detach(), _np(x)
+        what = f"mse_calibrate {tuple(x.shape)} per_channel={per_channel} pre={pre is not None}"
+        mn, mx = oracle.c_minmax(t_np, per_channel)
+        mv = oracle.c_absmax(mn, mx)
+        _bits_equal(_np(cal.absmax), mv, what + " absmax")
+        grid = torch.stack([torch.linspace(0.1 * float(v), 1.2 * float(v), cal.n_cand) for v in mv.tolist()], 1)
+        _bits_equal(_np(cal.grid), grid.numpy(), what + " grid")
+        a = dict(x=t, grid=cal.grid, mbits_list=cal.mbits_list, per_channel=per_channel, n_bits=cal.n_bits, sign_bits=cal.sign_bits,
+                 mses=cal.mses)
+        self._check_mse_grid(a, cal.mses, np.zeros(1, np.float32))
+        self.count["mse_grid"] += 1
+        # the selection (range_estimators.py:350-369) from the device's own table, then the batch quantized with it
+        got = _np(cal.mses)
+        m, arg = self._choice(got)
+        assert float(cal.mbits.cpu()) == cal.mbits_list[m] and int(cal.vote.cpu()) == m, what
+        sel = _np(cal.grid)[arg, np.arange(got.shape[2])]
+        _bits_equal(_np(cal.maxval), sel, what + " maxval")
+        if y is not None:
+            _bits_equal(_np(y), oracle.c_quantize(t_np, sel, cal.mbits_list[m], cal.n_bits, cal.sign_bits), what + " y")
+            self.count["quantize"] += 1
+            self.elements += t_np.size
 
     def _check_mse_grid(self, a, out, pre):
         x, grid = a["x"].contiguous(), a["grid"]

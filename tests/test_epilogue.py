@@ -161,18 +161,23 @@ def test_mse_calibration_behind_bn_takes_the_fused_path(search, monkeypatch):
 
     x = torch.randn(4, 3, 16, 16, device="cuda")
     calls = []
-    real, real_bn = fp8q.ops.affine_act, torch.nn.functional.batch_norm
-    monkeypatch.setattr(fp8q.ops, "affine_act", lambda *a, **k: (calls.append("affine_act"), real(*a, **k))[1])
+    real_step, real_bn = fp8q.ops.MseCalibration.step, torch.nn.functional.batch_norm
+
+    def step(cal, x, quantize=True, pre=None):
+        calls.append("step+epilogue" if pre is not None else "step")
+        return real_step(cal, x, quantize, pre)
+    monkeypatch.setattr(fp8q.ops.MseCalibration, "step", step)
     monkeypatch.setattr(torch.nn.functional, "batch_norm", lambda *a, **k: (calls.append("batch_norm"), real_bn(*a, **k))[1])
     y1, r1 = run(build(), x)
-    assert calls.count("affine_act") == 3 and "batch_norm" not in calls
+    # three activation quantizers behind a BN: epilogue + search + quantization in one call each; three weight quantizers
+    assert calls.count("step+epilogue") == 3 and calls.count("step") == 3 and "batch_norm" not in calls
     del calls[:]
     os.environ["FP8Q_FUSE_EPILOGUE"] = "0"
     try:
         y2, r2 = run(build(), x)
     finally:
         os.environ.pop("FP8Q_FUSE_EPILOGUE")
-    assert calls.count("batch_norm") == 3 and "affine_act" not in calls
+    assert calls.count("batch_norm") == 3 and "step+epilogue" not in calls and calls.count("step") == 6
     # MIOpen's batch norm rounds differently from the kernel's (ATen CPU's) arithmetic in the last ulp: ranges chosen on a
     # 111-point grid agree unless a near-tie flips -- demand the first layer exactly (its input is x itself up to conv
     # rounding) and closeness after

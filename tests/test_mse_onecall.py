@@ -98,15 +98,20 @@ def test_calibrate_entry_point_validates_before_it_enqueues():
     mb = (ctypes.c_float * 1)(3.0)
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     ws = torch.zeros(1 << 16, dtype=torch.uint8, device="cuda")
-    args = lambda n_bits, wsn: (x.data_ptr(), None, 4, 64, ctypes.byref(cal._state), 1, 111, mb, 1, n_bits, 1, ws.data_ptr(), ws.numel(),      # noqa: E731
-                                ws.data_ptr(), ws.numel(), ws.data_ptr(), wsn, st)
+    args = lambda n_bits, wsn: (x.data_ptr(), None, 4, 64, ctypes.byref(cal._state), 1, 111, mb, 1, n_bits, 1, None, ws.data_ptr(),      # noqa: E731
+                                ws.numel(), ws.data_ptr(), ws.numel(), ws.data_ptr(), wsn, st)
     assert L.fp8q_mse_calibrate_f32(*args(40, ws.numel())) == -1           # FP8Q_EINVAL: format
     assert L.fp8q_mse_calibrate_f32(*args(8, 8)) != 0                      # workspace too small
     torch.cuda.synchronize()
     assert torch.equal(_bits(cal.mses), _bits(before))                     # nothing ran
     nul = MseState()
-    assert L.fp8q_mse_calibrate_f32(x.data_ptr(), None, 4, 64, ctypes.byref(nul), 1, 111, mb, 1, 8, 1, ws.data_ptr(), ws.numel(),
+    assert L.fp8q_mse_calibrate_f32(x.data_ptr(), None, 4, 64, ctypes.byref(nul), 1, 111, mb, 1, 8, 1, None, ws.data_ptr(), ws.numel(),
                                     ws.data_ptr(), ws.numel(), ws.data_ptr(), ws.numel(), st) == -1
+    # a pre-stage needs a per-tensor quantizer whose element count is the producer's
+    from fp8q._lib import AffinePre
+    pre = AffinePre(x.data_ptr(), None, None, 4, 8, 8, 1)
+    assert L.fp8q_mse_calibrate_f32(x.data_ptr(), None, 4, 64, ctypes.byref(cal._state), 1, 111, mb, 1, 8, 1, ctypes.byref(pre), ws.data_ptr(),
+                                    ws.numel(), ws.data_ptr(), ws.numel(), ws.data_ptr(), ws.numel(), st) == -1
 
 
 class _CountSyncs:
@@ -198,3 +203,36 @@ def test_votes_live_in_one_arena_and_come_over_in_one_copy():
         assert materialize_mantissa_bits(mgrs) == len(mgrs)
     assert len(c.torch_syncs) <= 1
     assert [float(m.quantizer.mantissa_bits) for m in mgrs] == want
+
+
+@pytest.mark.parametrize("search", [True, False])
+@pytest.mark.parametrize("shape,use_bn,use_res,act", [((8, 16, 14, 14), True, False, 2), ((64, 32, 56, 56), True, False, 2),
+                                                      ((4, 24, 7, 7), False, True, 0), ((8, 12, 6, 6), True, True, 1),
+                                                      ((16, 96, 56, 56), True, False, 2)])
+def test_pre_stage_equals_epilogue_then_one_call(shape, use_bn, use_res, act, search):
+    """calibrate_quantize(x, pre=(bn_ab, residual, act)) == calibrate_quantize(affine_act(x, ...)): tables, range, width, output --
+    first batch (abs-max and grid from the epilogue's own launch) and a second one (plain epilogue pass)"""
+    import fp8q
+    ops = fp8q.ops
+    torch.manual_seed(shape[1])
+    C = shape[1]
+    ab = None
+    if use_bn:
+        bn = (torch.randn(C, device="cuda"), 1 / torch.sqrt(torch.rand(C, device="cuda") + 0.5), torch.rand(C, device="cuda") + 0.5,
+              torch.randn(C, device="cuda"))
+        ab = ops.bn_fold(bn)
+    a, b = _manager(False, search, True), _manager(False, search, True)
+    for i in range(2):
+        x = torch.randn(shape, device="cuda") * (1.0 + i)
+        res = torch.randn(shape, device="cuda") if use_res else None
+        ya = a.range_estimator.calibrate_quantize(x, pre=(ab, res, act))
+        t = ops.affine_act(x, ab, res, act)
+        yb = b.range_estimator.calibrate_quantize(t)
+        ea, eb = a.range_estimator, b.range_estimator
+        assert torch.equal(_bits(ea.search_grid), _bits(eb.search_grid))
+        assert torch.equal(_bits(ea.mses), _bits(eb.mses))
+        assert torch.equal(_bits(a.quantizer.maxval), _bits(b.quantizer.maxval))
+        assert torch.equal(_bits(ya), _bits(yb))
+        for name in ("cur_min", "cur_max", "absmax"):
+            assert torch.equal(_bits(getattr(ea._cal, name)), _bits(getattr(eb._cal, name))), name
+    assert float(a.quantizer.mantissa_bits) == float(b.quantizer.mantissa_bits)
