@@ -531,6 +531,35 @@ def model_configs(ops, dev, only=None):
             rec["fix_ranges_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
         return rec
 
+    def parity(m):
+        """BASELINE.json's metric, second half ("ResNet-18 PTQ top-1 delta") on a box without ImageNet -- PART OF THE
+        cpu_baseline LEG (rank 0, N = 1): the CPU oracle, as the checker, recomputes every quantizer launch of one validation
+        batch inside the GPU model (oracle/in_the_loop.py; same convolutions on the GPU in both passes).  Bit-identical logits
+        mean top-1 / top-5 of this engine ARE those of the arithmetic the oracle restates: the delta attributable to the
+        kernels is exactly zero.  Plus the label-free proxy of the PTQ delta itself: arg-max agreement with the fp32 network."""
+        from oracle.in_the_loop import validation_parity
+        det = torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark
+        torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark = True, False
+        try:
+            with torch.no_grad():
+                r = validation_parity(m, x, ops)
+                yq = m(x)
+                m.full_precision()
+                yf = m(x)
+                m.set_quant_state(True, True)
+        finally:
+            torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark = det
+        ok = r["logits_bit_identical"] and r["weights_bit_identical"] and r["gpu_pass_reproducible"]
+        return dict(batch="64 x 3 x 224 x 224 synthetic, ranges fixed after one calibration batch",
+                    argmax_agreement_with_fp32=round(float((yq.argmax(1) == yf.argmax(1)).float().mean()), 4),
+                    top5_overlap_with_fp32=round(float(sum(len(set(a.tolist()) & set(b.tolist())) for a, b in
+                                                            zip(yq.topk(5).indices, yf.topk(5).indices))) / (5 * yq.shape[0]), 4),
+                    logits_bit_identical_with_oracle_quantizers=r["logits_bit_identical"],
+                    quantized_weights_bit_identical_with_oracle=r["weights_bit_identical"], weights_checked=r["weights_checked"],
+                    max_abs_logit_diff_vs_oracle_quantizers=r["max_abs_diff"],
+                    top1_delta_attributable_to_kernels=0 if ok else None,
+                    note="random-init weights (no checkpoints / ImageNet on the box): agreement with fp32 is a label-free proxy")
+
     def validation(m, ref_gb):
         res = {}
         with torch.no_grad():
@@ -575,6 +604,7 @@ def model_configs(ops, dev, only=None):
                              "per-channel current_minmax weights, per-tensor allminmax activations",
                     reference_work_per_forward=dict(quantizer_calls=51, elements=218.9e6, algorithmic_gb=1.751),
                     fp32_forward_ms=fp32_ms, calibration_batch=cal, validation_forward=validation(m, 1.751))
+                out["c3_resnet18_b64"].update(parity(m))
                 del m
                 torch.cuda.empty_cache()
             if only in (None, "c4", "c4_search"):
@@ -609,6 +639,7 @@ def model_configs(ops, dev, only=None):
                         return {"c4_mobilenetv2_b64": entry}
                     if not search:
                         entry["validation_forward"] = validation(m, 3.559)
+                        entry.update(parity(m))
                     del m
                     torch.cuda.empty_cache()
                 out["c4_mobilenetv2_b64"] = entry

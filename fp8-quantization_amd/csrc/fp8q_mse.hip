@@ -32,7 +32,8 @@ struct MseArgs {
                      // same bits as adding to +0: an entry is never -0)
 };
 
-__device__ __forceinline__ void table_add(float *p, float v, int overwrite) { *p = overwrite ? v : *p + v; }
+// (an agent-scope store: the last workgroup of the launch may read the entry for the winner selection, fp8q_select.h)
+__device__ __forceinline__ void table_add(float *p, float v, int overwrite) { agent_store(p, overwrite ? v : *p + v); }
 
 __global__ void __launch_bounds__(kMseBlock)
 k_mse_grid(const float *__restrict__ x, const float *__restrict__ grid, double *__restrict__ ws,
@@ -630,7 +631,7 @@ k_mse_final(const double *__restrict__ ws, float *mses, int64_t C, int n_m, int 
         }
     }
     // per-tensor quantizers: the last workgroup also selects the winner (fp8q_select.h)
-    if (so.enabled && last_workgroup(so.ticket, gridDim.x)) select_one_row(mses, grid, n_m, n_cand, so);
+    if (so.enabled && last_workgroup(so.ticket, gridDim.x, blockIdx.x)) select_one_row(mses, grid, n_m, n_cand, so);
 }
 
 // The same for FEW splits per row (per-channel weights: 1-32 partial sums, but C x n_m x n_cand rows -- 852 K for a
@@ -665,7 +666,7 @@ k_mse_final_tile(const double *__restrict__ ws, float *mses, int64_t C, int64_t 
         const int64_t c = c0 + lc, mi = m0 + lm;
         if (c < C && mi < NM) table_add(mses + mi * C + c, tile[lc][lm], overwrite);
     }
-    if (so.enabled && last_workgroup(so.ticket, gridDim.x * gridDim.y)) select_one_row(mses, grid, n_m, n_cand, so);
+    if (so.enabled && last_workgroup(so.ticket, gridDim.x * gridDim.y, blockIdx.y * gridDim.x + blockIdx.x)) select_one_row(mses, grid, n_m, n_cand, so);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -694,12 +695,12 @@ k_mse_linspace(const float *__restrict__ mx, int64_t C, int steps, double lo_fra
 // (torch.mode: the most frequent value, the smallest one on a tie -- :352-354), then per channel the winning width's argmin
 // candidate and its maxval (:356-362).
 __global__ void __launch_bounds__(kBlock)
-k_mse_select(const float *__restrict__ mses, const float *__restrict__ grid, int64_t C, int n_m, int n_cand, int *__restrict__ sel,
+k_mse_select(const float *__restrict__ mses, const float *__restrict__ grid, int64_t C, int n_m, int n_cand, int *sel,
              unsigned *__restrict__ ticket, MseArgs a /* fmt[m].M = width m */, float *__restrict__ mbits_out, int *__restrict__ vote_out,
              float *__restrict__ maxval_out, float *__restrict__ xmin_out, float sign)
 {
     __shared__ int hist[kMseMaxM];
-    __shared__ int s_vote, s_last;
+    __shared__ int s_vote;
     const int lane = threadIdx.x & 63;
     const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c < C) {
@@ -711,27 +712,20 @@ k_mse_select(const float *__restrict__ mses, const float *__restrict__ grid, int
                 if (argmin_less(o, am)) am = o;
             }
             am = wave_argmin(am);
-            if (lane == 0) sel[c * (1 + n_m) + 1 + m] = am.idx;
+            if (lane == 0) agent_store(&sel[c * (1 + n_m) + 1 + m], am.idx);
             const ArgMin o = {am.v, m};
             if (argmin_less(o, best_m)) best_m = o;
         }
-        if (lane == 0) sel[c * (1 + n_m)] = best_m.idx;
+        if (lane == 0) agent_store(&sel[c * (1 + n_m)], best_m.idx);
     }
     // (lane = channel with the waves splitting the candidates reads the table in full lines instead of 16 of every 128 bytes,
     // but turns 2 loads per lane into ~28 dependent trips per width: 36 us per call instead of 12.7 on MobileNetV2's weights
     // with the 6-width search.  Measured, dropped.)
-    if (gridDim.x > 1) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");          // every wave: its sel rows leave the XCD's L2 ...
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // ... before the ticket can be seen
-        __syncthreads();
-        if (threadIdx.x == 0) s_last = atomicInc(ticket, gridDim.x - 1u) == gridDim.x - 1u;
-        __syncthreads();
-        if (!s_last) return;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
+    // (no fences: sel travels through agent-scope stores / loads, fp8q_select.h)
+    if (!last_workgroup(ticket, gridDim.x, blockIdx.x)) return;
     if (threadIdx.x < kMseMaxM) hist[threadIdx.x] = 0;
     __syncthreads();
-    for (int64_t cc = threadIdx.x; cc < C; cc += kBlock) atomicAdd(&hist[sel[cc * (1 + n_m)]], 1);
+    for (int64_t cc = threadIdx.x; cc < C; cc += kBlock) atomicAdd(&hist[agent_load(&sel[cc * (1 + n_m)])], 1);
     __syncthreads();
     if (threadIdx.x == 0) {
         int v = 0;
@@ -744,7 +738,7 @@ k_mse_select(const float *__restrict__ mses, const float *__restrict__ grid, int
     __syncthreads();
     const int v = s_vote;
     for (int64_t cc = threadIdx.x; cc < C; cc += kBlock) {
-        const float mv = grid[(int64_t)sel[cc * (1 + n_m) + 1 + v] * C + cc];
+        const float mv = grid[(int64_t)agent_load(&sel[cc * (1 + n_m) + 1 + v]) * C + cc];
         maxval_out[cc] = mv;
         if (xmin_out) xmin_out[cc] = sign * mv;       // sign_bits * -1.0 * maxval (:369)
     }
@@ -770,11 +764,13 @@ static int mse_hist_mode()
     return v;
 }
 
-// The route's cost does not depend on the data: ~55 us of small launches + ~0.1 us per (width, candidate) pair for the borders
-// + ~4.3 ps per element (partition at the copy rate + the moments); k_mse_row costs ~40 us + ~0.26 ps per (element, pair)
-// on activation-like data (0.19 ps before it watched for near-ties; ReLU6 outputs, whose many elements at the clipping
-// value share every near-tie, are its worst case and the histogram's best).  Fitted on MobileNetV2's 19 activation shapes at
-// batch 64 (tools/mb_mse_c4.py, profiles/r05_mse_c4_shapes.txt): 111 pairs break even at ~1 M elements, 666 at ~0.5 M.
+// The route's cost does not depend on the data: ~60 us of small launches + ~0.1 us per (width, candidate) pair for the borders
+// + ~4.3 ps per element (partition at the copy rate + the moments).  k_mse_row costs ~0.12 ps per (element, pair) on top of a
+// floor that round 6's per-shape timelines put at ~75 us on activation-like data (ReLU6 outputs, whose many elements at the
+// clipping value share every near-tie and are all re-evaluated, are its worst case and the histogram's best: 79.6 us at 0.5 M
+// elements, 83.6 at 0.8 M -- profiles/r06_calib_timeline_*.txt), so with the moments kernel no longer latency-bound on small
+// tensors (hist_slice_min) every per-tensor row from 256 K elements takes the histogram: MobileNetV2's 14 activations of
+// 0.5-1.2 M elements, 100-104 us per calibration step through k_mse_row, take ~80.
 // Which route a row takes depends on its shape only, so a tensor is evaluated the same way on every call.
 static bool mse_use_hist_shape(int64_t C, int64_t inner, int64_t n_cand, int n_m)
 {
@@ -782,8 +778,8 @@ static bool mse_use_hist_shape(int64_t C, int64_t inner, int64_t n_cand, int n_m
     if (mse_hist_mode() == 3) return inner >= (1 << 16);
     if (inner < (1 << 18) || (int64_t)n_m * n_cand > 4096) return false;   // (8 KB of border-count table per pair)
     const double pairs = (double)(n_m * n_cand);
-    const double row = 40e-6 + (double)inner * pairs * 0.26e-12;
-    const double hist = 55e-6 + pairs * 0.095e-6 + (double)inner * 4.3e-12;
+    const double row = 75e-6 + (double)inner * pairs * 0.12e-12;
+    const double hist = 60e-6 + pairs * 0.095e-6 + (double)inner * 4.3e-12;
     return row > hist;
 }
 
@@ -798,7 +794,7 @@ int fp8q_mse_linspace_f32(const float *mx, int64_t C, int n_cand, double lo_frac
     return launch_rc();
 }
 
-size_t fp8q_mse_select_workspace_bytes(int64_t C, int n_m) { return C > 0 && n_m > 0 ? (size_t)C * (1 + n_m) * sizeof(int) + 32 : 32; }
+size_t fp8q_mse_select_workspace_bytes(int64_t C, int n_m) { return kTicketBytes + (C > 0 && n_m > 0 ? (size_t)C * (1 + n_m) * sizeof(int) : 0); }
 
 int fp8q_mse_select_f32(const float *mses, const float *grid, int64_t C, int64_t n_cand, const float *mbits_host, int n_m,
                         int sign_bits, float *mbits_out, int *vote_out, float *maxval_out, float *xmin_out, void *ws,
@@ -811,9 +807,9 @@ int fp8q_mse_select_f32(const float *mses, const float *grid, int64_t C, int64_t
     MseArgs a;
     memset(&a, 0, sizeof(a));
     for (int m = 0; m < n_m; ++m) a.fmt[m].M = mbits_host[m];   // the candidate widths as given (the vote returns one of them)
-    // ws: {reserved word, ticket, 2 reserved words} | sel
+    // ws: ticket block (kTicketBytes: zero between calls) | sel
     hipLaunchKernelGGL(k_mse_select, dim3((unsigned)cdiv(C, 4)), dim3(kBlock), 0, (hipStream_t)stream, mses, grid, C, n_m, (int)n_cand,
-                       (int *)((char *)ws + 16), (unsigned *)ws + 1, a, mbits_out, vote_out, maxval_out, xmin_out, -(float)sign_bits);
+                       (int *)((char *)ws + kTicketBytes), (unsigned *)ws, a, mbits_out, vote_out, maxval_out, xmin_out, -(float)sign_bits);
     return launch_rc();
 }
 
@@ -1026,7 +1022,7 @@ int fp8q_mse_calibrate_f32(float *x, float *y, int64_t C, int64_t inner, const f
     so.vote_out = s->vote;
     so.maxval_out = s->maxval;
     so.xmin_out = s->xmin;
-    so.ticket = (unsigned *)ws_select + 1;      // the selection workspace's header word: zero between calls
+    so.ticket = (unsigned *)ws_select;          // the selection workspace's ticket block: zero between calls
     so.sign = -(float)sign_bits;
     for (int m = 0; m < n_m; ++m) so.M[m] = mbits_host[m];
     so.enabled = 1;

@@ -1112,7 +1112,7 @@ k_mse_eval(const float *__restrict__ x, const float *__restrict__ grid, const fl
     if (is_nan || is_inf) {
         if (tid == 0) {
             const float v = is_nan ? __builtin_nanf("") : __builtin_inff();
-            *out = a.overwrite ? v : *out + v;
+            agent_store(out, a.overwrite ? v : *out + v);
         }
         // (falls through to the selection ticket below: every workgroup of the launch takes part)
     }
@@ -1227,10 +1227,10 @@ k_mse_eval(const float *__restrict__ x, const float *__restrict__ grid, const fl
     if (tid == 0 && !(is_nan || is_inf)) {
         double tot = s_red[0] < 0.0 ? 0.0 : s_red[0];           // (rounding can leave a tiny negative number for an exact fit)
         if (a.uns && flag != kFlagBrute) tot += reinterpret_cast<const double *>(maxkey)[1];   // negative elements: x^2 each
-        *out = a.overwrite ? (float)(tot * inv_inner) : *out + (float)(tot * inv_inner);
+        agent_store(out, a.overwrite ? (float)(tot * inv_inner) : *out + (float)(tot * inv_inner));
     }
     // the winner of the search: the last workgroup to finish its entry selects (fp8q_select.h; per-tensor quantizers)
-    if (so.enabled && last_workgroup(so.ticket, gridDim.x)) select_one_row(mses, grid, a.n_m, a.n_cand, so);
+    if (so.enabled && last_workgroup(so.ticket, gridDim.x, blockIdx.x)) select_one_row(mses, grid, a.n_m, a.n_cand, so);
 }
 
 // ---- host -----------------------------------------------------------------------------------------------------------------
@@ -1246,7 +1246,18 @@ int env_int(const char *name, int dflt, int lo, int hi)
 
 // tuning knobs (defaults are the measured best): borders per k_moments chunk, smallest key slice
 int hist_bcap() { static const int v = env_int("FP8Q_MSE_BCAP", 1024, 16, 6144); return v; }
-int hist_slice_min() { static const int v = env_int("FP8Q_MSE_SLICE", 16384, 1024, 65536); return v & ~3; }
+// Smallest key slice of a k_moments unit.  The launch has 2048 workgroups; a tensor of a few million keys cut into 16 K-key
+// slices gives a few hundred units -- most of the chip idle and k_moments latency-bound at ~29 us whatever the size.  Slices
+// that make ~2048-4096 units: [64,24,56,56] 29.2 -> 12.4 us, [64,192,14,14] 28.8 -> 11.1; at 25.7 M elements 16 K stays best
+// (profiles/r06_mse_slice_ab.txt).  FP8Q_MSE_SLICE overrides (A/B).
+int hist_slice_min(int64_t n)
+{
+    static const int env = getenv("FP8Q_MSE_SLICE") ? env_int("FP8Q_MSE_SLICE", 16384, 1024, 65536) & ~3 : 0;
+    if (env) return env;
+    int s = 2048;
+    while (s < 16384 && (int64_t)s * 2048 < n) s <<= 1;
+    return s;
+}
 
 
 struct HistLayout {
@@ -1321,7 +1332,7 @@ HistLayout hist_layout(int64_t n, int64_t n_pairs, int stride, int bcap, int sli
 // (called from fp8q_mse.hip)
 size_t fp8q_mse_hist_workspace_bytes(int64_t n, int64_t n_pairs)
 {
-    return hist_layout(n, n_pairs, kStrideBound, hist_bcap(), hist_slice_min()).total;
+    return hist_layout(n, n_pairs, kStrideBound, hist_bcap(), hist_slice_min(n)).total;
 }
 
 // formats this route takes: at most 8 bits, signed or unsigned (the cell tables are sized for them)
@@ -1352,7 +1363,7 @@ int fp8q_mse_hist_launch(const float *x, int64_t n, const float *grid, int64_t n
         if (a.ncells[m] > a.stride) a.stride = a.ncells[m];
     }
     if (a.stride > kStrideBound) return FP8Q_EUNSUPPORTED;
-    const int bcap = hist_bcap(), slice_min = hist_slice_min();
+    const int bcap = hist_bcap(), slice_min = hist_slice_min(n);
     const int64_t n_pairs = (int64_t)n_m * n_cand;
     const HistLayout L = hist_layout(n, n_pairs, a.stride, bcap, slice_min);
     if (ws_bytes < L.total) return FP8Q_EWORKSPACE;

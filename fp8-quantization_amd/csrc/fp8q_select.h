@@ -14,7 +14,7 @@ struct SelOne {
     int *vote_out;         // [1] or NULL
     float *maxval_out;     // [1]
     float *xmin_out;       // [1] or NULL
-    unsigned *ticket;      // zero between launches (atomicInc wraps it back): word 1 of the selection workspace's header
+    unsigned *ticket;      // the selection workspace's ticket block (its first kTicketBytes: zero between launches)
     float sign;            // -sign_bits
     float M[kSelMaxM];     // the candidate widths as given (the vote returns one of them)
     int enabled;
@@ -49,20 +49,46 @@ __device__ __forceinline__ ArgMin wave_argmin(ArgMin a)
     return a;
 }
 
-// All threads of the workgroup call this after their last store to the table; true (uniformly) in the workgroup that
-// finishes last, which may then read what every other workgroup of the launch wrote.
-__device__ __forceinline__ bool last_workgroup(unsigned *ticket, unsigned nwg)
+// Cross-workgroup hand-over WITHOUT fences: what the last workgroup reads is written with agent-scope atomic stores
+// (write-through: performed at the device's coherence point once vmcnt says so) and read with agent-scope atomic loads (served
+// past this CU's L1 and the XCD's L2).  An agent-scope RELEASE fence instead writes back the XCD's whole L2: with one per
+// workgroup k_mse_eval went from 10.9 to 48.2 us on 666 workgroups (profiles/r06_select_fence_ab.txt).
+__device__ __forceinline__ void agent_store(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void agent_store(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float agent_load(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int agent_load(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// The ticket block: zero between launches (every counter wraps back to zero when its last member arrives).  A single
+// counter serialises one returning atomic per workgroup on one address (666 workgroups of k_mse_eval: +15 us); here the
+// workgroups are dealt round-robin to up to 31 groups whose counters lie 128 bytes apart, and only a group's last member
+// goes on to the launch's own counter (word 1): the longest chain on one address is ~nwg / 31 + 31.
+constexpr size_t kTicketBytes = 4096;       // word 1: the launch; words 32 g, g = 1 .. 31: the groups
+constexpr unsigned kTicketGroups = 31;
+
+// All threads of the workgroup call this after their last agent_store() to the data the last workgroup will read; true
+// (uniformly) in the workgroup that finishes last -- which must read the others' data with agent_load().
+// `wg`: this workgroup's linear index in the launch.
+__device__ __forceinline__ bool last_workgroup(unsigned *tickets, unsigned nwg, unsigned wg)
 {
     __shared__ int s_last_wg;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this thread's stores are performed ...
+    __syncthreads();                                       // ... and every other thread's of the workgroup
     if (nwg <= 1u) return true;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      // this workgroup's table entries leave the XCD's L2 ...
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // ... before the ticket can be seen
+    if (threadIdx.x == 0) {
+        unsigned *top = tickets + 1;
+        const unsigned ng = nwg <= 32u ? 1u : (nwg / 16u < kTicketGroups ? nwg / 16u : kTicketGroups);
+        int last;
+        if (ng <= 1u) {
+            last = atomicInc(top, nwg - 1u) == nwg - 1u;
+        } else {
+            const unsigned g = wg % ng, members = nwg / ng + (g < nwg % ng ? 1u : 0u);
+            last = 0;
+            if (atomicInc(tickets + 32u * (g + 1u), members - 1u) == members - 1u) last = atomicInc(top, ng - 1u) == ng - 1u;
+        }
+        s_last_wg = last;
+    }
     __syncthreads();
-    if (threadIdx.x == 0) s_last_wg = atomicInc(ticket, nwg - 1u) == nwg - 1u;
-    __syncthreads();
-    if (!s_last_wg) return false;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    return true;
+    return s_last_wg != 0;
 }
 
 // One workgroup (any multiple of 64 threads up to 1024): mses [n_m, n_cand] of the single row, grid [n_cand].
@@ -76,7 +102,7 @@ __device__ __forceinline__ void select_one_row(const float *mses, const float *g
     for (int m = 0; m < n_m; ++m) {
         ArgMin am = {__builtin_inff(), 0x7fffffff};
         for (int i = threadIdx.x; i < n_cand; i += blockDim.x) {
-            const ArgMin o = {mses[(int64_t)m * n_cand + i], i};
+            const ArgMin o = {agent_load(mses + (int64_t)m * n_cand + i), i};
             if (argmin_less(o, am)) am = o;
         }
         am = wave_argmin(am);

@@ -190,9 +190,10 @@ int fp8q_mse_grid_f32(const float *x, int64_t C, int64_t inner, const float *gri
  *                          channel maxval_out[c] = grid[argmin_i mses[vote, i, c], c] and xmin_out[c] = -sign_bits *
  *                          maxval (may be NULL).  torch.min / argmin semantics: first index of the minimum, NaN first.
  *                          ONE launch (round 5).  ws: at least fp8q_mse_select_workspace_bytes(C, n_m) bytes, 4-byte
- *                          aligned; its first 16 bytes follow the min/max workspace contract (zero before the first call
- *                          that uses the buffer, zero again after every call: word 1 is the ticket by which the last
- *                          workgroup of a per-channel call finds out that it is the last).
+ *                          aligned; its first 4096 bytes (the ticket block) follow the min/max workspace contract: zero
+ *                          before the first call that uses the buffer, zero again after every call (counters by which the
+ *                          last workgroup of a launch finds out that it is the last; fp8q_mse_calibrate_f32 uses the same
+ *                          block for the per-tensor selection it appends to the table-finishing launch).
  *   fp8q_quantize_dm_f32   K1 (fp8q_quantize_f32) with the mantissa width read from a DEVICE scalar, so that the batch
  *                          that follows the vote in the same calibration forward needs no host round trip.  One row
  *                          per workgroup column whatever the row length: a calibration path, not the tuned K1 routes.

@@ -457,31 +457,7 @@ def test_every_launch_of_a_full_size_model_pass(tag, n_weight, n_act_min, monkey
 # "top-1 unchanged" (BASELINE metric, second half) without ImageNet on the box: the whole validation pass with the HIP
 # quantizers against the same pass with every quantizer replaced by the CPU oracle
 # ---------------------------------------------------------------------------------------------------------------------
-class OracleInTheLoop:
-    """fp8q.ops look-alike for CUDA tensors whose arithmetic is the CPU oracle (device -> host -> oracle -> device): the
-    convolutions / matmuls of the model stay on the GPU (same MIOpen / rocBLAS kernels as in the HIP run), only the
-    quantizers change.  TEST USE ONLY."""
-
-    @staticmethod
-    def _dev(a, like):
-        return torch.from_numpy(np.ascontiguousarray(a)).to(like.device)
-
-    @classmethod
-    def quantize(cls, x, maxval, mbits, n_bits=8, sign_bits=1, out=None):
-        y = cls._dev(oracle.c_quantize(_np(x), _np(maxval).reshape(-1), mbits, n_bits, sign_bits), x)
-        if out is not None:
-            out.copy_(y)
-            return out
-        return y
-
-    @classmethod
-    def affine_act_quantize(cls, x, maxval, mbits, n_bits=8, sign_bits=1, bn=None, residual=None, act=0, out=None, bn_ab=None,
-                            prep=None):
-        # (bn_ab / prep: the folded BN vector and the prepared quantizer table the layers also hand over -- the oracle
-        # forms alpha / beta' from `bn` and the table from `maxval` itself)
-        t = oracle.c_affine_act(_np(x), tuple(_np(b) for b in bn) if bn is not None else None,
-                                _np(residual) if residual is not None else None, act)
-        return cls._dev(oracle.c_quantize(t, _np(maxval).reshape(-1), mbits, n_bits, sign_bits), x)
+from oracle.in_the_loop import OracleInTheLoop, validation_parity  # noqa: E402  (the checker bench.py's cpu_baseline leg uses too)
 
 
 @pytest.mark.parametrize("tag", ["r18", "mbv2"])
@@ -501,26 +477,9 @@ def test_validation_logits_identical_with_oracle_quantizers(tag, monkeypatch):
         q.set_quant_state(True, True)
         q(calib)
         q.fix_ranges()
-        for _ in range(2):          # MIOpen settles on its convolution algorithms during the first passes over a shape
-            q(val)
-        hip = q(val).clone()
-        hip_again = q(val).clone()
-        assert torch.equal(hip, hip_again), "the GPU pass itself must be reproducible for this comparison to mean anything"
-        # the layers' cached quantized weights came from the HIP multi-tensor launch: the oracle must give the very same
-        # tensors (checked in place, so that the weight buffers -- and with them MIOpen's choices -- stay what they were)
-        n_w = 0
-        for m in q.modules():
-            wq = getattr(m, "_wq_cache", None)
-            if wq is not None:
-                qz = m.weight_quantizer.quantizer
-                ref_w = OracleInTheLoop.quantize(m.get_weight_bias()[0].detach(), qz.maxval, float(qz.mantissa_bits),
-                                                 qz.n_bits, qz.sign_bits)
-                assert torch.equal(ref_w.view(torch.int32), wq.view(torch.int32)), type(m).__name__
-                n_w += 1
-        assert n_w >= 21
-        monkeypatch.setattr(ops, "quantize", OracleInTheLoop.quantize)
-        monkeypatch.setattr(ops, "affine_act_quantize", OracleInTheLoop.affine_act_quantize)
-        ref = q(val)
-    assert torch.equal(hip.view(torch.int32), ref.view(torch.int32)), \
-        f"logits differ: max |d| = {(hip - ref).abs().max().item():.3e}"
-    assert torch.equal(hip.argmax(1), ref.argmax(1)) and torch.equal(hip.topk(5).indices, ref.topk(5).indices)
+    r = validation_parity(q, val, ops)
+    assert r["gpu_pass_reproducible"], "the GPU pass itself must be reproducible for this comparison to mean anything"
+    # the layers' cached quantized weights came from the HIP multi-tensor launch: the oracle gives the very same tensors
+    assert r["weights_checked"] >= 21 and r["weights_bit_identical"], r
+    assert r["logits_bit_identical"], f"logits differ: max |d| = {r['max_abs_diff']:.3e}"
+    assert r["argmax_equal"] and r["top5_equal"]
