@@ -15,8 +15,10 @@ Inputs are resident in HBM before the timed region.
 N > 1 (one process per GPU, torch.distributed/RCCL).  `value` is north_star's own weight flow END TO END: one
 [N * 2^21, 3, 7, 7] tensor held by every rank, rank r quantizes channels channel_partition(C, N)[r] (the N = 1 kernel on
 the N = 1 shard: weak scaling) and the shards are re-assembled on every rank with one RCCL all-gather over xGMI
-(fp8q.dist.quantize_weight_sharded) -- all elements / max-over-ranks wall time, collective included.  Top-level keys next
-to it: `value_kernel_only` (the same elements / the kernel phase alone: what `value` was before round 4), `kernel_us`,
+(round 6: as 1-byte storage codes -- fp8q.dist.quantize_weight_sharded_codes with the fixed ranges: encode -> all-gather ->
+decode, bit-identical to the fp32 form and a quarter of its xGMI bytes; `value_fp32_wire` is the fp32 form of the same flow,
+timed right after the judged region) -- all elements / max-over-ranks wall time, collective included.  Top-level keys next
+to it: `value_kernel_only` (the same elements / the kernel phases alone), `kernel_us`,
 `collective_us`, `xgmi_gb_s` (bytes each rank receives / collective time), and from `north_star_path`, which times the
 two exchange steps north_star names at any N (N = 1: the collectives are no-ops and the figures are the kernels' own):
 `value_codes_wire` (same flow with 1-byte storage codes on the wire), `value_resnet18_strong` (ResNet-18's 21 weight
@@ -253,6 +255,40 @@ def extras(ops, dev):
     yw = torch.empty_like(w)
     rec("conv1_64x3x7x7_fused_minmax_quant_e5m2", w.numel(), 8,
         lambda: ops.minmax_quantize(w, 2, 8, 1, out=yw), iters=200)
+    # BASELINE config 2 at its literal size is a 37 KB tensor: the launch is all latency.  An event pair around ONE launch also
+    # measures the stream's start-up gap and this script's own Python call (~10 us of host per call: the GPU waits for it); the
+    # kernel's own cost shows when launches are queued faster than they run -- 200 of them replayed from a HIP graph
+    c1 = out["conv1_64x3x7x7_fused_minmax_quant_e5m2"]
+    c1["kernel"] = "k_small_rows_fused<3> (one wave per row, row in registers; round 6)"
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(200):
+        ops.minmax_quantize(w, 2, 8, 1, out=yw)
+    e1.record()
+    torch.cuda.synchronize()
+    c1["back_to_back_python_loop_us"] = round(e0.elapsed_time(e1) * 1e3 / 200, 2)
+    try:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            ops.minmax_quantize(w, 2, 8, 1, out=yw)
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for _ in range(200):
+                ops.minmax_quantize(w, 2, 8, 1, out=yw)
+        for _ in range(3):
+            graph.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        graph.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        c1["hipgraph_200_launches_us_per_launch"] = round(e0.elapsed_time(e1) * 1e3 / 200, 2)
+    except Exception as e:   # noqa: BLE001 -- informational entry only
+        c1["hipgraph_200_launches_us_per_launch"] = {"error": repr(e)[:200]}
     # all 21 ResNet-18 weight tensors (11.68 M elements), re-quantized as on every forward
     shapes = [(64, 3, 7, 7)] + [(64, 64, 3, 3)] * 4 + [(128, 64, 3, 3), (128, 128, 3, 3), (128, 64, 1, 1)] + \
         [(128, 128, 3, 3)] * 2 + [(256, 128, 3, 3), (256, 256, 3, 3), (256, 128, 1, 1)] + [(256, 256, 3, 3)] * 2 + \
@@ -864,7 +900,10 @@ def dry_run(args, world, rank):
         g = torch.Generator().manual_seed(1234)
         w = torch.randn(world * scale, 3, 7, 7, generator=g) * 0.1
         mv = ops.minmax(w, True, want_maxval=True)[2]
-        section("headline: quantize_weight_sharded(fixed ranges)", lambda: fd.quantize_weight_sharded(w, MBITS, NBITS, SIGN, maxval=mv, ops=ops))
+        section("headline: quantize_weight_sharded_codes(fixed ranges)",
+                lambda: fd.quantize_weight_sharded_codes(w, MBITS, NBITS, SIGN, maxval=mv, ops=ops))
+        section("headline, fp32 wire (value_fp32_wire): quantize_weight_sharded(fixed ranges)",
+                lambda: fd.quantize_weight_sharded(w, MBITS, NBITS, SIGN, maxval=mv, ops=ops))
         section("weights_allgather.fp32: quantize_weight_sharded(current_minmax)", lambda: fd.quantize_weight_sharded(w, MBITS, NBITS, SIGN, ops=ops))
         section("weights_allgather.codes_u8: quantize_weight_sharded_codes", lambda: fd.quantize_weight_sharded_codes(w, MBITS, NBITS, SIGN, ops=ops))
         shapes = [(64, 3, 7, 7)] + [(64, 64, 3, 3)] * 4 + [(128, 64, 3, 3), (128, 128, 3, 3), (128, 64, 1, 1)] + \
@@ -885,8 +924,10 @@ def dry_run(args, world, rank):
     if rank == 0:
         ne, nc = N_CH * ROW, N_CH
         full = {
-            "headline (value at --gpus N)": {"all_gather_into_tensor values": {"send_bytes_per_rank": ne * 4, "received_per_rank": (R - 1) * ne * 4},
-                                             "all_gather_into_tensor ranges": {"send_bytes_per_rank": nc * 4, "received_per_rank": (R - 1) * nc * 4}},
+            "headline (value at --gpus N)": {"all_gather_into_tensor codes": {"send_bytes_per_rank": ne, "received_per_rank": (R - 1) * ne},
+                                             "bound": "received_per_rank <= (R - 1) / R * R * 2^21 * 147 B (1 byte per element of the other ranks' shards; the ranges are fixed and not shipped)"},
+            "headline, fp32 wire (value_fp32_wire)": {"all_gather_into_tensor values": {"send_bytes_per_rank": ne * 4, "received_per_rank": (R - 1) * ne * 4},
+                                                      "all_gather_into_tensor ranges": {"send_bytes_per_rank": nc * 4, "received_per_rank": (R - 1) * nc * 4}},
             "weights_allgather [N*2^18,3,7,7] codes_u8": {"all_gather_into_tensor codes": {"send_bytes_per_rank": (1 << 18) * ROW},
                                                           "all_gather_into_tensor ranges": {"send_bytes_per_rank": (1 << 18) * 4}},
             "resnet18_weights_one_allgather": {"all_gather_into_tensor bucket": {
@@ -895,6 +936,12 @@ def dry_run(args, world, rank):
                 "note": "real shapes: this IS the full-size count (1-byte codes + fp32 ranges of every tensor's shard, padded to 16 B)"}},
             "c5 [512,4096,512] per rank": {"all_reduce MAX": {"send_bytes_per_rank": 16, "note": "{-min, max, nan flags}: 4 floats"}},
         }
+        # the headline's wire budget: one collective, 1 byte per element of this rank's shard, so a rank
+        # receives (R - 1) / R of the R * 2^21 * 147 bytes of the full tensor and nothing else
+        head = seq["headline: quantize_weight_sharded_codes(fixed ranges)"]
+        assert len(head) == 1 and head[0]["op"] == "all_gather_into_tensor" and head[0]["dtype"] == "uint8", head
+        assert head[0]["send_bytes"] == scale * ROW, head
+        assert (R - 1) * ne <= (R - 1) * N_CH * ROW and (R - 1) * ne * R <= (R - 1) * (R * N_CH * ROW)
         print(json.dumps({"dry_run": True, "ranks": R, "ranks_seen": int(one.item()), "backend": "gloo (CPU tensors, compute stub)",
                           "scaled_down_to": {"channels_per_rank": scale, "c5_slab": [8, 64, 64]},
                           "call_sequence_as_executed": seq, "full_size_bytes": full}), flush=True)
@@ -991,7 +1038,13 @@ def main():
         shard, y = x[lo:hi], torch.empty(hi - lo, 3, 7, 7, device=dev)
         full = [None]
 
-        def step(t=None):     # quantize this rank's channels (fixed ranges, as at N = 1) + all-gather of the shards
+        # quantize this rank's channels (fixed ranges, as at N = 1), all-gather, re-assemble.  Round 6: the shards travel as
+        # 1-byte storage codes (fp8q_encode_u8 -> all-gather -> fp8q_decode_u8): bit-identical tensors, a quarter of the xGMI
+        # bytes of the fp32 form, which is timed right after the judged region and reported as value_fp32_wire
+        def step(t=None):
+            full[0] = fd.quantize_weight_sharded_codes(x, MBITS, NBITS, SIGN, maxval=maxval, timing=t)
+
+        def step_fp32(t=None):
             full[0] = fd.quantize_weight_sharded(x, MBITS, NBITS, SIGN, maxval=maxval, timing=t)
     torch.cuda.synchronize()
 
@@ -1030,9 +1083,22 @@ def main():
         t = torch.tensor([elapsed], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        e = timing["events"]
-        step_s = sorted(e[3 * i].elapsed_time(e[3 * i + 1]) * 1e-3 for i in range(args.steps))
-        collective_s = sum(e[3 * i + 1].elapsed_time(e[3 * i + 2]) * 1e-3 for i in range(args.steps)) / max(args.steps, 1)
+        e = timing["events"]       # per step: before | encode done | all-gather done | decode done
+        step_s = sorted((e[4 * i].elapsed_time(e[4 * i + 1]) + e[4 * i + 2].elapsed_time(e[4 * i + 3])) * 1e-3 for i in range(args.steps))
+        collective_s = sum(e[4 * i + 1].elapsed_time(e[4 * i + 2]) * 1e-3 for i in range(args.steps)) / max(args.steps, 1)
+        # the fp32 wire form of the same flow (round 5's headline), same steps, outside the judged region
+        for _ in range(min(args.warmup, 2)):
+            step_fp32()
+        torch.cuda.synchronize()
+        dist.barrier()
+        t32 = time.perf_counter()
+        for _ in range(args.steps):
+            step_fp32()
+        torch.cuda.synchronize()
+        dist.barrier()
+        t32 = torch.tensor([time.perf_counter() - t32], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(t32, op=dist.ReduceOp.MAX)
+        elapsed_fp32 = float(t32.item())
     else:
         step_s = sorted(a.elapsed_time(b) * 1e-3 for a, b in evs)
     kern_s = sum(step_s) / max(len(step_s), 1)
@@ -1042,7 +1108,8 @@ def main():
     value = total_elem * args.steps / elapsed / 1e9
     achieved = n_elem * BYTES_PER_ELEM / kern_s / 1e9
     wall_gbs = n_elem * BYTES_PER_ELEM / (elapsed / args.steps) / 1e9
-    rx_bytes = (world - 1) * (n_elem + shard.shape[0]) * 4       # what the all-gathers (values + ranges) bring to a rank
+    rx_bytes = (world - 1) * n_elem                              # what the all-gather brings to a rank: 1-byte codes (the ranges are fixed: everywhere already)
+    rx_bytes_fp32 = (world - 1) * (n_elem + shard.shape[0]) * 4  # the fp32 form: values + ranges
 
     line = None
     if rank == 0:
@@ -1076,8 +1143,9 @@ def main():
                        "elements_per_gpu": n_elem,
                        "parallelism": "1 GPU" if world == 1 else (
                            f"one [{world * n_ch},3,7,7] tensor on every rank, channel-sharded x{world}: each rank quantizes its "
-                           f"{n_ch} channels, one all-gather re-assembles values + ranges on every rank; `value` INCLUDES the "
-                           "collective, `value_kernel_only` does not"),
+                           f"{n_ch} channels to 1-byte storage codes, one all-gather re-assembles the codes on every rank, every rank "
+                           "decodes (fixed ranges: every rank holds them already); `value` INCLUDES the collective, "
+                           "`value_kernel_only` (encode + decode launches) does not; `value_fp32_wire`: the same flow shipping fp32 values"),
                        "prewarm_ms": int(PREWARM_S * 1e3)},
             "roofline": {"bound": "hbm", "kernel": "k_rows_flat<0,NT>", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
@@ -1090,8 +1158,12 @@ def main():
         }
         if world > 1:
             line.update(kernel_us=round(kern_s * 1e6, 1), collective_us=round(collective_s * 1e6, 1),
+                        wire="codes_u8 (1 byte per element; ranges fixed, not shipped)",
                         xgmi_bytes_received_per_rank=int(rx_bytes),
-                        xgmi_gb_s=round(rx_bytes / max(collective_s, 1e-9) / 1e9, 2) if args.backend == "nccl" else None)
+                        xgmi_gb_s=round(rx_bytes / max(collective_s, 1e-9) / 1e9, 2) if args.backend == "nccl" else None,
+                        value_fp32_wire=round(total_elem * args.steps / elapsed_fp32 / 1e9, 2),
+                        fp32_wire_ms_per_step=round(elapsed_fp32 / args.steps * 1e3, 4),
+                        fp32_wire_xgmi_bytes_received_per_rank=int(rx_bytes_fp32))
         if world == 1 and not args.no_cpu_baseline:
             # bounded sample: generate only what the CPU leg needs
             sample_ch = 1 << 18

@@ -765,7 +765,7 @@ static int mse_hist_mode()
 }
 
 // The route's cost does not depend on the data: ~60 us of small launches + ~0.1 us per (width, candidate) pair for the borders
-// + ~4.3 ps per element (partition at the copy rate + the moments).  k_mse_row costs ~0.12 ps per (element, pair) on top of a
+// + ~4.3 ps per element (partition at the copy rate + the moments).  k_mse_row costs ~0.2 ps per (element, pair) on top of a
 // floor that round 6's per-shape timelines put at ~75 us on activation-like data (ReLU6 outputs, whose many elements at the
 // clipping value share every near-tie and are all re-evaluated, are its worst case and the histogram's best: 79.6 us at 0.5 M
 // elements, 83.6 at 0.8 M -- profiles/r06_calib_timeline_*.txt), so with the moments kernel no longer latency-bound on small
@@ -778,7 +778,7 @@ static bool mse_use_hist_shape(int64_t C, int64_t inner, int64_t n_cand, int n_m
     if (mse_hist_mode() == 3) return inner >= (1 << 16);
     if (inner < (1 << 18) || (int64_t)n_m * n_cand > 4096) return false;   // (8 KB of border-count table per pair)
     const double pairs = (double)(n_m * n_cand);
-    const double row = 75e-6 + (double)inner * pairs * 0.12e-12;
+    const double row = 75e-6 + (double)inner * pairs * 0.2e-12;     // (0.5 M elements x 666 pairs: 163 us measured)
     const double hist = 60e-6 + pairs * 0.095e-6 + (double)inner * 4.3e-12;
     return row > hist;
 }

@@ -942,17 +942,39 @@ k_moments(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ sb, co
 // exact in double-double; the scaling is by powers of two >= 2^-298 on numbers >= 1 (no underflow in either part).
 // One workgroup per superblock of 1024 intervals: exclusive prefix WITHIN the superblock + the superblock's totals;
 // k_iv_scan_top turns the totals into exclusive prefixes; prefix_at() adds the two levels (fixed association: deterministic).
-__global__ void __launch_bounds__(kSuper)
-k_iv_scan_super(const uint32_t *__restrict__ boff, const uint32_t *__restrict__ g_n, const unsigned long long *__restrict__ g_d,
-                const unsigned long long *__restrict__ g_d2lo, const unsigned long long *__restrict__ g_d2hi, int64_t ni,
-                DD *__restrict__ p1, DD *__restrict__ p2, uint32_t *__restrict__ pn, DD *__restrict__ t1, DD *__restrict__ t2,
-                uint32_t *__restrict__ tn)
+// AGENT: the results are written with agent-scope stores (for readers in the SAME launch: the dropped scan + evaluation fusion, see mse_eval_body)
+template <bool AGENT>
+__device__ __forceinline__ void put_dd(DD *p, DD v)
+{
+    if (AGENT) {
+        agent_store(&p->hi, v.hi);
+        agent_store(&p->lo, v.lo);
+    } else {
+        *p = v;
+    }
+}
+
+template <bool AGENT>
+__device__ __forceinline__ DD get_dd(const DD *p)
+{
+    if (AGENT) return DD{agent_load(&p->hi), agent_load(&p->lo)};
+    return *p;
+}
+
+template <bool AGENT>
+__device__ __forceinline__ uint32_t get_u32(const uint32_t *p) { return AGENT ? agent_load(p) : *p; }
+
+template <bool AGENT>
+__device__ __forceinline__ void iv_scan_super_body(int sblk, const uint32_t *__restrict__ boff, const uint32_t *__restrict__ g_n,
+                                                   const unsigned long long *__restrict__ g_d, const unsigned long long *__restrict__ g_d2lo,
+                                                   const unsigned long long *__restrict__ g_d2hi, int64_t ni, DD *p1, DD *p2, uint32_t *pn,
+                                                   DD *t1, DD *t2, uint32_t *tn)
 {
     __shared__ DD s1[2 * (kSuper / 64)], s2[2 * (kSuper / 64)];     // wave totals, then their inclusive scan
     __shared__ uint32_t sn[2 * (kSuper / 64)];
     __shared__ uint32_t s_first[kHBuckets];       // first interval id of every bucket
     const int tid = threadIdx.x;
-    const int64_t i = (int64_t)blockIdx.x * kSuper + tid;
+    const int64_t i = (int64_t)sblk * kSuper + tid;
     for (int b = tid; b < kHBuckets; b += kSuper) s_first[b] = boff[b] + (uint32_t)b;
     const DD zero{0.0, 0.0};
     DD v1 = zero, v2 = zero;
@@ -1035,16 +1057,25 @@ k_iv_scan_super(const uint32_t *__restrict__ boff, const uint32_t *__restrict__ 
             en += sn[kW + wave - 1];
         }
         if (i <= ni) {                                  // exclusive, within the superblock (entry ni: everything)
-            p1[i] = e1;
-            p2[i] = e2;
-            pn[i] = en;
+            put_dd<AGENT>(p1 + i, e1);
+            put_dd<AGENT>(p2 + i, e2);
+            if (AGENT) agent_store(pn + i, en); else pn[i] = en;
         }
         if (tid == kSuper - 1) {                        // the superblock's totals
-            t1[blockIdx.x] = s1[2 * kW - 1];
-            t2[blockIdx.x] = s2[2 * kW - 1];
-            tn[blockIdx.x] = sn[2 * kW - 1];
+            put_dd<AGENT>(t1 + sblk, s1[2 * kW - 1]);
+            put_dd<AGENT>(t2 + sblk, s2[2 * kW - 1]);
+            if (AGENT) agent_store(tn + sblk, sn[2 * kW - 1]); else tn[sblk] = sn[2 * kW - 1];
         }
     }
+}
+
+__global__ void __launch_bounds__(kSuper)
+k_iv_scan_super(const uint32_t *__restrict__ boff, const uint32_t *__restrict__ g_n, const unsigned long long *__restrict__ g_d,
+                const unsigned long long *__restrict__ g_d2lo, const unsigned long long *__restrict__ g_d2hi, int64_t ni,
+                DD *__restrict__ p1, DD *__restrict__ p2, uint32_t *__restrict__ pn, DD *__restrict__ t1, DD *__restrict__ t2,
+                uint32_t *__restrict__ tn)
+{
+    iv_scan_super_body<false>((int)blockIdx.x, boff, g_n, g_d, g_d2lo, g_d2hi, ni, p1, p2, pn, t1, t2, tn);
 }
 
 __global__ void __launch_bounds__(64)
@@ -1091,24 +1122,48 @@ k_iv_scan_top(DD *__restrict__ t1, DD *__restrict__ t2, uint32_t *__restrict__ t
 
 // ---- 6. candidates --------------------------------------------------------------------------------------------------------
 // one workgroup per (mantissa width, candidate); a lane per cell (looping when a format has more than 256 cells)
-__global__ void __launch_bounds__(kBlock)
-k_mse_eval(const float *__restrict__ x, const float *__restrict__ grid, const float *__restrict__ bt, const float *__restrict__ bq,
-           const uint32_t *__restrict__ rank, const int *__restrict__ cflag, const uint32_t *__restrict__ maxkey,
-           const DD *__restrict__ p1, const DD *__restrict__ p2, const uint32_t *__restrict__ pn, const DD *__restrict__ t1,
-           const DD *__restrict__ t2, const uint32_t *__restrict__ tn, int64_t ni, int nsb, float *mses, HistArgs a,
-           double inv_inner, const uint32_t *__restrict__ nunits, SelOne so)
+// NT threads per workgroup.  WAIT: the prefixes are being written by scan workgroups of the SAME launch (lower block indices:
+// dispatched first) -- thread 0 polls their completion counter `done` until it reaches nsb, everything they wrote is read with
+// agent-scope loads; bounded: after ~2^22 polls the entry becomes NaN instead of hanging the queue.  Round 6 measured that
+// fusion (scan + evaluation in one launch of 1024-thread workgroups) and DROPPED it: 26.7 us against 8.5 + 11.6 as two launches
+// with 111 pairs, 71.6 against 8.7 + 22.1 with 666 (profiles/r06_scan_eval_fusion_ab.txt) -- sixteen uncached agent-scope loads per
+// cell and 1024-thread workgroups for a 260-cell job cost more than the launch they save.  The shipped kernel is <kBlock, false>.
+template <int NT, bool WAIT>
+__device__ __forceinline__ void mse_eval_body(int j, int nwg, const float *__restrict__ x, const float *__restrict__ grid,
+                                              const float *__restrict__ bt, const float *__restrict__ bq, const uint32_t *__restrict__ rank,
+                                              const int *__restrict__ cflag, const uint32_t *__restrict__ maxkey, const DD *p1, const DD *p2,
+                                              const uint32_t *pn, const DD *t1, const DD *t2, const uint32_t *tn, int64_t ni, int nsb,
+                                              float *mses, const HistArgs &a, double inv_inner, const uint32_t *nunits, const SelOne &so,
+                                              const uint32_t *done)
 {
-    __shared__ double s_red[kBlock];
+    __shared__ double s_red[NT];
     __shared__ float s_scale[kLutMax];
-    __shared__ DD s_t1[kTopLds], s_t2[kTopLds], s_w1[kBlock / 64], s_w2[kBlock / 64];
-    __shared__ uint32_t s_tn[kTopLds], s_wn[kBlock / 64];
+    __shared__ DD s_t1[kTopLds], s_t2[kTopLds], s_w1[NT / 64], s_w2[NT / 64];
+    __shared__ uint32_t s_tn[kTopLds], s_wn[NT / 64];
+    __shared__ int s_lost;
     const int tid = threadIdx.x;
-    const int j = blockIdx.x, m = j / a.n_cand;
+    const int m = j / a.n_cand;
     float *out = mses + j;
     // non-finite keys: the reference's mean is NaN (a NaN element) or +inf (an infinite one: (x - xq)^2 = inf)
     const uint32_t last = maxkey[0];
     const int flag = cflag[j];
-    const bool is_nan = last > 0x7f800000u || flag == kFlagNaN || nunits[2], is_inf = !is_nan && last == 0x7f800000u;
+    bool is_nan = last > 0x7f800000u || flag == kFlagNaN || nunits[2];
+    const bool is_inf = !is_nan && last == 0x7f800000u;
+    if (WAIT && !is_nan && !is_inf && flag != kFlagBrute) {
+        if (tid == 0) {
+            int spins = 0, lost = 0;
+            while (agent_load(done) < (uint32_t)nsb) {
+                if (++spins > (1 << 22)) {
+                    lost = 1;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            s_lost = lost;
+        }
+        __syncthreads();
+        is_nan = s_lost != 0;
+    }
     if (is_nan || is_inf) {
         if (tid == 0) {
             const float v = is_nan ? __builtin_nanf("") : __builtin_inff();
@@ -1126,9 +1181,9 @@ k_mse_eval(const float *__restrict__ x, const float *__restrict__ grid, const fl
         const float mv = fabsf(fmaxf(fabsf(-gv), gv));
         const Chan ch = make_chan(mv, f);
         const float pmaxf = (float)f.pmax;
-        for (int p = tid + 1; p <= f.pmax; p += kBlock) s_scale[p] = lut_entry(ch, p, f.M).x;
+        for (int p = tid + 1; p <= f.pmax; p += NT) s_scale[p] = lut_entry(ch, p, f.M).x;
         __syncthreads();
-        for (int64_t i = tid; i < a.n; i += kBlock) {
+        for (int64_t i = tid; i < a.n; i += NT) {
             const float xv = x[i];
             const float xc = __builtin_amdgcn_fmed3f(xv, ch.minv, ch.maxv);          // (unsigned formats: negative -> 0)
             const float ls = floorf(log2_tab(fabsf(xc), kFastTab) + ch.bias);
@@ -1147,10 +1202,10 @@ k_mse_eval(const float *__restrict__ x, const float *__restrict__ grid, const fl
             const int lane = tid & 63, wave = tid >> 6;
             DD carry1 = zero, carry2 = zero;
             uint32_t carryn = 0u;
-            for (int base = 0; base < nsb; base += kBlock) {           // (one trip for up to 256 superblocks)
+            for (int base = 0; base < nsb; base += NT) {               // (one trip for up to NT superblocks)
                 const int i = base + tid;
-                DD v1 = i < nsb ? t1[i] : zero, v2 = i < nsb ? t2[i] : zero;
-                uint32_t vn = i < nsb ? tn[i] : 0u;
+                DD v1 = i < nsb ? get_dd<WAIT>(t1 + i) : zero, v2 = i < nsb ? get_dd<WAIT>(t2 + i) : zero;
+                uint32_t vn = i < nsb ? get_u32<WAIT>(tn + i) : 0u;
                 DD i1 = v1, i2 = v2;
                 uint32_t in = vn;
 #pragma unroll
@@ -1188,7 +1243,7 @@ k_mse_eval(const float *__restrict__ x, const float *__restrict__ grid, const fl
                     s_t2[i] = dd_add(c2, e2);
                     s_tn[i] = cn + en;
                 }
-                for (int w = 0; w < kBlock / 64; ++w) {
+                for (int w = 0; w < NT / 64; ++w) {
                     carry1 = dd_add(carry1, s_w1[w]);
                     carry2 = dd_add(carry2, s_w2[w]);
                     carryn += s_wn[w];
@@ -1202,15 +1257,15 @@ k_mse_eval(const float *__restrict__ x, const float *__restrict__ grid, const fl
         const int ncells = a.ncells[m];
         const float *T = bt + (int64_t)j * a.stride, *Q = bq + (int64_t)j * a.stride;
         const uint32_t *R = rank + (int64_t)j * a.stride;
-        for (int c = tid; c < ncells; c += kBlock) {
+        for (int c = tid; c < ncells; c += NT) {
             const float lo = T[c], hi = c + 1 < ncells ? T[c + 1] : __builtin_inff();
             if (!(lo < hi)) continue;
             const int64_t i0 = c ? (int64_t)R[c] : 0, i1 = hi < __builtin_inff() ? (int64_t)R[c + 1] : ni;   // (T = +inf: not a border)
             const int64_t b0 = i0 / kSuper, b1 = i1 / kSuper;
-            const uint32_t cnt = (qn[b1] + pn[i1]) - (qn[b0] + pn[i0]);
+            const uint32_t cnt = (qn[b1] + get_u32<WAIT>(pn + i1)) - (qn[b0] + get_u32<WAIT>(pn + i0));
             if (cnt == 0u) continue;
-            const DD m1lo = dd_add(q1[b0], p1[i0]), m1hi = dd_add(q1[b1], p1[i1]);
-            const DD m2lo = dd_add(q2[b0], p2[i0]), m2hi = dd_add(q2[b1], p2[i1]);
+            const DD m1lo = dd_add(q1[b0], get_dd<WAIT>(p1 + i0)), m1hi = dd_add(q1[b1], get_dd<WAIT>(p1 + i1));
+            const DD m2lo = dd_add(q2[b0], get_dd<WAIT>(p2 + i0)), m2hi = dd_add(q2[b1], get_dd<WAIT>(p2 + i1));
             // S2 - 2 q S1 + n q^2 in double-double (q^2 of an fp32 q is exact in double); the cell's result is >= 0
             const double qd = (double)Q[c];
             const DD d2 = dd_add(m2hi, dd_neg(m2lo)), d1 = dd_add(m1hi, dd_neg(m1lo));
@@ -1220,7 +1275,7 @@ k_mse_eval(const float *__restrict__ x, const float *__restrict__ grid, const fl
     }
     s_red[tid] = acc;
     __syncthreads();
-    for (int off = kBlock / 2; off >= 1; off >>= 1) {            // fixed tree: deterministic
+    for (int off = NT / 2; off >= 1; off >>= 1) {                // fixed tree: deterministic
         if (tid < off) s_red[tid] += s_red[tid + off];
         __syncthreads();
     }
@@ -1230,7 +1285,18 @@ k_mse_eval(const float *__restrict__ x, const float *__restrict__ grid, const fl
         agent_store(out, a.overwrite ? (float)(tot * inv_inner) : *out + (float)(tot * inv_inner));
     }
     // the winner of the search: the last workgroup to finish its entry selects (fp8q_select.h; per-tensor quantizers)
-    if (so.enabled && last_workgroup(so.ticket, gridDim.x, blockIdx.x)) select_one_row(mses, grid, a.n_m, a.n_cand, so);
+    if (so.enabled && last_workgroup(so.ticket, (unsigned)nwg, (unsigned)j)) select_one_row(mses, grid, a.n_m, a.n_cand, so);
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_mse_eval(const float *__restrict__ x, const float *__restrict__ grid, const float *__restrict__ bt, const float *__restrict__ bq,
+           const uint32_t *__restrict__ rank, const int *__restrict__ cflag, const uint32_t *__restrict__ maxkey,
+           const DD *__restrict__ p1, const DD *__restrict__ p2, const uint32_t *__restrict__ pn, const DD *__restrict__ t1,
+           const DD *__restrict__ t2, const uint32_t *__restrict__ tn, int64_t ni, int nsb, float *mses, HistArgs a,
+           double inv_inner, const uint32_t *__restrict__ nunits, SelOne so)
+{
+    mse_eval_body<kBlock, false>((int)blockIdx.x, (int)gridDim.x, x, grid, bt, bq, rank, cflag, maxkey, p1, p2, pn, t1, t2, tn, ni, nsb, mses, a,
+                                 inv_inner, nunits, so, nullptr);
 }
 
 // ---- host -----------------------------------------------------------------------------------------------------------------
@@ -1413,6 +1479,9 @@ int fp8q_mse_hist_launch(const float *x, int64_t n, const float *grid, int64_t n
     }
     hipLaunchKernelGGL(k_moments, dim3(2048), dim3(kBlock), shmem, st, keys, sb, gtab, units, nunits, gn, gd, gd2lo, gd2hi, bcap);
     if (int rc = launch_rc()) return rc;
+    SelOne so;
+    memset(&so, 0, sizeof(so));
+    if (sel) so = *sel;
     hipLaunchKernelGGL(k_iv_scan_super, dim3((unsigned)L.nsb), dim3(kSuper), 0, st, boff, gn, gd, gd2lo, gd2hi, L.ni, p1, p2, pn, t1,
                        t2, tn);
     if (int rc = launch_rc()) return rc;
@@ -1420,9 +1489,6 @@ int fp8q_mse_hist_launch(const float *x, int64_t n, const float *grid, int64_t n
         hipLaunchKernelGGL(k_iv_scan_top, dim3(1), dim3(64), 0, st, t1, t2, tn, L.nsb);
         if (int rc = launch_rc()) return rc;
     }
-    SelOne so;
-    memset(&so, 0, sizeof(so));
-    if (sel) so = *sel;
     hipLaunchKernelGGL(k_mse_eval, dim3((unsigned)n_pairs), dim3(kBlock), 0, st, x, grid, bt, bq, rank, cflag, maxkey, p1, p2, pn, t1,
                        t2, tn, L.ni, (int)L.nsb, mses, a, 1.0 / (double)n, nunits, so);
     return launch_rc();

@@ -1265,6 +1265,59 @@ k_quant_scalar(const float *__restrict__ x, float *__restrict__ y, int64_t inner
     quant_scalar_body(x, y, inner, maxval, per_channel, f);
 }
 
+// BASELINE config 2 at its literal size (conv1 [64, 3, 7, 7]: 37 KB) and every other weight tensor that small: the launch is
+// all latency.  k_rows_direct makes two passes (row min/max from global, tables, then the rows again as one flat range) around
+// two workgroup barriers and builds R tables per workgroup in one thread each: 8.5 us for a tensor whose launch floor is ~4.
+// Here a WAVE owns a row for the whole kernel: the row sits in registers (EPL elements per lane), min / max by wave shuffles,
+// the channel constants once per wave, the {s, 1/s} table by the wave's 64 lanes into its own slice of LDS, the quantized row
+// straight from the registers -- one pass, no workgroup barrier.  Same per-element arithmetic (quant_one) and the same min / max
+// semantics (mm_acc, NaN flag) as the other fused routes: bit-identical results.
+template <int EPL>
+__global__ void __launch_bounds__(kBlock)
+k_small_rows_fused(const float *__restrict__ x, float *__restrict__ y, int64_t C, int inner, float *row_min, float *row_max,
+                   float *maxval_out, QFmt f)
+{
+    __shared__ float2 lut[kBlock / 64][kLutMax];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row = (int64_t)blockIdx.x * (kBlock / 64) + wave;
+    if (row >= C) return;                       // (no workgroup barrier below)
+    const float *xr = x + row * inner;
+    float *yr = y + row * inner;
+    float v[EPL];
+    MinMax m;
+    mm_init(m);
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        const int i = lane + 64 * e;
+        v[e] = 0.0f;
+        if (i < inner) {
+            v[e] = xr[i];
+            mm_acc(m, v[e]);
+        }
+    }
+    mm_wave_reduce(m);
+    if (m.nan) m.mn = m.mx = __builtin_nanf("");
+    const float mv = fabsf(tmax(fabsf(m.mn), m.mx));   // fp8_quantizer.py:236
+    if (lane == 0) {
+        if (row_min) row_min[row] = m.mn;
+        if (row_max) row_max[row] = m.mx;
+        if (maxval_out) maxval_out[row] = mv;
+    }
+    const Chan cfull = make_chan(mv, f);
+    lut_part(lut[wave], cfull, f, lane, 64);
+    __builtin_amdgcn_wave_barrier();
+    const ChanLite c = lite(cfull);
+    const float pmaxf = (float)f.pmax;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        const int i = lane + 64 * e;
+        if (i < inner) yr[i] = quant_one(v[e], c, lut[wave], pmaxf, f.qthr);
+    }
+}
+
+constexpr int64_t kSmallFusedElems = 16384;    // tensors up to 64 KB ...
+constexpr int kSmallFusedInner = 512;          // ... of rows up to 8 elements per lane
+
 // K1 with the mantissa width read from DEVICE memory (fp8q_quantize_dm_f32): the MSE estimator's plurality vote on the
 // mantissa bits (range_estimators.py:350-354) stays on the GPU, and the batch that follows it in the same calibration
 // forward is quantized with the winner without a host round trip.  The host cannot know the format, so it passes the
@@ -1283,12 +1336,37 @@ __device__ __forceinline__ QFmt pick_fmt(const FmtSel &s)
     return s.tab[(int)M - 1];
 }
 
+template <bool NT, int U>
 __global__ void __launch_bounds__(kBlock)
 k_quant_rows_dm(const float *__restrict__ x, float *__restrict__ y, int64_t inner, const float *__restrict__ maxval,
                 int per_channel, FmtSel sel)
 {
     const QFmt f = pick_fmt(sel);
-    quant_rows_body<false, kUnroll>(x, y, inner, maxval, per_channel, f);
+    quant_rows_body<NT, U>(x, y, inner, maxval, per_channel, f);
+}
+
+// Short per-channel rows with the width in device memory (MobileNetV2's weights in the mantissa search: [1280, 320],
+// [96, 1, 3, 3] ...): a WAVE per row -- its channel constants and {s, 1/s} table built once per wave in the wave's own slice of
+// LDS, the row streamed by its 64 lanes -- instead of a 256-thread workgroup (and a ~50-operation double-precision set-up) per
+// row of a few hundred elements.  Same arithmetic as quant_rows_body (quant_one), bit for bit.
+__global__ void __launch_bounds__(kBlock)
+k_quant_short_rows_dm(const float *__restrict__ x, float *__restrict__ y, int64_t C, int inner, const float *__restrict__ maxval,
+                      FmtSel sel)
+{
+    __shared__ float2 lut[kBlock / 64][kLutMax];
+    const QFmt f = pick_fmt(sel);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float pmaxf = (float)f.pmax;
+    for (int64_t row = (int64_t)blockIdx.x * (kBlock / 64) + wave; row < C; row += (int64_t)gridDim.x * (kBlock / 64)) {
+        const Chan cfull = make_chan(maxval[row], f);
+        for (int i = lane; i <= f.pmax; i += 64) lut[wave][i] = lut_entry(cfull, i, f.M);
+        __builtin_amdgcn_wave_barrier();
+        const ChanLite c = lite(cfull);
+        const float *xr = x + row * inner;
+        float *yr = y + row * inner;
+        for (int i = lane; i < inner; i += 64) yr[i] = quant_one(xr[i], c, lut[wave], pmaxf, f.qthr);
+        __builtin_amdgcn_wave_barrier();       // (the next row's table overwrites this one)
+    }
 }
 
 __global__ void __launch_bounds__(kBlock)
@@ -1832,21 +1910,40 @@ int fp8q_quantize_dm_f32(const float *x, float *y, int64_t C, int64_t inner, con
         inner *= C;
         C = 1;
     }
+    if (per_channel && inner <= 2048 && inner < (1ll << 31) / 4) {
+        // short rows: a wave per row
+        const int64_t blocks = cdiv(C, kBlock / 64);
+        hipLaunchKernelGGL(k_quant_short_rows_dm, dim3((unsigned)(blocks < 8 * kTargetBlocks ? blocks : 8 * kTargetBlocks)), dim3(kBlock), 0, st,
+                           x, y, C, (int)inner, maxval, sel);
+        return launch_rc();
+    }
     for (int64_t c0 = 0; c0 < C; c0 += 65535) {   // gridDim.y limit
         const int64_t cn = (C - c0) < 65535 ? (C - c0) : 65535;
         const float *xs = x + c0 * inner;
         float *ys = y + c0 * inner;
         // k_quant_rows peels every row to 16-byte alignment assuming x and y rows are co-aligned
         const bool aligned = (((uintptr_t)xs ^ (uintptr_t)ys) & 15) == 0 && ((uintptr_t)xs & 3) == 0;
-        const int64_t pieces = inner / (4 * kBlock * kUnroll) > 0 ? inner / (4 * kBlock * kUnroll) : 1;
-        const int64_t cap = (4 * kTargetBlocks) / cn > 0 ? (4 * kTargetBlocks) / cn : 1;
+        // the geometry of fp8q_quantize_f32 (nontemporal beyond the caches, 4 KiB pieces on a resident grid for cache-sized
+        // per-tensor rows): the format is the only thing this entry point does not know on the host
+        const bool nt = cn * inner * 4 >= kNtBytes;
+        const bool small = cn == 1 && inner < ((int64_t)8 << 20);
+        const int U = small ? 1 : kUnroll;
+        const int64_t pieces = inner / (4 * kBlock * U) > 0 ? inner / (4 * kBlock * U) : 1;
+        const int64_t total_cap = (!nt || pieces * cn <= 4096) ? kTargetBlocks : 65536;
+        const int64_t cap = total_cap / cn > 0 ? total_cap / cn : 1;
         const int64_t bx = balanced_blocks(pieces, cap);
         if (aligned) {
-            hipLaunchKernelGGL(k_quant_rows_dm, dim3((unsigned)bx, (unsigned)cn), dim3(kBlock), 0, st, xs, ys, inner,
-                               maxval + (per_channel ? c0 : 0), per_channel, sel);
+            const dim3 g((unsigned)bx, (unsigned)cn), b(kBlock);
+            const float *mvp = maxval + (per_channel ? c0 : 0);
+            if (nt)
+                hipLaunchKernelGGL((k_quant_rows_dm<true, kUnroll>), g, b, 0, st, xs, ys, inner, mvp, per_channel, sel);
+            else if (small)
+                hipLaunchKernelGGL((k_quant_rows_dm<false, 1>), g, b, 0, st, xs, ys, inner, mvp, per_channel, sel);
+            else
+                hipLaunchKernelGGL((k_quant_rows_dm<false, kUnroll>), g, b, 0, st, xs, ys, inner, mvp, per_channel, sel);
         } else {
             int64_t bs = cdiv(inner, kBlock);
-            if (bs > cap) bs = cap;
+            if (bs > cap * 4) bs = cap * 4;
             hipLaunchKernelGGL(k_quant_scalar_dm, dim3((unsigned)bs, (unsigned)cn), dim3(kBlock), 0, st, xs, ys, inner,
                                maxval + (per_channel ? c0 : 0), per_channel, sel);
         }
@@ -2027,6 +2124,22 @@ int fp8q_minmax_quantize_f32(const float *x, float *y, int64_t C, int64_t inner,
     if (inner > kDirectMaxInner) return FP8Q_ETOOLONG;
     if (((uintptr_t)x & 3) != 0 || ((uintptr_t)y & 3) != 0) return FP8Q_EINVAL;
     hipStream_t st = (hipStream_t)stream;
+    static const bool small_fused = [] {   // FP8Q_SMALL_FUSED=0: the general routes for small tensors too (A/B)
+        const char *e = getenv("FP8Q_SMALL_FUSED");
+        return !e || atoi(e) != 0;
+    }();
+    if (small_fused && C * inner <= kSmallFusedElems && inner <= kSmallFusedInner) {
+        const dim3 g((unsigned)cdiv(C, kBlock / 64)), b(kBlock);
+        const int epl = (int)cdiv(inner, 64);
+#define FP8Q_LAUNCH_SMALL(E) hipLaunchKernelGGL(k_small_rows_fused<E>, g, b, 0, st, x, y, C, (int)inner, row_min, row_max, maxval_out, f)
+        if (epl <= 1) FP8Q_LAUNCH_SMALL(1);
+        else if (epl <= 2) FP8Q_LAUNCH_SMALL(2);
+        else if (epl <= 3) FP8Q_LAUNCH_SMALL(3);
+        else if (epl <= 4) FP8Q_LAUNCH_SMALL(4);
+        else FP8Q_LAUNCH_SMALL(8);
+#undef FP8Q_LAUNCH_SMALL
+        return launch_rc();
+    }
     {
         const FoldArgs nofold = {0, 1, 0.0f, 0.0f};
         const int rc = launch_rows_reg(true, x, y, C, inner, row_min, row_max, maxval_out, f, nofold, st);

@@ -183,13 +183,14 @@ def calibrate_quantize_sharded(x_local, mbits, n_bits=8, sign_bits=1, state=None
     return y, (cur_min, cur_max)
 
 
-def quantize_weight_sharded_codes(w, mbits, n_bits=8, sign_bits=1, group=None, ops=None, timing=None):
+def quantize_weight_sharded_codes(w, mbits, n_bits=8, sign_bits=1, group=None, ops=None, timing=None, maxval=None):
     """Channel-sharded weight quantization that ships 1-byte storage codes instead of fp32 values
     (SURVEY.md 8f N3): rank r finds the ranges of its channels and encodes them (fp8q_encode_u8),
     the ranks all-gather codes (1 B/element: 4x less xGMI traffic than fp32) and per-channel
     ranges, and every rank decodes the full tensor locally (fp8q_decode_u8).  The result is
     bit-identical to quantize_weight_sharded / to the single-process quantizer.
-    Returns (w_q [C, ...], maxval [C], codes uint8 [C, ...])."""
+    maxval [C]: FIXED ranges that every rank already holds (after fix_ranges): nothing is estimated and only the codes
+    travel.  Returns (w_q [C, ...], maxval [C], codes uint8 [C, ...])."""
     ops = ops or _default_ops()
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -197,15 +198,29 @@ def quantize_weight_sharded_codes(w, mbits, n_bits=8, sign_bits=1, group=None, o
     inner = w.numel() // max(C, 1)
     lo, hi = channel_partition(C, world)[rank]
     shard = w[lo:hi].contiguous()
+    fixed = maxval is not None
     _mark(timing)
     if hi > lo:
-        mv_shard = ops.minmax(shard, True, want_maxval=True)[2]
+        mv_shard = maxval[lo:hi].contiguous() if fixed else ops.minmax(shard, True, want_maxval=True)[2]
         c_shard = ops.encode(shard, mv_shard, mbits, n_bits, sign_bits)
     else:
         mv_shard = w.new_empty(0)
         c_shard = torch.empty(0, dtype=torch.uint8, device=w.device)
     _mark(timing)
-    if _multi(group) and C % world == 0:
+    if fixed and _multi(group) and C % world == 0:
+        codes = torch.empty(w.shape, dtype=torch.uint8, device=w.device)
+        dist.all_gather_into_tensor(codes.view(-1), c_shard.reshape(-1), group=group)       # the ranges are everywhere already
+    elif fixed and world > 1:
+        per = -(-C // world)
+        send_c = torch.zeros(per * inner, dtype=torch.uint8, device=w.device)
+        send_c[: (hi - lo) * inner] = c_shard.reshape(-1)
+        recv_c = torch.empty(world * per * inner, dtype=torch.uint8, device=w.device)
+        dist.all_gather_into_tensor(recv_c, send_c, group=group)
+        codes = torch.cat([recv_c[r * per * inner: r * per * inner + (b - a) * inner]
+                           for r, (a, b) in enumerate(channel_partition(C, world))]).view(w.shape)
+    elif fixed:
+        codes = c_shard.view(w.shape)
+    elif _multi(group) and C % world == 0:
         # even split: gather straight into the final tensors (no padding, no re-assembly copies)
         codes = torch.empty(w.shape, dtype=torch.uint8, device=w.device)
         maxval = w.new_empty(C)

@@ -47,6 +47,10 @@ def test_dry_run_eight_ranks_cpu():
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"dry_run"' in ln][0])
     assert d["ranks"] == 8 and d["ranks_seen"] == 8
     seq = d["call_sequence_as_executed"]
+    head = seq["headline: quantize_weight_sharded_codes(fixed ranges)"]
+    assert len(head) == 1 and head[0]["dtype"] == "uint8" and head[0]["send_bytes"] == 1024 * 147
+    full = d["full_size_bytes"]["headline (value at --gpus N)"]["all_gather_into_tensor codes"]
+    assert full["received_per_rank"] == 7 * (1 << 21) * 147 <= 7 / 8 * 8 * (1 << 21) * 147
     r18 = seq["resnet18_weights_one_allgather: quantize_weights_sharded_bucketed (REAL shapes)"]
     assert len(r18) == 1 and r18[0]["dtype"] == "uint8" and abs(r18[0]["send_bytes"] - (11678912 + 4800 * 4) / 8) < 0.01 * 11678912 / 8
     assert seq["c5: calibrate_quantize_sharded"] == [dict(op="all_reduce", dtype="float32", send_bytes=16, reduce="MAX")]
@@ -62,9 +66,13 @@ def test_dry_run_ranks_prints_the_call_sequence_cpu():
     d = json.loads(lines[0])
     assert d["ranks"] == 4 and d["ranks_seen"] == 4
     seq = d["call_sequence_as_executed"]
-    head = seq["headline: quantize_weight_sharded(fixed ranges)"]
-    assert [c["op"] for c in head] == ["all_gather_into_tensor", "all_gather_into_tensor"]
-    assert head[0]["send_bytes"] == 1024 * 147 * 4 and head[1]["send_bytes"] == 1024 * 4
+    # the headline ships 1-byte codes of fixed-range channels: ONE collective, a quarter of the fp32 form's bytes, no ranges
+    head = seq["headline: quantize_weight_sharded_codes(fixed ranges)"]
+    assert [c["op"] for c in head] == ["all_gather_into_tensor"] and head[0]["dtype"] == "uint8"
+    assert head[0]["send_bytes"] == 1024 * 147
+    head32 = seq["headline, fp32 wire (value_fp32_wire): quantize_weight_sharded(fixed ranges)"]
+    assert [c["op"] for c in head32] == ["all_gather_into_tensor", "all_gather_into_tensor"]
+    assert head32[0]["send_bytes"] == 1024 * 147 * 4 and head32[1]["send_bytes"] == 1024 * 4
     codes = seq["weights_allgather.codes_u8: quantize_weight_sharded_codes"]
     assert codes[0]["dtype"] == "uint8" and codes[0]["send_bytes"] == 1024 * 147
     r18 = seq["resnet18_weights_one_allgather: quantize_weights_sharded_bucketed (REAL shapes)"]
@@ -75,8 +83,10 @@ def test_dry_run_ranks_prints_the_call_sequence_cpu():
     c5 = seq["c5: calibrate_quantize_sharded"]
     assert c5 == [dict(op="all_reduce", dtype="float32", send_bytes=16, reduce="MAX")]
     full = d["full_size_bytes"]["headline (value at --gpus N)"]
-    assert full["all_gather_into_tensor values"]["send_bytes_per_rank"] == (1 << 21) * 147 * 4
-    assert full["all_gather_into_tensor values"]["received_per_rank"] == 3 * (1 << 21) * 147 * 4
+    assert full["all_gather_into_tensor codes"]["send_bytes_per_rank"] == (1 << 21) * 147
+    assert full["all_gather_into_tensor codes"]["received_per_rank"] == 3 * (1 << 21) * 147 <= 3 / 4 * 4 * (1 << 21) * 147
+    full32 = d["full_size_bytes"]["headline, fp32 wire (value_fp32_wire)"]
+    assert full32["all_gather_into_tensor values"]["received_per_rank"] == 3 * (1 << 21) * 147 * 4
 
 
 def test_world_size_mismatch_is_an_error():
@@ -96,14 +106,15 @@ def test_bare_two_rank_gloo_bench_on_one_gpu():
     assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["scaling"] == "weak"
     # `value` is north_star's weight flow END TO END (shard -> quantize -> all-gather): it contains the collective
     for k in ("value_kernel_only", "kernel_us", "collective_us", "xgmi_bytes_received_per_rank", "xgmi_gb_s",
-              "value_codes_wire", "value_resnet18_strong", "value_c5"):
+              "value_codes_wire", "value_resnet18_strong", "value_c5", "value_fp32_wire", "fp32_wire_ms_per_step", "wire"):
         assert k in line, k
     assert line["collective_us"] > 0 and line["kernel_us"] > 0
     assert line["ms_per_step"] * 1e3 >= line["kernel_us"] + 0.9 * line["collective_us"]      # the step time holds both phases
     assert line["value"] < line["value_kernel_only"]
     n_total = 2 * 65536 * 147
     assert abs(line["value"] - n_total / (line["ms_per_step"] * 1e-3) / 1e9) <= 0.02 * line["value"]
-    assert line["xgmi_bytes_received_per_rank"] == (65536 * 147 + 65536) * 4 and line["xgmi_gb_s"] is None   # gloo: no xGMI figure
+    assert line["xgmi_bytes_received_per_rank"] == 65536 * 147 and line["xgmi_gb_s"] is None   # 1-byte codes; gloo: no xGMI figure
+    assert line["fp32_wire_xgmi_bytes_received_per_rank"] == (65536 * 147 + 65536) * 4 and line["value_fp32_wire"] > 0
     assert "REDUCED" in line["config"]["workload"] and "INCLUDES the collective" in line["config"]["parallelism"]
     nsp = line["north_star_path"]
     assert nsp["ranks_seen"] == 2

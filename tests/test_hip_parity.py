@@ -262,6 +262,42 @@ def test_retired_workspace_is_still_checked(ops):
     assert not ops._ws_retired
 
 
+def test_spin_waiting_workgroups_make_progress_next_to_a_saturating_stream(ops):
+    """The single-launch min/max (its reducer workgroup polls the streaming workgroups' granules, fp8q_common.h) and the fused
+    interval scan + evaluation of K4 (evaluating workgroups poll the scan workgroups' counter, k_scan_eval) while a SECOND
+    stream keeps every CU busy with back-to-back 1 GiB copies: same results as on an idle GPU, no reducer time-out
+    (check_workspaces), no NaN table entry (the bounded spins give up with NaN rather than hang)."""
+    ops.check_workspaces()
+    x = torch.randn(64, 64, 112, 112, device="cuda")
+    big = torch.randn(1 << 28, device="cuda")
+    bout = torch.empty_like(big)
+    a = torch.clamp(torch.randn(64, 24, 56, 56, device="cuda") * 2.5, 0, 6)
+    s_busy, s_work = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s_work):
+        mn0, mx0 = ops.minmax(x, False)
+        cal0 = ops.MseCalibration(1, a.device, [1.0, 2.0, 3.0, 4.0, 5.0, 6.0], 8, 1)
+        y0 = cal0.step(a)
+    torch.cuda.synchronize()
+    results = []
+    for it in range(12):
+        with torch.cuda.stream(s_busy):
+            for _ in range(3):
+                ops.copy(big, out=bout)            # 65536-workgroup launches: the CUs stay full
+        with torch.cuda.stream(s_work):
+            mn, mx = ops.minmax(x, False)
+            cal = ops.MseCalibration(1, a.device, [1.0, 2.0, 3.0, 4.0, 5.0, 6.0], 8, 1)
+            y = cal.step(a)
+            results.append((mn, mx, cal, y))
+    torch.cuda.synchronize()
+    for mn, mx, cal, y in results:
+        assert torch.equal(mn, mn0) and torch.equal(mx, mx0)
+        assert torch.isfinite(cal.mses).all()
+        assert torch.equal(cal.mses.view(torch.int32), cal0.mses.view(torch.int32))
+        assert torch.equal(cal.maxval, cal0.maxval) and torch.equal(cal.mbits, cal0.mbits) and torch.equal(y, y0)
+    ops.check_workspaces()                         # raises if any reducer timed out
+
+
 @pytest.mark.parametrize("shape,pc", [((64, 3, 7, 7), True), ((64, 3, 7, 7), False), ((4, 8, 6, 6), False),
                                       ((1000, 512), True), ((8, 300000), True), ((3, 5), True),
                                       ((64, 64, 56, 56), False), ((2, 2049), True)])
@@ -311,6 +347,32 @@ def test_fused_minmax_quantize_bit_exact(ops, shape, M):
     np.testing.assert_array_equal(mx.cpu().numpy(), rmx)
     np.testing.assert_array_equal(mv.cpu().numpy(), rmv)
     assert_bit_exact(y.cpu().numpy(), oracle.c_quantize(x, rmv, M, 8, 1), f"fused {shape}")
+
+
+@pytest.mark.parametrize("shape", [(64, 147), (16, 1), (33, 64), (50, 65), (100, 129), (64, 256), (20, 300), (32, 512), (1, 512),
+                                   (257, 63), (5, 3, 1, 1)])
+@pytest.mark.parametrize("M,sign", [(2, 1), (3, 1), (5, 0), (7, 1)])
+def test_small_tensor_fused_route_bit_exact(ops, shape, M, sign):
+    """tensors of <= 64 KB with rows of <= 512 elements: a wave per row, the row in registers (k_small_rows_fused, BASELINE
+    config 2's literal size) -- every row length class (1 .. 8 elements per lane), special values, degenerate rows"""
+    rng = np.random.RandomState(shape[0] * 31 + shape[1] + M)
+    x = (rng.randn(*shape) * rng.choice([1e-3, 0.1, 3.0, 200.0])).astype(np.float32)
+    flat = x.reshape(shape[0], -1)
+    if shape[0] > 8:
+        flat[1] = 0                        # all-zero row -> NaN row
+        flat[2, 0] = np.nan                # a NaN: the row's range is NaN
+        flat[3, -1] = np.inf
+        flat[4, 0] = -0.0
+        flat[5] = np.abs(flat[5])          # one-sided row
+        flat[6] = 1e-41                    # denormals only
+    y, mn, mx, mv = ops.minmax_quantize(dev(x), M, 8, sign)
+    rmn, rmx = oracle.c_minmax(x, True)
+    rmv = oracle.c_absmax(rmn, rmx)
+    for got, ref, what in ((mn, rmn, "min"), (mx, rmx, "max"), (mv, rmv, "maxval")):
+        got = got.cpu().numpy()
+        assert np.array_equal(np.isnan(got), np.isnan(ref)) and np.array_equal(got[~np.isnan(ref)].view(np.int32),
+                                                                                ref[~np.isnan(ref)].view(np.int32)), what
+    assert_bit_exact(y.cpu().numpy(), oracle.c_quantize(x, rmv, M, 8, sign), f"small fused {shape} M={M} sign={sign}")
 
 
 def test_config2_conv1_vs_reference(ops, golden_dir):
