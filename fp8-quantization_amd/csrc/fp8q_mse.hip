@@ -18,6 +18,7 @@ namespace {
 constexpr int kMseBlock = 128;
 constexpr int kMseTile = 2048;
 constexpr int kMseMaxM = 8;
+constexpr int kSelK = 8;              // k_mse_select's 16-slot form: candidates per slot (n_cand <= 128)
 
 struct MseArgs {
     QFmt fmt[kMseMaxM];
@@ -30,6 +31,11 @@ struct MseArgs {
     int64_t C;
     int overwrite;   // the table entries are written, not added to (first batch of fp8q_mse_calibrate_f32: no cleared table needed;
                      // same bits as adding to +0: an entry is never -0)
+    // k_mse_grid on the FIRST calibration batch of a per-channel quantizer (fp8q_mse_calibrate_f32): the search grid does not
+    // exist yet -- every workgroup finds its row's min / max itself (rows < 2048 elements: a few loads per thread from L2),
+    // takes its candidate from linspace_at(max|row|, 0.1, 1.2, n_cand, cand), and the row's first workgroup writes the range
+    // and the grid column for the batches to come.  Saves the separate abs-max + grid launch (12 us x 53 weight tensors).
+    float *first_min, *first_max, *first_absmax, *first_grid;     // all NULL: the grid is given
 };
 
 // (an agent-scope store: the last workgroup of the launch may read the entry for the winner selection, fp8q_select.h)
@@ -51,8 +57,38 @@ k_mse_grid(const float *__restrict__ x, const float *__restrict__ grid, double *
     float *lut = xs + kMseTile + tid * stride;   // s_p of this candidate, exact (scale_exact)
     const bool active = cand < a.n_cand;
 
-    // set_quant_range(-g, g): maxval = |max(|-g|, g)|  (fp8_quantizer.py:236)
-    const float gv = active ? grid[(int64_t)cand * a.C + c] : 1.0f;
+    float gv;
+    if (a.first_grid) {
+        // the row's min / max as fp8q_minmax_f32 forms them (mm_acc: NaN flag, IEEE min / max), |max(|min|, max)|, the grid point
+        __shared__ float s_mn[kMseBlock / 64], s_mx[kMseBlock / 64];
+        __shared__ int s_nan[kMseBlock / 64];
+        const float *xrow = x + c * a.inner;
+        MinMax mm;
+        mm_init(mm);
+        for (int64_t i = tid; i < a.inner; i += kMseBlock) mm_acc(mm, xrow[i]);
+        mm_wave_reduce(mm);
+        if ((tid & 63) == 0) {
+            s_mn[tid >> 6] = mm.mn;
+            s_mx[tid >> 6] = mm.mx;
+            s_nan[tid >> 6] = mm.nan;
+        }
+        __syncthreads();
+        float mn = fminf(s_mn[0], s_mn[1]), mx = fmaxf(s_mx[0], s_mx[1]);
+        if (s_nan[0] | s_nan[1]) mn = mx = __builtin_nanf("");
+        const float absmax = fabsf(tmax(fabsf(mn), mx));               // fp8_quantizer.py:236
+        gv = active ? linspace_at(absmax, 0.1, 1.2, a.n_cand, cand) : 1.0f;
+        if (split == 0 && m == 0) {
+            if (active) a.first_grid[(int64_t)cand * a.C + c] = gv;
+            if (blockIdx.y == 0 && tid == 0) {
+                a.first_min[c] = mn;
+                a.first_max[c] = mx;
+                a.first_absmax[c] = absmax;
+            }
+        }
+    } else {
+        // set_quant_range(-g, g): maxval = |max(|-g|, g)|  (fp8_quantizer.py:236)
+        gv = active ? grid[(int64_t)cand * a.C + c] : 1.0f;
+    }
     const Chan ch = make_chan(fabsf(fmaxf(fabsf(-gv), gv)), f);
     lut[0] = __builtin_nanf("");
     {
@@ -701,6 +737,54 @@ k_mse_select(const float *__restrict__ mses, const float *__restrict__ grid, int
 {
     __shared__ int hist[kMseMaxM];
     __shared__ int s_vote;
+    if (n_cand <= 16 * kSelK) {
+        // Phase 1, round 6: 16 channels x 16 candidate slots per workgroup.  A thread owns channel c0 + (tid & 15) and the
+        // candidates i = slot, slot + 16, ...: every load of a wave covers four 64-byte runs of the [n_m, n_cand, C] table (the
+        // wave-per-channel form read 4 bytes of each 64), and all n_m * ceil(n_cand / 16) loads of a thread are independent
+        // -- one memory round trip instead of n_m dependent ones.  Then the 16 slots of a channel meet in LDS.
+        // (MobileNetV2's weights with the 6-width search: 14.3 -> see profiles/r06_c4_search_kernels.txt)
+        __shared__ float s_v[kMseMaxM][16][17];
+        __shared__ int s_i[kMseMaxM][16][17];
+        const int ch = threadIdx.x & 15, slot = threadIdx.x >> 4;
+        const int64_t c = (int64_t)blockIdx.x * 16 + ch;
+        float v[kMseMaxM][kSelK];
+#pragma unroll
+        for (int m = 0; m < kMseMaxM; ++m)
+#pragma unroll
+            for (int k = 0; k < kSelK; ++k) {
+                const int i = slot + 16 * k;
+                v[m][k] = (m < n_m && i < n_cand && c < C) ? mses[((int64_t)m * n_cand + i) * C + c] : __builtin_inff();
+            }
+#pragma unroll
+        for (int m = 0; m < kMseMaxM; ++m) {
+            ArgMin am = {__builtin_inff(), 0x7fffffff};
+#pragma unroll
+            for (int k = 0; k < kSelK; ++k) {
+                const int i = slot + 16 * k;
+                const ArgMin o = {v[m][k], i};
+                if (i < n_cand && argmin_less(o, am)) am = o;
+            }
+            if (m < n_m) {
+                s_v[m][ch][slot] = am.v;
+                s_i[m][ch][slot] = am.idx;
+            }
+        }
+        __syncthreads();
+        if (slot == 0 && c < C) {
+            ArgMin best_m = {__builtin_inff(), 0x7fffffff};
+            for (int m = 0; m < n_m; ++m) {
+                ArgMin am = {s_v[m][ch][0], s_i[m][ch][0]};
+                for (int q = 1; q < 16; ++q) {
+                    const ArgMin o = {s_v[m][ch][q], s_i[m][ch][q]};
+                    if (argmin_less(o, am)) am = o;
+                }
+                agent_store(&sel[c * (1 + n_m) + 1 + m], am.idx);
+                const ArgMin o = {am.v, m};
+                if (argmin_less(o, best_m)) best_m = o;
+            }
+            agent_store(&sel[c * (1 + n_m)], best_m.idx);
+        }
+    } else {
     const int lane = threadIdx.x & 63;
     const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c < C) {
@@ -718,9 +802,9 @@ k_mse_select(const float *__restrict__ mses, const float *__restrict__ grid, int
         }
         if (lane == 0) agent_store(&sel[c * (1 + n_m)], best_m.idx);
     }
-    // (lane = channel with the waves splitting the candidates reads the table in full lines instead of 16 of every 128 bytes,
-    // but turns 2 loads per lane into ~28 dependent trips per width: 36 us per call instead of 12.7 on MobileNetV2's weights
-    // with the 6-width search.  Measured, dropped.)
+    // (round 5: lane = channel with the WAVES splitting the candidates turned 2 loads per lane into ~28 dependent trips per
+    // width: 36 us per call instead of 12.7.  The 16 x 16 form above keeps every load independent.)
+    }
     // (no fences: sel travels through agent-scope stores / loads, fp8q_select.h)
     if (!last_workgroup(ticket, gridDim.x, blockIdx.x)) return;
     if (threadIdx.x < kMseMaxM) hist[threadIdx.x] = 0;
@@ -808,7 +892,7 @@ int fp8q_mse_select_f32(const float *mses, const float *grid, int64_t C, int64_t
     memset(&a, 0, sizeof(a));
     for (int m = 0; m < n_m; ++m) a.fmt[m].M = mbits_host[m];   // the candidate widths as given (the vote returns one of them)
     // ws: ticket block (kTicketBytes: zero between calls) | sel
-    hipLaunchKernelGGL(k_mse_select, dim3((unsigned)cdiv(C, 4)), dim3(kBlock), 0, (hipStream_t)stream, mses, grid, C, n_m, (int)n_cand,
+    hipLaunchKernelGGL(k_mse_select, dim3((unsigned)cdiv(C, n_cand <= 16 * kSelK ? 16 : 4)), dim3(kBlock), 0, (hipStream_t)stream, mses, grid, C, n_m, (int)n_cand,
                        (int *)((char *)ws + kTicketBytes), (unsigned *)ws, a, mbits_out, vote_out, maxval_out, xmin_out, -(float)sign_bits);
     return launch_rc();
 }
@@ -902,10 +986,22 @@ size_t fp8q_mse_workspace_bytes(int64_t C, int64_t inner, int64_t n_cand, int n_
     return (size_t)C * n_m * n_cand * ns * sizeof(double) + 16;
 }
 
+// true when mse_grid_impl will run k_mse_grid for this shape (per-channel rows below 2048 elements: the weights) -- the kernel
+// that can also make the first batch's ranges and grid itself (MseArgs::first_grid)
+static bool mse_first_batch_in_grid_kernel(const float *x, int64_t C, int64_t inner, int64_t n_cand, int n_m)
+{
+    static const bool on = [] {   // FP8Q_MSE_FIRST_IN_GRID=0: the separate abs-max + grid launch (A/B)
+        const char *e = getenv("FP8Q_MSE_FIRST_IN_GRID");
+        return !e || atoi(e) != 0;
+    }();
+    if (!on || C <= 1 || mse_use_hist_shape(C, inner, n_cand, n_m)) return false;
+    return !(mse_use_row(C, inner) && ((uintptr_t)x & 3) == 0);
+}
+
 static int mse_grid_impl(const float *x, int64_t C, int64_t inner, const float *grid, int64_t n_cand,
                          const float *mbits_host, int n_m, int n_bits, int sign_bits, float *mses,
                          void *ws, size_t ws_bytes, fp8q_stream_t stream, int overwrite, const SelOne *sel = nullptr,
-                         int *sel_done = nullptr)
+                         int *sel_done = nullptr, const fp8q_mse_state *first_state = nullptr)
 {
     SelOne so;
     memset(&so, 0, sizeof(so));
@@ -931,6 +1027,7 @@ static int mse_grid_impl(const float *x, int64_t C, int64_t inner, const float *
     a.inner = inner;
     a.C = C;
     a.overwrite = overwrite;
+    a.first_min = a.first_max = a.first_absmax = a.first_grid = nullptr;
     hipStream_t st = (hipStream_t)stream;
     if (mse_use_hist_shape(C, inner, n_cand, n_m) && fp8q_mse_hist_supported(a.fmt, n_m, n_bits))
     {
@@ -944,6 +1041,12 @@ static int mse_grid_impl(const float *x, int64_t C, int64_t inner, const float *
         hipLaunchKernelGGL(k_mse_row, dim3((unsigned)g.nblk, (unsigned)g.ngroup, (unsigned)C), dim3(64), 0, st, x, grid,
                            (double *)ws, a, g.ntiles, g.tpb, g.ngroup, g.gsize);
     } else {
+        if (first_state) {     // (the caller asked mse_first_batch_in_grid_kernel() before: this is the route it promised)
+            a.first_min = first_state->cur_min;
+            a.first_max = first_state->cur_max;
+            a.first_absmax = first_state->absmax;
+            a.first_grid = first_state->grid;
+        }
         const size_t shmem = (size_t)kMseTile * 4 + (size_t)kMseBlock * ((pmax_all + 1) | 1) * sizeof(float);
         if (shmem > 64 * 1024) {
             // per device, cheap: a process may drive several GPUs (fp8q.ops._on_device)
@@ -1000,6 +1103,7 @@ int fp8q_mse_calibrate_f32(float *x, float *y, int64_t C, int64_t inner, const f
         if (int rc = make_fmt(mbits_host[m], n_bits, sign_bits, &f)) return rc;
     }
     if (C > 65535) return FP8Q_ETOOMANY;
+    bool first_in_grid = false;
     if (pre && (C != 1 || !pre->x || pre->N <= 0 || pre->N * pre->C * pre->HW != inner)) return FP8Q_EINVAL;
     if (!ws_mse || ws_mse_bytes < fp8q_mse_workspace_bytes(C, inner, n_cand, n_m) || ((uintptr_t)ws_mse & 7)) return FP8Q_EWORKSPACE;
     if (!ws_select || ws_select_bytes < fp8q_mse_select_workspace_bytes(C, n_m) || ((uintptr_t)ws_select & 3)) return FP8Q_EWORKSPACE;
@@ -1007,7 +1111,8 @@ int fp8q_mse_calibrate_f32(float *x, float *y, int64_t C, int64_t inner, const f
         // max|x| per row and the search grid of that maximum in one launch (:295-316); the table needs no clearing: the
         // first batch's entries are written, not added.  Behind a BN + activation the same launch also writes t.
         if (!s->cur_min || !s->cur_max || !s->absmax) return FP8Q_EINVAL;
-        const int rc = pre ? fp8q_affine_act_minmax_linspace_f32(pre->x, pre->residual, x, pre->N, pre->C, pre->HW, pre->alpha_beta, pre->act,
+        first_in_grid = !pre && mse_first_batch_in_grid_kernel(x, C, inner, n_cand, n_m);
+        const int rc = first_in_grid ? FP8Q_OK : pre ? fp8q_affine_act_minmax_linspace_f32(pre->x, pre->residual, x, pre->N, pre->C, pre->HW, pre->alpha_beta, pre->act,
                                                                  s->cur_min, s->cur_max, s->absmax, s->grid, n_cand, 0.1, 1.2, ws_minmax,
                                                                  ws_minmax_bytes, stream)
                            : fp8q_minmax_linspace_f32(x, C, inner, s->cur_min, s->cur_max, s->absmax, s->grid, n_cand, 0.1, 1.2, ws_minmax,
@@ -1028,7 +1133,7 @@ int fp8q_mse_calibrate_f32(float *x, float *y, int64_t C, int64_t inner, const f
     so.enabled = 1;
     int sel_done = 0;
     if (int rc = mse_grid_impl(x, C, inner, s->grid, n_cand, mbits_host, n_m, n_bits, sign_bits, s->mses, ws_mse, ws_mse_bytes, stream,
-                               first != 0, &so, &sel_done))
+                               first != 0, &so, &sel_done, first_in_grid ? s : nullptr))
         return rc;
     if (!sel_done)
         if (int rc = fp8q_mse_select_f32(s->mses, s->grid, C, n_cand, mbits_host, n_m, sign_bits, s->mbits, s->vote, s->maxval, s->xmin,

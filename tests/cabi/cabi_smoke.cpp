@@ -1,6 +1,6 @@
 // cabi_smoke.cpp -- the drop-in boundary used the way a non-Python host would use it: plain HIP runtime
 // calls for memory, plain pointers and sizes into libfp8q_hip.so (include/fp8q.h), no torch anywhere.
-// Checks K1 (by value and with a device-resident mantissa width), the float64 lane, the device-side MSE grid + winner selection, the folded-BN epilogue, the fused min/max+quantize, the folding min/max (zeroed workspace, packed ranges, workspace check), the multi-tensor call and its prepared
+// Checks K1 (by value and with a device-resident mantissa width), the float64 lane, the device-side MSE grid + winner selection, the one-call MSE calibration step (with and without the BN + activation pre-stage), the folded-BN epilogue, the fused min/max+quantize, the folding min/max (zeroed workspace, packed ranges, workspace check), the multi-tensor call and its prepared
 // plan, the storage codec and the FP-MSE grid search against the CPU
 // oracle (libfp8q_oracle.so, test infrastructure) bit for bit.  Built by tests/test_cabi_and_host.py
 // (hipcc cross-compiles it on the CPU box); run by the -m gpu test of the same file.
@@ -299,6 +299,120 @@ int main()
         }
         printf(good ? "ok   fp8q_mse_linspace_f32 + fp8q_mse_select_f32 (grid endpoints, vote, per-channel argmin)\n"
                     : "FAIL fp8q_mse_linspace_f32 / fp8q_mse_select_f32\n");
+        ok &= good;
+    }
+    // one-call MSE calibration step (fp8q_mse_calibrate_f32): per-channel rows and a per-tensor row behind a folded BN + ReLU6,
+    // against the entry points it replaces called one by one (bit for bit) -- state block and workspaces caller-owned
+    {
+        const int n_cand = 111, n_m = 2;
+        const float mb[2] = {2.0f, 3.0f};
+        int good = 1;
+        for (int variant = 0; variant < 2; ++variant) {
+            const int64_t Cc = variant == 0 ? C : 1, in_c = variant == 0 ? inner : n;
+            const int64_t N_ = 3, Cb = 100, HW = n / (N_ * Cb);               // variant 1: x as [3, 100, 147] (C * HW a multiple of 4)
+            const size_t nblk = (size_t)(5 * Cc + n_cand * Cc + n_m * n_cand * Cc + 2);
+            float *blkA, *blkB, *dt, *dyA, *dyB, *dmbA, *dmbB, *dab = nullptr;
+            void *w0, *w2, *w3;
+            size_t b0 = 0, b2 = 0;
+            const size_t b3 = fp8q_mse_calibrate_workspace_bytes(Cc, in_c, n_cand, n_m, &b0, &b2);
+            if (variant == 1) {
+                const size_t ba = fp8q_affine_act_minmax_workspace_bytes(N_, Cb, HW);
+                if (ba > b0) b0 = ba;
+            }
+            CK(hipMalloc((void **)&blkA, nblk * 4));
+            CK(hipMalloc((void **)&blkB, nblk * 4));
+            CK(hipMalloc((void **)&dt, n * 4));
+            CK(hipMalloc((void **)&dyA, n * 4));
+            CK(hipMalloc((void **)&dyB, n * 4));
+            CK(hipMalloc((void **)&dmbA, 4));
+            CK(hipMalloc((void **)&dmbB, 4));
+            CK(hipMalloc(&w0, b0 + 16));
+            CK(hipMalloc(&w2, b2));
+            CK(hipMalloc(&w3, b3));
+            CK(hipMemset(w0, 0, b0 + 16));           // zero once: the contract of the min/max workspace ...
+            CK(hipMemset(w2, 0, b2));                // ... and of the selection workspace's ticket block
+            auto state = [&](float *b, float *mbits) {
+                fp8q_mse_state s_;
+                s_.cur_min = b;
+                s_.cur_max = b + Cc;
+                s_.absmax = b + 2 * Cc;
+                s_.maxval = b + 3 * Cc;
+                s_.xmin = b + 4 * Cc;
+                s_.grid = b + 5 * Cc;
+                s_.mses = b + 5 * Cc + n_cand * Cc;
+                s_.mbits = mbits;
+                s_.vote = (int *)(b + 5 * Cc + n_cand * Cc + n_m * n_cand * Cc);
+                return s_;
+            };
+            const fp8q_mse_state sa = state(blkA, dmbA), sb = state(blkB, dmbB);
+            fp8q_affine_pre pre;
+            float hab[200];
+            if (variant == 1) {
+                for (int c = 0; c < 100; ++c) {
+                    hab[2 * c] = 0.5f + 0.01f * (float)c;
+                    hab[2 * c + 1] = 0.1f - 0.003f * (float)c;
+                }
+                CK(hipMalloc((void **)&dab, sizeof(hab)));
+                CK(hipMemcpy(dab, hab, sizeof(hab), hipMemcpyHostToDevice));
+                pre.x = dx;
+                pre.residual = nullptr;
+                pre.alpha_beta = dab;
+                pre.N = N_;
+                pre.C = Cb;
+                pre.HW = HW;
+                pre.act = 2;
+            }
+            for (int batch = 0; batch < 2; ++batch) {        // the second batch accumulates into the same tables
+                // A: one call
+                CK(fp8q_mse_calibrate_f32(variant == 1 ? dt : dx, dyA, Cc, in_c, &sa, batch == 0, n_cand, mb, n_m, 8, 1, variant == 1 ? &pre : nullptr,
+                                          w0, b0, w2, b2, w3, b3, st));
+                // B: the entry points it enqueues, one by one
+                const float *src = dx;
+                if (variant == 1) {
+                    if (batch == 0)
+                        CK(fp8q_affine_act_minmax_linspace_f32(dx, nullptr, dt, N_, Cb, HW, dab, 2, sb.cur_min, sb.cur_max, sb.absmax, sb.grid, n_cand, 0.1,
+                                                               1.2, w0, b0, st));
+                    else
+                        CK(fp8q_affine_act_f32(dx, nullptr, dt, N_, Cb, HW, dab, 2, st));
+                    src = dt;
+                } else if (batch == 0) {
+                    CK(fp8q_minmax_linspace_f32(dx, Cc, in_c, sb.cur_min, sb.cur_max, sb.absmax, sb.grid, n_cand, 0.1, 1.2, w0, b0, st));
+                }
+                if (batch == 0) CK(hipMemsetAsync(sb.mses, 0, sizeof(float) * n_m * n_cand * Cc, st));
+                CK(fp8q_mse_grid_f32(src, Cc, in_c, sb.grid, n_cand, mb, n_m, 8, 1, sb.mses, w3, b3, st));
+                CK(fp8q_mse_select_f32(sb.mses, sb.grid, Cc, n_cand, mb, n_m, 1, sb.mbits, sb.vote, sb.maxval, sb.xmin, w2, b2, st));
+                CK(fp8q_quantize_dm_f32(src, dyB, Cc, in_c, sb.maxval, Cc, sb.mbits, 8, 1, st));
+                CK(hipStreamSynchronize(st));
+                float *ha = (float *)malloc(nblk * 4), *hb = (float *)malloc(nblk * 4);
+                CK(hipMemcpy(ha, blkA, nblk * 4, hipMemcpyDeviceToHost));
+                CK(hipMemcpy(hb, blkB, nblk * 4, hipMemcpyDeviceToHost));
+                good &= memcmp(ha, hb, (nblk - 2) * 4) == 0 && memcmp(ha + nblk - 2, hb + nblk - 2, 4) == 0;   // tables, ranges, vote
+                float ma, mbv;
+                CK(hipMemcpy(&ma, dmbA, 4, hipMemcpyDeviceToHost));
+                CK(hipMemcpy(&mbv, dmbB, 4, hipMemcpyDeviceToHost));
+                good &= ma == mbv && (ma == 2.0f || ma == 3.0f);
+                CK(hipMemcpy(y, dyA, n * 4, hipMemcpyDeviceToHost));
+                CK(hipMemcpy(ref, dyB, n * 4, hipMemcpyDeviceToHost));
+                good &= memcmp(y, ref, n * 4) == 0;
+                if (variant == 0 && batch == 0) {            // and the table itself against the oracle (1e-5, as K4 promises)
+                    float *rm = (float *)calloc((size_t)n_m * n_cand * Cc, 4);
+                    orc_mse_grid_f32(x, Cc, in_c, ha + 5 * Cc, n_cand, mb, n_m, 8, 1, rm);
+                    const float *tab = ha + 5 * Cc + n_cand * Cc;
+                    for (int64_t i = 0; i < n_m * n_cand * Cc; ++i)
+                        if (rm[i] == rm[i] && !(tab[i] >= rm[i] * (1.0f - 1e-4f) && tab[i] <= rm[i] * (1.0f + 1e-4f))) {
+                            if (good) printf("FAIL fp8q_mse_calibrate_f32 table[%lld]: %g vs %g\n", (long long)i, tab[i], rm[i]);
+                            good = 0;
+                        }
+                    free(rm);
+                }
+                free(ha);
+                free(hb);
+            }
+            hipFree(blkA), hipFree(blkB), hipFree(dt), hipFree(dyA), hipFree(dyB), hipFree(dmbA), hipFree(dmbB), hipFree(w0), hipFree(w2), hipFree(w3);
+            if (dab) hipFree(dab);
+        }
+        printf(good ? "ok   fp8q_mse_calibrate_f32 (per-channel rows; per-tensor behind folded BN + ReLU6: two batches each == the separate entry points, bit for bit)\n"
+                    : "FAIL fp8q_mse_calibrate_f32 vs the separate entry points\n");
         ok &= good;
     }
     // the float64 lane: K1, row min/max and the candidate search on doubles, bit for bit / to 1e-13 against the oracle

@@ -158,6 +158,8 @@ def test_model_calibration_pass_is_sync_free_and_fix_ranges_syncs_at_most_twice(
     net = Net().cuda().eval()
     x = torch.randn(8, 3, 16, 16, device="cuda")
     fp8q.ops.mse_linspace(torch.ones(1, device="cuda"))       # the once-per-process self-check synchronises
+    fp8q.ops.check_workspaces()
+    fp8q.ops._ws_cache.clear()                                # (workspaces of earlier tests' streams would each get their check)
     with torch.no_grad():
         net.set_quant_state(True, True)
         net.estimate_ranges()
