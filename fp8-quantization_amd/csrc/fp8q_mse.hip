@@ -18,7 +18,6 @@ namespace {
 constexpr int kMseBlock = 128;
 constexpr int kMseTile = 2048;
 constexpr int kMseMaxM = 8;
-constexpr int kSelK = 8;              // k_mse_select's 16-slot form: candidates per slot (n_cand <= 128)
 
 struct MseArgs {
     QFmt fmt[kMseMaxM];
@@ -737,54 +736,6 @@ k_mse_select(const float *__restrict__ mses, const float *__restrict__ grid, int
 {
     __shared__ int hist[kMseMaxM];
     __shared__ int s_vote;
-    if (n_cand <= 16 * kSelK) {
-        // Phase 1, round 6: 16 channels x 16 candidate slots per workgroup.  A thread owns channel c0 + (tid & 15) and the
-        // candidates i = slot, slot + 16, ...: every load of a wave covers four 64-byte runs of the [n_m, n_cand, C] table (the
-        // wave-per-channel form read 4 bytes of each 64), and all n_m * ceil(n_cand / 16) loads of a thread are independent
-        // -- one memory round trip instead of n_m dependent ones.  Then the 16 slots of a channel meet in LDS.
-        // (MobileNetV2's weights with the 6-width search: 14.3 -> see profiles/r06_c4_search_kernels.txt)
-        __shared__ float s_v[kMseMaxM][16][17];
-        __shared__ int s_i[kMseMaxM][16][17];
-        const int ch = threadIdx.x & 15, slot = threadIdx.x >> 4;
-        const int64_t c = (int64_t)blockIdx.x * 16 + ch;
-        float v[kMseMaxM][kSelK];
-#pragma unroll
-        for (int m = 0; m < kMseMaxM; ++m)
-#pragma unroll
-            for (int k = 0; k < kSelK; ++k) {
-                const int i = slot + 16 * k;
-                v[m][k] = (m < n_m && i < n_cand && c < C) ? mses[((int64_t)m * n_cand + i) * C + c] : __builtin_inff();
-            }
-#pragma unroll
-        for (int m = 0; m < kMseMaxM; ++m) {
-            ArgMin am = {__builtin_inff(), 0x7fffffff};
-#pragma unroll
-            for (int k = 0; k < kSelK; ++k) {
-                const int i = slot + 16 * k;
-                const ArgMin o = {v[m][k], i};
-                if (i < n_cand && argmin_less(o, am)) am = o;
-            }
-            if (m < n_m) {
-                s_v[m][ch][slot] = am.v;
-                s_i[m][ch][slot] = am.idx;
-            }
-        }
-        __syncthreads();
-        if (slot == 0 && c < C) {
-            ArgMin best_m = {__builtin_inff(), 0x7fffffff};
-            for (int m = 0; m < n_m; ++m) {
-                ArgMin am = {s_v[m][ch][0], s_i[m][ch][0]};
-                for (int q = 1; q < 16; ++q) {
-                    const ArgMin o = {s_v[m][ch][q], s_i[m][ch][q]};
-                    if (argmin_less(o, am)) am = o;
-                }
-                agent_store(&sel[c * (1 + n_m) + 1 + m], am.idx);
-                const ArgMin o = {am.v, m};
-                if (argmin_less(o, best_m)) best_m = o;
-            }
-            agent_store(&sel[c * (1 + n_m)], best_m.idx);
-        }
-    } else {
     const int lane = threadIdx.x & 63;
     const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c < C) {
@@ -802,9 +753,10 @@ k_mse_select(const float *__restrict__ mses, const float *__restrict__ grid, int
         }
         if (lane == 0) agent_store(&sel[c * (1 + n_m)], best_m.idx);
     }
-    // (round 5: lane = channel with the WAVES splitting the candidates turned 2 loads per lane into ~28 dependent trips per
-    // width: 36 us per call instead of 12.7.  The 16 x 16 form above keeps every load independent.)
-    }
+    // (Reading the table in 64-byte runs does not pay.  Round 5: lane = channel with the waves splitting the candidates: ~28
+    // dependent trips per width, 36 us per call instead of 12.7.  Round 6: 16 channels x 16 candidate slots per workgroup, all
+    // n_m * 7 loads of a thread independent, the slots combined through LDS: 12.4 us instead of 6.7 with one width, 20.5
+    // instead of 14.3 with six (profiles/r06_select_fence_ab.txt).  Measured, dropped: a wave per channel it stays.)
     // (no fences: sel travels through agent-scope stores / loads, fp8q_select.h)
     if (!last_workgroup(ticket, gridDim.x, blockIdx.x)) return;
     if (threadIdx.x < kMseMaxM) hist[threadIdx.x] = 0;
@@ -892,7 +844,7 @@ int fp8q_mse_select_f32(const float *mses, const float *grid, int64_t C, int64_t
     memset(&a, 0, sizeof(a));
     for (int m = 0; m < n_m; ++m) a.fmt[m].M = mbits_host[m];   // the candidate widths as given (the vote returns one of them)
     // ws: ticket block (kTicketBytes: zero between calls) | sel
-    hipLaunchKernelGGL(k_mse_select, dim3((unsigned)cdiv(C, n_cand <= 16 * kSelK ? 16 : 4)), dim3(kBlock), 0, (hipStream_t)stream, mses, grid, C, n_m, (int)n_cand,
+    hipLaunchKernelGGL(k_mse_select, dim3((unsigned)cdiv(C, 4)), dim3(kBlock), 0, (hipStream_t)stream, mses, grid, C, n_m, (int)n_cand,
                        (int *)((char *)ws + kTicketBytes), (unsigned *)ws, a, mbits_out, vote_out, maxval_out, xmin_out, -(float)sign_bits);
     return launch_rc();
 }
@@ -1050,8 +1002,9 @@ static int mse_grid_impl(const float *x, int64_t C, int64_t inner, const float *
         const size_t shmem = (size_t)kMseTile * 4 + (size_t)kMseBlock * ((pmax_all + 1) | 1) * sizeof(float);
         if (shmem > 64 * 1024) {
             // per device, cheap: a process may drive several GPUs (fp8q.ops._on_device)
+            // (the kernel also has a few words of static LDS -- the first-batch row range --: 160 KiB is the CU's total)
             hipError_t e = hipFuncSetAttribute((const void *)k_mse_grid, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               160 * 1024);
+                                               159 * 1024);
             if (e != hipSuccess) return (int)e;
         }
         hipLaunchKernelGGL(k_mse_grid, dim3((unsigned)a.nsplit, (unsigned)(n_m * a.cgroups), (unsigned)C),
