@@ -688,7 +688,6 @@ class MseCalibration:
         n_tab = 0 if adopt else (n_cand * C + n_m * n_cand * C)
         blk = torch.empty(5 * C + n_tab + 1, dtype=torch.float32, device=device)
         self._blk = blk
-        self.cur_min, self.cur_max, self.absmax, self.maxval, self.xmin = (blk[i * C:(i + 1) * C] for i in range(5))
         if adopt:           # tables made by the generic path (an earlier batch in another layout): keep accumulating into them
             _require(grid, "grid")
             _require(mses, "mses", like=grid)
@@ -699,17 +698,26 @@ class MseCalibration:
         else:
             self.grid = blk[5 * C:5 * C + n_cand * C].view(n_cand, C)
             self.mses = blk[5 * C + n_cand * C:5 * C + n_tab].view(n_m, n_cand, C)
-        self.vote = blk[5 * C + n_tab:].view(torch.int32)
+        self.maxval = blk[3 * C:4 * C]
         self.mbits = vote_slot(blk.device)
         self.first = not adopt
-        self._state = MseState(self.cur_min.data_ptr(), self.cur_max.data_ptr(), self.absmax.data_ptr(), self.grid.data_ptr(),
-                               self.mses.data_ptr(), self.maxval.data_ptr(), self.xmin.data_ptr(), self.mbits.data_ptr(),
-                               self.vote.data_ptr())
+        # (the other vectors of the block are views made on demand -- cur_min, cur_max, absmax, xmin, vote: a calibration pass
+        # constructs 116 of these objects, every tensor view costs the host a microsecond or two)
+        p0 = blk.data_ptr()
+        self._state = MseState(p0, p0 + 4 * C, p0 + 8 * C, self.grid.data_ptr(), self.mses.data_ptr(), p0 + 12 * C, p0 + 16 * C,
+                               self.mbits.data_ptr(), p0 + 4 * (5 * C + n_tab))
         self._sref = ctypes.byref(self._state)
         self._mb = (ctypes.c_float * n_m)(*self.mbits_list)
         self._fn = lib().fp8q_mse_calibrate_f32
         self._dev = blk.device
         self._idx = blk.device.index
+        self._n_tab = n_tab
+
+    cur_min = property(lambda self: self._blk[0:self.C])
+    cur_max = property(lambda self: self._blk[self.C:2 * self.C])
+    absmax = property(lambda self: self._blk[2 * self.C:3 * self.C])
+    xmin = property(lambda self: self._blk[4 * self.C:5 * self.C])
+    vote = property(lambda self: self._blk[5 * self.C + self._n_tab:].view(torch.int32))
 
     def _sizes(self, inner, pre_geo=None):
         import ctypes
@@ -749,7 +757,10 @@ class MseCalibration:
             xin = t
         else:
             mm, sel, mse = self._sizes(inner)
-        ws_mm = _workspace(dev, mm, zeroed=True)
+        # (short per-channel rows need no min/max workspace: fp8q_minmax_workspace_bytes says 16 -- none is created then, so a
+        # stream that only ever calibrates weights (QuantizedModel: calibrate_weights_ahead) owns no buffer that
+        # check_workspaces() would have to synchronise for)
+        ws_mm = _workspace(dev, mm, zeroed=True) if (mm > 16 or self.C == 1) else None
         ws_sel = _workspace(dev, sel, kind="select")
         ws_mse = _workspace(dev, mse)
         y = torch.empty_like(x) if quantize else None
@@ -760,7 +771,8 @@ class MseCalibration:
             torch.cuda.set_device(self._idx)
         try:
             rc = self._fn(xin.data_ptr(), y.data_ptr() if quantize else None, self.C, inner, self._sref, int(first), self.n_cand,
-                          self._mb, self.n_m, self.n_bits, self.sign_bits, pre_ref, ws_mm.data_ptr(), ws_mm.numel(), ws_sel.data_ptr(),
+                          self._mb, self.n_m, self.n_bits, self.sign_bits, pre_ref, ws_mm.data_ptr() if ws_mm is not None else None,
+                          ws_mm.numel() if ws_mm is not None else 0, ws_sel.data_ptr(),
                           ws_sel.numel(), ws_mse.data_ptr(), ws_mse.numel(),
                           _raw_stream(self._idx) if _raw_stream is not None else _stream(x))
         finally:

@@ -221,6 +221,17 @@ class QuantizationHijacker(QuantizedModule):
         the un-cached kernels).  Any in-place weight update, range change or state change invalidates."""
         import os
         from .manager import Qstates
+        ctl = self.__dict__.pop("_ahead_ctl", None)
+        if ctl is not None:
+            # estimate state inside a QuantizedModel: the weight calibrations run ahead of the forward on a side stream
+            # (quantization/model.py: calibrate_weights_ahead) -- this layer's event, then its tensor (used once, like the
+            # per-forward result it stands for), and the next layer in the queue is started
+            ahead = self.__dict__.pop("_wq_ahead", None)
+            if ahead is not None and ahead[2] == weight.data_ptr() and ahead[3] == weight._version:
+                torch.cuda.current_stream(weight.device).wait_event(ahead[1])
+                ctl.advance(1)
+                return ahead[0]
+            ctl.forget(self)           # not started yet (or the weight changed since): this layer calibrates its own
         mgr = self.weight_quantizer
         q = getattr(mgr, "quantizer", None)
         if (os.environ.get("FP8Q_CACHE_WEIGHTS", "1") == "0" or getattr(mgr, "state", None) != Qstates.fix_ranges

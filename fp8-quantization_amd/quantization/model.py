@@ -260,10 +260,101 @@ class GraphedForward:
         return self.static_out
 
 
+_SIDE_STREAMS = {}      # device index -> the stream weight calibrations run ahead on
+
+
+class _WeightsAhead:
+    """The weight calibrations of one forward, running ahead of it on a side stream: `pending` = [(layer, weight)] in module
+    order, not yet enqueued.  A few are enqueued before the forward starts, one more every time a layer picks its result up
+    -- the host alternates between the two streams instead of enqueuing all 53 weight searches (2 ms of host time) before the
+    first layer of the forward."""
+    __slots__ = ("pending", "side", "main", "dev")
+    LOOKAHEAD = 4
+
+    def __init__(self, pending, side, main, dev):
+        self.pending, self.side, self.main, self.dev = pending, side, main, dev
+
+    def advance(self, n=1):
+        if not self.pending:
+            return
+        with torch.cuda.stream(self.side):
+            while n > 0 and self.pending:
+                m, w = self.pending.pop(0)
+                n -= 1
+                wq = m.quantize_weights(w)
+                ev = torch.cuda.Event()
+                ev.record(self.side)
+                if isinstance(wq, torch.Tensor) and wq.is_cuda:
+                    wq.record_stream(self.main)        # allocated on the side stream, consumed on the forward's
+                m.__dict__["_wq_ahead"] = (wq, ev, w.data_ptr(), w._version)
+
+    def forget(self, layer):
+        """`layer` is about to calibrate its weight itself (its turn came before its place in the queue: a forward that
+        does not follow module order): it must not be calibrated a second time"""
+        self.pending = [(m, w) for m, w in self.pending if m is not layer]
+
+
+def calibrate_weights_ahead(model):
+    """Weight quantizers in estimate state do not depend on the data: their range estimation + quantization (per layer one
+    library call: fp8q_mse_calibrate_f32 / fp8q_minmax_quantize_f32; the reference runs it inside every layer's forward,
+    hijacker.py:88-98) runs AHEAD of the forward on a side stream, and each layer waits for its own event.  The small,
+    latency-bound launches of the 53 MobileNetV2 weight searches (2 ms of GPU time per batch with a fixed mantissa width,
+    4 ms with the search) then overlap the activations' chains instead of standing in line with them: HIP streams, as the
+    chip wants them.  Same kernels on the same inputs: bit-identical results; a layer the forward never reaches is never
+    calibrated (as in the reference).
+    Returns the number of layers queued (0: CPU model, nothing in estimate state, FP8Q_WEIGHTS_AHEAD=0)."""
+    import os
+
+    from .layers import QuantizationHijacker
+    layers = model.__dict__.get("_hijackers")
+    if layers is None:
+        layers = model.__dict__["_hijackers"] = [m for m in model.modules() if isinstance(m, QuantizationHijacker)]
+    for m in layers:                               # (whatever an earlier forward left behind)
+        m.__dict__.pop("_ahead_ctl", None)
+        m.__dict__.pop("_wq_ahead", None)
+    if os.environ.get("FP8Q_WEIGHTS_AHEAD", "1") == "0":
+        return 0
+    todo = []
+    dev = None
+    for m in layers:
+        if not m._qw:
+            continue
+        mgr = m.weight_quantizer
+        if not mgr._estimating():
+            continue
+        w = m.get_weight_bias()[0]
+        if not (isinstance(w, torch.Tensor) and w.is_cuda) or (w.requires_grad and torch.is_grad_enabled()):
+            continue
+        if dev is None:
+            dev = w.device
+        if w.device == dev:
+            todo.append((m, w))
+    if not todo:
+        return 0
+    main = torch.cuda.current_stream(dev)
+    side = _SIDE_STREAMS.get(dev.index)
+    if side is None:
+        side = _SIDE_STREAMS[dev.index] = torch.cuda.Stream(device=dev)
+    side.wait_stream(main)                    # whatever wrote the weights on the current stream comes first
+    ctl = _WeightsAhead(list(todo), side, main, dev)
+    for m, _ in todo:
+        m.__dict__["_ahead_ctl"] = ctl
+    ctl.advance(_WeightsAhead.LOOKAHEAD)
+    return len(todo)
+
+
 class QuantizedModel(nn.Module):
     def __init__(self, input_size=(1, 3, 224, 224)):
         super().__init__()
         self.input_size = input_size
+        self.register_forward_pre_hook(QuantizedModel._weights_ahead_hook)
+
+    @staticmethod
+    def _weights_ahead_hook(module, args):
+        # (ranges fixed -- every validation forward: one attribute test)
+        if not module.__dict__.get("_ranges_fixed", False) and args and isinstance(args[0], torch.Tensor) and args[0].is_cuda \
+                and not torch.cuda.is_current_stream_capturing():
+            calibrate_weights_ahead(module)
 
     def state_dict_with_ranges(self, *args, **kwargs):
         """state_dict() plus the calibrated FP8 ranges (see quantizer_ranges)."""
@@ -328,15 +419,21 @@ class QuantizedModel(nn.Module):
         self.apply(visit)
 
     def estimate_ranges(self):
+        self.__dict__["_ranges_fixed"] = False
         _for_managers(self, lambda m: m.estimate_ranges(), need_init=False)
 
     def estimate_ranges_train(self):
+        self.__dict__["_ranges_fixed"] = False
         _for_managers(self, lambda m: m.estimate_ranges_train(), need_init=True)
 
     def learn_ranges(self):
+        self.__dict__["_ranges_fixed"] = False
         _for_managers(self, lambda m: m.learn_ranges(), need_init=True)
 
     def fix_ranges(self):
+        self.__dict__["_ranges_fixed"] = True
+        for idx, side in _SIDE_STREAMS.items():        # ranges written by calibrate_weights_ahead(): ordered before what follows
+            torch.cuda.current_stream(idx).wait_stream(side)
         _for_managers(self, lambda m: m.fix_ranges(), need_init=True)
         materialize_mantissa_bits(self)
         # end of calibration = the one place where a host sync is free: surface what the enqueue-only min/max

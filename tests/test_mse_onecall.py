@@ -238,3 +238,109 @@ def test_pre_stage_equals_epilogue_then_one_call(shape, use_bn, use_res, act, se
         for name in ("cur_min", "cur_max", "absmax"):
             assert torch.equal(_bits(getattr(ea._cal, name)), _bits(getattr(eb._cal, name))), name
     assert float(a.quantizer.mantissa_bits) == float(b.quantizer.mantissa_bits)
+
+
+def test_weights_are_calibrated_ahead_on_a_side_stream(monkeypatch):
+    """QuantizedModel: the weight quantizers' estimate + quantize of ALL layers is enqueued on a side stream at the start of a
+    calibration forward (they do not depend on the data) and every layer waits for its own event -- same ranges, widths and
+    outputs, bit for bit, as with each layer calibrating its weight inside its own forward (FP8Q_WEIGHTS_AHEAD=0); nothing of
+    it happens once the ranges are fixed."""
+    import os
+    import fp8q
+    from quantization import model as qmodel
+    from quantization.autoquant_utils import quantize_model
+    from quantization.base_quantized_model import QuantizedModel
+    from quantization.quantization_manager import QMethods, QuantizationManager
+    from quantization.range_estimators import RangeEstimators
+    from torch import nn
+
+    def build(w_est, a_est, search):
+        class Net(QuantizedModel):
+            def __init__(self):
+                super().__init__((1, 3, 16, 16))
+                torch.manual_seed(4)
+                seq = nn.Sequential(nn.Conv2d(3, 8, 3, padding=1, bias=False), nn.BatchNorm2d(8), nn.ReLU6(),
+                                    nn.Conv2d(8, 8, 3, padding=1, groups=8, bias=False), nn.BatchNorm2d(8), nn.ReLU6(),
+                                    nn.ConvTranspose2d(8, 6, 2, bias=False), nn.ReLU(), nn.Conv2d(6, 16, 1, bias=False), nn.BatchNorm2d(16))
+                self.features = quantize_model(seq, method=QMethods.fp_quantizer.cls, n_bits=8, per_channel_weights=True,
+                                               weight_range_method=RangeEstimators[w_est].cls, act_range_method=RangeEstimators[a_est].cls,
+                                               fp8_kwargs=dict(mantissa_bits=3, set_maxval=True, mse_include_mantissa_bits=search))
+
+            def forward(self, x):
+                return self.features(x)
+        return Net().cuda().eval()
+
+    x1, x2 = torch.randn(8, 3, 16, 16, device="cuda"), torch.randn(8, 3, 16, 16, device="cuda") * 2
+
+    def run(net):
+        with torch.no_grad():
+            net.set_quant_state(True, True)
+            net.estimate_ranges()
+            ys = [net(x1), net(x2)]
+            net.fix_ranges()
+            ys.append(net(x1))
+        torch.cuda.synchronize()
+        state = [(m.quantizer.maxval.clone(), float(m.quantizer.mantissa_bits)) for m in net.modules() if isinstance(m, QuantizationManager)]
+        return ys, state
+
+    for w_est, a_est, search in (("MSE", "MSE", True), ("MSE", "MSE", False), ("current_minmax", "allminmax", False)):
+        calls = []
+        real = qmodel.calibrate_weights_ahead
+        monkeypatch.setattr(qmodel, "calibrate_weights_ahead", lambda m: (calls.append(real(m)), calls[-1])[1])
+        ya, sa = run(build(w_est, a_est, search))
+        assert calls == [4, 4], calls                    # two calibration forwards x 4 weight layers; none with fixed ranges
+        monkeypatch.setattr(qmodel, "calibrate_weights_ahead", real)
+        os.environ["FP8Q_WEIGHTS_AHEAD"] = "0"
+        try:
+            yb, sb = run(build(w_est, a_est, search))
+        finally:
+            os.environ.pop("FP8Q_WEIGHTS_AHEAD")
+        for a, b in zip(ya, yb):
+            assert torch.equal(_bits(a), _bits(b)), (w_est, search)
+        for (mva, ma), (mvb, mb) in zip(sa, sb):
+            assert torch.equal(_bits(mva), _bits(mvb)) and ma == mb
+
+
+def test_weights_ahead_tolerates_a_forward_that_does_not_follow_module_order():
+    """six layers registered in one order and executed in the opposite one: the layers whose turn comes before their place in the
+    side stream's queue calibrate their own weight (once!), the others pick up what ran ahead -- tables after two batches equal
+    those of the plain per-layer flow"""
+    import os
+    from quantization.autoquant_utils import quantize_model
+    from quantization.base_quantized_model import QuantizedModel
+    from quantization.quantization_manager import QMethods
+    from quantization.range_estimators import RangeEstimators
+    from torch import nn
+
+    class Net(QuantizedModel):
+        def __init__(self):
+            super().__init__((1, 4, 8, 8))
+            torch.manual_seed(9)
+            self.convs = nn.ModuleList([quantize_model(nn.Conv2d(4, 4, 1, bias=False), method=QMethods.fp_quantizer.cls, n_bits=8,
+                                                       per_channel_weights=True, weight_range_method=RangeEstimators.MSE.cls,
+                                                       act_range_method=RangeEstimators.MSE.cls,
+                                                       fp8_kwargs=dict(mantissa_bits=3, set_maxval=True, mse_include_mantissa_bits=True))
+                                        for _ in range(6)])
+
+        def forward(self, x):
+            for conv in reversed(self.convs):
+                x = conv(x)
+            return x
+
+    def run():
+        net = Net().cuda().eval()
+        with torch.no_grad():
+            net.set_quant_state(True, True)
+            net.estimate_ranges()
+            ys = [net(torch.full((2, 4, 8, 8), 0.5, device="cuda") + i) for i in range(2)]
+        torch.cuda.synchronize()
+        return ys, [c.weight_quantizer.range_estimator.mses.clone() for c in net.convs]
+
+    ya, ta = run()
+    os.environ["FP8Q_WEIGHTS_AHEAD"] = "0"
+    try:
+        yb, tb = run()
+    finally:
+        os.environ.pop("FP8Q_WEIGHTS_AHEAD")
+    assert all(torch.equal(_bits(a), _bits(b)) for a, b in zip(ya, yb))
+    assert all(torch.equal(_bits(a), _bits(b)) for a, b in zip(ta, tb))
