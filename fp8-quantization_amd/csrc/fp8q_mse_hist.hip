@@ -908,6 +908,9 @@ k_moments(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ sb, co
         // 2^csh copies of every interval's counters, interleaved (copy c of interval i at (i << csh) + c: neighbouring
         // banks), a lane uses copy lane % 2^csh: with ~100 intervals per bucket (111 candidates) two thirds of the kernel's
         // LDS cycles were conflicts of lanes adding to the same counter
+        // (round 6: up to 64 copies -- a copy per LANE when the chunk has <= 15 intervals -- changed nothing: 62.1 us and
+        // 8.59 M conflict cycles of 15.4 M with 8, 32 or 64 copies on [64,32,112,112] x 111, profiles/r06_moments_copies_ab.txt:
+        // what conflicts are the random gathers of the sub-bin table and the borders, not the adds)
         int csh = 0;
         while (csh < 3 && ((cnt + 1) << (csh + 1)) <= bcap + 1) ++csh;
         const int ncnt = (cnt + 1) << csh, cpy = tid & ((1 << csh) - 1);

@@ -92,14 +92,15 @@ def _rows(x, per_channel):
     return 1, x.numel()
 
 
-def _workspace(dev, nbytes, zeroed=False, kind=None):
+def _workspace(dev, nbytes, zeroed=False, kind=None, stream=None):
     """Per-(device, stream) scratch buffer.  zeroed=True: the min/max entry points' workspace, whose leading ticket
     counters must be zero on first use and are left zero by every call (include/fp8q.h) -- allocated zero-filled and
     never shared with the kernels that scribble over their scratch (MSE partial sums).  kind="select": the winner
     selection's buffer -- allocated zero-filled too (its header holds a ticket that every call leaves zero), but the rest
     of it is ordinary scratch, so it is neither shared with the min/max workspace nor inspected by check_workspaces()."""
-    key = (dev.index, _raw_stream(dev.index) if _raw_stream is not None else torch.cuda.current_stream(dev).cuda_stream,
-           zeroed, kind)
+    if stream is None:       # (callers that make several requests per launch pass the raw stream they already looked up)
+        stream = _raw_stream(dev.index) if _raw_stream is not None else torch.cuda.current_stream(dev).cuda_stream
+    key = (dev.index, stream, zeroed, kind)
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
         if ws is not None and zeroed:
@@ -738,6 +739,7 @@ class MseCalibration:
         quantization run on act(bn(x) + residual), formed inside the same call (per-tensor quantizers only)."""
         inner = x.numel() // self.C
         dev = self._dev
+        st = _raw_stream(self._idx) if _raw_stream is not None else torch.cuda.current_stream(dev).cuda_stream
         pre_ref, keep = None, None
         xin = x
         if pre is not None:
@@ -750,7 +752,7 @@ class MseCalibration:
                                              or res.device != x.device)):
                 raise Fp8qError("MseCalibration.step: bad `pre` (per-tensor quantizer, folded [C, 2] BN vector, residual like x)")
             mm, sel, mse = self._sizes(inner, (N, C, HW))
-            t = _workspace(dev, 4 * inner, kind="pre")         # the tensor the quantizer sees: scratch, consumed by this call
+            t = _workspace(dev, 4 * inner, kind="pre", stream=st)   # the tensor the quantizer sees: scratch, consumed by this call
             keep = AffinePre(x.data_ptr(), res.data_ptr() if res is not None else None, ab.data_ptr() if ab is not None else None,
                              N, C, HW, int(act))
             pre_ref = ctypes.byref(keep)
@@ -760,9 +762,9 @@ class MseCalibration:
         # (short per-channel rows need no min/max workspace: fp8q_minmax_workspace_bytes says 16 -- none is created then, so a
         # stream that only ever calibrates weights (QuantizedModel: calibrate_weights_ahead) owns no buffer that
         # check_workspaces() would have to synchronise for)
-        ws_mm = _workspace(dev, mm, zeroed=True) if (mm > 16 or self.C == 1) else None
-        ws_sel = _workspace(dev, sel, kind="select")
-        ws_mse = _workspace(dev, mse)
+        ws_mm = _workspace(dev, mm, zeroed=True, stream=st) if (mm > 16 or self.C == 1) else None
+        ws_sel = _workspace(dev, sel, kind="select", stream=st)
+        ws_mse = _workspace(dev, mse, stream=st)
         y = torch.empty_like(x) if quantize else None
         first, self.first = self.first, False
         other = torch.cuda.current_device() != self._idx
@@ -773,8 +775,7 @@ class MseCalibration:
             rc = self._fn(xin.data_ptr(), y.data_ptr() if quantize else None, self.C, inner, self._sref, int(first), self.n_cand,
                           self._mb, self.n_m, self.n_bits, self.sign_bits, pre_ref, ws_mm.data_ptr() if ws_mm is not None else None,
                           ws_mm.numel() if ws_mm is not None else 0, ws_sel.data_ptr(),
-                          ws_sel.numel(), ws_mse.data_ptr(), ws_mse.numel(),
-                          _raw_stream(self._idx) if _raw_stream is not None else _stream(x))
+                          ws_sel.numel(), ws_mse.data_ptr(), ws_mse.numel(), st)
         finally:
             if other:
                 torch.cuda.set_device(prev)

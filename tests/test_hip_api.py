@@ -533,3 +533,20 @@ def test_fixed_range_weight_cache_is_invalidated_correctly(golden_dir):
         lin.weight_quantizer.quantizer.maxval = lin.weight_quantizer.quantizer.maxval * 2   # new range tensor
         w4, _ = lin.get_params()
         assert w4 is not w3 and torch.equal(w4, lin.weight_quantizer(lin.weight))
+
+
+@pytest.mark.parametrize("per_channel", [True, False])
+def test_percentile_estimator_close_to_the_references_numpy_percentile(per_channel):
+    """CurrentMinMaxEstimator(percentile=p) (range_estimators.py:64-71; unreachable from the reference CLI: hijacker.py:57
+    compares a class with an enum member): the reference takes numpy's percentile of a host copy -- a float64 result, which
+    would then drag the whole quantizer into float64 --; here torch.quantile on the device, float32.  Pinned to numpy's values
+    to float32 accuracy (not to its dtype)."""
+    from quantization.range_estimators import CurrentMinMaxEstimator
+    rng = np.random.RandomState(5)
+    x = rng.randn(48, 300).astype(np.float32)
+    for p in (0.1, 1.0, 5.0):
+        est = CurrentMinMaxEstimator(percentile=p, per_channel=per_channel)
+        lo, hi = est(torch.from_numpy(x).cuda())
+        rlo, rhi = np.percentile(x, (p, 100 - p), axis=-1 if per_channel else None)
+        np.testing.assert_allclose(lo.cpu().numpy(), rlo, rtol=2e-6, atol=1e-7)
+        np.testing.assert_allclose(hi.cpu().numpy(), rhi, rtol=2e-6, atol=1e-7)

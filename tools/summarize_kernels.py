@@ -65,7 +65,9 @@ def model_trace(tag, name, trace_csv, log, title, n_fwd=20):
             d[0] += 1
             d[1] += dur[i]
     cb = entry.get("calibration_batch") or entry.get("calibration_batch_fixed_mantissa") or entry.get("calibration_batch_mantissa_search_6") or {}
-    out.append(f"# CALIBRATION (the batch TWICE -- bench.py times a first and a steady-state pass -- + fix_ranges; this library's kernels before the validation forwards): "
+    out.append(f"# CALIBRATION (the batch FIVE times -- bench.py runs a first pass, a steady-state pass under its event timer and three plain ones for the wall time -- "
+               f"+ fix_ranges; this library's kernels before the validation forwards.  Round 6: the weight quantizers' launches (k_mse_grid, k_mse_select, "
+               f"k_quant_short_rows_dm, k_rows_*) run on a side stream NEXT TO the activations' chains, so durations here overlap and do not add up to the pass): "
                f"{sum(v[0] for v in cal.values())} launches, {sum(v[1] for v in cal.values()) / 1e3:.1f} us"
                + (f"; ONE steady-state pass by HIP events: {cb.get('library_us')} us in {cb.get('launches')} calls, wall {cb.get('wall_ms')} ms"
                   f" (host-side estimator logic and the convolutions included; first pass: {(cb.get('first_pass') or {}).get('wall_ms')} ms)" if cb else ""))
