@@ -958,34 +958,13 @@ k_moments(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ sb, co
 // exact in double-double; the scaling is by powers of two >= 2^-298 on numbers >= 1 (no underflow in either part).
 // One workgroup per superblock of 1024 intervals: exclusive prefix WITHIN the superblock + the superblock's totals;
 // k_iv_scan_top turns the totals into exclusive prefixes; prefix_at() adds the two levels (fixed association: deterministic).
-// AGENT: the results are written with agent-scope stores (for readers in the SAME launch: the dropped scan + evaluation fusion, see mse_eval_body)
-template <bool AGENT>
-__device__ __forceinline__ void put_dd(DD *p, DD v)
+__global__ void __launch_bounds__(kSuper)
+k_iv_scan_super(const uint32_t *__restrict__ boff, const uint32_t *__restrict__ g_n, const unsigned long long *__restrict__ g_d,
+                const unsigned long long *__restrict__ g_d2lo, const unsigned long long *__restrict__ g_d2hi, int64_t ni,
+                DD *__restrict__ p1, DD *__restrict__ p2, uint32_t *__restrict__ pn, DD *__restrict__ t1, DD *__restrict__ t2,
+                uint32_t *__restrict__ tn)
 {
-    if (AGENT) {
-        agent_store(&p->hi, v.hi);
-        agent_store(&p->lo, v.lo);
-    } else {
-        *p = v;
-    }
-}
-
-template <bool AGENT>
-__device__ __forceinline__ DD get_dd(const DD *p)
-{
-    if (AGENT) return DD{agent_load(&p->hi), agent_load(&p->lo)};
-    return *p;
-}
-
-template <bool AGENT>
-__device__ __forceinline__ uint32_t get_u32(const uint32_t *p) { return AGENT ? agent_load(p) : *p; }
-
-template <bool AGENT>
-__device__ __forceinline__ void iv_scan_super_body(int sblk, const uint32_t *__restrict__ boff, const uint32_t *__restrict__ g_n,
-                                                   const unsigned long long *__restrict__ g_d, const unsigned long long *__restrict__ g_d2lo,
-                                                   const unsigned long long *__restrict__ g_d2hi, int64_t ni, DD *p1, DD *p2, uint32_t *pn,
-                                                   DD *t1, DD *t2, uint32_t *tn)
-{
+    const int sblk = (int)blockIdx.x;
     __shared__ DD s1[2 * (kSuper / 64)], s2[2 * (kSuper / 64)];     // wave totals, then their inclusive scan
     __shared__ uint32_t sn[2 * (kSuper / 64)];
     __shared__ uint32_t s_first[kHBuckets];       // first interval id of every bucket
@@ -1073,26 +1052,18 @@ __device__ __forceinline__ void iv_scan_super_body(int sblk, const uint32_t *__r
             en += sn[kW + wave - 1];
         }
         if (i <= ni) {                                  // exclusive, within the superblock (entry ni: everything)
-            put_dd<AGENT>(p1 + i, e1);
-            put_dd<AGENT>(p2 + i, e2);
-            if (AGENT) agent_store(pn + i, en); else pn[i] = en;
+            p1[i] = e1;
+            p2[i] = e2;
+            pn[i] = en;
         }
         if (tid == kSuper - 1) {                        // the superblock's totals
-            put_dd<AGENT>(t1 + sblk, s1[2 * kW - 1]);
-            put_dd<AGENT>(t2 + sblk, s2[2 * kW - 1]);
-            if (AGENT) agent_store(tn + sblk, sn[2 * kW - 1]); else tn[sblk] = sn[2 * kW - 1];
+            t1[sblk] = s1[2 * kW - 1];
+            t2[sblk] = s2[2 * kW - 1];
+            tn[sblk] = sn[2 * kW - 1];
         }
     }
 }
 
-__global__ void __launch_bounds__(kSuper)
-k_iv_scan_super(const uint32_t *__restrict__ boff, const uint32_t *__restrict__ g_n, const unsigned long long *__restrict__ g_d,
-                const unsigned long long *__restrict__ g_d2lo, const unsigned long long *__restrict__ g_d2hi, int64_t ni,
-                DD *__restrict__ p1, DD *__restrict__ p2, uint32_t *__restrict__ pn, DD *__restrict__ t1, DD *__restrict__ t2,
-                uint32_t *__restrict__ tn)
-{
-    iv_scan_super_body<false>((int)blockIdx.x, boff, g_n, g_d, g_d2lo, g_d2hi, ni, p1, p2, pn, t1, t2, tn);
-}
 
 __global__ void __launch_bounds__(64)
 k_iv_scan_top(DD *__restrict__ t1, DD *__restrict__ t2, uint32_t *__restrict__ tn, int64_t nsb)
@@ -1138,48 +1109,30 @@ k_iv_scan_top(DD *__restrict__ t1, DD *__restrict__ t2, uint32_t *__restrict__ t
 
 // ---- 6. candidates --------------------------------------------------------------------------------------------------------
 // one workgroup per (mantissa width, candidate); a lane per cell (looping when a format has more than 256 cells)
-// NT threads per workgroup.  WAIT: the prefixes are being written by scan workgroups of the SAME launch (lower block indices:
-// dispatched first) -- thread 0 polls their completion counter `done` until it reaches nsb, everything they wrote is read with
-// agent-scope loads; bounded: after ~2^22 polls the entry becomes NaN instead of hanging the queue.  Round 6 measured that
-// fusion (scan + evaluation in one launch of 1024-thread workgroups) and DROPPED it: 26.7 us against 8.5 + 11.6 as two launches
-// with 111 pairs, 71.6 against 8.7 + 22.1 with 666 (profiles/r06_scan_eval_fusion_ab.txt) -- sixteen uncached agent-scope loads per
-// cell and 1024-thread workgroups for a 260-cell job cost more than the launch they save.  The shipped kernel is <kBlock, false>.
-template <int NT, bool WAIT>
-__device__ __forceinline__ void mse_eval_body(int j, int nwg, const float *__restrict__ x, const float *__restrict__ grid,
-                                              const float *__restrict__ bt, const float *__restrict__ bq, const uint32_t *__restrict__ rank,
-                                              const int *__restrict__ cflag, const uint32_t *__restrict__ maxkey, const DD *p1, const DD *p2,
-                                              const uint32_t *pn, const DD *t1, const DD *t2, const uint32_t *tn, int64_t ni, int nsb,
-                                              float *mses, const HistArgs &a, double inv_inner, const uint32_t *nunits, const SelOne &so,
-                                              const uint32_t *done)
+// Round 6 measured this kernel fused with the interval scan (scan workgroups count themselves done, 1024-thread evaluating
+// workgroups poll the counter and read the prefixes with agent-scope loads) and DROPPED it: 26.7 us against 8.5 + 11.6 as two
+// launches with 111 pairs, 71.6 against 8.7 + 22.1 with 666 (profiles/r06_scan_eval_fusion_ab.txt).
+__global__ void __launch_bounds__(kBlock)
+k_mse_eval(const float *__restrict__ x, const float *__restrict__ grid, const float *__restrict__ bt, const float *__restrict__ bq,
+           const uint32_t *__restrict__ rank, const int *__restrict__ cflag, const uint32_t *__restrict__ maxkey,
+           const DD *__restrict__ p1, const DD *__restrict__ p2, const uint32_t *__restrict__ pn, const DD *__restrict__ t1,
+           const DD *__restrict__ t2, const uint32_t *__restrict__ tn, int64_t ni, int nsb, float *mses, HistArgs a,
+           double inv_inner, const uint32_t *__restrict__ nunits, SelOne so)
 {
+    constexpr int NT = kBlock;
+    const int j = (int)blockIdx.x, nwg = (int)gridDim.x;
     __shared__ double s_red[NT];
     __shared__ float s_scale[kLutMax];
     __shared__ DD s_t1[kTopLds], s_t2[kTopLds], s_w1[NT / 64], s_w2[NT / 64];
     __shared__ uint32_t s_tn[kTopLds], s_wn[NT / 64];
-    __shared__ int s_lost;
     const int tid = threadIdx.x;
     const int m = j / a.n_cand;
     float *out = mses + j;
     // non-finite keys: the reference's mean is NaN (a NaN element) or +inf (an infinite one: (x - xq)^2 = inf)
     const uint32_t last = maxkey[0];
     const int flag = cflag[j];
-    bool is_nan = last > 0x7f800000u || flag == kFlagNaN || nunits[2];
+    const bool is_nan = last > 0x7f800000u || flag == kFlagNaN || nunits[2];
     const bool is_inf = !is_nan && last == 0x7f800000u;
-    if (WAIT && !is_nan && !is_inf && flag != kFlagBrute) {
-        if (tid == 0) {
-            int spins = 0, lost = 0;
-            while (agent_load(done) < (uint32_t)nsb) {
-                if (++spins > (1 << 22)) {
-                    lost = 1;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(2);
-            }
-            s_lost = lost;
-        }
-        __syncthreads();
-        is_nan = s_lost != 0;
-    }
     if (is_nan || is_inf) {
         if (tid == 0) {
             const float v = is_nan ? __builtin_nanf("") : __builtin_inff();
@@ -1220,8 +1173,8 @@ __device__ __forceinline__ void mse_eval_body(int j, int nwg, const float *__res
             uint32_t carryn = 0u;
             for (int base = 0; base < nsb; base += NT) {               // (one trip for up to NT superblocks)
                 const int i = base + tid;
-                DD v1 = i < nsb ? get_dd<WAIT>(t1 + i) : zero, v2 = i < nsb ? get_dd<WAIT>(t2 + i) : zero;
-                uint32_t vn = i < nsb ? get_u32<WAIT>(tn + i) : 0u;
+                DD v1 = i < nsb ? t1[i] : zero, v2 = i < nsb ? t2[i] : zero;
+                uint32_t vn = i < nsb ? tn[i] : 0u;
                 DD i1 = v1, i2 = v2;
                 uint32_t in = vn;
 #pragma unroll
@@ -1278,10 +1231,10 @@ __device__ __forceinline__ void mse_eval_body(int j, int nwg, const float *__res
             if (!(lo < hi)) continue;
             const int64_t i0 = c ? (int64_t)R[c] : 0, i1 = hi < __builtin_inff() ? (int64_t)R[c + 1] : ni;   // (T = +inf: not a border)
             const int64_t b0 = i0 / kSuper, b1 = i1 / kSuper;
-            const uint32_t cnt = (qn[b1] + get_u32<WAIT>(pn + i1)) - (qn[b0] + get_u32<WAIT>(pn + i0));
+            const uint32_t cnt = (qn[b1] + pn[i1]) - (qn[b0] + pn[i0]);
             if (cnt == 0u) continue;
-            const DD m1lo = dd_add(q1[b0], get_dd<WAIT>(p1 + i0)), m1hi = dd_add(q1[b1], get_dd<WAIT>(p1 + i1));
-            const DD m2lo = dd_add(q2[b0], get_dd<WAIT>(p2 + i0)), m2hi = dd_add(q2[b1], get_dd<WAIT>(p2 + i1));
+            const DD m1lo = dd_add(q1[b0], p1[i0]), m1hi = dd_add(q1[b1], p1[i1]);
+            const DD m2lo = dd_add(q2[b0], p2[i0]), m2hi = dd_add(q2[b1], p2[i1]);
             // S2 - 2 q S1 + n q^2 in double-double (q^2 of an fp32 q is exact in double); the cell's result is >= 0
             const double qd = (double)Q[c];
             const DD d2 = dd_add(m2hi, dd_neg(m2lo)), d1 = dd_add(m1hi, dd_neg(m1lo));
@@ -1304,16 +1257,6 @@ __device__ __forceinline__ void mse_eval_body(int j, int nwg, const float *__res
     if (so.enabled && last_workgroup(so.ticket, (unsigned)nwg, (unsigned)j)) select_one_row(mses, grid, a.n_m, a.n_cand, so);
 }
 
-__global__ void __launch_bounds__(kBlock)
-k_mse_eval(const float *__restrict__ x, const float *__restrict__ grid, const float *__restrict__ bt, const float *__restrict__ bq,
-           const uint32_t *__restrict__ rank, const int *__restrict__ cflag, const uint32_t *__restrict__ maxkey,
-           const DD *__restrict__ p1, const DD *__restrict__ p2, const uint32_t *__restrict__ pn, const DD *__restrict__ t1,
-           const DD *__restrict__ t2, const uint32_t *__restrict__ tn, int64_t ni, int nsb, float *mses, HistArgs a,
-           double inv_inner, const uint32_t *__restrict__ nunits, SelOne so)
-{
-    mse_eval_body<kBlock, false>((int)blockIdx.x, (int)gridDim.x, x, grid, bt, bq, rank, cflag, maxkey, p1, p2, pn, t1, t2, tn, ni, nsb, mses, a,
-                                 inv_inner, nunits, so, nullptr);
-}
 
 // ---- host -----------------------------------------------------------------------------------------------------------------
 size_t align_up(size_t v, size_t al) { return (v + al - 1) / al * al; }

@@ -300,6 +300,29 @@ def test_mse_search_channel_sharded_rank_without_channels():
     assert res[1][2].size == 0
 
 
+def _codes_fixed_job(rank, world):
+    """the bench's N > 1 headline flow: fixed ranges held by every rank, the shards travel as 1-byte codes, nothing else"""
+    from fp8q import dist as fd
+    out = []
+    for C in (16, 13, 3):            # even split, uneven split, more ranks than some ranks' channels
+        rng = np.random.RandomState(C)
+        w = torch.from_numpy((rng.randn(C, 3, 5) * 0.2).astype(np.float32))
+        mn, mx = oracle.c_minmax(w.numpy(), True)
+        mv = torch.from_numpy(oracle.c_absmax(mn, mx))
+        q, mv_out, codes = fd.quantize_weight_sharded_codes(w, 2, 8, 1, ops=OracleOps, maxval=mv)
+        assert mv_out is mv and codes.dtype == torch.uint8 and codes.shape == w.shape
+        out.append((w.numpy(), mv.numpy(), q.numpy()))
+    return out
+
+
+def test_codes_wire_with_fixed_ranges_equals_the_single_process_quantizer():
+    for world in (2, 4):
+        for res in run(_codes_fixed_job, world=world):
+            for w, mv, q in res:
+                ref = oracle.c_quantize(w, mv, 2, 8, 1)
+                assert np.array_equal(q.view(np.int32), ref.view(np.int32))
+
+
 def _bucket_weights():
     rng = np.random.RandomState(7)
     return [(rng.randn(*shp) * 0.1).astype(np.float32) for shp in ((13, 3, 3, 3), (8, 13, 1, 1), (5, 8), (1, 7), (16, 4, 3, 3))]

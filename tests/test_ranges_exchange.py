@@ -204,6 +204,9 @@ def test_rccl_runs_every_collective_of_the_path_single_rank():
         assert torch.equal(q.view(torch.int32), rq.view(torch.int32)) and torch.equal(mv, rmv)
         qc, mvc, codes = fd.quantize_weight_sharded_codes(w, 2, 8, 1)
         assert torch.equal(qc.view(torch.int32), rq.view(torch.int32)) and torch.equal(mvc, rmv) and codes.dtype == torch.uint8
+        # the bench's N > 1 headline: FIXED ranges, only the 1-byte codes travel (one uint8 all-gather on RCCL)
+        qf, mvf, cf = fd.quantize_weight_sharded_codes(w, 2, 8, 1, maxval=rmv)
+        assert torch.equal(qf.view(torch.int32), rq.view(torch.int32)) and mvf is rmv and torch.equal(cf, codes)
         for bb in (None, 1 << 16):
             for (a, b), (c, d) in zip(fd.quantize_weights_sharded_bucketed(ws, 2, 8, 1, bucket_bytes=bb), rb):
                 assert torch.equal(a.view(torch.int32), c.view(torch.int32)) and torch.equal(b, d)
