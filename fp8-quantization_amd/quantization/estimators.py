@@ -107,10 +107,12 @@ class CurrentMinMaxEstimator(RangeEstimatorBase):
         if self.percentile:
             # unreachable from the reference CLI (hijacker.py:57 compares a class with an enum
             # member); kept for API completeness through torch.quantile on the device
+            # (in float64, as numpy's percentile interpolates: with a float32 `q` the position 0.999 * (n - 1) is already off by
+            # 1e-5 of a step; the result is narrowed to float32 -- the reference keeps numpy's float64, which would drag the whole
+            # quantizer into float64)
             f = x.reshape(x.shape[0], -1) if self.per_channel else x.reshape(-1)
-            q = torch.tensor([self.percentile / 100.0, 1 - self.percentile / 100.0], device=x.device,
-                             dtype=torch.float32)
-            lo, hi = torch.quantile(f.float(), q, dim=-1)
+            q = torch.tensor([self.percentile / 100.0, 1 - self.percentile / 100.0], device=x.device, dtype=torch.float64)
+            lo, hi = torch.quantile(f.double(), q, dim=-1).float()
             self.current_xmin, self.current_xmax = lo, hi
             self.last_maxval = None
             return lo, hi

@@ -261,6 +261,7 @@ class GraphedForward:
 
 
 _SIDE_STREAMS = {}      # device index -> the stream weight calibrations run ahead on
+_AHEAD_DEPTH = [0]      # QuantizedModel forwards in progress (nesting depth)
 
 
 class _WeightsAhead:
@@ -348,13 +349,21 @@ class QuantizedModel(nn.Module):
         super().__init__()
         self.input_size = input_size
         self.register_forward_pre_hook(QuantizedModel._weights_ahead_hook)
+        self.register_forward_hook(QuantizedModel._weights_ahead_done, always_call=True)
 
     @staticmethod
     def _weights_ahead_hook(module, args):
         # (ranges fixed -- every validation forward: one attribute test)
-        if not module.__dict__.get("_ranges_fixed", False) and args and isinstance(args[0], torch.Tensor) and args[0].is_cuda \
-                and not torch.cuda.is_current_stream_capturing():
+        _AHEAD_DEPTH[0] += 1
+        if _AHEAD_DEPTH[0] == 1 and not module.__dict__.get("_ranges_fixed", False) and args and isinstance(args[0], torch.Tensor) \
+                and args[0].is_cuda and not torch.cuda.is_current_stream_capturing():
+            # (only the OUTERMOST QuantizedModel of a forward: a nested one would throw away -- and repeat -- what the outer
+            # one has already started for its layers)
             calibrate_weights_ahead(module)
+
+    @staticmethod
+    def _weights_ahead_done(module, args, output):
+        _AHEAD_DEPTH[0] = max(_AHEAD_DEPTH[0] - 1, 0)
 
     def state_dict_with_ranges(self, *args, **kwargs):
         """state_dict() plus the calibrated FP8 ranges (see quantizer_ranges)."""

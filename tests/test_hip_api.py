@@ -548,5 +548,5 @@ def test_percentile_estimator_close_to_the_references_numpy_percentile(per_chann
         est = CurrentMinMaxEstimator(percentile=p, per_channel=per_channel)
         lo, hi = est(torch.from_numpy(x).cuda())
         rlo, rhi = np.percentile(x, (p, 100 - p), axis=-1 if per_channel else None)
-        np.testing.assert_allclose(lo.cpu().numpy(), rlo, rtol=2e-6, atol=1e-7)
-        np.testing.assert_allclose(hi.cpu().numpy(), rhi, rtol=2e-6, atol=1e-7)
+        np.testing.assert_allclose(lo.cpu().numpy(), rlo, rtol=2e-6, atol=2e-6)      # (float32 interpolation between two order statistics of O(1) values)
+        np.testing.assert_allclose(hi.cpu().numpy(), rhi, rtol=2e-6, atol=2e-6)

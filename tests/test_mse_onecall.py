@@ -344,3 +344,56 @@ def test_weights_ahead_tolerates_a_forward_that_does_not_follow_module_order():
         os.environ.pop("FP8Q_WEIGHTS_AHEAD")
     assert all(torch.equal(_bits(a), _bits(b)) for a, b in zip(ya, yb))
     assert all(torch.equal(_bits(a), _bits(b)) for a, b in zip(ta, tb))
+
+
+def test_weights_ahead_with_nested_quantized_models():
+    """a QuantizedModel inside a QuantizedModel: only the outermost forward starts the weight calibrations (a nested start would
+    discard and repeat what is already running: tables accumulated twice)"""
+    import os
+    from quantization import model as qmodel
+    from quantization.autoquant_utils import quantize_model
+    from quantization.base_quantized_model import QuantizedModel
+    from quantization.quantization_manager import QMethods
+    from quantization.range_estimators import RangeEstimators
+    from torch import nn
+
+    def qconv():
+        return quantize_model(nn.Conv2d(4, 4, 1, bias=False), method=QMethods.fp_quantizer.cls, n_bits=8, per_channel_weights=True,
+                              weight_range_method=RangeEstimators.MSE.cls, act_range_method=RangeEstimators.MSE.cls,
+                              fp8_kwargs=dict(mantissa_bits=3, set_maxval=True, mse_include_mantissa_bits=False))
+
+    class Inner(QuantizedModel):
+        def __init__(self):
+            super().__init__((1, 4, 8, 8))
+            self.c1, self.c2 = qconv(), qconv()
+
+        def forward(self, x):
+            return self.c2(self.c1(x))
+
+    class Outer(QuantizedModel):
+        def __init__(self):
+            super().__init__((1, 4, 8, 8))
+            torch.manual_seed(12)
+            self.head, self.inner, self.tail = qconv(), Inner(), qconv()
+
+        def forward(self, x):
+            return self.tail(self.inner(self.head(x)))
+
+    def run():
+        net = Outer().cuda().eval()
+        with torch.no_grad():
+            net.set_quant_state(True, True)
+            net.estimate_ranges()
+            y = net(torch.randn(2, 4, 8, 8, generator=torch.Generator().manual_seed(1)).cuda())
+        torch.cuda.synchronize()
+        assert qmodel._AHEAD_DEPTH[0] == 0
+        convs = [net.head, net.inner.c1, net.inner.c2, net.tail]
+        return y, [c.weight_quantizer.range_estimator.mses.clone() for c in convs]
+
+    ya, ta = run()
+    os.environ["FP8Q_WEIGHTS_AHEAD"] = "0"
+    try:
+        yb, tb = run()
+    finally:
+        os.environ.pop("FP8Q_WEIGHTS_AHEAD")
+    assert torch.equal(_bits(ya), _bits(yb)) and all(torch.equal(_bits(a), _bits(b)) for a, b in zip(ta, tb))
