@@ -380,7 +380,62 @@ def case_f64_search(rng):
     return x.size * n_cand
 
 
-FAMILIES = [("K1 fp32 (+ device mantissa width)", case_k1, 6), ("fused min/max + quantize", case_fused, 4),
+def case_one_call(rng):
+    """the one-call MSE calibration step (fp8q_mse_calibrate_f32, with and without the BN + activation pre-stage) over two batches
+    against the entry points it replaces called one after the other: tables, grid, range, width and output bit for bit"""
+    pc = bool(rng.randint(2))
+    pre = (not pc) and bool(rng.randint(2))
+    if pre:
+        N, C, HW = int(rng.choice([1, 3, 16])), int(rng.choice([4, 12, 96])), int(rng.choice([1, 9, 49, 196, 3136]))
+        shape, rows = (N, C, HW), 1
+    else:
+        rows = int(rng.choice([1, 3, 32, 96, 320])) if pc else 1
+        inner = int(rng.choice([1, 9, 147, 576, 2047, 2048, 4608, 70000, 300000, 1200000])) if rows <= 32 else int(rng.choice([1, 9, 147, 576, 2047]))
+        shape = (rows, inner)
+    n_bits = int(rng.choice([8, 8, 6]))
+    sb = int(rng.choice([1, 1, 0]))
+    hi = n_bits - sb
+    widths = [float(m) for m in range(1, hi)] if rng.randint(2) else [float(rng.randint(1, hi))]
+    ab = res = None
+    act = 0
+    if pre:
+        C = shape[1]
+        ab = torch.from_numpy(np.stack([rng.uniform(0.5, 1.5, C), rng.standard_normal(C) * 0.2], 1).astype(np.float32)).cuda()
+        act = int(rng.randint(3))
+        if rng.randint(3) == 0:
+            res = True
+        if rng.randint(4) == 0:
+            ab = None
+            if res is None and act == 0:
+                act = 1
+    a = ops.MseCalibration(rows, torch.device("cuda", 0), widths, n_bits, sb)
+    g = m = None
+    n_el = 0
+    for batch in range(2):
+        x = data(rng, int(np.prod(shape[:-1])), shape[-1]).reshape(shape)
+        x = np.nan_to_num(x, nan=0.25, posinf=3.0, neginf=-3.0)
+        xd = torch.from_numpy(x).cuda()
+        rd = torch.from_numpy(data(rng, int(np.prod(shape[:-1])), shape[-1]).reshape(shape)).cuda().nan_to_num(0.5, 1.0, -1.0) if res else None
+        ya = a.step(xd, pre=(ab, rd, act) if pre else None)
+        t = ops.affine_act(xd, ab, rd, act) if pre else xd
+        if batch == 0:
+            _, _, mv0, g = ops.minmax_linspace(t, pc, 111)
+            g = g.contiguous()
+            m = torch.zeros(len(widths), 111, rows, device="cuda")
+            assert np.array_equal(bits(a.absmax.cpu().numpy()), bits(mv0.cpu().numpy())), ("one-call absmax", shape, pc, pre)
+        ops.mse_grid(t, pc, g, widths, n_bits, sb, m)
+        mb, vote, maxval, xmin = ops.mse_select(m, g, widths, sb)
+        yb = ops.quantize(t, maxval, mb if len(widths) > 1 else widths[0], n_bits, sb)
+        what = ("one-call step", shape, pc, pre, widths, n_bits, sb, act, batch)
+        assert np.array_equal(bits(a.grid.cpu().numpy()), bits(g.cpu().numpy())), what + ("grid",)
+        assert np.array_equal(bits(a.mses.cpu().numpy()), bits(m.cpu().numpy())), what + ("table",)
+        assert np.array_equal(bits(a.maxval.cpu().numpy()), bits(maxval.cpu().numpy())) and float(a.mbits.cpu()) == float(mb.cpu()), what + ("choice",)
+        assert np.array_equal(bits(ya.cpu().numpy()), bits(yb.cpu().numpy())), what + ("output",)
+        n_el += x.size
+    return n_el * 111 * len(widths)
+
+
+FAMILIES = [("one-call MSE calibration step", case_one_call, 3), ("K1 fp32 (+ device mantissa width)", case_k1, 6), ("fused min/max + quantize", case_fused, 4),
             ("storage codes", case_codes, 3), ("epilogue (bn / folded / prepared / min-max)", case_epilogue, 4),
             ("multi-tensor K1", case_multi, 1), ("K1 fp64", case_f64, 3), ("K4 interval histogram vs row kernel vs oracle", case_sorted, 1), ("ranges: min/max, folds, packed record", case_ranges, 4),
             ("K4 per-channel / short rows", case_mse_small, 3), ("search grid + selection", case_select, 2),
