@@ -560,6 +560,25 @@ def model_configs(ops, dev, only=None):
                 enq.append((t1 - t0) * 1e3)
             rec["wall_ms"] = round(sorted(walls)[1], 3)
             rec["host_enqueue_ms"] = round(sorted(enq)[1], 3)
+            # batches >= 3 of a shape: the calibration forward replayed from a HIP graph (quantization/model.py:
+            # GraphedCalibration -- the pass enqueues only, its decisions live in device state): no Python, no launches
+            try:
+                from quantization.base_quantized_model import GraphedCalibration
+                for mod in m.modules():
+                    if isinstance(mod, QuantizationManager) and mod.range_estimator is not None:
+                        mod.range_estimator.reset()
+                gc = GraphedCalibration(m)
+                for _ in range(3):
+                    gc(xc)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    gc(xc)
+                torch.cuda.synchronize()
+                rec["wall_ms_hipgraph_replay_batch4plus"] = round((time.perf_counter() - t0) / 5 * 1e3, 3)
+                del gc
+            except Exception as e:      # noqa: BLE001 -- informational entry only
+                rec["wall_ms_hipgraph_replay_batch4plus"] = {"error": repr(e)[:200]}
             rec["wall_over_library"] = round(rec["wall_ms"] * 1e3 / max(rec["library_us"], 1e-3), 2)
             t0 = time.perf_counter()
             m.fix_ranges()

@@ -309,7 +309,8 @@ def validate_quantized(a):
         enable_distributed_calibration(model)
     if a.load_type == "fp32":
         pass_data_for_range_estimation(loader=train_loader, model=model, act_quant=a.act_quant,
-                                       weight_quant=a.weight_quant, max_num_batches=a.num_est_batches)
+                                       weight_quant=a.weight_quant, max_num_batches=a.num_est_batches,
+                                       hip_graph=a.hip_graph and world == 1)      # (collectives stay out of the capture)
         model.set_quant_state(a.weight_quant, a.act_quant)
     model.fix_ranges()
     print("Model with the ranges estimated:\n{}".format(model))

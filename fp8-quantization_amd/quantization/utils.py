@@ -3,7 +3,7 @@ import torch
 
 
 def pass_data_for_range_estimation(loader, model, act_quant, weight_quant, max_num_batches=20,
-                                   cross_entropy_layer=None, inp_idx=0):
+                                   cross_entropy_layer=None, inp_idx=0, hip_graph=False):
     """Run up to `max_num_batches` batches through the model with every manager in
     estimate_ranges state.  Unlike the reference (:103) the inputs are not copied back to the
     host: that copy is unused there and costs a device sync per batch."""
@@ -13,10 +13,14 @@ def pass_data_for_range_estimation(loader, model, act_quant, weight_quant, max_n
     if cross_entropy_layer is not None:
         raise NotImplementedError("cross-entropy range estimation is not part of this build")
     device = next(model.parameters()).device
+    forward = model
+    if hip_graph and device.type == "cuda":       # batches >= 3 of a shape replay a captured calibration forward
+        from .model import GraphedCalibration
+        forward = GraphedCalibration(model)
     with torch.no_grad():
         for i, data in enumerate(loader):
             if isinstance(data, (tuple, list)):
-                model(data[inp_idx].to(device=device))
+                forward(data[inp_idx].to(device=device))
             else:
                 model(**{k: v.to(device=device) for k, v in data.items()})
             print(f"proccesed step={i}")

@@ -397,3 +397,53 @@ def test_weights_ahead_with_nested_quantized_models():
     finally:
         os.environ.pop("FP8Q_WEIGHTS_AHEAD")
     assert torch.equal(_bits(ya), _bits(yb)) and all(torch.equal(_bits(a), _bits(b)) for a, b in zip(ta, tb))
+
+
+@pytest.mark.parametrize("w_est,a_est,search", [("MSE", "MSE", True), ("MSE", "MSE", False), ("current_minmax", "allminmax", False),
+                                                ("current_minmax", "running_minmax", False)])
+def test_calibration_forward_replayed_from_a_hip_graph(w_est, a_est, search):
+    """GraphedCalibration: batches 1 and 2 eager, batch 3 captured, batches 4 .. 5 replayed -- the estimators' device state
+    (tables, ranges, widths) and every batch's output equal the eager loop's, bit for bit; then fix_ranges() and validation."""
+    from quantization.autoquant_utils import quantize_model
+    from quantization.base_quantized_model import QuantizedModel, GraphedCalibration
+    from quantization.quantization_manager import QMethods, QuantizationManager
+    from quantization.range_estimators import RangeEstimators
+    from torch import nn
+
+    class Net(QuantizedModel):
+        def __init__(self):
+            super().__init__((1, 3, 16, 16))
+            torch.manual_seed(21)
+            seq = nn.Sequential(nn.Conv2d(3, 8, 3, padding=1, bias=False), nn.BatchNorm2d(8), nn.ReLU6(),
+                                nn.Conv2d(8, 8, 3, padding=1, groups=8, bias=False), nn.BatchNorm2d(8), nn.ReLU(),
+                                nn.Conv2d(8, 12, 1, bias=False), nn.BatchNorm2d(12), nn.AdaptiveAvgPool2d(1), nn.Flatten(), nn.Linear(12, 5))
+            self.features = quantize_model(seq, method=QMethods.fp_quantizer.cls, n_bits=8, per_channel_weights=True,
+                                           weight_range_method=RangeEstimators[w_est].cls, act_range_method=RangeEstimators[a_est].cls,
+                                           fp8_kwargs=dict(mantissa_bits=3, set_maxval=True, mse_include_mantissa_bits=search))
+
+        def forward(self, x):
+            return self.features(x)
+
+    g = torch.Generator().manual_seed(3)
+    xs = [torch.randn(8, 3, 16, 16, generator=g).cuda() * (1 + 0.3 * i) for i in range(5)]
+
+    def run(graphed):
+        net = Net().cuda().eval()
+        with torch.no_grad():
+            net.set_quant_state(True, True)
+            net.estimate_ranges()
+            fwd = GraphedCalibration(net) if graphed else net
+            ys = [fwd(x).clone() for x in xs]
+            assert (not graphed) or fwd.graph is not None
+            net.fix_ranges()
+            ys.append(net(xs[0]).clone())
+        torch.cuda.synchronize()
+        st = [(m.quantizer.maxval.clone(), float(m.quantizer.mantissa_bits)) for m in net.modules() if isinstance(m, QuantizationManager)]
+        return ys, st
+
+    ya, sa = run(True)
+    yb, sb = run(False)
+    for i, (a, b) in enumerate(zip(ya, yb)):
+        assert torch.equal(_bits(a), _bits(b)), i
+    for (mva, ma), (mvb, mb) in zip(sa, sb):
+        assert torch.equal(_bits(mva), _bits(mvb)) and ma == mb
