@@ -233,9 +233,12 @@ __device__ __forceinline__ void part_hist_body(int w, uint32_t *s_hist, const ui
 // scatter: per tile a counting sort by bucket in LDS (ranks from returning LDS atomics), then position p of the sorted
 // tile goes to delta[bucket] + p: consecutive lanes write consecutive addresses within a run.  The order of the keys inside
 // a (workgroup, bucket) run depends on the LDS atomics' timing; nothing downstream depends on it (integer moments).
+// The first key of bucket b in the partitioned array (koff[b]) is the exclusive scan of the column totals `hist`: every
+// workgroup makes it for itself (2048 entries, one block scan) -- so the scatter needs nothing from the plan and runs in the
+// launch that also sorts the borders (k_sort_plan_scatter).
 template <bool UNS>
 __device__ __forceinline__ void part_scatter_body(int w, uint32_t *s_raw, const uint32_t *__restrict__ x, int64_t n, int64_t ntiles,
-                                                  int tpw, const uint32_t *__restrict__ koff, const uint32_t *__restrict__ ktab,
+                                                  int tpw, const uint32_t *__restrict__ hist, const uint32_t *__restrict__ ktab,
                                                   uint32_t *__restrict__ out)
 {
     uint32_t *s_hist = s_raw;                    // counts, then the bucket's first position in the sorted tile
@@ -245,8 +248,22 @@ __device__ __forceinline__ void part_scatter_body(int w, uint32_t *s_raw, const 
     const int tid = threadIdx.x;
     constexpr int kPer = kHBuckets / kBlock;     // 8 consecutive buckets per thread in the scan
     uint32_t cur[kPer];                          // where this workgroup's next key of buckets tid * 8 .. tid * 8 + 7 goes
+    {
+        uint32_t h[kPer], mine[kPer], sum = 0u;
 #pragma unroll
-    for (int q = 0; q < kPer; ++q) cur[q] = koff[tid * kPer + q] + ktab[(int64_t)w * kHBuckets + tid * kPer + q];
+        for (int q = 0; q < kPer; ++q) {
+            h[q] = hist[tid * kPer + q];
+            mine[q] = ktab[(int64_t)w * kHBuckets + tid * kPer + q];
+            sum += h[q];
+        }
+        uint32_t total;
+        uint32_t run = block_excl_scan<kBlock>(sum, s_w, total);
+#pragma unroll
+        for (int q = 0; q < kPer; ++q) {
+            cur[q] = run + mine[q];
+            run += h[q];
+        }
+    }
     const int64_t t0 = (int64_t)w * tpw, t1 = min(t0 + tpw, ntiles);
     for (int64_t t = t0; t < t1; ++t) {
         for (int i = tid; i < kHBuckets; i += kBlock) s_hist[i] = 0u;
@@ -831,11 +848,37 @@ k_border_sort_plan(const float *__restrict__ bt, const uint32_t *__restrict__ bt
 
 template <bool UNS>
 __global__ void __launch_bounds__(kBlock)
-k_part_scatter(const uint32_t *__restrict__ x, int64_t n, int64_t ntiles, int tpw, const uint32_t *__restrict__ koff,
+k_part_scatter(const uint32_t *__restrict__ x, int64_t n, int64_t ntiles, int tpw, const uint32_t *__restrict__ hist,
                const uint32_t *__restrict__ ktab, uint32_t *__restrict__ keys)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_raw[kPartLds / 4];
-    part_scatter_body<UNS>((int)blockIdx.x, s_raw, x, n, ntiles, tpw, koff, ktab, keys);
+    part_scatter_body<UNS>((int)blockIdx.x, s_raw, x, n, ntiles, tpw, hist, ktab, keys);
+}
+
+// Round 6: border sort, plan and key scatter in ONE launch -- all three need only the column totals of k_tab_scan, none needs
+// another's result (the scatter makes its bucket offsets itself: part_scatter_body).  Workgroup 0 plans, 1 .. 2048 sort the
+// borders of a bucket each (most have none and leave at once; they come first in the grid so that the fullest buckets -- the
+// long pole of the sort, a chain of dependent loads -- start before the scatter saturates the memory system), the rest
+// scatter.  One dependent launch fewer per call: the sort (9-29 us on MobileNetV2's activations) hides behind the scatter.
+template <bool UNS>
+__global__ void __launch_bounds__(kBlock)
+k_sort_plan_scatter(const float *__restrict__ bt, const uint32_t *__restrict__ btab, const uint32_t *__restrict__ bhist, int n_pairs,
+                    int stride, uint32_t *__restrict__ sb, uint32_t *__restrict__ rank, uint32_t *__restrict__ gtab,
+                    uint64_t *__restrict__ pairs, const uint32_t *__restrict__ hist, const uint32_t *__restrict__ kmax,
+                    const double *__restrict__ kneg, int nkmax,
+                    uint32_t *__restrict__ koff, uint32_t *__restrict__ boff, Unit *__restrict__ units, uint32_t *__restrict__ nunits,
+                    uint32_t *__restrict__ maxkey, uint32_t units_max, int bcap, int slice_min,
+                    const uint32_t *__restrict__ x, int64_t n, int64_t ntiles, int tpw, const uint32_t *__restrict__ ktab,
+                    uint32_t *__restrict__ keys)
+{
+    constexpr int kRaw = kSortRaw > kPartLds / 4 ? kSortRaw : kPartLds / 4;
+    __shared__ __attribute__((aligned(16))) uint32_t s_raw[kRaw];
+    if (blockIdx.x == 0)
+        plan_body(s_raw, hist, bhist, kmax, kneg, nkmax, koff, boff, units, nunits, maxkey, units_max, bcap, slice_min);
+    else if (blockIdx.x <= (unsigned)kHBuckets)
+        border_sort_body((int)blockIdx.x - 1, s_raw, bt, btab, bhist, n_pairs, stride, sb, rank, gtab, pairs);
+    else
+        part_scatter_body<UNS>((int)blockIdx.x - 1 - kHBuckets, s_raw, x, n, ntiles, tpw, hist, ktab, keys);
 }
 
 // ---- 4. moments of the intervals ----------------------------------------------------------------------------------------
@@ -851,9 +894,9 @@ __device__ __forceinline__ void moments_keys4(const uint32_t (&kv)[4], const uin
     bool any = false;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const uint32_t s = subbin_of(kv[q]);
-        lo[q] = (int)tab[s];
-        hi[q] = (int)tab[s + 1];
+        const uint32_t e = tab[subbin_of(kv[q])];           // {borders below the sub-bin | borders below the next one << 16}
+        lo[q] = (int)(e & 0xffffu);
+        hi[q] = (int)(e >> 16);
         any |= lo[q] < hi[q];
     }
     while (any) {                                         // borders <= key
@@ -879,7 +922,28 @@ __device__ __forceinline__ void moments_keys4(const uint32_t (&kv)[4], const uin
     }
 }
 
-__global__ void __launch_bounds__(kBlock)
+// NT threads per workgroup: the kernel is latency-bound (a key is a chain global load -> table entry -> borders -> two LDS
+// atomics; 24.6 KB of LDS per workgroup allow six of them per CU), so 512 threads put 32 waves on a CU instead of 24 and the
+// next batch of keys is loaded before the current one is searched (round 6).
+template <int NT>
+__device__ __forceinline__ void moments_load16(const uint32_t *__restrict__ kp, int kn, int r0, uint32_t (&kv)[4][4])
+{
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int i0 = r0 + v * 4 * NT + tid * 4;
+        if (i0 + 3 < kn) {
+            const u32x4u w = *reinterpret_cast<const u32x4u *>(kp + i0);
+            kv[v][0] = w.x, kv[v][1] = w.y, kv[v][2] = w.z, kv[v][3] = w.w;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) kv[v][q] = i0 + q < kn ? kp[i0 + q] : 0u;   // 0: skipped
+        }
+    }
+}
+
+template <int NT>
+__global__ void __launch_bounds__(NT)
 k_moments(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ sb, const uint32_t *__restrict__ gtab,
           const Unit *__restrict__ units, const uint32_t *__restrict__ nunits, uint32_t *__restrict__ g_n,
           unsigned long long *__restrict__ g_d, unsigned long long *__restrict__ g_d2lo, unsigned long long *__restrict__ g_d2hi,
@@ -900,45 +964,45 @@ k_moments(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ sb, co
         const int a0 = (int)chn * bcap;
         const int cnt = min(nb - a0, bcap);                       // borders of this chunk (0 when the bucket has none)
         const bool last = a0 + cnt == nb;                         // the chunk that owns the interval behind the last border
+        const uint32_t *kp = keys + un.key0;
+        const int kn = (int)un.kn;
+        uint32_t kv[4][4];
+        moments_load16<NT>(kp, kn, 0, kv);                        // (in flight while the tables are staged)
         const uint32_t prev = a0 > 0 ? sb[bo + a0 - 1] : 0u;      // keys below it belong to an earlier chunk
         const uint32_t *gt = gtab + (int64_t)un.li * (kHSub + 1);
-        for (int i = tid; i <= kHSub; i += kBlock) {
-            const int v = nb ? (int)gt[i] - a0 : 0;               // the bucket's table, relative to the chunk
-            tab[i] = (uint32_t)min(max(v, 0), cnt);
+        for (int i = tid; i < kHSub; i += NT) {                   // the bucket's table, relative to the chunk; both ends of a
+            const int v = nb ? (int)gt[i] - a0 : 0;               // sub-bin in one word: one LDS read per key (round 6; bcap < 2^16)
+            const int w = nb ? (int)gt[i + 1] - a0 : 0;
+            tab[i] = (uint32_t)min(max(v, 0), cnt) | ((uint32_t)min(max(w, 0), cnt) << 16);
         }
-        for (int i = tid; i < cnt; i += kBlock) bord[i] = sb[bo + a0 + i];
+        for (int i = tid; i < cnt; i += NT) bord[i] = sb[bo + a0 + i];
         // 2^csh copies of every interval's counters, interleaved (copy c of interval i at (i << csh) + c: neighbouring
         // banks), a lane uses copy lane % 2^csh: with ~100 intervals per bucket (111 candidates) two thirds of the kernel's
         // LDS cycles were conflicts of lanes adding to the same counter
         // (round 6: up to 64 copies -- a copy per LANE when the chunk has <= 15 intervals -- changed nothing: 62.1 us and
-        // 8.59 M conflict cycles of 15.4 M with 8, 32 or 64 copies on [64,32,112,112] x 111, profiles/r06_moments_copies_ab.txt:
-        // what conflicts are the random gathers of the sub-bin table and the borders, not the adds)
+        // 8.59 M conflict cycles of 15.4 M with 8, 32 or 64 copies on [64,32,112,112] x 111, profiles/r06_moments_copies_ab.txt;
+        // neither did one table read per key instead of two: 47.2 us against 48.4)
         int csh = 0;
         while (csh < 3 && ((cnt + 1) << (csh + 1)) <= bcap + 1) ++csh;
         const int ncnt = (cnt + 1) << csh, cpy = tid & ((1 << csh) - 1);
-        for (int i = tid; i < ncnt; i += kBlock) cntA[i] = cntB[i] = 0ull;
+        for (int i = tid; i < ncnt; i += NT) cntA[i] = cntB[i] = 0ull;
         __syncthreads();
-        const uint32_t *kp = keys + un.key0;
-        const int kn = (int)un.kn;
-        for (int r0 = 0; r0 < kn; r0 += 16 * kBlock) {
-            uint32_t kv[4][4];
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int i0 = r0 + v * 4 * kBlock + tid * 4;
-                if (i0 + 3 < kn) {
-                    const u32x4u w = *reinterpret_cast<const u32x4u *>(kp + i0);
-                    kv[v][0] = w.x, kv[v][1] = w.y, kv[v][2] = w.z, kv[v][3] = w.w;
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) kv[v][q] = i0 + q < kn ? kp[i0 + q] : 0u;   // 0: skipped
-                }
-            }
+        for (int r0 = 0; r0 < kn; r0 += 16 * NT) {
+            uint32_t nx[4][4];
+            const bool more = r0 + 16 * NT < kn;
+            if (more) moments_load16<NT>(kp, kn, r0 + 16 * NT, nx);
 #pragma unroll
             for (int v = 0; v < 4; ++v) moments_keys4(kv[v], tab, bord, cntA, cntB, prev, cnt, last, csh, cpy);
+            if (more) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) kv[v][q] = nx[v][q];
+            }
         }
         __syncthreads();
         const uint32_t gid0 = bo + b + (uint32_t)a0;
-        for (int i = tid; i <= cnt; i += kBlock) {
+        for (int i = tid; i <= cnt; i += NT) {
             unsigned long long A = 0ull, B = 0ull;
             for (int c = 0; c < (1 << csh); ++c) {
                 A += cntA[(i << csh) + c];
@@ -1413,6 +1477,8 @@ int fp8q_mse_hist_launch(const float *x, int64_t n, const float *grid, int64_t n
 
     const uint32_t *xb = reinterpret_cast<const uint32_t *>(x);
     const int64_t ntiles = cdiv(n, kPartTile);
+    // (round 6: an even split of the tiles over all 768 workgroups -- 4 or 5 tiles each instead of 628 workgroups of 5 on
+    // [64,32,112,112] -- was slower: histogram 21.8 -> 23.8 us, scatter 44.4 -> 47.9)
     const int tpw = (int)cdiv(ntiles, kPartWgs);              // tiles per partition workgroup
     const int pwgs = (int)cdiv(ntiles, tpw);                  // <= kPartWgs, none of them empty
     if (a.uns)
@@ -1425,20 +1491,38 @@ int fp8q_mse_hist_launch(const float *x, int64_t n, const float *grid, int64_t n
     hipLaunchKernelGGL(k_tab_scan, dim3(kHBuckets / 32, 2), dim3(1024), 0, st, ktab, pwgs, hist, btab, (int)n_pairs, bhist,
                        (uint4 *)at(L.zero0), (int64_t)(L.zero_bytes / 16));
     if (int rc = launch_rc()) return rc;
-    hipLaunchKernelGGL(k_border_sort_plan, dim3(kHBuckets + 1), dim3(kBlock), 0, st, bt, btab, bhist, (int)n_pairs, a.stride, sb, rank,
-                       gtab, pairs, hist, kmax, kneg, pwgs, koff, boff, units, nunits, maxkey, L.units_max, bcap, slice_min);
-    if (int rc = launch_rc()) return rc;
-    if (a.uns)
-        hipLaunchKernelGGL(k_part_scatter<true>, dim3((unsigned)pwgs), dim3(kBlock), 0, st, xb, n, ntiles, tpw, koff, ktab, keys);
-    else
-        hipLaunchKernelGGL(k_part_scatter<false>, dim3((unsigned)pwgs), dim3(kBlock), 0, st, xb, n, ntiles, tpw, koff, ktab, keys);
-    if (int rc = launch_rc()) return rc;
+    static const int merged = env_int("FP8Q_MSE_MERGE", 1, 0, 1);      // 0: sort + plan and scatter as two launches (A/B)
+    if (merged) {
+        if (a.uns)
+            hipLaunchKernelGGL(k_sort_plan_scatter<true>, dim3((unsigned)(1 + kHBuckets + pwgs)), dim3(kBlock), 0, st, bt, btab, bhist,
+                               (int)n_pairs, a.stride, sb, rank, gtab, pairs, hist, kmax, kneg, pwgs, koff, boff, units, nunits, maxkey,
+                               L.units_max, bcap, slice_min, xb, n, ntiles, tpw, ktab, keys);
+        else
+            hipLaunchKernelGGL(k_sort_plan_scatter<false>, dim3((unsigned)(1 + kHBuckets + pwgs)), dim3(kBlock), 0, st, bt, btab, bhist,
+                               (int)n_pairs, a.stride, sb, rank, gtab, pairs, hist, kmax, kneg, pwgs, koff, boff, units, nunits, maxkey,
+                               L.units_max, bcap, slice_min, xb, n, ntiles, tpw, ktab, keys);
+        if (int rc = launch_rc()) return rc;
+    } else {
+        hipLaunchKernelGGL(k_border_sort_plan, dim3(kHBuckets + 1), dim3(kBlock), 0, st, bt, btab, bhist, (int)n_pairs, a.stride, sb,
+                           rank, gtab, pairs, hist, kmax, kneg, pwgs, koff, boff, units, nunits, maxkey, L.units_max, bcap, slice_min);
+        if (int rc = launch_rc()) return rc;
+        if (a.uns)
+            hipLaunchKernelGGL(k_part_scatter<true>, dim3((unsigned)pwgs), dim3(kBlock), 0, st, xb, n, ntiles, tpw, hist, ktab, keys);
+        else
+            hipLaunchKernelGGL(k_part_scatter<false>, dim3((unsigned)pwgs), dim3(kBlock), 0, st, xb, n, ntiles, tpw, hist, ktab, keys);
+        if (int rc = launch_rc()) return rc;
+    }
     const size_t shmem = (size_t)(bcap + 1) * 16 + (size_t)bcap * 4 + (kHSub + 1) * 4;
+    static const int mom_nt = env_int("FP8Q_MSE_MOM_NT", 256, 256, 512);      // threads per k_moments workgroup (A/B)
     if (shmem > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_moments, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute(mom_nt == 512 ? (const void *)k_moments<512> : (const void *)k_moments<256>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return hip_rc(e);
     }
-    hipLaunchKernelGGL(k_moments, dim3(2048), dim3(kBlock), shmem, st, keys, sb, gtab, units, nunits, gn, gd, gd2lo, gd2hi, bcap);
+    if (mom_nt == 512)
+        hipLaunchKernelGGL(k_moments<512>, dim3(2048), dim3(512), shmem, st, keys, sb, gtab, units, nunits, gn, gd, gd2lo, gd2hi, bcap);
+    else
+        hipLaunchKernelGGL(k_moments<256>, dim3(2048), dim3(256), shmem, st, keys, sb, gtab, units, nunits, gn, gd, gd2lo, gd2hi, bcap);
     if (int rc = launch_rc()) return rc;
     SelOne so;
     memset(&so, 0, sizeof(so));
