@@ -787,6 +787,9 @@ size_t fp8q_mse_hist_workspace_bytes(int64_t n, int64_t n_pairs);
 bool fp8q_mse_hist_supported(const QFmt *fmts, int n_m, int n_bits);
 int fp8q_mse_hist_launch(const float *x, int64_t n, const float *grid, int64_t n_cand, const QFmt *fmts, int n_m, float *mses,
                          void *ws, size_t ws_bytes, hipStream_t st, int brute, int overwrite, const SelOne *sel);
+// (fp8q_quant.hip) K1 of a per-tensor quantizer with the winner selection in its prologue
+int fp8q_quantize_select_f32(const float *x, float *y, int64_t n, const float *mses, const float *grid, int n_m, int n_cand,
+                             const SelOne *so, int n_bits, int sign_bits, hipStream_t st);
 
 // FP8Q_MSE_HIST: 1 (default) = long per-tensor rows of a signed format of <= 8 bits go through the interval-histogram
 // evaluation; 0 = never (the lane-per-element kernel everywhere); 2 = same routing with every candidate evaluated element by
@@ -1084,10 +1087,20 @@ int fp8q_mse_calibrate_f32(float *x, float *y, int64_t C, int64_t inner, const f
     so.sign = -(float)sign_bits;
     for (int m = 0; m < n_m; ++m) so.M[m] = mbits_host[m];
     so.enabled = 1;
+    // per-tensor quantizer, mantissa search, the batch quantized right away: the selection rides in the prologue of that K1
+    // launch (k_quant_rows_sel) instead of behind a ticket in the launch that finishes the table
+    static const int sel_in_k1 = getenv("FP8Q_SEL_IN_K1") ? atoi(getenv("FP8Q_SEL_IN_K1")) : 1;
+    const bool late = sel_in_k1 && y && C == 1 && n_m > 1 && n_m <= kSelMaxM && (int64_t)n_m * n_cand <= 4096 &&
+                      (((uintptr_t)x ^ (uintptr_t)y) & 15) == 0 && ((uintptr_t)x & 3) == 0;
+    if (late) so.enabled = 0;
     int sel_done = 0;
     if (int rc = mse_grid_impl(x, C, inner, s->grid, n_cand, mbits_host, n_m, n_bits, sign_bits, s->mses, ws_mse, ws_mse_bytes, stream,
                                first != 0, &so, &sel_done, first_in_grid ? s : nullptr))
         return rc;
+    if (late) {
+        so.enabled = 1;
+        return fp8q_quantize_select_f32(x, y, inner, s->mses, s->grid, n_m, n_cand, &so, n_bits, sign_bits, (hipStream_t)stream);
+    }
     if (!sel_done)
         if (int rc = fp8q_mse_select_f32(s->mses, s->grid, C, n_cand, mbits_host, n_m, sign_bits, s->mbits, s->vote, s->maxval, s->xmin,
                                          ws_select, ws_select_bytes, stream))

@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "fp8q_common.h"
+#include "fp8q_select.h"
 
 namespace {
 
@@ -1345,6 +1346,93 @@ k_quant_rows_dm(const float *__restrict__ x, float *__restrict__ y, int64_t inne
     quant_rows_body<NT, U>(x, y, inner, maxval, per_channel, f);
 }
 
+// K1 of a per-tensor quantizer whose winner -- mantissa width and clipping value -- is still the MSE table of the search that ran
+// just before it (fp8q_mse_calibrate_f32 with the mantissa search): every workgroup takes the selection for itself -- a few
+// loads per thread from L2 (n_m x n_cand <= 8 x 128 entries), the reference's two-level vote (range_estimators.py:350-369 with
+// one channel) as ONE arg-min over the table in (width, candidate) order: the smallest entry, the first of equals, a NaN before
+// everything -- and workgroup 0 writes the estimator's outputs.  The kernel boundary makes the table visible: no tickets, no
+// agent-scope traffic in the launch that finishes the table (k_mse_eval with the selection appended: 20.4 us per MobileNetV2
+// activation with six widths, 12.5 without).
+struct SelIn {
+    const float *mses, *grid;
+    int n_m, n_cand;
+    SelOne so;
+};
+
+template <bool NT, int U>
+__global__ void __launch_bounds__(kBlock)
+k_quant_rows_sel(const float *__restrict__ x, float *__restrict__ y, int64_t inner, FmtSel sel, SelIn si)
+{
+    __shared__ float s_v[kBlock / 64], s_g[kBlock / 64];
+    __shared__ int s_i[kBlock / 64];
+    __shared__ float s_mv;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int total = si.n_m * si.n_cand;
+    ArgMin a = {__builtin_inff(), 0x7fffffff};
+    float ag = 0.0f;
+    for (int i0 = 0; i0 < total; i0 += 4 * kBlock) {
+        float t[4], g[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                 // (all loads of a trip before the first use)
+            const int i = i0 + q * kBlock + tid;
+            t[q] = i < total ? si.mses[i] : 0.0f;
+            g[q] = i < total ? si.grid[i % si.n_cand] : 0.0f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = i0 + q * kBlock + tid;
+            const ArgMin o = {t[q], i};
+            if (i < total && argmin_less(o, a)) {
+                a = o;
+                ag = g[q];
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        ArgMin o;
+        o.v = __shfl_xor(a.v, off, 64);
+        o.idx = __shfl_xor(a.idx, off, 64);
+        const float og = __shfl_xor(ag, off, 64);
+        if (argmin_less(o, a)) {
+            a = o;
+            ag = og;
+        }
+    }
+    if (lane == 0) {
+        s_v[wave] = a.v;
+        s_i[wave] = a.idx;
+        s_g[wave] = ag;
+    }
+    __syncthreads();
+    a = ArgMin{s_v[0], s_i[0]};
+    ag = s_g[0];
+#pragma unroll
+    for (int w = 1; w < kBlock / 64; ++w) {
+        const ArgMin o = {s_v[w], s_i[w]};
+        if (argmin_less(o, a)) {
+            a = o;
+            ag = s_g[w];
+        }
+    }
+    const int vote = a.idx / si.n_cand;
+    const float mb = si.so.M[vote];
+    if (tid == 0) {
+        s_mv = ag;
+        if (blockIdx.x == 0 && blockIdx.y == 0) {
+            si.so.mbits_out[0] = mb;
+            if (si.so.vote_out) si.so.vote_out[0] = vote;
+            si.so.maxval_out[0] = ag;
+            if (si.so.xmin_out) si.so.xmin_out[0] = si.so.sign * ag;      // sign_bits * -1.0 * maxval (:369)
+        }
+    }
+    __syncthreads();
+    float M = rintf(mb);
+    M = fminf(fmaxf(M, 1.0f), (float)sel.hi);
+    const QFmt f = sel.tab[(int)M - 1];
+    quant_rows_body<NT, U>(x, y, inner, &s_mv, 0, f);
+}
+
 // Short per-channel rows with the width in device memory (MobileNetV2's weights in the mantissa search: [1280, 320],
 // [96, 1, 3, 3] ...): a WAVE per row -- its channel constants and {s, 1/s} table built once per wave in the wave's own slice of
 // LDS, the row streamed by its 64 lanes -- instead of a 256-thread workgroup (and a ~50-operation double-precision set-up) per
@@ -1951,6 +2039,48 @@ int fp8q_quantize_dm_f32(const float *x, float *y, int64_t C, int64_t inner, con
     }
     return FP8Q_OK;
 }
+
+}  // extern "C"
+
+// (called from fp8q_mse.hip: the last step of fp8q_mse_calibrate_f32 for a per-tensor quantizer with the mantissa search)
+// Returns FP8Q_EUNSUPPORTED when the tensor does not take the aligned vector kernel: the caller then selects in its own launch.
+int fp8q_quantize_select_f32(const float *x, float *y, int64_t n, const float *mses, const float *grid, int n_m, int n_cand,
+                             const SelOne *so, int n_bits, int sign_bits, hipStream_t st)
+{
+    FmtSel sel;
+    sel.mbits_dev = nullptr;
+    sel.hi = n_bits - sign_bits;
+    if (sel.hi < 1 || sel.hi > 8 || n_m < 1 || n_m > kSelMaxM || n_cand < 1 || !so || !x || !y || n <= 0) return FP8Q_EINVAL;
+    for (int M = 1; M <= 8; ++M)
+        if (int rc = make_fmt((float)(M <= sel.hi ? M : sel.hi), n_bits, sign_bits, &sel.tab[M - 1])) return rc;
+    const bool aligned = (((uintptr_t)x ^ (uintptr_t)y) & 15) == 0 && ((uintptr_t)x & 3) == 0;
+    if (!aligned) return FP8Q_EUNSUPPORTED;
+    SelIn si;
+    si.mses = mses;
+    si.grid = grid;
+    si.n_m = n_m;
+    si.n_cand = n_cand;
+    si.so = *so;
+    // the geometry of fp8q_quantize_dm_f32 for one row
+    const bool nt = n * 4 >= kNtBytes;
+    const bool small = n < ((int64_t)8 << 20);
+    const int U = small ? 1 : kUnroll;
+    const int64_t pieces = n / (4 * kBlock * U) > 0 ? n / (4 * kBlock * U) : 1;
+    // (a resident grid also beyond the caches -- fp8q_quantize_dm_f32 gives every 16 KiB piece its own workgroup there --: the
+    // selection prologue is paid once per workgroup: 39.8 us with 6272 workgroups on [64,32,112,112] against 32.7 without it)
+    static const int64_t sel_cap = getenv("FP8Q_SEL_CAP") ? atoll(getenv("FP8Q_SEL_CAP")) : kTargetBlocks;
+    const int64_t cap = (!nt || pieces <= 4096) ? kTargetBlocks : sel_cap;
+    const dim3 g((unsigned)balanced_blocks(pieces, cap), 1u), b(kBlock);
+    if (nt)
+        hipLaunchKernelGGL((k_quant_rows_sel<true, kUnroll>), g, b, 0, st, x, y, n, sel, si);
+    else if (small)
+        hipLaunchKernelGGL((k_quant_rows_sel<false, 1>), g, b, 0, st, x, y, n, sel, si);
+    else
+        hipLaunchKernelGGL((k_quant_rows_sel<false, kUnroll>), g, b, 0, st, x, y, n, sel, si);
+    return launch_rc();
+}
+
+extern "C" {
 
 static int minmax_nsplit(int64_t C, int64_t inner)
 {

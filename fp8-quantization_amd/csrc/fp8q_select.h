@@ -92,37 +92,53 @@ __device__ __forceinline__ bool last_workgroup(unsigned *tickets, unsigned nwg, 
 }
 
 // One workgroup (any multiple of 64 threads up to 1024): mses [n_m, n_cand] of the single row, grid [n_cand].
+// The entries of ALL widths are requested before any is used: an agent-scope load is a round trip past the caches (~2 us), and
+// a loop over the widths with one load and two barriers each made the selection 10 us of k_mse_eval with the six widths of the
+// mantissa search (21.6 us per launch on every MobileNetV2 activation; 8.3 us with one width).
 __device__ __forceinline__ void select_one_row(const float *mses, const float *grid, int n_m, int n_cand, const SelOne &so)
 {
-    __shared__ float s_v[16];
-    __shared__ int s_i[16];
+    __shared__ float s_v[kSelMaxM * 16];
+    __shared__ int s_i[kSelMaxM * 16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    ArgMin best_m = {__builtin_inff(), 0x7fffffff};
-    int best_arg = 0;
-    for (int m = 0; m < n_m; ++m) {
-        ArgMin am = {__builtin_inff(), 0x7fffffff};
-        for (int i = threadIdx.x; i < n_cand; i += blockDim.x) {
-            const ArgMin o = {agent_load(mses + (int64_t)m * n_cand + i), i};
-            if (argmin_less(o, am)) am = o;
-        }
-        am = wave_argmin(am);
-        __syncthreads();                       // (the previous width's slots are no longer read)
-        if (lane == 0) {
-            s_v[wave] = am.v;
-            s_i[wave] = am.idx;
-        }
-        __syncthreads();
-        for (int w = 0; w < nw; ++w) {
-            const ArgMin o = {s_v[w], s_i[w]};
-            if (w == 0 || argmin_less(o, am)) am = o;      // every thread: the block's argmin for this width
-        }
-        const ArgMin o = {am.v, m};
-        if (argmin_less(o, best_m)) {
-            best_m = o;
-            best_arg = am.idx;
+    ArgMin am[kSelMaxM];
+#pragma unroll
+    for (int m = 0; m < kSelMaxM; ++m) am[m] = ArgMin{__builtin_inff(), 0x7fffffff};
+    for (int i = threadIdx.x; i < n_cand; i += blockDim.x) {
+        float t[kSelMaxM];
+#pragma unroll
+        for (int m = 0; m < kSelMaxM; ++m) t[m] = m < n_m ? agent_load(mses + (int64_t)m * n_cand + i) : 0.0f;
+#pragma unroll
+        for (int m = 0; m < kSelMaxM; ++m) {
+            const ArgMin o = {t[m], i};
+            if (m < n_m && argmin_less(o, am[m])) am[m] = o;
         }
     }
+#pragma unroll
+    for (int m = 0; m < kSelMaxM; ++m) {
+        if (m < n_m) {                             // (uniform)
+            const ArgMin w = wave_argmin(am[m]);
+            if (lane == 0) {
+                s_v[m * 16 + wave] = w.v;
+                s_i[m * 16 + wave] = w.idx;
+            }
+        }
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
+        ArgMin best_m = {__builtin_inff(), 0x7fffffff};
+        int best_arg = 0;
+        for (int m = 0; m < n_m; ++m) {
+            ArgMin a = {s_v[m * 16], s_i[m * 16]};
+            for (int w = 1; w < nw; ++w) {
+                const ArgMin o = {s_v[m * 16 + w], s_i[m * 16 + w]};
+                if (argmin_less(o, a)) a = o;      // the block's argmin for this width
+            }
+            const ArgMin o = {a.v, m};
+            if (argmin_less(o, best_m)) {
+                best_m = o;
+                best_arg = a.idx;
+            }
+        }
         const int v = best_m.idx;
         so.mbits_out[0] = so.M[v];
         if (so.vote_out) so.vote_out[0] = v;
