@@ -1087,10 +1087,11 @@ int fp8q_mse_calibrate_f32(float *x, float *y, int64_t C, int64_t inner, const f
     so.sign = -(float)sign_bits;
     for (int m = 0; m < n_m; ++m) so.M[m] = mbits_host[m];
     so.enabled = 1;
-    // per-tensor quantizer, mantissa search, the batch quantized right away: the selection rides in the prologue of that K1
-    // launch (k_quant_rows_sel) instead of behind a ticket in the launch that finishes the table
-    static const int sel_in_k1 = getenv("FP8Q_SEL_IN_K1") ? atoi(getenv("FP8Q_SEL_IN_K1")) : 1;
-    const bool late = sel_in_k1 && y && C == 1 && n_m > 1 && n_m <= kSelMaxM && (int64_t)n_m * n_cand <= 4096 &&
+    // per-tensor quantizer, the batch quantized right away: the selection rides in the prologue of that K1 launch
+    // (k_quant_rows_sel) instead of behind a ticket in the launch that finishes the table (k_mse_eval 20.6 -> 11.0 us with six
+    // widths, 11.1 -> 7.7 with one, K1 + 1..2 us; FP8Q_SEL_IN_K1=0: tickets, =1: only with the mantissa search)
+    static const int sel_in_k1 = getenv("FP8Q_SEL_IN_K1") ? atoi(getenv("FP8Q_SEL_IN_K1")) : 2;
+    const bool late = sel_in_k1 && y && C == 1 && (n_m > 1 || sel_in_k1 == 2) && n_m <= kSelMaxM && (int64_t)n_m * n_cand <= 4096 &&
                       (((uintptr_t)x ^ (uintptr_t)y) & 15) == 0 && ((uintptr_t)x & 3) == 0;
     if (late) so.enabled = 0;
     int sel_done = 0;

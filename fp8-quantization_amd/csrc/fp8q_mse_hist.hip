@@ -761,6 +761,7 @@ __device__ __forceinline__ void border_sort_body(int b, uint32_t *s_raw, const f
         if (tid == 0) s_w[4] = 0u;
         __syncthreads();
         // gather (any order) + count per sub-bin: four candidates per thread and trip, their table entries loaded together
+        uint32_t gathered = 0u;
         for (int j0 = 0; j0 < n_pairs; j0 += 4 * kBlock) {
             uint32_t ent[4];
 #pragma unroll
@@ -768,25 +769,55 @@ __device__ __forceinline__ void border_sort_body(int b, uint32_t *s_raw, const f
                 const int j = j0 + q * kBlock + tid;
                 ent[q] = j < n_pairs ? btab[(int64_t)j * kHBuckets + b] : 0u;
             }
+            // where a candidate's borders go: an exclusive scan of the counts over the workgroup (a returning LDS atomic per
+            // candidate on ONE address serialised 666 lanes)
             uint32_t pos[4];
+            {
+                uint32_t mine = 0u, total;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) pos[q] = (ent[q] & 0xffffu) ? atomicAdd(&s_w[4], ent[q] & 0xffffu) : 0u;
+                for (int q = 0; q < 4; ++q) mine += ent[q] & 0xffffu;
+                uint32_t run = gathered + block_excl_scan<kBlock>(mine, s_w, total);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    pos[q] = run;
+                    run += ent[q] & 0xffffu;
+                }
+                gathered += total;
+            }
+            // a candidate's borders in this bucket (<= ~9 with 64 cells per binade): the first ten of all four candidates are
+            // requested before any is used -- ONE memory round trip per trip of the loop (one per candidate and batch of
+            // eight made the gather 7-8 us of a full bucket's ~18 with 666 pairs: instrumented, round 6)
+            constexpr uint32_t kFirst = 10u;
+            uint32_t vv[4][kFirst];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const uint32_t c = ent[q] & 0xffffu, cs = ent[q] >> 16;
                 const uint32_t j = (uint32_t)(j0 + q * kBlock + tid);
-                // a candidate's borders in this bucket (<= ~9 with 64 cells per binade): loaded eight at a time -- one memory
-                // round trip instead of one per border (the launch is a chain of dependent loads: 27 us with 666 pairs)
-                for (uint32_t i0 = 0; i0 < c; i0 += 8u) {
-                    uint32_t vv[8];
 #pragma unroll
-                    for (uint32_t u = 0; u < 8u; ++u) vv[u] = i0 + u < c ? __float_as_uint(bt[j * (uint32_t)stride + cs + i0 + u]) : 0u;
+                for (uint32_t u = 0; u < kFirst; ++u) vv[q][u] = u < c ? __float_as_uint(bt[j * (uint32_t)stride + cs + u]) : 0u;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t c = ent[q] & 0xffffu, cs = ent[q] >> 16;
+                const uint32_t j = (uint32_t)(j0 + q * kBlock + tid);
+#pragma unroll
+                for (uint32_t u = 0; u < kFirst; ++u) {
+                    if (u < c) {
+                        const uint32_t idx = j * (uint32_t)stride + cs + u;
+                        dst[pos[q] + u] = ((uint64_t)vv[q][u] << 32) | (uint64_t)idx;
+                        atomicAdd(&tab[subbin_of(vv[q][u]) + 1], 1u);
+                    }
+                }
+                for (uint32_t i0 = kFirst; i0 < c; i0 += 8u) {          // (formats with more than 64 cells per binade)
+                    uint32_t v8[8];
+#pragma unroll
+                    for (uint32_t u = 0; u < 8u; ++u) v8[u] = i0 + u < c ? __float_as_uint(bt[j * (uint32_t)stride + cs + i0 + u]) : 0u;
 #pragma unroll
                     for (uint32_t u = 0; u < 8u; ++u) {
                         if (i0 + u < c) {
                             const uint32_t idx = j * (uint32_t)stride + cs + i0 + u;
-                            dst[pos[q] + i0 + u] = ((uint64_t)vv[u] << 32) | (uint64_t)idx;
-                            atomicAdd(&tab[subbin_of(vv[u]) + 1], 1u);
+                            dst[pos[q] + i0 + u] = ((uint64_t)v8[u] << 32) | (uint64_t)idx;
+                            atomicAdd(&tab[subbin_of(v8[u]) + 1], 1u);
                         }
                     }
                 }
@@ -805,10 +836,37 @@ __device__ __forceinline__ void border_sort_body(int b, uint32_t *s_raw, const f
             for (int i = tid; i < nb; i += kBlock)            // place into the sub-bin's segment (any order inside it)
                 perm[atomicAdd(&cur[subbin_of((uint32_t)(e[i] >> 32))], 1u)] = (uint16_t)i;
             __syncthreads();
+            // rank inside the sub-bin = smaller {value, owner} pairs there.  A thread per SUB-BIN (round 6): its <= 8 members
+            // (~1.6 on average in a full bucket) are fetched with independent LDS reads -- two dependent levels in all -- and
+            // ranked in registers; a thread per border re-read its sub-bin through perm -> e for every member and waited for the
+            // fullest sub-bin of its wave in every round: 6-9 us of a full bucket's ~18 with 666 pairs (instrumented).
+            for (int sbin = tid; sbin < kHSub; sbin += kBlock) {
+                const uint32_t s0 = tab[sbin], s1 = tab[sbin + 1];
+                const uint32_t np = s1 - s0;
+                if (np == 0u) continue;
+                if (np <= 8u) {
+                    uint64_t v[8];
+#pragma unroll
+                    for (uint32_t u = 0; u < 8u; ++u) v[u] = u < np ? e[perm[s0 + u]] : ~0ull;      // (~0: never smaller)
+#pragma unroll
+                    for (uint32_t u = 0; u < 8u; ++u) {
+                        if (u < np) {
+                            uint32_t r = s0;
+#pragma unroll
+                            for (uint32_t w = 0; w < 8u; ++w) r += v[w] < v[u] ? 1u : 0u;
+                            sb[o + r] = (uint32_t)(v[u] >> 32);
+                            rank[(uint32_t)v[u]] = o + (uint32_t)b + r + 1u;
+                        }
+                    }
+                }
+            }
+            // fuller sub-bins (the six widths of one candidate share its clamp border: ~27 borders sit around the smallest
+            // candidate's): a thread per MEMBER, so that no thread ever does a sub-bin's quadratic work alone
             for (int i = tid; i < nb; i += kBlock) {
                 const uint64_t me = e[i];
-                const uint32_t s = subbin_of((uint32_t)(me >> 32));
-                const uint32_t s0 = tab[s], s1 = tab[s + 1];
+                const uint32_t sbin = subbin_of((uint32_t)(me >> 32));
+                const uint32_t s0 = tab[sbin], s1 = tab[sbin + 1];
+                if (s1 - s0 <= 8u) continue;
                 uint32_t r = s0;
                 for (uint32_t k = s0; k < s1; ++k) r += e[perm[k]] < me ? 1u : 0u;
                 sb[o + r] = (uint32_t)(me >> 32);
@@ -1513,7 +1571,13 @@ int fp8q_mse_hist_launch(const float *x, int64_t n, const float *grid, int64_t n
         if (int rc = launch_rc()) return rc;
     }
     const size_t shmem = (size_t)(bcap + 1) * 16 + (size_t)bcap * 4 + (kHSub + 1) * 4;
-    static const int mom_nt = env_int("FP8Q_MSE_MOM_NT", 256, 256, 512);      // threads per k_moments workgroup (A/B)
+    // threads per k_moments workgroup.  At 25.7 M keys the kernel is bound by the LDS atomics' throughput and 256 threads are
+    // best (48.6 us against 51.7 with 111 pairs, 88 against 107 with 666); on MobileNetV2's smaller activations a few hundred
+    // units of one or two 4096-key batches each leave most CUs with one workgroup, the unit's own latency is the launch's
+    // duration, and 512 threads halve it: 25.9 -> 17.7 us at 0.5 M elements, 42.1 -> 27.4 at 7.2 M with 666 pairs
+    // (profiles/r06_moments_nt_ab.txt).  FP8Q_MSE_MOM_NT = 256 / 512 overrides.
+    static const int mom_env = env_int("FP8Q_MSE_MOM_NT", 0, 0, 512);
+    const int mom_nt = mom_env >= 256 ? (mom_env >= 512 ? 512 : 256) : (n <= (n_pairs > 256 ? (12ll << 20) : (3ll << 20)) ? 512 : 256);
     if (shmem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(mom_nt == 512 ? (const void *)k_moments<512> : (const void *)k_moments<256>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
