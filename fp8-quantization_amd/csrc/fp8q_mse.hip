@@ -793,7 +793,7 @@ int fp8q_quantize_select_f32(const float *x, float *y, int64_t n, const float *m
 
 // FP8Q_MSE_HIST: 1 (default) = long per-tensor rows of a signed format of <= 8 bits go through the interval-histogram
 // evaluation; 0 = never (the lane-per-element kernel everywhere); 2 = same routing with every candidate evaluated element by
-// element (the self-check of the cell logic the tests use); 3 = the route for every per-tensor row of >= 2^16 elements (tuning)
+// element (the self-check of the cell logic the tests use); 3 = the route for every per-tensor row of >= 2^12 elements (tuning)
 static int mse_hist_mode()
 {
     static const int v = [] {
@@ -814,12 +814,13 @@ static int mse_hist_mode()
 static bool mse_use_hist_shape(int64_t C, int64_t inner, int64_t n_cand, int n_m)
 {
     if (mse_hist_mode() == 0 || C != 1 || inner >= (1ll << 31)) return false;
-    if (mse_hist_mode() == 3) return inner >= (1 << 16);
-    if (inner < (1 << 18) || (int64_t)n_m * n_cand > 4096) return false;   // (8 KB of border-count table per pair)
-    const double pairs = (double)(n_m * n_cand);
-    const double row = 75e-6 + (double)inner * pairs * 0.2e-12;     // (0.5 M elements x 666 pairs: 163 us measured)
-    const double hist = 60e-6 + pairs * 0.095e-6 + (double)inner * 4.3e-12;
-    return row > hist;
+    if (mse_hist_mode() == 3) return inner >= (1 << 12);
+    // Round 6, after the chain lost two launches and its sort / selection / moments their serial parts: ~48 us + 0.05 us per pair
+    // + 4.3 ps per element, below k_mse_row's own floor (~62 us) on every row it is built for -- measured down to
+    // [64, 1280] = 82 K elements (MobileNetV2's pooled features: the calibration step 78.4 -> 66.3 us with 111 pairs,
+    // 115.9 -> 93.3 with 666) and on to 16 K elements (66.8 -> 65.0 / 103.6 -> 91.0; at 4 K elements the six-width search is
+    // faster element by element: 82.3 against 90.2).  From 16 K elements every per-tensor row takes the histogram.
+    return inner >= (1 << 14) && (int64_t)n_m * n_cand <= 4096;            // (8 KB of border-count table per pair)
 }
 
 extern "C" {

@@ -42,6 +42,16 @@ for name, t in cases.items():
     out[name] = mses.cpu().numpy()
     out[name + "_grid"] = grid.cpu().numpy()
     out[name + "_x"] = t.cpu().numpy() if name in ("gauss", "relu", "pow2", "ongrid") else np.zeros(1)
+# unsigned formats, seven widths: M = 7 has 128 cells per binade = 16+ borders of one candidate in a coarse bucket (the border
+# gather's second trip), negative elements are clipped to 0
+t = torch.relu(x) - 0.01 * (torch.rand(n, device="cuda") < 0.001)
+mx = t.abs().max().reshape(1)
+grid = ops.mse_linspace(mx, 111)
+mses = torch.zeros(7, 111, 1, device="cuda")
+ops.mse_grid(t, False, grid, [1.0, 2.0, 3.0, 4.0, 5.0, 6.0, 7.0], 8, 0, mses)
+out["uns"] = mses.cpu().numpy()
+out["uns_grid"] = grid.cpu().numpy()
+out["uns_x"] = t.cpu().numpy()
 np.savez(sys.argv[1], **out)
 """ % (ROOT, os.path.join(ROOT, "fp8-quantization_amd"))
 
@@ -76,6 +86,10 @@ def test_hist_path_equals_elementwise_evaluation_and_row_kernel(tmp_path):
         # the argmin the estimator would take: identical
         if name not in ("pow2", "ongrid"):       # (there several candidates represent the data exactly: MSE ~ 0 for all of them)
             assert np.array_equal(np.nanargmin(np.where(ok, S, np.inf), axis=1), np.nanargmin(np.where(ok, R, np.inf), axis=1)), name
+    np.testing.assert_allclose(s["uns"], b["uns"], rtol=2e-6, atol=1e-24 * float(s["uns"].max()))
+    np.testing.assert_allclose(s["uns"], r["uns"], rtol=1e-5)
+    ref = oracle.c_mse_grid(s["uns_x"], False, s["uns_grid"][[0, 40, 110]], [1.0, 7.0], 8, 0)
+    np.testing.assert_allclose(s["uns"][[0, 6]][:, [0, 40, 110], :], ref, rtol=1e-5)
     assert np.isinf(s["inf"]).all() and np.isinf(r["inf"]).all() and (s["inf"] > 0).all()
     assert np.isnan(s["nan"]).all() and np.isnan(r["nan"]).all()
     # against the CPU oracle on a subset of the candidates (two passes were accumulated)
