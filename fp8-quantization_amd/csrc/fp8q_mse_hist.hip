@@ -405,14 +405,19 @@ __device__ __forceinline__ void borders_body(int j, uint32_t *s_hist, const floa
     float *s_scale = reinterpret_cast<float *>(s_hist + kHBuckets);   // s_p, p = 1 .. pmax (exact: lut_entry)
     float *s_border = s_scale + kLutMax;                               // L_p (L_1 = 0, L_(pmax+1) = +inf)
     uint32_t *s_w = reinterpret_cast<uint32_t *>(s_border + kLutMax);
+    // the log2 / exp2 tables in LDS (behind the cells' tables: s_raw of k_stage1): fetched together with the candidate in ONE
+    // round trip -- from global memory the channel constants alone were three dependent ones (table entry by table entry)
+    double *s_tab = reinterpret_cast<double *>(s_hist + kHBuckets + 2 * kLutMax + 16 + 2 * kStrideBound);
     const int tid = threadIdx.x;
+    const int m = j / a.n_cand, cand = j - m * a.n_cand;
+    const float gv = grid[cand];
+    stage_fast_tab(s_tab);
     for (int i = tid; i < kHBuckets; i += kBlock) s_hist[i] = 0u;
     uint32_t *row = btab + (int64_t)j * kHBuckets;
-    const int m = j / a.n_cand, cand = j - m * a.n_cand;
     const QFmt f = a.fmt[m];
-    const float gv = grid[cand];
     const float mv = fabsf(fmaxf(fabsf(-gv), gv));              // set_quant_range(-g, g): fp8_quantizer.py:236
-    const Chan ch = make_chan(mv, f);
+    __syncthreads();
+    const Chan ch = make_chan_fast(mv, f, s_tab);
     const int M = (int)f.M, pmax = f.pmax;
     if (!(fabsf(ch.bias) < __builtin_inff())) {                 // maxval 0 / inf / NaN: every element quantizes to NaN
         if (tid == 0) cflag[j] = kFlagNaN;
@@ -421,7 +426,7 @@ __device__ __forceinline__ void borders_body(int j, uint32_t *s_hist, const floa
     }
     const float pmaxf = (float)pmax;
     auto p_of = [&](float k) -> float {                         // K1's exact binade decision (quant_exact)
-        const float ls = floorf(log2_tab(k, kFastTab) + ch.bias);
+        const float ls = floorf(log2_tab(k, s_tab) + ch.bias);
         return __builtin_amdgcn_fmed3f(ls, 1.0f, pmaxf);
     };
     for (int p = tid + 1; p <= pmax + 1; p += kBlock) {
@@ -522,7 +527,8 @@ k_stage1(const uint32_t *__restrict__ x, int64_t n, int64_t ntiles, int tpw, uin
          double *__restrict__ kneg, const float *__restrict__ grid, HistArgs a, int brute, float *__restrict__ bt, float *__restrict__ bq,
          int *__restrict__ cflag, uint32_t *__restrict__ btab)
 {
-    __shared__ __attribute__((aligned(8))) uint32_t s_raw[kHBuckets + 2 * kLutMax + 16 + 2 * kStrideBound];
+    static_assert(((kHBuckets + 2 * kLutMax + 16 + 2 * kStrideBound) & 1) == 0, "the tables' LDS copy is 8-byte aligned");
+    __shared__ __attribute__((aligned(8))) uint32_t s_raw[kHBuckets + 2 * kLutMax + 16 + 2 * kStrideBound + 2 * kFastTabSize];
     const int n_pairs = a.n_m * a.n_cand;
     if ((int)blockIdx.x < n_pairs)
         borders_body((int)blockIdx.x, s_raw, grid, a, brute, bt, bq, cflag, btab);
