@@ -357,8 +357,9 @@ def extras(ops, dev):
         out[f"k4_mse_111cand_{len(mb)}m_64x32x112x112"] = dict(
             us=round(med * 1e6, 1), t_cand_elem_s=round(ce / med / 1e12, 3), hbm_gb_s=round(a4.numel() * 4 / med / 1e9, 1),
             algorithmic_bytes_per_element=4, route_bytes_per_element=16, frac_of_8tbs_at_16B=round(a4.numel() * 16 / med / 8e12, 3),
-            route="interval histogram: k_stage1 (borders + key histogram) -> k_tab_scan -> k_border_sort_plan -> "
-                  "k_part_scatter -> k_moments -> k_iv_scan_super/top -> k_mse_eval; per-kernel times: profiles/r05_mse_timeline.txt")
+            route="interval histogram: k_stage1 (borders + key histogram) -> k_tab_scan -> k_sort_plan_scatter (border sort + "
+                  "plan + key scatter in one launch) -> k_moments -> k_iv_scan_super/top -> k_mse_eval; per-kernel times: "
+                  "profiles/r06_mse_timeline.txt")
     del x, y
     return out
 

@@ -146,7 +146,7 @@ if mse:
                      "(E4M3), three launches of the whole chain; means per launch of each kernel",
            "traffic": "FETCH_SIZE / WRITE_SIZE are in KB; FETCH_SIZE x 1024 x 2 on gfx950 for 16-B/lane coalesced streams "
                       "(MI355X_MICROARCH.md HBM section), WRITE_SIZE x 1024.  Algorithmic bytes of the chain: 4 B/element read by the key "
-                      "histogram (k_stage1), 4 + 4 B/element by the scatter (k_part_scatter), 4 B/element read by k_moments = 16 B per "
+                      "histogram (k_stage1), 4 + 4 B/element by the scatter (k_sort_plan_scatter), 4 B/element read by k_moments = 16 B per "
                       "nonzero element, 12 on the wire when the second read of x still sits in the Infinity Cache",
            "how_to_read": "SQ_INSTS_VALU = wave-level VALU instructions per launch (x64 lanes = lane-instructions; a v_pk_* "
                           "counts once and does two elements); VALU issue utilisation = SQ_ACTIVE_INST_VALU * 4 / "
