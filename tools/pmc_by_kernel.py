@@ -2,7 +2,7 @@ import csv, sys, glob, collections
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
+        k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
     for k, d in acc.items():
         if k.startswith("k_"):
