@@ -25,10 +25,12 @@ def _plan_signature(m, q):
             bool(getattr(m, "_qw", False)))
 
 
-def materialize_mantissa_bits(model):
+def materialize_mantissa_bits(model, modules=None):
     """Bring every mantissa width that is still pending on the GPU (the MSE estimators' votes) to the host in ONE
-    device-to-host copy; afterwards every quantizer passes its width by value again (the tuned K1 routes)."""
-    pending = [(q, q._pending_mantissa_bits()) for q in model.modules() if hasattr(q, "_pending_mantissa_bits")]
+    device-to-host copy; afterwards every quantizer passes its width by value again (the tuned K1 routes).
+    `modules`: list(model.modules()) when the caller already has it (one walk of a 500-module model is ~0.4 ms)."""
+    pending = [(q, q._pending_mantissa_bits()) for q in (model.modules() if modules is None else modules)
+               if hasattr(q, "_pending_mantissa_bits")]
     pending = [(q, t) for q, t in pending if t is not None]
     if not pending:
         return 0
@@ -91,7 +93,7 @@ def load_quantizer_ranges(model, ranges, strict=True):
         m.state = q.state = Qstates[r["state"]]
 
 
-def _plan_layers(model):
+def _plan_layers(model, modules=None):
     """[(layer, weight, quantizer, maxval, swap)] of every layer a multi-tensor plan can cover: FP8 weight quantizer with
     fixed ranges on a contiguous CUDA fp32 weight that autograd is not tracking.  swap: a transposed convolution with
     per-channel ranges -- its weight is [in, out, ...] and the quantizer works on the [out, in, ...] copy
@@ -104,7 +106,7 @@ def _plan_layers(model):
     if os.environ.get("FP8Q_CACHE_WEIGHTS", "1") == "0":
         return []
     found = []
-    for m in model.modules():
+    for m in (model.modules() if modules is None else modules):
         if not isinstance(m, QuantizationHijacker) or not getattr(m, "_qw", False):
             continue
         swap = False
@@ -137,13 +139,13 @@ def _store_planned(mods, outs):
         m._wq_key = m._weight_cache_key(m.get_weight_bias()[0], q)
 
 
-def prequantize_weights(model):
+def prequantize_weights(model, modules=None):
     """With fixed ranges every layer's weight quantization is independent of the data: instead of one
     small launch per layer in its first forward (the reference: hijacker.py:88-98, every forward), all FP8
     weight tensors go through ONE multi-tensor launch (fp8q_multi_quantize_f32) and fill the layers' caches.
     Bit-identical to the per-layer path; a no-op for anything it does not cover (CPU tensors, INT
     quantizers, layers that override quantize_weights, FP8Q_CACHE_WEIGHTS=0).  Returns the number of layers."""
-    found = _plan_layers(model)
+    found = _plan_layers(model, modules)
     if not found:
         _PLANS.pop(model, None)
         return 0
@@ -481,15 +483,19 @@ class QuantizedModel(nn.Module):
         self.__dict__["_ranges_fixed"] = True
         for idx, side in _SIDE_STREAMS.items():        # ranges written by calibrate_weights_ahead(): ordered before what follows
             torch.cuda.current_stream(idx).wait_stream(side)
-        _for_managers(self, lambda m: m.fix_ranges(), need_init=True)
-        materialize_mantissa_bits(self)
+        from .manager import QuantizationManager
+        mods = list(self.modules())              # ONE walk for the three steps below (each walk of MobileNetV2: ~0.4 ms)
+        for m in mods:                           # (= _for_managers(self, fix_ranges, need_init=True); apply() visits children first,
+            if isinstance(m, QuantizationManager) and m.quantizer.is_initialized:      # the managers do not depend on the order)
+                m.fix_ranges()
+        materialize_mantissa_bits(self, mods)
         # end of calibration = the one place where a host sync is free: surface what the enqueue-only min/max
         # launches could not report (a reducer block that timed out -> NaN range; a dirty workspace)
         import fp8q
         fp8q.ops.check_workspaces()
         dev = next((p.device for p in self.parameters() if p.is_cuda), None)
         fp8q.ops.release_workspaces(device=dev)   # the MSE search's scratch (4 B per element of the largest activation): not needed again
-        self.prequantize_weights()
+        prequantize_weights(self, mods)
 
     def prequantize_weights(self):
         return prequantize_weights(self)

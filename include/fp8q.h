@@ -222,7 +222,9 @@ int fp8q_quantize_dm_f32(const float *x, float *y, int64_t C, int64_t inner, con
  *                written instead of added (the table need not be cleared beforehand)                            (:295-316)
  *   always       mses[n_m, n_cand, C] += row-mean((x - q(x; mbits[m], grid[i, c]))^2)   (fp8q_mse_grid_f32)   (:337-347)
  *                vote of the mantissa width, per-row argmin -> state.mbits / vote / maxval / xmin (fp8q_mse_select_f32) (:350-369)
- *   y != NULL    y = quantize(x; maxval, voted width)  (fp8q_quantize_f32 when n_m == 1, else fp8q_quantize_dm_f32)
+ *   y != NULL    y = quantize(x; maxval, voted width)  (fp8q_quantize_f32 when n_m == 1, else fp8q_quantize_dm_f32).  For a
+ *                per-tensor quantizer (C == 1, x and y 16-byte co-aligned) vote + argmin ride in the prologue of this K1 launch
+ *                instead of a launch of their own: same outputs in state.mbits / vote / maxval / xmin, same y.
  * Everything is enqueued on `stream`; nothing comes back to the host.  The state is caller-owned device memory
  * (any layout; the torch host allocates one block per estimator) and persists between the batches of a calibration.
  * Workspaces: ws_minmax as fp8q_minmax_f32 (zeroed, left zero; only read when first != 0), ws_select as fp8q_mse_select_f32
