@@ -842,6 +842,8 @@ __device__ __forceinline__ void border_sort_body(int b, uint32_t *s_raw, const f
             for (int i = tid; i < nb; i += kBlock)            // place into the sub-bin's segment (any order inside it)
                 perm[atomicAdd(&cur[subbin_of((uint32_t)(e[i] >> 32))], 1u)] = (uint16_t)i;
             __syncthreads();
+            if (tid == 0) cur[0] = 0u;        // (the cursors are done with: cur becomes the list of the fuller sub-bins)
+            __syncthreads();
             // rank inside the sub-bin = smaller {value, owner} pairs there.  A thread per SUB-BIN (round 6): its <= 8 members
             // (~1.6 on average in a full bucket) are fetched with independent LDS reads -- two dependent levels in all -- and
             // ranked in registers; a thread per border re-read its sub-bin through perm -> e for every member and waited for the
@@ -864,19 +866,44 @@ __device__ __forceinline__ void border_sort_body(int b, uint32_t *s_raw, const f
                             rank[(uint32_t)v[u]] = o + (uint32_t)b + r + 1u;
                         }
                     }
+                } else {
+                    cur[1u + atomicAdd(&cur[0], 1u)] = (uint32_t)sbin;      // (<= kHSub entries)
                 }
             }
-            // fuller sub-bins (the six widths of one candidate share its clamp border: ~27 borders sit around the smallest
-            // candidate's): a thread per MEMBER, so that no thread ever does a sub-bin's quadratic work alone
-            for (int i = tid; i < nb; i += kBlock) {
-                const uint64_t me = e[i];
-                const uint32_t sbin = subbin_of((uint32_t)(me >> 32));
-                const uint32_t s0 = tab[sbin], s1 = tab[sbin + 1];
-                if (s1 - s0 <= 8u) continue;
-                uint32_t r = s0;
-                for (uint32_t k = s0; k < s1; ++k) r += e[perm[k]] < me ? 1u : 0u;
-                sb[o + r] = (uint32_t)(me >> 32);
-                rank[(uint32_t)me] = o + (uint32_t)b + r + 1u;
+            __syncthreads();
+            // fuller sub-bins (the six widths of one candidate share its clamp border: up to 27 borders sit around the smallest
+            // candidate's; two or three such sub-bins per full bucket): a WAVE per sub-bin, a lane per member -- every member is
+            // broadcast in turn (shuffles), a lane counts the smaller ones: no LDS traffic beyond the members themselves.  (A
+            // thread per member walking the sub-bin through perm -> e: 4.5-6 us of a full bucket's 16; a thread alone: 108 us.)
+            {
+                const int nheavy = (int)cur[0];
+                const int lane = tid & 63;
+                for (int h = tid >> 6; h < nheavy; h += kBlock / 64) {
+                    const uint32_t sbin = cur[1 + h];
+                    const uint32_t s0 = tab[sbin], s1 = tab[sbin + 1];
+                    const uint32_t np = s1 - s0;
+                    if (np <= 64u) {
+                        const uint64_t me = (uint32_t)lane < np ? e[perm[s0 + (uint32_t)lane]] : ~0ull;
+                        const uint32_t mhi = (uint32_t)(me >> 32), mlo = (uint32_t)me;
+                        uint32_t r = s0;
+                        for (uint32_t k = 0; k < np; ++k) {
+                            const uint32_t ohi = (uint32_t)__shfl((int)mhi, (int)k, 64), olo = (uint32_t)__shfl((int)mlo, (int)k, 64);
+                            r += (ohi < mhi || (ohi == mhi && olo < mlo)) ? 1u : 0u;
+                        }
+                        if ((uint32_t)lane < np) {
+                            sb[o + r] = mhi;
+                            rank[mlo] = o + (uint32_t)b + r + 1u;
+                        }
+                    } else {
+                        for (uint32_t i = s0 + (uint32_t)lane; i < s1; i += 64u) {      // (never seen: > 64 borders in one sub-bin)
+                            const uint64_t me = e[perm[i]];
+                            uint32_t r = s0;
+                            for (uint32_t k = s0; k < s1; ++k) r += e[perm[k]] < me ? 1u : 0u;
+                            sb[o + r] = (uint32_t)(me >> 32);
+                            rank[(uint32_t)me] = o + (uint32_t)b + r + 1u;
+                        }
+                    }
+                }
             }
         } else {
             bitonic_sort(dst, nb);     // (global memory: a workgroup's own stores are visible to it after the barrier)
