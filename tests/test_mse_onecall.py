@@ -2,12 +2,15 @@
 protocol calls it replaces (estimator.forward -> set_quant_range -> quantizer.forward: quantization_manager.py:114-122 of the
 reference) -- bit for bit -- and the host-side promises around it: no synchronisation in the pass, at most two in fix_ranges().
 """
+import os
 import warnings
 
+import numpy as np
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _manager(per_channel, search, one_call, mbits=3):
@@ -447,3 +450,50 @@ def test_calibration_forward_replayed_from_a_hip_graph(w_est, a_est, search):
         assert torch.equal(_bits(a), _bits(b)), i
     for (mva, ma), (mvb, mb) in zip(sa, sb):
         assert torch.equal(_bits(mva), _bits(mvb)) and ma == mb
+
+
+_SEL_SCRIPT = r"""
+import sys, numpy as np, torch
+sys.path[:0] = [r"%s", r"%s"]
+import fp8q
+ops = fp8q.ops
+torch.manual_seed(11)
+out = {}
+for name, shape, mb, pre in (("search_pre", (8, 24, 28, 28), [1.0, 2.0, 3.0, 4.0, 5.0, 6.0], True), ("fixed_pre", (8, 24, 28, 28), [3.0], True),
+                            ("search_plain", (4, 3, 130, 131), [1.0, 2.0, 3.0, 4.0, 5.0, 6.0], False), ("fixed_big", (64, 32, 112, 112), [3.0], False),
+                            ("search_tiny", (2, 5, 9, 7), [1.0, 2.0, 3.0, 4.0, 5.0, 6.0], False)):
+    x = torch.randn(*shape, device="cuda") * 2.0
+    ab = None
+    if pre:
+        C = shape[1]
+        ab = ops.bn_fold((torch.randn(C, device="cuda") * 0.1, torch.rand(C, device="cuda") + 0.7, torch.rand(C, device="cuda") + 0.5,
+                          torch.randn(C, device="cuda") * 0.1))
+    cal = ops.MseCalibration(1, x.device, mb, 8, 1)
+    for b in range(3):                      # the table accumulates over the batches; the winner is taken after each
+        xb = x * (1.0 + 0.25 * b)
+        y = cal.step(xb, pre=(ab, None, 2) if pre else None)
+        out[f"{name}_y{b}"] = y.cpu().numpy().view(np.uint32)
+        out[f"{name}_mv{b}"] = cal.maxval.cpu().numpy().view(np.uint32)
+        out[f"{name}_mb{b}"] = cal.mbits.cpu().numpy()
+        out[f"{name}_vote{b}"] = cal.vote.cpu().numpy()
+        out[f"{name}_xmin{b}"] = cal.xmin.cpu().numpy().view(np.uint32)
+np.savez(sys.argv[1], **out)
+""" % (ROOT, os.path.join(ROOT, "fp8-quantization_amd"))
+
+
+def test_selection_in_the_k1_prologue_equals_the_ticket_path(tmp_path):
+    """k_quant_rows_sel (the winner selection in the prologue of the K1 launch, the default of fp8q_mse_calibrate_f32 for
+    per-tensor quantizers) against FP8Q_SEL_IN_K1=0 (select_one_row behind tickets in the launch that finishes the table):
+    quantized batches, clipping value, voted width, its index and xmin after each of three batches -- bit for bit."""
+    import subprocess
+    import sys
+    res = {}
+    for mode in ("0", "2"):
+        path = os.path.join(str(tmp_path), f"sel{mode}.npz")
+        r = subprocess.run([sys.executable, "-c", _SEL_SCRIPT, path], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, FP8Q_SEL_IN_K1=mode))
+        assert r.returncode == 0, r.stdout + r.stderr
+        res[mode] = np.load(path)
+    assert set(res["0"].files) == set(res["2"].files) and len(res["0"].files) == 75
+    for k in res["0"].files:
+        assert np.array_equal(res["0"][k], res["2"][k]), k
