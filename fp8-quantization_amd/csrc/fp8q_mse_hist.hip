@@ -27,6 +27,9 @@
 //   6. k_mse_eval     one workgroup per candidate, a lane per cell: two prefix lookups, S2 - 2 q S1 + n q^2 in
 //                     double-double (the three terms cancel: on data that sit on the grid the squared error is 1e-13 of
 //                     the signal energy), fixed-tree sum, mses += mean.
+// Launches (round 6): k_stage1 (1 || the histogram pass of 2) -> k_tab_scan (column scans, counters cleared) -> k_sort_plan_scatter
+// (3 || the unit plan || the scatter pass of 2: all three need only the column totals) -> k_moments -> k_iv_scan_super -> k_mse_eval:
+// six dependent launches, ~48 us + 0.05 us per (width, candidate) pair + 4.3 ps per element.
 // Every element is classified exactly as K1 / the oracle classify it; what differs from the reference is only that
 // (k - q)^2 is summed in (near-)exact arithmetic instead of fp32-rounded per element: ~1e-7 relative, inside K4's stated
 // contract (include/fp8q.h).  Cost for a 25.7 M-element activation: 12 B of HBM traffic per key for the partition (histogram pass 4, scatter
