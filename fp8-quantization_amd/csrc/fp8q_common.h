@@ -114,8 +114,9 @@ inline void fold_debug_env(FoldArgs &fa)
 
 constexpr size_t kMinmaxWsHeader = 16;   // bytes in front of the granules: {timeout count, 3 reserved words}
 
-__device__ __forceinline__ void fold_store(float mn, float mx, int64_t row, float *cur_min,
-                                           float *cur_max, float *maxval_out, const FoldArgs &fa)
+// (returns the row's max|x| after the fold)
+__device__ __forceinline__ float fold_store(float mn, float mx, int64_t row, float *cur_min,
+                                            float *cur_max, float *maxval_out, const FoldArgs &fa)
 {
     if (!fa.first && fa.mode == FP8Q_FOLD_ALL) {
         mn = tmin(cur_min[row], mn);
@@ -139,6 +140,7 @@ __device__ __forceinline__ void fold_store(float mn, float mx, int64_t row, floa
         reinterpret_cast<float4 *>(fa.packed)[row] =
             make_float4(nmn ? ninf : -mn, nmx ? ninf : mx, nmn ? 1.0f : 0.0f, nmx ? 1.0f : 0.0f);
     }
+    return absmax;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -201,6 +203,7 @@ __device__ __forceinline__ void block_minmax_publish(MinMax m, unsigned long lon
 }
 
 // the reducer block of a row
+constexpr int kCollectBatch = 4;
 __device__ __forceinline__ void block_minmax_collect(unsigned long long *slots, int nsplit, unsigned tag, int64_t row,
                                                      float *cur_min, float *cur_max, float *maxval_out, const FoldArgs &fa)
 {
@@ -208,31 +211,60 @@ __device__ __forceinline__ void block_minmax_collect(unsigned long long *slots, 
     MinMax m;
     mm_init(m);
     int lost = 0;
-    for (int s2 = tid; s2 < nsplit; s2 += kBlock) {
-        unsigned long long a = 0, b = 0;
-        int spins = 0;
-        for (;;) {   // agent-scope atomic loads (sc1): served past this CU's L1, see other XCDs' write-through stores
-            a = __hip_atomic_load(slots + 2 * s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            b = __hip_atomic_load(slots + 2 * s2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (((unsigned)(a >> 32) == tag) & ((unsigned)(b >> 32) == tag)) break;
-            if (++spins > fa.spin_limit) {   // ~2 s: something upstream died; do not hang the queue
-                lost = 1;
-                if (fa.status) atomicAdd(fa.status, 1u);
-                break;
+    // kCollectBatch granule pairs per thread are requested together (round 6): an agent-scope load is a round trip past the
+    // caches (~2 us), and a thread that polled its slots one after the other made a row of 2048 partials a chain of eight
+    for (int s0 = 0; s0 < nsplit; s0 += kBlock * kCollectBatch) {
+        unsigned long long a[kCollectBatch], b[kCollectBatch];
+#pragma unroll
+        for (int q = 0; q < kCollectBatch; ++q) {
+            const int s2 = s0 + q * kBlock + tid;
+            a[q] = b[q] = 0ull;
+            if (s2 < nsplit) {
+                a[q] = __hip_atomic_load(slots + 2 * s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                b[q] = __hip_atomic_load(slots + 2 * s2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            __builtin_amdgcn_s_sleep(2);
         }
-        const float mn = __uint_as_float((unsigned)a), mx = __uint_as_float((unsigned)b);
-        // an EMPTY split (a row a few elements longer than a whole number of steps) holds {+inf, -inf}
-        m.nan |= (mn != mn) | (mx != mx) | lost;
-        m.mn = fminf(m.mn, mn);
-        m.mx = fmaxf(m.mx, mx);
-        // consumed: back to zero for the next call on this workspace (ordered behind this kernel: same stream)
-        __hip_atomic_store(slots + 2 * s2, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(slots + 2 * s2 + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int q = 0; q < kCollectBatch; ++q) {
+            const int s2 = s0 + q * kBlock + tid;
+            if (s2 >= nsplit) continue;
+            int spins = 0;
+            // agent-scope atomic loads (sc1): served past this CU's L1, see other XCDs' write-through stores
+            while (!(((unsigned)(a[q] >> 32) == tag) & ((unsigned)(b[q] >> 32) == tag))) {
+                if (++spins > fa.spin_limit) {   // ~2 s: something upstream died; do not hang the queue
+                    lost = 1;
+                    if (fa.status) atomicAdd(fa.status, 1u);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+                a[q] = __hip_atomic_load(slots + 2 * s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                b[q] = __hip_atomic_load(slots + 2 * s2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            const float mn = __uint_as_float((unsigned)a[q]), mx = __uint_as_float((unsigned)b[q]);
+            // an EMPTY split (a row a few elements longer than a whole number of steps) holds {+inf, -inf}
+            m.nan |= (mn != mn) | (mx != mx) | lost;
+            m.mn = fminf(m.mn, mn);
+            m.mx = fmaxf(m.mx, mx);
+            // consumed: back to zero for the next call on this workspace (ordered behind this kernel: same stream)
+            __hip_atomic_store(slots + 2 * s2, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(slots + 2 * s2 + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
+    // the search grid of the row's maximum (first batch of an MSE estimator) is written by the whole workgroup: 111 entries
+    // of double arithmetic one after the other in thread 0 were ~2 us at the end of every such launch
+    __shared__ float s_absmax;
     float mn, mx;
-    if (block_minmax(m, mn, mx)) fold_store(mn, mx, row, cur_min, cur_max, maxval_out, fa);
+    if (block_minmax(m, mn, mx)) {
+        FoldArgs f2 = fa;
+        f2.lin_grid = nullptr;
+        s_absmax = fold_store(mn, mx, row, cur_min, cur_max, maxval_out, f2);
+    }
+    if (fa.lin_grid) {
+        __syncthreads();
+        const float absmax = s_absmax;
+        for (int i = tid; i < fa.lin_steps; i += kBlock)
+            fa.lin_grid[(int64_t)i * fa.lin_C + row] = linspace_at(absmax, fa.lin_lo, fa.lin_hi, fa.lin_steps, i);
+    }
 }
 
 // per-call tag of the granules: nonzero, different from call to call (a multiplicative hash of a counter; this header is

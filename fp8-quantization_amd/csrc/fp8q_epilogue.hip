@@ -180,7 +180,7 @@ k_affine_act(const float *__restrict__ x, const float *__restrict__ res, float *
             for (int u = 0; u < U; ++u) {
                 const int j = base + u * kBlock + tid;
                 if (j >= nvec) break;
-                const vf4 v = ld16<NT>(xv + j);
+                const vf4 v = xv[j];
                 const vf4 r = a.has_res ? ld16<NT>(rv + j) : vf4{0.0f, 0.0f, 0.0f, 0.0f};
                 float e[4] = {v.x, v.y, v.z, v.w};
                 transform(u * kBlock + tid, e, r);
@@ -423,6 +423,24 @@ static void affine_grid(int64_t N, const AffineArgs &a, bool quant, int64_t *bx,
     }
 }
 
+// k_affine_minmax<true> (the epilogue that also WRITES t: first calibration batch of an MSE estimator): the read-only twin's
+// persistent grid of <= 2048 blocks with four 16-byte groups per thread and step leaves a small activation on a fraction of
+// the chip ([64,160,7,7]: 128 blocks, 10.5 us against 4.9 for the plain epilogue on the same tensor) -- a group per thread
+// while the grid stays below FP8Q_EPI_MM_GRID (2048) blocks (more blocks = more partials for the reducer to poll: 4096 and up were slower on
+// every shape; four groups per thread and step requested together, or nontemporal accesses beyond the caches: no gain / slower).
+static void affine_grid_store(int64_t N, const AffineArgs &a, int64_t *bx, int64_t *by)
+{
+    static const int64_t cap_env = [] {
+        const char *e = getenv("FP8Q_EPI_MM_GRID");
+        const long v = e ? atol(e) : 0;
+        return (int64_t)(v > 0 ? v : 2048);
+    }();
+    *by = N < 65534 ? N : 65534;
+    const int64_t nvec = a.image >> 2;
+    const int64_t pieces = cdiv(nvec, kBlock);
+    *bx = balanced_blocks(pieces, cap_env / *by > 0 ? cap_env / *by : 1);
+}
+
 // FP8Q_EPI_SMALL_KIND: 0 = the staged kernel for small tensors too (round 3), 1 = k_affine_act_small, 2 = with early loads
 static int small_kind()
 {
@@ -536,9 +554,11 @@ size_t fp8q_affine_act_minmax_workspace_bytes(int64_t N, int64_t C, int64_t HW)
 {
     AffineArgs a;
     if (N <= 0 || affine_args(N, C, HW, 0, false, false, &a) != FP8Q_OK) return 16;
-    int64_t bx, by;
+    int64_t bx, by, sx, sy;
     affine_grid(N, a, false, &bx, &by);
-    return kMinmaxWsHeader + (size_t)(bx * by) * 2 * sizeof(unsigned long long);   // header + two tagged granules per streaming block
+    affine_grid_store(N, a, &sx, &sy);           // (the variant that writes t has its own grid: the larger of the two)
+    const int64_t parts = bx * by > sx * sy ? bx * by : sx * sy;
+    return kMinmaxWsHeader + (size_t)parts * 2 * sizeof(unsigned long long);   // header + two tagged granules per streaming block
 }
 
 static int affine_minmax_impl(const float *x, const float *residual, int64_t N, int64_t C, int64_t HW,
@@ -564,7 +584,10 @@ static int affine_minmax_impl(const float *x, const float *residual, int64_t N, 
             if (int rc = fp8q_minmax_workspace_check(ws, fp8q_affine_act_minmax_workspace_bytes(N, C, HW), 0, stream)) return rc;
     }
     int64_t bx, by;
-    affine_grid(N, a, false, &bx, &by);
+    if (t_out)
+        affine_grid_store(N, a, &bx, &by);
+    else
+        affine_grid(N, a, false, &bx, &by);
     hipStream_t st = (hipStream_t)stream;
     FoldArgs fa;
     fa.mode = fold_mode;
