@@ -1326,12 +1326,14 @@ constexpr int kSmallFusedInner = 512;          // ... of rows up to 8 elements p
 // blockIdx.y whatever the row length (the by-value kernels keep their tuned routes).
 struct FmtSel {
     const float *mbits_dev;
+    const unsigned char *signed_dev;   // fp8q_quantize_ds_f32: the SIGN in device memory instead (1: tab[0], 0: tab[1]), else null
     int hi;           // n_bits - sign_bits
     QFmt tab[8];      // tab[M - 1]
 };
 
 __device__ __forceinline__ QFmt pick_fmt(const FmtSel &s)
 {
+    if (s.signed_dev) return s.tab[*s.signed_dev ? 0 : 1];
     float M = rintf(*s.mbits_dev);                       // torch.round: half to even (fp8_quantizer.py:105)
     M = fminf(fmaxf(M, 1.0f), (float)s.hi);              // NaN -> 1 (the by-value entry point refuses NaN on the host)
     return s.tab[(int)M - 1];
@@ -1980,16 +1982,13 @@ int fp8q_quantize_f32(const float *x, float *y, int64_t C, int64_t inner, const 
     return launch_rc();
 }
 
-int fp8q_quantize_dm_f32(const float *x, float *y, int64_t C, int64_t inner, const float *maxval, int64_t n_maxval,
-                         const float *mbits_dev, int n_bits, int sign_bits, fp8q_stream_t stream)
+}  // extern "C"
+
+// the launch geometry shared by the entry points whose format is chosen on the device (width: fp8q_quantize_dm_f32, sign:
+// fp8q_quantize_ds_f32)
+static int quantize_sel_launch(const float *x, float *y, int64_t C, int64_t inner, const float *maxval, int64_t n_maxval,
+                               const FmtSel &sel, fp8q_stream_t stream)
 {
-    if (C < 0 || inner < 0 || (n_maxval != 1 && n_maxval != C) || !mbits_dev) return FP8Q_EINVAL;
-    FmtSel sel;
-    sel.mbits_dev = mbits_dev;
-    sel.hi = n_bits - sign_bits;
-    if (sel.hi < 1 || sel.hi > 8) return FP8Q_EINVAL;
-    for (int M = 1; M <= 8; ++M)
-        if (int rc = make_fmt((float)(M <= sel.hi ? M : sel.hi), n_bits, sign_bits, &sel.tab[M - 1])) return rc;
     if (C == 0 || inner == 0) return FP8Q_OK;
     if (!x || !y || !maxval) return FP8Q_EINVAL;
     hipStream_t st = (hipStream_t)stream;
@@ -2040,6 +2039,59 @@ int fp8q_quantize_dm_f32(const float *x, float *y, int64_t C, int64_t inner, con
     return FP8Q_OK;
 }
 
+extern "C" {
+
+int fp8q_quantize_dm_f32(const float *x, float *y, int64_t C, int64_t inner, const float *maxval, int64_t n_maxval,
+                         const float *mbits_dev, int n_bits, int sign_bits, fp8q_stream_t stream)
+{
+    if (C < 0 || inner < 0 || (n_maxval != 1 && n_maxval != C) || !mbits_dev) return FP8Q_EINVAL;
+    FmtSel sel;
+    sel.mbits_dev = mbits_dev;
+    sel.signed_dev = nullptr;
+    sel.hi = n_bits - sign_bits;
+    if (sel.hi < 1 || sel.hi > 8) return FP8Q_EINVAL;
+    for (int M = 1; M <= 8; ++M)
+        if (int rc = make_fmt((float)(M <= sel.hi ? M : sel.hi), n_bits, sign_bits, &sel.tab[M - 1])) return rc;
+    return quantize_sel_launch(x, y, C, inner, maxval, n_maxval, sel, stream);
+}
+
+// K1 of a quantizer with allow_unsigned whose sign_bits is still a flag in device memory (fp8q_sign_fold_u8): both formats
+// of the width travel by value, the kernel reads the flag (fp8_quantizer.py:216-225 decides it with a host round trip).
+int fp8q_quantize_ds_f32(const float *x, float *y, int64_t C, int64_t inner, const float *maxval, int64_t n_maxval,
+                         float mbits, int n_bits, const unsigned char *signed_flag, fp8q_stream_t stream)
+{
+    if (C < 0 || inner < 0 || (n_maxval != 1 && n_maxval != C) || !signed_flag) return FP8Q_EINVAL;
+    FmtSel sel;
+    sel.mbits_dev = nullptr;
+    sel.signed_dev = signed_flag;
+    sel.hi = 2;
+    if (int rc = make_fmt(mbits, n_bits, 1, &sel.tab[0])) return rc;
+    if (int rc = make_fmt(mbits, n_bits, 0, &sel.tab[1])) return rc;
+    for (int i = 2; i < 8; ++i) sel.tab[i] = sel.tab[1];
+    return quantize_sel_launch(x, y, C, inner, maxval, n_maxval, sel, stream);
+}
+
+// FPQuantizer.set_quant_range's sign decision (fp8_quantizer.py:216-225: `allow_unsigned and torch.all(x_min >= 0)` ->
+// sign_bits = 0, never back) on the device: signed_flag[0] stays 1 only while some range minimum is not >= 0 (NaN: signed).
+__global__ void __launch_bounds__(kBlock) k_sign_fold(const float *__restrict__ x_min, int64_t C, unsigned char *flag)
+{
+    __shared__ int s_any;
+    if (threadIdx.x == 0) s_any = 0;
+    __syncthreads();
+    int any = 0;
+    for (int64_t i = threadIdx.x; i < C; i += kBlock) any |= !(x_min[i] >= 0.0f);
+    if (any) s_any = 1;
+    __syncthreads();
+    if (threadIdx.x == 0 && !s_any) flag[0] = 0;
+}
+
+int fp8q_sign_fold_u8(const float *x_min, int64_t C, unsigned char *signed_flag, fp8q_stream_t stream)
+{
+    if (C < 0 || !signed_flag || (C > 0 && !x_min)) return FP8Q_EINVAL;
+    hipLaunchKernelGGL(k_sign_fold, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, x_min, C, signed_flag);
+    return launch_rc();
+}
+
 }  // extern "C"
 
 // (called from fp8q_mse.hip: the last step of fp8q_mse_calibrate_f32 for a per-tensor quantizer with the mantissa search)
@@ -2049,6 +2101,7 @@ int fp8q_quantize_select_f32(const float *x, float *y, int64_t n, const float *m
 {
     FmtSel sel;
     sel.mbits_dev = nullptr;
+    sel.signed_dev = nullptr;
     sel.hi = n_bits - sign_bits;
     if (sel.hi < 1 || sel.hi > 8 || n_m < 1 || n_m > kSelMaxM || n_cand < 1 || !so || !x || !y || n <= 0) return FP8Q_EINVAL;
     for (int M = 1; M <= 8; ++M)

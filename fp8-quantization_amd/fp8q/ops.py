@@ -144,6 +144,16 @@ def quantize(x, maxval, mbits, n_bits=8, sign_bits=1, out=None):
                                             mbits.data_ptr(), int(n_bits), int(sign_bits), _stream(x))
         check(rc, "fp8q_quantize_dm_f32")
         return y
+    if isinstance(sign_bits, torch.Tensor):
+        # sign_bits still a flag in DEVICE memory (sign_fold: allow_unsigned decided without a host round trip): fp8q_quantize_ds_f32
+        _require(sign_bits, "sign_bits", torch.uint8, like=x)
+        if sign_bits.numel() != 1 or x.dtype != torch.float32:
+            raise Fp8qError("a device-resident sign flag must be a 1-element uint8 tensor, x float32")
+        with _on_device(x):
+            rc = lib().fp8q_quantize_ds_f32(x.data_ptr(), y.data_ptr(), C, inner, maxval.data_ptr(), n_mv, float(mbits),
+                                            int(n_bits), sign_bits.data_ptr(), _stream(x))
+        check(rc, "fp8q_quantize_ds_f32")
+        return y
     # float64 input (BASELINE config 1): the reference's chain under ATen's type promotion -- bias in float32,
     # everything downstream of x in float64 (fp8q_quantize_f64)
     fn = lib().fp8q_quantize_f64 if x.dtype == torch.float64 else lib().fp8q_quantize_f32
@@ -152,6 +162,20 @@ def quantize(x, maxval, mbits, n_bits=8, sign_bits=1, out=None):
                 int(sign_bits), _stream(x))
     check(rc, "fp8q_quantize_f64" if x.dtype == torch.float64 else "fp8q_quantize_f32")
     return y
+
+
+def sign_fold(x_min, signed_flag=None):
+    """FPQuantizer.set_quant_range's sign decision on the device (fp8_quantizer.py:216-225): the 1-element uint8 flag
+    (1 = signed; a fresh one when None) is cleared when every value of x_min is >= 0, and never set again.  Enqueue-only."""
+    _require(x_min, "x_min")
+    if signed_flag is None:
+        signed_flag = torch.ones(1, dtype=torch.uint8, device=x_min.device)
+    _require(signed_flag, "signed_flag", torch.uint8, like=x_min)
+    xm = x_min.detach().contiguous().view(-1)
+    with _on_device(xm):
+        rc = lib().fp8q_sign_fold_u8(xm.data_ptr(), xm.numel(), signed_flag.data_ptr(), _stream(xm))
+    check(rc, "fp8q_sign_fold_u8")
+    return signed_flag
 
 
 def _pack_descs(items):

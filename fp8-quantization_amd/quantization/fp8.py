@@ -104,7 +104,8 @@ def _host_float(t):
 
 def quantize_to_fp8_ste_MM(x_float, n_bits, maxval, num_mantissa_bits, sign_bits):
     """Same call signature as fp8_quantizer.py:91-97.  maxval: tensor [1] or [C] on x's device.  num_mantissa_bits: a
-    number / host tensor (passed to the kernel by value) or a 1-element tensor on x's GPU (read by the kernel)."""
+    number / host tensor (passed to the kernel by value) or a 1-element tensor on x's GPU (read by the kernel).
+    sign_bits: 0 / 1, or a 1-element uint8 tensor on x's GPU (FPQuantizer's pending flag: read by the kernel)."""
     mb_grad = isinstance(num_mantissa_bits, torch.Tensor) and num_mantissa_bits.requires_grad and torch.is_grad_enabled()
     on_device = (isinstance(num_mantissa_bits, torch.Tensor) and num_mantissa_bits.is_cuda and num_mantissa_bits.numel() == 1
                  and x_float.dtype == torch.float32 and not mb_grad
@@ -115,6 +116,12 @@ def quantize_to_fp8_ste_MM(x_float, n_bits, maxval, num_mantissa_bits, sign_bits
     maxval = maxval.to(device=x_float.device, dtype=torch.float32).reshape(-1)
     if torch.is_grad_enabled() and (x_float.requires_grad or maxval.requires_grad or mb_grad):
         return _FakeQuantSTE.apply(x_float, maxval, num_mantissa_bits if mb_grad else mbits, int(n_bits), int(sign_bits))
+    if isinstance(sign_bits, torch.Tensor):
+        # FPQuantizer's pending device flag (allow_unsigned, not yet read by the host): the kernel reads it
+        if not (sign_bits.is_cuda and sign_bits.dtype == torch.uint8 and x_float.dtype == torch.float32 and not on_device
+                and x_float.is_cuda):
+            sign_bits = int(sign_bits)
+        return _ops.quantize(x_float, maxval.detach(), mbits, int(n_bits), sign_bits)
     return _ops.quantize(x_float, maxval.detach(), mbits, int(n_bits), int(sign_bits))
 
 
@@ -240,6 +247,36 @@ class FPQuantizer(QuantizerBase):
         else:
             self.__dict__["_mbits_dev"], self.__dict__["_mbits_host"] = None, value
 
+    # `sign_bits` is a host int, as in the reference.  One producer decides it on the DEVICE: set_quant_range() with
+    # allow_unsigned and a CUDA range minimum (fp8q_sign_fold_u8 instead of the reference's `if torch.all(x_min >= 0)`,
+    # a host round trip per call).  Such a flag stays pending -- forward() hands it to the kernel (fp8q_quantize_ds_f32) --
+    # until somebody reads the attribute (one copy, then cached) or QuantizedModel.fix_ranges() collects a model's.
+    @property
+    def sign_bits(self):
+        host = self.__dict__.get("_sign_host")
+        if host is None:
+            host = int(self.__dict__["_sign_dev"].item())                             # synchronises
+            self.__dict__["_sign_host"] = host
+            if host == 0:
+                self.__dict__["_sign_dev"] = None
+        return host
+
+    @sign_bits.setter
+    def sign_bits(self, value):
+        self.__dict__["_sign_host"], self.__dict__["_sign_dev"] = int(value), None
+
+    def _pending_sign_bits(self):
+        """the device flag (uint8 [1], 1 = signed) not yet seen by the host, or None"""
+        return self.__dict__.get("_sign_dev") if self.__dict__.get("_sign_host") is None else None
+
+    def _sign_bits_arg(self):
+        """what forward() passes to the kernel: the host int when it is known, else the pending device flag (a pending
+        mantissa width next to it: the kernels take one of the two from the device -- the sign comes to the host)"""
+        host = self.__dict__.get("_sign_host")
+        if host is not None or self._pending_mantissa_bits() is not None:
+            return self.sign_bits
+        return self.__dict__["_sign_dev"]
+
     def _mantissa_bits_arg(self):
         """what forward() passes to the kernel: the Parameter when the width is being learned, else the host value when
         it is known, else the pending device scalar"""
@@ -263,6 +300,9 @@ class FPQuantizer(QuantizerBase):
         if name == "mantissa_bits":
             FPQuantizer.mantissa_bits.fset(self, value)
             return
+        if name == "sign_bits":
+            FPQuantizer.sign_bits.fset(self, value)
+            return
         super().__setattr__(name, value)
 
     # -- hot path ---------------------------------------------------------------------------
@@ -270,7 +310,7 @@ class FPQuantizer(QuantizerBase):
         if self.maxval.device != x_float.device:
             self.maxval = self.maxval.to(x_float.device)
         return quantize_to_fp8_ste_MM(x_float, self.n_bits, self.maxval, self._mantissa_bits_arg(),
-                                      self.sign_bits)
+                                      self._sign_bits_arg())
 
     # NB: plain methods, as in the reference (:207-211): truthy when used without a call
     def is_initialized(self):
@@ -289,9 +329,25 @@ class FPQuantizer(QuantizerBase):
             return bool(torch.all(x_min >= 0))
         return x_min >= 0
 
+    def _fold_sign(self, x_min):
+        """:216-225 without the host round trip: `if allow_unsigned and torch.all(x_min >= 0): sign_bits = 0` as one tiny
+        launch on a device flag (sticky, like the reference's attribute); the host value is pending until it is read."""
+        d = self.__dict__
+        if d.get("_sign_host") == 0:
+            return                                   # unsigned already: stays
+        flag = d.get("_sign_dev")
+        if flag is None or flag.device != x_min.device:
+            flag = None
+        d["_sign_dev"] = _ops.sign_fold(x_min.detach().float(), flag)
+        d["_sign_host"] = None
+        object.__setattr__(self, "_range_epoch", getattr(self, "_range_epoch", 0) + 1)
+
     def set_quant_range(self, x_min, x_max):
         """:222-240.  Only acts when set_maxval=True: maxval = |max(|x_min|, x_max)|."""
-        if self._make_unsigned(x_min):
+        if self.allow_unsigned and isinstance(x_min, torch.Tensor) and x_min.is_cuda and hasattr(_ops, "sign_fold") \
+                and x_min.dtype in (torch.float32, torch.float64, torch.float16, torch.bfloat16):
+            self._fold_sign(x_min)
+        elif self._make_unsigned(x_min):
             self.sign_bits = 0
         if not self.set_maxval:
             return

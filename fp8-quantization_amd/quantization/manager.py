@@ -108,10 +108,11 @@ class QuantizationManager(nn.Module):
                 return y
         if not fast:
             xmin, xmax = est(x)                      # generic protocol, reference order
-            if (type(q) is FPQuantizer and type(est) is FP_MSE_Estimator and q.set_maxval and not q.allow_unsigned
+            if (type(q) is FPQuantizer and type(est) is FP_MSE_Estimator and q.set_maxval
                     and est.last_maxval is not None):
                 # set_quant_range(xmin, xmax) would store |max(|xmin|, xmax)| == xmax (three tiny launches): the
-                # estimator's select kernel already wrote it
+                # estimator's select kernel already wrote it (allow_unsigned: the estimator has set sign_bits itself --
+                # xmin = -sign_bits * maxval says nothing new)
                 q._set_maxval_tensor(est.last_maxval)
             else:
                 self.set_quant_range(xmin, xmax)

@@ -55,6 +55,24 @@ def materialize_mantissa_bits(model, modules=None):
     return len(pending)
 
 
+def materialize_sign_bits(model, modules=None):
+    """Bring every sign flag that is still pending on the GPU (FPQuantizer.set_quant_range with allow_unsigned) to the host
+    in ONE device-to-host copy per device."""
+    pending = [(q, q._pending_sign_bits()) for q in (model.modules() if modules is None else modules)
+               if hasattr(q, "_pending_sign_bits")]
+    pending = [(q, t) for q, t in pending if t is not None]
+    by_dev = {}
+    for q, t in pending:
+        by_dev.setdefault(t.device, []).append((q, t))
+    for items in by_dev.values():
+        host = torch.cat([t.reshape(1) for _, t in items]).cpu().tolist()
+        for (q, _), v in zip(items, host):
+            q.__dict__["_sign_host"] = int(v)            # (not an assignment: the range epoch stays)
+            if not v:
+                q.__dict__["_sign_dev"] = None
+    return len(pending)
+
+
 def quantizer_ranges(model):
     """{manager name: {maxval, mantissa_bits, sign_bits, state}} for every FP8 quantizer of `model`.
 
@@ -489,6 +507,7 @@ class QuantizedModel(nn.Module):
             if isinstance(m, QuantizationManager) and m.quantizer.is_initialized:      # the managers do not depend on the order)
                 m.fix_ranges()
         materialize_mantissa_bits(self, mods)
+        materialize_sign_bits(self, mods)
         # end of calibration = the one place where a host sync is free: surface what the enqueue-only min/max
         # launches could not report (a reducer block that timed out -> NaN range; a dirty workspace)
         import fp8q

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define FP8Q_VERSION 600 /* 0.6.0: one-call MSE calibration step (fp8q_mse_calibrate_f32), fused small-tensor routes */
+#define FP8Q_VERSION 601 /* 0.6.1: 0.6.0 (one-call MSE calibration step fp8q_mse_calibrate_f32, fused small-tensor routes) + sign_bits decided on the device (fp8q_sign_fold_u8, fp8q_quantize_ds_f32) */
 
 #define FP8Q_OK 0
 #define FP8Q_EINVAL (-1)       /* null pointer, negative size, n_maxval not in {1, C}, ... */
@@ -213,6 +213,19 @@ int fp8q_mse_select_f32(const float *mses, const float *grid, int64_t C, int64_t
                         size_t ws_bytes, fp8q_stream_t stream);
 int fp8q_quantize_dm_f32(const float *x, float *y, int64_t C, int64_t inner, const float *maxval, int64_t n_maxval,
                          const float *mbits_dev, int n_bits, int sign_bits, fp8q_stream_t stream);
+
+/*
+ * FPQuantizer with allow_unsigned=True (quantization/quantizers/fp8_quantizer.py:216-225): set_quant_range() switches the
+ * quantizer to an unsigned format (sign_bits = 0, for good) when every range minimum is >= 0 -- in the reference a host
+ * round trip per call (`torch.all(x_min >= 0)` inside an `if`).  Here the decision stays on the device:
+ *   fp8q_sign_fold_u8      signed_flag[0] (1 = signed; the caller initialises it to 1) is cleared when all C values of x_min
+ *                          are >= 0 (a NaN minimum keeps the sign bit, as the reference's comparison does); never set again.
+ *   fp8q_quantize_ds_f32   K1 (fp8q_quantize_f32) with sign_bits read from that flag: both formats of the width travel by
+ *                          value, every workgroup picks one.  Same launch geometry as fp8q_quantize_dm_f32.
+ */
+int fp8q_sign_fold_u8(const float *x_min, int64_t C, unsigned char *signed_flag, fp8q_stream_t stream);
+int fp8q_quantize_ds_f32(const float *x, float *y, int64_t C, int64_t inner, const float *maxval, int64_t n_maxval,
+                         float mbits, int n_bits, const unsigned char *signed_flag, fp8q_stream_t stream);
 
 /*
  * One calibration step of a quantizer whose range comes from FP_MSE_Estimator, in ONE call:

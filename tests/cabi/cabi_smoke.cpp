@@ -248,6 +248,32 @@ int main()
         }
         CK(hipFree(dmb));
     }
+    // sign_bits decided on the device (allow_unsigned without the host round trip of fp8_quantizer.py:216-225)
+    {
+        unsigned char *dflag, hflag;
+        float *dmin;
+        CK(hipMalloc((void **)&dflag, 1));
+        CK(hipMalloc((void **)&dmin, 3 * sizeof(float)));
+        const float mins[3][3] = {{-0.5f, 0.0f, 2.0f}, {0.0f, 1.0f, 2.0f}, {-1.0f, -2.0f, 3.0f}};
+        const int want[3] = {1, 0, 0};             // signed; every minimum >= 0: unsigned; unsigned for good
+        hflag = 1;
+        CK(hipMemcpy(dflag, &hflag, 1, hipMemcpyHostToDevice));
+        for (int k = 0; k < 3; ++k) {
+            CK(hipMemcpy(dmin, mins[k], sizeof(mins[k]), hipMemcpyHostToDevice));
+            CK(fp8q_sign_fold_u8(dmin, 3, dflag, st));
+            CK(fp8q_quantize_ds_f32(dx, dy, C, inner, dmv, C, 3.0f, 8, dflag, st));
+            CK(hipStreamSynchronize(st));
+            CK(hipMemcpy(&hflag, dflag, 1, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(y, dy, n * 4, hipMemcpyDeviceToHost));
+            orc_quantize_f32(x, ref, C, inner, mv, C, 3.0f, 8, want[k]);
+            char what[80];
+            snprintf(what, sizeof what, "fp8q_sign_fold_u8 + fp8q_quantize_ds_f32 (step %d: sign_bits %d)", k, want[k]);
+            if ((int)hflag != want[k]) { printf("FAIL %s: flag %d\n", what, (int)hflag); ok = 0; }
+            ok &= same_bits(y, ref, n, what);
+        }
+        CK(hipFree(dflag));
+        CK(hipFree(dmin));
+    }
     // device-side search grid + winner selection (sync-free MSE calibration)
     {
         const int n_cand = 111, n_m = 3;

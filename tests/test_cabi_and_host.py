@@ -23,7 +23,7 @@ def test_header_symbols_exported():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/fp8q.h but not exported"
     assert set(fp8q._lib.SIGNATURES) == names, "ctypes signature table out of sync with the header"
-    assert fp8q.lib().fp8q_version() == 600
+    assert fp8q.lib().fp8q_version() == 601
     assert fp8q.lib().fp8q_strerror(-2).decode().startswith("unsupported")
 
 

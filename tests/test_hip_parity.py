@@ -41,7 +41,7 @@ def assert_bit_exact(y, y_ref, what=""):
 
 def test_library_loaded(ops):
     import fp8q
-    assert fp8q.lib().fp8q_version() == 600
+    assert fp8q.lib().fp8q_version() == 601
     assert os.path.exists(fp8q.so_path())
 
 
