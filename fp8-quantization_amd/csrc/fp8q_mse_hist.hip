@@ -993,22 +993,34 @@ __device__ __forceinline__ void moments_keys4(const uint32_t (&kv)[4], const uin
         hi[q] = (int)(e >> 16);
         any |= lo[q] < hi[q];
     }
-    while (any) {                                         // borders <= key
+    // borders <= key.  Branch-free per key (third session of round 6): a trip is taken whenever ONE of the wave's 256 keys lies in
+    // a sub-bin with a border inside -- practically always -- and as four predicated blocks (an `if` per key) a trip was ~100
+    // instructions with one LDS round trip per key; selects instead: the four reads of a trip are in flight together.  A key that
+    // is done reads bord[lo] (lo <= cnt <= bcap: inside the allocation, the sub-bin table follows) and keeps its bounds.
+    while (any) {
+        int mid[4];
+        uint32_t bv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            mid[q] = (lo[q] + hi[q]) >> 1;
+            bv[q] = bord[mid[q]];
+        }
         any = false;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            if (lo[q] < hi[q]) {
-                const int mid = (lo[q] + hi[q]) >> 1;
-                if (bord[mid] <= kv[q]) lo[q] = mid + 1; else hi[q] = mid;
-                any |= lo[q] < hi[q];
-            }
+            const bool act = lo[q] < hi[q], le = bv[q] <= kv[q];
+            lo[q] = (act && le) ? mid[q] + 1 : lo[q];
+            hi[q] = (act && !le) ? mid[q] : hi[q];
+            any |= lo[q] < hi[q];
         }
     }
+    const uint32_t pmin = prev > 1u ? prev : 1u;          // (a real key is never 0: zeros were dropped; 0 = padding of a ragged batch)
+    const int cx = last ? -1 : cnt;                       // (lo is never negative)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const uint32_t key = kv[q];
-        // (a real key is never 0: zeros were dropped); keys below `prev` or behind the chunk's last border: another chunk's
-        if (key == 0u || key < prev || (lo[q] == cnt && !last)) continue;
+        // keys below `prev` or behind the chunk's last border: another chunk's
+        if ((int)(key < pmin) | (int)(lo[q] == cx)) continue;        // (one predicate, one branch)
         const unsigned long long d = key & kHMask;
         const int at = (lo[q] << csh) + cpy;
         atomicAdd(&cntA[at], (1ull << 40) + d);
