@@ -50,6 +50,7 @@ constexpr int kStrideBound = 520;                   // cells of one candidate of
 constexpr int kSuper = 1024;                        // intervals per scan superblock
 constexpr int kTopLds = 512;                        // superblock totals that k_mse_eval scans for itself in LDS
 constexpr int kSortLds = 4096;                      // borders of one bucket sorted in LDS (more: a bitonic network on global memory)
+constexpr int kMomTabWords = (kHSub + 1 + 3) & ~3;  // k_moments' sub-bin table in LDS, padded to 16 bytes
 constexpr int kPartLds = 4 * (2 * kHBuckets + kPartTile + 4);   // bytes of LDS of a scatter workgroup: 49168 (3 per CU)
 
 typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(4)));
@@ -976,13 +977,14 @@ k_sort_plan_scatter(const float *__restrict__ bt, const uint32_t *__restrict__ b
 }
 
 // ---- 4. moments of the intervals ----------------------------------------------------------------------------------------
-// dynamic LDS: uint64 cntA[bcap + 1] {n << 40 | sum d} | uint64 cntB[bcap + 1] {sum d^2} | uint32 bord[bcap] | uint32 tab[1025]
+// dynamic LDS: uint32 tab[1025 (+3)] | uint32 bord[bcap (+pad)] | uint64 cnt[bcap + 1][2] = {n << 40 | sum d, sum d^2} -- the table at
+// offset 0 (its address is two operations on the key), the two counters of an interval side by side (one address per key)
 // tab[s] = borders of the chunk below sub-bin s (the key's next 10 bits), from the bucket's table (border_sort_body): a key's
 // interval is found with the two table entries of its sub-bin and a bisection over the handful of borders between them
 // (with 64 sub-bins the bisection -- 5-7 dependent LDS reads per key -- was 2/3 of the kernel).  16 keys per lane are in
 // flight (four 16-byte loads) and searched side by side, four at a time.
-__device__ __forceinline__ void moments_keys4(const uint32_t (&kv)[4], const uint32_t *tab, const uint32_t *bord, unsigned long long *cntA,
-                                              unsigned long long *cntB, uint32_t prev, int cnt, bool last, int csh, int cpy)
+__device__ __forceinline__ void moments_keys4(const uint32_t (&kv)[4], const uint32_t *tab, const uint32_t *bord, unsigned long long *cnt2,
+                                              uint32_t prev, int cnt, bool last, int csh1, int cpy2)
 {
     int lo[4], hi[4];
     bool any = false;
@@ -996,7 +998,7 @@ __device__ __forceinline__ void moments_keys4(const uint32_t (&kv)[4], const uin
     // borders <= key.  Branch-free per key (third session of round 6): a trip is taken whenever ONE of the wave's 256 keys lies in
     // a sub-bin with a border inside -- practically always -- and as four predicated blocks (an `if` per key) a trip was ~100
     // instructions with one LDS round trip per key; selects instead: the four reads of a trip are in flight together.  A key that
-    // is done reads bord[lo] (lo <= cnt <= bcap: inside the allocation, the sub-bin table follows) and keeps its bounds.
+    // is done reads bord[lo] (lo <= cnt <= bcap: inside the allocation, the counters follow) and keeps its bounds.
     while (any) {
         int mid[4];
         uint32_t bv[4];
@@ -1022,9 +1024,9 @@ __device__ __forceinline__ void moments_keys4(const uint32_t (&kv)[4], const uin
         // keys below `prev` or behind the chunk's last border: another chunk's
         if ((int)(key < pmin) | (int)(lo[q] == cx)) continue;        // (one predicate, one branch)
         const unsigned long long d = key & kHMask;
-        const int at = (lo[q] << csh) + cpy;
-        atomicAdd(&cntA[at], (1ull << 40) + d);
-        atomicAdd(&cntB[at], d * d);
+        unsigned long long *c = cnt2 + ((lo[q] << csh1) + cpy2);       // csh1 = csh + 1, cpy2 = 2 * copy
+        atomicAdd(c, (1ull << 40) + d);
+        atomicAdd(c + 1, d * d);
     }
 }
 
@@ -1056,10 +1058,9 @@ k_moments(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ sb, co
           int bcap)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned long long *cntA = reinterpret_cast<unsigned long long *>(smem);
-    unsigned long long *cntB = cntA + (bcap + 1);
-    uint32_t *bord = reinterpret_cast<uint32_t *>(cntB + (bcap + 1));
-    uint32_t *tab = bord + bcap;                  // kHSub + 1 entries
+    uint32_t *tab = reinterpret_cast<uint32_t *>(smem);            // kHSub + 1 entries (kMomTabWords with the padding)
+    uint32_t *bord = tab + kMomTabWords;
+    unsigned long long *cnt2 = reinterpret_cast<unsigned long long *>(bord + ((bcap + 3) & ~3));
     const int tid = threadIdx.x;
     const uint32_t nu = nunits[0];
     for (uint32_t u = blockIdx.x; u < nu; u += gridDim.x) {
@@ -1091,14 +1092,14 @@ k_moments(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ sb, co
         int csh = 0;
         while (csh < 3 && ((cnt + 1) << (csh + 1)) <= bcap + 1) ++csh;
         const int ncnt = (cnt + 1) << csh, cpy = tid & ((1 << csh) - 1);
-        for (int i = tid; i < ncnt; i += NT) cntA[i] = cntB[i] = 0ull;
+        for (int i = tid; i < 2 * ncnt; i += NT) cnt2[i] = 0ull;
         __syncthreads();
         for (int r0 = 0; r0 < kn; r0 += 16 * NT) {
             uint32_t nx[4][4];
             const bool more = r0 + 16 * NT < kn;
             if (more) moments_load16<NT>(kp, kn, r0 + 16 * NT, nx);
 #pragma unroll
-            for (int v = 0; v < 4; ++v) moments_keys4(kv[v], tab, bord, cntA, cntB, prev, cnt, last, csh, cpy);
+            for (int v = 0; v < 4; ++v) moments_keys4(kv[v], tab, bord, cnt2, prev, cnt, last, csh + 1, 2 * cpy);
             if (more) {
 #pragma unroll
                 for (int v = 0; v < 4; ++v)
@@ -1111,8 +1112,8 @@ k_moments(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ sb, co
         for (int i = tid; i <= cnt; i += NT) {
             unsigned long long A = 0ull, B = 0ull;
             for (int c = 0; c < (1 << csh); ++c) {
-                A += cntA[(i << csh) + c];
-                B += cntB[(i << csh) + c];
+                A += cnt2[2 * ((i << csh) + c)];
+                B += cnt2[2 * ((i << csh) + c) + 1];
             }
             if (A == 0ull || (i == cnt && !last)) continue;
             atomicAdd(&g_n[gid0 + i], (uint32_t)(A >> 40));
@@ -1618,7 +1619,7 @@ int fp8q_mse_hist_launch(const float *x, int64_t n, const float *grid, int64_t n
             hipLaunchKernelGGL(k_part_scatter<false>, dim3((unsigned)pwgs), dim3(kBlock), 0, st, xb, n, ntiles, tpw, hist, ktab, keys);
         if (int rc = launch_rc()) return rc;
     }
-    const size_t shmem = (size_t)(bcap + 1) * 16 + (size_t)bcap * 4 + (kHSub + 1) * 4;
+    const size_t shmem = (size_t)kMomTabWords * 4 + (size_t)((bcap + 3) & ~3) * 4 + (size_t)(bcap + 1) * 16;
     // threads per k_moments workgroup.  At 25.7 M keys the kernel is bound by the LDS atomics' throughput and 256 threads are
     // best (48.6 us against 51.7 with 111 pairs, 88 against 107 with 666); on MobileNetV2's smaller activations a few hundred
     // units of one or two 4096-key batches each leave most CUs with one workgroup, the unit's own latency is the launch's
