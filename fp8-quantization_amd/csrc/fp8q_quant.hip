@@ -1339,10 +1339,26 @@ __device__ __forceinline__ QFmt pick_fmt(const FmtSel &s)
     return s.tab[(int)M - 1];
 }
 
-template <bool NT, int U>
+// width AND sign in device memory (fp8q_quantize_dms_f32: an MSE estimator's vote next to the flag of fp8q_sign_fold_u8)
+struct FmtSel2 {
+    const float *mbits_dev;
+    const unsigned char *signed_dev;
+    int hi[2];          // n_bits - sign_bits for sign_bits = 1, 0
+    QFmt tab[2][8];     // tab[1 - sign_bits][M - 1]
+};
+
+__device__ __forceinline__ QFmt pick_fmt(const FmtSel2 &s)
+{
+    const int u = *s.signed_dev ? 0 : 1;
+    float M = rintf(*s.mbits_dev);
+    M = fminf(fmaxf(M, 1.0f), (float)s.hi[u]);
+    return s.tab[u][(int)M - 1];
+}
+
+template <bool NT, int U, class SEL>
 __global__ void __launch_bounds__(kBlock)
 k_quant_rows_dm(const float *__restrict__ x, float *__restrict__ y, int64_t inner, const float *__restrict__ maxval,
-                int per_channel, FmtSel sel)
+                int per_channel, SEL sel)
 {
     const QFmt f = pick_fmt(sel);
     quant_rows_body<NT, U>(x, y, inner, maxval, per_channel, f);
@@ -1439,9 +1455,10 @@ k_quant_rows_sel(const float *__restrict__ x, float *__restrict__ y, int64_t inn
 // [96, 1, 3, 3] ...): a WAVE per row -- its channel constants and {s, 1/s} table built once per wave in the wave's own slice of
 // LDS, the row streamed by its 64 lanes -- instead of a 256-thread workgroup (and a ~50-operation double-precision set-up) per
 // row of a few hundred elements.  Same arithmetic as quant_rows_body (quant_one), bit for bit.
+template <class SEL>
 __global__ void __launch_bounds__(kBlock)
 k_quant_short_rows_dm(const float *__restrict__ x, float *__restrict__ y, int64_t C, int inner, const float *__restrict__ maxval,
-                      FmtSel sel)
+                      SEL sel)
 {
     __shared__ float2 lut[kBlock / 64][kLutMax];
     const QFmt f = pick_fmt(sel);
@@ -1459,9 +1476,10 @@ k_quant_short_rows_dm(const float *__restrict__ x, float *__restrict__ y, int64_
     }
 }
 
+template <class SEL>
 __global__ void __launch_bounds__(kBlock)
 k_quant_scalar_dm(const float *__restrict__ x, float *__restrict__ y, int64_t inner, const float *__restrict__ maxval,
-                  int per_channel, FmtSel sel)
+                  int per_channel, SEL sel)
 {
     const QFmt f = pick_fmt(sel);
     quant_scalar_body(x, y, inner, maxval, per_channel, f);
@@ -1986,8 +2004,9 @@ int fp8q_quantize_f32(const float *x, float *y, int64_t C, int64_t inner, const 
 
 // the launch geometry shared by the entry points whose format is chosen on the device (width: fp8q_quantize_dm_f32, sign:
 // fp8q_quantize_ds_f32)
+template <class SEL>
 static int quantize_sel_launch(const float *x, float *y, int64_t C, int64_t inner, const float *maxval, int64_t n_maxval,
-                               const FmtSel &sel, fp8q_stream_t stream)
+                               const SEL &sel, fp8q_stream_t stream)
 {
     if (C == 0 || inner == 0) return FP8Q_OK;
     if (!x || !y || !maxval) return FP8Q_EINVAL;
@@ -2000,7 +2019,7 @@ static int quantize_sel_launch(const float *x, float *y, int64_t C, int64_t inne
     if (per_channel && inner <= 2048 && inner < (1ll << 31) / 4) {
         // short rows: a wave per row
         const int64_t blocks = cdiv(C, kBlock / 64);
-        hipLaunchKernelGGL(k_quant_short_rows_dm, dim3((unsigned)(blocks < 8 * kTargetBlocks ? blocks : 8 * kTargetBlocks)), dim3(kBlock), 0, st,
+        hipLaunchKernelGGL(k_quant_short_rows_dm<SEL>, dim3((unsigned)(blocks < 8 * kTargetBlocks ? blocks : 8 * kTargetBlocks)), dim3(kBlock), 0, st,
                            x, y, C, (int)inner, maxval, sel);
         return launch_rc();
     }
@@ -2023,15 +2042,15 @@ static int quantize_sel_launch(const float *x, float *y, int64_t C, int64_t inne
             const dim3 g((unsigned)bx, (unsigned)cn), b(kBlock);
             const float *mvp = maxval + (per_channel ? c0 : 0);
             if (nt)
-                hipLaunchKernelGGL((k_quant_rows_dm<true, kUnroll>), g, b, 0, st, xs, ys, inner, mvp, per_channel, sel);
+                hipLaunchKernelGGL((k_quant_rows_dm<true, kUnroll, SEL>), g, b, 0, st, xs, ys, inner, mvp, per_channel, sel);
             else if (small)
-                hipLaunchKernelGGL((k_quant_rows_dm<false, 1>), g, b, 0, st, xs, ys, inner, mvp, per_channel, sel);
+                hipLaunchKernelGGL((k_quant_rows_dm<false, 1, SEL>), g, b, 0, st, xs, ys, inner, mvp, per_channel, sel);
             else
-                hipLaunchKernelGGL((k_quant_rows_dm<false, kUnroll>), g, b, 0, st, xs, ys, inner, mvp, per_channel, sel);
+                hipLaunchKernelGGL((k_quant_rows_dm<false, kUnroll, SEL>), g, b, 0, st, xs, ys, inner, mvp, per_channel, sel);
         } else {
             int64_t bs = cdiv(inner, kBlock);
             if (bs > cap * 4) bs = cap * 4;
-            hipLaunchKernelGGL(k_quant_scalar_dm, dim3((unsigned)bs, (unsigned)cn), dim3(kBlock), 0, st, xs, ys, inner,
+            hipLaunchKernelGGL(k_quant_scalar_dm<SEL>, dim3((unsigned)bs, (unsigned)cn), dim3(kBlock), 0, st, xs, ys, inner,
                                maxval + (per_channel ? c0 : 0), per_channel, sel);
         }
         if (int rc = launch_rc()) return rc;
@@ -2068,6 +2087,24 @@ int fp8q_quantize_ds_f32(const float *x, float *y, int64_t C, int64_t inner, con
     if (int rc = make_fmt(mbits, n_bits, 1, &sel.tab[0])) return rc;
     if (int rc = make_fmt(mbits, n_bits, 0, &sel.tab[1])) return rc;
     for (int i = 2; i < 8; ++i) sel.tab[i] = sel.tab[1];
+    return quantize_sel_launch(x, y, C, inner, maxval, n_maxval, sel, stream);
+}
+
+// ... and with the mantissa width in device memory as well (the MSE estimator's vote for a quantizer whose sign is still
+// pending): 2 x 8 formats by value.
+int fp8q_quantize_dms_f32(const float *x, float *y, int64_t C, int64_t inner, const float *maxval, int64_t n_maxval,
+                          const float *mbits_dev, int n_bits, const unsigned char *signed_flag, fp8q_stream_t stream)
+{
+    if (C < 0 || inner < 0 || (n_maxval != 1 && n_maxval != C) || !mbits_dev || !signed_flag) return FP8Q_EINVAL;
+    FmtSel2 sel;
+    sel.mbits_dev = mbits_dev;
+    sel.signed_dev = signed_flag;
+    for (int u = 0; u < 2; ++u) {
+        sel.hi[u] = n_bits - (1 - u);
+        if (sel.hi[u] < 1 || sel.hi[u] > 8) return FP8Q_EINVAL;
+        for (int M = 1; M <= 8; ++M)
+            if (int rc = make_fmt((float)(M <= sel.hi[u] ? M : sel.hi[u]), n_bits, 1 - u, &sel.tab[u][M - 1])) return rc;
+    }
     return quantize_sel_launch(x, y, C, inner, maxval, n_maxval, sel, stream);
 }
 

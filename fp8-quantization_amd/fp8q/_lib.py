@@ -56,6 +56,7 @@ SIGNATURES = {
     "fp8q_quantize_dm_f32": (_i, [_vp, _vp, _i64, _i64, _vp, _i64, _vp, _i, _i, _vp]),
     "fp8q_quantize_ds_f32": (_i, [_vp, _vp, _i64, _i64, _vp, _i64, _f, _i, _vp, _vp]),
     "fp8q_sign_fold_u8": (_i, [_vp, _i64, _vp, _vp]),
+    "fp8q_quantize_dms_f32": (_i, [_vp, _vp, _i64, _i64, _vp, _i64, _vp, _i, _vp, _vp]),
     "fp8q_mse_calibrate_workspace_bytes": (ctypes.c_size_t, [_i64, _i64, _i64, _i, ctypes.POINTER(ctypes.c_size_t),
                                                              ctypes.POINTER(ctypes.c_size_t)]),
     "fp8q_mse_calibrate_f32": (_i, [_vp, _vp, _i64, _i64, ctypes.POINTER(MseState), _i, _i, ctypes.POINTER(_f), _i, _i, _i,

@@ -139,6 +139,15 @@ def quantize(x, maxval, mbits, n_bits=8, sign_bits=1, out=None):
         _require(mbits, "mbits", like=x)
         if mbits.numel() != 1 or x.dtype != torch.float32:
             raise Fp8qError("a device-resident mantissa width must be a 1-element float32 tensor, x float32")
+        if isinstance(sign_bits, torch.Tensor):     # ... and the sign still a device flag (sign_fold): fp8q_quantize_dms_f32
+            _require(sign_bits, "sign_bits", torch.uint8, like=x)
+            if sign_bits.numel() != 1:
+                raise Fp8qError("a device-resident sign flag must be a 1-element uint8 tensor")
+            with _on_device(x):
+                rc = lib().fp8q_quantize_dms_f32(x.data_ptr(), y.data_ptr(), C, inner, maxval.data_ptr(), n_mv,
+                                                 mbits.data_ptr(), int(n_bits), sign_bits.data_ptr(), _stream(x))
+            check(rc, "fp8q_quantize_dms_f32")
+            return y
         with _on_device(x):
             rc = lib().fp8q_quantize_dm_f32(x.data_ptr(), y.data_ptr(), C, inner, maxval.data_ptr(), n_mv,
                                             mbits.data_ptr(), int(n_bits), int(sign_bits), _stream(x))

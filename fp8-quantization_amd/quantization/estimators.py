@@ -196,7 +196,8 @@ class FP_MSE_Estimator(RangeEstimatorBase):
     mantissa width reaches the quantizer as a device scalar (FPQuantizer.mantissa_bits keeps it pending; the batch
     that follows in the same forward is quantized by fp8q_quantize_dm_f32) and comes to the host when somebody reads
     it -- QuantizedModel.fix_ranges() collects all of a model's in one copy.
-    Still synchronising: allow_unsigned=True (the reference's any(x < 0) decides sign_bits, a host-side int).
+    allow_unsigned=True: the sign is a device flag as well (_forward_sign_on_device; float64 data and multi-process
+    calibration keep the reference's host decision).
     """
     N_GRID = 111   # hard-coded in the reference (:305); `num_candidates` is accepted and ignored
 
@@ -279,7 +280,8 @@ class FP_MSE_Estimator(RangeEstimatorBase):
                 mx = None
             elif not self._dist_batch():
                 # max|x| and the grid [111, C] (== torch.linspace per channel) in the abs-max launch itself
-                self.search_grid = _ops.minmax_linspace(x, self.per_channel, self.N_GRID)[3]
+                mn_rows, _, _, self.search_grid = _ops.minmax_linspace(x, self.per_channel, self.N_GRID)
+                self.__dict__["_batch_min"] = mn_rows        # (allow_unsigned decides the sign from it: forward)
                 mx = None
             else:
                 _, _, mx = _ops.minmax(x, self.per_channel, want_maxval=True)
@@ -291,17 +293,73 @@ class FP_MSE_Estimator(RangeEstimatorBase):
             self.mses = torch.zeros(n_m, self.N_GRID, self.search_grid.shape[1], device=x.device)
         return self.search_grid, self.mses
 
-    def _accumulate(self, x, grid, mbit_list, q, mses):
+    def _accumulate(self, x, grid, mbit_list, q, mses, sign_bits=None):
         """mses += this batch's per-channel mean squared error of every (width, candidate)"""
+        sign_bits = q.sign_bits if sign_bits is None else sign_bits
         if x.dtype == torch.float64:        # the reference adds a float64 mean into its float32 table (:346-347)
             inc = torch.zeros(mses.shape, dtype=torch.float64, device=mses.device)
-            _ops.mse_grid_f64(x, self.per_channel, grid, mbit_list, q.n_bits, q.sign_bits, inc, reduce="mean")
+            _ops.mse_grid_f64(x, self.per_channel, grid, mbit_list, q.n_bits, sign_bits, inc, reduce="mean")
             mses.copy_((mses.double() + inc).float())       # float32 += float64: ATen adds in float64, then rounds once
         else:
-            _ops.mse_grid(x, self.per_channel, grid, mbit_list, q.n_bits, q.sign_bits, mses)
+            _ops.mse_grid(x, self.per_channel, grid, mbit_list, q.n_bits, sign_bits, mses)
+
+    def _sign_on_device(self, x):
+        """allow_unsigned without the reference's `int(torch.any(x < 0))` round trip (:333): possible for float32 CUDA data in
+        one process when the quantizer takes its range from us"""
+        q = self.quantizer
+        return (q.allow_unsigned and q.set_maxval and x.is_cuda and x.dtype == torch.float32 and hasattr(_ops, "sign_fold")
+                and not self._dist_batch() and type(q).__name__ == "FPQuantizer" and q.n_bits <= 8)
+
+    def _forward_sign_on_device(self, x, q):
+        """forward() for allow_unsigned with the sign decided on the GPU.  The reference's flow per batch: sign = any(x < 0);
+        one-sided data switches the quantizer to unsigned for good BEFORE the candidates are evaluated (set_quant_range inside
+        the loop, fp8_quantizer.py:216-225); the batch's errors are then those of the formats the quantizer has now.  Here the
+        decision is a device flag (fp8q_sign_fold_u8 on the batch's row minima: `all(min >= 0)` for `not any(x < 0)`; they
+        differ only on NaN data, whose tables are NaN either way).  While the host has not seen the flag, the batch is
+        searched with BOTH format sets and the flag picks the increment (twice the K4 time for such a quantizer instead of a
+        host round trip per quantizer and batch); once the host knows the quantizer is unsigned only that set runs."""
+        d = q.__dict__
+        pend = d.get("_sign_host") is None
+        if pend and self._mbit_list is not None:
+            mbit_list = self._mbit_list
+        elif q.mse_include_mantissa_bits:
+            mbit_list = [float(m) for m in range(1, q.n_bits - q.sign_bits)]
+        else:
+            mbit_list = [float(q.mantissa_bits)]
+        if self.mses is not None and len(mbit_list) != self.mses.shape[0]:
+            mbit_list = self._mbit_list                  # (see forward: the candidate set of the first batch stays)
+        self._mbit_list = mbit_list
+        self.__dict__["_batch_min"] = None
+        grid, mses = self._define_search_range(x, len(mbit_list))
+        assert mses.shape[1:] == grid.shape, f"{mses.shape}, {grid.shape}"
+        mn_rows = self.__dict__.pop("_batch_min", None)
+        if mn_rows is None:
+            mn_rows = _ops.minmax(x, self.per_channel)[0]
+        neg = _ops.sign_fold(mn_rows.reshape(-1))                      # 1: this batch has an element that is not >= 0
+        if d.get("_sign_host") == 0:
+            self._accumulate(x, grid, mbit_list, q, mses, sign_bits=0)
+        else:
+            flag = d.get("_sign_dev")
+            if flag is None or flag.device != x.device:
+                flag = torch.ones(1, dtype=torch.uint8, device=x.device)
+            _ops.sign_fold(mn_rows.reshape(-1), flag)                  # sticky: cleared once a batch is one-sided
+            inc_s, inc_u = torch.zeros_like(mses), torch.zeros_like(mses)
+            self._accumulate(x, grid, mbit_list, q, inc_s, sign_bits=1)
+            self._accumulate(x, grid, mbit_list, q, inc_u, sign_bits=0)
+            mses += torch.where(flag.bool(), inc_s, inc_u)
+            d["_sign_dev"], d["_sign_host"] = flag, None
+            object.__setattr__(q, "_range_epoch", getattr(q, "_range_epoch", 0) + 1)
+        mbits_dev, _vote, maxval, xmin = _ops.mse_select(mses, grid, mbit_list, 1)
+        xmin = xmin * neg.to(xmin.dtype)                               # sign_bits * -1.0 * maxval (:369); -0.0 for one-sided data
+        q.mantissa_bits = mbits_dev if len(mbit_list) > 1 else torch.tensor([float(mbit_list[0])])
+        q.maxval = grid[-1].clone()
+        self.last_maxval = maxval
+        return xmin, maxval
 
     def forward(self, x):
         q = self.quantizer
+        if self._sign_on_device(x):
+            return self._forward_sign_on_device(x, q)
         if q.mse_include_mantissa_bits:
             mbit_list = [float(m) for m in range(1, q.n_bits - q.sign_bits)]
         else:

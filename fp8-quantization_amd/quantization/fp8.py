@@ -118,8 +118,7 @@ def quantize_to_fp8_ste_MM(x_float, n_bits, maxval, num_mantissa_bits, sign_bits
         return _FakeQuantSTE.apply(x_float, maxval, num_mantissa_bits if mb_grad else mbits, int(n_bits), int(sign_bits))
     if isinstance(sign_bits, torch.Tensor):
         # FPQuantizer's pending device flag (allow_unsigned, not yet read by the host): the kernel reads it
-        if not (sign_bits.is_cuda and sign_bits.dtype == torch.uint8 and x_float.dtype == torch.float32 and not on_device
-                and x_float.is_cuda):
+        if not (sign_bits.is_cuda and sign_bits.dtype == torch.uint8 and x_float.dtype == torch.float32 and x_float.is_cuda):
             sign_bits = int(sign_bits)
         return _ops.quantize(x_float, maxval.detach(), mbits, int(n_bits), sign_bits)
     return _ops.quantize(x_float, maxval.detach(), mbits, int(n_bits), int(sign_bits))
@@ -270,12 +269,10 @@ class FPQuantizer(QuantizerBase):
         return self.__dict__.get("_sign_dev") if self.__dict__.get("_sign_host") is None else None
 
     def _sign_bits_arg(self):
-        """what forward() passes to the kernel: the host int when it is known, else the pending device flag (a pending
-        mantissa width next to it: the kernels take one of the two from the device -- the sign comes to the host)"""
+        """what forward() passes to the kernel: the host int when it is known, else the pending device flag (next to a
+        pending mantissa width: fp8q_quantize_dms_f32 reads both)"""
         host = self.__dict__.get("_sign_host")
-        if host is not None or self._pending_mantissa_bits() is not None:
-            return self.sign_bits
-        return self.__dict__["_sign_dev"]
+        return host if host is not None else self.__dict__["_sign_dev"]
 
     def _mantissa_bits_arg(self):
         """what forward() passes to the kernel: the Parameter when the width is being learned, else the host value when

@@ -222,10 +222,15 @@ int fp8q_quantize_dm_f32(const float *x, float *y, int64_t C, int64_t inner, con
  *                          are >= 0 (a NaN minimum keeps the sign bit, as the reference's comparison does); never set again.
  *   fp8q_quantize_ds_f32   K1 (fp8q_quantize_f32) with sign_bits read from that flag: both formats of the width travel by
  *                          value, every workgroup picks one.  Same launch geometry as fp8q_quantize_dm_f32.
+ *   fp8q_quantize_dms_f32  the same with the width read from device memory as well.
  */
 int fp8q_sign_fold_u8(const float *x_min, int64_t C, unsigned char *signed_flag, fp8q_stream_t stream);
 int fp8q_quantize_ds_f32(const float *x, float *y, int64_t C, int64_t inner, const float *maxval, int64_t n_maxval,
                          float mbits, int n_bits, const unsigned char *signed_flag, fp8q_stream_t stream);
+/* ... with the mantissa width in device memory too (fp8q_quantize_dm_f32's mbits_dev): an MSE estimator's vote for a quantizer
+ * whose sign is still that flag.  n_bits <= 8 (both signs' widths 1 .. n_bits - sign_bits travel by value). */
+int fp8q_quantize_dms_f32(const float *x, float *y, int64_t C, int64_t inner, const float *maxval, int64_t n_maxval,
+                          const float *mbits_dev, int n_bits, const unsigned char *signed_flag, fp8q_stream_t stream);
 
 /*
  * One calibration step of a quantizer whose range comes from FP_MSE_Estimator, in ONE call:

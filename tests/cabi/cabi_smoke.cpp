@@ -270,6 +270,18 @@ int main()
             snprintf(what, sizeof what, "fp8q_sign_fold_u8 + fp8q_quantize_ds_f32 (step %d: sign_bits %d)", k, want[k]);
             if ((int)hflag != want[k]) { printf("FAIL %s: flag %d\n", what, (int)hflag); ok = 0; }
             ok &= same_bits(y, ref, n, what);
+            // ... and with the mantissa width in device memory as well
+            float *dmb2;
+            const float mbv = 2.0f + (float)k;
+            CK(hipMalloc((void **)&dmb2, 4));
+            CK(hipMemcpy(dmb2, &mbv, 4, hipMemcpyHostToDevice));
+            CK(fp8q_quantize_dms_f32(dx, dy, C, inner, dmv, C, dmb2, 8, dflag, st));
+            CK(hipStreamSynchronize(st));
+            CK(hipMemcpy(y, dy, n * 4, hipMemcpyDeviceToHost));
+            orc_quantize_f32(x, ref, C, inner, mv, C, mbv, 8, want[k]);
+            snprintf(what, sizeof what, "fp8q_quantize_dms_f32 (device width %.0f, device sign %d)", mbv, want[k]);
+            ok &= same_bits(y, ref, n, what);
+            CK(hipFree(dmb2));
         }
         CK(hipFree(dflag));
         CK(hipFree(dmin));

@@ -194,3 +194,74 @@ def test_quantized_model_with_allow_unsigned_calibrates_without_a_round_trip():
             fp8q.ops.sign_fold = saved
     assert [m.quantizer.sign_bits for m in mgrs] == signs
     assert torch.equal(y.view(torch.int32), y2.view(torch.int32))
+
+
+@pytest.mark.parametrize("per_channel", [False, True])
+@pytest.mark.parametrize("search", [True, False])
+@pytest.mark.parametrize("seq", ["signed", "relu", "signed_then_relu", "relu_then_signed"])
+def test_mse_estimator_with_allow_unsigned_is_sync_free(per_channel, search, seq):
+    """FP_MSE_Estimator + allow_unsigned: the reference's `int(torch.any(x < 0))` per batch (range_estimators.py:333) as a device
+    flag -- three batches enqueue without a host round trip and leave the tables, the winner, the sign and the quantized
+    batches of the flow that decides on the host."""
+    from quantization.quantizers.fp8_quantizer import FPQuantizer
+    from quantization.range_estimators import FP_MSE_Estimator
+    from quantization.quantization_manager import QuantizationManager
+    import fp8q
+    ops = fp8q.ops
+    torch.manual_seed(11)
+    shape = (24, 3, 5, 5) if per_channel else (4, 16, 14, 14)
+    raw = [torch.randn(shape, device="cuda") * (1 + i) for i in range(3)]
+    kinds = {"signed": "sss", "relu": "rrr", "signed_then_relu": "srr", "relu_then_signed": "rss"}[seq]
+    batches = [torch.relu(b) if k == "r" else b for b, k in zip(raw, kinds)]
+    ops.mse_linspace(torch.ones(1, device="cuda"))       # the once-per-process self-check synchronises
+
+    def make():
+        return QuantizationManager(qmethod=FPQuantizer, init=FP_MSE_Estimator, per_channel=per_channel,
+                                   qparams=dict(n_bits=8, mantissa_bits=3, set_maxval=True, mse_include_mantissa_bits=search,
+                                                allow_unsigned=True))
+
+    mgr = make()
+    [mgr(b) for b in batches]                            # (allocations, code objects)
+    mgr = make()
+    with _NoSync():
+        outs = [mgr(b) for b in batches]
+    q, est = mgr.quantizer, mgr.range_estimator
+    assert q._pending_sign_bits() is not None
+    # the host-decided flow (the reference's): the same estimator without the device flag
+    saved = ops.sign_fold
+    try:
+        del ops.sign_fold
+        ref = make()
+        want = [ref(b) for b in batches]
+    finally:
+        ops.sign_fold = saved
+    rq, rest = ref.quantizer, ref.range_estimator
+    assert q.sign_bits == rq.sign_bits == {"sss": 1, "rrr": 0, "srr": 0, "rss": 0}[kinds]
+    assert q._pending_sign_bits() is None
+    assert torch.equal(est.search_grid, rest.search_grid)
+    assert torch.equal(est.mses.view(torch.int32), rest.mses.view(torch.int32)), (per_channel, search, seq)
+    assert float(q.mantissa_bits) == float(rq.mantissa_bits)
+    assert torch.equal(q.maxval, rq.maxval)
+    for i, (a, b) in enumerate(zip(outs, want)):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (per_channel, search, seq, i)
+    mgr.fix_ranges()
+    with _NoSync():
+        y = mgr(batches[0])
+    ref.fix_ranges()
+    assert torch.equal(y, ref(batches[0]))
+
+
+def test_k1_with_width_and_sign_in_device_memory():
+    import fp8q
+    ops = fp8q.ops
+    g = torch.Generator().manual_seed(77)
+    for shape, pc in (((8, 16, 28, 28), False), ((64, 3, 7, 7), True), ((5, 70000), True), ((70001,), False)):
+        x = (torch.randn(*shape, generator=g) * 2.0).cuda()
+        mv = ops.minmax(x, pc, want_maxval=True)[2] * 0.8
+        for m in (1.0, 2.6, 4.0, 7.0, 8.0):
+            for sb in (1, 0):
+                flag = torch.tensor([sb], dtype=torch.uint8, device="cuda")
+                md = torch.tensor([m], device="cuda")
+                want = ops.quantize(x, mv, m, 8, sb)
+                got = ops.quantize(x, mv, md, 8, flag)
+                assert torch.equal(got.view(torch.int32), want.view(torch.int32)), (shape, m, sb)
