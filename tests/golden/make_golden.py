@@ -27,6 +27,8 @@ Fixture files:
   g10_autograd.npz   backward of quantize_to_fp8_ste_MM (d/dx, d/dmaxval)
   g11_wrappers.npz   quantize_model on two toy nets built of the wrappers g7-g9 do not reach: QuantConv1d, QuantConvTranspose1d/2d
                      (dims 0/1 swapped around the per-channel quantizer), BNQConv1d, BNQLinear, QuantLayerNorm (autoquant_utils.py:20-174)
+  g12_allow_unsigned.npz allow_unsigned over three batches through QuantizationManager (min/max estimators, MSE with a fixed width):
+                     outputs, maxval and sign_bits after every batch (fp8_quantizer.py:216-225 is sticky)
   g1c_quantize_f64.npz quantize_to_fp8_ste_MM on FLOAT64 inputs (ATen type promotion: bias float32, the rest float64)
   (g5 also holds LineSearchEstimator.loss_array -- 1001 float64 sums per distribution and format -- and the chosen index)
 """
@@ -272,6 +274,41 @@ def make_g4c():
         out[f"{name}_grid"] = est.search_grid.numpy().copy()
     np.savez_compressed(os.path.join(OUT, "g4c_mse_f64.npz"), **out)
     print("g4c ok")
+
+
+def make_g12():
+    """allow_unsigned over several batches (fp8_quantizer.py:216-225 inside QuantizationManager.forward in estimate state): the
+    sign bit goes once the ranges are one-sided and never comes back.  Four data sequences (s = signed batch, r = ReLU batch)
+    x the three min/max estimators x per tensor / per channel, and the MSE estimator with a fixed mantissa width (with the
+    mantissa search the reference indexes past its table as soon as a one-sided batch is followed by another batch:
+    range_estimators.py:337-347 -- nothing to pin there).  Stored: inputs, every batch's output, maxval and sign_bits."""
+    out = {}
+    torch.manual_seed(12)
+    shapes = {0: (2, 8, 14, 14), 1: (24, 3, 5, 5)}
+    raw = {pc: [torch.randn(*shapes[pc]) * (1 + i) for i in range(3)] for pc in (0, 1)}
+    for pc in (0, 1):
+        out[f"raw_pc{pc}"] = np.stack([b.numpy() for b in raw[pc]])
+    seqs = {"signed": "sss", "relu": "rrr", "signed_then_relu": "srr", "relu_then_signed": "rss"}
+    ests = {"current_minmax": RangeEstimators.current_minmax.cls, "allminmax": RangeEstimators.allminmax.cls,
+            "running_minmax": RangeEstimators.running_minmax.cls, "MSE": RangeEstimators.MSE.cls}
+    for ename, ecls in ests.items():
+        for pc in (0, 1):
+            for sname, kinds in seqs.items():
+                qm = QuantizationManager(qmethod=QMethods.fp_quantizer.cls, init=ecls, per_channel=bool(pc),
+                                         qparams=dict(n_bits=8, mantissa_bits=3, maxval=None, set_maxval=True,
+                                                      mse_include_mantissa_bits=False, allow_unsigned=True))
+                ys, mvs, sgn = [], [], []
+                for b, k in zip(raw[pc], kinds):
+                    x = torch.relu(b) if k == "r" else b
+                    ys.append(qm(x).numpy().copy())
+                    mvs.append(qm.quantizer.maxval.numpy().copy().reshape(-1))
+                    sgn.append(int(qm.quantizer.sign_bits))
+                key = f"{ename}_pc{pc}_{sname}"
+                out[key + "_y"] = np.stack(ys)
+                out[key + "_maxval"] = np.stack(mvs)
+                out[key + "_sign"] = np.array(sgn)
+    np.savez_compressed(os.path.join(OUT, "g12_allow_unsigned.npz"), **out)
+    print("g12 ok")
 
 
 def make_g6():
@@ -804,4 +841,5 @@ if __name__ == "__main__":
     make_g8()
     make_g9()
     make_g11()
+    make_g12()
     assert not os.path.exists(os.path.join(REF, "quantization", "__pycache__")), "pycache leaked"
