@@ -1637,9 +1637,11 @@ int fp8q_mse_hist_launch(const float *x, int64_t n, const float *grid, int64_t n
     // best (48.6 us against 51.7 with 111 pairs, 88 against 107 with 666); on MobileNetV2's smaller activations a few hundred
     // units of one or two 4096-key batches each leave most CUs with one workgroup, the unit's own latency is the launch's
     // duration, and 512 threads halve it: 25.9 -> 17.7 us at 0.5 M elements, 42.1 -> 27.4 at 7.2 M with 666 pairs
-    // (profiles/r06_moments_nt_ab.txt).  FP8Q_MSE_MOM_NT = 256 / 512 overrides.
+    // (profiles/r06_moments_nt_ab.txt).  Third session, after the branch-free bisection: the same rule holds -- with 111 pairs 256
+    // threads win from 4.8 M keys (10.7 us against 14.1), with 666 pairs 512 threads up to 12.8 M (33.2 against 37.5; 19.3 M: 51.7
+    // against 47.8) -- the second threshold moved from 12 M to 16 M elements.  FP8Q_MSE_MOM_NT = 256 / 512 overrides.
     static const int mom_env = env_int("FP8Q_MSE_MOM_NT", 0, 0, 512);
-    const int mom_nt = mom_env >= 256 ? (mom_env >= 512 ? 512 : 256) : (n <= (n_pairs > 256 ? (12ll << 20) : (3ll << 20)) ? 512 : 256);
+    const int mom_nt = mom_env >= 256 ? (mom_env >= 512 ? 512 : 256) : (n <= (n_pairs > 256 ? (16ll << 20) : (3ll << 20)) ? 512 : 256);
     if (shmem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(mom_nt == 512 ? (const void *)k_moments<512> : (const void *)k_moments<256>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
