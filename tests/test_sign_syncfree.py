@@ -1,7 +1,6 @@
 """allow_unsigned without a host round trip: FPQuantizer.set_quant_range decides sign_bits on the device (fp8q_sign_fold_u8
 for the reference's `if allow_unsigned and torch.all(x_min >= 0)`, fp8_quantizer.py:216-225), K1 reads the flag
 (fp8q_quantize_ds_f32) until the host asks for the attribute."""
-import numpy as np
 import pytest
 import torch
 
