@@ -1633,7 +1633,7 @@ int fp8q_mse_hist_launch(const float *x, int64_t n, const float *grid, int64_t n
         if (int rc = launch_rc()) return rc;
     }
     const size_t shmem = (size_t)kMomTabWords * 4 + (size_t)((bcap + 3) & ~3) * 4 + (size_t)(bcap + 1) * 16;
-    // threads per k_moments workgroup.  At 25.7 M keys the kernel is bound by the LDS atomics' throughput and 256 threads are
+    // threads per k_moments workgroup.  At 25.7 M keys the kernel is bound by VALU issue (~44 instructions per key) and 256 threads are
     // best (48.6 us against 51.7 with 111 pairs, 88 against 107 with 666); on MobileNetV2's smaller activations a few hundred
     // units of one or two 4096-key batches each leave most CUs with one workgroup, the unit's own latency is the launch's
     // duration, and 512 threads halve it: 25.9 -> 17.7 us at 0.5 M elements, 42.1 -> 27.4 at 7.2 M with 666 pairs
