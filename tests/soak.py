@@ -96,6 +96,17 @@ def case_k1(rng):
     md = torch.tensor([M], dtype=torch.float32, device="cuda")
     y2 = ops.quantize(xd, mvd, md, nb, sb).cpu().numpy()
     assert np.array_equal(bits(y2), bits(ref)), ("quantize, device mbits", C, inner, M, nb, sb, pc)
+    # sign_bits as the device flag of allow_unsigned (fp8q_sign_fold_u8 / fp8q_quantize_ds_f32 / _dms_f32)
+    flag = torch.tensor([sb], dtype=torch.uint8, device="cuda")
+    y3 = ops.quantize(xd, mvd, M, nb, flag).cpu().numpy()
+    assert np.array_equal(bits(y3), bits(ref)), ("quantize, device sign", C, inner, M, nb, sb, pc)
+    y4 = ops.quantize(xd, mvd, md, nb, flag).cpu().numpy()
+    assert np.array_equal(bits(y4), bits(ref)), ("quantize, device mbits + sign", C, inner, M, nb, sb, pc)
+    xm = x.reshape(C, -1).min(1) if x.size else np.zeros(0, np.float32)
+    with np.errstate(invalid="ignore"):
+        want = 0 if bool(np.all(xm >= 0)) else 1                       # fp8_quantizer.py:216-225 (NaN: not >= 0)
+    got = int(ops.sign_fold(torch.from_numpy(np.ascontiguousarray(xm, np.float32)).cuda()).item())
+    assert got == want, ("sign_fold", C, inner, got, want)
     return x.size
 
 
@@ -435,7 +446,7 @@ def case_one_call(rng):
     return n_el * 111 * len(widths)
 
 
-FAMILIES = [("one-call MSE calibration step", case_one_call, 3), ("K1 fp32 (+ device mantissa width)", case_k1, 6), ("fused min/max + quantize", case_fused, 4),
+FAMILIES = [("one-call MSE calibration step", case_one_call, 3), ("K1 fp32 (+ device mantissa width / sign)", case_k1, 6), ("fused min/max + quantize", case_fused, 4),
             ("storage codes", case_codes, 3), ("epilogue (bn / folded / prepared / min-max)", case_epilogue, 4),
             ("multi-tensor K1", case_multi, 1), ("K1 fp64", case_f64, 3), ("K4 interval histogram vs row kernel vs oracle", case_sorted, 1), ("ranges: min/max, folds, packed record", case_ranges, 4),
             ("K4 per-channel / short rows", case_mse_small, 3), ("search grid + selection", case_select, 2),
